@@ -1,0 +1,380 @@
+// fxg_device.h -- device-side building blocks of the gfx950 FASTQ engine (wave64, LDS, HBM streaming).
+//
+// Nothing here is GEMM shaped: every kernel is a byte scan / gather bounded by HBM bandwidth, except
+// the adapter aligner which is a per-thread fp32 dynamic program bounded by VALU issue.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fxg.h"
+
+typedef unsigned int       u32;
+typedef unsigned long long u64;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// pure per-thread helpers are __host__ __device__ so that tests/emu can run them on the CPU
+#define FXG_HD __host__ __device__ __forceinline__
+
+#define FXG_BLOCK 256           // threads per workgroup = 4 wave64
+#define FXG_WAVES (FXG_BLOCK / 64)
+#define FXG_MAX_TILE 256        // reads per tile (one thread decides one read)
+
+// ------------------------------------------------------------------------------------------------
+// launch arguments (passed by value; adapter bytes therefore live in the kernarg segment / SGPRs)
+// ------------------------------------------------------------------------------------------------
+struct FxgKArgs {
+    const uint8_t  *bases;
+    const uint8_t  *qual;
+    const uint16_t *len;
+    u64  n;
+    u64  total_bytes;       // n * stride
+    u32  fixed_len;
+    u32  stride;
+    u32  tile_reads;        // power of two, <= FXG_MAX_TILE
+    u32  ntiles;
+    // outputs
+    u32      *res;
+    uint8_t  *out_bases;
+    uint8_t  *out_qual;
+    uint16_t *out_len;
+    u32      *kept_index;
+    u64      *out_off;
+    // engine state
+    u64 *status_cnt;        // [ntiles] decoupled look-back granules (kept reads)
+    u64 *status_bytes;      // [ntiles] decoupled look-back granules (kept bytes)
+    u64 *partial;           // [grid][FXG_NCOUNTERS]
+    u32 *errflag;
+    u32  compact;           // 1 = stream-compact kept reads into out_bases/out_qual
+    // folded tool parameters
+    u32  stages;
+    u32  tq;                // quality trimmer: byte >= tq  <=>  q >= -t      (0..128)
+    u32  fq;                // quality filter : byte <  fq  <=>  q <  -q      (0..128)
+    int  qt_min_len;
+    int  qf_keep_pct;       // 100 - p
+    u32  qf_drop_all;       // quirk F2: -p omitted and -q > 93
+    int  alen;
+    u32  clip_min_len;
+    int  clip_keep_delta;
+    int  clip_min_adapter_len;
+    u32  clip_flags;
+    int  ft_first, ft_last;
+    u32  ft_trim_end, ft_min_len;
+    char adapter[100];
+};
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 fxg_lane() { return threadIdx.x & 63u; }
+
+// byte >= thr for every byte of w (bytes assumed < 128, thr in 0..128): bit 7 of each byte.
+// K = (128 - thr) * 0x01010101
+FXG_HD u32 fxg_ge_flags(u32 w, u32 K) { return (((w & 0x7f7f7f7fu) + K) | w) & 0x80808080u; }
+
+// gather the four bit-7 flags of a dword into bits 0..3
+FXG_HD u32 fxg_pack4(u32 f)
+{
+    u32 t = f >> 7;          // bits 0, 8, 16, 24
+    t |= t >> 7;             // bit 1 <- 8, bit 17 <- 24
+    t |= t >> 14;            // bit 2 <- 16, bit 3 <- 17
+    return t & 0xFu;
+}
+
+FXG_HD u32 fxg_mask16(u32x4 v, u32 K)
+{
+    return fxg_pack4(fxg_ge_flags(v.x, K)) | (fxg_pack4(fxg_ge_flags(v.y, K)) << 4) |
+           (fxg_pack4(fxg_ge_flags(v.z, K)) << 8) | (fxg_pack4(fxg_ge_flags(v.w, K)) << 12);
+}
+
+// 16-byte load from an arbitrarily aligned address (one global_load_dwordx4 on gfx950)
+FXG_HD u32x4 fxg_ld16(const uint8_t *p)
+{
+    u32x4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+
+// bytes [vlo, vhi) of a 16-byte window starting at absolute offset off; the rest is zero.
+// The fast path needs the whole window inside [0, total); the slow path touches only needed bytes.
+FXG_HD u32x4 fxg_window(const uint8_t *arr, long long off, u64 total, int vlo, int vhi)
+{
+    if (off >= 0 && (u64)off + 16 <= total) return fxg_ld16(arr + off);
+    u64 lo = 0, hi = 0;
+    for (int i = vlo; i < vhi; ++i) {
+        const u64 b = arr[off + i];
+        if (i < 8) lo |= b << (8 * i); else hi |= b << (8 * (i - 8));
+    }
+    u32x4 v = {(u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32)};
+    return v;
+}
+
+FXG_HD u64 fxg_lowbytes64(int x)   // x in [0, 8]: low x bytes set
+{
+    return x >= 8 ? ~0ull : ((1ull << (8 * x)) - 1ull);
+}
+
+// keep bytes [lo, hi) of v (0 <= lo <= hi <= 16)
+FXG_HD u32x4 fxg_keep_bytes(u32x4 v, int lo, int hi)
+{
+    const int lo0 = lo < 8 ? lo : 8, hi0 = hi < 8 ? hi : 8;
+    const int lo1 = lo > 8 ? lo - 8 : 0, hi1 = hi > 8 ? hi - 8 : 0;
+    const u64 m0 = fxg_lowbytes64(hi0) & ~fxg_lowbytes64(lo0);
+    const u64 m1 = fxg_lowbytes64(hi1) & ~fxg_lowbytes64(lo1);
+    v.x &= (u32)m0; v.y &= (u32)(m0 >> 32); v.z &= (u32)m1; v.w &= (u32)(m1 >> 32);
+    return v;
+}
+
+FXG_HD u32x4 fxg_reverse16(u32x4 v)
+{
+    u32x4 r = {__builtin_bswap32(v.w), __builtin_bswap32(v.z), __builtin_bswap32(v.y), __builtin_bswap32(v.x)};
+    return r;
+}
+
+// A<->T, C<->G, N->N (case preserved) on four packed ASCII bases:  A^T = 0x15, C^G = 0x04.
+//   bit1 clear          -> A/T
+//   bit1 set, bit3 clear -> C/G
+FXG_HD u32 fxg_complement4(u32 w)
+{
+    const u32 b1 = (w >> 1) & 0x01010101u;
+    const u32 at = b1 ^ 0x01010101u;
+    const u32 cg = b1 & ~(w >> 3) & 0x01010101u;
+    return w ^ (at * 0x15u) ^ (cg << 2);
+}
+
+// nonzero if any byte of w selected by m (0x00/0xFF per byte) is not one of ACGTN/acgtn
+FXG_HD u32 fxg_invalid_bases4(u32 w, u32 m)
+{
+    const u32 x = (w & 0xDFDFDFDFu) ^ 0x40404040u;         // A=01 C=03 G=07 N=0E T=14
+    const u32 LUT = (1u << 0x01) | (1u << 0x03) | (1u << 0x07) | (1u << 0x0E) | (1u << 0x14);
+    const u32 nb = (~(LUT >> (x & 31u)) & m) | (~(LUT >> ((x >> 8) & 31u)) & (m >> 8)) |
+                   (~(LUT >> ((x >> 16) & 31u)) & (m >> 16)) | (~(LUT >> ((x >> 24) & 31u)) & (m >> 24));
+    return (x & 0xE0E0E0E0u & m) | (nb & 1u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bit-range queries on an LDS bitmap (bit i = byte i of the tile)
+// ------------------------------------------------------------------------------------------------
+// 1 + index (relative to s0) of the highest set bit in [s0, s0+n), 0 if none
+FXG_HD u32 fxg_bits_last(const u32 *bm, u32 s0, u32 n)
+{
+    if (n == 0) return 0;
+    const u32 e1 = s0 + n - 1;
+    int w = (int)(e1 >> 5);
+    const int w0 = (int)(s0 >> 5);
+    u32 x = bm[w] & (0xFFFFFFFFu >> (31u - (e1 & 31u)));
+    for (;;) {
+        if (w == w0) x &= 0xFFFFFFFFu << (s0 & 31u);
+        if (x) return ((u32)w << 5) + 32u - (u32)__builtin_clz(x) - s0;
+        if (w == w0) return 0;
+        --w;
+        x = bm[w];
+    }
+}
+
+// number of set bits in [s0, s0+n)
+FXG_HD u32 fxg_bits_count(const u32 *bm, u32 s0, u32 n)
+{
+    if (n == 0) return 0;
+    const u32 e1 = s0 + n - 1;
+    const u32 w0 = s0 >> 5, w1 = e1 >> 5;
+    u32 c = 0;
+    for (u32 w = w0; w <= w1; ++w) {
+        u32 x = bm[w];
+        if (w == w0) x &= 0xFFFFFFFFu << (s0 & 31u);
+        if (w == w1) x &= 0xFFFFFFFFu >> (31u - (e1 & 31u));
+        c += (u32)__builtin_popcount(x);
+    }
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// inter-workgroup granules (decoupled look-back).  One naturally aligned u64 = {status:2, value:62},
+// written by ONE relaxed agent-scope store (sc1) and polled with relaxed agent-scope loads: the data
+// is its own flag, so no fence is needed and nothing depends on workgroup placement.
+// ------------------------------------------------------------------------------------------------
+#define FXG_ST_INVALID 0ull
+#define FXG_ST_AGG     1ull
+#define FXG_ST_PREFIX  2ull
+#define FXG_ST_VALUE(x) ((x) & 0x3FFFFFFFFFFFFFFFull)
+
+__device__ __forceinline__ void fxg_granule_store(u64 *g, u64 status, u64 value)
+{
+    __hip_atomic_store(g, (status << 62) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 fxg_granule_load(u64 *g)
+{
+    return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// sum over the 32 lanes of each half-wave, result in every lane of that half
+__device__ __forceinline__ u64 fxg_half_sum(u64 v)
+{
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) {
+        u32 lo = __shfl_xor((u32)v, d, 64), hi = __shfl_xor((u32)(v >> 32), d, 64);
+        v += ((u64)hi << 32) | lo;
+    }
+    return v;
+}
+
+// Executed by wave 0 only.  Lanes 0..31 resolve the kept-read prefix, lanes 32..63 the kept-byte
+// prefix, both walking back over predecessor tiles 32 at a time.  Returns the exclusive prefix of this
+// tile in (*base_cnt, *base_bytes) for every lane.
+__device__ __forceinline__ void fxg_lookback(const FxgKArgs &a, u32 tile, u64 agg_cnt, u64 agg_bytes,
+                                             u64 *base_cnt, u64 *base_bytes)
+{
+    const u32 lane = fxg_lane();
+    const u32 half = lane >> 5, hl = lane & 31u;
+    u64 *st = half ? a.status_bytes : a.status_cnt;
+    const u64 agg = half ? agg_bytes : agg_cnt;
+    u64 running = 0;
+    if (tile != 0) {
+        if (hl == 0) fxg_granule_store(st + tile, FXG_ST_AGG, agg);
+        long long pos = (long long)tile - 1 - (long long)hl;
+        bool done = false;
+        const u64 t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+        u32 spins = 0;
+        for (;;) {
+            u64 v = (FXG_ST_PREFIX << 62);                  // virtual tile -1: prefix 0
+            if (!done && pos >= 0) v = fxg_granule_load(st + pos);
+            const u32 s = (u32)(v >> 62);
+            const u64 b_inv = __ballot(s == FXG_ST_INVALID);
+            const u64 b_pfx = __ballot(s == FXG_ST_PREFIX);
+            const u32 inv = (u32)(b_inv >> (32 * half)), pfx = (u32)(b_pfx >> (32 * half));
+            const u32 fp = pfx ? (u32)__builtin_ctz(pfx) : 32u;          // nearest predecessor with a full prefix
+            const u32 need = (fp >= 31u) ? 0xFFFFFFFFu : ((2u << fp) - 1u);
+            const bool ready = !done && ((inv & need) == 0u);
+            // every lane takes part in the shuffles; only ready halves consume the sum
+            const u64 contrib = (ready && hl <= fp) ? FXG_ST_VALUE(v) : 0ull;
+            const u64 sum = fxg_half_sum(contrib);
+            if (ready) {
+                running += sum;
+                if (fp < 32u) done = true; else pos -= 32;
+            }
+            if (__ballot(!done) == 0ull) break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 255u) == 0u) {   // never hang the GPU: 2 s without progress, or another workgroup already gave up
+                const bool late = __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull;
+                const u32 flagged = __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & FXG_DEV_ERR_SCAN_TIMEOUT;
+                if (late || flagged) {
+                    if (lane == 0) atomicOr(a.errflag, FXG_DEV_ERR_SCAN_TIMEOUT);
+                    break;
+                }
+            }
+        }
+    }
+    if (hl == 0) fxg_granule_store(st + tile, FXG_ST_PREFIX, running + agg);
+    *base_cnt = ((u64)__shfl((u32)(running >> 32), 0, 64) << 32) | __shfl((u32)running, 0, 64);
+    *base_bytes = ((u64)__shfl((u32)(running >> 32), 32, 64) << 32) | __shfl((u32)running, 32, 64);
+}
+
+// ------------------------------------------------------------------------------------------------
+// workgroup exclusive scan of (keep, out_len) over FXG_BLOCK threads.  scratch: u32[2*FXG_WAVES + 2]
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fxg_block_scan2(u32 c, u32 b, u32 *scratch, u32 *ex_c, u32 *ex_b, u32 *tot_c, u32 *tot_b)
+{
+    const u32 lane = fxg_lane(), wave = threadIdx.x >> 6;
+    u32 ic = c, ib = b;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 tc = __shfl_up(ic, d, 64), tb = __shfl_up(ib, d, 64);
+        if ((int)lane >= d) { ic += tc; ib += tb; }
+    }
+    if (lane == 63) { scratch[wave] = ic; scratch[FXG_WAVES + wave] = ib; }
+    __syncthreads();
+    u32 oc = 0, ob = 0, sc = 0, sb = 0;
+#pragma unroll
+    for (int w = 0; w < FXG_WAVES; ++w) {
+        const u32 wc = scratch[w], wb = scratch[FXG_WAVES + w];
+        if (w < (int)wave) { oc += wc; ob += wb; }
+        sc += wc; sb += wb;
+    }
+    *ex_c = oc + ic - c; *ex_b = ob + ib - b; *tot_c = sc; *tot_b = sb;
+}
+
+// ------------------------------------------------------------------------------------------------
+// order-preserving gather of one tile's kept reads into the packed output.
+//   v_off[0..nreads] : exclusive prefix of kept lengths inside the tile (LDS)
+//   v_src[r]         : tile-relative source byte of output byte 0 of read r (LDS)
+//   REV              : output byte k comes from source byte v_src[r] - k, complemented (bases)
+// Work item = one 16-byte aligned chunk of the GLOBAL output; consecutive lanes write consecutive
+// chunks (1 KiB per wave store).  A chunk that straddles reads is assembled from one window per read.
+// ------------------------------------------------------------------------------------------------
+template <bool REV>
+FXG_HD u32 fxg_tile_gather(const FxgKArgs &a, const u32 *v_off, const u32 *v_src, u32 nreads,
+                           u64 tile_in_base, u64 B, u32 S, u32 tid, u32 nthreads)
+{
+    if (S == 0) return 0u;
+    const bool has_q = a.qual != nullptr && a.out_qual != nullptr;
+    const u64 c_first = B >> 4, c_last = (B + S - 1) >> 4;
+    u32 bad = 0;
+    for (u64 c = c_first + tid; c <= c_last; c += nthreads) {
+        const long long cs = (long long)(c << 4) - (long long)B;   // tile-relative output offset of chunk byte 0
+        const int lo_c = cs < 0 ? (int)(-cs) : 0;
+        const long long rem = (long long)S - cs;
+        const int hi_c = rem >= 16 ? 16 : (int)rem;
+        u32 o = (u32)(cs + lo_c);
+        const u32 o_end = (u32)(cs + hi_c);
+        // largest r with v_off[r] <= o   (v_off[0] = 0 <= o < S = v_off[nreads])
+        u32 lo = 0, hi = nreads;
+        while (hi - lo > 1) {
+            const u32 mid = (lo + hi) >> 1;
+            if (v_off[mid] <= o) lo = mid; else hi = mid;
+        }
+        u32 r = lo;
+        u32x4 accb = {0u, 0u, 0u, 0u}, accq = {0u, 0u, 0u, 0u};
+        while (o < o_end) {
+            const u32 e = v_off[r + 1];
+            if (e > o) {
+                const u32 seg_end = e < o_end ? e : o_end;
+                const int blo = (int)((long long)o - cs), bhi = (int)((long long)seg_end - cs);
+                const u32 j0 = o - v_off[r];
+                long long src;
+                int vlo, vhi;
+                if (REV) { src = (long long)v_src[r] - (long long)j0 + blo - 15; vlo = 16 - bhi; vhi = 16 - blo; }
+                else     { src = (long long)v_src[r] + (long long)j0 - blo;      vlo = blo;      vhi = bhi; }
+                const long long abs_off = (long long)tile_in_base + src;
+                u32x4 wb = fxg_window(a.bases, abs_off, a.total_bytes, vlo, vhi);
+                if (REV) {
+                    wb = fxg_reverse16(wb);
+                    const u32x4 m = fxg_keep_bytes((u32x4){~0u, ~0u, ~0u, ~0u}, blo, bhi);
+                    bad |= fxg_invalid_bases4(wb.x, m.x) | fxg_invalid_bases4(wb.y, m.y) |
+                           fxg_invalid_bases4(wb.z, m.z) | fxg_invalid_bases4(wb.w, m.w);
+                    wb.x = fxg_complement4(wb.x); wb.y = fxg_complement4(wb.y);
+                    wb.z = fxg_complement4(wb.z); wb.w = fxg_complement4(wb.w);
+                }
+                wb = fxg_keep_bytes(wb, blo, bhi);
+                accb |= wb;
+                if (has_q) {
+                    u32x4 wq = fxg_window(a.qual, abs_off, a.total_bytes, vlo, vhi);
+                    if (REV) wq = fxg_reverse16(wq);
+                    accq |= fxg_keep_bytes(wq, blo, bhi);
+                }
+                o = seg_end;
+            }
+            ++r;
+        }
+        if (lo_c == 0 && hi_c == 16) {
+            *reinterpret_cast<u32x4 *>(a.out_bases + (c << 4)) = accb;
+            if (has_q) *reinterpret_cast<u32x4 *>(a.out_qual + (c << 4)) = accq;
+        } else {   // first / last chunk of the tile: the neighbouring tile owns the other bytes
+            const u64 b0 = ((u64)accb.y << 32) | accb.x, b1 = ((u64)accb.w << 32) | accb.z;
+            const u64 q0 = ((u64)accq.y << 32) | accq.x, q1 = ((u64)accq.w << 32) | accq.z;
+            for (int i = lo_c; i < hi_c; ++i) {
+                const int sh = 8 * (i & 7);
+                a.out_bases[(c << 4) + i] = (uint8_t)((i < 8 ? b0 : b1) >> sh);
+                if (has_q) a.out_qual[(c << 4) + i] = (uint8_t)((i < 8 ? q0 : q1) >> sh);
+            }
+        }
+    }
+    return bad;   // nonzero: a byte outside ACGTN/acgtn reached the complement (REV only)
+}
+
+// persistent-grid tile order: workgroup b runs on XCD b % 8 (observed, speed only); give each XCD a
+// contiguous run of tiles inside every sweep so neighbouring tiles (which share an output cache line
+// and hand prefixes to each other) stay on one L2.
+__device__ __forceinline__ u32 fxg_first_tile()
+{
+    const u32 g = gridDim.x, b = blockIdx.x;
+    return (g % 8u == 0u) ? (b % 8u) * (g / 8u) + b / 8u : b;
+}

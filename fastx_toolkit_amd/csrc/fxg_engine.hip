@@ -1,0 +1,343 @@
+// fxg_engine.hip -- host side of the C-ABI declared in include/fxg.h (gfx950 only).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "fxg_plan.h"
+
+struct fxg_ctx {
+    int device;
+    int cus;
+    hipStream_t own_stream;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    hipEvent_t kev0, kev1;  // around the dominant kernel when profiling
+    int profiling, kev_valid;
+    u64 *status;            // 2 * status_cap granules
+    size_t status_cap;      // in tiles
+    u64 *partial;           // partial_cap rows of FXG_NCOUNTERS
+    size_t partial_cap;
+    u32 *errflag;
+    u64 *counters_scratch;  // used when the caller passes no counter block
+    char err[512];
+    char last_kernel[96];
+    u32 last_grid, last_block, last_lds, last_tile;
+};
+
+static int fxg_fail(fxg_ctx *ctx, int code, const char *fmt, ...)
+{
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define FXG_HIP(ctx, call)                                                                              \
+    do {                                                                                                \
+        hipError_t e__ = (call);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return fxg_fail(ctx, FXG_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" int fxg_abi_version(void) { return FXG_ABI_VERSION; }
+
+extern "C" int fxg_ctx_create(int device_id, fxg_ctx **out)
+{
+    if (!out) return FXG_E_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return FXG_E_HIP;
+    fxg_ctx *c = (fxg_ctx *)calloc(1, sizeof(fxg_ctx));
+    if (!c) return FXG_E_NOMEM;
+    c->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&prop, device_id) != hipSuccess) { free(c); return FXG_E_HIP; }
+    c->cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { free(c); return FXG_E_HIP; }
+    c->stream = c->own_stream;
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreate(&c->kev0) != hipSuccess || hipEventCreate(&c->kev1) != hipSuccess ||
+        hipMalloc((void **)&c->errflag, sizeof(u32)) != hipSuccess ||
+        hipMalloc((void **)&c->counters_scratch, FXG_NCOUNTERS * sizeof(u64)) != hipSuccess) {
+        free(c);
+        return FXG_E_HIP;
+    }
+    *out = c;
+    return FXG_OK;
+}
+
+extern "C" void fxg_ctx_destroy(fxg_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->status); (void)hipFree(c->partial); (void)hipFree(c->errflag); (void)hipFree(c->counters_scratch);
+    (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
+    (void)hipEventDestroy(c->kev0); (void)hipEventDestroy(c->kev1);
+    (void)hipStreamDestroy(c->own_stream);
+    free(c);
+}
+
+extern "C" const char *fxg_last_error(const fxg_ctx *c) { return c ? c->err : "null context"; }
+
+extern "C" int fxg_set_stream(fxg_ctx *c, void *s)
+{
+    if (!c) return FXG_E_INVALID;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return FXG_OK;
+}
+
+extern "C" int fxg_sync(fxg_ctx *c)
+{
+    if (!c) return FXG_E_INVALID;
+    FXG_HIP(c, hipStreamSynchronize(c->stream));
+    return FXG_OK;
+}
+
+extern "C" int fxg_device_info(fxg_ctx *c, int *cus, size_t *total_mem, char *name, size_t cap)
+{
+    if (!c) return FXG_E_INVALID;
+    hipDeviceProp_t prop;
+    FXG_HIP(c, hipGetDeviceProperties(&prop, c->device));
+    if (cus) *cus = prop.multiProcessorCount;
+    if (total_mem) *total_mem = prop.totalGlobalMem;
+    if (name && cap) snprintf(name, cap, "%s (%s)", prop.name, prop.gcnArchName);
+    return FXG_OK;
+}
+
+extern "C" int fxg_malloc_device(fxg_ctx *c, size_t bytes, void **p)
+{
+    if (!c || !p) return FXG_E_INVALID;
+    FXG_HIP(c, hipSetDevice(c->device));
+    FXG_HIP(c, hipMalloc(p, bytes ? bytes : 16));
+    return FXG_OK;
+}
+extern "C" int fxg_free_device(fxg_ctx *c, void *p) { if (!c) return FXG_E_INVALID; FXG_HIP(c, hipFree(p)); return FXG_OK; }
+extern "C" int fxg_malloc_host(fxg_ctx *c, size_t bytes, void **p)
+{
+    if (!c || !p) return FXG_E_INVALID;
+    FXG_HIP(c, hipHostMalloc(p, bytes ? bytes : 16, hipHostMallocDefault));
+    return FXG_OK;
+}
+extern "C" int fxg_free_host(fxg_ctx *c, void *p) { if (!c) return FXG_E_INVALID; FXG_HIP(c, hipHostFree(p)); return FXG_OK; }
+extern "C" int fxg_memcpy_h2d(fxg_ctx *c, void *d, const void *s, size_t n)
+{
+    if (!c) return FXG_E_INVALID;
+    FXG_HIP(c, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, c->stream));
+    return FXG_OK;
+}
+extern "C" int fxg_memcpy_d2h(fxg_ctx *c, void *d, const void *s, size_t n)
+{
+    if (!c) return FXG_E_INVALID;
+    FXG_HIP(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, c->stream));
+    return FXG_OK;
+}
+extern "C" int fxg_memset_device(fxg_ctx *c, void *d, int v, size_t n)
+{
+    if (!c) return FXG_E_INVALID;
+    FXG_HIP(c, hipMemsetAsync(d, v, n, c->stream));
+    return FXG_OK;
+}
+
+extern "C" int fxg_timer_start(fxg_ctx *c)
+{
+    if (!c) return FXG_E_INVALID;
+    FXG_HIP(c, hipEventRecord(c->ev0, c->stream));
+    return FXG_OK;
+}
+extern "C" int fxg_timer_stop(fxg_ctx *c, float *ms)
+{
+    if (!c || !ms) return FXG_E_INVALID;
+    FXG_HIP(c, hipEventRecord(c->ev1, c->stream));
+    FXG_HIP(c, hipEventSynchronize(c->ev1));
+    FXG_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return FXG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename K>
+static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &ka, u32 lds, u64 *counters)
+{
+    FXG_HIP(c, hipSetDevice(c->device));
+    FXG_HIP(c, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    FXG_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, FXG_BLOCK, lds));
+    if (per_cu < 1) return fxg_fail(c, FXG_E_INVALID, "%s does not fit on a CU (lds=%u)", kname, lds);
+    // every workgroup must be resident (look-back waits on predecessors): stay one below the API's
+    // answer, which can over-report by one for SGPR-heavy 256-thread kernels, and never above 8.
+    int use = per_cu > 1 ? per_cu - 1 : 1;
+    if (use > 8) use = 8;
+    const char *env = getenv("FXG_BLOCKS_PER_CU");
+    if (env && atoi(env) > 0 && atoi(env) <= per_cu) use = atoi(env);
+    u64 grid = (u64)c->cus * (u64)use;
+    if (grid > ka.ntiles) grid = ka.ntiles;
+    if (grid >= 8) grid &= ~7ull;
+    if (grid < 1) grid = 1;
+
+    if (ka.compact) {
+        if (c->status_cap < ka.ntiles) {
+            (void)hipFree(c->status);
+            c->status = nullptr; c->status_cap = 0;
+            size_t cap = (size_t)ka.ntiles + (size_t)ka.ntiles / 4 + 1024;
+            FXG_HIP(c, hipMalloc((void **)&c->status, 2 * cap * sizeof(u64)));
+            c->status_cap = cap;
+        }
+        ka.status_cnt = c->status;
+        ka.status_bytes = c->status + c->status_cap;
+        FXG_HIP(c, hipMemsetAsync(ka.status_cnt, 0, (size_t)ka.ntiles * sizeof(u64), c->stream));
+        FXG_HIP(c, hipMemsetAsync(ka.status_bytes, 0, (size_t)ka.ntiles * sizeof(u64), c->stream));
+    }
+    if (c->partial_cap < grid) {
+        (void)hipFree(c->partial);
+        c->partial = nullptr; c->partial_cap = 0;
+        FXG_HIP(c, hipMalloc((void **)&c->partial, (size_t)grid * FXG_NCOUNTERS * sizeof(u64)));
+        c->partial_cap = grid;
+    }
+    ka.partial = c->partial;
+    ka.errflag = c->errflag;
+    FXG_HIP(c, hipMemsetAsync(c->errflag, 0, sizeof(u32), c->stream));
+
+    if (c->profiling) FXG_HIP(c, hipEventRecord(c->kev0, c->stream));
+    hipLaunchKernelGGL(kernel, dim3((u32)grid), dim3(FXG_BLOCK), lds, c->stream, ka);
+    FXG_HIP(c, hipGetLastError());
+    if (c->profiling) { FXG_HIP(c, hipEventRecord(c->kev1, c->stream)); c->kev_valid = 1; }
+    hipLaunchKernelGGL(fxg_kernel_reduce_counters, dim3(1), dim3(256), 0, c->stream, (const u64 *)c->partial, (u32)grid,
+                       (const u32 *)c->errflag, counters ? counters : c->counters_scratch);
+    FXG_HIP(c, hipGetLastError());
+    snprintf(c->last_kernel, sizeof c->last_kernel, "%s", kname);
+    c->last_grid = (u32)grid; c->last_block = FXG_BLOCK; c->last_lds = lds; c->last_tile = ka.tile_reads;
+    return FXG_OK;
+}
+
+extern "C" int fxg_run_pipeline(fxg_ctx *c, const fxg_batch *in, const fxg_params *p, const fxg_out *out)
+{
+    if (!c || !in || !p || !out) return FXG_E_INVALID;
+    FxgPlan pl;
+    const int rc = fxg_make_plan(in, p, out, &pl, c->err, sizeof c->err);
+    if (rc != FXG_OK) return rc;
+    if (in->n == 0) {
+        if (out->counters) FXG_HIP(c, hipMemsetAsync(out->counters, 0, FXG_NCOUNTERS * sizeof(u64), c->stream));
+        return FXG_OK;
+    }
+    u64 *ctr = (u64 *)out->counters;
+#define FXG_GO(K) return fxg_launch_tiles(c, K, #K, pl.ka, pl.lds, ctr)
+    if (pl.group_a) {
+        switch (pl.amax) {
+        case 0: FXG_GO(fxg_kernel_clip_qtrim_qfilter<0>);
+        case 16: FXG_GO(fxg_kernel_clip_qtrim_qfilter<16>);
+        case 32: FXG_GO(fxg_kernel_clip_qtrim_qfilter<32>);
+        case 64: FXG_GO(fxg_kernel_clip_qtrim_qfilter<64>);
+        default: FXG_GO(fxg_kernel_clip_qtrim_qfilter<100>);
+        }
+    }
+    if (pl.rev) FXG_GO(fxg_kernel_revcomp_ftrim<true>);
+    FXG_GO(fxg_kernel_revcomp_ftrim<false>);
+#undef FXG_GO
+}
+
+static void fxg_params_default(fxg_params *p)
+{
+    memset(p, 0, sizeof *p);
+    p->qoffset = 33;
+    strcpy(p->adapter, "CCTTAAGG");   // fastx_clipper.cpp:68
+    p->clip_min_len = 5;              // :69
+    p->ft_first = 1;
+}
+
+extern "C" int fxg_run_qtrim_qfilter(fxg_ctx *c, const fxg_batch *in, int qoffset, int use_trim, int trim_threshold,
+                                     int trim_min_len, int use_filter, int filter_min_quality, int filter_min_percent,
+                                     const fxg_out *out)
+{
+    fxg_params p;
+    fxg_params_default(&p);
+    p.qoffset = qoffset;
+    if (use_trim) { p.stages |= FXG_STAGE_QTRIM; p.qt_threshold = trim_threshold; p.qt_min_len = trim_min_len; }
+    if (use_filter) { p.stages |= FXG_STAGE_QFILTER; p.qf_min_quality = filter_min_quality; p.qf_min_percent = filter_min_percent; }
+    return fxg_run_pipeline(c, in, &p, out);
+}
+
+extern "C" int fxg_run_clip(fxg_ctx *c, const fxg_batch *in, const char *adapter, uint32_t min_len, int keep_delta,
+                            int min_adapter_len, uint32_t clip_flags, const fxg_out *out)
+{
+    fxg_params p;
+    fxg_params_default(&p);
+    p.stages = FXG_STAGE_CLIP;
+    if (adapter) { strncpy(p.adapter, adapter, sizeof p.adapter - 1); p.adapter[sizeof p.adapter - 1] = 0; }
+    p.clip_min_len = min_len; p.clip_keep_delta = keep_delta; p.clip_min_adapter_len = min_adapter_len; p.clip_flags = clip_flags;
+    return fxg_run_pipeline(c, in, &p, out);
+}
+
+extern "C" int fxg_run_revcomp_trim(fxg_ctx *c, const fxg_batch *in, int reverse_complement, int first_base, int last_base,
+                                    const fxg_out *out)
+{
+    fxg_params p;
+    fxg_params_default(&p);
+    if (reverse_complement) p.stages |= FXG_STAGE_REVCOMP;
+    if (first_base != 1 || last_base != 0 || !reverse_complement) { p.stages |= FXG_STAGE_FTRIM; p.ft_first = first_base; p.ft_last = last_base; }
+    return fxg_run_pipeline(c, in, &p, out);
+}
+
+extern "C" int fxg_read_counters(fxg_ctx *c, const uint64_t *d_counters, uint64_t host[FXG_NCOUNTERS])
+{
+    if (!c || !host) return FXG_E_INVALID;
+    const u64 *src = d_counters ? (const u64 *)d_counters : c->counters_scratch;
+    FXG_HIP(c, hipMemcpyAsync(host, src, FXG_NCOUNTERS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    FXG_HIP(c, hipStreamSynchronize(c->stream));
+    if (host[FXG_C_ERRORS] & FXG_DEV_ERR_SCAN_TIMEOUT) return fxg_fail(c, FXG_E_DEVICE, "device: look-back scan timed out");
+    if (host[FXG_C_ERRORS] & FXG_DEV_ERR_BAD_BASE)
+        return fxg_fail(c, FXG_E_DEVICE, "Invalid nucleotide value in reverse_complement_base()");   // fastx_reverse_complement.c:67-68
+    return FXG_OK;
+}
+
+extern "C" int fxg_synth_generate(fxg_ctx *c, uint64_t seed, uint64_t first, uint64_t n, uint32_t L, int with_adapter,
+                                  uint8_t *bases, uint8_t *qual, uint32_t stride)
+{
+    if (!c || !bases || L == 0 || stride < L) return FXG_E_INVALID;
+    if ((((uintptr_t)bases | (uintptr_t)qual) & 15u) != 0) return fxg_fail(c, FXG_E_INVALID, "synth: buffers must be 16-byte aligned");
+    if (n == 0) return FXG_OK;
+    const u32 lds = 2 * fxg_r16(FXG_SYNTH_TILE * stride);
+    if (lds > 160 * 1024) return fxg_fail(c, FXG_E_INVALID, "synth: stride %u too large", stride);
+    FXG_HIP(c, hipSetDevice(c->device));
+    FXG_HIP(c, hipFuncSetAttribute((const void *)fxg_kernel_synth, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const u64 blocks = (n + FXG_SYNTH_TILE - 1) / FXG_SYNTH_TILE;
+    if (blocks > 0x7FFFFFFFull) return fxg_fail(c, FXG_E_INVALID, "synth: too many reads for one launch");
+    hipLaunchKernelGGL(fxg_kernel_synth, dim3((u32)blocks), dim3(FXG_BLOCK), lds, c->stream, (u64)seed, (u64)first, (u64)n, L,
+                       with_adapter, bases, qual, stride);
+    FXG_HIP(c, hipGetLastError());
+    return FXG_OK;
+}
+
+extern "C" int fxg_set_profiling(fxg_ctx *c, int enabled)
+{
+    if (!c) return FXG_E_INVALID;
+    c->profiling = enabled ? 1 : 0;
+    c->kev_valid = 0;
+    return FXG_OK;
+}
+
+extern "C" int fxg_last_kernel_ms(fxg_ctx *c, float *ms)
+{
+    if (!c || !ms) return FXG_E_INVALID;
+    if (!c->kev_valid) return fxg_fail(c, FXG_E_INVALID, "no profiled launch recorded");
+    FXG_HIP(c, hipEventSynchronize(c->kev1));
+    FXG_HIP(c, hipEventElapsedTime(ms, c->kev0, c->kev1));
+    return FXG_OK;
+}
+
+extern "C" int fxg_last_launch_info(const fxg_ctx *c, char *name, size_t cap, uint32_t *grid, uint32_t *block, uint32_t *lds,
+                                    uint32_t *tile)
+{
+    if (!c) return FXG_E_INVALID;
+    if (name && cap) snprintf(name, cap, "%s", c->last_kernel);
+    if (grid) *grid = c->last_grid;
+    if (block) *block = c->last_block;
+    if (lds) *lds = c->last_lds;
+    if (tile) *tile = c->last_tile;
+    return FXG_OK;
+}

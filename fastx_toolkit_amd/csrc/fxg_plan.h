@@ -1,0 +1,81 @@
+// fxg_plan.h -- host-side validation of a request and folding of the tool parameters into launch
+// arguments.  Shared by the engine (fxg_engine.hip) and by the CPU emulator used in tests/emu.
+#pragma once
+#include <cstdio>
+#include <cstring>
+
+#include "fxg_kernels.h"
+
+struct FxgPlan {
+    FxgKArgs ka;
+    bool group_a;   // [CLIP][QTRIM][QFILTER] chain (else [REVCOMP][FTRIM*])
+    bool clip, use_q, rev;
+    int  amax;      // adapter bucket of the clip kernel instance (0 = no clip)
+    u32  lds;       // dynamic LDS bytes per workgroup
+};
+
+static inline int fxg_clampi(long long v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : (int)v); }
+
+static inline u32 fxg_pick_tile(u32 stride, bool clip)
+{
+    // keep the LDS footprint around 64 KiB or less so that at least two workgroups share a CU
+    const u64 budget = clip ? 60ull * 1024 : 192ull * 1024;   // bytes of tile rows one workgroup may cover
+    u32 T = FXG_MAX_TILE;
+    while (T > 1 && (u64)T * stride > budget) T >>= 1;
+    return T;
+}
+
+#define FXG_PLAN_FAIL(...) do { snprintf(err, cap, __VA_ARGS__); return FXG_E_INVALID; } while (0)
+
+static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const fxg_out *out, FxgPlan *pl, char *err, size_t cap)
+{
+    const u32 st = p->stages;
+    const bool ga = (st & (FXG_STAGE_CLIP | FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0;
+    const bool gb = (st & (FXG_STAGE_REVCOMP | FXG_STAGE_FTRIM | FXG_STAGE_FTRIM_END)) != 0;
+    if (ga == gb) FXG_PLAN_FAIL("unsupported stage chain 0x%x: use [CLIP][QTRIM][QFILTER] or [REVCOMP][FTRIM|FTRIM_END]", st);
+    if ((st & FXG_STAGE_FTRIM) && (st & FXG_STAGE_FTRIM_END))
+        FXG_PLAN_FAIL("[-t], [-f] and [-l] options can not be used together");   // fastx_trimmer.c:112-113
+    if (!in->bases || !out->res) FXG_PLAN_FAIL("bases and res are mandatory");
+    if ((st & (FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) && !in->qual) FXG_PLAN_FAIL("quality stages need qual");
+    if (in->stride == 0 || in->stride > FXG_MAX_READ_LEN || (!in->len && (in->fixed_len == 0 || in->fixed_len > in->stride)))
+        FXG_PLAN_FAIL("bad stride/fixed_len (%u/%u)", in->stride, in->fixed_len);
+    if ((((uintptr_t)in->bases | (uintptr_t)in->qual | (uintptr_t)out->out_bases | (uintptr_t)out->out_qual) & 15u) != 0)
+        FXG_PLAN_FAIL("bases/qual/out_bases/out_qual must be 16-byte aligned");
+    if (out->out_bases && in->qual && !out->out_qual) FXG_PLAN_FAIL("out_qual missing");
+
+    FxgKArgs &ka = pl->ka;
+    memset(&ka, 0, sizeof ka);
+    ka.bases = in->bases; ka.qual = in->qual; ka.len = in->len;
+    ka.n = in->n; ka.total_bytes = in->n * (u64)in->stride;
+    ka.fixed_len = in->fixed_len; ka.stride = in->stride;
+    ka.res = out->res; ka.out_bases = out->out_bases; ka.out_qual = out->out_qual;
+    ka.out_len = out->out_len; ka.kept_index = out->kept_index; ka.out_off = (u64 *)out->out_off;
+    ka.compact = out->out_bases ? 1u : 0u;
+    ka.stages = st;
+    ka.tq = (u32)fxg_clampi((long long)p->qt_threshold + p->qoffset, 0, 128);
+    ka.fq = (u32)fxg_clampi((long long)p->qf_min_quality + p->qoffset, 0, 128);
+    ka.qt_min_len = p->qt_min_len;
+    ka.qf_keep_pct = 100 - p->qf_min_percent;
+    ka.qf_drop_all = (p->qf_min_percent == 0 && p->qf_min_quality > 93) ? 1u : 0u;   // quirk F2
+    ka.clip_min_len = p->clip_min_len; ka.clip_keep_delta = p->clip_keep_delta;
+    ka.clip_min_adapter_len = p->clip_min_adapter_len; ka.clip_flags = p->clip_flags;
+    ka.ft_first = p->ft_first; ka.ft_last = p->ft_last; ka.ft_trim_end = p->ft_trim_end; ka.ft_min_len = p->ft_min_len;
+    memcpy(ka.adapter, p->adapter, sizeof ka.adapter);
+    ka.adapter[sizeof ka.adapter - 1] = 0;
+    ka.alen = (int)strlen(ka.adapter);
+
+    pl->group_a = ga;
+    pl->clip = (st & FXG_STAGE_CLIP) != 0;
+    pl->use_q = (st & (FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0;
+    pl->rev = (st & FXG_STAGE_REVCOMP) != 0;
+    if (pl->clip && (ka.alen < 1 || ka.alen > FXG_MAX_ADAPTER)) FXG_PLAN_FAIL("adapter length %d out of range", ka.alen);
+    if (pl->clip && in->stride > 65000u) FXG_PLAN_FAIL("clip: reads longer than 65000 are not supported");
+    if ((st & FXG_STAGE_FTRIM) && p->ft_first < 1) FXG_PLAN_FAIL("-f must be >= 1");
+    pl->amax = !pl->clip ? 0 : ka.alen <= 16 ? 16 : ka.alen <= 32 ? 32 : ka.alen <= 64 ? 64 : 100;
+    const u32 T = fxg_pick_tile(in->stride, pl->clip);
+    const u64 ntiles = (in->n + T - 1) / T;
+    if (ntiles > 0x7FFFFFFFull) FXG_PLAN_FAIL("batch too large (%llu tiles)", (unsigned long long)ntiles);
+    ka.tile_reads = T; ka.ntiles = (u32)ntiles;
+    pl->lds = ga ? fxg_lds_layout(T, in->stride, pl->use_q, pl->clip).total : fxg_lds_layout(T, in->stride, false, false).total;
+    return FXG_OK;
+}

@@ -1,0 +1,55 @@
+"""One process per GPU; reads shard by contiguous index range, so concatenating the ranks' packed outputs
+in rank order reproduces the single-process output order.  There is no exchange during
+compute; the only collective is one all-gather of each rank's 16-slot counter block (128 bytes), from
+which every rank derives the job totals and its own offset into the global kept-read / kept-byte stream.
+Backend "nccl" is RCCL on ROCm (xGMI); "gloo" is used by the CPU tests.
+"""
+import os
+
+import numpy as np
+
+from .engine import C_ERRORS, C_KEPT, C_KEPT_BASES, NCOUNTERS
+
+
+def shard_range(n_total, rank, world):
+    """Reads [lo, hi) owned by `rank`: g*N/G .. (g+1)*N/G."""
+    return (n_total * rank) // world, (n_total * (rank + 1)) // world
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun's environment; returns (rank, local_rank, world)."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def epilogue(counters, group=None):
+    """counters: int64[16] tensor of this rank (device tensor for RCCL, CPU tensor for gloo).
+
+    Returns (totals uint64[16], kept_read_offset, kept_byte_offset, per_rank uint64[world, 16]).
+    """
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        c = counters.detach().cpu().numpy().view(np.uint64)
+        return c.copy(), 0, 0, c.reshape(1, -1).copy()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    gathered = torch.empty((world, NCOUNTERS), dtype=counters.dtype, device=counters.device)
+    dist.all_gather_into_tensor(gathered, counters.contiguous(), group=group) if counters.is_cuda else \
+        dist.all_gather(list(gathered.unbind(0)), counters.contiguous(), group=group)
+    per_rank = gathered.cpu().numpy().view(np.uint64).reshape(world, NCOUNTERS)
+    totals = per_rank.sum(axis=0, dtype=np.uint64)
+    totals[C_ERRORS] = np.bitwise_or.reduce(per_rank[:, C_ERRORS])
+    read_off = int(per_rank[:rank, C_KEPT].sum(dtype=np.uint64))
+    byte_off = int(per_rank[:rank, C_KEPT_BASES].sum(dtype=np.uint64))
+    return totals, read_off, byte_off, per_rank

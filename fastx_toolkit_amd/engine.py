@@ -1,0 +1,267 @@
+"""Thin Python view of the C-ABI in include/fxg.h.
+
+PyTorch is used only as plumbing: device allocations (tensors), the current HIP stream and
+torch.distributed.  All compute happens inside libfxg.so's HIP kernels; there is no CPU or
+PyTorch fallback -- if the library or a GPU is missing, construction fails.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+STAGE_CLIP, STAGE_QTRIM, STAGE_QFILTER, STAGE_REVCOMP, STAGE_FTRIM, STAGE_FTRIM_END = 1, 2, 4, 8, 16, 32
+CLIP_DISCARD_NON_CLIPPED, CLIP_DISCARD_CLIPPED, CLIP_KEEP_N, CLIP_ADAPTER_ONLY = 1, 2, 4, 8
+NCOUNTERS = 16
+(C_INPUT, C_KEPT, C_KEPT_BASES, C_CLIP_TOO_SHORT, C_CLIP_ADAPTER_ONLY, C_CLIP_NO_ADAPTER, C_CLIP_ADAPTER_FOUND,
+ C_CLIP_N, C_QTRIM_DROPPED, C_QFILTER_DROPPED, C_FTRIM_DROPPED, C_CLIP_OUT, C_QTRIM_OUT) = range(13)
+C_ERRORS = 15
+
+EXPORTS = [
+    "fxg_abi_version", "fxg_ctx_create", "fxg_ctx_destroy", "fxg_last_error", "fxg_set_stream", "fxg_sync",
+    "fxg_device_info", "fxg_malloc_device", "fxg_free_device", "fxg_malloc_host", "fxg_free_host", "fxg_memcpy_h2d",
+    "fxg_memcpy_d2h", "fxg_memset_device", "fxg_timer_start", "fxg_timer_stop", "fxg_run_pipeline",
+    "fxg_run_qtrim_qfilter", "fxg_run_clip", "fxg_run_revcomp_trim", "fxg_read_counters", "fxg_synth_generate",
+    "fxg_last_launch_info", "fxg_set_profiling", "fxg_last_kernel_ms",
+]
+
+
+class FxgParams(C.Structure):
+    _fields_ = [
+        ("stages", C.c_uint32), ("qoffset", C.c_int32),
+        ("qt_threshold", C.c_int32), ("qt_min_len", C.c_int32),
+        ("qf_min_quality", C.c_int32), ("qf_min_percent", C.c_int32),
+        ("adapter", C.c_char * 100), ("clip_min_len", C.c_uint32), ("clip_keep_delta", C.c_int32),
+        ("clip_min_adapter_len", C.c_int32), ("clip_flags", C.c_uint32),
+        ("ft_first", C.c_int32), ("ft_last", C.c_int32), ("ft_trim_end", C.c_uint32), ("ft_min_len", C.c_uint32),
+    ]
+
+
+class FxgBatch(C.Structure):
+    _fields_ = [("bases", C.c_void_p), ("qual", C.c_void_p), ("len", C.c_void_p),
+                ("fixed_len", C.c_uint32), ("stride", C.c_uint32), ("n", C.c_uint64)]
+
+
+class FxgOut(C.Structure):
+    _fields_ = [("res", C.c_void_p), ("out_bases", C.c_void_p), ("out_qual", C.c_void_p), ("out_len", C.c_void_p),
+                ("kept_index", C.c_void_p), ("out_off", C.c_void_p), ("counters", C.c_void_p)]
+
+
+def make_params(stages=0, qoffset=33, qt_threshold=0, qt_min_len=0, qf_min_quality=0, qf_min_percent=0,
+                adapter=b"CCTTAAGG", clip_min_len=5, clip_keep_delta=0, clip_min_adapter_len=0, clip_flags=0,
+                ft_first=1, ft_last=0, ft_trim_end=0, ft_min_len=0):
+    """fxg_params with the reference tools' defaults (fastx_args.c:43, fastx_clipper.cpp:68-69)."""
+    if isinstance(adapter, str):
+        adapter = adapter.encode()
+    p = FxgParams()
+    p.stages, p.qoffset = stages, qoffset
+    p.qt_threshold, p.qt_min_len = qt_threshold, qt_min_len
+    p.qf_min_quality, p.qf_min_percent = qf_min_quality, qf_min_percent
+    p.adapter = adapter
+    p.clip_min_len, p.clip_keep_delta = clip_min_len, clip_keep_delta
+    p.clip_min_adapter_len, p.clip_flags = clip_min_adapter_len, clip_flags
+    p.ft_first, p.ft_last, p.ft_trim_end, p.ft_min_len = ft_first, ft_last, ft_trim_end, ft_min_len
+    return p
+
+
+_LIB = None
+
+
+def load_library(path=None):
+    """dlopen libfxg.so (building it in-tree if needed) and declare the prototypes.  Needs no GPU."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    so = path or _build.LIBFXG
+    if not os.path.exists(so):
+        _build.build_engine()
+    if not os.path.exists(so):
+        raise RuntimeError("libfxg.so is missing and could not be built; there is no fallback path")
+    L = C.CDLL(so)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    L.fxg_abi_version.restype = C.c_int
+    L.fxg_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    L.fxg_ctx_destroy.argtypes = [vp]; L.fxg_ctx_destroy.restype = None
+    L.fxg_last_error.argtypes = [vp]; L.fxg_last_error.restype = C.c_char_p
+    L.fxg_set_stream.argtypes = [vp, vp]
+    L.fxg_sync.argtypes = [vp]
+    L.fxg_device_info.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+    L.fxg_malloc_device.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.fxg_free_device.argtypes = [vp, vp]
+    L.fxg_malloc_host.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.fxg_free_host.argtypes = [vp, vp]
+    L.fxg_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    L.fxg_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    L.fxg_memset_device.argtypes = [vp, vp, i32, C.c_size_t]
+    L.fxg_timer_start.argtypes = [vp]
+    L.fxg_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    L.fxg_run_pipeline.argtypes = [vp, C.POINTER(FxgBatch), C.POINTER(FxgParams), C.POINTER(FxgOut)]
+    L.fxg_run_qtrim_qfilter.argtypes = [vp, C.POINTER(FxgBatch), i32, i32, i32, i32, i32, i32, i32, C.POINTER(FxgOut)]
+    L.fxg_run_clip.argtypes = [vp, C.POINTER(FxgBatch), C.c_char_p, u32, i32, i32, u32, C.POINTER(FxgOut)]
+    L.fxg_run_revcomp_trim.argtypes = [vp, C.POINTER(FxgBatch), i32, i32, i32, C.POINTER(FxgOut)]
+    L.fxg_read_counters.argtypes = [vp, vp, C.POINTER(u64 * NCOUNTERS)]
+    L.fxg_synth_generate.argtypes = [vp, u64, u64, u64, u32, i32, vp, vp, u32]
+    L.fxg_last_launch_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.fxg_set_profiling.argtypes = [vp, i32]
+    L.fxg_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    if path is None:
+        _LIB = L
+    return L
+
+
+class FxgError(RuntimeError):
+    pass
+
+
+class Result:
+    """Device-resident outputs of one pipeline run (torch tensors) plus lazily fetched host counters."""
+
+    def __init__(self, engine, res, out_bases, out_qual, out_len, kept_index, out_off, counters):
+        self.engine = engine
+        self.res, self.out_bases, self.out_qual = res, out_bases, out_qual
+        self.out_len, self.kept_index, self.out_off = out_len, kept_index, out_off
+        self.d_counters = counters
+        self._counters = None
+
+    @property
+    def counters(self):
+        if self._counters is None:
+            self._counters = self.engine.read_counters(self.d_counters)
+        return self._counters
+
+    @property
+    def kept(self):
+        return int(self.counters[C_KEPT])
+
+    @property
+    def kept_bytes(self):
+        return int(self.counters[C_KEPT_BASES])
+
+    def to_host(self):
+        """numpy copies trimmed to the kept counts (same keys as the oracle's run_pipeline)."""
+        c = self.counters
+        kept, nbytes = int(c[C_KEPT]), int(c[C_KEPT_BASES])
+        d = dict(res=self.res.cpu().numpy().view(np.uint32), counters=c)
+        d["out_bases"] = self.out_bases[:nbytes].cpu().numpy() if self.out_bases is not None else None
+        d["out_qual"] = self.out_qual[:nbytes].cpu().numpy() if self.out_qual is not None else None
+        d["out_len"] = self.out_len[:kept].cpu().numpy().view(np.uint16) if self.out_len is not None else None
+        d["kept_index"] = self.kept_index[:kept].cpu().numpy().view(np.uint32) if self.kept_index is not None else None
+        d["out_off"] = self.out_off[:kept].cpu().numpy().view(np.uint64) if self.out_off is not None else None
+        return d
+
+
+class Engine:
+    """One context on one GPU (one process per GPU)."""
+
+    def __init__(self, device_id=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise FxgError("no HIP device visible: the fastx engine has no CPU fallback")
+        self.torch = torch
+        self.lib = load_library()
+        self.device_id = device_id
+        self.device = torch.device("cuda", device_id)
+        h = C.c_void_p()
+        rc = self.lib.fxg_ctx_create(device_id, C.byref(h))
+        if rc != 0:
+            raise FxgError("fxg_ctx_create(%d) failed: %d" % (device_id, rc))
+        self.ctx = h
+        self.use_torch_stream()
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.fxg_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise FxgError("fxg error %d: %s" % (rc, self.lib.fxg_last_error(self.ctx).decode(errors="replace")))
+
+    def use_torch_stream(self):
+        """Enqueue on torch's current stream so tensors allocated by torch are ordered with the kernels."""
+        s = self.torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.fxg_set_stream(self.ctx, C.c_void_p(s)))
+
+    def sync(self):
+        self._check(self.lib.fxg_sync(self.ctx))
+
+    def device_info(self):
+        cus, mem = C.c_int(), C.c_size_t()
+        name = C.create_string_buffer(128)
+        self._check(self.lib.fxg_device_info(self.ctx, C.byref(cus), C.byref(mem), name, 128))
+        return dict(compute_units=cus.value, total_mem=mem.value, name=name.value.decode())
+
+    def last_launch(self):
+        name = C.create_string_buffer(128)
+        g, b, l, t = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._check(self.lib.fxg_last_launch_info(self.ctx, name, 128, C.byref(g), C.byref(b), C.byref(l), C.byref(t)))
+        return dict(kernel=name.value.decode(), grid=g.value, block=b.value, lds=l.value, tile_reads=t.value)
+
+    def set_profiling(self, on=True):
+        self._check(self.lib.fxg_set_profiling(self.ctx, int(on)))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self._check(self.lib.fxg_last_kernel_ms(self.ctx, C.byref(ms)))
+        return ms.value
+
+    def timer_start(self):
+        self._check(self.lib.fxg_timer_start(self.ctx))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._check(self.lib.fxg_timer_stop(self.ctx, C.byref(ms)))
+        return ms.value
+
+    # ---- data ----
+    def empty(self, n, dtype=None):
+        return self.torch.empty(int(n), dtype=dtype or self.torch.uint8, device=self.device)
+
+    def synth(self, seed, first, n, read_len, with_adapter=False, stride=None, want_qual=True):
+        """Deterministic synthetic reads generated on the device. Returns (bases, qual) uint8 [n, stride]."""
+        stride = stride or read_len
+        bases = self.torch.empty((n, stride), dtype=self.torch.uint8, device=self.device)
+        qual = self.torch.empty((n, stride), dtype=self.torch.uint8, device=self.device) if want_qual else None
+        self._check(self.lib.fxg_synth_generate(self.ctx, seed, first, n, read_len, int(with_adapter), bases.data_ptr(),
+                                                qual.data_ptr() if want_qual else None, stride))
+        return bases, qual
+
+    def upload(self, arr):
+        t = self.torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1))
+        return t.to(self.device)
+
+    def alloc_outputs(self, n, stride, compact=True, meta=True, has_qual=True):
+        t = self.torch
+        o = dict(res=t.empty(n, dtype=t.int32, device=self.device), counters=t.zeros(NCOUNTERS, dtype=t.int64, device=self.device))
+        o["out_bases"] = t.empty(n * stride + 16, dtype=t.uint8, device=self.device) if compact else None
+        o["out_qual"] = t.empty(n * stride + 16, dtype=t.uint8, device=self.device) if (compact and has_qual) else None
+        o["out_len"] = t.empty(n, dtype=t.int16, device=self.device) if (compact and meta) else None
+        o["kept_index"] = t.empty(n, dtype=t.int32, device=self.device) if (compact and meta) else None
+        o["out_off"] = t.empty(n, dtype=t.int64, device=self.device) if (compact and meta) else None
+        return o
+
+    def run(self, bases, qual, params, lens=None, fixed_len=None, compact=True, meta=True, outputs=None):
+        """Enqueue one pipeline pass.  bases/qual: uint8 device tensors [n, stride]; lens: int16 device tensor or None."""
+        n, stride = bases.shape
+        if outputs is None:
+            outputs = self.alloc_outputs(n, stride, compact, meta, qual is not None)
+        o = outputs
+        b = FxgBatch(bases.data_ptr(), qual.data_ptr() if qual is not None else None,
+                     lens.data_ptr() if lens is not None else None, int(fixed_len or stride), stride, n)
+        ptr = lambda k: (o[k].data_ptr() if o.get(k) is not None else None)
+        fo = FxgOut(ptr("res"), ptr("out_bases"), ptr("out_qual"), ptr("out_len"), ptr("kept_index"), ptr("out_off"), ptr("counters"))
+        self._check(self.lib.fxg_run_pipeline(self.ctx, C.byref(b), C.byref(params), C.byref(fo)))
+        return Result(self, o["res"], o.get("out_bases"), o.get("out_qual"), o.get("out_len"), o.get("kept_index"),
+                      o.get("out_off"), o["counters"])
+
+    def read_counters(self, d_counters):
+        host = (C.c_uint64 * NCOUNTERS)()
+        self._check(self.lib.fxg_read_counters(self.ctx, d_counters.data_ptr() if d_counters is not None else None, C.byref(host)))
+        return np.array(list(host), dtype=np.uint64)

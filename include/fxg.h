@@ -1,0 +1,210 @@
+/*
+ * fxg.h -- C-ABI of the MI355X (gfx950) FASTQ preprocessing engine.
+ *
+ * This is the drop-in boundary for the fastx_toolkit hot path: the per-read loop bodies of
+ *   fastq_quality_trimmer     (reference src/fastq_quality_trimmer/fastq_quality_trimmer.c:91-103)
+ *   fastq_quality_filter      (src/fastq_quality_filter/fastq_quality_filter.c:78-129,150-156)
+ *   fastx_clipper             (src/fastx_clipper/fastx_clipper.cpp:159-241,257-320 +
+ *                              src/libfastx/sequence_alignment.cpp:113-129,340-428,496-650)
+ *   fastx_trimmer             (src/fastx_trimmer/fastx_trimmer.c:120-148)
+ *   fastx_reverse_complement  (src/fastx_reverse_complement/fastx_reverse_complement.c:43-104)
+ * run as batched HIP kernels over a Structure-of-Arrays batch instead of once per
+ * fastx_read_next_record() (src/libfastx/fastx.h:120-142).  The reference has no FFI of its own; the
+ * host-side C layer that keeps the libfastx record API and the five command lines on top of these
+ * entry points lives in fastx_toolkit_amd/host/ (see INTEGRATION.md).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes only.  Every function returns 0 on success or a negative
+ *    FXG_E_* code; fxg_last_error(ctx) describes the most recent failure on that context.
+ *  - All fxg_batch / fxg_out pointers are DEVICE pointers (hipMalloc'ed by the caller or through
+ *    fxg_malloc_device).  bases/qual/out_bases/out_qual must be 16-byte aligned.
+ *  - Work is enqueued on the context's HIP stream and is asynchronous; fxg_sync() waits for it.
+ *  - There is no CPU fallback anywhere: without a usable HIP device fxg_ctx_create() fails.
+ */
+#ifndef FXG_H
+#define FXG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FXG_ABI_VERSION 1
+
+/* ---- error codes ---- */
+#define FXG_OK            0
+#define FXG_E_INVALID    -1   /* bad argument / unsupported stage combination */
+#define FXG_E_HIP        -2   /* a HIP runtime call failed */
+#define FXG_E_NOMEM      -3
+#define FXG_E_DEVICE     -4   /* device-side failure flag (scan time-out, invalid nucleotide, ...) */
+
+/* ---- pipeline stages.  Supported chains: [CLIP][QTRIM][QFILTER]  and  [REVCOMP][FTRIM|FTRIM_END] ---- */
+#define FXG_STAGE_CLIP      0x01u  /* fastx_clipper            */
+#define FXG_STAGE_QTRIM     0x02u  /* fastq_quality_trimmer    */
+#define FXG_STAGE_QFILTER   0x04u  /* fastq_quality_filter     */
+#define FXG_STAGE_REVCOMP   0x08u  /* fastx_reverse_complement */
+#define FXG_STAGE_FTRIM     0x10u  /* fastx_trimmer -f/-l      */
+#define FXG_STAGE_FTRIM_END 0x20u  /* fastx_trimmer -t/-m      */
+
+/* fastx_clipper switches (fastx_clipper.cpp:90-146) */
+#define FXG_CLIP_DISCARD_NON_CLIPPED 0x1u /* -c */
+#define FXG_CLIP_DISCARD_CLIPPED     0x2u /* -C */
+#define FXG_CLIP_KEEP_N              0x4u /* -n */
+#define FXG_CLIP_ADAPTER_ONLY        0x8u /* -k */
+
+#define FXG_MAX_ADAPTER 99           /* fastx_clipper.cpp:40 MAX_ADAPTER_LEN 100 incl. NUL */
+#define FXG_MAX_READ_LEN 65535u      /* device limit; the reference reader stops at 24999 (fastx.h:33) */
+
+/* Per-read result word written to fxg_out.res[r]:
+ *   bits  0..15  new length (bases kept; for dropped reads the length at the point of the drop)
+ *   bit   16     keep
+ *   bits 17..20  drop reason (FXG_R_*)
+ *   bit   21     adapter found and clipped (clipper's i > 0)                                      */
+#define FXG_RES_LEN(w)     ((uint32_t)(w) & 0xFFFFu)
+#define FXG_RES_KEEP(w)    (((uint32_t)(w) >> 16) & 1u)
+#define FXG_RES_REASON(w)  (((uint32_t)(w) >> 17) & 0xFu)
+#define FXG_RES_CLIPPED(w) (((uint32_t)(w) >> 21) & 1u)
+
+enum fxg_reason {
+    FXG_R_KEPT = 0,
+    FXG_R_CLIP_TOO_SHORT = 1,     /* fastx_clipper.cpp:297-300 */
+    FXG_R_CLIP_ADAPTER_ONLY = 2,  /* :289-295 */
+    FXG_R_CLIP_NO_ADAPTER = 3,    /* :302-305 (-c) */
+    FXG_R_CLIP_ADAPTER_FOUND = 4, /* :307-310 (-C) */
+    FXG_R_CLIP_N = 5,             /* :312-315 */
+    FXG_R_QTRIM = 6,              /* fastq_quality_trimmer.c:101 */
+    FXG_R_QFILTER = 7,            /* fastq_quality_filter.c:155 */
+    FXG_R_FTRIM = 8,              /* fastx_trimmer.c:127,137,140 */
+    FXG_R_CLIP_K_MODE = 9         /* fastx_clipper.cpp:317 (-k: only adapter-only reads are written) */
+};
+
+/* slots of the u64 counter block (feeds the tools' -v reports, a12) */
+enum fxg_counter {
+    FXG_C_INPUT = 0,
+    FXG_C_KEPT = 1,
+    FXG_C_KEPT_BASES = 2,
+    FXG_C_CLIP_TOO_SHORT = 3,
+    FXG_C_CLIP_ADAPTER_ONLY = 4,
+    FXG_C_CLIP_NO_ADAPTER = 5,
+    FXG_C_CLIP_ADAPTER_FOUND = 6,
+    FXG_C_CLIP_N = 7,
+    FXG_C_QTRIM_DROPPED = 8,
+    FXG_C_QFILTER_DROPPED = 9,
+    FXG_C_FTRIM_DROPPED = 10,
+    FXG_C_CLIP_OUT = 11,          /* reads that survive the clip stage */
+    FXG_C_QTRIM_OUT = 12,         /* reads that survive the quality-trim stage */
+    FXG_C_ERRORS = 15,            /* device error bits, see FXG_DEV_ERR_* */
+    FXG_NCOUNTERS = 16
+};
+#define FXG_DEV_ERR_SCAN_TIMEOUT 0x1u
+#define FXG_DEV_ERR_BAD_BASE     0x2u  /* fastx_reverse_complement.c:67-68 "Invalid nucleotide value" */
+
+/* Tool parameters, one block for the whole chain (flag meaning = the reference's getopt handlers). */
+typedef struct fxg_params {
+    uint32_t stages;              /* FXG_STAGE_* mask */
+    int32_t  qoffset;             /* -Q, fastx_args.c:43 (default 33) */
+    int32_t  qt_threshold;        /* fastq_quality_trimmer -t (strtol; may be negative) */
+    int32_t  qt_min_len;          /* fastq_quality_trimmer -l */
+    int32_t  qf_min_quality;      /* fastq_quality_filter -q */
+    int32_t  qf_min_percent;      /* fastq_quality_filter -p, 0 = flag omitted (quirk F2) */
+    char     adapter[100];        /* fastx_clipper -a, NUL terminated */
+    uint32_t clip_min_len;        /* fastx_clipper -l (default 5) */
+    int32_t  clip_keep_delta;     /* fastx_clipper -d N, already += strlen(adapter) when N>0 (:153-154) */
+    int32_t  clip_min_adapter_len;/* fastx_clipper -M */
+    uint32_t clip_flags;          /* FXG_CLIP_* */
+    int32_t  ft_first;            /* fastx_trimmer -f (1-based, default 1) */
+    int32_t  ft_last;             /* fastx_trimmer -l (0 = to the end) */
+    uint32_t ft_trim_end;         /* fastx_trimmer -t */
+    uint32_t ft_min_len;          /* fastx_trimmer -m */
+} fxg_params;
+
+/* Input batch (replaces the one-record FASTX struct, fastx.h:62-117): row r of bases/qual starts at
+ * r*stride; its length is len[r], or fixed_len when len == NULL.  qual == NULL means FASTA input
+ * (only CLIP / REVCOMP / FTRIM* make sense then).  Quality bytes are the raw ASCII characters; the
+ * -Q offset is folded into the thresholds on the host side of the launch. */
+typedef struct fxg_batch {
+    const uint8_t  *bases;
+    const uint8_t  *qual;
+    const uint16_t *len;
+    uint32_t        fixed_len;
+    uint32_t        stride;
+    uint64_t        n;
+} fxg_batch;
+
+/* Output.  res is mandatory.  If out_bases != NULL the kept reads are stream-compacted in input order:
+ * their (transformed) bases and qualities are concatenated without gaps into out_bases/out_qual
+ * (same offsets in both), which is what fastx_write_record (fastx.c:440-473) would print line by
+ * line.  out_len / kept_index / out_off (all optional) describe kept read k = 0..kept-1.
+ * counters (optional, device u64[FXG_NCOUNTERS]) is overwritten by each run. */
+typedef struct fxg_out {
+    uint32_t *res;
+    uint8_t  *out_bases;
+    uint8_t  *out_qual;
+    uint16_t *out_len;
+    uint32_t *kept_index;
+    uint64_t *out_off;
+    uint64_t *counters;
+} fxg_out;
+
+typedef struct fxg_ctx fxg_ctx;
+
+/* ---- context ---- */
+int  fxg_abi_version(void);
+int  fxg_ctx_create(int device_id, fxg_ctx **out);
+void fxg_ctx_destroy(fxg_ctx *ctx);
+const char *fxg_last_error(const fxg_ctx *ctx);
+int  fxg_set_stream(fxg_ctx *ctx, void *hip_stream);   /* NULL = the context's own stream */
+int  fxg_sync(fxg_ctx *ctx);
+int  fxg_device_info(fxg_ctx *ctx, int *compute_units, size_t *total_mem, char *name, size_t name_cap);
+
+/* ---- memory helpers so that a C host needs no HIP headers ---- */
+int  fxg_malloc_device(fxg_ctx *ctx, size_t bytes, void **dptr);
+int  fxg_free_device(fxg_ctx *ctx, void *dptr);
+int  fxg_malloc_host(fxg_ctx *ctx, size_t bytes, void **hptr);     /* pinned */
+int  fxg_free_host(fxg_ctx *ctx, void *hptr);
+int  fxg_memcpy_h2d(fxg_ctx *ctx, void *dst, const void *src, size_t bytes);   /* async on the ctx stream */
+int  fxg_memcpy_d2h(fxg_ctx *ctx, void *dst, const void *src, size_t bytes);   /* async on the ctx stream */
+int  fxg_memset_device(fxg_ctx *ctx, void *dst, int value, size_t bytes);
+
+/* ---- timing on the stream the kernels run on (HIP events) ---- */
+int  fxg_timer_start(fxg_ctx *ctx);
+int  fxg_timer_stop(fxg_ctx *ctx, float *elapsed_ms);               /* synchronises on the stop event */
+
+/* ---- the hot path ---- */
+/* General entry: runs the chain described by p->stages over the batch. */
+int  fxg_run_pipeline(fxg_ctx *ctx, const fxg_batch *in, const fxg_params *p, const fxg_out *out);
+
+/* Per-tool entry points (thin wrappers that fill fxg_params and call fxg_run_pipeline). */
+int  fxg_run_qtrim_qfilter(fxg_ctx *ctx, const fxg_batch *in, int qoffset,
+                           int use_trim, int trim_threshold, int trim_min_len,
+                           int use_filter, int filter_min_quality, int filter_min_percent,
+                           const fxg_out *out);
+int  fxg_run_clip(fxg_ctx *ctx, const fxg_batch *in, const char *adapter, uint32_t min_len,
+                  int keep_delta, int min_adapter_len, uint32_t clip_flags, const fxg_out *out);
+int  fxg_run_revcomp_trim(fxg_ctx *ctx, const fxg_batch *in, int reverse_complement,
+                          int first_base, int last_base, const fxg_out *out);
+
+/* Copies the counter block to the host after synchronising; returns FXG_E_DEVICE if the kernels
+ * raised an error bit (counters[FXG_C_ERRORS]). */
+int  fxg_read_counters(fxg_ctx *ctx, const uint64_t *d_counters, uint64_t host_counters[FXG_NCOUNTERS]);
+
+/* Deterministic synthetic reads generated straight into device memory. */
+int  fxg_synth_generate(fxg_ctx *ctx, uint64_t seed, uint64_t first_read, uint64_t n, uint32_t read_len,
+                        int with_adapter, uint8_t *d_bases, uint8_t *d_qual, uint32_t stride);
+
+/* Kernel-level timing: when enabled, every fxg_run_pipeline brackets its dominant kernel (not the
+ * memset / counter-reduce helpers) with HIP events on the launch stream; fxg_last_kernel_ms waits for
+ * that launch and returns its duration. */
+int  fxg_set_profiling(fxg_ctx *ctx, int enabled);
+int  fxg_last_kernel_ms(fxg_ctx *ctx, float *elapsed_ms);
+
+/* Name and launch geometry of the dominant kernel of the last fxg_run_pipeline (for profiling). */
+int  fxg_last_launch_info(const fxg_ctx *ctx, char *kernel_name, size_t cap, uint32_t *grid, uint32_t *block,
+                          uint32_t *lds_bytes, uint32_t *tile_reads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FXG_H */

@@ -1,0 +1,74 @@
+"""ctypes view of tests/emu/libfxgemu.so (serial CPU emulation of the tile kernels, test-only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_EMU = os.path.join(_HERE, "emu")
+_LIB = None
+NCOUNTERS = 16
+
+
+class Batch(C.Structure):
+    _fields_ = [("bases", C.c_void_p), ("qual", C.c_void_p), ("len", C.c_void_p),
+                ("fixed_len", C.c_uint32), ("stride", C.c_uint32), ("n", C.c_uint64)]
+
+
+class Out(C.Structure):
+    _fields_ = [("res", C.c_void_p), ("out_bases", C.c_void_p), ("out_qual", C.c_void_p), ("out_len", C.c_void_p),
+                ("kept_index", C.c_void_p), ("out_off", C.c_void_p), ("counters", C.c_void_p)]
+
+
+def build():
+    src = os.path.join(_EMU, "fxg_emu.cpp")
+    so = os.path.join(_EMU, "libfxgemu.so")
+    csrc = os.path.join(_HERE, "..", "fastx_toolkit_amd", "csrc")
+    deps = [src] + [os.path.join(csrc, f) for f in ("fxg_device.h", "fxg_kernels.h", "fxg_plan.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["hipcc", "--cuda-host-only", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+                               "-Wno-pass-failed", "-DFXG_HOST_EMULATION", src, "-o", so])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.fxg_emu_run_pipeline.argtypes = [C.POINTER(Batch), C.c_void_p, C.POINTER(Out), C.c_char_p, C.c_size_t]
+        _LIB.fxg_emu_tile_reads.restype = C.c_uint
+    return _LIB
+
+
+def _aligned(n, dtype=np.uint8):
+    """16-byte aligned zeroed array of n items."""
+    item = np.dtype(dtype).itemsize
+    raw = np.zeros(n * item + 32, dtype=np.uint8)
+    off = (-raw.ctypes.data) % 16
+    return raw[off:off + n * item].view(dtype)
+
+
+def run_pipeline(bases, qual, lens, params, fixed_len=None, compact=True):
+    n, stride = bases.shape
+    b = _aligned(n * stride); b[:] = bases.reshape(-1)
+    q = None
+    if qual is not None:
+        q = _aligned(n * stride); q[:] = qual.reshape(-1)
+    if lens is not None:
+        lens = np.ascontiguousarray(lens, dtype=np.uint16)
+    res = np.zeros(n, dtype=np.uint32)
+    ob, oq = _aligned(n * stride + 16), _aligned(n * stride + 16)
+    ol, ki, oo = np.zeros(n, dtype=np.uint16), np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint64)
+    ctr = np.zeros(NCOUNTERS, dtype=np.uint64)
+    bt = Batch(b.ctypes.data, q.ctypes.data if q is not None else None, lens.ctypes.data if lens is not None else None,
+               int(fixed_len or stride), stride, n)
+    o = Out(res.ctypes.data, ob.ctypes.data if compact else None, oq.ctypes.data if (compact and q is not None) else None,
+            ol.ctypes.data, ki.ctypes.data, oo.ctypes.data, ctr.ctypes.data)
+    err = C.create_string_buffer(512)
+    rc = lib().fxg_emu_run_pipeline(C.byref(bt), C.addressof(params), C.byref(o), err, 512)
+    if rc != 0:
+        raise ValueError("emu rc=%d: %s" % (rc, err.value.decode()))
+    kept, nbytes = int(ctr[1]), int(ctr[2])
+    return dict(res=res, out_bases=ob[:nbytes].copy(), out_qual=oq[:nbytes].copy() if q is not None else None,
+                out_len=ol[:kept], kept_index=ki[:kept], out_off=oo[:kept], counters=ctr)

@@ -1,0 +1,106 @@
+"""Shared helpers for the parity tests (oracle side = checker only)."""
+import hashlib
+import os
+
+import numpy as np
+
+from oracle import fxoracle_py as fo
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KEYS = ("res", "out_bases", "out_qual", "out_len", "kept_index")
+
+
+def md5(b):
+    return hashlib.md5(b).hexdigest()
+
+
+def oracle_params(d):
+    return fo.make_params(**d)
+
+
+def assert_same(o, e, what=""):
+    """o = oracle result dict, e = engine/emulator result dict."""
+    for k in KEYS:
+        if o.get(k) is None:
+            continue
+        assert e.get(k) is not None, "%s: %s missing" % (what, k)
+        assert o[k].shape == e[k].shape, "%s: %s shape %s vs %s" % (what, k, o[k].shape, e[k].shape)
+        if not np.array_equal(o[k], e[k]):
+            i = int(np.nonzero(o[k] != e[k])[0][0])
+            raise AssertionError("%s: %s differs first at %d: oracle %r engine %r" % (what, k, i, o[k][i], e[k][i]))
+    if e.get("out_off") is not None:
+        ol = o["out_len"].astype(np.uint64)
+        off = np.concatenate([[0], np.cumsum(ol)[:-1]]).astype(np.uint64) if len(ol) else np.zeros(0, np.uint64)
+        assert np.array_equal(off, e["out_off"]), "%s: out_off" % what
+    assert np.array_equal(o["counters"][:13], e["counters"][:13]), "%s: counters %s vs %s" % (what, o["counters"][:13], e["counters"][:13])
+
+
+def text_through(run, text, params, qoffset=33):
+    """FASTQ text -> SoA (oracle parser) -> run(bases, qual, lens, params) -> FASTQ text (oracle formatter)."""
+    p = fo.parse_fastq(text, qoffset)
+    r = run(p["bases"], p["qual"], p["lens"], params)
+    return fo.format_fastq(text, p["names"], r["out_bases"], r["out_qual"], r["out_len"], r["kept_index"]), r
+
+
+def random_batch(rng, n, stride, lmin, lmax, fixed=False, p_n=0.02, adapter=None):
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    b = rng.choice(acgt, size=(n, stride))
+    b[rng.random((n, stride)) < p_n] = ord("N")
+    q = rng.integers(33, 33 + 42, size=(n, stride), dtype=np.uint8)
+    for i in range(n):
+        d = int(rng.integers(0, stride + 1))
+        q[i, d:] = rng.integers(33, 33 + 15, size=stride - d)
+    lens = None if fixed else rng.integers(lmin, lmax + 1, size=n).astype(np.uint16)
+    if adapter is not None:
+        ad = np.frombuffer(adapter, dtype=np.uint8)
+        for i in range(n):
+            if rng.random() < 0.6:
+                L = lmax if fixed else int(lens[i])
+                pos = int(rng.integers(0, L + 1))
+                k = min(len(ad), L - pos)
+                a2 = ad.copy()
+                if rng.random() < 0.3:
+                    a2[int(rng.integers(0, len(ad)))] = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8))
+                b[i, pos:pos + k] = a2[:k]
+    return np.ascontiguousarray(b), np.ascontiguousarray(q), lens
+
+
+def fuzz_cases(seed, trials, clip_trials):
+    """Yields (name, bases, qual, lens, fixed_len, params_dict) covering ragged lengths, tiny reads, odd strides, all flags."""
+    rng = np.random.default_rng(seed)
+    for trial in range(trials):
+        stride = int(rng.choice([1, 2, 7, 15, 16, 17, 33, 36, 64, 100, 150, 151, 250, 300, 1000]))
+        lmin = max(1, int(rng.integers(1, stride + 1)))
+        fixed = rng.random() < 0.4
+        n = int(rng.integers(1, 900))
+        b, q, lens = random_batch(rng, n, stride, lmin, stride, fixed)
+        fl = int(rng.integers(1, stride + 1)) if fixed else None
+        t = int(rng.integers(-5, 45)) or 7
+        ml = int(rng.integers(0, stride + 2))
+        mq, pc = int(rng.integers(0, 45)), int(rng.integers(0, 101))
+        qo = int(rng.choice([33, 33, 64, 30]))
+        for st in (2, 4, 6):
+            yield ("t%d.st%d.s%d.n%d" % (trial, st, stride, n), b, q, lens, fl,
+                   dict(stages=st, qt_threshold=t, qt_min_len=ml, qf_min_quality=mq, qf_min_percent=pc, qoffset=qo))
+        f, l = int(rng.integers(1, stride + 2)), int(rng.integers(0, stride + 3))
+        for st in (8, 16, 24):
+            yield ("t%d.st%d.f%d.l%d.s%d" % (trial, st, f, l, stride), b, q, lens, fl, dict(stages=st, ft_first=f, ft_last=l))
+        for st in (32, 40):
+            yield ("t%d.st%d.s%d" % (trial, st, stride), b, q, lens, fl,
+                   dict(stages=st, ft_trim_end=int(rng.integers(1, stride + 2)), ft_min_len=int(rng.integers(0, stride + 1))))
+    adapters = [b"AGATCGGAAGAGC", b"CCTTAAGG", b"CAATTGGTTAATCCCCCTATATA", b"ACGT", b"TGGAATTCTCGGGTGCCAAGGAACTCCAGTCAC",
+                b"ANNTCGNA", b"A" * 40 + b"CGT" * 8, b"ACGTTGCA" * 9]
+    for trial in range(clip_trials):
+        ad = adapters[trial % len(adapters)]
+        stride = int(rng.choice([5, 13, 20, 36, 50, 75, 100, 151]))
+        n = int(rng.integers(1, 700))
+        b, q, _ = random_batch(rng, n, stride, stride, stride, True, adapter=ad)
+        flags = int(rng.integers(0, 16))
+        d = int(rng.integers(0, 3)) * int(rng.integers(0, 8))
+        kd = d + len(ad) if d > 0 else 0
+        yield ("clip%d.a%d.s%d.fl%d" % (trial, len(ad), stride, flags), b, q, None, stride,
+               dict(stages=1, adapter=ad, clip_min_len=int(rng.integers(0, 25)), clip_keep_delta=kd,
+                    clip_min_adapter_len=int(rng.choice([0, 0, 3, 8])), clip_flags=flags))
+        yield ("clip7_%d" % trial, b, q, None, stride,
+               dict(stages=7, adapter=ad, clip_min_len=5, clip_flags=flags & 7, qt_threshold=15, qt_min_len=4,
+                    qf_min_quality=12, qf_min_percent=60))

@@ -1,0 +1,54 @@
+"""CPU tier: the kernels' per-thread device code, run serially on the host (tests/emu), against the oracle.
+
+The emulator executes the same __host__ __device__ phase bodies as the GPU kernels (bitmap build,
+per-read decision incl. the forward-carried clipper DP, 16-byte chunk gather, reverse-complement);
+only the wave-level scan / look-back is replaced by a serial prefix.  Bit-exact or it fails.
+"""
+import numpy as np
+
+import emu_py as emu
+from helpers import assert_same, fuzz_cases, oracle_params
+from oracle import fxoracle_py as fo
+
+
+def test_emulated_kernels_on_configs():
+    cfgs = [
+        ((2, 0, 20000, 150, False), dict(stages=6, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80)),
+        ((1, 0, 10000, 36, False), dict(stages=2, qt_threshold=20, qt_min_len=30)),
+        ((2, 0, 20000, 150, False), dict(stages=24, ft_first=5, ft_last=145)),
+        ((3, 0, 5000, 100, True), dict(stages=1, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=4)),
+        ((5, 0, 5000, 150, True), dict(stages=7, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=4, qt_threshold=20,
+                                       qt_min_len=30, qf_min_quality=20, qf_min_percent=80)),
+    ]
+    for gen, pd in cfgs:
+        b, q = fo.synth_batch(*gen)
+        p = oracle_params(pd)
+        o = fo.run_pipeline(b, q, None, p)
+        e = emu.run_pipeline(b, q, None, p)
+        assert 0 < int(o["counters"][fo.C_KEPT]) <= gen[2]
+        assert_same(o, e, str(pd))
+
+
+def test_emulated_kernels_fuzz():
+    kept_total = 0
+    for name, b, q, lens, fl, pd in fuzz_cases(7, trials=40, clip_trials=32):
+        p = oracle_params(pd)
+        o = fo.run_pipeline(b, q, lens, p, fixed_len=fl)
+        e = emu.run_pipeline(b, q, lens, p, fixed_len=fl)
+        assert_same(o, e, name)
+        kept_total += int(o["counters"][fo.C_KEPT])
+    assert kept_total > 10000
+
+
+def test_emulated_decision_only_and_bad_base():
+    b, q = fo.synth_batch(9, 0, 3000, 50)
+    p = oracle_params(dict(stages=6, qt_threshold=20, qt_min_len=10, qf_min_quality=15, qf_min_percent=70))
+    o = fo.run_pipeline(b, q, None, p)
+    e = emu.run_pipeline(b, q, None, p, compact=False)
+    assert np.array_equal(o["res"], e["res"]) and np.array_equal(o["counters"][:13], e["counters"][:13])
+    b2 = b.copy()
+    b2[17, 3] = ord("X")
+    e = emu.run_pipeline(b2, q, None, oracle_params(dict(stages=8)))
+    assert int(e["counters"][15]) & 2          # fastx_reverse_complement.c:67-68
+    e = emu.run_pipeline(b2, q, None, oracle_params(dict(stages=16, ft_first=2)))
+    assert int(e["counters"][15]) == 0         # the fixed trimmer never looks at the alphabet

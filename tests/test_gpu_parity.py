@@ -1,0 +1,187 @@
+"""GPU tier (-m gpu): the HIP path, called through the C-ABI of libfxg.so, against the oracle.
+
+Bit-exact on every array (integer/byte work; the clipper's fp32 DP only feeds integer decisions, so it
+is bit-exact too).  Sizes: oracle-sized seeded inputs + fuzz here, BASELINE.json's full sizes through
+size-independent properties (prefix/suffix windows vs the oracle, offset algebra, determinism).
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_same, fuzz_cases, md5, oracle_params
+from oracle import fxoracle_py as fo
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine_params(pd):
+    from fastx_toolkit_amd import make_params
+    return make_params(**pd)
+
+
+def _run(engine, b, q, lens, pd, fixed_len=None, compact=True):
+    import torch
+    db = engine.upload(b).view(b.shape)
+    dq = engine.upload(q).view(q.shape) if q is not None else None
+    dl = torch.from_numpy(np.ascontiguousarray(lens).view(np.int16)).to(engine.device) if lens is not None else None
+    r = engine.run(db, dq, _engine_params(pd), lens=dl, fixed_len=fixed_len, compact=compact)
+    return r.to_host()
+
+
+def test_synth_generator_matches_oracle(engine):
+    for seed, first, n, L, ad, stride in [(2, 0, 3000, 150, False, 150), (3, 12345, 2000, 100, True, 100), (5, 7, 1111, 150, True, 160),
+                                          (1, 99, 777, 36, False, 36), (8, 1 << 33, 100, 13, True, 29)]:
+        b, q = engine.synth(seed, first, n, L, ad, stride)
+        ob, oq = fo.synth_batch(seed, first, n, L, ad, stride)
+        assert np.array_equal(b.cpu().numpy(), ob) and np.array_equal(q.cpu().numpy(), oq), (seed, first, n, L, ad, stride)
+
+
+def test_configs_vs_oracle_and_reference_md5(engine, cases):
+    """cfg1..cfg5 at oracle-able sizes: arrays vs oracle, formatted text vs the reference's md5."""
+    for c in cases["synthetic"]:
+        if c["n"] > 200000 and c["name"] != "cfg2_1m":
+            continue
+        text = fo.synth_fastq(c["seed"], 0, c["n"], c["L"], c["adapter"])
+        p = fo.parse_fastq(text)
+        o = fo.run_pipeline(p["bases"], p["qual"], p["lens"], oracle_params(c["params"]))
+        e = _run(engine, p["bases"], p["qual"], None, c["params"], fixed_len=c["L"])
+        assert_same(o, e, c["name"])
+        got = fo.format_fastq(text, p["names"], e["out_bases"], e["out_qual"], e["out_len"], e["kept_index"])
+        assert md5(got) == c["output_md5"], c["name"]
+        assert (int(e["counters"][1]), int(e["counters"][2])) == (c["kept"], c["kept_bases"])
+
+
+def test_variable_length_inputs(engine, cases):
+    import os
+    from helpers import GOLDEN
+    for c in cases["varlen"]:
+        if c["name"] == "var_clip_history":
+            continue   # note N3: the reference clipper is history dependent on ragged input; engine contract = fixed length
+        text = open(os.path.join(GOLDEN, "synthetic", c["name"] + ".fq"), "rb").read()
+        exp = open(os.path.join(GOLDEN, "synthetic", c["name"] + ".out"), "rb").read()
+        p = fo.parse_fastq(text)
+        e = _run(engine, p["bases"], p["qual"], p["lens"], c["params"])
+        assert fo.format_fastq(text, p["names"], e["out_bases"], e["out_qual"], e["out_len"], e["kept_index"]) == exp, c["name"]
+
+
+def test_fuzz_vs_oracle(engine):
+    kept = 0
+    for name, b, q, lens, fl, pd in fuzz_cases(11, trials=40, clip_trials=32):
+        o = fo.run_pipeline(b, q, lens, oracle_params(pd), fixed_len=fl)
+        e = _run(engine, b, q, lens, pd, fixed_len=fl)
+        assert_same(o, e, name)
+        kept += int(o["counters"][1])
+    assert kept > 10000
+
+
+def test_decision_only_fasta_and_tool_entry_points(engine):
+    import ctypes as C
+    import torch
+    from fastx_toolkit_amd.engine import FxgBatch, FxgOut
+    b, q = fo.synth_batch(9, 0, 30000, 75)
+    pd = dict(stages=6, qt_threshold=20, qt_min_len=10, qf_min_quality=15, qf_min_percent=70)
+    o = fo.run_pipeline(b, q, None, oracle_params(pd))
+    e = _run(engine, b, q, None, pd, compact=False)
+    assert np.array_equal(o["res"], e["res"]) and np.array_equal(o["counters"][:13], e["counters"][:13])
+    # FASTA (no qualities): clipper and reverse-complement
+    for pd2 in (dict(stages=1, adapter=b"AGATCGGAAGAGC", clip_flags=4), dict(stages=24, ft_first=3, ft_last=60)):
+        o = fo.run_pipeline(b, None, None, oracle_params(pd2))
+        e = _run(engine, b, None, None, pd2)
+        assert_same(o, e, "fasta %s" % pd2)
+    # per-tool C entry points == general entry
+    db, dq = engine.upload(b).view(b.shape), engine.upload(q).view(q.shape)
+    outs = engine.alloc_outputs(b.shape[0], b.shape[1])
+    bt = FxgBatch(db.data_ptr(), dq.data_ptr(), None, 75, 75, b.shape[0])
+    fo_ = FxgOut(*[outs[k].data_ptr() for k in ("res", "out_bases", "out_qual", "out_len", "kept_index", "out_off", "counters")])
+    engine._check(engine.lib.fxg_run_qtrim_qfilter(engine.ctx, C.byref(bt), 33, 1, 20, 10, 1, 15, 70, C.byref(fo_)))
+    from fastx_toolkit_amd.engine import Result
+    r = Result(engine, outs["res"], outs["out_bases"], outs["out_qual"], outs["out_len"], outs["kept_index"], outs["out_off"], outs["counters"]).to_host()
+    assert_same(fo.run_pipeline(b, q, None, oracle_params(pd)), r, "fxg_run_qtrim_qfilter")
+    engine._check(engine.lib.fxg_run_clip(engine.ctx, C.byref(bt), b"AGATCGGAAGAGC", 15, 0, 0, 4, C.byref(fo_)))
+    r = Result(engine, outs["res"], outs["out_bases"], outs["out_qual"], outs["out_len"], outs["kept_index"], outs["out_off"], outs["counters"]).to_host()
+    assert_same(fo.run_pipeline(b, q, None, oracle_params(dict(stages=1, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=4))), r, "fxg_run_clip")
+    engine._check(engine.lib.fxg_run_revcomp_trim(engine.ctx, C.byref(bt), 1, 5, 70, C.byref(fo_)))
+    r = Result(engine, outs["res"], outs["out_bases"], outs["out_qual"], outs["out_len"], outs["kept_index"], outs["out_off"], outs["counters"]).to_host()
+    assert_same(fo.run_pipeline(b, q, None, oracle_params(dict(stages=24, ft_first=5, ft_last=70))), r, "fxg_run_revcomp_trim")
+    torch.cuda.synchronize()
+
+
+def test_invalid_requests_and_bad_base(engine):
+    from fastx_toolkit_amd import FxgError
+    b, q = fo.synth_batch(9, 0, 2000, 40)
+    with pytest.raises(FxgError):
+        _run(engine, b, q, None, dict(stages=2 | 8, qt_threshold=20))        # mixed chains
+    with pytest.raises(FxgError):
+        _run(engine, b, q, None, dict(stages=16 | 32, ft_first=2, ft_trim_end=3))
+    with pytest.raises(FxgError):
+        _run(engine, b, None, None, dict(stages=2, qt_threshold=20))         # quality stage without qualities
+    b2 = b.copy()
+    b2[1234, 7] = ord("X")
+    with pytest.raises(FxgError, match="Invalid nucleotide"):
+        _run(engine, b2, q, None, dict(stages=8))
+    e = _run(engine, b2, q, None, dict(stages=16, ft_first=2))
+    assert int(e["counters"][1]) == 2000
+
+
+def _window_check(engine, seed, N, L, ad, pd, K=40000):
+    """Full-size run on device-generated reads; check a prefix and a suffix window against the oracle, the
+    offset algebra on the device, and run-to-run determinism."""
+    import torch
+    b, q = engine.synth(seed, 0, N, L, ad)
+    r = engine.run(b, q, _engine_params(pd), fixed_len=L)
+    c = r.counters
+    kept, nbytes = int(c[1]), int(c[2])
+    res = r.res.view(torch.int32)
+    keepmask = ((res >> 16) & 1).bool()
+    lens = (res & 0xFFFF).to(torch.int64)
+    assert int(keepmask.sum()) == kept and int(lens[keepmask].sum()) == nbytes and int(c[0]) == N
+    # offsets = exclusive scan of kept lengths, indices strictly increasing and equal to the kept reads
+    ol = r.out_len[:kept].to(torch.int64) & 0xFFFF
+    assert torch.equal(ol, lens[keepmask])
+    off = torch.cumsum(ol, 0) - ol
+    assert torch.equal(off, r.out_off[:kept])
+    assert torch.equal(r.kept_index[:kept].to(torch.int64), torch.nonzero(keepmask).flatten())
+    # prefix window
+    ob, oq = fo.synth_batch(seed, 0, K, L, ad)
+    o = fo.run_pipeline(ob, oq, None, oracle_params(pd))
+    k0, n0 = int(o["counters"][1]), int(o["counters"][2])
+    assert np.array_equal(r.res[:K].cpu().numpy().view(np.uint32), o["res"])
+    assert np.array_equal(r.out_bases[:n0].cpu().numpy(), o["out_bases"]) and np.array_equal(r.out_qual[:n0].cpu().numpy(), o["out_qual"])
+    assert np.array_equal(r.out_len[:k0].cpu().numpy().view(np.uint16), o["out_len"])
+    # suffix window: the last K reads must be the tail of the packed output
+    ob, oq = fo.synth_batch(seed, N - K, K, L, ad)
+    o = fo.run_pipeline(ob, oq, None, oracle_params(pd))
+    k1, n1 = int(o["counters"][1]), int(o["counters"][2])
+    assert np.array_equal(r.res[N - K:].cpu().numpy().view(np.uint32), o["res"])
+    assert np.array_equal(r.out_bases[nbytes - n1:nbytes].cpu().numpy(), o["out_bases"])
+    assert np.array_equal(r.out_qual[nbytes - n1:nbytes].cpu().numpy(), o["out_qual"])
+    assert np.array_equal(r.kept_index[kept - k1:kept].cpu().numpy().view(np.uint32), o["kept_index"] + np.uint32(N - K))
+    # determinism of the whole packed stream
+    r2 = engine.run(b, q, _engine_params(pd), fixed_len=L)
+    assert int(r2.counters[1]) == kept
+    assert torch.equal(r2.out_bases[:nbytes], r.out_bases[:nbytes]) and torch.equal(r2.out_qual[:nbytes], r.out_qual[:nbytes])
+    return kept, nbytes
+
+
+def test_full_size_cfg2_quality_trim_filter(engine):
+    """BASELINE config 2: 50 M x 150 bp, fastq_quality_trimmer -t 20 -l 30 | fastq_quality_filter -q 20 -p 80."""
+    kept, nbytes = _window_check(engine, 2, 50_000_000, 150, False,
+                                 dict(stages=6, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80))
+    assert 0.6 < kept / 50e6 < 0.75
+
+
+def test_full_size_cfg4_revcomp_trim(engine):
+    """BASELINE config 4 (scaled to 100 M reads to bound test time): fastx_reverse_complement | fastx_trimmer -f 5 -l 145."""
+    kept, nbytes = _window_check(engine, 2, 100_000_000, 150, False, dict(stages=24, ft_first=5, ft_last=145), K=20000)
+    assert kept == 100_000_000 and nbytes == 141 * kept
+
+
+def test_full_size_cfg3_clipper(engine):
+    """BASELINE config 3: 50 M x 100 bp, fastx_clipper -a AGATCGGAAGAGC -l 15 -n."""
+    _window_check(engine, 3, 50_000_000, 100, True, dict(stages=1, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=4), K=20000)
+
+
+def test_cfg5_pipeline_shard(engine):
+    """BASELINE config 5, one rank's shard of 1 B / 8 reads: clip -> quality-trim -> filter in one pass."""
+    _window_check(engine, 5, 125_000_000 // 5, 150, True,
+                  dict(stages=7, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=4, qt_threshold=20, qt_min_len=30,
+                       qf_min_quality=20, qf_min_percent=80), K=20000)
