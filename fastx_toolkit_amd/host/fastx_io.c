@@ -1,0 +1,473 @@
+/*
+ * fastx_io.c -- block-buffered FASTA/FASTQ record reader and writer behind the libfastx-compatible API
+ * of fastx.h, shared with the batch path (fxh_batch.c).
+ *
+ * What is reproduced from the reference (src/libfastx/fastx.c) is behaviour, not code: the input rules
+ * R1-R9 of SURVEY.md section 8(a), the error texts with their line numbers, and the output bytes.  What is
+ * different is how: whole-block read(2)/write(2) with memchr line splitting instead of four fgets() and
+ * one fprintf("%c") per quality value.
+ */
+#define _GNU_SOURCE
+#include "fastx.h"
+#include "fxh_internal.h"
+
+#include <err.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/types.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+/* ---------------------------------------------------------------------------------------------- */
+/* reader                                                                                         */
+/* ---------------------------------------------------------------------------------------------- */
+struct fxh_reader *fxh_reader_open(const char *filename, size_t capacity)
+{
+    struct fxh_reader *r = (struct fxh_reader *)calloc(1, sizeof *r);
+    if (!r) err(1, "out of memory");
+    if (strncmp(filename, "-", 1) == 0) r->fd = STDIN_FILENO;      /* reference: any name starting with '-' */
+    else {
+        r->fd = open(filename, O_RDONLY);
+        if (r->fd < 0) err(1, "failed to open input file '%s'", filename);
+    }
+    r->cap = capacity ? capacity : (4u << 20);
+    r->buf = (char *)malloc(r->cap + 1);
+    if (!r->buf) err(1, "out of memory");
+    return r;
+}
+
+/* move the unread tail to the front and read until the buffer is full or the input ends */
+void fxh_reader_fill(struct fxh_reader *r)
+{
+    if (r->beg > 0) {
+        memmove(r->buf, r->buf + r->beg, r->end - r->beg);
+        r->end -= r->beg;
+        r->beg = 0;
+    }
+    while (!r->eof && r->end < r->cap) {
+        ssize_t k = read(r->fd, r->buf + r->end, r->cap - r->end);
+        if (k < 0) { if (errno == EINTR) continue; err(1, "read failed"); }
+        if (k == 0) { r->eof = 1; break; }
+        r->end += (size_t)k;
+    }
+}
+
+int fxh_reader_peek(struct fxh_reader *r)
+{
+    if (r->beg == r->end && !r->eof) fxh_reader_fill(r);
+    return r->beg < r->end ? (unsigned char)r->buf[r->beg] : -1;
+}
+
+/* One fgets() worth of input: *p/*raw = the line including its '\n' (if any).  0 at end of input.
+ * If the line is not complete in the buffer: refill when allowed, otherwise report -1 (batch mode). */
+int fxh_reader_line(struct fxh_reader *r, const char **p, size_t *raw, int may_refill)
+{
+    for (;;) {
+        const char *s = r->buf + r->beg;
+        const char *nl = (const char *)memchr(s, '\n', r->end - r->beg);
+        if (nl) { *p = s; *raw = (size_t)(nl - s) + 1; r->beg += *raw; return 1; }
+        if (r->eof) {
+            if (r->beg == r->end) return 0;
+            *p = s; *raw = r->end - r->beg; r->beg = r->end; return 1;
+        }
+        if (!may_refill) return -1;
+        if (r->beg == 0 && r->end == r->cap) errx(1, "input line longer than %zu bytes", r->cap);
+        fxh_reader_fill(r);
+    }
+}
+
+size_t fxh_chomp_len(const char *s, size_t n)   /* chomp.c:36-41: cut at the first CR or LF */
+{
+    size_t k = 0;
+    while (k < n && s[k] != '\r' && s[k] != '\n') k++;
+    return k;
+}
+
+void chomp(char *string)
+{
+    string[fxh_chomp_len(string, strlen(string))] = 0;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* record parser shared by the per-record API and the batch packer                                */
+/* ---------------------------------------------------------------------------------------------- */
+static void fxh_fail(FASTX *fx, struct fxh_rawrec *rec, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    if (rec && rec->defer_errors) {
+        vsnprintf(rec->errmsg, sizeof rec->errmsg, fmt, ap);
+        rec->failed = 1;
+        va_end(ap);
+        return;
+    }
+    (void)fx;
+    verrx(1, fmt, ap);
+}
+
+/* Returns 1 = record parsed, 0 = end of input at a record boundary, -1 = record not complete in the buffer
+ * (only when may_refill == 0; nothing consumed), -2 = deferred error (rec->errmsg set). */
+int fxh_next_raw(FASTX *fx, struct fxh_rawrec *rec, int may_refill)
+{
+    struct fxh_reader *r = fx->reader;
+    const char *p;
+    size_t raw;
+    int rc;
+    rec->failed = 0;
+    if (may_refill) {   /* the buffer moves on refill: make the whole record resident before taking pointers into it */
+        const size_t want = fx->read_fastq ? 4 : 2;
+        for (;;) {
+            size_t nl = 0, i = r->beg;
+            while (nl < want && i < r->end) {
+                const char *q = (const char *)memchr(r->buf + i, '\n', r->end - i);
+                if (!q) break;
+                nl++;
+                i = (size_t)(q - r->buf) + 1;
+            }
+            if (nl >= want || r->eof) break;
+            if (r->beg == 0 && r->end == r->cap) errx(1, "input record longer than %zu bytes", r->cap);
+            fxh_reader_fill(r);
+        }
+    }
+    const size_t save_beg = r->beg;
+    const unsigned long long save_line = fx->input_line_number;
+
+    fx->input_line_number++;
+    rc = fxh_reader_line(r, &p, &raw, 0);
+    if (rc == 0) return 0;
+    if (rc < 0) goto incomplete;
+    rec->prefix = p[0];
+    rec->name = p + 1;
+    rec->name_len = fxh_chomp_len(p + 1, raw - 1);
+    if (fx->read_fastq && rec->prefix != '@') {
+        fxh_fail(fx, rec, "Invalid input: expecting FASTQ prefix character '@' on line %lld. Is this a valid FASTQ file?\n", fx->input_line_number);
+        return -2;
+    }
+    if (!fx->read_fastq && rec->prefix != '>') {
+        size_t k = fxh_chomp_len(p, raw), i = 0;
+        while (i < k && fx->allowed_nucleotides[(unsigned char)p[i]]) i++;
+        if (i == k)
+            fxh_fail(fx, rec, "Invalid input: This looks like a multi-line FASTA file.\nLine %lld contains a nucleotides string instead of a '>' prefix.\n"
+                              "FASTX-Toolkit can't handle multi-line FASTA files.\nPlease use the FASTA-Formatter tool to convert this file into a single-line FASTA.\n",
+                     fx->input_line_number);
+        else
+            fxh_fail(fx, rec, "Invalid input: expecting FASTA prefix character '>' on line %lld. Is this a valid FASTA file?\n", fx->input_line_number);
+        return -2;
+    }
+
+    fx->input_line_number++;
+    rc = fxh_reader_line(r, &p, &raw, 0);
+    if (rc < 0) goto incomplete;
+    if (rc == 0) { fxh_fail(fx, rec, "Failed to read complete record, missing 2nd line (nucleotides), on line %lld\n", fx->input_line_number); return -2; }
+    rec->seq = p;
+    rec->seq_len = fxh_chomp_len(p, raw);
+    if (rec->seq_len == 0) { fxh_fail(fx, rec, "found empty nucleotide sequence on line %lld\n", fx->input_line_number); return -2; }
+    if (rec->seq_len >= MAX_SEQ_LINE_LENGTH - 1) { fxh_fail(fx, rec, "sequence longer than %d on line %lld\n", MAX_SEQ_LINE_LENGTH - 2, fx->input_line_number); return -2; }
+    {
+        size_t i = 0;
+        unsigned ok = 1;
+        for (; i < rec->seq_len; ++i) ok &= fx->allowed_nucleotides[(unsigned char)p[i]];
+        if (!ok) { fxh_fail(fx, rec, "found invalid nucleotide sequence (%.*s) on line %lld\n", (int)rec->seq_len, p, fx->input_line_number); return -2; }
+    }
+    rec->name2 = NULL; rec->name2_len = 0; rec->qual = NULL; rec->qual_len = 0; rec->is_ascii = 1;
+    if (fx->read_fastq) {
+        fx->input_line_number++;
+        rc = fxh_reader_line(r, &p, &raw, 0);
+        if (rc < 0) goto incomplete;
+        if (rc == 0) { fxh_fail(fx, rec, "Failed to read complete record, missing 3rd line (name-2), on line %lld\n", fx->input_line_number); return -2; }
+        rec->name2 = p + 1;                                  /* first byte dropped whatever it is (R5) */
+        rec->name2_len = raw > 0 ? fxh_chomp_len(p + 1, raw - 1) : 0;
+        fx->input_line_number++;
+        rc = fxh_reader_line(r, &p, &raw, 0);
+        if (rc < 0) goto incomplete;
+        if (rc == 0) { fxh_fail(fx, rec, "Failed to read complete record, missing 4th line (quality), on line %lld\n", fx->input_line_number); return -2; }
+        rec->qual = p;
+        rec->qual_len = fxh_chomp_len(p, raw);
+        rec->is_ascii = (rec->qual_len == rec->seq_len);     /* R6 */
+    }
+    return 1;
+
+incomplete:
+    r->beg = save_beg;
+    fx->input_line_number = save_line;
+    return -1;
+}
+
+/* quality line -> numeric scores; returns 0 or sets a (possibly deferred) error and returns -1 */
+int fxh_decode_quality(FASTX *fx, struct fxh_rawrec *rec, int *out_i32, unsigned char *out_phred33)
+{
+    const int Q = fx->fastq_ascii_quality_offset;
+    if (rec->is_ascii) {
+        for (size_t i = 0; i < rec->qual_len; ++i) {
+            const int q = (int)(signed char)rec->qual[i] - Q;          /* fastx.c:127 */
+            if (q < MIN_QUALITY_VALUE || q > MAX_QUALITY_VALUE) {
+                fxh_fail(fx, rec, "Invalid quality score value (char '%c' ord %d quality value %d) on line %lld",
+                         rec->qual[i], rec->qual[i], q, fx->input_line_number);
+                return -1;
+            }
+            if (out_i32) out_i32[i] = q;
+            if (out_phred33) out_phred33[i] = (unsigned char)(q + 33);
+        }
+        return 0;
+    }
+    /* numeric scores separated by blanks (fastx.c:137-167) */
+    {
+        char tmp[64];
+        size_t idx = 0, pos = 0;
+        const char *s = rec->qual;
+        const size_t n = rec->qual_len;
+        do {
+            size_t k = 0, j = pos;
+            while (j < n && (s[j] == ' ' || s[j] == '\t')) j++;
+            while (j < n && k < sizeof tmp - 1 && (s[j] == '-' || s[j] == '+' || (s[j] >= '0' && s[j] <= '9'))) tmp[k++] = s[j++];
+            tmp[k] = 0;
+            char *end;
+            long v = strtol(tmp, &end, 10);
+            if (end == tmp) {
+                fxh_fail(fx, rec, "Error: invalid quality score data on line %lld (quality_tok = \"%.*s\"", fx->input_line_number, (int)(n - pos), s + pos);
+                return -1;
+            }
+            if (v > 93 || v < -15) { fxh_fail(fx, rec, "invalid quality score value (%d) in line %lld.", (int)v, fx->input_line_number); return -1; }
+            if (idx < rec->seq_len) {
+                if (out_i32) out_i32[idx] = (int)v;
+                if (out_phred33) out_phred33[idx] = (unsigned char)(v + 33);
+            }
+            idx++;
+            pos = j;
+        } while (pos < n);
+        if (idx != rec->seq_len) {
+            fxh_fail(fx, rec, "number of quality values (%zu) doesn't match number of nucleotides (%zu) on line %lld", idx, rec->seq_len, fx->input_line_number);
+            return -1;
+        }
+    }
+    return 0;
+}
+
+int fxh_reads_count(const FASTX *fx, const char *name, size_t name_len)   /* fastx.c:475-495 */
+{
+    if (fx->read_fastq) return 1;
+    const char *dash = (const char *)memchr(name, '-', name_len);
+    if (!dash) return 1;
+    char tmp[24];
+    size_t k = (size_t)(name + name_len - (dash + 1));
+    if (k > sizeof tmp - 1) k = sizeof tmp - 1;
+    memcpy(tmp, dash + 1, k);
+    tmp[k] = 0;
+    int c = atoi(tmp);
+    return c > 0 ? c : 1;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* writer                                                                                         */
+/* ---------------------------------------------------------------------------------------------- */
+static struct fxh_writer *g_writers[8];
+
+static void fxh_flush_all(void)
+{
+    for (size_t i = 0; i < sizeof g_writers / sizeof g_writers[0]; ++i)
+        if (g_writers[i]) fxh_writer_close(g_writers[i]);
+}
+
+void fxh_writer_flush(struct fxh_writer *w)
+{
+    size_t off = 0;
+    while (off < w->len) {
+        ssize_t k = write(w->fd, w->buf + off, w->len - off);
+        if (k < 0) { if (errno == EINTR) continue; err(1, "writing output failed"); }
+        off += (size_t)k;
+    }
+    w->len = 0;
+}
+
+char *fxh_writer_reserve(struct fxh_writer *w, size_t n)
+{
+    if (w->len + n > w->cap) {
+        fxh_writer_flush(w);
+        if (n > w->cap) {
+            w->buf = (char *)realloc(w->buf, n);
+            if (!w->buf) err(1, "out of memory");
+            w->cap = n;
+        }
+    }
+    return w->buf + w->len;
+}
+
+void fxh_writer_close(struct fxh_writer *w)
+{
+    if (!w || w->fd < 0) return;
+    fxh_writer_flush(w);
+    if (w->fd != STDOUT_FILENO || w->child > 0) close(w->fd);
+    w->fd = -1;
+    if (w->child > 0) { int st; (void)waitpid(w->child, &st, 0); w->child = 0; }   /* the reference never waits (N4) */
+}
+
+static int fxh_open_output(const char *filename)
+{
+    if (strcmp(filename, "-") == 0) return STDOUT_FILENO;
+    int fd = open(filename, O_CREAT | O_WRONLY | O_TRUNC, 0666);
+    if (fd == -1) err(1, "Failed to create output file (%s)", filename);
+    return fd;
+}
+
+static struct fxh_writer *fxh_writer_open(const char *filename, int gzip)
+{
+    struct fxh_writer *w = (struct fxh_writer *)calloc(1, sizeof *w);
+    if (!w) err(1, "out of memory");
+    w->cap = 8u << 20;
+    w->buf = (char *)malloc(w->cap);
+    if (!w->buf) err(1, "out of memory");
+    if (!gzip) w->fd = fxh_open_output(filename);
+    else {                                       /* pipe through a gzip child whose stdout is the output file */
+        int pp[2];
+        if (pipe(pp) != 0) err(1, "pipe (for gzip) failed");
+        pid_t pid = fork();
+        if (pid < 0) err(1, "fork (for gzip) failed");
+        if (pid == 0) {
+            dup2(pp[0], STDIN_FILENO);
+            close(pp[1]);
+            int fd = fxh_open_output(filename);
+            dup2(fd, STDOUT_FILENO);
+            execlp("gzip", "gzip", (char *)NULL);
+            err(1, "execlp(gzip) failed");
+        }
+        close(pp[0]);
+        w->fd = pp[1];
+        w->child = pid;
+    }
+    static int registered;
+    if (!registered) { atexit(fxh_flush_all); registered = 1; }
+    for (size_t i = 0; i < sizeof g_writers / sizeof g_writers[0]; ++i)
+        if (!g_writers[i]) { g_writers[i] = w; break; }
+    return w;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* libfastx-compatible API                                                                        */
+/* ---------------------------------------------------------------------------------------------- */
+void fastx_init_reader(FASTX *fx, const char *filename, ALLOWED_INPUT_FILE_TYPES allowed_input_filetype,
+                       ALLOWED_INPUT_BASES allow_bases, ALLOWED_INPUT_CASE allow_lowercase, int fastq_ascii_quality_offset)
+{
+    if (fx == NULL) errx(1, "Internal error: pFASTX==NULL (%s:%d)", __FILE__, __LINE__);
+    memset(fx, 0, sizeof *fx);
+    const char *cap_env = getenv("FXH_READ_BUFFER_MB");
+    fx->reader = fxh_reader_open(filename, cap_env && atoi(cap_env) > 0 ? (size_t)atoi(cap_env) << 20 : 0);
+    strncpy(fx->input_file_name, filename, sizeof fx->input_file_name - 1);
+    fx->allow_input_filetype = allowed_input_filetype;
+    fx->allow_lowercase = allow_lowercase;
+    fx->allow_N = (allow_bases & ALLOW_N) != 0;
+    fx->allow_U = (allow_bases & ALLOW_U) != 0;
+    fx->fastq_ascii_quality_offset = fastq_ascii_quality_offset;
+    {   /* alphabet table (fastx.c:56-84) */
+        const char *up = "ACGT", *p;
+        for (p = up; *p; ++p) { fx->allowed_nucleotides[(unsigned char)*p] = 1; if (allow_lowercase) fx->allowed_nucleotides[(unsigned char)(*p | 0x20)] = 1; }
+        if (fx->allow_N) { fx->allowed_nucleotides['N'] = 1; if (allow_lowercase) fx->allowed_nucleotides['n'] = 1; }
+        if (fx->allow_U) { fx->allowed_nucleotides['U'] = 1; if (allow_lowercase) fx->allowed_nucleotides['u'] = 1; }
+    }
+    const int c = fxh_reader_peek(fx->reader);    /* format sniff on the first byte (R1) */
+    if (c == '>') {
+        if (allowed_input_filetype == FASTQ_ONLY) errx(1, "input file (%s) is FASTA, but only FASTQ input is allowed.", fx->input_file_name);
+        fx->read_fastq = 0;
+    } else if (c == '@') {
+        if (allowed_input_filetype == FASTA_ONLY) errx(1, "input file (%s) is FASTQ, but only FASTA input is allowed.", fx->input_file_name);
+        fx->read_fastq = 1;
+    } else if (c == -1) {
+        errx(1, "Premature End-Of-File (filename ='%s')", fx->input_file_name);
+    } else {
+        errx(1, "input file (%s) has unknown file format (not FASTA or FASTQ), first character = %c (%d)", fx->input_file_name, c, c);
+    }
+}
+
+void fastx_init_writer(FASTX *fx, const char *filename, OUTPUT_FILE_TYPE output_type, int compress_output)
+{
+    if (fx == NULL) errx(1, "Internal error: pFASTX==NULL (%s:%d)", __FILE__, __LINE__);
+    if (fx->reader == NULL) errx(1, "Internal error: pFASTX not initialized (%s:%d)", __FILE__, __LINE__);
+    fx->compress_output = compress_output;
+    strncpy(fx->output_file_name, filename, sizeof fx->output_file_name - 1);
+    fx->writer = fxh_writer_open(filename, compress_output);
+    switch (output_type) {
+    case OUTPUT_FASTA:
+        fx->write_fastq = 0; fx->output_sequence_id_prefix = '>';
+        break;
+    case OUTPUT_FASTQ_ASCII_QUAL:
+    case OUTPUT_FASTQ_NUMERIC_QUAL:
+        if (!fx->read_fastq) errx(1, "Can't output FASTQ when input is FASTA.");
+        fx->write_fastq = 1; fx->write_fastq_ascii = (output_type == OUTPUT_FASTQ_ASCII_QUAL); fx->output_sequence_id_prefix = '@';
+        break;
+    case OUTPUT_SAME_AS_INPUT:
+        fx->write_fastq = fx->read_fastq; fx->write_fastq_ascii = 1; fx->copy_input_fastq_format_to_output = 1;
+        fx->output_sequence_id_prefix = fx->write_fastq ? '@' : '>';
+        break;
+    default:
+        errx(1, __FILE__ ":%d: Unknown output_type (%d)", __LINE__, output_type);
+    }
+}
+
+int fastx_read_next_record(FASTX *fx)
+{
+    struct fxh_rawrec rec;
+    if (fx == NULL) errx(1, "Internal error: pFASTX==NULL (%s:%d)", __FILE__, __LINE__);
+    memset(&rec, 0, sizeof rec);
+    if (fxh_next_raw(fx, &rec, 1) == 0) return 0;
+    memcpy(fx->name, rec.name, rec.name_len); fx->name[rec.name_len] = 0;
+    memcpy(fx->nucleotides, rec.seq, rec.seq_len); fx->nucleotides[rec.seq_len] = 0;
+    if (fx->read_fastq) {
+        memcpy(fx->name2, rec.name2, rec.name2_len); fx->name2[rec.name2_len] = 0;
+        fxh_decode_quality(fx, &rec, fx->quality, NULL);
+        fx->read_fastq_ascii = rec.is_ascii;
+        if (fx->copy_input_fastq_format_to_output) fx->write_fastq_ascii = fx->read_fastq_ascii;
+    }
+    fx->num_input_sequences++;
+    fx->num_input_reads += (size_t)get_reads_count(fx);
+    return 1;
+}
+
+size_t fxh_format_numeric(char *dst, const int *q, const unsigned char *phred33, size_t n)
+{
+    size_t w = 0;
+    for (size_t i = 0; i < n; ++i) {
+        int v = q ? q[i] : (int)phred33[i] - 33;
+        if (i) dst[w++] = ' ';
+        if (v < 0) { dst[w++] = '-'; v = -v; }
+        if (v >= 10) dst[w++] = (char)('0' + v / 10);
+        dst[w++] = (char)('0' + v % 10);
+    }
+    return w;
+}
+
+void fastx_write_record(FASTX *fx)
+{
+    if (fx == NULL) errx(1, "Internal error: pFASTX==NULL (%s:%d)", __FILE__, __LINE__);
+    struct fxh_writer *w = fx->writer;
+    const size_t nl = strlen(fx->name), sl = strlen(fx->nucleotides), n2 = strlen(fx->name2);
+    char *d = fxh_writer_reserve(w, nl + sl + n2 + 5 * sl + 16);
+    size_t k = 0;
+    d[k++] = fx->output_sequence_id_prefix;
+    memcpy(d + k, fx->name, nl); k += nl; d[k++] = '\n';
+    memcpy(d + k, fx->nucleotides, sl); k += sl; d[k++] = '\n';
+    if (fx->write_fastq) {
+        d[k++] = '+';
+        memcpy(d + k, fx->name2, n2); k += n2; d[k++] = '\n';
+        if (fx->write_fastq_ascii)
+            for (size_t i = 0; i < sl; ++i) d[k++] = (char)(fx->quality[i] + fx->fastq_ascii_quality_offset);   /* fastx.c:412 */
+        else
+            k += fxh_format_numeric(d + k, fx->quality, NULL, sl);
+        d[k++] = '\n';
+    }
+    w->len += k;
+    fx->num_output_sequences++;
+    fx->num_output_reads += (size_t)get_reads_count(fx);
+}
+
+int get_reads_count(const FASTX *fx) { return fxh_reads_count(fx, fx->name, strlen(fx->name)); }
+size_t num_input_sequences(const FASTX *fx) { return fx->num_input_sequences; }
+size_t num_input_reads(const FASTX *fx) { return fx->num_input_reads; }
+size_t num_output_sequences(const FASTX *fx) { return fx->num_output_sequences; }
+size_t num_output_reads(const FASTX *fx) { return fx->num_output_reads; }
+
+void fastx_finish(FASTX *fx)
+{
+    if (fx && fx->writer) fxh_writer_close(fx->writer);
+}

@@ -1,0 +1,46 @@
+/* fxh_internal.h -- shared between fastx_io.c (record API) and fxh_batch.c (batch path). Not installed. */
+#ifndef FXH_INTERNAL_H
+#define FXH_INTERNAL_H
+#include <stddef.h>
+#include <sys/types.h>
+
+#include "fastx.h"
+
+struct fxh_reader {
+    int fd;
+    char *buf;
+    size_t cap, beg, end;   /* unread bytes are buf[beg, end) */
+    int eof;
+};
+
+struct fxh_writer {
+    int fd;
+    char *buf;
+    size_t cap, len;
+    pid_t child;            /* gzip child, if any */
+};
+
+/* one record as slices of the reader's buffer (valid until the next fill) */
+struct fxh_rawrec {
+    char prefix;
+    const char *name, *seq, *name2, *qual;
+    size_t name_len, seq_len, name2_len, qual_len;
+    int is_ascii;           /* R6: quality line has as many characters as the sequence */
+    int defer_errors;       /* batch mode: record the message instead of exiting, so earlier records are flushed first */
+    int failed;
+    char errmsg[768];
+};
+
+struct fxh_reader *fxh_reader_open(const char *filename, size_t capacity);
+void   fxh_reader_fill(struct fxh_reader *r);
+int    fxh_reader_peek(struct fxh_reader *r);
+int    fxh_reader_line(struct fxh_reader *r, const char **p, size_t *raw, int may_refill);
+size_t fxh_chomp_len(const char *s, size_t n);
+int    fxh_next_raw(FASTX *fx, struct fxh_rawrec *rec, int may_refill);
+int    fxh_decode_quality(FASTX *fx, struct fxh_rawrec *rec, int *out_i32, unsigned char *out_phred33);
+int    fxh_reads_count(const FASTX *fx, const char *name, size_t name_len);
+size_t fxh_format_numeric(char *dst, const int *q, const unsigned char *phred33, size_t n);
+void   fxh_writer_flush(struct fxh_writer *w);
+char  *fxh_writer_reserve(struct fxh_writer *w, size_t n);
+void   fxh_writer_close(struct fxh_writer *w);
+#endif
