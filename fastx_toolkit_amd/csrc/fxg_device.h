@@ -42,9 +42,11 @@ struct FxgKArgs {
     // engine state
     u64 *status_cnt;        // [ntiles] decoupled look-back granules (kept reads)
     u64 *status_bytes;      // [ntiles] decoupled look-back granules (kept bytes)
-    u64 *partial;           // [grid][FXG_NCOUNTERS]
+    u64 *partial;           // [count grid][FXG_NCOUNTERS]
+    u32 *ticket;            // dynamic tile dispenser (zeroed before every launch)
     u32 *errflag;
     u32  compact;           // 1 = stream-compact kept reads into out_bases/out_qual
+    u32  debug;             // FXG_DEBUG ablation bits (timing experiments only; results are wrong when set)
     // folded tool parameters
     u32  stages;
     u32  tq;                // quality trimmer: byte >= tq  <=>  q >= -t      (0..128)
@@ -217,11 +219,26 @@ __device__ __forceinline__ u64 fxg_half_sum(u64 v)
     return v;
 }
 
-// Executed by wave 0 only.  Lanes 0..31 resolve the kept-read prefix, lanes 32..63 the kept-byte
-// prefix, both walking back over predecessor tiles 32 at a time.  Returns the exclusive prefix of this
-// tile in (*base_cnt, *base_bytes) for every lane.
-__device__ __forceinline__ void fxg_lookback(const FxgKArgs &a, u32 tile, u64 agg_cnt, u64 agg_bytes,
-                                             u64 *base_cnt, u64 *base_bytes)
+// Both helpers are executed by wave 0 only.  Lanes 0..31 handle the kept-read count, lanes 32..63 the
+// kept-byte count.
+//
+// fxg_publish_aggregate: as soon as a tile knows its own totals it publishes them (tile 0 publishes its
+// inclusive prefix right away).  It never waits, so every running workgroup always makes progress.
+__device__ __forceinline__ void fxg_publish_aggregate(const FxgKArgs &a, u32 tile, u64 agg_cnt, u64 agg_bytes)
+{
+    const u32 lane = fxg_lane();
+    if ((lane & 31u) == 0u) {
+        u64 *st = (lane >> 5) ? a.status_bytes : a.status_cnt;
+        fxg_granule_store(st + tile, tile == 0 ? FXG_ST_PREFIX : FXG_ST_AGG, (lane >> 5) ? agg_bytes : agg_cnt);
+    }
+}
+
+// fxg_resolve_prefix: walk back over predecessor tiles, 32 per step, summing aggregates until a tile with
+// a full prefix is met; then publish this tile's inclusive prefix.  Tiles are handed out by a global
+// ticket, so every predecessor is owned by a workgroup that is already running: the wait terminates
+// whatever the residency or placement.  Returns the exclusive prefix in every lane.
+__device__ __forceinline__ void fxg_resolve_prefix(const FxgKArgs &a, u32 tile, u64 agg_cnt, u64 agg_bytes,
+                                                   u64 *base_cnt, u64 *base_bytes)
 {
     const u32 lane = fxg_lane();
     const u32 half = lane >> 5, hl = lane & 31u;
@@ -229,7 +246,6 @@ __device__ __forceinline__ void fxg_lookback(const FxgKArgs &a, u32 tile, u64 ag
     const u64 agg = half ? agg_bytes : agg_cnt;
     u64 running = 0;
     if (tile != 0) {
-        if (hl == 0) fxg_granule_store(st + tile, FXG_ST_AGG, agg);
         long long pos = (long long)tile - 1 - (long long)hl;
         bool done = false;
         const u64 t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
@@ -252,7 +268,7 @@ __device__ __forceinline__ void fxg_lookback(const FxgKArgs &a, u32 tile, u64 ag
                 if (fp < 32u) done = true; else pos -= 32;
             }
             if (__ballot(!done) == 0ull) break;
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
             if ((++spins & 255u) == 0u) {   // never hang the GPU: 2 s without progress, or another workgroup already gave up
                 const bool late = __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull;
                 const u32 flagged = __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & FXG_DEV_ERR_SCAN_TIMEOUT;
@@ -262,8 +278,8 @@ __device__ __forceinline__ void fxg_lookback(const FxgKArgs &a, u32 tile, u64 ag
                 }
             }
         }
+        if (hl == 0) fxg_granule_store(st + tile, FXG_ST_PREFIX, running + agg);
     }
-    if (hl == 0) fxg_granule_store(st + tile, FXG_ST_PREFIX, running + agg);
     *base_cnt = ((u64)__shfl((u32)(running >> 32), 0, 64) << 32) | __shfl((u32)running, 0, 64);
     *base_bytes = ((u64)__shfl((u32)(running >> 32), 32, 64) << 32) | __shfl((u32)running, 32, 64);
 }
@@ -305,7 +321,7 @@ FXG_HD u32 fxg_tile_gather(const FxgKArgs &a, const u32 *v_off, const u32 *v_src
                            u64 tile_in_base, u64 B, u32 S, u32 tid, u32 nthreads)
 {
     if (S == 0) return 0u;
-    const bool has_q = a.qual != nullptr && a.out_qual != nullptr;
+    const bool has_q = a.qual != nullptr && a.out_qual != nullptr && !(a.debug & 4u);
     const u64 c_first = B >> 4, c_last = (B + S - 1) >> 4;
     u32 bad = 0;
     for (u64 c = c_first + tid; c <= c_last; c += nthreads) {
@@ -368,13 +384,4 @@ FXG_HD u32 fxg_tile_gather(const FxgKArgs &a, const u32 *v_off, const u32 *v_src
         }
     }
     return bad;   // nonzero: a byte outside ACGTN/acgtn reached the complement (REV only)
-}
-
-// persistent-grid tile order: workgroup b runs on XCD b % 8 (observed, speed only); give each XCD a
-// contiguous run of tiles inside every sweep so neighbouring tiles (which share an output cache line
-// and hand prefixes to each other) stay on one L2.
-__device__ __forceinline__ u32 fxg_first_tile()
-{
-    const u32 g = gridDim.x, b = blockIdx.x;
-    return (g % 8u == 0u) ? (b % 8u) * (g / 8u) + b / 8u : b;
 }

@@ -20,7 +20,7 @@ struct fxg_ctx {
     size_t status_cap;      // in tiles
     u64 *partial;           // partial_cap rows of FXG_NCOUNTERS
     size_t partial_cap;
-    u32 *errflag;
+    u32 *errflag;           // [0] device error bits, [1] tile ticket
     u64 *counters_scratch;  // used when the caller passes no counter block
     char err[512];
     char last_kernel[96];
@@ -63,7 +63,7 @@ extern "C" int fxg_ctx_create(int device_id, fxg_ctx **out)
     c->stream = c->own_stream;
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreate(&c->kev0) != hipSuccess || hipEventCreate(&c->kev1) != hipSuccess ||
-        hipMalloc((void **)&c->errflag, sizeof(u32)) != hipSuccess ||
+        hipMalloc((void **)&c->errflag, 2 * sizeof(u32)) != hipSuccess ||
         hipMalloc((void **)&c->counters_scratch, FXG_NCOUNTERS * sizeof(u64)) != hipSuccess) {
         free(c);
         return FXG_E_HIP;
@@ -161,6 +161,8 @@ extern "C" int fxg_timer_stop(fxg_ctx *c, float *ms)
 }
 
 // ------------------------------------------------------------------------------------------------
+#define FXG_COUNT_GRID 1024u
+
 template <typename K>
 static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &ka, u32 lds, u64 *counters)
 {
@@ -169,15 +171,12 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
     int per_cu = 0;
     FXG_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, FXG_BLOCK, lds));
     if (per_cu < 1) return fxg_fail(c, FXG_E_INVALID, "%s does not fit on a CU (lds=%u)", kname, lds);
-    // every workgroup must be resident (look-back waits on predecessors): stay one below the API's
-    // answer, which can over-report by one for SGPR-heavy 256-thread kernels, and never above 8.
-    int use = per_cu > 1 ? per_cu - 1 : 1;
-    if (use > 8) use = 8;
+    // Tiles are dispensed by ticket, so nothing depends on every workgroup being resident: fill the chip.
+    int use = per_cu > 8 ? 8 : per_cu;
     const char *env = getenv("FXG_BLOCKS_PER_CU");
-    if (env && atoi(env) > 0 && atoi(env) <= per_cu) use = atoi(env);
+    if (env && atoi(env) > 0 && atoi(env) <= 16) use = atoi(env);
     u64 grid = (u64)c->cus * (u64)use;
     if (grid > ka.ntiles) grid = ka.ntiles;
-    if (grid >= 8) grid &= ~7ull;
     if (grid < 1) grid = 1;
 
     if (ka.compact) {
@@ -193,21 +192,29 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
         FXG_HIP(c, hipMemsetAsync(ka.status_cnt, 0, (size_t)ka.ntiles * sizeof(u64), c->stream));
         FXG_HIP(c, hipMemsetAsync(ka.status_bytes, 0, (size_t)ka.ntiles * sizeof(u64), c->stream));
     }
-    if (c->partial_cap < grid) {
+    if (c->partial_cap < FXG_COUNT_GRID) {
         (void)hipFree(c->partial);
         c->partial = nullptr; c->partial_cap = 0;
-        FXG_HIP(c, hipMalloc((void **)&c->partial, (size_t)grid * FXG_NCOUNTERS * sizeof(u64)));
-        c->partial_cap = grid;
+        FXG_HIP(c, hipMalloc((void **)&c->partial, (size_t)FXG_COUNT_GRID * FXG_NCOUNTERS * sizeof(u64)));
+        c->partial_cap = FXG_COUNT_GRID;
     }
     ka.partial = c->partial;
+    { const char *dbg = getenv("FXG_DEBUG"); ka.debug = dbg ? (u32)atoi(dbg) : 0u; }
     ka.errflag = c->errflag;
-    FXG_HIP(c, hipMemsetAsync(c->errflag, 0, sizeof(u32), c->stream));
+    ka.ticket = c->errflag + 1;
+    FXG_HIP(c, hipMemsetAsync(c->errflag, 0, 2 * sizeof(u32), c->stream));
 
     if (c->profiling) FXG_HIP(c, hipEventRecord(c->kev0, c->stream));
     hipLaunchKernelGGL(kernel, dim3((u32)grid), dim3(FXG_BLOCK), lds, c->stream, ka);
     FXG_HIP(c, hipGetLastError());
     if (c->profiling) { FXG_HIP(c, hipEventRecord(c->kev1, c->stream)); c->kev_valid = 1; }
-    hipLaunchKernelGGL(fxg_kernel_reduce_counters, dim3(1), dim3(256), 0, c->stream, (const u64 *)c->partial, (u32)grid,
+    // -v report counters: one pass over res[] (4 B/read), then fold the partial rows
+    u64 cgrid = (ka.n + FXG_BLOCK * 8 - 1) / (FXG_BLOCK * 8);
+    if (cgrid > FXG_COUNT_GRID) cgrid = FXG_COUNT_GRID;
+    if (cgrid < 1) cgrid = 1;
+    hipLaunchKernelGGL(fxg_kernel_count_res, dim3((u32)cgrid), dim3(FXG_BLOCK), 0, c->stream, (const u32 *)ka.res, ka.n, ka.stages, c->partial);
+    FXG_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(fxg_kernel_reduce_counters, dim3(1), dim3(256), 0, c->stream, (const u64 *)c->partial, (u32)cgrid,
                        (const u32 *)c->errflag, counters ? counters : c->counters_scratch);
     FXG_HIP(c, hipGetLastError());
     snprintf(c->last_kernel, sizeof c->last_kernel, "%s", kname);
@@ -226,19 +233,19 @@ extern "C" int fxg_run_pipeline(fxg_ctx *c, const fxg_batch *in, const fxg_param
         return FXG_OK;
     }
     u64 *ctr = (u64 *)out->counters;
-#define FXG_GO(K) return fxg_launch_tiles(c, K, #K, pl.ka, pl.lds, ctr)
+#define FXG_TILES_A(N) (fxg_kernel_tiles<N, 0>)
     if (pl.group_a) {
         switch (pl.amax) {
-        case 0: FXG_GO(fxg_kernel_clip_qtrim_qfilter<0>);
-        case 16: FXG_GO(fxg_kernel_clip_qtrim_qfilter<16>);
-        case 32: FXG_GO(fxg_kernel_clip_qtrim_qfilter<32>);
-        case 64: FXG_GO(fxg_kernel_clip_qtrim_qfilter<64>);
-        default: FXG_GO(fxg_kernel_clip_qtrim_qfilter<100>);
+        case 0: return fxg_launch_tiles(c, FXG_TILES_A(0), "fxg_kernel_tiles<0,0> qtrim+qfilter", pl.ka, pl.lds, ctr);
+        case 16: return fxg_launch_tiles(c, FXG_TILES_A(16), "fxg_kernel_tiles<16,0> clip[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
+        case 32: return fxg_launch_tiles(c, FXG_TILES_A(32), "fxg_kernel_tiles<32,0> clip[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
+        case 64: return fxg_launch_tiles(c, FXG_TILES_A(64), "fxg_kernel_tiles<64,0> clip[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
+        default: return fxg_launch_tiles(c, FXG_TILES_A(100), "fxg_kernel_tiles<100,0> clip[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
         }
     }
-    if (pl.rev) FXG_GO(fxg_kernel_revcomp_ftrim<true>);
-    FXG_GO(fxg_kernel_revcomp_ftrim<false>);
-#undef FXG_GO
+    if (pl.rev) return fxg_launch_tiles(c, fxg_kernel_tiles<0, 2>, "fxg_kernel_tiles<0,2> revcomp[+ftrim]", pl.ka, pl.lds, ctr);
+    return fxg_launch_tiles(c, fxg_kernel_tiles<0, 1>, "fxg_kernel_tiles<0,1> ftrim", pl.ka, pl.lds, ctr);
+#undef FXG_TILES_A
 }
 
 static void fxg_params_default(fxg_params *p)

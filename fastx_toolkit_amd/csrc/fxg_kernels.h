@@ -1,32 +1,38 @@
-// fxg_kernels.h -- the persistent tile kernels of the engine.
+// fxg_kernels.h -- the tile kernels of the engine.
 //
-// One workgroup (256 threads = 4 wave64) owns a tile of up to 256 consecutive reads and walks
-// tiles tile0, tile0+grid, ... (persistent grid, every workgroup co-resident).  Per tile:
-//   1. stream the quality rows once, 16 B per lane, and reduce them to two LDS bitmaps
-//      (bit = "byte >= trim threshold", bit = "byte < filter threshold")           [HBM read: L bytes/read]
-//   2. one thread per read: (clip DP over LDS-staged bases,) trim point = highest set bit,
-//      filter count = popcount over the trimmed prefix -> keep / new length -> res[]  [HBM write: 4 B/read]
-//   3. workgroup scan of (keep, new_len) + decoupled look-back across tiles -> output offsets
-//   4. order-preserving gather of the kept prefixes into the packed output, one 16 B aligned output
-//      chunk per lane                                            [HBM read <= 2L, write 2*new_len per kept read]
+// One workgroup (256 threads = 4 wave64) owns a tile of up to 256 consecutive reads.  Tiles are handed out
+// by a global ticket (so a workgroup only ever waits on tiles whose owners are already running) and each
+// workgroup runs a two-stage software pipeline over its tiles:
+//   stage A(tile i+1)  1. stream the quality rows once, 16 B per lane, into two LDS bitmaps
+//                         (bit = "byte >= trim threshold", bit = "byte < filter threshold")      [HBM read L B/read]
+//                      2. one thread per read: (clip DP over LDS-staged bases,) trim point = highest set
+//                         bit, filter count = popcount of the trimmed prefix -> res[]            [HBM write 4 B/read]
+//                      3. workgroup scan of (keep, new_len); publish the tile's totals (never waits)
+//   stage B(tile i)    4. resolve the tile's global offsets by decoupled look-back (predecessors have had a
+//                         whole stage A to publish, so the hand-off latency is off the critical path)
+//                      5. order-preserving gather of the kept prefixes into the packed output, one 16 B
+//                         aligned output chunk per lane                    [HBM read <= 2L, write 2*new_len / kept read]
+// The -v report counters are not kept in this kernel: a second tiny pass reduces res[] (4 B/read).
 #pragma once
 #include "fxg_device.h"
 
 #define FXG_INVALID_TUPLE 0xFFFFFFFFu
 
-// LDS carve-up shared by host (size) and device (pointers); every region is 16-byte aligned (G17)
+// LDS carve-up shared by host (size) and device (pointers); every region is 16-byte aligned (G17).
+// v_off / v_src / v_rank are double buffered: stage B of tile i reads slot s while stage A of tile i+1 fills slot s^1.
 struct FxgLds {
-    u32 off_voff, off_vsrc, off_scratch, off_cacc, off_bm_g, off_bm_l, off_bases, total;
+    u32 slot_bytes, so_vsrc, so_vrank;   // slot k lives at k * slot_bytes: v_off at +0, v_src at +so_vsrc, v_rank at +so_vrank
+    u32 off_scratch, off_bm_g, off_bm_l, off_bases, total;
 };
 __host__ __device__ inline u32 fxg_r16(u32 x) { return (x + 15u) & ~15u; }
 __host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, bool bitmaps, bool stage_bases)
 {
     FxgLds l;
-    u32 o = 0;
-    l.off_voff = o;    o += fxg_r16((T + 1) * 4);
-    l.off_vsrc = o;    o += fxg_r16(T * 4);
-    l.off_scratch = o; o += fxg_r16(32 * 4);
-    l.off_cacc = o;    o += fxg_r16(FXG_NCOUNTERS * 8);
+    l.so_vsrc = fxg_r16((T + 1) * 4);
+    l.so_vrank = l.so_vsrc + fxg_r16(T * 4);
+    l.slot_bytes = l.so_vrank + fxg_r16(T * 2);
+    u32 o = 2 * l.slot_bytes;
+    l.off_scratch = o; o += fxg_r16(48 * 4);
     const u32 words = (T * stride + 31) / 32 + 2;
     l.off_bm_g = o;    o += bitmaps ? fxg_r16(words * 4) : 0;
     l.off_bm_l = o;    o += bitmaps ? fxg_r16(words * 4) : 0;
@@ -110,35 +116,70 @@ FXG_HD void fxg_clip_read(const FxgKArgs &a, const uint8_t *rd, int len,
     *out_len = (u32)cur; *keep = k; *reason = why; *clipped = cl; *adapter_only = ao;
 }
 
-// per-thread event counters, folded into the workgroup's partial[] row once at the end
+// The -v report counters are a pure function of res[]: one accumulator set per thread of the
+// counting pass (or per emulated run).
 struct FxgCounts {
-    u32 in, kept, too_short, adapter_only, no_adapter, adapter_found, has_n, qtrim, qfilter, ftrim, clip_out, qtrim_out;
-    u64 bases;
+    u64 in, kept, bases, too_short, adapter_only, no_adapter, adapter_found, has_n, qtrim, qfilter, ftrim, k_mode;
 };
+#define FXG_RES_ADAPTER_ONLY_BIT 22   /* clipper found the adapter at index 0 (counted even when -k keeps the read) */
 
-#ifndef FXG_HOST_EMULATION
-__device__ __forceinline__ void fxg_flush_counts(const FxgKArgs &a, const FxgCounts &k, u64 *cacc)
+FXG_HD void fxg_count_res(u32 w, FxgCounts &c)
 {
-    // cacc was zeroed at kernel start; LDS atomics, once per workgroup lifetime
-    const u64 v[13] = {k.in, k.kept, k.bases, k.too_short, k.adapter_only, k.no_adapter, k.adapter_found,
-                       k.has_n, k.qtrim, k.qfilter, k.ftrim, k.clip_out, k.qtrim_out};
-#pragma unroll
-    for (int i = 0; i < 13; ++i)
-        if (v[i]) atomicAdd(&cacc[i], v[i]);
-    __syncthreads();
-    if (threadIdx.x < FXG_NCOUNTERS) a.partial[(u64)blockIdx.x * FXG_NCOUNTERS + threadIdx.x] = cacc[threadIdx.x];
+    const u32 keep = (w >> 16) & 1u, why = (w >> 17) & 0xFu;
+    c.in++;
+    c.kept += keep;
+    c.bases += keep ? (w & 0xFFFFu) : 0u;
+    c.adapter_only += (w >> FXG_RES_ADAPTER_ONLY_BIT) & 1u;
+    c.too_short += (why == FXG_R_CLIP_TOO_SHORT);
+    c.no_adapter += (why == FXG_R_CLIP_NO_ADAPTER);
+    c.adapter_found += (why == FXG_R_CLIP_ADAPTER_FOUND);
+    c.has_n += (why == FXG_R_CLIP_N);
+    c.qtrim += (why == FXG_R_QTRIM);
+    c.qfilter += (why == FXG_R_QFILTER);
+    c.ftrim += (why == FXG_R_FTRIM);
+    c.k_mode += (why == FXG_R_CLIP_K_MODE);
 }
 
-#endif  // FXG_HOST_EMULATION
+// counters[] from the accumulators; clip_out / qtrim_out are what survives each stage of the chain
+FXG_HD void fxg_counts_to_slots(const FxgCounts &c, u32 stages, u64 *slot)
+{
+    for (int i = 0; i < FXG_NCOUNTERS; ++i) slot[i] = 0;
+    slot[FXG_C_INPUT] = c.in; slot[FXG_C_KEPT] = c.kept; slot[FXG_C_KEPT_BASES] = c.bases;
+    slot[FXG_C_CLIP_TOO_SHORT] = c.too_short; slot[FXG_C_CLIP_ADAPTER_ONLY] = c.adapter_only;
+    slot[FXG_C_CLIP_NO_ADAPTER] = c.no_adapter; slot[FXG_C_CLIP_ADAPTER_FOUND] = c.adapter_found; slot[FXG_C_CLIP_N] = c.has_n;
+    slot[FXG_C_QTRIM_DROPPED] = c.qtrim; slot[FXG_C_QFILTER_DROPPED] = c.qfilter; slot[FXG_C_FTRIM_DROPPED] = c.ftrim;
+    const u64 clip_out = c.kept + c.qtrim + c.qfilter;
+    slot[FXG_C_CLIP_OUT] = (stages & FXG_STAGE_CLIP) ? clip_out : 0;
+    slot[FXG_C_QTRIM_OUT] = (stages & FXG_STAGE_QTRIM) ? c.kept + c.qfilter : 0;
+}
 
 // ---- per-thread phase bodies (host+device so tests/emu can run them serially) ----
 
-// phase 1: quality rows of the tile -> two bitmaps, 16 B per step
+// phase 1: quality rows of the tile -> two bitmaps.  Full in-range tiles take the batched path: five
+// independent 16-byte loads per lane are issued before any is consumed.
 FXG_HD void fxg_phase_bitmaps(const FxgKArgs &a, u64 tb, u32 tbytes, u32 *bm_g, u32 *bm_l, u32 tid, u32 nthreads)
 {
     const u32 Kg = (128u - a.tq) * 0x01010101u, Kf = (128u - a.fq) * 0x01010101u;
     const u32 nchunks = (tbytes + 15u) >> 4;
     uint16_t *g16 = reinterpret_cast<uint16_t *>(bm_g), *l16 = reinterpret_cast<uint16_t *>(bm_l);
+    const uint8_t *src = a.qual + tb;
+    if ((tbytes & 15u) == 0u && tb + tbytes <= a.total_bytes) {
+        constexpr u32 U = 5;
+        for (u32 c0 = tid; c0 < nchunks; c0 += nthreads * U) {
+            u32x4 v[U];
+#pragma unroll
+            for (u32 u = 0; u < U; ++u) {
+                const u32 c = c0 + u * nthreads;
+                if (c < nchunks) v[u] = fxg_ld16(src + ((u64)c << 4));
+            }
+#pragma unroll
+            for (u32 u = 0; u < U; ++u) {
+                const u32 c = c0 + u * nthreads;
+                if (c < nchunks) { g16[c] = (uint16_t)fxg_mask16(v[u], Kg); l16[c] = (uint16_t)(~fxg_mask16(v[u], Kf)); }
+            }
+        }
+        return;
+    }
     for (u32 c = tid; c < nchunks; c += nthreads) {
         const u32 o = c << 4;
         const u32x4 v = fxg_window(a.qual, (long long)(tb + o), a.total_bytes, 0, (int)(tbytes - o < 16u ? tbytes - o : 16u));
@@ -161,47 +202,33 @@ FXG_HD void fxg_phase_stage_bases(const FxgKArgs &a, u64 tb, u32 tbytes, uint8_t
 // phase 2, group A: thread tid decides read r0 + tid
 template <int AMAX>
 FXG_HD void fxg_decide_a(const FxgKArgs &a, const u32 *bm_g, const u32 *bm_l, const uint8_t *sb, u32 r0, u32 tid,
-                         FxgCounts &cnt, u32 *keep_out, u32 *len_out)
+                         u32 *keep_out, u32 *len_out)
 {
     const u32 stride = a.stride;
     const u32 rl = a.len ? (u32)a.len[r0 + tid] : a.fixed_len;
-    u32 reason = FXG_R_KEPT, clipped = 0, keep = 1, curlen = rl;
-    cnt.in++;
-    if constexpr (AMAX > 0) {
-        u32 ao;
-        fxg_clip_read<AMAX>(a, sb + tid * stride, (int)rl, &curlen, &keep, &reason, &clipped, &ao);
-        cnt.adapter_only += ao;
-        cnt.too_short += (reason == FXG_R_CLIP_TOO_SHORT);
-        cnt.no_adapter += (reason == FXG_R_CLIP_NO_ADAPTER);
-        cnt.adapter_found += (reason == FXG_R_CLIP_ADAPTER_FOUND);
-        cnt.has_n += (reason == FXG_R_CLIP_N);
-        cnt.clip_out += keep;
-    }
+    u32 reason = FXG_R_KEPT, clipped = 0, keep = 1, curlen = rl, ao = 0;
+    if constexpr (AMAX > 0) fxg_clip_read<AMAX>(a, sb + tid * stride, (int)rl, &curlen, &keep, &reason, &clipped, &ao);
     if (keep && (a.stages & FXG_STAGE_QTRIM)) {             // fastq_quality_trimmer.c:94-101
         const u32 k = fxg_bits_last(bm_g, tid * stride, curlen);
         curlen = k;
-        if (!(k > 0 && (int)k >= a.qt_min_len)) { keep = 0; reason = FXG_R_QTRIM; cnt.qtrim++; }
-        else cnt.qtrim_out++;
+        if (!(k > 0 && (int)k >= a.qt_min_len)) { keep = 0; reason = FXG_R_QTRIM; }
     }
     if (keep && (a.stages & FXG_STAGE_QFILTER)) {           // fastq_quality_filter.c:110-129,155 in closed form
         const u32 low = fxg_bits_count(bm_l, tid * stride, curlen);
         int n0 = (int)curlen * a.qf_keep_pct / 100;
         if (n0 < 0) n0 = 0;
-        if (a.qf_drop_all || (int)low > n0) { keep = 0; reason = FXG_R_QFILTER; cnt.qfilter++; }
+        if (a.qf_drop_all || (int)low > n0) { keep = 0; reason = FXG_R_QFILTER; }
     }
-    a.res[r0 + tid] = (curlen & 0xFFFFu) | (keep << 16) | (reason << 17) | (clipped << 21);
-    cnt.kept += keep;
-    cnt.bases += keep ? curlen : 0u;
+    a.res[r0 + tid] = (curlen & 0xFFFFu) | (keep << 16) | (reason << 17) | (clipped << 21) | (ao << FXG_RES_ADAPTER_ONLY_BIT);
     *keep_out = keep; *len_out = curlen;
 }
 
 // phase 2, group B: fixed trimming is arithmetic on the length; reverse-complement only moves the anchor
 template <bool REV>
-FXG_HD void fxg_decide_b(const FxgKArgs &a, u32 r0, u32 tid, FxgCounts &cnt, u32 *keep_out, u32 *len_out, u32 *anchor_out)
+FXG_HD void fxg_decide_b(const FxgKArgs &a, u32 r0, u32 tid, u32 *keep_out, u32 *len_out, u32 *anchor_out)
 {
     const u32 rl = a.len ? (u32)a.len[r0 + tid] : a.fixed_len;
     u32 reason = FXG_R_KEPT, start = 0, keep = 1, curlen = rl;
-    cnt.in++;
     if (a.stages & FXG_STAGE_FTRIM) {                       // fastx_trimmer.c:122-134
         if (a.ft_last != 0 && (u32)a.ft_last < curlen) curlen = (u32)a.ft_last;
         if (a.ft_first != 1) {
@@ -214,10 +241,8 @@ FXG_HD void fxg_decide_b(const FxgKArgs &a, u32 r0, u32 tid, FxgCounts &cnt, u32
         else if (curlen - a.ft_trim_end < a.ft_min_len) keep = 0;
         else curlen -= a.ft_trim_end;
     }
-    if (!keep) { reason = FXG_R_FTRIM; cnt.ftrim++; }
+    if (!keep) reason = FXG_R_FTRIM;
     a.res[r0 + tid] = (curlen & 0xFFFFu) | (keep << 16) | (reason << 17);
-    cnt.kept += keep;
-    cnt.bases += keep ? curlen : 0u;
     // output byte k of this read comes from source byte anchor + k (forward) or anchor - k (reverse-complement)
     *anchor_out = REV ? tid * a.stride + (rl - 1u - start) : tid * a.stride + start;
     *keep_out = keep; *len_out = curlen;
@@ -232,97 +257,113 @@ FXG_HD void fxg_write_kept_meta(const FxgKArgs &a, u64 rank, u32 olen, u32 read_
 }
 
 #ifndef FXG_HOST_EMULATION   // everything below is device code proper (wave intrinsics, __global__)
-// steps 3+4 shared by both kernels.  Called by every thread of the workgroup.
-template <bool REV>
-__device__ __forceinline__ void fxg_tile_emit(const FxgKArgs &a, unsigned char *smem, const FxgLds &L, u32 tile, u32 r0,
-                                              u32 nreads, u64 tile_in_base, u32 keep, u32 olen, u32 src_anchor)
-{
-    u32 *v_off = reinterpret_cast<u32 *>(smem + L.off_voff);
-    u32 *v_src = reinterpret_cast<u32 *>(smem + L.off_vsrc);
-    u32 *scratch = reinterpret_cast<u32 *>(smem + L.off_scratch);
-    const u32 tid = threadIdx.x;
-    u32 exc, exb, totc, totb;
-    fxg_block_scan2(keep, keep ? olen : 0u, scratch, &exc, &exb, &totc, &totb);
-    if (!a.compact) return;
-    if (tid < nreads) { v_off[tid] = exb; v_src[tid] = src_anchor; }
-    if (tid == 0) v_off[nreads] = totb;
-    u64 *bc = reinterpret_cast<u64 *>(scratch + 16);
-    if (tid < 64) {
-        u64 base_c, base_b;
-        fxg_lookback(a, tile, totc, totb, &base_c, &base_b);
-        if (tid == 0) { bc[0] = base_c; bc[1] = base_b; }
-    }
-    __syncthreads();
-    const u64 base_c = bc[0], base_b = bc[1];
-    if (keep) fxg_write_kept_meta(a, base_c + exc, olen, r0 + tid, base_b + exb);
-    const u32 bad = fxg_tile_gather<REV>(a, v_off, v_src, nreads, tile_in_base, base_b, totb, tid, FXG_BLOCK);
-    if (REV && bad) atomicOr(a.errflag, FXG_DEV_ERR_BAD_BASE);
-}
 
-// ------------------------------------------------------------------------------------------------
-// group A: [fastx_clipper] -> [fastq_quality_trimmer] -> [fastq_quality_filter]
-// ------------------------------------------------------------------------------------------------
-template <int AMAX>
-__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_clip_qtrim_qfilter(const FxgKArgs a)
+// MODE 0: [clip][qtrim][qfilter] (AMAX = adapter bucket, 0 = no clip); MODE 1: fixed trim; MODE 2: reverse-complement [+ fixed trim]
+template <int AMAX, int MODE>
+__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_tiles(const FxgKArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool REV = (MODE == 2);
     const u32 T = a.tile_reads, stride = a.stride, tid = threadIdx.x;
-    const bool use_q = (a.stages & (FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0;
-    const FxgLds L = fxg_lds_layout(T, stride, use_q, AMAX > 0);
+    const bool use_q = MODE == 0 && (a.stages & (FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0;
+    const FxgLds L = fxg_lds_layout(T, stride, use_q, MODE == 0 && AMAX > 0);
     u32 *bm_g = reinterpret_cast<u32 *>(smem + L.off_bm_g);
     u32 *bm_l = reinterpret_cast<u32 *>(smem + L.off_bm_l);
     uint8_t *sb = smem + L.off_bases;
-    u64 *cacc = reinterpret_cast<u64 *>(smem + L.off_cacc);
-    if (tid < FXG_NCOUNTERS) cacc[tid] = 0ull;
-    FxgCounts cnt = {};
+    u32 *scratch = reinterpret_cast<u32 *>(smem + L.off_scratch);   // [0,8) scan, [8,12) tile totals per slot, [12,14) tickets
+    u64 *bc = reinterpret_cast<u64 *>(scratch + 16);                // [0,2) broadcast of the resolved bases
+    u32 *s_tot = scratch + 8, *s_ticket = scratch + 12;
 
-    for (u32 tile = fxg_first_tile(); tile < a.ntiles; tile += gridDim.x) {
-        const u32 r0 = tile * T;
-        const u64 left = a.n - (u64)r0;
-        const u32 nreads = left < (u64)T ? (u32)left : T;
-        const u64 tb = (u64)r0 * stride;
-        const u32 tbytes = nreads * stride;
-
-        if (use_q) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, FXG_BLOCK);
-        if constexpr (AMAX > 0) fxg_phase_stage_bases(a, tb, tbytes, sb, tid, FXG_BLOCK);
-        __syncthreads();
-
-        u32 keep = 0, curlen = 0;
-        if (tid < nreads) fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, cnt, &keep, &curlen);
-
-        fxg_tile_emit<false>(a, smem, L, tile, r0, nreads, tb, keep, curlen, tid * stride);
-        __syncthreads();
+    if (tid == 0) s_ticket[0] = atomicAdd(a.ticket, 1u);
+    __syncthreads();
+    u32 cur = s_ticket[0];
+    u32 pend = 0xFFFFFFFFu;
+    u32 slot = 0, tk = 0;
+    for (;;) {
+        // ------------------------------ stage A: tile `cur` into slot `slot` ------------------------------
+        if (cur < a.ntiles) {
+            if (tid == 0) s_ticket[tk ^ 1u] = atomicAdd(a.ticket, 1u);   // next ticket: in flight while this tile is decided
+            const u32 r0 = cur * T;
+            const u64 left = a.n - (u64)r0;
+            const u32 nreads = left < (u64)T ? (u32)left : T;
+            const u64 tb = (u64)r0 * stride;
+            const u32 tbytes = nreads * stride;
+            if constexpr (MODE == 0) {
+                if (use_q && !(a.debug & 8u)) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, FXG_BLOCK);
+                if constexpr (AMAX > 0) fxg_phase_stage_bases(a, tb, tbytes, sb, tid, FXG_BLOCK);
+                __syncthreads();
+            }
+            u32 keep = 0, olen = 0, anchor = tid * stride;
+            if (tid < nreads) {
+                if constexpr (MODE == 0) fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen);
+                else fxg_decide_b<REV>(a, r0, tid, &keep, &olen, &anchor);
+            }
+            u32 exc, exb, totc, totb;
+            fxg_block_scan2(keep, keep ? olen : 0u, scratch, &exc, &exb, &totc, &totb);   // one __syncthreads inside
+            if (a.compact) {
+                unsigned char *sl = smem + slot * L.slot_bytes;
+                u32 *v_off = reinterpret_cast<u32 *>(sl);
+                u32 *v_src = reinterpret_cast<u32 *>(sl + L.so_vsrc);
+                uint16_t *v_rank = reinterpret_cast<uint16_t *>(sl + L.so_vrank);
+                if (tid < nreads) { v_off[tid] = exb; v_src[tid] = anchor; v_rank[tid] = (uint16_t)exc; }
+                if (tid == 0) { v_off[nreads] = totb; s_tot[2 * slot] = totc; s_tot[2 * slot + 1] = totb; }
+                if (tid < 64 && !(a.debug & 2u)) fxg_publish_aggregate(a, cur, totc, totb);
+            }
+        }
+        // ------------------------------ stage B: tile `pend` from slot `slot ^ 1` ------------------------------
+        if (pend != 0xFFFFFFFFu && a.compact) {
+            const u32 ps = slot ^ 1u;
+            const u32 r0 = pend * T;
+            const u64 left = a.n - (u64)r0;
+            const u32 nreads = left < (u64)T ? (u32)left : T;
+            const unsigned char *sl = smem + ps * L.slot_bytes;
+            const u32 *v_off = reinterpret_cast<const u32 *>(sl);
+            const u32 *v_src = reinterpret_cast<const u32 *>(sl + L.so_vsrc);
+            const uint16_t *v_rank = reinterpret_cast<const uint16_t *>(sl + L.so_vrank);
+            if (tid < 64) {
+                u64 base_c = 0, base_b = 0;
+                if (!(a.debug & 2u)) fxg_resolve_prefix(a, pend, s_tot[2 * ps], s_tot[2 * ps + 1], &base_c, &base_b);
+                if (tid == 0) { bc[0] = base_c; bc[1] = base_b; }
+            }
+            __syncthreads();
+            const u64 base_c = bc[0], base_b = bc[1];
+            const u32 totb = v_off[nreads];
+            if (tid < nreads) {
+                const u32 olen = v_off[tid + 1] - v_off[tid];      // kept reads are never empty
+                if (olen) fxg_write_kept_meta(a, base_c + v_rank[tid], olen, r0 + tid, base_b + v_off[tid]);
+            }
+            if (!(a.debug & 1u)) {
+                const u32 bad = fxg_tile_gather<REV>(a, v_off, v_src, nreads, (u64)r0 * stride, base_b, totb, tid, FXG_BLOCK);
+                if (REV && bad) atomicOr(a.errflag, FXG_DEV_ERR_BAD_BASE);
+            }
+        }
+        if (cur >= a.ntiles) break;
+        __syncthreads();            // ticket written by thread 0 in stage A; also fences slot reuse two iterations apart
+        pend = cur;
+        tk ^= 1u;
+        cur = s_ticket[tk];
+        slot ^= 1u;
     }
-    fxg_flush_counts(a, cnt, cacc);
 }
 
-// ------------------------------------------------------------------------------------------------
-// group B: [fastx_reverse_complement] -> [fastx_trimmer]   (pure index remap + complement)
-// ------------------------------------------------------------------------------------------------
-template <bool REV>
-__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_revcomp_ftrim(const FxgKArgs a)
+// res[] -> per-workgroup partial counters (the -v report inputs, a12)
+__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_count_res(const u32 *res, u64 n, u32 stages, u64 *partial)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const u32 T = a.tile_reads, stride = a.stride, tid = threadIdx.x;
-    const FxgLds L = fxg_lds_layout(T, stride, false, false);
-    u64 *cacc = reinterpret_cast<u64 *>(smem + L.off_cacc);
-    if (tid < FXG_NCOUNTERS) cacc[tid] = 0ull;
-    FxgCounts cnt = {};
-
-    for (u32 tile = fxg_first_tile(); tile < a.ntiles; tile += gridDim.x) {
-        const u32 r0 = tile * T;
-        const u64 left = a.n - (u64)r0;
-        const u32 nreads = left < (u64)T ? (u32)left : T;
-        const u64 tb = (u64)r0 * stride;
-        u32 keep = 0, curlen = 0, anchor = 0;
-        if (tid < nreads) fxg_decide_b<REV>(a, r0, tid, cnt, &keep, &curlen, &anchor);
-        fxg_tile_emit<REV>(a, smem, L, tile, r0, nreads, tb, keep, curlen, anchor);
-        __syncthreads();
-    }
-    fxg_flush_counts(a, cnt, cacc);
+    __shared__ u64 acc[FXG_NCOUNTERS];
+    if (threadIdx.x < FXG_NCOUNTERS) acc[threadIdx.x] = 0ull;
+    __syncthreads();
+    FxgCounts c = {};
+    for (u64 i = (u64)blockIdx.x * FXG_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * FXG_BLOCK) fxg_count_res(res[i], c);
+    u64 slot[FXG_NCOUNTERS];
+    fxg_counts_to_slots(c, stages, slot);
+#pragma unroll
+    for (int i = 0; i < FXG_NCOUNTERS; ++i)
+        if (slot[i]) atomicAdd(&acc[i], slot[i]);
+    __syncthreads();
+    if (threadIdx.x < FXG_NCOUNTERS) partial[(u64)blockIdx.x * FXG_NCOUNTERS + threadIdx.x] = acc[threadIdx.x];
 }
 
-// partial[grid][16] -> counters[16]; also folds the device error word into counters[FXG_C_ERRORS]
+// partial[rows][16] -> counters[16]; also folds the device error word into counters[FXG_C_ERRORS]
 __global__ void fxg_kernel_reduce_counters(const u64 *partial, u32 rows, const u32 *errflag, u64 *counters)
 {
     __shared__ u64 acc[FXG_NCOUNTERS];

@@ -2,6 +2,7 @@
 // arguments.  Shared by the engine (fxg_engine.hip) and by the CPU emulator used in tests/emu.
 #pragma once
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "fxg_kernels.h"
@@ -21,6 +22,8 @@ static inline u32 fxg_pick_tile(u32 stride, bool clip)
     // keep the LDS footprint around 64 KiB or less so that at least two workgroups share a CU
     const u64 budget = clip ? 60ull * 1024 : 192ull * 1024;   // bytes of tile rows one workgroup may cover
     u32 T = FXG_MAX_TILE;
+    const char *env = getenv("FXG_TILE");   // tuning knob: 1..256, power of two
+    if (env && atoi(env) >= 1 && atoi(env) <= FXG_MAX_TILE && (atoi(env) & (atoi(env) - 1)) == 0) T = (u32)atoi(env);
     while (T > 1 && (u64)T * stride > budget) T >>= 1;
     return T;
 }

@@ -61,11 +61,13 @@ extern "C" {
  *   bits  0..15  new length (bases kept; for dropped reads the length at the point of the drop)
  *   bit   16     keep
  *   bits 17..20  drop reason (FXG_R_*)
- *   bit   21     adapter found and clipped (clipper's i > 0)                                      */
+ *   bit   21     adapter found and clipped (clipper's i > 0)
+ *   bit   22     adapter found at index 0 ("adapter-only", fastx_clipper.cpp:289-295; counted even when -k keeps it) */
 #define FXG_RES_LEN(w)     ((uint32_t)(w) & 0xFFFFu)
 #define FXG_RES_KEEP(w)    (((uint32_t)(w) >> 16) & 1u)
 #define FXG_RES_REASON(w)  (((uint32_t)(w) >> 17) & 0xFu)
 #define FXG_RES_CLIPPED(w) (((uint32_t)(w) >> 21) & 1u)
+#define FXG_RES_ADAPTER_ONLY(w) (((uint32_t)(w) >> 22) & 1u)
 
 enum fxg_reason {
     FXG_R_KEPT = 0,

@@ -304,7 +304,7 @@ int fxo_run_pipeline(const fxo_batch *in, const fxo_params *p, fxo_out *out)
         const uint8_t *b = in->bases + r * in->stride;
         const uint8_t *q = in->qual ? in->qual + r * in->stride : NULL;
         int len = in->len ? in->len[r] : (int)in->fixed_len;
-        int keep = 1, reason = FXO_R_KEPT, clipped = 0;
+        int keep = 1, reason = FXO_R_KEPT, clipped = 0, aonly = 0;
         int start = 0;       /* forward view: output = b[start .. start+len) */
         int reversed = 0;
         out->counters[FXO_C_INPUT]++;
@@ -320,7 +320,7 @@ int fxo_run_pipeline(const fxo_batch *in, const fxo_params *p, fxo_out *out)
                 clipped = 1;
             }
             if (i == 0) {
-                out->counters[FXO_C_CLIP_ADAPTER_ONLY]++;
+                out->counters[FXO_C_CLIP_ADAPTER_ONLY]++; aonly = 1;
                 if (p->clip_flags & FXO_CLIP_ADAPTER_ONLY) { keep = 1; cur = len; }
                 else { keep = 0; reason = FXO_R_CLIP_ADAPTER_ONLY; }
             } else if ((unsigned)cur < p->clip_min_len) {
@@ -365,8 +365,7 @@ int fxo_run_pipeline(const fxo_batch *in, const fxo_params *p, fxo_out *out)
             if (!keep) { reason = FXO_R_FTRIM; out->counters[FXO_C_FTRIM_DROPPED]++; }
         }
 
-        if (!keep) len = (reason == FXO_R_QTRIM) ? len : len;
-        out->res[r] = ((uint32_t)len & 0xFFFFu) | ((uint32_t)keep << 16) | ((uint32_t)reason << 17) | ((uint32_t)clipped << 21);
+        out->res[r] = ((uint32_t)len & 0xFFFFu) | ((uint32_t)keep << 16) | ((uint32_t)reason << 17) | ((uint32_t)clipped << 21) | ((uint32_t)aonly << 22);
         if (!keep) continue;
 
         /* materialise the kept read (a3: the writer emits strlen(nucleotides) bases and as many qualities) */

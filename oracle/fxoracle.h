@@ -108,7 +108,7 @@ typedef struct {
 } fxo_batch;
 
 typedef struct {
-    uint32_t *res;         /* [n]  new_len | keep<<16 | reason<<17 | clipped<<21 */
+    uint32_t *res;         /* [n]  new_len | keep<<16 | reason<<17 | clipped<<21 | adapter_only<<22 */
     uint8_t  *out_bases;   /* packed concatenation of kept reads, input order */
     uint8_t  *out_qual;
     uint16_t *out_len;     /* [kept] (may be NULL) */

@@ -19,8 +19,8 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
     std::vector<unsigned char> lds(pl.lds + 64, 0);
     unsigned char *smem = lds.data();
     const FxgLds L = pl.group_a ? fxg_lds_layout(T, stride, pl.use_q, pl.clip) : fxg_lds_layout(T, stride, false, false);
-    u32 *v_off = reinterpret_cast<u32 *>(smem + L.off_voff);
-    u32 *v_src = reinterpret_cast<u32 *>(smem + L.off_vsrc);
+    u32 *v_off = reinterpret_cast<u32 *>(smem);
+    u32 *v_src = reinterpret_cast<u32 *>(smem + L.so_vsrc);
     u32 *bm_g = reinterpret_cast<u32 *>(smem + L.off_bm_g);
     u32 *bm_l = reinterpret_cast<u32 *>(smem + L.off_bm_l);
     uint8_t *sb = smem + L.off_bases;
@@ -40,11 +40,11 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
                 if constexpr (AMAX > 0) fxg_phase_stage_bases(a, tb, tbytes, sb, tid, NT);
             }
             for (u32 tid = 0; tid < nreads; ++tid) {
-                fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, cnt, &keep[tid], &olen[tid]);
+                fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid]);
                 anchor[tid] = tid * stride;
             }
         } else {
-            for (u32 tid = 0; tid < nreads; ++tid) fxg_decide_b<REV>(a, r0, tid, cnt, &keep[tid], &olen[tid], &anchor[tid]);
+            for (u32 tid = 0; tid < nreads; ++tid) fxg_decide_b<REV>(a, r0, tid, &keep[tid], &olen[tid], &anchor[tid]);
         }
         if (!a.compact) continue;
         u32 exb = 0, exc = 0;
@@ -56,11 +56,11 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
         for (u32 tid = 0; tid < NT; ++tid) bad |= fxg_tile_gather<REV>(a, v_off, v_src, nreads, tb, base_b, exb, tid, NT);
         base_c += exc; base_b += exb;
     }
-    const u64 v[13] = {cnt.in, cnt.kept, cnt.bases, cnt.too_short, cnt.adapter_only, cnt.no_adapter, cnt.adapter_found,
-                       cnt.has_n, cnt.qtrim, cnt.qfilter, cnt.ftrim, cnt.clip_out, cnt.qtrim_out};
+    for (u64 i = 0; i < a.n; ++i) fxg_count_res(a.res[i], cnt);   // same reduction the counting kernel performs
     if (counters) {
-        for (int i = 0; i < FXG_NCOUNTERS; ++i) counters[i] = 0;
-        for (int i = 0; i < 13; ++i) counters[i] = v[i];
+        u64 slot[FXG_NCOUNTERS];
+        fxg_counts_to_slots(cnt, a.stages, slot);
+        for (int i = 0; i < FXG_NCOUNTERS; ++i) counters[i] = slot[i];
         counters[FXG_C_ERRORS] = (REV && bad) ? FXG_DEV_ERR_BAD_BASE : 0;
     }
     (void)err; (void)cap;
