@@ -1,0 +1,40 @@
+/*
+ * fxh_batch.h -- batch path of the host layer: records are parsed in bulk from the block-buffered reader,
+ * packed into a Structure-of-Arrays batch, pushed through the HIP engine (include/fxg.h) and the kept
+ * records are formatted back in input order.  This replaces the reference tools'
+ *     while (fastx_read_next_record(&fastx)) { <loop body>; fastx_write_record(&fastx); }
+ * (e.g. fastq_quality_trimmer.c:89-104) with one engine call per few hundred thousand records; the loop
+ * bodies themselves run on the GPU.  There is no CPU implementation of the loop bodies in this layer.
+ */
+#ifndef FXH_BATCH_H
+#define FXH_BATCH_H
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/fxg.h"
+#include "fastx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Totals for the tools' -v reports (a12).  *_reads are weighted by get_reads_count() like the reference's. */
+typedef struct fxh_totals {
+    size_t input_sequences, input_reads, output_sequences, output_reads;
+    /* fastx_clipper.cpp:80-85 (32-bit unsigned there; printed with %u) */
+    unsigned int clip_input, clip_too_short, clip_adapter_only, clip_no_adapter, clip_adapter_found, clip_n;
+} fxh_totals;
+
+/* Runs the whole input of `fx` (reader and writer already initialised) through the engine with the stage
+ * chain in `p`.  On a malformed record every earlier record is processed and written first, then the
+ * reference's message is printed and the process exits with status 1 (same observable order as errx()
+ * inside fastx_read_next_record).  Returns 0. */
+int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *totals);
+
+/* fxg_params with the reference tools' defaults (qoffset from -Q). */
+void fxh_default_params(fxg_params *p, int qoffset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,116 @@
+"""GPU tier (-m gpu): the five command-line tools (C host layer + HIP engine) against the reference.
+
+* every Galaxy known-answer pair of the hot tools, byte for byte;
+* the seeded synthetic cases of tests/golden/cases.json by md5 (reference output);
+* where oracle/_ref/fxref travelled to the box: fuzzed text incl. -v reports, exit codes and the
+  "flush everything before the bad record, then fail with the reference's message" behaviour.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from helpers import GOLDEN, md5
+from oracle import fxoracle_py as fo
+
+pytestmark = pytest.mark.gpu
+HOST = os.path.join(ROOT, "fastx_toolkit_amd", "host")
+REF = fo.ref_binary()
+
+
+@pytest.fixture(scope="module")
+def tools():
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    return os.path.join(HOST, "bin")
+
+
+def _run(cmd, data, env=None):
+    p = subprocess.run(cmd, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    return p.returncode, p.stdout, p.stderr
+
+
+def _msg(err):
+    lines = [l for l in err.split(b"\n") if b"amdgpu.ids" not in l]
+    return b"\n".join(lines).split(b": ", 1)[-1]
+
+
+def test_galaxy_known_answers(tools, cases):
+    for g in cases["galaxy"]:
+        inp = open(os.path.join(GOLDEN, "galaxy", g["input"]), "rb").read()
+        exp = open(os.path.join(GOLDEN, "galaxy", g["expect"]), "rb").read()
+        rc, out, err = _run([os.path.join(tools, g["cmd"][0])] + g["cmd"][1:], inp)
+        assert rc == 0, err
+        assert out == exp, g["name"]
+
+
+def test_synthetic_cases_md5(tools, cases):
+    for c in cases["synthetic"]:
+        if c["n"] > 200000:
+            continue
+        text = fo.synth_fastq(c["seed"], 0, c["n"], c["L"], c["adapter"])
+        for cmd in c["chain"]:
+            rc, text, err = _run([os.path.join(tools, cmd[0])] + cmd[1:], text)
+            assert rc == 0, err
+        assert md5(text) == c["output_md5"], c["name"]
+    for c in cases["varlen"]:
+        if c["name"] == "var_clip_history":
+            continue   # N3: ragged-input clipper history quirk is outside the engine contract
+        text = open(os.path.join(GOLDEN, "synthetic", c["name"] + ".fq"), "rb").read()
+        for cmd in c["chain"]:
+            rc, text, err = _run([os.path.join(tools, cmd[0])] + cmd[1:], text)
+            assert rc == 0, err
+        assert text == open(os.path.join(GOLDEN, "synthetic", c["name"] + ".out"), "rb").read(), c["name"]
+
+
+def test_files_reports_gzip_and_small_buffers(tools, tmp_path):
+    text = fo.synth_fastq(31, 0, 30000, 100, True)
+    inp, outp = tmp_path / "in.fq", tmp_path / "out.fq"
+    inp.write_bytes(text)
+    env = dict(os.environ, FXH_READ_BUFFER_MB="1")             # forces many engine calls with records straddling refills
+    rc, out, err = _run([os.path.join(tools, "fastq_quality_trimmer"), "-t", "25", "-l", "40", "-v", "-i", str(inp), "-o", str(outp)], b"", env)
+    assert rc == 0, err
+    exp, r = None, None
+    from helpers import oracle_params, text_through
+    exp, r = text_through(fo.run_pipeline, text, oracle_params(dict(stages=2, qt_threshold=25, qt_min_len=40)))
+    assert outp.read_bytes() == exp
+    kept = int(r["counters"][1])
+    assert out.decode() == ("Minimum Quality Threshold: 25\nMinimum Length: 40\nInput: 30000 reads.\nOutput: %d reads.\n"
+                            "discarded %d (%d%%) too-short reads.\n" % (kept, 30000 - kept, (30000 - kept) * 100 // 30000))   # -o => report on stdout
+    rc, out, err = _run([os.path.join(tools, "fastx_reverse_complement"), "-z", "-i", str(inp)], b"")
+    assert rc == 0
+    import gzip
+    exp, _ = text_through(fo.run_pipeline, text, oracle_params(dict(stages=8)))
+    assert gzip.decompress(out) == exp
+
+
+@pytest.mark.skipif(REF is None, reason="oracle/_ref/fxref not on this box")
+def test_fuzz_cli_vs_reference(tools):
+    rng = np.random.default_rng(9)
+    ad = b"AGATCGGAAGAGC"
+    for trial in range(24):
+        L = int(rng.integers(20, 90))
+        recs = []
+        for i in range(int(rng.integers(50, 400))):
+            s = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=L, p=[.24, .24, .24, .24, .04])
+            if rng.random() < 0.5:
+                pos = int(rng.integers(0, L + 1)); k = min(len(ad), L - pos)
+                s[pos:pos + k] = np.frombuffer(ad, np.uint8)[:k]
+            q = rng.integers(33, 75, size=L, dtype=np.uint8); q[int(rng.integers(0, L + 1)):] = 36
+            recs.append(b"@r%d some text\n%s\n+\n%s\n" % (i, s.tobytes(), q.tobytes()))
+        data = b"".join(recs)
+        if trial % 4 == 3:      # malformed record in the middle: earlier output must still appear, exit code 1
+            k = len(b"".join(recs[:len(recs) // 2])) + 12
+            data = data[:k] + b"!" + data[k + 1:]
+        argvs = [["fastq_quality_trimmer", "-t", str(int(rng.integers(5, 40))), "-l", str(int(rng.integers(0, 50))), "-v"],
+                 ["fastq_quality_filter", "-q", str(int(rng.integers(5, 40))), "-p", str(int(rng.integers(1, 101))), "-v"],
+                 ["fastx_trimmer", "-f", str(int(rng.integers(1, 30))), "-l", str(int(rng.integers(30, 100))), "-v"],
+                 ["fastx_trimmer", "-t", str(int(rng.integers(1, 30))), "-m", str(int(rng.integers(1, 60))), "-v"],
+                 ["fastx_reverse_complement", "-v"],
+                 ["fastx_clipper", "-a", ad.decode(), "-l", str(int(rng.integers(0, 25))), "-v"] + list(rng.choice(["-n", "-c", "-C", "-k"], size=2, replace=False))]
+        for argv in argvs:
+            rc, out, err = _run([os.path.join(tools, argv[0])] + argv[1:], data)
+            rrc, rout, rerr = _run([REF] + argv, data)
+            assert (rc, out) == (rrc, rout), (trial, argv)
+            assert _msg(err) == _msg(rerr), (trial, argv)
