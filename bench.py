@@ -85,6 +85,8 @@ def main():
     rank, local, world = fxd.init_from_env()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    if os.environ.get("FXG_BENCH_SHARED_GPU"):      # smoke-testing the N>1 path on a 1-GPU box (with FXG_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     eng = Engine(local)
     R, L = args.reads, READ_LEN
@@ -116,7 +118,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+        t = torch.tensor([dt], dtype=torch.float64, device=eng.device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

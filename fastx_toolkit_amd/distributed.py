@@ -26,7 +26,7 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        backend = backend or os.environ.get("FXG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -44,9 +44,15 @@ def epilogue(counters, group=None):
         c = counters.detach().cpu().numpy().view(np.uint64)
         return c.copy(), 0, 0, c.reshape(1, -1).copy()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if dist.get_backend(group) == "gloo":      # CPU tests / shared-GPU smoke runs: stage through host memory
+        counters = counters.detach().cpu()
     gathered = torch.empty((world, NCOUNTERS), dtype=counters.dtype, device=counters.device)
-    dist.all_gather_into_tensor(gathered, counters.contiguous(), group=group) if counters.is_cuda else \
-        dist.all_gather(list(gathered.unbind(0)), counters.contiguous(), group=group)
+    if counters.is_cuda:
+        dist.all_gather_into_tensor(gathered, counters.contiguous(), group=group)
+    else:
+        parts = [torch.empty(NCOUNTERS, dtype=counters.dtype) for _ in range(world)]
+        dist.all_gather(parts, counters.contiguous(), group=group)
+        gathered = torch.stack(parts)
     per_rank = gathered.cpu().numpy().view(np.uint64).reshape(world, NCOUNTERS)
     totals = per_rank.sum(axis=0, dtype=np.uint64)
     totals[C_ERRORS] = np.bitwise_or.reduce(per_rank[:, C_ERRORS])

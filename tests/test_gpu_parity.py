@@ -185,3 +185,24 @@ def test_cfg5_pipeline_shard(engine):
     _window_check(engine, 5, 125_000_000 // 5, 150, True,
                   dict(stages=7, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=4, qt_threshold=20, qt_min_len=30,
                        qf_min_quality=20, qf_min_percent=80), K=20000)
+
+
+def test_bench_two_ranks_on_one_gpu_via_gloo():
+    """The N>1 code path of bench.py end to end (sharded generation, per-step epilogue, barrier, max-over-ranks);
+    the two ranks share this box's single GPU and use gloo, the driver's 8-GPU run uses RCCL."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, FXG_BENCH_SHARED_GPU="1", FXG_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--reads", "2000000"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
+    assert d["config"]["reads_per_gpu"] == 2000000
