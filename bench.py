@@ -141,7 +141,8 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            pj = json.load(open(pmc))
+            traffic = pj.get("hbm_bytes_per_launch") if (pj.get("reads_per_launch") == R and compact) else None
         except Exception:
             traffic = None
 

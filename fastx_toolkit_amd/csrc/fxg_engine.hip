@@ -237,6 +237,20 @@ extern "C" int fxg_run_pipeline(fxg_ctx *c, const fxg_batch *in, const fxg_param
     if (pl.group_a) {
         switch (pl.amax) {
         case 0: return fxg_launch_tiles(c, FXG_TILES_A(0), "fxg_kernel_tiles<0,0> qtrim+qfilter", pl.ka, pl.lds, ctr);
+        case -4: return fxg_launch_tiles(c, FXG_TILES_A(-4), "fxg_kernel_tiles<-4,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
+        case -8: return fxg_launch_tiles(c, FXG_TILES_A(-8), "fxg_kernel_tiles<-8,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
+        case -9: return fxg_launch_tiles(c, FXG_TILES_A(-9), "fxg_kernel_tiles<-9,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
+        case -10: return fxg_launch_tiles(c, FXG_TILES_A(-10), "fxg_kernel_tiles<-10,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
+        case -11: return fxg_launch_tiles(c, FXG_TILES_A(-11), "fxg_kernel_tiles<-11,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
+        case -12: return fxg_launch_tiles(c, FXG_TILES_A(-12), "fxg_kernel_tiles<-12,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
+        case -13: return fxg_launch_tiles(c, FXG_TILES_A(-13), "fxg_kernel_tiles<-13,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
+        case -14: return fxg_launch_tiles(c, FXG_TILES_A(-14), "fxg_kernel_tiles<-14,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
+        case -15: return fxg_launch_tiles(c, FXG_TILES_A(-15), "fxg_kernel_tiles<-15,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
+        case -16: return fxg_launch_tiles(c, FXG_TILES_A(-16), "fxg_kernel_tiles<-16,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
+        case -20: return fxg_launch_tiles(c, FXG_TILES_A(-20), "fxg_kernel_tiles<-20,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
+        case -24: return fxg_launch_tiles(c, FXG_TILES_A(-24), "fxg_kernel_tiles<-24,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
+        case -28: return fxg_launch_tiles(c, FXG_TILES_A(-28), "fxg_kernel_tiles<-28,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
+        case -32: return fxg_launch_tiles(c, FXG_TILES_A(-32), "fxg_kernel_tiles<-32,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
         case 16: return fxg_launch_tiles(c, FXG_TILES_A(16), "fxg_kernel_tiles<16,0> clip[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
         case 32: return fxg_launch_tiles(c, FXG_TILES_A(32), "fxg_kernel_tiles<32,0> clip[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
         case 64: return fxg_launch_tiles(c, FXG_TILES_A(64), "fxg_kernel_tiles<64,0> clip[+qtrim+qfilter]", pl.ka, pl.lds, ctr);

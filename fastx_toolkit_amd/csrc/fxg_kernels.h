@@ -48,53 +48,10 @@ __host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, bool bitmaps
 // counts), fastx_clipper.cpp:192-240 (accept rules), :282-319 (clip / discard cascade).
 //   w0 = query_start<<16 | target_start<<8 | mismatches        w1 = path_len<<16 | matches
 // ------------------------------------------------------------------------------------------------
-template <int AMAX>
-FXG_HD void fxg_clip_read(const FxgKArgs &a, const uint8_t *rd, int len,
-                                              u32 *out_len, u32 *keep, u32 *reason, u32 *clipped, u32 *adapter_only)
+// accept rules (fastx_clipper.cpp:192-240) + clip/discard cascade (:282-319) on the decoded alignment summary
+FXG_HD void fxg_clip_finish(const FxgKArgs &a, int len, int qs, int ts, int mism, int sz, int matches, int bq, int first_n,
+                            u32 *out_len, u32 *keep, u32 *reason, u32 *clipped, u32 *adapter_only)
 {
-    float S[AMAX];
-    u32 W0[AMAX], W1[AMAX];
-    const int A = a.alen;
-#pragma unroll
-    for (int t = 0; t < AMAX; ++t) {
-        S[t] = (t <= 3) ? 0.0f : -5.0f * (float)(t - 3);   // target_border (:355-361)
-        W0[t] = FXG_INVALID_TUPLE; W1[t] = 0u;
-    }
-    float best = -1000000.0f;
-    u32 bw0 = FXG_INVALID_TUPLE, bw1 = 0u;
-    int bq = 0, first_n = len;
-    for (int q = 0; q < len; ++q) {
-        const u32 c = rd[q];
-        const bool qn = (c == (u32)'N');
-        if (qn && first_n == len) first_n = q;
-        float dS = 0.0f, uS = 0.0f;                        // S[q-1][-1] and S[q][-1]: query_border = 0 (N1 for q == 0)
-        u32 dW0 = FXG_INVALID_TUPLE, dW1 = 0u, uW0 = FXG_INVALID_TUPLE, uW1 = 0u;
-#pragma unroll
-        for (int t = 0; t < AMAX; ++t) {
-            if (t >= A) break;
-            const u32 tc = (u32)(uint8_t)a.adapter[t];
-            const bool tn = (tc == (u32)'N');
-            const bool eq = (c == tc);
-            const bool neutral = qn || tn;
-            const float pair = neutral ? ((qn && tn) ? 0.0f : 0.1f) : (eq ? 1.0f : -1.0f);   // sequence_alignment.h:157-169
-            const float ul = dS + pair;
-            const float up = uS + -5.0f;
-            float left = S[t] + -5.0f;
-            if (t > 3 && t - 3 > q) left = -100000.0f;      // :387-389
-            float sc = ul; u32 w0 = dW0, w1 = dW1; bool diag = true;   // ul always beats the -1e8 seed
-            if (up > sc)   { sc = up;   w0 = uW0;   w1 = uW1;   diag = false; }
-            if (left > sc) { sc = left; w0 = W0[t]; w1 = W1[t]; diag = false; }
-            if (w0 == FXG_INVALID_TUPLE) { w0 = ((u32)q << 16) | ((u32)t << 8); w1 = 0u; }   // path enters the matrix here
-            w1 += 0x10000u + ((diag && !neutral && eq) ? 1u : 0u);
-            w0 += (diag && !neutral && !eq) ? 1u : 0u;
-            dS = S[t]; dW0 = W0[t]; dW1 = W1[t];
-            S[t] = sc; W0[t] = w0; W1[t] = w1;
-            uS = sc; uW0 = w0; uW1 = w1;
-            if (sc > best) { best = sc; bw0 = w0; bw1 = w1; bq = q; }   // first maximum in query-major order (:421-425)
-        }
-    }
-    const int qs = (int)(bw0 >> 16), ts = (int)((bw0 >> 8) & 0xFFu), mism = (int)(bw0 & 0xFFu);
-    const int sz = (int)(bw1 >> 16), matches = (int)(bw1 & 0xFFFFu);
     int i = -1;
     if (sz != 0 && !(a.clip_min_adapter_len > 0 && sz < a.clip_min_adapter_len)) {
         if (bq == len - 1 && mism == 0) i = qs;
@@ -114,6 +71,139 @@ FXG_HD void fxg_clip_read(const FxgKArgs &a, const uint8_t *rd, int len,
     else if (!(a.clip_flags & FXG_CLIP_KEEP_N) && first_n < cur) { k = 0; why = FXG_R_CLIP_N; }
     else if (a.clip_flags & FXG_CLIP_ADAPTER_ONLY) { k = 0; why = FXG_R_CLIP_K_MODE; }
     *out_len = (u32)cur; *keep = k; *reason = why; *clipped = cl; *adapter_only = ao;
+}
+
+// General form: w0 = query_start<<16 | target_start<<8 | mismatches, w1 = path_len<<16 | matches.
+// Every select is written as a ternary on values (no control flow) so that the cell is ~30 straight VALU ops.
+template <int AMAX>
+FXG_HD void fxg_clip_read(const FxgKArgs &a, const uint8_t *rd, int len,
+                          u32 *out_len, u32 *keep, u32 *reason, u32 *clipped, u32 *adapter_only)
+{
+    float S[AMAX];
+    u32 W0[AMAX], W1[AMAX];
+    const int A = a.alen;
+#pragma unroll
+    for (int t = 0; t < AMAX; ++t) {
+        S[t] = (t <= 3) ? 0.0f : -5.0f * (float)(t - 3);   // target_border (:355-361)
+        W0[t] = FXG_INVALID_TUPLE; W1[t] = 0u;
+    }
+    float best = -1000000.0f;
+    u32 bw0 = FXG_INVALID_TUPLE, bw1 = 0u, bq = 0u;
+    int first_n = len;
+#pragma unroll 1
+    for (int q = 0; q < len; ++q) {
+        const u32 c = rd[q];
+        const bool qn = (c == (u32)'N');
+        first_n = (qn && first_n == len) ? q : first_n;
+        float dS = 0.0f, uS = 0.0f;                        // S[q-1][-1] and S[q][-1]: query_border = 0 (N1 for q == 0)
+        u32 dW0 = FXG_INVALID_TUPLE, dW1 = 0u, uW0 = FXG_INVALID_TUPLE, uW1 = 0u;
+#pragma unroll
+        for (int t = 0; t < AMAX; ++t) {
+            // No break and no guard: the trip count stays a compile-time constant (t indexes registers) and the body is
+            // straight-line.  Cells with t >= A compute harmless garbage (they only feed cells further right) and are
+            // excluded from the best-cell update below.
+            const u32 tc = (u32)(uint8_t)a.adapter[t];
+            const bool tn = (tc == (u32)'N');
+            const bool eq = (c == tc);
+            const bool neutral = qn || tn;
+            const float pair = neutral ? ((qn && tn) ? 0.0f : 0.1f) : (eq ? 1.0f : -1.0f);   // sequence_alignment.h:157-169
+            const float ul = dS + pair;
+            const float up = uS + -5.0f;
+            float left = S[t] + -5.0f;
+            if (t > 3) left = (t - 3 > q) ? -100000.0f : left;                  // :387-389
+            const bool g1 = up > ul;                                            // ul always beats the -1e8 seed; diag > up > left on ties
+            float sc = g1 ? up : ul;
+            u32 w0 = g1 ? uW0 : dW0, w1 = g1 ? uW1 : dW1;
+            const bool g2 = left > sc;
+            sc = g2 ? left : sc;
+            w0 = g2 ? W0[t] : w0; w1 = g2 ? W1[t] : w1;
+            const bool diag = !(g1 || g2);
+            const bool fresh = (w0 == FXG_INVALID_TUPLE);                       // the path enters the matrix in this cell
+            w0 = fresh ? (((u32)q << 16) | ((u32)t << 8)) : w0;
+            w1 = fresh ? 0u : w1;
+            w1 += 0x10000u + ((diag && !neutral && eq) ? 1u : 0u);
+            w0 += (diag && !neutral && !eq) ? 1u : 0u;
+            dS = S[t]; dW0 = W0[t]; dW1 = W1[t];
+            S[t] = sc; W0[t] = w0; W1[t] = w1;
+            uS = sc; uW0 = w0; uW1 = w1;
+            const bool gb = (sc > best) && (t < A);                             // first maximum in query-major order (:421-425)
+            best = gb ? sc : best; bw0 = gb ? w0 : bw0; bw1 = gb ? w1 : bw1; bq = gb ? (u32)q : bq;
+        }
+    }
+    fxg_clip_finish(a, len, (int)(bw0 >> 16), (int)((bw0 >> 8) & 0xFFu), (int)(bw0 & 0xFFu), (int)(bw1 >> 16), (int)(bw1 & 0xFFFFu),
+                    (int)bq, first_n, out_len, keep, reason, clipped, adapter_only);
+}
+
+// Packed form for reads <= 255 and adapters <= 31 (every BASELINE config): the whole path summary is ONE u32
+//   w = query_start:8 | target_start:5 | mismatches:5 | matches:5 | path_len:9      (path_len <= L + A <= 286)
+// which halves the selects and the registers of the general form.  0xFFFFFFFF cannot occur (query_start <= 254).
+#define FXG_PK_SZ1   1u
+#define FXG_PK_MAT1  (1u << 9)
+#define FXG_PK_MIS1  (1u << 14)
+template <int AMAX, bool EARLY>
+FXG_HD void fxg_clip_row_packed(const FxgKArgs &a, int A, u32 c, int q, float (&S)[AMAX], u32 (&W)[AMAX], float &best, u32 &bw, u32 &bq)
+{
+    const bool qn = (c == (u32)'N');
+    float dS = 0.0f, uS = 0.0f;                            // S[q-1][-1] and S[q][-1]: query_border = 0 (N1 for q == 0)
+    u32 dW = FXG_INVALID_TUPLE, uW = FXG_INVALID_TUPLE;
+#pragma unroll
+    for (int t = 0; t < AMAX; ++t) {
+        const u32 tc = (u32)(uint8_t)a.adapter[t];    // straight-line body, see fxg_clip_read
+        const bool tn = (tc == (u32)'N');
+        const bool eq = (c == tc);
+        const bool neutral = qn || tn;
+        const float pair = neutral ? ((qn && tn) ? 0.0f : 0.1f) : (eq ? 1.0f : -1.0f);      // sequence_alignment.h:157-169
+        const u32 dinc = neutral ? FXG_PK_SZ1 : (eq ? (FXG_PK_SZ1 + FXG_PK_MAT1) : (FXG_PK_SZ1 + FXG_PK_MIS1));   // if the diagonal wins
+        const float ul = dS + pair;
+        const float up = uS + -5.0f;
+        float left = S[t] + -5.0f;
+        if (EARLY && t > 3) left = (t - 3 > q) ? -100000.0f : left;                          // :387-389, only rows q < A-4
+        const bool g1 = up > ul;                                                             // diag > up > left on ties
+        float sc = g1 ? up : ul;
+        u32 w = g1 ? uW : dW;
+        u32 inc = g1 ? FXG_PK_SZ1 : dinc;
+        const bool g2 = left > sc;
+        sc = g2 ? left : sc;
+        w = g2 ? W[t] : w;
+        inc = g2 ? FXG_PK_SZ1 : inc;
+        w = (w == FXG_INVALID_TUPLE) ? (((u32)q << 24) | ((u32)t << 19)) : w;                // the path enters the matrix here
+        w += inc;
+        dS = S[t]; dW = W[t];
+        S[t] = sc; W[t] = w;
+        uS = sc; uW = w;
+        const bool gb = (sc > best) && (t < A);                                              // first maximum in query-major order
+        best = gb ? sc : best; bw = gb ? w : bw; bq = gb ? (u32)q : bq;
+    }
+}
+
+template <int AMAX>
+FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len,
+                                 u32 *out_len, u32 *keep, u32 *reason, u32 *clipped, u32 *adapter_only)
+{
+    float S[AMAX];
+    u32 W[AMAX];
+    const int A = a.alen;
+#pragma unroll
+    for (int t = 0; t < AMAX; ++t) { S[t] = (t <= 3) ? 0.0f : -5.0f * (float)(t - 3); W[t] = FXG_INVALID_TUPLE; }
+    float best = -1000000.0f;
+    u32 bw = FXG_INVALID_TUPLE, bq = 0u;
+    int first_n = len;
+    const int early_rows = (A - 4 < len) ? (A - 4 > 0 ? A - 4 : 0) : len;    // rows where "t - 3 > q" can still hold for some t < A
+    int q = 0;
+#pragma unroll 1
+    for (; q < early_rows; ++q) {
+        const u32 c = rd[q];
+        first_n = (c == (u32)'N' && first_n == len) ? q : first_n;
+        fxg_clip_row_packed<AMAX, true>(a, A, c, q, S, W, best, bw, bq);
+    }
+#pragma unroll 1
+    for (; q < len; ++q) {
+        const u32 c = rd[q];
+        first_n = (c == (u32)'N' && first_n == len) ? q : first_n;
+        fxg_clip_row_packed<AMAX, false>(a, A, c, q, S, W, best, bw, bq);
+    }
+    fxg_clip_finish(a, len, (int)(bw >> 24), (int)((bw >> 19) & 31u), (int)((bw >> 14) & 31u), (int)(bw & 511u), (int)((bw >> 9) & 31u),
+                    (int)bq, first_n, out_len, keep, reason, clipped, adapter_only);
 }
 
 // The -v report counters are a pure function of res[]: one accumulator set per thread of the
@@ -200,6 +290,7 @@ FXG_HD void fxg_phase_stage_bases(const FxgKArgs &a, u64 tb, u32 tbytes, uint8_t
 }
 
 // phase 2, group A: thread tid decides read r0 + tid
+// AMAX > 0: general clipper; AMAX < 0: packed clipper with bucket -AMAX (reads <= 255, adapter <= 31)
 template <int AMAX>
 FXG_HD void fxg_decide_a(const FxgKArgs &a, const u32 *bm_g, const u32 *bm_l, const uint8_t *sb, u32 r0, u32 tid,
                          u32 *keep_out, u32 *len_out)
@@ -208,6 +299,7 @@ FXG_HD void fxg_decide_a(const FxgKArgs &a, const u32 *bm_g, const u32 *bm_l, co
     const u32 rl = a.len ? (u32)a.len[r0 + tid] : a.fixed_len;
     u32 reason = FXG_R_KEPT, clipped = 0, keep = 1, curlen = rl, ao = 0;
     if constexpr (AMAX > 0) fxg_clip_read<AMAX>(a, sb + tid * stride, (int)rl, &curlen, &keep, &reason, &clipped, &ao);
+    if constexpr (AMAX < 0) fxg_clip_read_packed<-AMAX>(a, sb + tid * stride, (int)rl, &curlen, &keep, &reason, &clipped, &ao);
     if (keep && (a.stages & FXG_STAGE_QTRIM)) {             // fastq_quality_trimmer.c:94-101
         const u32 k = fxg_bits_last(bm_g, tid * stride, curlen);
         curlen = k;
@@ -266,7 +358,7 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_tiles(const FxgKArgs a)
     constexpr bool REV = (MODE == 2);
     const u32 T = a.tile_reads, stride = a.stride, tid = threadIdx.x;
     const bool use_q = MODE == 0 && (a.stages & (FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0;
-    const FxgLds L = fxg_lds_layout(T, stride, use_q, MODE == 0 && AMAX > 0);
+    const FxgLds L = fxg_lds_layout(T, stride, use_q, MODE == 0 && AMAX != 0);
     u32 *bm_g = reinterpret_cast<u32 *>(smem + L.off_bm_g);
     u32 *bm_l = reinterpret_cast<u32 *>(smem + L.off_bm_l);
     uint8_t *sb = smem + L.off_bases;
@@ -290,7 +382,7 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_tiles(const FxgKArgs a)
             const u32 tbytes = nreads * stride;
             if constexpr (MODE == 0) {
                 if (use_q && !(a.debug & 8u)) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, FXG_BLOCK);
-                if constexpr (AMAX > 0) fxg_phase_stage_bases(a, tb, tbytes, sb, tid, FXG_BLOCK);
+                if constexpr (AMAX != 0) fxg_phase_stage_bases(a, tb, tbytes, sb, tid, FXG_BLOCK);
                 __syncthreads();
             }
             u32 keep = 0, olen = 0, anchor = tid * stride;

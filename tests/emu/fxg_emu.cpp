@@ -37,7 +37,7 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
         if (pl.group_a) {
             for (u32 tid = 0; tid < NT; ++tid) {
                 if (pl.use_q) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, NT);
-                if constexpr (AMAX > 0) fxg_phase_stage_bases(a, tb, tbytes, sb, tid, NT);
+                if constexpr (AMAX != 0) fxg_phase_stage_bases(a, tb, tbytes, sb, tid, NT);
             }
             for (u32 tid = 0; tid < nreads; ++tid) {
                 fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid]);
@@ -77,6 +77,20 @@ extern "C" int fxg_emu_run_pipeline(const fxg_batch *in, const fxg_params *p, co
     if (pl.group_a) {
         switch (pl.amax) {
         case 0: return emu_run<0, false>(pl, ctr, err, cap);
+        case -4: return emu_run<-4, false>(pl, ctr, err, cap);
+        case -8: return emu_run<-8, false>(pl, ctr, err, cap);
+        case -9: return emu_run<-9, false>(pl, ctr, err, cap);
+        case -10: return emu_run<-10, false>(pl, ctr, err, cap);
+        case -11: return emu_run<-11, false>(pl, ctr, err, cap);
+        case -12: return emu_run<-12, false>(pl, ctr, err, cap);
+        case -13: return emu_run<-13, false>(pl, ctr, err, cap);
+        case -14: return emu_run<-14, false>(pl, ctr, err, cap);
+        case -15: return emu_run<-15, false>(pl, ctr, err, cap);
+        case -16: return emu_run<-16, false>(pl, ctr, err, cap);
+        case -20: return emu_run<-20, false>(pl, ctr, err, cap);
+        case -24: return emu_run<-24, false>(pl, ctr, err, cap);
+        case -28: return emu_run<-28, false>(pl, ctr, err, cap);
+        case -32: return emu_run<-32, false>(pl, ctr, err, cap);
         case 16: return emu_run<16, false>(pl, ctr, err, cap);
         case 32: return emu_run<32, false>(pl, ctr, err, cap);
         case 64: return emu_run<64, false>(pl, ctr, err, cap);
