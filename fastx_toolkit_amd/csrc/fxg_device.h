@@ -18,6 +18,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define FXG_BLOCK 256           // threads per workgroup = 4 wave64
 #define FXG_WAVES (FXG_BLOCK / 64)
 #define FXG_MAX_TILE 256        // reads per tile (one thread decides one read)
+#define FXG_TICKET_GROUPS 8      // a single device-scope counter saturates near 88 tickets/us; shard it (one per XCD)
+#define FXG_TICKET_STRIDE 32     // u32 words between dispensers (128 B: one cache line each)
 
 // ------------------------------------------------------------------------------------------------
 // launch arguments (passed by value; adapter bytes therefore live in the kernarg segment / SGPRs)
@@ -43,7 +45,8 @@ struct FxgKArgs {
     u64 *status_cnt;        // [ntiles] decoupled look-back granules (kept reads)
     u64 *status_bytes;      // [ntiles] decoupled look-back granules (kept bytes)
     u64 *partial;           // [count grid][FXG_NCOUNTERS]
-    u32 *ticket;            // dynamic tile dispenser (zeroed before every launch)
+    u32 *ticket;            // dynamic tile dispensers, FXG_TICKET_STRIDE words apart (zeroed before every launch)
+    u32  ticket_groups;     // number of dispensers (<= 8): dispenser g hands out tiles g, g+groups, g+2*groups, ...
     u32 *errflag;
     u32  compact;           // 1 = stream-compact kept reads into out_bases/out_qual
     u32  debug;             // FXG_DEBUG ablation bits (timing experiments only; results are wrong when set)
@@ -316,71 +319,124 @@ __device__ __forceinline__ void fxg_block_scan2(u32 c, u32 b, u32 *scratch, u32 
 // Work item = one 16-byte aligned chunk of the GLOBAL output; consecutive lanes write consecutive
 // chunks (1 KiB per wave store).  A chunk that straddles reads is assembled from one window per read.
 // ------------------------------------------------------------------------------------------------
+// One source segment of an output chunk: chunk bytes [blo, bhi) come from the 16-byte window that starts
+// `src` bytes after the tile's first input byte (read backwards when REV).  Everything per lane is 32-bit and
+// tile-relative; the 64-bit bases are wave-uniform and stay in SGPRs.
+struct FxgSeg { int src; int blo, bhi; };
+
+template <bool REV>
+FXG_HD FxgSeg fxg_make_seg(const u32 *v_off, const u32 *v_src, u32 r, u32 o, u32 seg_end, int cs)
+{
+    FxgSeg g;
+    g.blo = (int)o - cs;
+    g.bhi = (int)seg_end - cs;
+    const int j0 = (int)(o - v_off[r]);
+    g.src = REV ? (int)v_src[r] - j0 + g.blo - 15 : (int)v_src[r] + j0 - g.blo;
+    return g;
+}
+
+// The 16-byte window of one array for one segment, reversed/complemented/validated when REV, masked to
+// [blo, bhi).  tile_ptr = array + tile_in_base (uniform); [lo_ok, hi_ok) = tile-relative range of the array.
+template <bool REV, bool BASES>
+FXG_HD u32x4 fxg_seg_bytes(const uint8_t *tile_ptr, int lo_ok, int hi_ok, const FxgSeg &g, u32 *bad)
+{
+    const int vlo = REV ? 16 - g.bhi : g.blo, vhi = REV ? 16 - g.blo : g.bhi;
+    u32x4 w;
+    if (g.src >= lo_ok && g.src + 16 <= hi_ok) w = fxg_ld16(tile_ptr + g.src);
+    else {                                         // window pokes out of the array: touch only the needed bytes
+        u64 lo = 0, hi = 0;
+        for (int i = vlo; i < vhi; ++i) {
+            const u64 b = tile_ptr[g.src + i];
+            if (i < 8) lo |= b << (8 * i); else hi |= b << (8 * (i - 8));
+        }
+        w = (u32x4){(u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32)};
+    }
+    if (REV) {
+        w = fxg_reverse16(w);
+        if (BASES) {
+            const u32x4 m = fxg_keep_bytes((u32x4){~0u, ~0u, ~0u, ~0u}, g.blo, g.bhi);
+            *bad |= fxg_invalid_bases4(w.x, m.x) | fxg_invalid_bases4(w.y, m.y) | fxg_invalid_bases4(w.z, m.z) | fxg_invalid_bases4(w.w, m.w);
+            w.x = fxg_complement4(w.x); w.y = fxg_complement4(w.y); w.z = fxg_complement4(w.z); w.w = fxg_complement4(w.w);
+        }
+    }
+    return fxg_keep_bytes(w, g.blo, g.bhi);
+}
+
+// one array of one chunk: both candidate windows in flight, then the (rare) tail of further segments
+template <bool REV, bool BASES>
+FXG_HD void fxg_gather_array(const uint8_t *tile_ptr, int lo_ok, int hi_ok, uint8_t *out_chunk, const u32 *v_off, const u32 *v_src,
+                             const FxgSeg &s1, const FxgSeg &s2, bool two, bool more, u32 r_next, u32 o_next, u32 o_end, int cs,
+                             int lo_c, int hi_c, u32 *bad)
+{
+    u32x4 acc = fxg_seg_bytes<REV, BASES>(tile_ptr, lo_ok, hi_ok, s1, bad);
+    if (two) acc |= fxg_seg_bytes<REV, BASES>(tile_ptr, lo_ok, hi_ok, s2, bad);
+    if (more) {
+        u32 r = r_next, o = o_next;
+        while (o < o_end) {
+            const u32 e = v_off[r + 1];
+            if (e > o) {
+                const u32 se = e < o_end ? e : o_end;
+                const FxgSeg g = fxg_make_seg<REV>(v_off, v_src, r, o, se, cs);
+                acc |= fxg_seg_bytes<REV, BASES>(tile_ptr, lo_ok, hi_ok, g, bad);
+                o = se;
+            }
+            ++r;
+        }
+    }
+    if (lo_c == 0 && hi_c == 16) { *reinterpret_cast<u32x4 *>(out_chunk) = acc; return; }
+    // first / last chunk of the tile: the neighbouring tile owns the other bytes
+    const u64 b0 = ((u64)acc.y << 32) | acc.x, b1 = ((u64)acc.w << 32) | acc.z;
+    for (int i = lo_c; i < hi_c; ++i) out_chunk[i] = (uint8_t)((i < 8 ? b0 : b1) >> (8 * (i & 7)));
+}
+
 template <bool REV>
 FXG_HD u32 fxg_tile_gather(const FxgKArgs &a, const u32 *v_off, const u32 *v_src, u32 nreads,
                            u64 tile_in_base, u64 B, u32 S, u32 tid, u32 nthreads)
 {
     if (S == 0) return 0u;
     const bool has_q = a.qual != nullptr && a.out_qual != nullptr && !(a.debug & 4u);
-    const u64 c_first = B >> 4, c_last = (B + S - 1) >> 4;
+    // wave-uniform 64-bit quantities
+    const u64 c_first = B >> 4;
+    const u32 nchunks = (u32)(((B + S - 1) >> 4) - c_first) + 1u;
+    const int head = (int)(B & 15u);                                   // chunk 0 starts `head` bytes before the tile's output
+    const uint8_t *src_b = a.bases + tile_in_base, *src_q = has_q ? a.qual + tile_in_base : nullptr;
+    uint8_t *out_b = a.out_bases + (c_first << 4), *out_q = has_q ? a.out_qual + (c_first << 4) : nullptr;
+    const int lo_ok = tile_in_base > 0x3FFFFFFFull ? -0x3FFFFFFF : -(int)tile_in_base;
+    const u64 after = a.total_bytes - tile_in_base;
+    const int hi_ok = after > 0x3FFFFFFFull ? 0x3FFFFFFF : (int)after;
     u32 bad = 0;
-    for (u64 c = c_first + tid; c <= c_last; c += nthreads) {
-        const long long cs = (long long)(c << 4) - (long long)B;   // tile-relative output offset of chunk byte 0
-        const int lo_c = cs < 0 ? (int)(-cs) : 0;
-        const long long rem = (long long)S - cs;
-        const int hi_c = rem >= 16 ? 16 : (int)rem;
-        u32 o = (u32)(cs + lo_c);
-        const u32 o_end = (u32)(cs + hi_c);
-        // largest r with v_off[r] <= o   (v_off[0] = 0 <= o < S = v_off[nreads])
+    for (u32 ci = tid; ci < nchunks; ci += nthreads) {
+        const int cs = (int)(ci << 4) - head;                          // tile-relative output offset of chunk byte 0
+        const int lo_c = cs < 0 ? -cs : 0;
+        const int rem = (int)S - cs;
+        const int hi_c = rem >= 16 ? 16 : rem;
+        const u32 o = (u32)(cs + lo_c), o_end = (u32)(cs + hi_c);
+        // largest r with v_off[r] <= o   (v_off[0] = 0 <= o < S = v_off[nreads]); that read is never empty
         u32 lo = 0, hi = nreads;
         while (hi - lo > 1) {
             const u32 mid = (lo + hi) >> 1;
             if (v_off[mid] <= o) lo = mid; else hi = mid;
         }
-        u32 r = lo;
-        u32x4 accb = {0u, 0u, 0u, 0u}, accq = {0u, 0u, 0u, 0u};
-        while (o < o_end) {
-            const u32 e = v_off[r + 1];
-            if (e > o) {
-                const u32 seg_end = e < o_end ? e : o_end;
-                const int blo = (int)((long long)o - cs), bhi = (int)((long long)seg_end - cs);
-                const u32 j0 = o - v_off[r];
-                long long src;
-                int vlo, vhi;
-                if (REV) { src = (long long)v_src[r] - (long long)j0 + blo - 15; vlo = 16 - bhi; vhi = 16 - blo; }
-                else     { src = (long long)v_src[r] + (long long)j0 - blo;      vlo = blo;      vhi = bhi; }
-                const long long abs_off = (long long)tile_in_base + src;
-                u32x4 wb = fxg_window(a.bases, abs_off, a.total_bytes, vlo, vhi);
-                if (REV) {
-                    wb = fxg_reverse16(wb);
-                    const u32x4 m = fxg_keep_bytes((u32x4){~0u, ~0u, ~0u, ~0u}, blo, bhi);
-                    bad |= fxg_invalid_bases4(wb.x, m.x) | fxg_invalid_bases4(wb.y, m.y) |
-                           fxg_invalid_bases4(wb.z, m.z) | fxg_invalid_bases4(wb.w, m.w);
-                    wb.x = fxg_complement4(wb.x); wb.y = fxg_complement4(wb.y);
-                    wb.z = fxg_complement4(wb.z); wb.w = fxg_complement4(wb.w);
-                }
-                wb = fxg_keep_bytes(wb, blo, bhi);
-                accb |= wb;
-                if (has_q) {
-                    u32x4 wq = fxg_window(a.qual, abs_off, a.total_bytes, vlo, vhi);
-                    if (REV) wq = fxg_reverse16(wq);
-                    accq |= fxg_keep_bytes(wq, blo, bhi);
-                }
-                o = seg_end;
-            }
-            ++r;
+        const u32 e1 = v_off[lo + 1];
+        const u32 end1 = e1 < o_end ? e1 : o_end;
+        const FxgSeg s1 = fxg_make_seg<REV>(v_off, v_src, lo, o, end1, cs);
+        FxgSeg s2 = s1;
+        bool two = false, more = false;
+        u32 r_next = 0, o_next = 0;
+        if (end1 < o_end) {                                            // the chunk continues in the next non-empty read
+            u32 r = lo + 1;
+            while (v_off[r + 1] == end1) ++r;
+            const u32 e2 = v_off[r + 1];
+            const u32 end2 = e2 < o_end ? e2 : o_end;
+            s2 = fxg_make_seg<REV>(v_off, v_src, r, end1, end2, cs);
+            two = true;
+            more = end2 < o_end;
+            r_next = r + 1; o_next = end2;
         }
-        if (lo_c == 0 && hi_c == 16) {
-            *reinterpret_cast<u32x4 *>(a.out_bases + (c << 4)) = accb;
-            if (has_q) *reinterpret_cast<u32x4 *>(a.out_qual + (c << 4)) = accq;
-        } else {   // first / last chunk of the tile: the neighbouring tile owns the other bytes
-            const u64 b0 = ((u64)accb.y << 32) | accb.x, b1 = ((u64)accb.w << 32) | accb.z;
-            const u64 q0 = ((u64)accq.y << 32) | accq.x, q1 = ((u64)accq.w << 32) | accq.z;
-            for (int i = lo_c; i < hi_c; ++i) {
-                const int sh = 8 * (i & 7);
-                a.out_bases[(c << 4) + i] = (uint8_t)((i < 8 ? b0 : b1) >> sh);
-                if (has_q) a.out_qual[(c << 4) + i] = (uint8_t)((i < 8 ? q0 : q1) >> sh);
-            }
+        fxg_gather_array<REV, true>(src_b, lo_ok, hi_ok, out_b + (ci << 4), v_off, v_src, s1, s2, two, more, r_next, o_next, o_end, cs, lo_c, hi_c, &bad);
+        if (has_q) {
+            u32 dummy = 0;
+            fxg_gather_array<REV, false>(src_q, lo_ok, hi_ok, out_q + (ci << 4), v_off, v_src, s1, s2, two, more, r_next, o_next, o_end, cs, lo_c, hi_c, &dummy);
         }
     }
     return bad;   // nonzero: a byte outside ACGTN/acgtn reached the complement (REV only)

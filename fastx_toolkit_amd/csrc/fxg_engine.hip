@@ -20,7 +20,7 @@ struct fxg_ctx {
     size_t status_cap;      // in tiles
     u64 *partial;           // partial_cap rows of FXG_NCOUNTERS
     size_t partial_cap;
-    u32 *errflag;           // [0] device error bits, [1] tile ticket
+    u32 *errflag;           // [0] device error bits; tile dispensers start at word FXG_TICKET_STRIDE
     u64 *counters_scratch;  // used when the caller passes no counter block
     char err[512];
     char last_kernel[96];
@@ -63,7 +63,7 @@ extern "C" int fxg_ctx_create(int device_id, fxg_ctx **out)
     c->stream = c->own_stream;
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreate(&c->kev0) != hipSuccess || hipEventCreate(&c->kev1) != hipSuccess ||
-        hipMalloc((void **)&c->errflag, 2 * sizeof(u32)) != hipSuccess ||
+        hipMalloc((void **)&c->errflag, (FXG_TICKET_GROUPS + 1) * FXG_TICKET_STRIDE * sizeof(u32)) != hipSuccess ||
         hipMalloc((void **)&c->counters_scratch, FXG_NCOUNTERS * sizeof(u64)) != hipSuccess) {
         free(c);
         return FXG_E_HIP;
@@ -161,7 +161,7 @@ extern "C" int fxg_timer_stop(fxg_ctx *c, float *ms)
 }
 
 // ------------------------------------------------------------------------------------------------
-#define FXG_COUNT_GRID 1024u
+#define FXG_COUNT_GRID 512u
 
 template <typename K>
 static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &ka, u32 lds, u64 *counters)
@@ -201,15 +201,16 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
     ka.partial = c->partial;
     { const char *dbg = getenv("FXG_DEBUG"); ka.debug = dbg ? (u32)atoi(dbg) : 0u; }
     ka.errflag = c->errflag;
-    ka.ticket = c->errflag + 1;
-    FXG_HIP(c, hipMemsetAsync(c->errflag, 0, 2 * sizeof(u32), c->stream));
+    ka.ticket = c->errflag + FXG_TICKET_STRIDE;
+    { const char *tg = getenv("FXG_TICKET_GROUPS"); u32 g = (tg && atoi(tg) > 0 && atoi(tg) <= FXG_TICKET_GROUPS) ? (u32)atoi(tg) : FXG_TICKET_GROUPS; ka.ticket_groups = g < grid ? g : (u32)grid; }
+    FXG_HIP(c, hipMemsetAsync(c->errflag, 0, (FXG_TICKET_GROUPS + 1) * FXG_TICKET_STRIDE * sizeof(u32), c->stream));
 
     if (c->profiling) FXG_HIP(c, hipEventRecord(c->kev0, c->stream));
     hipLaunchKernelGGL(kernel, dim3((u32)grid), dim3(FXG_BLOCK), lds, c->stream, ka);
     FXG_HIP(c, hipGetLastError());
     if (c->profiling) { FXG_HIP(c, hipEventRecord(c->kev1, c->stream)); c->kev_valid = 1; }
     // -v report counters: one pass over res[] (4 B/read), then fold the partial rows
-    u64 cgrid = (ka.n + FXG_BLOCK * 8 - 1) / (FXG_BLOCK * 8);
+    u64 cgrid = (ka.n / 4 + FXG_BLOCK * 16 - 1) / (FXG_BLOCK * 16);
     if (cgrid > FXG_COUNT_GRID) cgrid = FXG_COUNT_GRID;
     if (cgrid < 1) cgrid = 1;
     hipLaunchKernelGGL(fxg_kernel_count_res, dim3((u32)cgrid), dim3(FXG_BLOCK), 0, c->stream, (const u32 *)ka.res, ka.n, ka.stages, c->partial);

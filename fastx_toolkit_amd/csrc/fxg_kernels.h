@@ -1,7 +1,7 @@
 // fxg_kernels.h -- the tile kernels of the engine.
 //
-// One workgroup (256 threads = 4 wave64) owns a tile of up to 256 consecutive reads.  Tiles are handed out
-// by a global ticket (so a workgroup only ever waits on tiles whose owners are already running) and each
+// One workgroup (256 threads = 4 wave64) owns a tile of up to 256 consecutive reads.  Tiles are
+// handed out by eight interleaved global tickets (so a workgroup only ever waits on tiles whose owners are already running) and each
 // workgroup runs a two-stage software pipeline over its tiles:
 //   stage A(tile i+1)  1. stream the quality rows once, 16 B per lane, into two LDS bitmaps
 //                         (bit = "byte >= trim threshold", bit = "byte < filter threshold")      [HBM read L B/read]
@@ -351,8 +351,11 @@ FXG_HD void fxg_write_kept_meta(const FxgKArgs &a, u64 rank, u32 olen, u32 read_
 #ifndef FXG_HOST_EMULATION   // everything below is device code proper (wave intrinsics, __global__)
 
 // MODE 0: [clip][qtrim][qfilter] (AMAX = adapter bucket, 0 = no clip); MODE 1: fixed trim; MODE 2: reverse-complement [+ fixed trim]
+#ifndef FXG_MIN_WAVES
+#define FXG_MIN_WAVES 5   // __launch_bounds__ 2nd argument (waves per SIMD) for the streaming instances: 5 workgroups/CU measured best
+#endif
 template <int AMAX, int MODE>
-__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_tiles(const FxgKArgs a)
+__global__ __launch_bounds__(FXG_BLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void fxg_kernel_tiles(const FxgKArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool REV = (MODE == 2);
@@ -366,15 +369,21 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_tiles(const FxgKArgs a)
     u64 *bc = reinterpret_cast<u64 *>(scratch + 16);                // [0,2) broadcast of the resolved bases
     u32 *s_tot = scratch + 8, *s_ticket = scratch + 12;
 
-    if (tid == 0) s_ticket[0] = atomicAdd(a.ticket, 1u);
+    // Sharded dispenser: workgroup b draws from counter g = b % groups, which hands out tiles g, g+groups, ...
+    // The smallest unfinished tile is always either owned by a running workgroup or the next ticket of its
+    // counter (whose earlier tiles are all finished, so a workgroup of that group is about to draw it):
+    // progress never depends on residency, dispatch order or placement.
+    const u32 G = a.ticket_groups, grp = blockIdx.x % G;
+    u32 *my_ticket = a.ticket + grp * FXG_TICKET_STRIDE;
+    if (tid == 0) s_ticket[0] = atomicAdd(my_ticket, 1u);
     __syncthreads();
-    u32 cur = s_ticket[0];
+    u32 cur = s_ticket[0] * G + grp;
     u32 pend = 0xFFFFFFFFu;
     u32 slot = 0, tk = 0;
     for (;;) {
         // ------------------------------ stage A: tile `cur` into slot `slot` ------------------------------
         if (cur < a.ntiles) {
-            if (tid == 0) s_ticket[tk ^ 1u] = atomicAdd(a.ticket, 1u);   // next ticket: in flight while this tile is decided
+            if (tid == 0) s_ticket[tk ^ 1u] = atomicAdd(my_ticket, 1u);   // next ticket: in flight while this tile is decided
             const u32 r0 = cur * T;
             const u64 left = a.n - (u64)r0;
             const u32 nreads = left < (u64)T ? (u32)left : T;
@@ -433,7 +442,7 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_tiles(const FxgKArgs a)
         __syncthreads();            // ticket written by thread 0 in stage A; also fences slot reuse two iterations apart
         pend = cur;
         tk ^= 1u;
-        cur = s_ticket[tk];
+        cur = s_ticket[tk] * G + grp;
         slot ^= 1u;
     }
 }
@@ -445,7 +454,22 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_count_res(const u32 *res
     if (threadIdx.x < FXG_NCOUNTERS) acc[threadIdx.x] = 0ull;
     __syncthreads();
     FxgCounts c = {};
-    for (u64 i = (u64)blockIdx.x * FXG_BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * FXG_BLOCK) fxg_count_res(res[i], c);
+    const u64 nvec = n >> 2;                                   // res[] is 16-byte aligned (hipMalloc / torch): 4 words per load
+    const u32x4 *rv = reinterpret_cast<const u32x4 *>(res);
+    const u64 step = (u64)gridDim.x * FXG_BLOCK;
+    u64 i = (u64)blockIdx.x * FXG_BLOCK + threadIdx.x;
+    for (; i + 3 * step < nvec; i += 4 * step) {               // four independent 16-byte loads in flight per lane
+        const u32x4 w0 = rv[i], w1 = rv[i + step], w2 = rv[i + 2 * step], w3 = rv[i + 3 * step];
+        fxg_count_res(w0.x, c); fxg_count_res(w0.y, c); fxg_count_res(w0.z, c); fxg_count_res(w0.w, c);
+        fxg_count_res(w1.x, c); fxg_count_res(w1.y, c); fxg_count_res(w1.z, c); fxg_count_res(w1.w, c);
+        fxg_count_res(w2.x, c); fxg_count_res(w2.y, c); fxg_count_res(w2.z, c); fxg_count_res(w2.w, c);
+        fxg_count_res(w3.x, c); fxg_count_res(w3.y, c); fxg_count_res(w3.z, c); fxg_count_res(w3.w, c);
+    }
+    for (; i < nvec; i += step) {
+        const u32x4 w = rv[i];
+        fxg_count_res(w.x, c); fxg_count_res(w.y, c); fxg_count_res(w.z, c); fxg_count_res(w.w, c);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (u32)(n & 3u)) fxg_count_res(res[(nvec << 2) + threadIdx.x], c);
     u64 slot[FXG_NCOUNTERS];
     fxg_counts_to_slots(c, stages, slot);
 #pragma unroll

@@ -42,8 +42,8 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     if ((st & (FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) && !in->qual) FXG_PLAN_FAIL("quality stages need qual");
     if (in->stride == 0 || in->stride > FXG_MAX_READ_LEN || (!in->len && (in->fixed_len == 0 || in->fixed_len > in->stride)))
         FXG_PLAN_FAIL("bad stride/fixed_len (%u/%u)", in->stride, in->fixed_len);
-    if ((((uintptr_t)in->bases | (uintptr_t)in->qual | (uintptr_t)out->out_bases | (uintptr_t)out->out_qual) & 15u) != 0)
-        FXG_PLAN_FAIL("bases/qual/out_bases/out_qual must be 16-byte aligned");
+    if ((((uintptr_t)in->bases | (uintptr_t)in->qual | (uintptr_t)out->out_bases | (uintptr_t)out->out_qual | (uintptr_t)out->res) & 15u) != 0)
+        FXG_PLAN_FAIL("bases/qual/res/out_bases/out_qual must be 16-byte aligned");
     if (out->out_bases && in->qual && !out->out_qual) FXG_PLAN_FAIL("out_qual missing");
 
     FxgKArgs &ka = pl->ka;

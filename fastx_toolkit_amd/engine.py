@@ -73,7 +73,7 @@ def load_library(path=None):
     global _LIB
     if _LIB is not None and path is None:
         return _LIB
-    so = path or _build.LIBFXG
+    so = path or os.environ.get("FXG_LIB") or _build.LIBFXG   # FXG_LIB: A/B experiments with alternative builds
     if not os.path.exists(so):
         _build.build_engine()
     if not os.path.exists(so):

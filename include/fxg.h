@@ -17,7 +17,7 @@
  *  - extern "C", plain pointers and sizes only.  Every function returns 0 on success or a negative
  *    FXG_E_* code; fxg_last_error(ctx) describes the most recent failure on that context.
  *  - All fxg_batch / fxg_out pointers are DEVICE pointers (hipMalloc'ed by the caller or through
- *    fxg_malloc_device).  bases/qual/out_bases/out_qual must be 16-byte aligned.
+ *    fxg_malloc_device).  bases/qual/res/out_bases/out_qual must be 16-byte aligned.
  *  - Work is enqueued on the context's HIP stream and is asynchronous; fxg_sync() waits for it.
  *  - There is no CPU fallback anywhere: without a usable HIP device fxg_ctx_create() fails.
  */

@@ -17,7 +17,7 @@ eng.set_profiling(True)
 
 
 def t(label, env, compact=True, reps=4):
-    for k in ("FXG_DEBUG", "FXG_TILE", "FXG_BLOCKS_PER_CU"):
+    for k in ("FXG_DEBUG", "FXG_TILE", "FXG_BLOCKS_PER_CU", "FXG_TICKET_GROUPS"):
         os.environ.pop(k, None)
     os.environ.update(env)
     ms = []
