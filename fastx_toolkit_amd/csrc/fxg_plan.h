@@ -84,7 +84,7 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     }
     const u32 T = fxg_pick_tile(in->stride, pl->clip);
     const u64 ntiles = (in->n + T - 1) / T;
-    if (ntiles > 0x7FFFFFFFull) FXG_PLAN_FAIL("batch too large (%llu tiles)", (unsigned long long)ntiles);
+    if (ntiles > 0x7FFFFFFFull || in->n > 0xFFFFFFFFull) FXG_PLAN_FAIL("batch too large (%llu reads): split it", (unsigned long long)in->n);
     ka.tile_reads = T; ka.ntiles = (u32)ntiles;
     pl->lds = ga ? fxg_lds_layout(T, in->stride, pl->use_q, pl->clip).total : fxg_lds_layout(T, in->stride, false, false).total;
     return FXG_OK;

@@ -39,6 +39,16 @@ struct fxh_reader *fxh_reader_open(const char *filename, size_t capacity)
     return r;
 }
 
+/* enlarge the block (batch mode wants tens of MB per engine call); existing unread bytes are kept */
+void fxh_reader_reserve(struct fxh_reader *r, size_t capacity)
+{
+    if (capacity <= r->cap) return;
+    char *nb = (char *)realloc(r->buf, capacity + 1);
+    if (!nb) err(1, "out of memory");
+    r->buf = nb;
+    r->cap = capacity;
+}
+
 /* move the unread tail to the front and read until the buffer is full or the input ends */
 void fxh_reader_fill(struct fxh_reader *r)
 {

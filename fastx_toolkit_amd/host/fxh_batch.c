@@ -6,8 +6,17 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <unistd.h>
 
 #include "fxh_internal.h"
+
+static double fxh_now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 typedef struct {
     const char *name, *seq, *name2, *qual;
@@ -30,9 +39,6 @@ typedef struct {
     uint32_t *d_res;
     uint64_t *d_counters;
     size_t d_cap_bytes, d_cap_reads;
-    /* record index of the current batch */
-    fxh_rec *rec;
-    size_t rec_cap;
 } fxh_state;
 
 #define FXG_CHECK(st, call)                                                                     \
@@ -90,38 +96,384 @@ static void fxh_grow(fxh_state *st, size_t reads, size_t bytes, int revcomp)
     }
 }
 
-/* emit one kept record; seq/qual point at `len` output bytes; qual bytes are either raw input characters
- * (raw_qual) or Phred+33 codes (engine output / numeric input) */
-static void fxh_emit(FASTX *fx, const fxh_rec *r, const uint8_t *seq, const uint8_t *qual, size_t len, int raw_qual)
+/* Size (dst == NULL) or write one kept record; seq/qual point at `len` output bytes; qual bytes are either raw input
+ * characters (raw_qual) or Phred+33 codes (engine output / numeric input).  Returns the number of bytes. */
+static size_t fxh_emit(const FASTX *fx, const fxh_rec *r, const uint8_t *seq, const uint8_t *qual, size_t len, int raw_qual, char *d)
 {
-    struct fxh_writer *w = fx->writer;
-    char *d = fxh_writer_reserve(w, (size_t)r->name_len + r->name2_len + 6 * len + 16);
     size_t k = 0;
-    d[k++] = fx->output_sequence_id_prefix;
-    memcpy(d + k, r->name, r->name_len); k += r->name_len; d[k++] = '\n';
-    memcpy(d + k, seq, len); k += len; d[k++] = '\n';
+#define PUTC(ch) do { if (d) d[k] = (char)(ch); k++; } while (0)
+#define PUTS(ptr, n_) do { if (d) memcpy(d + k, (ptr), (n_)); k += (n_); } while (0)
+    PUTC(fx->output_sequence_id_prefix);
+    PUTS(r->name, r->name_len); PUTC('\n');
+    PUTS(seq, len); PUTC('\n');
     if (fx->write_fastq) {
         const int ascii = fx->copy_input_fastq_format_to_output ? r->is_ascii : fx->write_fastq_ascii;   /* R6 */
-        d[k++] = '+';
-        memcpy(d + k, r->name2, r->name2_len); k += r->name2_len; d[k++] = '\n';
+        PUTC('+');
+        PUTS(r->name2, r->name2_len); PUTC('\n');
         if (ascii) {
-            if (raw_qual) { memcpy(d + k, qual, len); k += len; }                      /* R8: q + Q is the input byte */
-            else { const int sh = fx->fastq_ascii_quality_offset - 33; for (size_t i = 0; i < len; ++i) d[k++] = (char)(qual[i] + sh); }
+            if (raw_qual) PUTS(qual, len);                                              /* R8: q + Q is the input byte */
+            else { const int sh = fx->fastq_ascii_quality_offset - 33; for (size_t i = 0; i < len; ++i) PUTC(qual[i] + sh); }
         } else {
-            if (raw_qual) {   /* ASCII input, numeric output requested */
-                unsigned char tmp[64]; size_t i = 0;
-                while (i < len) {
-                    size_t m = len - i < sizeof tmp ? len - i : sizeof tmp;
-                    for (size_t j = 0; j < m; ++j) tmp[j] = (unsigned char)((int)(signed char)qual[i + j] - fx->fastq_ascii_quality_offset + 33);
-                    if (i) d[k++] = ' ';
-                    k += fxh_format_numeric(d + k, NULL, tmp, m);
-                    i += m;
-                }
-            } else k += fxh_format_numeric(d + k, NULL, qual, len);
+            for (size_t i = 0; i < len; ++i) {
+                int v = raw_qual ? (int)(signed char)qual[i] - fx->fastq_ascii_quality_offset : (int)qual[i] - 33;
+                if (i) PUTC(' ');
+                if (v < 0) { PUTC('-'); v = -v; }
+                if (v >= 10) PUTC('0' + v / 10);
+                PUTC('0' + v % 10);
+            }
         }
-        d[k++] = '\n';
+        PUTC('\n');
     }
-    w->len += k;
+#undef PUTC
+#undef PUTS
+    return k;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* worker threads: every host phase (index+validate, pack, format) is split by record range         */
+/* ---------------------------------------------------------------------------------------------- */
+#include <pthread.h>
+
+typedef struct fxh_job fxh_job;
+typedef struct fxh_worker {
+    int id;
+    fxh_job *job;
+    FASTX *shadow;                 /* private parser state; reads the shared buffer through `view` */
+    struct fxh_reader view;
+    struct fxh_rawrec raw;
+    size_t a0, a1, nl_count, first_nl;     /* newline census of the raw byte range [a0, a1) */
+    size_t start;                          /* first record boundary at or after a0 */
+    unsigned long long start_line;         /* lines before `start` (absolute input line numbering) */
+    fxh_rec *rec;
+    size_t nrec, rec_cap, maxlen, minlen;
+    int rc_end;                            /* why indexing stopped: 0 end of input, -1 range/buffer end, -2 error */
+    size_t end_pos;
+    unsigned long long end_line;
+    char errmsg[768];
+    long bad_q;                            /* local index of the first record with an invalid quality line, or -1 */
+    size_t rec0, use;                      /* global index of rec[0]; how many of this worker's records are in the batch */
+    size_t out_bytes, out_off, kept_bytes, kept_off;
+    fxh_totals tot;
+} fxh_worker;
+
+struct fxh_job {
+    FASTX *fx;
+    fxh_state *st;
+    const fxg_params *p;
+    int nworkers, has_q, revcomp, lpr;
+    uint32_t stride, fwd_start;
+    char *out_dst;
+    void (*phase)(fxh_worker *);
+    fxh_worker *w;
+};
+
+static void *fxh_thread_main(void *arg) { fxh_worker *w = (fxh_worker *)arg; w->job->phase(w); return NULL; }
+
+static void fxh_parallel(fxh_job *job, void (*phase)(fxh_worker *))
+{
+    pthread_t th[64];
+    job->phase = phase;
+    for (int i = 1; i < job->nworkers; ++i)
+        if (pthread_create(&th[i], NULL, fxh_thread_main, &job->w[i]) != 0) err(1, "pthread_create");
+    phase(&job->w[0]);
+    for (int i = 1; i < job->nworkers; ++i) pthread_join(th[i], NULL);
+}
+
+static void fxh_phase_census(fxh_worker *w)
+{
+    const struct fxh_reader *rd = w->job->fx->reader;
+    size_t n = 0, first = (size_t)-1, i = w->a0;
+    while (i < w->a1) {
+        const char *q = (const char *)memchr(rd->buf + i, '\n', w->a1 - i);
+        if (!q) break;
+        if (first == (size_t)-1) first = (size_t)(q - rd->buf);
+        n++;
+        i = (size_t)(q - rd->buf) + 1;
+    }
+    w->nl_count = n; w->first_nl = first;
+}
+
+static void fxh_phase_index(fxh_worker *w)
+{
+    FASTX *sh = w->shadow;
+    w->nrec = 0; w->maxlen = 0; w->minlen = (size_t)-1; w->rc_end = -1;
+    sh->reader = &w->view;
+    sh->input_line_number = w->start_line;
+    if (w->view.beg >= w->view.end && !w->view.eof) { w->end_pos = w->view.beg; w->end_line = sh->input_line_number; return; }
+    for (;;) {
+        int rc = fxh_next_raw(sh, &w->raw, 0);
+        if (rc != 1) {
+            w->rc_end = rc;
+            if (rc == -2) memcpy(w->errmsg, w->raw.errmsg, sizeof w->errmsg);
+            break;
+        }
+        if (w->nrec == w->rec_cap) {
+            w->rec_cap = w->rec_cap ? w->rec_cap * 2 : (1u << 14);
+            w->rec = (fxh_rec *)realloc(w->rec, w->rec_cap * sizeof(fxh_rec));
+            if (!w->rec) err(1, "out of memory");
+        }
+        fxh_rec *r = &w->rec[w->nrec++];
+        r->name = w->raw.name; r->seq = w->raw.seq; r->name2 = w->raw.name2; r->qual = w->raw.qual;
+        r->name_len = (uint32_t)w->raw.name_len; r->seq_len = (uint32_t)w->raw.seq_len;
+        r->name2_len = (uint32_t)w->raw.name2_len; r->qual_len = (uint32_t)w->raw.qual_len;
+        r->is_ascii = (uint8_t)w->raw.is_ascii;
+        r->reads_count = (uint32_t)fxh_reads_count(sh, w->raw.name, w->raw.name_len);
+        if (w->raw.seq_len > w->maxlen) w->maxlen = w->raw.seq_len;
+        if (w->raw.seq_len < w->minlen) w->minlen = w->raw.seq_len;
+    }
+    w->end_pos = w->view.beg;
+    w->end_line = sh->input_line_number;
+}
+
+static void fxh_phase_pack(fxh_worker *w)
+{
+    fxh_job *job = w->job;
+    fxh_state *st = job->st;
+    FASTX *sh = w->shadow;
+    const uint32_t stride = job->stride;
+    const int lpr = job->lpr;
+    w->bad_q = -1;
+    for (size_t k = 0; k < w->use; ++k) {
+        const fxh_rec *r = &w->rec[k];
+        const size_t i = w->rec0 + k;
+        memcpy(st->h_bases + i * stride, r->seq, r->seq_len);
+        st->h_len[i] = (uint16_t)r->seq_len;
+        if (!job->has_q) continue;
+        uint8_t *q = st->h_qual + i * stride;
+        if (r->is_ascii && sh->fastq_ascii_quality_offset == 33) {
+            uint8_t bad = 0;
+            for (uint32_t j = 0; j < r->qual_len; ++j) { const uint8_t c = (uint8_t)r->qual[j]; bad |= (uint8_t)((c < 18) | (c > 126)); }
+            if (!bad) { memcpy(q, r->qual, r->qual_len); continue; }
+        }
+        w->raw.seq_len = r->seq_len; w->raw.qual = r->qual; w->raw.qual_len = r->qual_len; w->raw.is_ascii = r->is_ascii;
+        sh->input_line_number = w->start_line + (unsigned long long)lpr * (k + 1);   /* the quality line of this record */
+        if (fxh_decode_quality(sh, &w->raw, NULL, q) != 0) {   /* first bad record of this range */
+            w->bad_q = (long)k;
+            memcpy(w->errmsg, w->raw.errmsg, sizeof w->errmsg);
+            return;
+        }
+    }
+}
+
+/* bytes this worker will write and the report totals of its records */
+static void fxh_phase_size(fxh_worker *w)
+{
+    fxh_job *job = w->job;
+    fxh_state *st = job->st;
+    const FASTX *fx = job->fx;
+    memset(&w->tot, 0, sizeof w->tot);
+    size_t bytes = 0, kept_bytes = 0;
+    for (size_t k = 0; k < w->use; ++k) {
+        const fxh_rec *r = &w->rec[k];
+        const size_t i = w->rec0 + k;
+        const uint32_t x = st->h_res[i], len = FXG_RES_LEN(x), rc_ = r->reads_count;
+        fxh_totals *t = &w->tot;
+        t->input_sequences++; t->input_reads += rc_;
+        t->clip_input += rc_;
+        if (FXG_RES_ADAPTER_ONLY(x)) t->clip_adapter_only += rc_;
+        switch (FXG_RES_REASON(x)) {
+        case FXG_R_CLIP_TOO_SHORT: t->clip_too_short += rc_; break;
+        case FXG_R_CLIP_NO_ADAPTER: t->clip_no_adapter += rc_; break;
+        case FXG_R_CLIP_ADAPTER_FOUND: t->clip_adapter_found += rc_; break;
+        case FXG_R_CLIP_N: t->clip_n += rc_; break;
+        default: break;
+        }
+        if (!FXG_RES_KEEP(x)) continue;
+        t->output_sequences++; t->output_reads += rc_;
+        kept_bytes += len;
+        /* only numeric-quality output depends on the values (digit counts); reversal does not change their multiset */
+        const uint8_t *qv = st->h_qual ? st->h_qual + i * job->stride + (job->revcomp ? r->seq_len - job->fwd_start - len : job->fwd_start) : NULL;
+        bytes += fxh_emit(fx, r, (const uint8_t *)r->seq, r->is_ascii ? (const uint8_t *)r->seq : qv, len, 0, NULL);
+    }
+    w->out_bytes = bytes; w->kept_bytes = kept_bytes;
+}
+
+static void fxh_phase_format(fxh_worker *w)
+{
+    fxh_job *job = w->job;
+    fxh_state *st = job->st;
+    const FASTX *fx = job->fx;
+    char *d = job->out_dst + w->out_off;
+    size_t k2 = 0, opos = w->kept_off;
+    for (size_t k = 0; k < w->use; ++k) {
+        const fxh_rec *r = &w->rec[k];
+        const size_t i = w->rec0 + k;
+        const uint32_t x = st->h_res[i], len = FXG_RES_LEN(x);
+        if (!FXG_RES_KEEP(x)) continue;
+        if (job->revcomp) {
+            k2 += fxh_emit(fx, r, st->h_out_bases + opos, st->h_out_qual ? st->h_out_qual + opos : NULL, len, 0, d + k2);
+            opos += len;
+        } else if (r->is_ascii) {
+            k2 += fxh_emit(fx, r, (const uint8_t *)r->seq + job->fwd_start, (const uint8_t *)r->qual + job->fwd_start, len, 1, d + k2);
+        } else {
+            k2 += fxh_emit(fx, r, (const uint8_t *)r->seq + job->fwd_start, st->h_qual + i * job->stride + job->fwd_start, len, 0, d + k2);
+        }
+    }
+    w->out_bytes = k2;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* I/O overlap: one thread reads the next block while the current one is processed, another one     */
+/* writes the previous output while the next is being formatted                                     */
+/* ---------------------------------------------------------------------------------------------- */
+#include <errno.h>
+#define FXH_GAP_MAX ((size_t)1 << 20)  /* room in front of a prefetched block for the previous block's unread tail */
+
+typedef struct {
+    pthread_t th;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    int fd, started;
+    /* request / response, protected by mu */
+    size_t gap;                        /* min(1 MB, cap / 4) */
+    char *buf; size_t cap;             /* buffer to fill: data goes to buf[gap, cap) */
+    size_t filled; int eof;
+    int state;                         /* 0 idle, 1 requested, 2 done, 3 quit */
+} fxh_prefetch;
+
+static void *fxh_prefetch_main(void *arg)
+{
+    fxh_prefetch *pf = (fxh_prefetch *)arg;
+    pthread_mutex_lock(&pf->mu);
+    for (;;) {
+        while (pf->state != 1 && pf->state != 3) pthread_cond_wait(&pf->cv, &pf->mu);
+        if (pf->state == 3) break;
+        char *buf = pf->buf; const size_t cap = pf->cap;
+        pthread_mutex_unlock(&pf->mu);
+        size_t got = 0; int eof = 0;
+        const size_t gap = pf->gap;
+        while (gap + got < cap) {
+            ssize_t k = read(pf->fd, buf + gap + got, cap - gap - got);
+            if (k < 0) { if (errno == EINTR) continue; err(1, "read failed"); }
+            if (k == 0) { eof = 1; break; }
+            got += (size_t)k;
+        }
+        pthread_mutex_lock(&pf->mu);
+        pf->filled = got; pf->eof = eof; pf->state = 2;
+        pthread_cond_broadcast(&pf->cv);
+    }
+    pthread_mutex_unlock(&pf->mu);
+    return NULL;
+}
+
+static void fxh_prefetch_request(fxh_prefetch *pf, char *buf, size_t cap)
+{
+    pthread_mutex_lock(&pf->mu);
+    pf->buf = buf; pf->cap = cap; pf->state = 1;
+    pthread_cond_broadcast(&pf->cv);
+    pthread_mutex_unlock(&pf->mu);
+}
+
+/* Make the next block current: [unread tail of the old block | prefetched data]; hand the old buffer back to the thread. */
+static void fxh_next_block(fxh_prefetch *pf, struct fxh_reader *rd, char **spare)
+{
+    if (!pf->started) {                /* first block: synchronous, then start reading ahead */
+        fxh_reader_fill(rd);
+        if (!rd->eof) {
+            pthread_mutex_init(&pf->mu, NULL); pthread_cond_init(&pf->cv, NULL);
+            pf->fd = rd->fd; pf->state = 0; pf->started = 1;
+            pf->gap = rd->cap / 4 < FXH_GAP_MAX ? rd->cap / 4 : FXH_GAP_MAX;
+            if (pthread_create(&pf->th, NULL, fxh_prefetch_main, pf) != 0) err(1, "pthread_create");
+            *spare = (char *)malloc(rd->cap + 1);
+            if (!*spare) err(1, "out of memory");
+            fxh_prefetch_request(pf, *spare, rd->cap);
+        }
+        return;
+    }
+    if (rd->eof) return;               /* everything has been read already; only the tail remains in rd */
+    pthread_mutex_lock(&pf->mu);
+    while (pf->state != 2) pthread_cond_wait(&pf->cv, &pf->mu);
+    pf->state = 0;
+    char *nb = pf->buf; const size_t filled = pf->filled; const int eof = pf->eof;
+    pthread_mutex_unlock(&pf->mu);
+    const size_t tail = rd->end - rd->beg;
+    if (tail > pf->gap) errx(1, "input record longer than %zu bytes", pf->gap);
+    memcpy(nb + pf->gap - tail, rd->buf + rd->beg, tail);
+    char *old = rd->buf;
+    rd->buf = nb; rd->beg = pf->gap - tail; rd->end = pf->gap + filled; rd->eof = eof;
+    *spare = old;
+    if (!eof) fxh_prefetch_request(pf, old, rd->cap);
+}
+
+static void fxh_prefetch_stop(fxh_prefetch *pf)
+{
+    if (!pf->started) return;
+    pthread_mutex_lock(&pf->mu);
+    while (pf->state == 1) pthread_cond_wait(&pf->cv, &pf->mu);
+    pf->state = 3;
+    pthread_cond_broadcast(&pf->cv);
+    pthread_mutex_unlock(&pf->mu);
+    pthread_join(pf->th, NULL);
+}
+
+typedef struct {
+    pthread_t th;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    int fd, started;
+    const char *buf; size_t len;
+    int state;                         /* 0 idle, 1 pending, 3 quit */
+} fxh_awriter;
+
+static void *fxh_awriter_main(void *arg)
+{
+    fxh_awriter *aw = (fxh_awriter *)arg;
+    pthread_mutex_lock(&aw->mu);
+    for (;;) {
+        while (aw->state != 1 && aw->state != 3) pthread_cond_wait(&aw->cv, &aw->mu);
+        if (aw->state == 3) break;
+        const char *b = aw->buf; size_t n = aw->len;
+        pthread_mutex_unlock(&aw->mu);
+        size_t off = 0;
+        while (off < n) {
+            ssize_t k = write(aw->fd, b + off, n - off);
+            if (k < 0) { if (errno == EINTR) continue; err(1, "writing output failed"); }
+            off += (size_t)k;
+        }
+        pthread_mutex_lock(&aw->mu);
+        aw->state = 0;
+        pthread_cond_broadcast(&aw->cv);
+    }
+    pthread_mutex_unlock(&aw->mu);
+    return NULL;
+}
+
+static void fxh_awriter_wait(fxh_awriter *aw)
+{
+    if (!aw->started) return;
+    pthread_mutex_lock(&aw->mu);
+    while (aw->state == 1) pthread_cond_wait(&aw->cv, &aw->mu);
+    pthread_mutex_unlock(&aw->mu);
+}
+
+/* hand the writer's filled buffer to the thread and continue formatting into the other one */
+static void fxh_awriter_submit(fxh_awriter *aw, struct fxh_writer *w, char **spare, size_t *spare_cap)
+{
+    if (!aw->started) {
+        pthread_mutex_init(&aw->mu, NULL); pthread_cond_init(&aw->cv, NULL);
+        aw->fd = w->fd; aw->state = 0; aw->started = 1;
+        if (pthread_create(&aw->th, NULL, fxh_awriter_main, aw) != 0) err(1, "pthread_create");
+    }
+    fxh_awriter_wait(aw);              /* the other buffer is free again */
+    if (!*spare) { *spare_cap = w->cap; *spare = (char *)malloc(*spare_cap); if (!*spare) err(1, "out of memory"); }
+    pthread_mutex_lock(&aw->mu);
+    aw->buf = w->buf; aw->len = w->len; aw->state = 1;
+    pthread_cond_broadcast(&aw->cv);
+    pthread_mutex_unlock(&aw->mu);
+    char *t = w->buf; size_t tc = w->cap;
+    w->buf = *spare; w->cap = *spare_cap; w->len = 0;
+    *spare = t; *spare_cap = tc;
+}
+
+static void fxh_awriter_stop(fxh_awriter *aw)
+{
+    if (!aw->started) return;
+    fxh_awriter_wait(aw);
+    pthread_mutex_lock(&aw->mu);
+    aw->state = 3;
+    pthread_cond_broadcast(&aw->cv);
+    pthread_mutex_unlock(&aw->mu);
+    pthread_join(aw->th, NULL);
 }
 
 int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *tot)
@@ -129,143 +481,200 @@ int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *tot)
     fxh_state st;
     memset(&st, 0, sizeof st);
     memset(tot, 0, sizeof *tot);
+    const int timing = getenv("FXH_TIMING") != NULL;
+    double t_init = fxh_now(), t_read = 0, t_index = 0, t_pack = 0, t_gpu = 0, t_fmt = 0, t0;
     {
         const char *dev = getenv("FXG_DEVICE");
         int rc = fxg_ctx_create(dev ? atoi(dev) : 0, &st.ctx);
         if (rc != 0) errx(1, "no usable MI355X/HIP device (fxg_ctx_create = %d); this build has no CPU path", rc);
     }
     FXG_CHECK(&st, fxg_malloc_device(st.ctx, FXG_NCOUNTERS * sizeof(uint64_t), (void **)&st.d_counters));
-    const int revcomp = (p->stages & FXG_STAGE_REVCOMP) != 0;
-    const int has_q = fx->read_fastq;
-    const uint32_t fwd_start = (p->stages & FXG_STAGE_FTRIM) && p->ft_first > 1 ? (uint32_t)p->ft_first - 1u : 0u;
-    const size_t max_batch = 4u << 20;   /* reads per engine call */
+    t_init = fxh_now() - t_init;
     struct fxh_reader *rd = fx->reader;
-    struct fxh_rawrec raw;
-    memset(&raw, 0, sizeof raw);
-    raw.defer_errors = 1;
-    char errmsg[sizeof raw.errmsg];
+    if (!getenv("FXH_READ_BUFFER_MB")) fxh_reader_reserve(rd, (size_t)64 << 20);   /* one engine call per 64 MB of text */
+    fxh_job job;
+    memset(&job, 0, sizeof job);
+    job.fx = fx; job.st = &st; job.p = p;
+    job.revcomp = (p->stages & FXG_STAGE_REVCOMP) != 0;
+    job.has_q = fx->read_fastq;
+    job.lpr = fx->read_fastq ? 4 : 2;
+    job.fwd_start = (p->stages & FXG_STAGE_FTRIM) && p->ft_first > 1 ? (uint32_t)p->ft_first - 1u : 0u;
+    {
+        const char *te = getenv("FXH_THREADS");
+        long nt = te ? atol(te) : 16, ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+        if (nt < 1) nt = 1;
+        if (nt > 64) nt = 64;
+        if (ncpu > 0 && nt > ncpu) nt = ncpu;
+        job.nworkers = (int)nt;
+    }
+    job.w = (fxh_worker *)calloc((size_t)job.nworkers, sizeof(fxh_worker));
+    if (!job.w) err(1, "out of memory");
+    for (int i = 0; i < job.nworkers; ++i) {
+        fxh_worker *w = &job.w[i];
+        w->id = i; w->job = &job;
+        w->shadow = (FASTX *)malloc(sizeof(FASTX));
+        if (!w->shadow) err(1, "out of memory");
+        memcpy(w->shadow, fx, sizeof(FASTX));
+        w->raw.defer_errors = 1;
+    }
+    char errmsg[768];
     int have_err = 0, at_eof = 0;
+    fxh_prefetch pf;
+    fxh_awriter aw;
+    memset(&pf, 0, sizeof pf);
+    memset(&aw, 0, sizeof aw);
+    char *rd_spare = NULL, *wr_spare = NULL;
+    size_t wr_spare_cap = 0;
+    const int overlap = getenv("FXH_NO_OVERLAP") == NULL;
 
     while (!at_eof && !have_err) {
-        /* ---- 1. index the records that are completely inside the buffer ---- */
-        fxh_reader_fill(rd);
-        size_t n = 0, maxlen = 0, minlen = (size_t)-1;
-        const unsigned long long first_line = fx->input_line_number;
-        for (;;) {
-            if (n == max_batch) break;
-            int rc = fxh_next_raw(fx, &raw, 0);
-            if (rc == 0) { at_eof = 1; break; }
-            if (rc == -1) {
-                if (n == 0) errx(1, "input record does not fit in the %zu MB read buffer", rd->cap >> 20);
-                break;
-            }
-            if (rc == -2) { have_err = 1; memcpy(errmsg, raw.errmsg, sizeof errmsg); break; }
-            if (n == st.rec_cap) {
-                st.rec_cap = st.rec_cap ? st.rec_cap * 2 : (1u << 16);
-                st.rec = (fxh_rec *)realloc(st.rec, st.rec_cap * sizeof(fxh_rec));
-                if (!st.rec) err(1, "out of memory");
-            }
-            fxh_rec *r = &st.rec[n++];
-            r->name = raw.name; r->seq = raw.seq; r->name2 = raw.name2; r->qual = raw.qual;
-            r->name_len = (uint32_t)raw.name_len; r->seq_len = (uint32_t)raw.seq_len;
-            r->name2_len = (uint32_t)raw.name2_len; r->qual_len = (uint32_t)raw.qual_len;
-            r->is_ascii = (uint8_t)raw.is_ascii;
-            r->reads_count = (uint32_t)fxh_reads_count(fx, raw.name, raw.name_len);
-            if (raw.seq_len > maxlen) maxlen = raw.seq_len;
-            if (raw.seq_len < minlen) minlen = raw.seq_len;
+        /* ---- 1. fill the block, split it into record-aligned ranges, index + validate them in parallel ---- */
+        t0 = fxh_now();
+        if (overlap) fxh_next_block(&pf, rd, &rd_spare); else fxh_reader_fill(rd);
+        t_read += fxh_now() - t0; t0 = fxh_now();
+        const size_t beg = rd->beg, end = rd->end;
+        if (beg == end && rd->eof) break;
+        const int T = job.nworkers;
+        for (int i = 0; i < T; ++i) {
+            job.w[i].a0 = beg + (size_t)((unsigned long long)(end - beg) * (unsigned)i / (unsigned)T);
+            job.w[i].a1 = beg + (size_t)((unsigned long long)(end - beg) * (unsigned)(i + 1) / (unsigned)T);
         }
-        if (n == 0) break;
+        fxh_parallel(&job, fxh_phase_census);
+        {
+            /* worker i starts at the first record boundary at or after a0: lines are counted from the block start,
+             * which is itself a record boundary (the previous block stopped at one) */
+            unsigned long long lines_before = 0;          /* complete lines in [beg, a0) */
+            for (int i = 0; i < T; ++i) {
+                fxh_worker *w = &job.w[i];
+                size_t s;
+                unsigned long long ls;                    /* complete lines in [beg, s) */
+                if (i == 0) { s = beg; ls = 0; }
+                else if (w->first_nl == (size_t)-1) { s = (size_t)-1; ls = 0; }       /* no line starts here: same boundary as the next range */
+                else {
+                    s = w->first_nl + 1; ls = lines_before + 1;
+                    while (ls % (unsigned)job.lpr != 0) {         /* walk to the next record boundary */
+                        const char *q = s < end ? (const char *)memchr(rd->buf + s, '\n', end - s) : NULL;
+                        if (!q) { s = end; break; }
+                        s = (size_t)(q - rd->buf) + 1; ls++;
+                    }
+                }
+                if (s != (size_t)-1 && s > end) s = end;
+                w->start = s;
+                w->start_line = fx->input_line_number + ls;
+                lines_before += w->nl_count;
+            }
+            for (int i = T - 1; i >= 0; --i)                      /* ranges without a line start are empty */
+                if (job.w[i].start == (size_t)-1) job.w[i].start = (i + 1 < T) ? job.w[i + 1].start : end;
+            for (int i = 0; i < T; ++i) {
+                fxh_worker *w = &job.w[i];
+                w->view.buf = rd->buf; w->view.cap = rd->cap; w->view.fd = -1;
+                w->view.beg = w->start;
+                w->view.end = (i + 1 < T) ? job.w[i + 1].start : end;
+                w->view.eof = 0;
+            }
+            /* the last non-empty range owns the end-of-input / incomplete-tail semantics */
+            for (int i = T - 1; i >= 0; --i)
+                if (job.w[i].view.beg < end || i == 0) { job.w[i].view.end = end; job.w[i].view.eof = rd->eof; break; }
+        }
+        fxh_parallel(&job, fxh_phase_index);
+        /* merge in input order; the first error / end condition wins */
+        size_t n = 0, maxlen = 0, minlen = (size_t)-1;
+        int stop = -1;                                   /* worker at which the batch ends */
+        for (int i = 0; i < T; ++i) {
+            fxh_worker *w = &job.w[i];
+            w->rec0 = n; w->use = w->nrec;
+            n += w->nrec;
+            if (w->nrec) { if (w->maxlen > maxlen) maxlen = w->maxlen; if (w->minlen < minlen) minlen = w->minlen; }
+            const int is_last = (w->view.end == end);
+            if (w->rc_end == -2) { have_err = 1; memcpy(errmsg, w->errmsg, sizeof errmsg); stop = i; }
+            else if (w->rc_end == 0) { at_eof = 1; stop = i; }
+            else if (is_last) stop = i;
+            if (stop >= 0) { rd->beg = w->end_pos; fx->input_line_number = w->end_line; break; }
+        }
+        for (int i = stop + 1; i < T; ++i) { job.w[i].use = 0; job.w[i].rec0 = n; }
+        if (n == 0) {
+            if (!have_err && !at_eof) errx(1, "input record does not fit in the %zu MB read buffer", rd->cap >> 20);
+            break;
+        }
+        t_index += fxh_now() - t0; t0 = fxh_now();
 
         /* ---- 2. pack the SoA rows (qualities normalised to Phred+33 codes) ---- */
-        uint32_t stride = (uint32_t)maxlen;
-        fxh_grow(&st, n, n * (size_t)stride, revcomp);
-        {
-            unsigned long long line = first_line;   /* line number of the quality line for deferred messages */
-            for (size_t i = 0; i < n; ++i) {
-                const fxh_rec *r = &st.rec[i];
-                memcpy(st.h_bases + i * stride, r->seq, r->seq_len);
-                st.h_len[i] = (uint16_t)r->seq_len;
-                line += has_q ? 4 : 2;
-                if (!has_q) continue;
-                uint8_t *q = st.h_qual + i * stride;
-                if (r->is_ascii && fx->fastq_ascii_quality_offset == 33) {
-                    uint8_t bad = 0;
-                    for (uint32_t j = 0; j < r->qual_len; ++j) { const uint8_t c = (uint8_t)r->qual[j]; bad |= (uint8_t)((c < 18) | (c > 126)); }
-                    if (!bad) { memcpy(q, r->qual, r->qual_len); continue; }
-                }
-                raw.seq_len = r->seq_len; raw.qual = r->qual; raw.qual_len = r->qual_len; raw.is_ascii = r->is_ascii;
-                const unsigned long long save = fx->input_line_number;
-                fx->input_line_number = line;
-                const int qrc = fxh_decode_quality(fx, &raw, NULL, q);
-                fx->input_line_number = save;
-                if (qrc != 0) {                 /* first bad record wins: drop it and everything after it */
-                    have_err = 1; at_eof = 0;
-                    memcpy(errmsg, raw.errmsg, sizeof errmsg);
-                    n = i;
-                    break;
-                }
+        job.stride = (uint32_t)maxlen;
+        fxh_grow(&st, n, n * (size_t)job.stride, job.revcomp);
+        fxh_parallel(&job, fxh_phase_pack);
+        for (int i = 0; i <= stop; ++i) {
+            fxh_worker *w = &job.w[i];
+            if (w->bad_q >= 0) {                       /* first bad record wins: drop it and everything after it */
+                have_err = 1; at_eof = 0;
+                memcpy(errmsg, w->errmsg, sizeof errmsg);
+                n = w->rec0 + (size_t)w->bad_q;
+                w->use = (size_t)w->bad_q;
+                for (int j = i + 1; j < T; ++j) job.w[j].use = 0;
+                break;
             }
         }
-        if (n == 0) break;
+        t_pack += fxh_now() - t0; t0 = fxh_now();
+        if (n > 0) {
+            /* ---- 3. engine ---- */
+            const uint32_t stride = job.stride;
+            const size_t bytes = n * (size_t)stride;
+            const int fixed = (minlen == maxlen);
+            FXG_CHECK(&st, fxg_memcpy_h2d(st.ctx, st.d_bases, st.h_bases, bytes));
+            if (job.has_q) FXG_CHECK(&st, fxg_memcpy_h2d(st.ctx, st.d_qual, st.h_qual, bytes));
+            if (!fixed) FXG_CHECK(&st, fxg_memcpy_h2d(st.ctx, st.d_len, st.h_len, n * sizeof(uint16_t)));
+            fxg_batch in = {st.d_bases, job.has_q ? st.d_qual : NULL, fixed ? NULL : st.d_len, (uint32_t)maxlen, stride, n};
+            fxg_out out = {st.d_res, job.revcomp ? st.d_out_bases : NULL, (job.revcomp && job.has_q) ? st.d_out_qual : NULL, NULL, NULL, NULL, st.d_counters};
+            fxg_params pp = *p;
+            pp.qoffset = 33;                        /* rows hold Phred+33 codes whatever -Q was */
+            FXG_CHECK(&st, fxg_run_pipeline(st.ctx, &in, &pp, &out));
+            FXG_CHECK(&st, fxg_memcpy_d2h(st.ctx, st.h_res, st.d_res, n * sizeof(uint32_t)));
+            uint64_t ctr[FXG_NCOUNTERS];
+            {
+                int rc = fxg_read_counters(st.ctx, st.d_counters, ctr);   /* synchronises */
+                if (rc == FXG_E_DEVICE && (ctr[FXG_C_ERRORS] & FXG_DEV_ERR_BAD_BASE)) errx(1, "%s", fxg_last_error(st.ctx));
+                if (rc != 0) errx(1, "GPU engine error %d: %s", rc, fxg_last_error(st.ctx));
+            }
+            if (job.revcomp) {
+                FXG_CHECK(&st, fxg_memcpy_d2h(st.ctx, st.h_out_bases, st.d_out_bases, ctr[FXG_C_KEPT_BASES]));
+                if (job.has_q) FXG_CHECK(&st, fxg_memcpy_d2h(st.ctx, st.h_out_qual, st.d_out_qual, ctr[FXG_C_KEPT_BASES]));
+                FXG_CHECK(&st, fxg_sync(st.ctx));
+            }
+            t_gpu += fxh_now() - t0; t0 = fxh_now();
 
-        /* ---- 3. engine ---- */
-        const size_t bytes = n * (size_t)stride;
-        const int fixed = (minlen == maxlen);
-        FXG_CHECK(&st, fxg_memcpy_h2d(st.ctx, st.d_bases, st.h_bases, bytes));
-        if (has_q) FXG_CHECK(&st, fxg_memcpy_h2d(st.ctx, st.d_qual, st.h_qual, bytes));
-        if (!fixed) FXG_CHECK(&st, fxg_memcpy_h2d(st.ctx, st.d_len, st.h_len, n * sizeof(uint16_t)));
-        fxg_batch in = {st.d_bases, has_q ? st.d_qual : NULL, fixed ? NULL : st.d_len, (uint32_t)maxlen, stride, n};
-        fxg_out out = {st.d_res, revcomp ? st.d_out_bases : NULL, (revcomp && has_q) ? st.d_out_qual : NULL, NULL, NULL, NULL, st.d_counters};
-        fxg_params pp = *p;
-        pp.qoffset = 33;                        /* rows hold Phred+33 codes whatever -Q was */
-        FXG_CHECK(&st, fxg_run_pipeline(st.ctx, &in, &pp, &out));
-        FXG_CHECK(&st, fxg_memcpy_d2h(st.ctx, st.h_res, st.d_res, n * sizeof(uint32_t)));
-        uint64_t ctr[FXG_NCOUNTERS];
-        {
-            int rc = fxg_read_counters(st.ctx, st.d_counters, ctr);   /* synchronises */
-            if (rc == FXG_E_DEVICE && (ctr[FXG_C_ERRORS] & FXG_DEV_ERR_BAD_BASE)) errx(1, "%s", fxg_last_error(st.ctx));
-            if (rc != 0) errx(1, "GPU engine error %d: %s", rc, fxg_last_error(st.ctx));
-        }
-        if (revcomp) {
-            FXG_CHECK(&st, fxg_memcpy_d2h(st.ctx, st.h_out_bases, st.d_out_bases, ctr[FXG_C_KEPT_BASES]));
-            if (has_q) FXG_CHECK(&st, fxg_memcpy_d2h(st.ctx, st.h_out_qual, st.d_out_qual, ctr[FXG_C_KEPT_BASES]));
-            FXG_CHECK(&st, fxg_sync(st.ctx));
-        }
-
-        /* ---- 4. write the kept records in input order, tally the report counters ---- */
-        size_t opos = 0;
-        for (size_t i = 0; i < n; ++i) {
-            const fxh_rec *r = &st.rec[i];
-            const uint32_t w = st.h_res[i], len = FXG_RES_LEN(w), rc_ = r->reads_count;
-            tot->input_sequences++; tot->input_reads += rc_;
-            tot->clip_input += rc_;
-            if (FXG_RES_ADAPTER_ONLY(w)) tot->clip_adapter_only += rc_;
-            switch (FXG_RES_REASON(w)) {
-            case FXG_R_CLIP_TOO_SHORT: tot->clip_too_short += rc_; break;
-            case FXG_R_CLIP_NO_ADAPTER: tot->clip_no_adapter += rc_; break;
-            case FXG_R_CLIP_ADAPTER_FOUND: tot->clip_adapter_found += rc_; break;
-            case FXG_R_CLIP_N: tot->clip_n += rc_; break;
-            default: break;
+            /* ---- 4. format the kept records in input order (each worker its own slice), tally the report counters ---- */
+            fxh_parallel(&job, fxh_phase_size);
+            size_t total = 0, kept_total = 0;
+            for (int i = 0; i < T; ++i) {
+                fxh_worker *w = &job.w[i];
+                w->out_off = total; w->kept_off = kept_total;
+                total += w->out_bytes; kept_total += w->kept_bytes;
+                tot->input_sequences += w->tot.input_sequences; tot->input_reads += w->tot.input_reads;
+                tot->output_sequences += w->tot.output_sequences; tot->output_reads += w->tot.output_reads;
+                tot->clip_input += w->tot.clip_input; tot->clip_too_short += w->tot.clip_too_short;
+                tot->clip_adapter_only += w->tot.clip_adapter_only; tot->clip_no_adapter += w->tot.clip_no_adapter;
+                tot->clip_adapter_found += w->tot.clip_adapter_found; tot->clip_n += w->tot.clip_n;
             }
-            if (!FXG_RES_KEEP(w)) continue;
-            tot->output_sequences++; tot->output_reads += rc_;
-            if (revcomp) {
-                fxh_emit(fx, r, st.h_out_bases + opos, st.h_out_qual ? st.h_out_qual + opos : NULL, len, 0);
-                opos += len;
-            } else if (r->is_ascii) {
-                fxh_emit(fx, r, (const uint8_t *)r->seq + fwd_start, (const uint8_t *)r->qual + fwd_start, len, 1);
-            } else {
-                fxh_emit(fx, r, (const uint8_t *)r->seq + fwd_start, st.h_qual + i * stride + fwd_start, len, 0);
-            }
+            struct fxh_writer *wr = fx->writer;
+            job.out_dst = fxh_writer_reserve(wr, total + 16);
+            fxh_parallel(&job, fxh_phase_format);
+            wr->len += total;
+            if (overlap) fxh_awriter_submit(&aw, wr, &wr_spare, &wr_spare_cap); else fxh_writer_flush(wr);
+            fx->num_input_sequences = tot->input_sequences; fx->num_input_reads = tot->input_reads;
+            fx->num_output_sequences = tot->output_sequences; fx->num_output_reads = tot->output_reads;
+            t_fmt += fxh_now() - t0;
         }
-        fx->num_input_sequences = tot->input_sequences; fx->num_input_reads = tot->input_reads;
-        fx->num_output_sequences = tot->output_sequences; fx->num_output_reads = tot->output_reads;
     }
+    fxh_awriter_stop(&aw);
+    fxh_prefetch_stop(&pf);
     if (have_err) {
         fxh_writer_flush(fx->writer);   /* every record before the bad one has been written, like the reference */
         errx(1, "%s", errmsg);
     }
+    if (timing)
+        fprintf(stderr, "fxh timing (%d threads): init %.3f read %.3f index %.3f pack %.3f gpu(h2d+kernel+d2h) %.3f format+write %.3f s\n",
+                job.nworkers, t_init, t_read, t_index, t_pack, t_gpu, t_fmt);
     fxg_ctx_destroy(st.ctx);
-    free(st.rec);
+    for (int i = 0; i < job.nworkers; ++i) { free(job.w[i].rec); free(job.w[i].shadow); }
+    free(job.w);
     return 0;
 }

@@ -32,6 +32,7 @@ struct fxh_rawrec {
 };
 
 struct fxh_reader *fxh_reader_open(const char *filename, size_t capacity);
+void   fxh_reader_reserve(struct fxh_reader *r, size_t capacity);
 void   fxh_reader_fill(struct fxh_reader *r);
 int    fxh_reader_peek(struct fxh_reader *r);
 int    fxh_reader_line(struct fxh_reader *r, const char **p, size_t *raw, int may_refill);

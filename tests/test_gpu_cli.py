@@ -110,7 +110,8 @@ def test_fuzz_cli_vs_reference(tools):
                  ["fastx_reverse_complement", "-v"],
                  ["fastx_clipper", "-a", ad.decode(), "-l", str(int(rng.integers(0, 25))), "-v"] + list(rng.choice(["-n", "-c", "-C", "-k"], size=2, replace=False))]
         for argv in argvs:
-            rc, out, err = _run([os.path.join(tools, argv[0])] + argv[1:], data)
+            env = dict(os.environ, FXH_THREADS=str([16, 1, 3, 7][trial % 4]), FXH_READ_BUFFER_MB="1")
+            rc, out, err = _run([os.path.join(tools, argv[0])] + argv[1:], data, env)
             rrc, rout, rerr = _run([REF] + argv, data)
             assert (rc, out) == (rrc, rout), (trial, argv)
             assert _msg(err) == _msg(rerr), (trial, argv)
