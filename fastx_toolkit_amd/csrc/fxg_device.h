@@ -15,6 +15,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // pure per-thread helpers are __host__ __device__ so that tests/emu can run them on the CPU
 #define FXG_HD __host__ __device__ __forceinline__
 
+// timing-ablation switches exist only in -DFXG_ABLATION builds (scripts/ablate.py); the product build folds them to 0
+#ifdef FXG_ABLATION
+#define FXG_DBG(a, bit) ((a).debug & (bit))
+#else
+#define FXG_DBG(a, bit) 0u
+#endif
+
 #define FXG_BLOCK 256           // threads per workgroup = 4 wave64
 #define FXG_WAVES (FXG_BLOCK / 64)
 #define FXG_MAX_TILE 256        // reads per tile (one thread decides one read)
@@ -394,7 +401,7 @@ FXG_HD u32 fxg_tile_gather(const FxgKArgs &a, const u32 *v_off, const u32 *v_src
                            u64 tile_in_base, u64 B, u32 S, u32 tid, u32 nthreads)
 {
     if (S == 0) return 0u;
-    const bool has_q = a.qual != nullptr && a.out_qual != nullptr && !(a.debug & 4u);
+    const bool has_q = a.qual != nullptr && a.out_qual != nullptr && !FXG_DBG(a, 4u);
     // wave-uniform 64-bit quantities
     const u64 c_first = B >> 4;
     const u32 nchunks = (u32)(((B + S - 1) >> 4) - c_first) + 1u;

@@ -199,7 +199,9 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
         c->partial_cap = FXG_COUNT_GRID;
     }
     ka.partial = c->partial;
+#ifdef FXG_ABLATION
     { const char *dbg = getenv("FXG_DEBUG"); ka.debug = dbg ? (u32)atoi(dbg) : 0u; }
+#endif
     ka.errflag = c->errflag;
     ka.ticket = c->errflag + FXG_TICKET_STRIDE;
     { const char *tg = getenv("FXG_TICKET_GROUPS"); u32 g = (tg && atoi(tg) > 0 && atoi(tg) <= FXG_TICKET_GROUPS) ? (u32)atoi(tg) : FXG_TICKET_GROUPS; ka.ticket_groups = g < grid ? g : (u32)grid; }

@@ -390,7 +390,7 @@ __global__ __launch_bounds__(FXG_BLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void fx
             const u64 tb = (u64)r0 * stride;
             const u32 tbytes = nreads * stride;
             if constexpr (MODE == 0) {
-                if (use_q && !(a.debug & 8u)) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, FXG_BLOCK);
+                if (use_q && !FXG_DBG(a, 8u)) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, FXG_BLOCK);
                 if constexpr (AMAX != 0) fxg_phase_stage_bases(a, tb, tbytes, sb, tid, FXG_BLOCK);
                 __syncthreads();
             }
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(FXG_BLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void fx
                 uint16_t *v_rank = reinterpret_cast<uint16_t *>(sl + L.so_vrank);
                 if (tid < nreads) { v_off[tid] = exb; v_src[tid] = anchor; v_rank[tid] = (uint16_t)exc; }
                 if (tid == 0) { v_off[nreads] = totb; s_tot[2 * slot] = totc; s_tot[2 * slot + 1] = totb; }
-                if (tid < 64 && !(a.debug & 2u)) fxg_publish_aggregate(a, cur, totc, totb);
+                if (tid < 64 && !FXG_DBG(a, 2u)) fxg_publish_aggregate(a, cur, totc, totb);
             }
         }
         // ------------------------------ stage B: tile `pend` from slot `slot ^ 1` ------------------------------
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(FXG_BLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void fx
             const uint16_t *v_rank = reinterpret_cast<const uint16_t *>(sl + L.so_vrank);
             if (tid < 64) {
                 u64 base_c = 0, base_b = 0;
-                if (!(a.debug & 2u)) fxg_resolve_prefix(a, pend, s_tot[2 * ps], s_tot[2 * ps + 1], &base_c, &base_b);
+                if (!FXG_DBG(a, 2u)) fxg_resolve_prefix(a, pend, s_tot[2 * ps], s_tot[2 * ps + 1], &base_c, &base_b);
                 if (tid == 0) { bc[0] = base_c; bc[1] = base_b; }
             }
             __syncthreads();
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(FXG_BLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void fx
                 const u32 olen = v_off[tid + 1] - v_off[tid];      // kept reads are never empty
                 if (olen) fxg_write_kept_meta(a, base_c + v_rank[tid], olen, r0 + tid, base_b + v_off[tid]);
             }
-            if (!(a.debug & 1u)) {
+            if (!FXG_DBG(a, 1u)) {
                 const u32 bad = fxg_tile_gather<REV>(a, v_off, v_src, nreads, (u64)r0 * stride, base_b, totb, tid, FXG_BLOCK);
                 if (REV && bad) atomicOr(a.errflag, FXG_DEV_ERR_BAD_BASE);
             }
