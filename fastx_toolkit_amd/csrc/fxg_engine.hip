@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "fxg_plan.h"
+#include "fxg_text.h"
 
 struct fxg_ctx {
     int device;
@@ -22,6 +23,9 @@ struct fxg_ctx {
     size_t partial_cap;
     u32 *errflag;           // [0] device error bits; tile dispensers start at word FXG_TICKET_STRIDE
     u64 *counters_scratch;  // used when the caller passes no counter block
+    u64 *text_ws;           // newline census / scan levels / format items
+    size_t text_ws_cap;     // in u64 words
+    FxgTextState *text_state;
     char err[512];
     char last_kernel[96];
     u32 last_grid, last_block, last_lds, last_tile;
@@ -78,6 +82,7 @@ extern "C" void fxg_ctx_destroy(fxg_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->status); (void)hipFree(c->partial); (void)hipFree(c->errflag); (void)hipFree(c->counters_scratch);
+    (void)hipFree(c->text_ws); (void)hipFree(c->text_state);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipEventDestroy(c->kev0); (void)hipEventDestroy(c->kev1);
     (void)hipStreamDestroy(c->own_stream);
@@ -334,6 +339,153 @@ extern "C" int fxg_synth_generate(fxg_ctx *c, uint64_t seed, uint64_t first, uin
     hipLaunchKernelGGL(fxg_kernel_synth, dim3((u32)blocks), dim3(FXG_BLOCK), lds, c->stream, (u64)seed, (u64)first, (u64)n, L,
                        with_adapter, bases, qual, stride);
     FXG_HIP(c, hipGetLastError());
+    return FXG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// FASTQ text on the device
+// ------------------------------------------------------------------------------------------------
+static int fxg_text_reserve(fxg_ctx *c, size_t words)
+{
+    if (!c->text_state) FXG_HIP(c, hipMalloc((void **)&c->text_state, sizeof(FxgTextState)));
+    if (c->text_ws_cap >= words) return FXG_OK;
+    (void)hipFree(c->text_ws);
+    c->text_ws = nullptr; c->text_ws_cap = 0;
+    const size_t cap = words + words / 4 + 4096;
+    FXG_HIP(c, hipMalloc((void **)&c->text_ws, cap * sizeof(u64)));
+    c->text_ws_cap = cap;
+    return FXG_OK;
+}
+
+// in-place exclusive scan of data[0..n); tmp must hold the block-sum levels (n/1024 + n/1024^2 + ... + 8 words)
+static int fxg_scan_u64(fxg_ctx *c, u64 *data, u64 n, u64 *tmp)
+{
+    if (n == 0) return FXG_OK;
+    const u64 nb = (n + FXG_SCAN_PER_BLOCK - 1) / FXG_SCAN_PER_BLOCK;
+    hipLaunchKernelGGL(fxg_kernel_scan_blocks, dim3((u32)nb), dim3(FXG_BLOCK), 0, c->stream, data, n, tmp);
+    FXG_HIP(c, hipGetLastError());
+    if (nb > 1) {
+        const int rc = fxg_scan_u64(c, tmp, nb, tmp + nb);
+        if (rc != FXG_OK) return rc;
+        hipLaunchKernelGGL(fxg_kernel_scan_add, dim3((u32)nb), dim3(FXG_BLOCK), 0, c->stream, data, n, (const u64 *)tmp);
+        FXG_HIP(c, hipGetLastError());
+    }
+    return FXG_OK;
+}
+
+extern "C" int fxg_fastq_index(fxg_ctx *c, const uint8_t *d_text, uint64_t text_len, int at_eof, uint32_t *d_ls, uint64_t cap_lines,
+                               uint16_t *d_len, fxg_text_info *info)
+{
+    if (!c || !d_text || !d_ls || !d_len || !info) return FXG_E_INVALID;
+    memset(info, 0, sizeof *info);
+    info->first_bad = 0xFFFFFFFFu;
+    if (text_len == 0) return FXG_OK;
+    if (text_len > 0xFFFFFFF0ull) return fxg_fail(c, FXG_E_INVALID, "text block too large (%llu bytes)", (unsigned long long)text_len);
+    FXG_HIP(c, hipSetDevice(c->device));
+    const u64 nseg = (text_len + FXG_TEXT_SEG - 1) / FXG_TEXT_SEG;
+    int rc = fxg_text_reserve(c, (size_t)(nseg + nseg / 512 + 4096));
+    if (rc != FXG_OK) return rc;
+    FxgTextState init;
+    memset(&init, 0, sizeof init);
+    init.min_len = 0xFFFFFFFFu; init.first_bad = 0xFFFFFFFFu;
+    FXG_HIP(c, hipMemcpyAsync(c->text_state, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    u64 *seg = c->text_ws;
+    hipLaunchKernelGGL(fxg_kernel_nl_count, dim3((u32)nseg), dim3(FXG_BLOCK), 0, c->stream, d_text, (u64)text_len, seg, c->text_state);
+    FXG_HIP(c, hipGetLastError());
+    // total newlines = last exclusive prefix + last count: keep the last count before the scan overwrites it
+    u64 last_count = 0, last_off = 0;
+    FXG_HIP(c, hipMemcpyAsync(&last_count, seg + (nseg - 1), sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    rc = fxg_scan_u64(c, seg, nseg, seg + nseg);
+    if (rc != FXG_OK) return rc;
+    FXG_HIP(c, hipMemcpyAsync(&last_off, seg + (nseg - 1), sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    hipLaunchKernelGGL(fxg_kernel_nl_scatter, dim3((u32)nseg), dim3(FXG_BLOCK), 0, c->stream, d_text, (u64)text_len, (const u64 *)seg, d_ls, (u64)cap_lines);
+    FXG_HIP(c, hipGetLastError());
+    FXG_HIP(c, hipStreamSynchronize(c->stream));
+    const u64 lines = last_off + last_count;
+    info->lines = lines;
+    u64 n = lines / 4;
+    if (4 * n + 1 > cap_lines) n = (cap_lines - 1) / 4;
+    info->records = n;
+    if (n == 0) { if (at_eof && lines % 4 != 0) info->irregular |= FXG_TEXT_IRR_TAIL; return FXG_OK; }
+    hipLaunchKernelGGL(fxg_kernel_text_records, dim3((u32)((n + FXG_BLOCK - 1) / FXG_BLOCK)), dim3(FXG_BLOCK), 0, c->stream, d_text, (const u32 *)d_ls, n, d_len,
+                       c->text_state);
+    FXG_HIP(c, hipGetLastError());
+    FxgTextState st;
+    u32 consumed = 0;
+    FXG_HIP(c, hipMemcpyAsync(&st, c->text_state, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    FXG_HIP(c, hipMemcpyAsync(&consumed, d_ls + 4 * n, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    FXG_HIP(c, hipStreamSynchronize(c->stream));
+    info->consumed = consumed;
+    info->max_len = st.max_len; info->min_len = st.min_len;
+    info->irregular = st.irregular | (st.has_cr ? FXG_TEXT_IRR_CR : 0u);
+    info->first_bad = st.first_bad;
+    if (at_eof && (lines % 4 != 0 || consumed != text_len)) info->irregular |= FXG_TEXT_IRR_TAIL;
+    return FXG_OK;
+}
+
+extern "C" int fxg_fastq_pack(fxg_ctx *c, const uint8_t *d_text, uint64_t text_len, const uint32_t *d_ls, uint64_t n, uint32_t stride,
+                              int qoffset, uint8_t *d_bases, uint8_t *d_qual, uint32_t *irregular)
+{
+    if (!c || !d_text || !d_ls || !d_bases || !irregular || stride == 0) return FXG_E_INVALID;
+    *irregular = 0;
+    if (n == 0) return FXG_OK;
+    if ((((uintptr_t)d_bases | (uintptr_t)d_qual) & 15u) != 0) return fxg_fail(c, FXG_E_INVALID, "row arrays must be 16-byte aligned");
+    FXG_HIP(c, hipSetDevice(c->device));
+    const u64 nchunks = (n * (u64)stride + 15) >> 4;
+    u64 grid = (nchunks + FXG_BLOCK - 1) / FXG_BLOCK;
+    if (grid > 65536) grid = 65536;
+    FXG_HIP(c, hipMemsetAsync(&c->text_state->irregular, 0, sizeof(u32), c->stream));
+    hipLaunchKernelGGL(fxg_kernel_text_pack<false>, dim3((u32)grid), dim3(FXG_BLOCK), 0, c->stream, d_text, (u64)text_len, (const u32 *)d_ls, (u64)n, stride,
+                       qoffset, d_bases, c->text_state);
+    FXG_HIP(c, hipGetLastError());
+    if (d_qual) {
+        hipLaunchKernelGGL(fxg_kernel_text_pack<true>, dim3((u32)grid), dim3(FXG_BLOCK), 0, c->stream, d_text, (u64)text_len, (const u32 *)d_ls, (u64)n, stride,
+                           qoffset, d_qual, c->text_state);
+        FXG_HIP(c, hipGetLastError());
+    }
+    FXG_HIP(c, hipMemcpyAsync(irregular, &c->text_state->irregular, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    FXG_HIP(c, hipStreamSynchronize(c->stream));
+    return FXG_OK;
+}
+
+extern "C" int fxg_fastq_format(fxg_ctx *c, const uint8_t *d_text, const uint32_t *d_ls, uint64_t n, const uint32_t *d_res, uint32_t fwd_start,
+                                const uint8_t *d_pk_bases, const uint8_t *d_pk_qual, const uint64_t *d_pk_off, int qoffset, uint8_t *d_out,
+                                uint64_t *out_bytes)
+{
+    if (!c || !d_text || !d_ls || !d_res || !d_out || !out_bytes) return FXG_E_INVALID;
+    *out_bytes = 0;
+    if (n == 0) return FXG_OK;
+    if (d_pk_bases && (!d_pk_qual || !d_pk_off)) return fxg_fail(c, FXG_E_INVALID, "packed output needs bases, qual and out_off");
+    FXG_HIP(c, hipSetDevice(c->device));
+    int rc = fxg_text_reserve(c, (size_t)(n + n / 512 + 4096));
+    if (rc != FXG_OK) return rc;
+    u64 *item = c->text_ws;
+    const u32 nb = (u32)((n + FXG_BLOCK - 1) / FXG_BLOCK);
+    hipLaunchKernelGGL(fxg_kernel_text_sizes, dim3(nb), dim3(FXG_BLOCK), 0, c->stream, (const u32 *)d_ls, (const u32 *)d_res, (u64)n, item);
+    FXG_HIP(c, hipGetLastError());
+    u64 last_item = 0, last_scan = 0;
+    FXG_HIP(c, hipMemcpyAsync(&last_item, item + (n - 1), sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    rc = fxg_scan_u64(c, item, n, item + n);
+    if (rc != FXG_OK) return rc;
+    FXG_HIP(c, hipMemcpyAsync(&last_scan, item + (n - 1), sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    hipLaunchKernelGGL(fxg_kernel_text_format, dim3((u32)((n * 16 + FXG_BLOCK - 1) / FXG_BLOCK)), dim3(FXG_BLOCK), 0, c->stream, d_text, (const u32 *)d_ls,
+                       (const u32 *)d_res, (const u64 *)item, (u64)n, fwd_start, d_pk_bases, d_pk_qual, (const u64 *)d_pk_off, qoffset, d_out);
+    FXG_HIP(c, hipGetLastError());
+    FXG_HIP(c, hipStreamSynchronize(c->stream));
+    *out_bytes = ((last_scan + last_item) & ((1ull << 40) - 1ull));
+    return FXG_OK;
+}
+
+extern "C" int fxg_host_register(fxg_ctx *c, void *ptr, size_t bytes)
+{
+    if (!c || !ptr) return FXG_E_INVALID;
+    FXG_HIP(c, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return FXG_OK;
+}
+extern "C" int fxg_host_unregister(fxg_ctx *c, void *ptr)
+{
+    if (!c || !ptr) return FXG_E_INVALID;
+    FXG_HIP(c, hipHostUnregister(ptr));
     return FXG_OK;
 }
 

@@ -1,0 +1,306 @@
+// fxg_text.h -- FASTQ text <-> Structure-of-Arrays on the device.
+//
+// Replaces, for the regular case, the reference's record reader (src/libfastx/fastx.c:314-404) and writer
+// (:440-473): a block of FASTQ text already resident in HBM is indexed (newline positions by ballot/popcount +
+// prefix sums), checked, packed into the engine's SoA batch, and after the pipeline the kept records are
+// formatted back to text on the device.  "Regular" = LF line ends, four lines per record, '@' prefix, upper-case
+// ACGTN bases, as many quality characters as bases, qualities inside -15..93 after subtracting -Q.  Anything else
+// (CR bytes, numeric qualities, FASTA, malformed records) is only DETECTED here (info.irregular); the caller then
+// runs that block through the host parser, which owns the reference's exact error messages and corner cases.
+#pragma once
+#include "fxg_device.h"
+
+#define FXG_TEXT_SEG 4096u            // bytes of text per workgroup in the newline passes (256 lanes x 16 B)
+
+struct FxgTextState {                 // device-resident scalars of one block of text
+    u32 has_cr;                       // any '\r' byte
+    u32 max_len, min_len;
+    u32 irregular;                    // FXG_TEXT_IRR_* bits
+    u32 first_bad;                    // smallest irregular record index
+    u32 pad[3];
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// generic exclusive scan of u64 (three small kernels, recursive on the block sums)
+// ---------------------------------------------------------------------------------------------------------
+#define FXG_SCAN_PER_BLOCK 1024u      // 256 threads x 4 items
+
+__device__ __forceinline__ u64 fxg_wave_incl_scan64(u64 v)
+{
+    const u32 lane = fxg_lane();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 lo = __shfl_up((u32)v, d, 64), hi = __shfl_up((u32)(v >> 32), d, 64);
+        if ((int)lane >= d) v += ((u64)hi << 32) | lo;
+    }
+    return v;
+}
+
+// in-place exclusive scan of each 1024-item block; block totals to sums[]
+__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_scan_blocks(u64 *data, u64 n, u64 *sums)
+{
+    __shared__ u64 wsum[FXG_WAVES];
+    const u64 base = (u64)blockIdx.x * FXG_SCAN_PER_BLOCK + (u64)threadIdx.x * 4;
+    u64 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (base + i < n) ? data[base + i] : 0ull;
+    const u64 mine = v[0] + v[1] + v[2] + v[3];
+    const u64 incl = fxg_wave_incl_scan64(mine);
+    const u32 wave = threadIdx.x >> 6;
+    if (fxg_lane() == 63) wsum[wave] = incl;
+    __syncthreads();
+    u64 off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < FXG_WAVES; ++w) { if (w < (int)wave) off += wsum[w]; tot += wsum[w]; }
+    u64 run = off + incl - mine;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { if (base + i < n) data[base + i] = run; run += v[i]; }
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_scan_add(u64 *data, u64 n, const u64 *block_off)
+{
+    const u64 base = (u64)blockIdx.x * FXG_SCAN_PER_BLOCK + (u64)threadIdx.x * 4;
+    const u64 add = block_off[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (base + i < n) data[base + i] += add;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// newline census and scatter
+// ---------------------------------------------------------------------------------------------------------
+// bit i of the result = byte i of v equals ch
+FXG_HD u32 fxg_eq_mask16(u32x4 v, u32 ch)
+{
+    const u32 c4 = ch * 0x01010101u;
+    u32 m = 0;
+    const u32 w[4] = {v.x ^ c4, v.y ^ c4, v.z ^ c4, v.w ^ c4};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        // exact zero-byte detector: bit 7 of each byte is set iff the byte is non-zero
+        const u32 nz = (((w[i] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w[i]) & 0x80808080u;
+        m |= fxg_pack4(nz ^ 0x80808080u) << (4 * i);
+    }
+    return m;
+}
+
+// 16 bytes of text at offset off (zero beyond text_len); the buffer itself is readable 16 bytes past text_len
+__device__ __forceinline__ u32x4 fxg_text16(const uint8_t *text, u64 off, u64 text_len)
+{
+    u32x4 v = fxg_ld16(text + off);
+    if (off + 16 > text_len) {
+        const int keep = off >= text_len ? 0 : (int)(text_len - off);
+        v = fxg_keep_bytes(v, 0, keep);
+    }
+    return v;
+}
+
+// pass 1: newlines per 4 KB segment (+ carriage-return detection)
+__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_nl_count(const uint8_t *text, u64 text_len, u64 *seg_count, FxgTextState *st)
+{
+    __shared__ u32 wsum[FXG_WAVES];
+    const u64 off = (u64)blockIdx.x * FXG_TEXT_SEG + (u64)threadIdx.x * 16;
+    u32 c = 0, cr = 0;
+    if (off < text_len) {
+        const u32x4 v = fxg_text16(text, off, text_len);
+        c = (u32)__builtin_popcount(fxg_eq_mask16(v, '\n'));
+        cr = fxg_eq_mask16(v, '\r');
+    }
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if (fxg_lane() == 0) wsum[threadIdx.x >> 6] = c;
+    if (__ballot(cr != 0u) != 0ull && fxg_lane() == 0) atomicOr(&st->has_cr, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) seg_count[blockIdx.x] = (u64)wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// pass 2: line_start[j + 1] = position after the j-th newline (seg_off = exclusive scan of seg_count)
+__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_nl_scatter(const uint8_t *text, u64 text_len, const u64 *seg_off, u32 *line_start, u64 cap_lines)
+{
+    __shared__ u32 wsum[FXG_WAVES];
+    const u64 off = (u64)blockIdx.x * FXG_TEXT_SEG + (u64)threadIdx.x * 16;
+    u32 m = 0;
+    if (off < text_len) m = fxg_eq_mask16(fxg_text16(text, off, text_len), '\n');
+    const u32 mine = (u32)__builtin_popcount(m);
+    u32 incl = mine;
+    const u32 lane = fxg_lane(), wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += t; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    u32 woff = 0;
+#pragma unroll
+    for (int w = 0; w < FXG_WAVES; ++w) if (w < (int)wave) woff += wsum[w];
+    u64 j = seg_off[blockIdx.x] + woff + incl - mine;
+    if (blockIdx.x == 0 && threadIdx.x == 0) line_start[0] = 0u;
+    while (m) {
+        const u32 b = (u32)__builtin_ctz(m);
+        m &= m - 1u;
+        if (j + 1 < cap_lines) line_start[j + 1] = (u32)(off + b + 1);
+        ++j;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// per-record checks on the line index; writes len[] and the batch extrema
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_records(const uint8_t *text, const u32 *ls, u64 n, uint16_t *len, FxgTextState *st)
+{
+    const u64 r = (u64)blockIdx.x * FXG_BLOCK + threadIdx.x;
+    u32 irr = 0, sl = 0;
+    if (r < n) {
+        const u32 o0 = ls[4 * r], o1 = ls[4 * r + 1], o2 = ls[4 * r + 2], o3 = ls[4 * r + 3], o4 = ls[4 * r + 4];
+        sl = o2 - o1 - 1u;
+        const u32 ql = o4 - o3 - 1u;
+        if (text[o0] != '@') irr |= FXG_TEXT_IRR_PREFIX;
+        if (sl == 0u || sl >= 24998u) irr |= FXG_TEXT_IRR_SEQLEN;
+        if (ql != sl) irr |= FXG_TEXT_IRR_QUALLEN;
+        len[r] = (uint16_t)(sl > 65535u ? 65535u : sl);
+        if (irr) { atomicOr(&st->irregular, irr); atomicMin(&st->first_bad, (u32)r); }
+    }
+    // batch extrema: wave reduction, one atomic per wave
+    u32 mx = (r < n && !irr) ? sl : 0u, mn = (r < n && !irr) ? sl : 0xFFFFFFFFu;
+    for (int d = 32; d >= 1; d >>= 1) { mx = max(mx, (u32)__shfl_xor(mx, d, 64)); mn = min(mn, (u32)__shfl_xor(mn, d, 64)); }
+    if (fxg_lane() == 0) { if (mx) atomicMax(&st->max_len, mx); if (mn != 0xFFFFFFFFu) atomicMin(&st->min_len, mn); }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// text -> SoA rows.  One lane owns one 16-byte aligned chunk of the row array and assembles it from the
+// sequence (or quality) lines of the records that intersect it; bytes past a read's length are zero.
+// Qualities are normalised to Phred+33 codes (byte - (Q - 33)) and range-checked; bases are alphabet-checked.
+// ---------------------------------------------------------------------------------------------------------
+template <bool QUAL>
+__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_pack(const uint8_t *text, u64 text_len, const u32 *ls, u64 n, u32 stride,
+                                                                  int qoffset, uint8_t *rows, FxgTextState *st)
+{
+    const u64 total = n * (u64)stride;
+    const u64 nchunks = (total + 15) >> 4;
+    const int qlo = qoffset - 15 < 0 ? 0 : qoffset - 15, qhi = qoffset + 93 > 127 ? 127 : qoffset + 93;   // valid raw characters
+    const u32 Klo = (u32)(128 - qlo) * 0x01010101u, Khi = (u32)(128 - (qhi + 1)) * 0x01010101u;
+    const int dq = qoffset - 33;                                     // raw character -> Phred+33 code
+    const u32 adj4 = (u32)(dq >= 0 ? dq : -dq) * 0x01010101u;
+    u32 bad = 0;
+    for (u64 c = (u64)blockIdx.x * FXG_BLOCK + threadIdx.x; c < nchunks; c += (u64)gridDim.x * FXG_BLOCK) {
+        const u64 b0 = c << 4;
+        u64 r = b0 / stride;
+        u32 pos = (u32)(b0 - r * stride);            // position inside row r of chunk byte 0
+        u32x4 acc = {0u, 0u, 0u, 0u};
+        int filled = 0;
+        while (filled < 16 && r < n) {
+            const u32 o = QUAL ? ls[4 * r + 3] : ls[4 * r + 1];
+            const u32 rl = ls[4 * r + 2] - ls[4 * r + 1] - 1u;
+            const int take_row = (int)(stride - pos) < 16 - filled ? (int)(stride - pos) : 16 - filled;    // bytes of this row in the chunk
+            const int have = pos < rl ? ((int)(rl - pos) < take_row ? (int)(rl - pos) : take_row) : 0;    // of which real data
+            if (have > 0) {
+                // window whose byte `filled` is text[o + pos]
+                const long long src = (long long)o + pos - filled;
+                u32x4 w;
+                if (src >= 0 && (u64)src + 16 <= text_len + 16) w = fxg_ld16(text + src);
+                else {                                      // window would start before the buffer: assemble the needed bytes
+                    u64 lo = 0, hi = 0;
+                    for (int i = 0; i < have; ++i) {
+                        const u64 by = text[o + pos + i];
+                        const int k = filled + i;
+                        if (k < 8) lo |= by << (8 * k); else hi |= by << (8 * (k - 8));
+                    }
+                    w = (u32x4){(u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32)};
+                }
+                w = fxg_keep_bytes(w, filled, filled + have);
+                const u32x4 m = fxg_keep_bytes((u32x4){~0u, ~0u, ~0u, ~0u}, filled, filled + have);
+                if (QUAL) {
+                    // valid iff qlo <= byte <= qhi (bytes >= 128 are negative chars in the reference: invalid)
+                    const u32 ws[4] = {w.x, w.y, w.z, w.w}, ms[4] = {m.x, m.y, m.z, m.w};
+                    u32 outw[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const u32 ge_lo = (((ws[i] & 0x7f7f7f7fu) + Klo)) & 0x80808080u;                 // byte(7 bits) >= qlo
+                        const u32 ge_hi1 = (((ws[i] & 0x7f7f7f7fu) + Khi)) & 0x80808080u;               // byte(7 bits) >= qhi + 1
+                        const u32 hib = ws[i] & 0x80808080u;                                             // byte >= 128
+                        const u32 ok = ge_lo & ~ge_hi1 & ~hib;
+                        bad |= (~ok & 0x80808080u) & ms[i];
+                        // no borrow / carry between bytes when the bytes are valid: Q-33 <= qlo <= byte and byte + 33 - Q <= 126
+                        outw[i] = (dq >= 0 ? ws[i] - (adj4 & ms[i]) : ws[i] + (adj4 & ms[i])) & ms[i];
+                    }
+                    w = (u32x4){outw[0], outw[1], outw[2], outw[3]};
+                } else {
+                    // upper-case ACGTN only (fastx.c:56-84 with ALLOW_N, REQUIRE_UPPERCASE)
+                    const u32 ws[4] = {w.x, w.y, w.z, w.w}, ms[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bad |= fxg_invalid_bases4(ws[i], ms[i]) | ((ws[i] & 0x20202020u) & ms[i]);
+                }
+                acc |= w;
+            }
+            filled += take_row;
+            pos += (u32)take_row;
+            if (pos >= stride) { pos = 0; ++r; }
+        }
+        *reinterpret_cast<u32x4 *>(rows + b0) = acc;       // rows[] is padded to a multiple of 16 bytes by the caller
+    }
+    if (bad) atomicOr(&st->irregular, QUAL ? FXG_TEXT_IRR_QUAL : FXG_TEXT_IRR_BASE);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// formatting: sizes -> (scan on the host side of this header) -> copy
+// ---------------------------------------------------------------------------------------------------------
+// item r = output bytes of record r in the low 40 bits, keep flag above (the scan then yields offset and rank)
+__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_sizes(const u32 *ls, const u32 *res, u64 n, u64 *item)
+{
+    const u64 r = (u64)blockIdx.x * FXG_BLOCK + threadIdx.x;
+    if (r >= n) return;
+    const u32 w = res[r];
+    u64 v = 0;
+    if ((w >> 16) & 1u) {
+        const u32 name_len = ls[4 * r + 1] - ls[4 * r] - 2u;                       // without '@' and '\n'
+        const u32 l2 = ls[4 * r + 3] - ls[4 * r + 2] - 1u;                          // line 3 without '\n'
+        const u32 name2_len = l2 ? l2 - 1u : 0u;                                    // first byte dropped (R5)
+        const u32 len = w & 0xFFFFu;
+        v = (u64)(name_len + name2_len + 2u * len + 6u) | (1ull << 40);
+    }
+    item[r] = v;
+}
+
+// n bytes from src to dst, both arbitrarily aligned, by `lanes` cooperating lanes (lane id `l`); add is applied per byte
+__device__ __forceinline__ void fxg_copy_bytes(uint8_t *dst, const uint8_t *src, u32 n, u32 l, u32 lanes, int add)
+{
+    const u32 full = n >> 4;
+    const u32 a4 = (u32)(add >= 0 ? add : -add) * 0x01010101u;
+    for (u32 k = l; k < full; k += lanes) {
+        u32x4 v = fxg_ld16(src + (k << 4));
+        if (add > 0) { v.x += a4; v.y += a4; v.z += a4; v.w += a4; }        // Phred+33 code -> character: stays below 256 per byte
+        else if (add < 0) { v.x -= a4; v.y -= a4; v.z -= a4; v.w -= a4; }
+        __builtin_memcpy(dst + (k << 4), &v, 16);
+    }
+    for (u32 i = (full << 4) + l; i < n; i += lanes) dst[i] = (uint8_t)((int)src[i] + add);
+}
+
+// 16 lanes format one kept record: "@name\nSEQ\n+name2\nQUAL\n".
+//   fwd_start : first kept base for forward outputs (fastx_trimmer -f)          packed : reverse-complement outputs come
+//   from the engine's packed arrays at pk_off[rank] and hold Phred+33 codes; otherwise bases/quals are prefixes of the text.
+__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_format(const uint8_t *text, const u32 *ls, const u32 *res, const u64 *item_scan, u64 n,
+                                                                    u32 fwd_start, const uint8_t *pk_bases, const uint8_t *pk_qual, const u64 *pk_off,
+                                                                    int qoffset, uint8_t *out)
+{
+    const u32 l = threadIdx.x & 15u;
+    const u64 r = ((u64)blockIdx.x * FXG_BLOCK + threadIdx.x) >> 4;
+    if (r >= n) return;
+    const u32 w = res[r];
+    if (!((w >> 16) & 1u)) return;
+    const u64 sc = item_scan[r];
+    const u64 off = sc & ((1ull << 40) - 1ull), rank = sc >> 40;
+    const u32 o0 = ls[4 * r], o1 = ls[4 * r + 1], o2 = ls[4 * r + 2], o3 = ls[4 * r + 3];
+    const u32 name_len = o1 - o0 - 2u;
+    const u32 l2 = o3 - o2 - 1u, name2_len = l2 ? l2 - 1u : 0u;
+    const u32 len = w & 0xFFFFu;
+    uint8_t *d = out + off;
+    if (l == 0) { d[0] = '@'; d[1 + name_len] = '\n'; d[2 + name_len + len] = '\n'; d[3 + name_len + len] = '+';
+                  d[4 + name_len + len + name2_len] = '\n'; d[5 + name_len + 2 * len + name2_len] = '\n'; }
+    fxg_copy_bytes(d + 1, text + o0 + 1, name_len, l, 16, 0);
+    fxg_copy_bytes(d + 4 + name_len + len, text + o2 + 1, name2_len, l, 16, 0);
+    if (pk_bases) {
+        const u64 po = pk_off[rank];
+        fxg_copy_bytes(d + 2 + name_len, pk_bases + po, len, l, 16, 0);
+        fxg_copy_bytes(d + 5 + name_len + len + name2_len, pk_qual + po, len, l, 16, qoffset - 33);
+    } else {
+        fxg_copy_bytes(d + 2 + name_len, text + o1 + fwd_start, len, l, 16, 0);
+        fxg_copy_bytes(d + 5 + name_len + len + name2_len, text + o3 + fwd_start, len, l, 16, 0);    // R8: q + Q is the input byte
+    }
+}

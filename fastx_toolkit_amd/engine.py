@@ -24,6 +24,7 @@ EXPORTS = [
     "fxg_memcpy_d2h", "fxg_memset_device", "fxg_timer_start", "fxg_timer_stop", "fxg_run_pipeline",
     "fxg_run_qtrim_qfilter", "fxg_run_clip", "fxg_run_revcomp_trim", "fxg_read_counters", "fxg_synth_generate",
     "fxg_last_launch_info", "fxg_set_profiling", "fxg_last_kernel_ms",
+    "fxg_fastq_index", "fxg_fastq_pack", "fxg_fastq_format", "fxg_host_register", "fxg_host_unregister",
 ]
 
 
@@ -41,6 +42,11 @@ class FxgParams(C.Structure):
 class FxgBatch(C.Structure):
     _fields_ = [("bases", C.c_void_p), ("qual", C.c_void_p), ("len", C.c_void_p),
                 ("fixed_len", C.c_uint32), ("stride", C.c_uint32), ("n", C.c_uint64)]
+
+
+class FxgTextInfo(C.Structure):
+    _fields_ = [("lines", C.c_uint64), ("records", C.c_uint64), ("consumed", C.c_uint64), ("max_len", C.c_uint32),
+                ("min_len", C.c_uint32), ("irregular", C.c_uint32), ("first_bad", C.c_uint32)]
 
 
 class FxgOut(C.Structure):
@@ -103,6 +109,11 @@ def load_library(path=None):
     L.fxg_read_counters.argtypes = [vp, vp, C.POINTER(u64 * NCOUNTERS)]
     L.fxg_synth_generate.argtypes = [vp, u64, u64, u64, u32, i32, vp, vp, u32]
     L.fxg_last_launch_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.fxg_fastq_index.argtypes = [vp, vp, u64, i32, vp, u64, vp, C.POINTER(FxgTextInfo)]
+    L.fxg_fastq_pack.argtypes = [vp, vp, u64, vp, u64, u32, i32, vp, vp, C.POINTER(u32)]
+    L.fxg_fastq_format.argtypes = [vp, vp, vp, u64, vp, u32, vp, vp, vp, i32, vp, C.POINTER(u64)]
+    L.fxg_host_register.argtypes = [vp, vp, C.c_size_t]
+    L.fxg_host_unregister.argtypes = [vp, vp]
     L.fxg_set_profiling.argtypes = [vp, i32]
     L.fxg_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     if path is None:
@@ -260,6 +271,40 @@ class Engine:
         self._check(self.lib.fxg_run_pipeline(self.ctx, C.byref(b), C.byref(params), C.byref(fo)))
         return Result(self, o["res"], o.get("out_bases"), o.get("out_qual"), o.get("out_len"), o.get("kept_index"),
                       o.get("out_off"), o["counters"])
+
+    # ---- FASTQ text on the device ----
+    def text_upload(self, text, at_eof=True):
+        """Copy a block of FASTQ text to the device (16 bytes of slack; a final newline is appended at end of input)."""
+        if at_eof and text and not text.endswith(b"\n"):
+            text = text + b"\n"
+        t = self.torch.zeros(len(text) + 16, dtype=self.torch.uint8, device=self.device)
+        t[:len(text)] = self.torch.frombuffer(bytearray(text), dtype=self.torch.uint8).to(self.device)
+        return t, len(text)
+
+    def fastq_index(self, d_text, text_len, at_eof=True, cap_records=None):
+        cap_records = cap_records or (text_len // 8 + 2)
+        ls = self.torch.empty(4 * cap_records + 1, dtype=self.torch.int32, device=self.device)
+        lens = self.torch.empty(cap_records, dtype=self.torch.int16, device=self.device)
+        info = FxgTextInfo()
+        self._check(self.lib.fxg_fastq_index(self.ctx, d_text.data_ptr(), text_len, int(at_eof), ls.data_ptr(), ls.numel(), lens.data_ptr(), C.byref(info)))
+        return ls, lens, info
+
+    def fastq_pack(self, d_text, text_len, ls, n, stride, qoffset=33, want_qual=True):
+        nbytes = (n * stride + 15) // 16 * 16
+        bases = self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.device)
+        qual = self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.device) if want_qual else None
+        irr = C.c_uint32()
+        self._check(self.lib.fxg_fastq_pack(self.ctx, d_text.data_ptr(), text_len, ls.data_ptr(), n, stride, qoffset, bases.data_ptr(),
+                                            qual.data_ptr() if want_qual else None, C.byref(irr)))
+        return bases[:n * stride].view(n, stride), (qual[:n * stride].view(n, stride) if want_qual else None), irr.value
+
+    def fastq_format(self, d_text, text_len, ls, n, res, fwd_start=0, packed=None, qoffset=33):
+        out = self.torch.empty(text_len + 16, dtype=self.torch.uint8, device=self.device)
+        nb = C.c_uint64()
+        pb, pq, po = (packed[0].data_ptr(), packed[1].data_ptr(), packed[2].data_ptr()) if packed else (None, None, None)
+        self._check(self.lib.fxg_fastq_format(self.ctx, d_text.data_ptr(), ls.data_ptr(), n, res.data_ptr(), fwd_start, pb, pq, po, qoffset,
+                                              out.data_ptr(), C.byref(nb)))
+        return out[:nb.value]
 
     def read_counters(self, d_counters):
         host = (C.c_uint64 * NCOUNTERS)()

@@ -1,0 +1,107 @@
+"""GPU tier (-m gpu): FASTQ text parsed, packed and formatted ON THE DEVICE against the oracle's
+reader/writer restatement (itself pinned against the reference libfastx)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, md5, oracle_params, text_through
+from oracle import fxoracle_py as fo
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_text_pipeline(engine, text, pd, qoffset=33):
+    """text -> (device index/pack) -> engine pipeline -> (device format) -> text; returns (out_text, info)."""
+    from fastx_toolkit_amd import make_params
+    import torch
+    d_text, tl = engine.text_upload(text)
+    ls, lens, info = engine.fastq_index(d_text, tl)
+    assert info.irregular == 0, info.irregular
+    n = info.records
+    assert info.consumed == tl
+    stride = info.max_len
+    bases, qual, irr = engine.fastq_pack(d_text, tl, ls, n, stride, qoffset)
+    assert irr == 0
+    p = make_params(**dict(pd, qoffset=33))            # rows hold Phred+33 codes
+    rev = bool(pd["stages"] & 8)
+    fixed = info.min_len == info.max_len
+    r = engine.run(bases, qual, p, lens=None if fixed else lens[:n], fixed_len=stride, compact=rev, meta=rev)
+    fwd = pd.get("ft_first", 1) - 1 if (pd["stages"] & 16) else 0
+    out = engine.fastq_format(d_text, tl, ls, n, r.res, fwd_start=0 if rev else fwd,
+                              packed=(r.out_bases, r.out_qual, r.out_off) if rev else None, qoffset=qoffset)
+    torch.cuda.synchronize()
+    return bytes(out.cpu().numpy()), info, (bases, qual, lens)
+
+
+def test_index_and_pack_match_oracle_parser(engine):
+    rng = np.random.default_rng(3)
+    recs = []
+    for i in range(5000):
+        L = int(rng.integers(1, 120))
+        s = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=L).tobytes()
+        q = rng.integers(33, 127, size=L, dtype=np.uint8).tobytes()
+        recs.append(b"@r%d %s\n%s\n+%s\n%s\n" % (i, b"x" * int(rng.integers(0, 40)), s, b"" if i % 3 else b"r%d" % i, q))
+    text = b"".join(recs)
+    d_text, tl = engine.text_upload(text)
+    ls, lens, info = engine.fastq_index(d_text, tl)
+    p = fo.parse_fastq(text)
+    assert (info.records, info.lines, info.consumed, info.irregular) == (p["n"], 4 * p["n"], len(text), 0)
+    assert (info.max_len, info.min_len) == (int(p["lens"].max()), int(p["lens"].min()))
+    starts = np.concatenate([[0], np.nonzero(np.frombuffer(text, np.uint8) == 10)[0] + 1]).astype(np.uint32)
+    assert np.array_equal(ls[:4 * info.records + 1].cpu().numpy().view(np.uint32), starts)
+    assert np.array_equal(lens[:info.records].cpu().numpy().view(np.uint16), p["lens"])
+    for stride in (info.max_len, info.max_len + 5):
+        b, q, irr = engine.fastq_pack(d_text, tl, ls, info.records, stride)
+        pp = fo.parse_fastq(text, stride=stride)
+        assert irr == 0 and np.array_equal(b.cpu().numpy(), pp["bases"]) and np.array_equal(q.cpu().numpy(), pp["qual"])
+
+
+def test_text_to_text_matches_reference_md5(engine, cases):
+    for c in cases["synthetic"]:
+        if c["n"] > 200000 or len(c["chain"]) != 1 or (c["params"]["stages"] & 1 and c["L"] > 255):
+            continue
+        text = fo.synth_fastq(c["seed"], 0, c["n"], c["L"], c["adapter"])
+        out, info, _ = _gpu_text_pipeline(engine, text, c["params"])
+        assert md5(out) == c["output_md5"], c["name"]
+    for name, pd in (("var_qfilter", None), ("var_ftrim_end", None)):
+        c = [x for x in cases["varlen"] if x["name"] == name][0]
+        text = open(os.path.join(GOLDEN, "synthetic", name + ".fq"), "rb").read()
+        out, _, _ = _gpu_text_pipeline(engine, text, c["params"])
+        assert out == open(os.path.join(GOLDEN, "synthetic", name + ".out"), "rb").read(), name
+
+
+def test_revcomp_trim_and_offsets_text(engine):
+    text = fo.synth_fastq(41, 0, 30000, 75)
+    for pd in (dict(stages=8), dict(stages=16, ft_first=7, ft_last=60), dict(stages=32, ft_trim_end=10, ft_min_len=20),
+               dict(stages=2, qt_threshold=25, qt_min_len=20)):
+        exp, _ = text_through(fo.run_pipeline, text, oracle_params(pd))
+        out, _, _ = _gpu_text_pipeline(engine, text, pd)
+        assert out == exp, pd
+    g = open(os.path.join(GOLDEN, "galaxy", "fastq_quality_trimmer.fastq"), "rb").read()      # Phred+64 text
+    pd = dict(stages=2, qt_threshold=30, qt_min_len=16)
+    out, _, _ = _gpu_text_pipeline(engine, g, pd, qoffset=64)
+    assert out == open(os.path.join(GOLDEN, "galaxy", "fastq_quality_trimmer.out"), "rb").read()
+    exp, _ = text_through(fo.run_pipeline, g, oracle_params(dict(stages=8, qoffset=64)), qoffset=64)
+    out, _, _ = _gpu_text_pipeline(engine, g, dict(stages=8), qoffset=64)
+    assert out == exp
+
+
+def test_irregular_input_is_detected_not_processed(engine):
+    ok = b"@r1\nACGT\n+\nIIII\n@r2\nAC\n+\nII\n"
+    for text, bit in ((ok.replace(b"\n", b"\r\n"), 0x01), (b"r1\nACGT\n+\nIIII\n", 0x02), (b"@r1\n\n+\n\n", 0x04),
+                      (b"@r1\nACGT\n+\n40 40 40 40\n", 0x08), (ok + b"@r3\nAC\n+\n", 0x40)):
+        d_text, tl = engine.text_upload(text)
+        _, _, info = engine.fastq_index(d_text, tl)
+        assert info.irregular & bit, (text, info.irregular)
+    for text, bit in ((b"@r1\nACGX\n+\nIIII\n", 0x10), (b"@r1\nacgt\n+\nIIII\n", 0x10), (b"@r1\nACGT\n+\nII\x07I\n", 0x20),
+                      (b"@r1\nACGT\n+\nII\xc8I\n", 0x20)):
+        d_text, tl = engine.text_upload(text)
+        ls, _, info = engine.fastq_index(d_text, tl)
+        assert info.irregular == 0
+        _, _, irr = engine.fastq_pack(d_text, tl, ls, info.records, info.max_len)
+        assert irr & bit, (text, irr)
+    # a block that ends inside a record is not an error unless it is the end of input
+    d_text, tl = engine.text_upload(ok + b"@r3\nAC", at_eof=False)
+    _, _, info = engine.fastq_index(d_text, tl, at_eof=False)
+    assert info.irregular == 0 and info.records == 2 and info.consumed == len(ok)
