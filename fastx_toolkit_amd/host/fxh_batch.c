@@ -39,6 +39,13 @@ typedef struct {
     uint32_t *d_res;
     uint64_t *d_counters;
     size_t d_cap_bytes, d_cap_reads;
+    /* device text path (8f-1) */
+    uint8_t *d_text, *d_out_text;
+    uint32_t *d_ls;
+    uint16_t *d_len16;
+    uint64_t *d_out_off;
+    size_t d_text_cap, d_ls_cap, d_off_cap;
+    const void *registered[4];
 } fxh_state;
 
 #define FXG_CHECK(st, call)                                                                     \
@@ -476,6 +483,85 @@ static void fxh_awriter_stop(fxh_awriter *aw)
     pthread_join(aw->th, NULL);
 }
 
+/* ---------------------------------------------------------------------------------------------- */
+/* device text path: the block is indexed, checked, packed and formatted on the GPU.   */
+/* Returns 1 if the block was handled, 0 if it is irregular in any way (the caller then uses the     */
+/* host parser for this block, which owns the reference's messages and corner cases).               */
+/* ---------------------------------------------------------------------------------------------- */
+static void fxh_register_once(fxh_state *st, void *ptr, size_t bytes)
+{
+    for (int i = 0; i < 4; ++i) if (st->registered[i] == ptr) return;
+    for (int i = 0; i < 4; ++i)
+        if (!st->registered[i]) { if (fxg_host_register(st->ctx, ptr, bytes) == 0) st->registered[i] = ptr; return; }
+}
+
+static int fxh_block_gpu_text(FASTX *fx, fxh_state *st, const fxg_params *p, fxh_totals *tot, struct fxh_writer *wr, int revcomp, uint32_t fwd_start)
+{
+    struct fxh_reader *rd = fx->reader;
+    size_t len = rd->end - rd->beg;
+    if (len == 0) return 0;
+    if (rd->eof && rd->buf[rd->end - 1] != '\n') rd->buf[rd->end] = '\n', len += 1;     /* the buffer has one spare byte */
+    if (st->d_text_cap < len + 32) {
+        if (st->d_text) { fxg_free_device(st->ctx, st->d_text); fxg_free_device(st->ctx, st->d_out_text); }
+        st->d_text_cap = len + len / 8 + 4096;
+        FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_text_cap, (void **)&st->d_text));
+        FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_text_cap, (void **)&st->d_out_text));
+    }
+    const size_t cap_lines = len / 2 + 16;                  /* the shortest record "@\nA\n+\nI\n" has 8 bytes and 4 lines */
+    if (st->d_ls_cap < cap_lines) {
+        if (st->d_ls) { fxg_free_device(st->ctx, st->d_ls); fxg_free_device(st->ctx, st->d_len16); }
+        st->d_ls_cap = cap_lines + cap_lines / 8;
+        FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_ls_cap * sizeof(uint32_t), (void **)&st->d_ls));
+        FXG_CHECK(st, fxg_malloc_device(st->ctx, (st->d_ls_cap / 4 + 4) * sizeof(uint16_t), (void **)&st->d_len16));
+    }
+    fxh_register_once(st, rd->buf, rd->cap + 1);
+    FXG_CHECK(st, fxg_memcpy_h2d(st->ctx, st->d_text, rd->buf + rd->beg, len));
+    fxg_text_info info;
+    FXG_CHECK(st, fxg_fastq_index(st->ctx, st->d_text, len, rd->eof, st->d_ls, st->d_ls_cap, st->d_len16, &info));
+    if (info.irregular || info.records == 0) return 0;
+    const uint64_t n = info.records;
+    const uint32_t stride = info.max_len;
+    if ((uint64_t)n * stride > (uint64_t)8 * len + (1u << 20)) return 0;   /* ragged beyond reason: let the host path split it */
+    fxh_grow(st, n, (size_t)n * stride + 16, revcomp);
+    uint32_t irr = 0;
+    FXG_CHECK(st, fxg_fastq_pack(st->ctx, st->d_text, len, st->d_ls, n, stride, fx->fastq_ascii_quality_offset, st->d_bases, st->d_qual, &irr));
+    if (irr) return 0;
+    if (revcomp && st->d_off_cap < n) {
+        if (st->d_out_off) fxg_free_device(st->ctx, st->d_out_off);
+        st->d_off_cap = n + n / 8 + 1024;
+        FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_off_cap * sizeof(uint64_t), (void **)&st->d_out_off));
+    }
+    const int fixed = info.min_len == info.max_len;
+    fxg_batch in = {st->d_bases, st->d_qual, fixed ? NULL : st->d_len16, stride, stride, n};
+    fxg_out out = {st->d_res, revcomp ? st->d_out_bases : NULL, revcomp ? st->d_out_qual : NULL, NULL, NULL, revcomp ? st->d_out_off : NULL, st->d_counters};
+    fxg_params pp = *p;
+    pp.qoffset = 33;
+    FXG_CHECK(st, fxg_run_pipeline(st->ctx, &in, &pp, &out));
+    uint64_t ctr[FXG_NCOUNTERS];
+    {
+        int rc = fxg_read_counters(st->ctx, st->d_counters, ctr);
+        if (rc == FXG_E_DEVICE && (ctr[FXG_C_ERRORS] & FXG_DEV_ERR_BAD_BASE)) errx(1, "%s", fxg_last_error(st->ctx));
+        if (rc != 0) errx(1, "GPU engine error %d: %s", rc, fxg_last_error(st->ctx));
+    }
+    uint64_t out_bytes = 0;
+    FXG_CHECK(st, fxg_fastq_format(st->ctx, st->d_text, st->d_ls, n, st->d_res, revcomp ? 0u : fwd_start, revcomp ? st->d_out_bases : NULL,
+                                   revcomp ? st->d_out_qual : NULL, revcomp ? st->d_out_off : NULL, fx->fastq_ascii_quality_offset, st->d_out_text, &out_bytes));
+    char *dst = fxh_writer_reserve(wr, out_bytes + 16);
+    FXG_CHECK(st, fxg_memcpy_d2h(st->ctx, dst, st->d_out_text, out_bytes));
+    FXG_CHECK(st, fxg_sync(st->ctx));
+    wr->len += out_bytes;
+    /* FASTQ ids are never collapsed: every record counts as one read (fastx.c:480-481) */
+    tot->input_sequences += n; tot->input_reads += n;
+    tot->output_sequences += ctr[FXG_C_KEPT]; tot->output_reads += ctr[FXG_C_KEPT];
+    tot->clip_input += (unsigned)n;
+    tot->clip_too_short += (unsigned)ctr[FXG_C_CLIP_TOO_SHORT]; tot->clip_adapter_only += (unsigned)ctr[FXG_C_CLIP_ADAPTER_ONLY];
+    tot->clip_no_adapter += (unsigned)ctr[FXG_C_CLIP_NO_ADAPTER]; tot->clip_adapter_found += (unsigned)ctr[FXG_C_CLIP_ADAPTER_FOUND];
+    tot->clip_n += (unsigned)ctr[FXG_C_CLIP_N];
+    rd->beg += (size_t)info.consumed > rd->end - rd->beg ? rd->end - rd->beg : (size_t)info.consumed;
+    fx->input_line_number += 4ull * n;
+    return 1;
+}
+
 int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *tot)
 {
     fxh_state st;
@@ -526,14 +612,29 @@ int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *tot)
     char *rd_spare = NULL, *wr_spare = NULL;
     size_t wr_spare_cap = 0;
     const int overlap = getenv("FXH_NO_OVERLAP") == NULL;
+    /* device-side parse/format for FASTQ; FXH_HOST_PARSE=1 forces the host parser */
+    const int gpu_text = fx->read_fastq && getenv("FXH_HOST_PARSE") == NULL;
+    unsigned long n_fallback = 0;
 
     while (!at_eof && !have_err) {
         /* ---- 1. fill the block, split it into record-aligned ranges, index + validate them in parallel ---- */
         t0 = fxh_now();
         if (overlap) fxh_next_block(&pf, rd, &rd_spare); else fxh_reader_fill(rd);
         t_read += fxh_now() - t0; t0 = fxh_now();
+        if (rd->beg == rd->end && rd->eof) break;
+        if (gpu_text) {
+            struct fxh_writer *wr0 = fx->writer;
+            if (fxh_block_gpu_text(fx, &st, p, tot, wr0, job.revcomp, job.fwd_start)) {
+                t_gpu += fxh_now() - t0;
+                if (overlap) fxh_awriter_submit(&aw, wr0, &wr_spare, &wr_spare_cap); else fxh_writer_flush(wr0);
+                fx->num_input_sequences = tot->input_sequences; fx->num_input_reads = tot->input_reads;
+                fx->num_output_sequences = tot->output_sequences; fx->num_output_reads = tot->output_reads;
+                if (rd->eof && rd->beg >= rd->end) at_eof = 1;
+                continue;
+            }
+            n_fallback++;
+        }
         const size_t beg = rd->beg, end = rd->end;
-        if (beg == end && rd->eof) break;
         const int T = job.nworkers;
         for (int i = 0; i < T; ++i) {
             job.w[i].a0 = beg + (size_t)((unsigned long long)(end - beg) * (unsigned)i / (unsigned)T);
@@ -671,8 +772,8 @@ int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *tot)
         errx(1, "%s", errmsg);
     }
     if (timing)
-        fprintf(stderr, "fxh timing (%d threads): init %.3f read %.3f index %.3f pack %.3f gpu(h2d+kernel+d2h) %.3f format+write %.3f s\n",
-                job.nworkers, t_init, t_read, t_index, t_pack, t_gpu, t_fmt);
+        fprintf(stderr, "fxh timing (%d threads, %s parse, %lu host-parsed blocks): init %.3f read %.3f index %.3f pack %.3f gpu(h2d+kernel+d2h) %.3f format+write %.3f s\n",
+                job.nworkers, gpu_text ? "device" : "host", n_fallback, t_init, t_read, t_index, t_pack, t_gpu, t_fmt);
     fxg_ctx_destroy(st.ctx);
     for (int i = 0; i < job.nworkers; ++i) { free(job.w[i].rec); free(job.w[i].shadow); }
     free(job.w);

@@ -26,9 +26,22 @@ def tools():
     return os.path.join(HOST, "bin")
 
 
+PARSE_ENV = {}          # set per test run by the `parse_mode` fixture: {} = device-side parse/format, FXH_HOST_PARSE=1 = host parser
+
+
 def _run(cmd, data, env=None):
+    env = dict(env or os.environ, **PARSE_ENV)
     p = subprocess.run(cmd, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     return p.returncode, p.stdout, p.stderr
+
+
+@pytest.fixture(scope="module", params=["device-parse", "host-parse"], autouse=True)
+def parse_mode(request):
+    PARSE_ENV.clear()
+    if request.param == "host-parse":
+        PARSE_ENV["FXH_HOST_PARSE"] = "1"
+    yield request.param
+    PARSE_ENV.clear()
 
 
 def _msg(err):
