@@ -71,6 +71,8 @@ struct FxgKArgs {
     u32  clip_flags;
     int  ft_first, ft_last;
     u32  ft_trim_end, ft_min_len;
+    u32  mask_char;         // fastq_masker -r; the mask threshold shares `fq` (byte < fq is masked)
+    u64 *extra;             // [0] masked reads, [1] masked nucleotides (fastq_masker report)
     char adapter[100];
 };
 
@@ -344,19 +346,34 @@ FXG_HD FxgSeg fxg_make_seg(const u32 *v_off, const u32 *v_src, u32 r, u32 o, u32
 
 // The 16-byte window of one array for one segment, reversed/complemented/validated when REV, masked to
 // [blo, bhi).  tile_ptr = array + tile_in_base (uniform); [lo_ok, hi_ok) = tile-relative range of the array.
-template <bool REV, bool BASES>
-FXG_HD u32x4 fxg_seg_bytes(const uint8_t *tile_ptr, int lo_ok, int hi_ok, const FxgSeg &g, u32 *bad)
+template <bool REV, bool BASES, bool MASK = false>
+FXG_HD u32x4 fxg_seg_bytes(const uint8_t *tile_ptr, int lo_ok, int hi_ok, const FxgSeg &g, u32 *bad, const uint8_t *tile_q = nullptr,
+                           u32 Kmask = 0u, u32 mask4 = 0u)
 {
     const int vlo = REV ? 16 - g.bhi : g.blo, vhi = REV ? 16 - g.blo : g.bhi;
-    u32x4 w;
-    if (g.src >= lo_ok && g.src + 16 <= hi_ok) w = fxg_ld16(tile_ptr + g.src);
+    const bool inside = g.src >= lo_ok && g.src + 16 <= hi_ok;
+    u32x4 w, wq = {0u, 0u, 0u, 0u};
+    if (inside) { w = fxg_ld16(tile_ptr + g.src); if (MASK) wq = fxg_ld16(tile_q + g.src); }
     else {                                         // window pokes out of the array: touch only the needed bytes
-        u64 lo = 0, hi = 0;
+        u64 lo = 0, hi = 0, qlo = 0, qhi = 0;
         for (int i = vlo; i < vhi; ++i) {
             const u64 b = tile_ptr[g.src + i];
             if (i < 8) lo |= b << (8 * i); else hi |= b << (8 * (i - 8));
+            if (MASK) { const u64 q = tile_q[g.src + i]; if (i < 8) qlo |= q << (8 * i); else qhi |= q << (8 * (i - 8)); }
         }
         w = (u32x4){(u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32)};
+        if (MASK) wq = (u32x4){(u32)qlo, (u32)(qlo >> 32), (u32)qhi, (u32)(qhi >> 32)};
+    }
+    if (MASK) {                                    // fastq_masker.c:94-99: base := mask character where quality < threshold
+        const u32 ws[4] = {w.x, w.y, w.z, w.w}, qs[4] = {wq.x, wq.y, wq.z, wq.w};
+        u32 o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32 low = (fxg_ge_flags(qs[i], Kmask) ^ 0x80808080u) >> 7;     // 0x01 per byte with quality below the threshold
+            const u32 m = low * 0xFFu;
+            o[i] = (ws[i] & ~m) | (mask4 & m);
+        }
+        w = (u32x4){o[0], o[1], o[2], o[3]};
     }
     if (REV) {
         w = fxg_reverse16(w);
@@ -370,13 +387,13 @@ FXG_HD u32x4 fxg_seg_bytes(const uint8_t *tile_ptr, int lo_ok, int hi_ok, const 
 }
 
 // one array of one chunk: both candidate windows in flight, then the (rare) tail of further segments
-template <bool REV, bool BASES>
+template <bool REV, bool BASES, bool MASK = false>
 FXG_HD void fxg_gather_array(const uint8_t *tile_ptr, int lo_ok, int hi_ok, uint8_t *out_chunk, const u32 *v_off, const u32 *v_src,
                              const FxgSeg &s1, const FxgSeg &s2, bool two, bool more, u32 r_next, u32 o_next, u32 o_end, int cs,
-                             int lo_c, int hi_c, u32 *bad)
+                             int lo_c, int hi_c, u32 *bad, const uint8_t *tile_q = nullptr, u32 Kmask = 0u, u32 mask4 = 0u)
 {
-    u32x4 acc = fxg_seg_bytes<REV, BASES>(tile_ptr, lo_ok, hi_ok, s1, bad);
-    if (two) acc |= fxg_seg_bytes<REV, BASES>(tile_ptr, lo_ok, hi_ok, s2, bad);
+    u32x4 acc = fxg_seg_bytes<REV, BASES, MASK>(tile_ptr, lo_ok, hi_ok, s1, bad, tile_q, Kmask, mask4);
+    if (two) acc |= fxg_seg_bytes<REV, BASES, MASK>(tile_ptr, lo_ok, hi_ok, s2, bad, tile_q, Kmask, mask4);
     if (more) {
         u32 r = r_next, o = o_next;
         while (o < o_end) {
@@ -384,7 +401,7 @@ FXG_HD void fxg_gather_array(const uint8_t *tile_ptr, int lo_ok, int hi_ok, uint
             if (e > o) {
                 const u32 se = e < o_end ? e : o_end;
                 const FxgSeg g = fxg_make_seg<REV>(v_off, v_src, r, o, se, cs);
-                acc |= fxg_seg_bytes<REV, BASES>(tile_ptr, lo_ok, hi_ok, g, bad);
+                acc |= fxg_seg_bytes<REV, BASES, MASK>(tile_ptr, lo_ok, hi_ok, g, bad, tile_q, Kmask, mask4);
                 o = se;
             }
             ++r;
@@ -396,11 +413,12 @@ FXG_HD void fxg_gather_array(const uint8_t *tile_ptr, int lo_ok, int hi_ok, uint
     for (int i = lo_c; i < hi_c; ++i) out_chunk[i] = (uint8_t)((i < 8 ? b0 : b1) >> (8 * (i & 7)));
 }
 
-template <bool REV>
+template <bool REV, bool MASK = false>
 FXG_HD u32 fxg_tile_gather(const FxgKArgs &a, const u32 *v_off, const u32 *v_src, u32 nreads,
                            u64 tile_in_base, u64 B, u32 S, u32 tid, u32 nthreads)
 {
     if (S == 0) return 0u;
+    const u32 Kmask = (128u - a.fq) * 0x01010101u, mask4 = (a.mask_char & 0xFFu) * 0x01010101u;
     const bool has_q = a.qual != nullptr && a.out_qual != nullptr && !FXG_DBG(a, 4u);
     // wave-uniform 64-bit quantities
     const u64 c_first = B >> 4;
@@ -440,7 +458,8 @@ FXG_HD u32 fxg_tile_gather(const FxgKArgs &a, const u32 *v_off, const u32 *v_src
             more = end2 < o_end;
             r_next = r + 1; o_next = end2;
         }
-        fxg_gather_array<REV, true>(src_b, lo_ok, hi_ok, out_b + (ci << 4), v_off, v_src, s1, s2, two, more, r_next, o_next, o_end, cs, lo_c, hi_c, &bad);
+        fxg_gather_array<REV, true, MASK>(src_b, lo_ok, hi_ok, out_b + (ci << 4), v_off, v_src, s1, s2, two, more, r_next, o_next, o_end, cs, lo_c, hi_c, &bad,
+                                          a.qual + tile_in_base, Kmask, mask4);
         if (has_q) {
             u32 dummy = 0;
             fxg_gather_array<REV, false>(src_q, lo_ok, hi_ok, out_q + (ci << 4), v_off, v_src, s1, s2, two, more, r_next, o_next, o_end, cs, lo_c, hi_c, &dummy);

@@ -209,6 +209,7 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
 #endif
     ka.errflag = c->errflag;
     ka.ticket = c->errflag + FXG_TICKET_STRIDE;
+    ka.extra = (u64 *)(c->errflag + 2);          // words 2..5 of the (zeroed) control block
     { const char *tg = getenv("FXG_TICKET_GROUPS"); u32 g = (tg && atoi(tg) > 0 && atoi(tg) <= FXG_TICKET_GROUPS) ? (u32)atoi(tg) : FXG_TICKET_GROUPS; ka.ticket_groups = g < grid ? g : (u32)grid; }
     FXG_HIP(c, hipMemsetAsync(c->errflag, 0, (FXG_TICKET_GROUPS + 1) * FXG_TICKET_STRIDE * sizeof(u32), c->stream));
 
@@ -223,7 +224,7 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
     hipLaunchKernelGGL(fxg_kernel_count_res, dim3((u32)cgrid), dim3(FXG_BLOCK), 0, c->stream, (const u32 *)ka.res, ka.n, ka.stages, c->partial);
     FXG_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(fxg_kernel_reduce_counters, dim3(1), dim3(256), 0, c->stream, (const u64 *)c->partial, (u32)cgrid,
-                       (const u32 *)c->errflag, counters ? counters : c->counters_scratch);
+                       (const u32 *)c->errflag, (const u64 *)(c->errflag + 2), counters ? counters : c->counters_scratch);
     FXG_HIP(c, hipGetLastError());
     snprintf(c->last_kernel, sizeof c->last_kernel, "%s", kname);
     c->last_grid = (u32)grid; c->last_block = FXG_BLOCK; c->last_lds = lds; c->last_tile = ka.tile_reads;
@@ -265,6 +266,8 @@ extern "C" int fxg_run_pipeline(fxg_ctx *c, const fxg_batch *in, const fxg_param
         default: return fxg_launch_tiles(c, FXG_TILES_A(100), "fxg_kernel_tiles<100,0> clip[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
         }
     }
+    if (pl.mask) return fxg_launch_tiles(c, fxg_kernel_tiles<0, 3>, "fxg_kernel_tiles<0,3> mask", pl.ka, pl.lds, ctr);
+    if (pl.artifacts) return fxg_launch_tiles(c, fxg_kernel_tiles<0, 4>, "fxg_kernel_tiles<0,4> artifacts", pl.ka, pl.lds, ctr);
     if (pl.rev) return fxg_launch_tiles(c, fxg_kernel_tiles<0, 2>, "fxg_kernel_tiles<0,2> revcomp[+ftrim]", pl.ka, pl.lds, ctr);
     return fxg_launch_tiles(c, fxg_kernel_tiles<0, 1>, "fxg_kernel_tiles<0,1> ftrim", pl.ka, pl.lds, ctr);
 #undef FXG_TILES_A
@@ -277,6 +280,8 @@ static void fxg_params_default(fxg_params *p)
     strcpy(p->adapter, "CCTTAAGG");   // fastx_clipper.cpp:68
     p->clip_min_len = 5;              // :69
     p->ft_first = 1;
+    p->mask_min_quality = 10;         // fastq_masker.c:47-48
+    p->mask_char = 'N';
 }
 
 extern "C" int fxg_run_qtrim_qfilter(fxg_ctx *c, const fxg_batch *in, int qoffset, int use_trim, int trim_threshold,

@@ -209,7 +209,7 @@ FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len,
 // The -v report counters are a pure function of res[]: one accumulator set per thread of the
 // counting pass (or per emulated run).
 struct FxgCounts {
-    u64 in, kept, bases, too_short, adapter_only, no_adapter, adapter_found, has_n, qtrim, qfilter, ftrim, k_mode;
+    u64 in, kept, bases, too_short, adapter_only, no_adapter, adapter_found, has_n, qtrim, qfilter, ftrim, k_mode, artifact;
 };
 #define FXG_RES_ADAPTER_ONLY_BIT 22   /* clipper found the adapter at index 0 (counted even when -k keeps the read) */
 
@@ -228,6 +228,7 @@ FXG_HD void fxg_count_res(u32 w, FxgCounts &c)
     c.qfilter += (why == FXG_R_QFILTER);
     c.ftrim += (why == FXG_R_FTRIM);
     c.k_mode += (why == FXG_R_CLIP_K_MODE);
+    c.artifact += (why == FXG_R_ARTIFACT);
 }
 
 // counters[] from the accumulators; clip_out / qtrim_out are what survives each stage of the chain
@@ -241,6 +242,7 @@ FXG_HD void fxg_counts_to_slots(const FxgCounts &c, u32 stages, u64 *slot)
     const u64 clip_out = c.kept + c.qtrim + c.qfilter;
     slot[FXG_C_CLIP_OUT] = (stages & FXG_STAGE_CLIP) ? clip_out : 0;
     slot[FXG_C_QTRIM_OUT] = (stages & FXG_STAGE_QTRIM) ? c.kept + c.qfilter : 0;
+    slot[FXG_C_ARTIFACT_DROPPED] = c.artifact;
 }
 
 // ---- per-thread phase bodies (host+device so tests/emu can run them serially) ----
@@ -340,6 +342,32 @@ FXG_HD void fxg_decide_b(const FxgKArgs &a, u32 r0, u32 tid, u32 *keep_out, u32 
     *keep_out = keep; *len_out = curlen;
 }
 
+// fastq_masker (fastq_masker.c:92-108): every read is kept at full length; n_low = bases below the threshold
+FXG_HD void fxg_decide_mask(const FxgKArgs &a, const u32 *bm_l, u32 r0, u32 tid, u32 *keep_out, u32 *len_out, u32 *n_low)
+{
+    const u32 rl = a.len ? (u32)a.len[r0 + tid] : a.fixed_len;
+    *n_low = fxg_bits_count(bm_l, tid * a.stride, rl);
+    a.res[r0 + tid] = (rl & 0xFFFFu) | (1u << 16);
+    *keep_out = 1u; *len_out = rl;
+}
+
+// fastx_artifacts_filter (fastx_artifacts_filter.c:56-112): drop a read when one of A/C/G/T fills all but <= 3 positions
+FXG_HD void fxg_decide_artifacts(const FxgKArgs &a, const uint8_t *row, u32 r0, u32 tid, u32 *keep_out, u32 *len_out, u32 *bad)
+{
+    const u32 rl = a.len ? (u32)a.len[r0 + tid] : a.fixed_len;
+    u32 ca = 0, cc = 0, cg = 0, ct = 0, cn = 0;
+    for (u32 k = 0; k < rl; ++k) {
+        const u32 b = row[k];
+        ca += (b == 'A'); cc += (b == 'C'); cg += (b == 'G'); ct += (b == 'T'); cn += (b == 'N');
+    }
+    if (ca + cc + cg + ct + cn != rl) *bad = 1u;          // "invalid nucleotide value" in the reference
+    const int lim = (int)rl - 3;
+    const u32 art = ((int)ca >= lim) | ((int)cc >= lim) | ((int)cg >= lim) | ((int)ct >= lim);
+    const u32 keep = art ^ 1u;
+    a.res[r0 + tid] = (rl & 0xFFFFu) | (keep << 16) | ((art ? (u32)FXG_R_ARTIFACT : 0u) << 17);
+    *keep_out = keep; *len_out = rl;
+}
+
 // per-kept-read side outputs
 FXG_HD void fxg_write_kept_meta(const FxgKArgs &a, u64 rank, u32 olen, u32 read_index, u64 byte_off)
 {
@@ -350,7 +378,8 @@ FXG_HD void fxg_write_kept_meta(const FxgKArgs &a, u64 rank, u32 olen, u32 read_
 
 #ifndef FXG_HOST_EMULATION   // everything below is device code proper (wave intrinsics, __global__)
 
-// MODE 0: [clip][qtrim][qfilter] (AMAX = adapter bucket, 0 = no clip); MODE 1: fixed trim; MODE 2: reverse-complement [+ fixed trim]
+// MODE 0: [clip][qtrim][qfilter] (AMAX = adapter bucket, 0 = no clip); MODE 1: fixed trim; MODE 2: reverse-complement [+ fixed trim];
+// MODE 3: fastq_masker; MODE 4: fastx_artifacts_filter
 #ifndef FXG_MIN_WAVES
 #define FXG_MIN_WAVES 5   // __launch_bounds__ 2nd argument (waves per SIMD) for the streaming instances: 5 workgroups/CU measured best
 #endif
@@ -360,8 +389,9 @@ __global__ __launch_bounds__(FXG_BLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void fx
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool REV = (MODE == 2);
     const u32 T = a.tile_reads, stride = a.stride, tid = threadIdx.x;
-    const bool use_q = MODE == 0 && (a.stages & (FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0;
-    const FxgLds L = fxg_lds_layout(T, stride, use_q, MODE == 0 && AMAX != 0);
+    const bool use_q = (MODE == 0 && (a.stages & (FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0) || MODE == 3;
+    const FxgLds L = fxg_lds_layout(T, stride, use_q, (MODE == 0 && AMAX != 0) || MODE == 4);
+    u32 m_reads = 0, m_nt = 0, art_bad = 0;      // MODE 3 report counters / MODE 4 alphabet check, folded once at the end
     u32 *bm_g = reinterpret_cast<u32 *>(smem + L.off_bm_g);
     u32 *bm_l = reinterpret_cast<u32 *>(smem + L.off_bm_l);
     uint8_t *sb = smem + L.off_bases;
@@ -389,14 +419,16 @@ __global__ __launch_bounds__(FXG_BLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void fx
             const u32 nreads = left < (u64)T ? (u32)left : T;
             const u64 tb = (u64)r0 * stride;
             const u32 tbytes = nreads * stride;
-            if constexpr (MODE == 0) {
+            if constexpr (MODE == 0 || MODE == 3 || MODE == 4) {
                 if (use_q && !FXG_DBG(a, 8u)) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, FXG_BLOCK);
-                if constexpr (AMAX != 0) fxg_phase_stage_bases(a, tb, tbytes, sb, tid, FXG_BLOCK);
+                if constexpr ((MODE == 0 && AMAX != 0) || MODE == 4) fxg_phase_stage_bases(a, tb, tbytes, sb, tid, FXG_BLOCK);
                 __syncthreads();
             }
             u32 keep = 0, olen = 0, anchor = tid * stride;
             if (tid < nreads) {
                 if constexpr (MODE == 0) fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen);
+                else if constexpr (MODE == 3) { u32 nl; fxg_decide_mask(a, bm_l, r0, tid, &keep, &olen, &nl); m_nt += nl; m_reads += (nl != 0u); }
+                else if constexpr (MODE == 4) fxg_decide_artifacts(a, sb + tid * stride, r0, tid, &keep, &olen, &art_bad);
                 else fxg_decide_b<REV>(a, r0, tid, &keep, &olen, &anchor);
             }
             u32 exc, exb, totc, totb;
@@ -434,7 +466,7 @@ __global__ __launch_bounds__(FXG_BLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void fx
                 if (olen) fxg_write_kept_meta(a, base_c + v_rank[tid], olen, r0 + tid, base_b + v_off[tid]);
             }
             if (!FXG_DBG(a, 1u)) {
-                const u32 bad = fxg_tile_gather<REV>(a, v_off, v_src, nreads, (u64)r0 * stride, base_b, totb, tid, FXG_BLOCK);
+                const u32 bad = fxg_tile_gather<REV, MODE == 3>(a, v_off, v_src, nreads, (u64)r0 * stride, base_b, totb, tid, FXG_BLOCK);
                 if (REV && bad) atomicOr(a.errflag, FXG_DEV_ERR_BAD_BASE);
             }
         }
@@ -445,6 +477,11 @@ __global__ __launch_bounds__(FXG_BLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void fx
         cur = s_ticket[tk] * G + grp;
         slot ^= 1u;
     }
+    if constexpr (MODE == 3) {                       // masked reads / nucleotides: wave sums, one atomic pair per wave, once
+        for (int d = 32; d >= 1; d >>= 1) { m_reads += __shfl_xor(m_reads, d, 64); m_nt += __shfl_xor(m_nt, d, 64); }
+        if (fxg_lane() == 0 && (m_reads | m_nt)) { atomicAdd(&a.extra[0], (u64)m_reads); atomicAdd(&a.extra[1], (u64)m_nt); }
+    }
+    if constexpr (MODE == 4) { if (art_bad) atomicOr(a.errflag, FXG_DEV_ERR_BAD_BASE); }
 }
 
 // res[] -> per-workgroup partial counters (the -v report inputs, a12)
@@ -480,17 +517,25 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_count_res(const u32 *res
 }
 
 // partial[rows][16] -> counters[16]; also folds the device error word into counters[FXG_C_ERRORS]
-__global__ void fxg_kernel_reduce_counters(const u64 *partial, u32 rows, const u32 *errflag, u64 *counters)
+__global__ void fxg_kernel_reduce_counters(const u64 *partial, u32 rows, const u32 *errflag, const u64 *extra, u64 *counters)
 {
     __shared__ u64 acc[FXG_NCOUNTERS];
     if (threadIdx.x < FXG_NCOUNTERS) acc[threadIdx.x] = 0ull;
     __syncthreads();
-    const u32 col = threadIdx.x % FXG_NCOUNTERS;
-    u64 s = 0;
-    for (u32 r = threadIdx.x / FXG_NCOUNTERS; r < rows; r += blockDim.x / FXG_NCOUNTERS) s += partial[(u64)r * FXG_NCOUNTERS + col];
-    if (s) atomicAdd(&acc[col], s);
+    if (threadIdx.x < (blockDim.x / FXG_NCOUNTERS) * FXG_NCOUNTERS) {
+        const u32 col = threadIdx.x % FXG_NCOUNTERS;
+        u64 s = 0;
+        for (u32 r = threadIdx.x / FXG_NCOUNTERS; r < rows; r += blockDim.x / FXG_NCOUNTERS) s += partial[(u64)r * FXG_NCOUNTERS + col];
+        if (s) atomicAdd(&acc[col], s);
+    }
     __syncthreads();
-    if (threadIdx.x < FXG_NCOUNTERS) counters[threadIdx.x] = (threadIdx.x == FXG_C_ERRORS) ? (u64)*errflag : acc[threadIdx.x];
+    if (threadIdx.x < FXG_NCOUNTERS) {
+        u64 v = acc[threadIdx.x];
+        if (threadIdx.x == FXG_C_ERRORS) v = (u64)*errflag;
+        if (threadIdx.x == FXG_C_MASKED_READS) v = extra[0];
+        if (threadIdx.x == FXG_C_MASKED_NT) v = extra[1];
+        counters[threadIdx.x] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -9,8 +9,9 @@
 
 struct FxgPlan {
     FxgKArgs ka;
-    bool group_a;   // [CLIP][QTRIM][QFILTER] chain (else [REVCOMP][FTRIM*])
+    bool group_a;   // [CLIP][QTRIM][QFILTER] chain (else [REVCOMP][FTRIM*] unless mode3/mode4)
     bool clip, use_q, rev;
+    bool mask, artifacts;
     int  amax;      // adapter bucket of the clip kernel instance (0 = no clip)
     u32  lds;       // dynamic LDS bytes per workgroup
 };
@@ -35,7 +36,10 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     const u32 st = p->stages;
     const bool ga = (st & (FXG_STAGE_CLIP | FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0;
     const bool gb = (st & (FXG_STAGE_REVCOMP | FXG_STAGE_FTRIM | FXG_STAGE_FTRIM_END)) != 0;
-    if (ga == gb) FXG_PLAN_FAIL("unsupported stage chain 0x%x: use [CLIP][QTRIM][QFILTER] or [REVCOMP][FTRIM|FTRIM_END]", st);
+    const bool gm = (st & FXG_STAGE_MASK) != 0, gf = (st & FXG_STAGE_ARTIFACTS) != 0;
+    if ((int)ga + (int)gb + (int)gm + (int)gf != 1)
+        FXG_PLAN_FAIL("unsupported stage chain 0x%x: use [CLIP][QTRIM][QFILTER], [REVCOMP][FTRIM|FTRIM_END], [MASK] or [ARTIFACTS]", st);
+    if (gm && !in->qual) FXG_PLAN_FAIL("fastq_masker needs qualities");
     if ((st & FXG_STAGE_FTRIM) && (st & FXG_STAGE_FTRIM_END))
         FXG_PLAN_FAIL("[-t], [-f] and [-l] options can not be used together");   // fastx_trimmer.c:112-113
     if (!in->bases || !out->res) FXG_PLAN_FAIL("bases and res are mandatory");
@@ -56,7 +60,8 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     ka.compact = out->out_bases ? 1u : 0u;
     ka.stages = st;
     ka.tq = (u32)fxg_clampi((long long)p->qt_threshold + p->qoffset, 0, 128);
-    ka.fq = (u32)fxg_clampi((long long)p->qf_min_quality + p->qoffset, 0, 128);
+    ka.fq = (u32)fxg_clampi((long long)(gm ? p->mask_min_quality : p->qf_min_quality) + p->qoffset, 0, 128);
+    ka.mask_char = p->mask_char & 0xFFu;
     ka.qt_min_len = p->qt_min_len;
     ka.qf_keep_pct = 100 - p->qf_min_percent;
     ka.qf_drop_all = (p->qf_min_percent == 0 && p->qf_min_quality > 93) ? 1u : 0u;   // quirk F2
@@ -68,6 +73,7 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     ka.alen = (int)strlen(ka.adapter);
 
     pl->group_a = ga;
+    pl->mask = gm; pl->artifacts = gf;
     pl->clip = (st & FXG_STAGE_CLIP) != 0;
     pl->use_q = (st & (FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0;
     pl->rev = (st & FXG_STAGE_REVCOMP) != 0;
@@ -82,10 +88,12 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
         for (unsigned i = 0; i < sizeof pk / sizeof pk[0]; ++i) if (ka.alen <= pk[i]) { b = pk[i]; break; }
         pl->amax = -b;
     }
-    const u32 T = fxg_pick_tile(in->stride, pl->clip);
+    const u32 T = fxg_pick_tile(in->stride, pl->clip || gf);
     const u64 ntiles = (in->n + T - 1) / T;
     if (ntiles > 0x7FFFFFFFull || in->n > 0xFFFFFFFFull) FXG_PLAN_FAIL("batch too large (%llu reads): split it", (unsigned long long)in->n);
     ka.tile_reads = T; ka.ntiles = (u32)ntiles;
-    pl->lds = ga ? fxg_lds_layout(T, in->stride, pl->use_q, pl->clip).total : fxg_lds_layout(T, in->stride, false, false).total;
+    pl->lds = ga ? fxg_lds_layout(T, in->stride, pl->use_q, pl->clip).total
+               : gm ? fxg_lds_layout(T, in->stride, true, false).total
+               : gf ? fxg_lds_layout(T, in->stride, false, true).total : fxg_lds_layout(T, in->stride, false, false).total;
     return FXG_OK;
 }

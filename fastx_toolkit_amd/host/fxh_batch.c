@@ -61,6 +61,8 @@ void fxh_default_params(fxg_params *p, int qoffset)
     strcpy(p->adapter, "CCTTAAGG");   /* fastx_clipper.cpp:68 */
     p->clip_min_len = 5;              /* fastx_clipper.cpp:69 */
     p->ft_first = 1;
+    p->mask_min_quality = 10;         /* fastq_masker.c:47 */
+    p->mask_char = 'N';               /* fastq_masker.c:48 */
 }
 
 static void fxh_grow(fxh_state *st, size_t reads, size_t bytes, int revcomp)
@@ -557,6 +559,7 @@ static int fxh_block_gpu_text(FASTX *fx, fxh_state *st, const fxg_params *p, fxh
     tot->clip_too_short += (unsigned)ctr[FXG_C_CLIP_TOO_SHORT]; tot->clip_adapter_only += (unsigned)ctr[FXG_C_CLIP_ADAPTER_ONLY];
     tot->clip_no_adapter += (unsigned)ctr[FXG_C_CLIP_NO_ADAPTER]; tot->clip_adapter_found += (unsigned)ctr[FXG_C_CLIP_ADAPTER_FOUND];
     tot->clip_n += (unsigned)ctr[FXG_C_CLIP_N];
+    tot->masked_reads += ctr[FXG_C_MASKED_READS]; tot->masked_nucleotides += ctr[FXG_C_MASKED_NT];
     rd->beg += (size_t)info.consumed > rd->end - rd->beg ? rd->end - rd->beg : (size_t)info.consumed;
     fx->input_line_number += 4ull * n;
     return 1;
@@ -581,7 +584,7 @@ int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *tot)
     fxh_job job;
     memset(&job, 0, sizeof job);
     job.fx = fx; job.st = &st; job.p = p;
-    job.revcomp = (p->stages & FXG_STAGE_REVCOMP) != 0;
+    job.revcomp = (p->stages & (FXG_STAGE_REVCOMP | FXG_STAGE_MASK)) != 0;   /* stages whose output is not a slice of the input text */
     job.has_q = fx->read_fastq;
     job.lpr = fx->read_fastq ? 4 : 2;
     job.fwd_start = (p->stages & FXG_STAGE_FTRIM) && p->ft_first > 1 ? (uint32_t)p->ft_first - 1u : 0u;
@@ -735,6 +738,7 @@ int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *tot)
                 if (rc == FXG_E_DEVICE && (ctr[FXG_C_ERRORS] & FXG_DEV_ERR_BAD_BASE)) errx(1, "%s", fxg_last_error(st.ctx));
                 if (rc != 0) errx(1, "GPU engine error %d: %s", rc, fxg_last_error(st.ctx));
             }
+            tot->masked_reads += ctr[FXG_C_MASKED_READS]; tot->masked_nucleotides += ctr[FXG_C_MASKED_NT];
             if (job.revcomp) {
                 FXG_CHECK(&st, fxg_memcpy_d2h(st.ctx, st.h_out_bases, st.d_out_bases, ctr[FXG_C_KEPT_BASES]));
                 if (job.has_q) FXG_CHECK(&st, fxg_memcpy_d2h(st.ctx, st.h_out_qual, st.d_out_qual, ctr[FXG_C_KEPT_BASES]));

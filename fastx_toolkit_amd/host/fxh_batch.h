@@ -23,6 +23,8 @@ typedef struct fxh_totals {
     size_t input_sequences, input_reads, output_sequences, output_reads;
     /* fastx_clipper.cpp:80-85 (32-bit unsigned there; printed with %u) */
     unsigned int clip_input, clip_too_short, clip_adapter_only, clip_no_adapter, clip_adapter_found, clip_n;
+    /* fastq_masker.c:78-79 */
+    size_t masked_reads, masked_nucleotides;
 } fxh_totals;
 
 /* Runs the whole input of `fx` (reader and writer already initialised) through the engine with the stage

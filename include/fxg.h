@@ -40,13 +40,15 @@ extern "C" {
 #define FXG_E_NOMEM      -3
 #define FXG_E_DEVICE     -4   /* device-side failure flag (scan time-out, invalid nucleotide, ...) */
 
-/* ---- pipeline stages.  Supported chains: [CLIP][QTRIM][QFILTER]  and  [REVCOMP][FTRIM|FTRIM_END] ---- */
+/* ---- pipeline stages.  Supported chains: [CLIP][QTRIM][QFILTER], [REVCOMP][FTRIM|FTRIM_END], [MASK], [ARTIFACTS] ---- */
 #define FXG_STAGE_CLIP      0x01u  /* fastx_clipper            */
 #define FXG_STAGE_QTRIM     0x02u  /* fastq_quality_trimmer    */
 #define FXG_STAGE_QFILTER   0x04u  /* fastq_quality_filter     */
 #define FXG_STAGE_REVCOMP   0x08u  /* fastx_reverse_complement */
 #define FXG_STAGE_FTRIM     0x10u  /* fastx_trimmer -f/-l      */
 #define FXG_STAGE_FTRIM_END 0x20u  /* fastx_trimmer -t/-m      */
+#define FXG_STAGE_MASK      0x40u  /* fastq_masker             (reference src/fastq_masker/fastq_masker.c:92-108) */
+#define FXG_STAGE_ARTIFACTS 0x80u  /* fastx_artifacts_filter   (src/fastx_artifacts_filter/fastx_artifacts_filter.c:56-112) */
 
 /* fastx_clipper switches (fastx_clipper.cpp:90-146) */
 #define FXG_CLIP_DISCARD_NON_CLIPPED 0x1u /* -c */
@@ -79,7 +81,8 @@ enum fxg_reason {
     FXG_R_QTRIM = 6,              /* fastq_quality_trimmer.c:101 */
     FXG_R_QFILTER = 7,            /* fastq_quality_filter.c:155 */
     FXG_R_FTRIM = 8,              /* fastx_trimmer.c:127,137,140 */
-    FXG_R_CLIP_K_MODE = 9         /* fastx_clipper.cpp:317 (-k: only adapter-only reads are written) */
+    FXG_R_CLIP_K_MODE = 9,        /* fastx_clipper.cpp:317 (-k: only adapter-only reads are written) */
+    FXG_R_ARTIFACT = 10           /* fastx_artifacts_filter.c:101-109 */
 };
 
 /* slots of the u64 counter block (feeds the tools' -v reports, a12) */
@@ -97,8 +100,11 @@ enum fxg_counter {
     FXG_C_FTRIM_DROPPED = 10,
     FXG_C_CLIP_OUT = 11,          /* reads that survive the clip stage */
     FXG_C_QTRIM_OUT = 12,         /* reads that survive the quality-trim stage */
+    FXG_C_MASKED_READS = 13,      /* fastq_masker.c:100-101 */
+    FXG_C_MASKED_NT = 14,         /* fastq_masker.c:97 */
     FXG_C_ERRORS = 15,            /* device error bits, see FXG_DEV_ERR_* */
-    FXG_NCOUNTERS = 16
+    FXG_C_ARTIFACT_DROPPED = 16,
+    FXG_NCOUNTERS = 24
 };
 #define FXG_DEV_ERR_SCAN_TIMEOUT 0x1u
 #define FXG_DEV_ERR_BAD_BASE     0x2u  /* fastx_reverse_complement.c:67-68 "Invalid nucleotide value" */
@@ -120,6 +126,8 @@ typedef struct fxg_params {
     int32_t  ft_last;             /* fastx_trimmer -l (0 = to the end) */
     uint32_t ft_trim_end;         /* fastx_trimmer -t */
     uint32_t ft_min_len;          /* fastx_trimmer -m */
+    int32_t  mask_min_quality;    /* fastq_masker -q (default 10) */
+    uint32_t mask_char;           /* fastq_masker -r (default 'N') */
 } fxg_params;
 
 /* Input batch (replaces the one-record FASTX struct, fastx.h:62-117): row r of bases/qual starts at

@@ -289,7 +289,9 @@ int fxo_run_pipeline(const fxo_batch *in, const fxo_params *p, fxo_out *out)
     const uint32_t st = p->stages;
     const int group_a = (st & (FXO_STAGE_CLIP | FXO_STAGE_QTRIM | FXO_STAGE_QFILTER)) != 0;
     const int group_b = (st & (FXO_STAGE_REVCOMP | FXO_STAGE_FTRIM | FXO_STAGE_FTRIM_END)) != 0;
-    if (group_a == group_b) return -1;
+    const int group_c = (st & FXO_STAGE_MASK) != 0, group_d = (st & FXO_STAGE_ARTIFACTS) != 0;
+    if (group_a + group_b + group_c + group_d != 1) return -1;
+    if (group_c && !in->qual) return -1;
     if ((st & FXO_STAGE_FTRIM) && (st & FXO_STAGE_FTRIM_END)) return -1;   /* fastx_trimmer.c:112-113 */
     if ((st & (FXO_STAGE_QTRIM | FXO_STAGE_QFILTER)) && !in->qual) return -1;
 
@@ -348,6 +350,27 @@ int fxo_run_pipeline(const fxo_batch *in, const fxo_params *p, fxo_out *out)
             keep = fxo_qfilter_read(q, len, p->qoffset, p->qf_min_quality, p->qf_min_percent);
             if (!keep) { reason = FXO_R_QFILTER; out->counters[FXO_C_QFILTER_DROPPED]++; }
         }
+        if (st & FXO_STAGE_ARTIFACTS) {          /* fastx_artifacts_filter.c:56-112 */
+            int cnt[5] = {0, 0, 0, 0, 0}, total = 0;
+            for (int k = 0; k < len; ++k) {
+                total++;
+                switch (b[k]) {
+                case 'A': cnt[0]++; break; case 'C': cnt[1]++; break; case 'G': cnt[2]++; break; case 'T': cnt[3]++; break; case 'N': cnt[4]++; break;
+                default: rc = -2; goto done;
+                }
+            }
+            if (cnt[0] >= total - 3 || cnt[1] >= total - 3 || cnt[2] >= total - 3 || cnt[3] >= total - 3) {
+                keep = 0; reason = FXO_R_ARTIFACT; out->counters[FXO_C_ARTIFACT_DROPPED]++;
+            }
+        }
+        int masked = 0;
+        if (st & FXO_STAGE_MASK) {               /* fastq_masker.c:92-103: every read is written, low-quality bases replaced */
+            for (int k = 0; k < len; ++k) {
+                int qv = (int)(signed char)q[k] - p->qoffset;
+                if (qv < p->mask_min_quality) { masked = 1; out->counters[FXO_C_MASKED_NT]++; }
+            }
+            if (masked) out->counters[FXO_C_MASKED_READS]++;
+        }
         if (st & FXO_STAGE_REVCOMP) reversed = 1;
         if (keep && (st & FXO_STAGE_FTRIM)) {     /* fastx_trimmer.c:122-134 */
             if (p->ft_last != 0 && p->ft_last < len) len = p->ft_last;
@@ -381,6 +404,9 @@ int fxo_run_pipeline(const fxo_batch *in, const fxo_params *p, fxo_out *out)
             sb = tmpb; sq = q ? tmpq : NULL;
         }
         memcpy(out->out_bases + obytes, sb + start, (size_t)len);
+        if (masked)
+            for (int k = 0; k < len; ++k)
+                if ((int)(signed char)q[k] - p->qoffset < p->mask_min_quality) out->out_bases[obytes + k] = (uint8_t)p->mask_char;
         if (q && out->out_qual) memcpy(out->out_qual + obytes, sq + start, (size_t)len);
         if (out->out_len) out->out_len[kept] = (uint16_t)len;
         if (out->kept_index) out->kept_index[kept] = (uint32_t)r;

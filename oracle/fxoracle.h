@@ -31,6 +31,8 @@ extern "C" {
 #define FXO_STAGE_REVCOMP   0x08u  /* fastx_reverse_complement */
 #define FXO_STAGE_FTRIM     0x10u  /* fastx_trimmer -f/-l      */
 #define FXO_STAGE_FTRIM_END 0x20u  /* fastx_trimmer -t/-m      */
+#define FXO_STAGE_MASK      0x40u  /* fastq_masker             */
+#define FXO_STAGE_ARTIFACTS 0x80u  /* fastx_artifacts_filter   */
 
 #define FXO_CLIP_DISCARD_NON_CLIPPED 0x1u /* -c */
 #define FXO_CLIP_DISCARD_CLIPPED     0x2u /* -C */
@@ -48,7 +50,8 @@ enum {
     FXO_R_QTRIM = 6,
     FXO_R_QFILTER = 7,
     FXO_R_FTRIM = 8,
-    FXO_R_CLIP_K_MODE = 9 /* -k given and the read is not adapter-only */
+    FXO_R_CLIP_K_MODE = 9, /* -k given and the read is not adapter-only */
+    FXO_R_ARTIFACT = 10
 };
 
 /* counters[] slots */
@@ -66,7 +69,10 @@ enum {
     FXO_C_FTRIM_DROPPED = 10,
     FXO_C_CLIP_OUT = 11,
     FXO_C_QTRIM_OUT = 12,
-    FXO_NCOUNTERS = 16
+    FXO_C_MASKED_READS = 13,
+    FXO_C_MASKED_NT = 14,
+    FXO_C_ARTIFACT_DROPPED = 16,
+    FXO_NCOUNTERS = 24
 };
 
 #define FXO_RES_LEN(w)    ((uint32_t)(w) & 0xFFFFu)
@@ -94,6 +100,9 @@ typedef struct {
     int32_t  ft_last;            /* -l, 0 = keep to the end */
     uint32_t ft_trim_end;        /* -t */
     uint32_t ft_min_len;         /* -m */
+    /* fastq_masker */
+    int32_t  mask_min_quality;   /* -q */
+    uint32_t mask_char;          /* -r */
 } fxo_params;
 
 /* Structure-of-arrays batch: row r lives at bases + r*stride, length len[r] (or fixed_len if len==NULL).
@@ -142,7 +151,7 @@ void         fxo_aligner_free(fxo_aligner *a);
 void         fxo_align(fxo_aligner *a, const char *query, int qn, const char *target, int tn, fxo_align_res *res);
 int          fxo_adapter_cutoff_index(const fxo_align_res *r, int min_adapter_len);
 
-/* ---- batch pipeline: supported chains are [CLIP][QTRIM][QFILTER] and [REVCOMP][FTRIM|FTRIM_END] ---- */
+/* ---- batch pipeline: supported chains are [CLIP][QTRIM][QFILTER], [REVCOMP][FTRIM|FTRIM_END], [MASK], [ARTIFACTS] ---- */
 /* returns 0, or -1 on unsupported stage combination, -2 on invalid base for REVCOMP */
 int fxo_run_pipeline(const fxo_batch *in, const fxo_params *p, fxo_out *out);
 

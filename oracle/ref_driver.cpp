@@ -10,8 +10,8 @@
  * numeric/ASCII quality handling, output formatting, the aligner and its traceback -- is the
  * reference's own object code.
  *
- * usage:  fxref <tool> [tool flags]      tool = fastq_quality_trimmer | fastq_quality_filter |
- *                                               fastx_clipper | fastx_trimmer | fastx_reverse_complement
+ * usage:  fxref <tool> [tool flags]      tool = fastq_quality_trimmer | fastq_quality_filter | fastx_clipper | fastx_trimmer |
+ *                                               fastx_reverse_complement | fastq_masker | fastx_artifacts_filter
  */
 #include <err.h>
 #include <cstdio>
@@ -270,6 +270,64 @@ static int run_clipper(int argc, char **argv)
     return 0;
 }
 
+/* ---- fastq_masker.c:49-123 ---- */
+static int mk_min_quality = 10;
+static char mk_char = 'N';
+static int mk_args(int, int c, char *arg)
+{
+    if (c == 'q') { mk_min_quality = atoi(arg); if (mk_min_quality < -40) errx(1, "Invalid minimum length value (-q %s)", arg); }
+    else if (c == 'r') { if (strlen(arg) != 1) errx(1, "[-r] parameter requires a single character as value"); mk_char = arg[0]; }
+    else errx(1, "Unknown argument (%c)", c);
+    return 1;
+}
+static int run_masker(int argc, char **argv)
+{
+    size_t masked_reads = 0, masked_nt = 0;
+    fastx_parse_cmdline(argc, argv, "q:r:", mk_args);
+    fastx_init_reader(&fx, get_input_filename(), FASTQ_ONLY, ALLOW_N, REQUIRE_UPPERCASE, get_fastq_ascii_quality_offset());
+    fastx_init_writer(&fx, get_output_filename(), OUTPUT_SAME_AS_INPUT, compress_output_flag());
+    while (fastx_read_next_record(&fx)) {
+        int any = 0, n = (int)strlen(fx.nucleotides);
+        for (int i = 0; i < n; ++i)
+            if (fx.quality[i] < mk_min_quality) { fx.nucleotides[i] = mk_char; any = 1; ++masked_nt; }     /* :94-99 */
+        if (any) masked_reads += get_reads_count(&fx);
+        fastx_write_record(&fx);
+    }
+    if (verbose_flag()) {                                                           /* :110-120 */
+        FILE *rf = get_report_file();
+        fprintf(rf, "Minimum Quality Threshold: %d\n", mk_min_quality);
+        fprintf(rf, "Low-quality nucleotides replaced with '%c'\n", mk_char);
+        fprintf(rf, "Input: %zu reads.\nOutput: %zu reads.\n", num_input_reads(&fx), num_output_reads(&fx));
+        fprintf(rf, "Masked reads: %zu\nMasked nucleotides: %zu\n", masked_reads, masked_nt);
+    }
+    return 0;
+}
+
+/* ---- fastx_artifacts_filter.c:56-144 ---- */
+static int run_artifacts(int argc, char **argv)
+{
+    fastx_parse_cmdline(argc, argv, "", NULL);
+    fastx_init_reader(&fx, get_input_filename(), FASTA_OR_FASTQ, ALLOW_N, REQUIRE_UPPERCASE, get_fastq_ascii_quality_offset());
+    fastx_init_writer(&fx, get_output_filename(), OUTPUT_SAME_AS_INPUT, compress_output_flag());
+    while (fastx_read_next_record(&fx)) {
+        int cnt[256] = {0}, total = 0;
+        for (const char *p = fx.nucleotides; *p; ++p) {
+            if (!strchr("ACGTN", *p)) errx(1, "invalid nucleotide value (%c) at position %d", *p, total);
+            cnt[(unsigned char)*p]++; total++;
+        }
+        const int lim = total - 3;                                                  /* :101-109 */
+        if (cnt['A'] >= lim || cnt['C'] >= lim || cnt['G'] >= lim || cnt['T'] >= lim) continue;
+        fastx_write_record(&fx);
+    }
+    if (verbose_flag()) {                                                           /* :132-140 */
+        FILE *rf = get_report_file();
+        size_t in = num_input_reads(&fx), out = num_output_reads(&fx);
+        fprintf(rf, "Input: %zu reads.\nOutput: %zu reads.\n", in, out);
+        fprintf(rf, "discarded %zu (%zu%%) artifact reads.\n", in - out, ((in - out) * 100) / in);
+    }
+    return 0;
+}
+
 /* debugging aid for the parity tests: "fxref align QUERY TARGET" prints the 7 result fields */
 static int run_align(int argc, char **argv)
 {
@@ -290,6 +348,8 @@ int main(int argc, char **argv)
     if (!strcmp(tool, "fastx_trimmer")) return run_trimmer(argc, argv);
     if (!strcmp(tool, "fastx_reverse_complement")) return run_revcomp(argc, argv);
     if (!strcmp(tool, "fastx_clipper")) return run_clipper(argc, argv);
+    if (!strcmp(tool, "fastq_masker")) return run_masker(argc, argv);
+    if (!strcmp(tool, "fastx_artifacts_filter")) return run_artifacts(argc, argv);
     if (!strcmp(tool, "align")) return run_align(argc, argv);
     fputs(usage, stderr);
     return 2;

@@ -11,14 +11,15 @@
 
 #include "../../fastx_toolkit_amd/csrc/fxg_plan.h"
 
-template <int AMAX, bool REV>
+template <int AMAX, bool REV, int MODE = 0>
 static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
 {
     const FxgKArgs &a = pl.ka;
     const u32 T = a.tile_reads, stride = a.stride, NT = FXG_BLOCK;
     std::vector<unsigned char> lds(pl.lds + 64, 0);
     unsigned char *smem = lds.data();
-    const FxgLds L = pl.group_a ? fxg_lds_layout(T, stride, pl.use_q, pl.clip) : fxg_lds_layout(T, stride, false, false);
+    const FxgLds L = pl.group_a ? fxg_lds_layout(T, stride, pl.use_q, pl.clip) : fxg_lds_layout(T, stride, MODE == 3, MODE == 4);
+    u64 m_reads = 0, m_nt = 0;
     u32 *v_off = reinterpret_cast<u32 *>(smem);
     u32 *v_src = reinterpret_cast<u32 *>(smem + L.so_vsrc);
     u32 *bm_g = reinterpret_cast<u32 *>(smem + L.off_bm_g);
@@ -43,6 +44,16 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
                 fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid]);
                 anchor[tid] = tid * stride;
             }
+        } else if (MODE == 3) {
+            for (u32 tid = 0; tid < NT; ++tid) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, NT);
+            for (u32 tid = 0; tid < nreads; ++tid) {
+                u32 nl;
+                fxg_decide_mask(a, bm_l, r0, tid, &keep[tid], &olen[tid], &nl);
+                anchor[tid] = tid * stride; m_nt += nl; m_reads += (nl != 0u);
+            }
+        } else if (MODE == 4) {
+            for (u32 tid = 0; tid < NT; ++tid) fxg_phase_stage_bases(a, tb, tbytes, sb, tid, NT);
+            for (u32 tid = 0; tid < nreads; ++tid) { fxg_decide_artifacts(a, sb + tid * stride, r0, tid, &keep[tid], &olen[tid], &bad); anchor[tid] = tid * stride; }
         } else {
             for (u32 tid = 0; tid < nreads; ++tid) fxg_decide_b<REV>(a, r0, tid, &keep[tid], &olen[tid], &anchor[tid]);
         }
@@ -53,7 +64,7 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
             if (keep[tid]) { fxg_write_kept_meta(a, base_c + exc, olen[tid], r0 + tid, base_b + exb); exb += olen[tid]; exc++; }
         }
         v_off[nreads] = exb;
-        for (u32 tid = 0; tid < NT; ++tid) bad |= fxg_tile_gather<REV>(a, v_off, v_src, nreads, tb, base_b, exb, tid, NT);
+        for (u32 tid = 0; tid < NT; ++tid) bad |= fxg_tile_gather<REV, MODE == 3>(a, v_off, v_src, nreads, tb, base_b, exb, tid, NT);
         base_c += exc; base_b += exb;
     }
     for (u64 i = 0; i < a.n; ++i) fxg_count_res(a.res[i], cnt);   // same reduction the counting kernel performs
@@ -61,7 +72,8 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
         u64 slot[FXG_NCOUNTERS];
         fxg_counts_to_slots(cnt, a.stages, slot);
         for (int i = 0; i < FXG_NCOUNTERS; ++i) counters[i] = slot[i];
-        counters[FXG_C_ERRORS] = (REV && bad) ? FXG_DEV_ERR_BAD_BASE : 0;
+        counters[FXG_C_ERRORS] = ((REV || MODE == 4) && bad) ? FXG_DEV_ERR_BAD_BASE : 0;
+        counters[FXG_C_MASKED_READS] = m_reads; counters[FXG_C_MASKED_NT] = m_nt;
     }
     (void)err; (void)cap;
     return FXG_OK;
@@ -97,6 +109,8 @@ extern "C" int fxg_emu_run_pipeline(const fxg_batch *in, const fxg_params *p, co
         default: return emu_run<100, false>(pl, ctr, err, cap);
         }
     }
+    if (pl.mask) return emu_run<0, false, 3>(pl, ctr, err, cap);
+    if (pl.artifacts) return emu_run<0, false, 4>(pl, ctr, err, cap);
     return pl.rev ? emu_run<0, true>(pl, ctr, err, cap) : emu_run<0, false>(pl, ctr, err, cap);
 }
 

@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _EMU = os.path.join(_HERE, "emu")
 _LIB = None
-NCOUNTERS = 16
+NCOUNTERS = 24
 
 
 class Batch(C.Structure):

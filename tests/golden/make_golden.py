@@ -77,6 +77,9 @@ CASES = [
     ("ftrim_f20", (19, 1500, 75, False), [["fastx_trimmer", "-f", "20"]], P(stages=16, ft_first=20), True),
     ("ftrim_l20", (19, 1500, 75, False), [["fastx_trimmer", "-l", "20"]], P(stages=16, ft_last=20), True),
     ("revcomp", (20, 1500, 75, False), [["fastx_reverse_complement"]], P(stages=8), True),
+    ("masker_q20_dot", (23, 1500, 75, False), [["fastq_masker", "-q", "20", "-r", "."]], P(stages=64, mask_min_quality=20, mask_char="."), True),
+    ("masker_default", (23, 1500, 75, False), [["fastq_masker"]], P(stages=64), True),
+    ("artifacts", (24, 3000, 36, False), [["fastx_artifacts_filter"]], P(stages=128), True),
 ]
 
 # variable-length inputs: produced by quality-trimming a synthetic set first (the trimmed file is the INPUT)
@@ -108,6 +111,13 @@ GALAXY = [  # SURVEY.md section 4 (XML <tests> blocks)
          cmd=["fastx_reverse_complement"], params=P(stages=8)),
     dict(name="galaxy_revcomp_numeric", input="fastx_rev_comp2.fastq", expect="fastx_reverse_complement2.out",
          cmd=["fastx_reverse_complement"], params=P(stages=8)),
+    # neighbouring per-read tools on the same batch ABI
+    dict(name="galaxy_masker", input="fastq_masker.fastq", expect="fastq_masker.out",
+         cmd=["fastq_masker", "-Q", "64", "-q", "29", "-r", "x"], params=P(stages=64, qoffset=64, mask_min_quality=29, mask_char="x")),
+    dict(name="galaxy_artifacts_fasta", input="fastx_artifacts1.fasta", expect="fastx_artifacts1.out",
+         cmd=["fastx_artifacts_filter"], params=P(stages=128)),
+    dict(name="galaxy_artifacts_numeric", input="fastx_artifacts2.fastq", expect="fastx_artifacts2.out",
+         cmd=["fastx_artifacts_filter"], params=P(stages=128)),
 ]
 
 

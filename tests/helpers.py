@@ -32,7 +32,8 @@ def assert_same(o, e, what=""):
         ol = o["out_len"].astype(np.uint64)
         off = np.concatenate([[0], np.cumsum(ol)[:-1]]).astype(np.uint64) if len(ol) else np.zeros(0, np.uint64)
         assert np.array_equal(off, e["out_off"]), "%s: out_off" % what
-    assert np.array_equal(o["counters"][:13], e["counters"][:13]), "%s: counters %s vs %s" % (what, o["counters"][:13], e["counters"][:13])
+    sel = list(range(13)) + [13, 14, 16]
+    assert np.array_equal(o["counters"][sel], e["counters"][sel]), "%s: counters %s vs %s" % (what, o["counters"][sel], e["counters"][sel])
 
 
 def text_through(run, text, params, qoffset=33):
@@ -88,6 +89,13 @@ def fuzz_cases(seed, trials, clip_trials):
         for st in (32, 40):
             yield ("t%d.st%d.s%d" % (trial, st, stride), b, q, lens, fl,
                    dict(stages=st, ft_trim_end=int(rng.integers(1, stride + 2)), ft_min_len=int(rng.integers(0, stride + 1))))
+        yield ("t%d.mask.s%d" % (trial, stride), b, q, lens, fl,
+               dict(stages=64, mask_min_quality=int(rng.integers(-5, 45)), mask_char=str(rng.choice(list("N.x"))), qoffset=qo))
+        b2 = b.copy()
+        for i in range(0, n, 5):                                   # plant artifact-like reads (one base everywhere but <= 4 places)
+            b2[i, :] = ord("ACGT"[i % 4])
+            b2[i, :min(stride, int(rng.integers(0, 6)))] = ord("ACGTN"[int(rng.integers(0, 5))])
+        yield ("t%d.artifacts.s%d" % (trial, stride), b2, q, lens, fl, dict(stages=128))
     adapters = [b"AGATCGGAAGAGC", b"CCTTAAGG", b"CAATTGGTTAATCCCCCTATATA", b"ACGT", b"TGGAATTCTCGGGTGCCAAGGAACTCCAGTCAC",
                 b"ANNTCGNA", b"A" * 40 + b"CGT" * 8, b"ACGTTGCA" * 9]
     for trial in range(clip_trials):

@@ -57,6 +57,6 @@ def test_two_rank_sharding_and_epilogue():
 
 def test_single_process_epilogue_is_identity():
     from fastx_toolkit_amd import distributed as fxd
-    c = torch.arange(16, dtype=torch.int64)
+    c = torch.arange(24, dtype=torch.int64)
     totals, ro, bo, per = fxd.epilogue(c)
-    assert ro == 0 and bo == 0 and list(totals) == list(range(16)) and per.shape == (1, 16)
+    assert ro == 0 and bo == 0 and list(totals) == list(range(24)) and per.shape == (1, 24)

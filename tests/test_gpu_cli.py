@@ -121,6 +121,8 @@ def test_fuzz_cli_vs_reference(tools):
                  ["fastx_trimmer", "-f", str(int(rng.integers(1, 30))), "-l", str(int(rng.integers(30, 100))), "-v"],
                  ["fastx_trimmer", "-t", str(int(rng.integers(1, 30))), "-m", str(int(rng.integers(1, 60))), "-v"],
                  ["fastx_reverse_complement", "-v"],
+                 ["fastq_masker", "-q", str(int(rng.integers(0, 45))), "-r", str(rng.choice(list("N.x"))), "-v"],
+                 ["fastx_artifacts_filter", "-v"],
                  ["fastx_clipper", "-a", ad.decode(), "-l", str(int(rng.integers(0, 25))), "-v"] + list(rng.choice(["-n", "-c", "-C", "-k"], size=2, replace=False))]
         for argv in argvs:
             env = dict(os.environ, FXH_THREADS=str([16, 1, 3, 7][trial % 4]), FXH_READ_BUFFER_MB="1")

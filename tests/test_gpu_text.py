@@ -24,7 +24,7 @@ def _gpu_text_pipeline(engine, text, pd, qoffset=33):
     bases, qual, irr = engine.fastq_pack(d_text, tl, ls, n, stride, qoffset)
     assert irr == 0
     p = make_params(**dict(pd, qoffset=33))            # rows hold Phred+33 codes
-    rev = bool(pd["stages"] & 8)
+    rev = bool(pd["stages"] & (8 | 64))              # stages whose output is not a slice of the input: use the packed arrays
     fixed = info.min_len == info.max_len
     r = engine.run(bases, qual, p, lens=None if fixed else lens[:n], fixed_len=stride, compact=rev, meta=rev)
     fwd = pd.get("ft_first", 1) - 1 if (pd["stages"] & 16) else 0
@@ -74,7 +74,7 @@ def test_text_to_text_matches_reference_md5(engine, cases):
 def test_revcomp_trim_and_offsets_text(engine):
     text = fo.synth_fastq(41, 0, 30000, 75)
     for pd in (dict(stages=8), dict(stages=16, ft_first=7, ft_last=60), dict(stages=32, ft_trim_end=10, ft_min_len=20),
-               dict(stages=2, qt_threshold=25, qt_min_len=20)):
+               dict(stages=2, qt_threshold=25, qt_min_len=20), dict(stages=64, mask_min_quality=22, mask_char="."), dict(stages=128)):
         exp, _ = text_through(fo.run_pipeline, text, oracle_params(pd))
         out, _, _ = _gpu_text_pipeline(engine, text, pd)
         assert out == exp, pd

@@ -72,6 +72,25 @@ def test_trimmer_revcomp_vs_reference():
         assert got == exp
 
 
+def test_masker_and_artifacts_vs_reference():
+    rng = np.random.default_rng(6)
+    for trial in range(10):
+        text = _fastq(rng, 300, 1, 90)
+        lines = text.split(b"\n")
+        for k in range(1, len(lines) - 1, 28):                      # plant homopolymer-ish reads
+            L = len(lines[k])
+            lines[k] = (b"A" * L)[:L - min(L, trial % 5)] + lines[k][L - min(L, trial % 5):]
+        text = b"\n".join(lines)
+        mq, ch = int(rng.integers(-3, 45)), str(rng.choice(list("N.x")))
+        exp = _ref(text, [["fastq_masker", "-q", str(mq), "-r", ch]])
+        got, _ = text_through(fo.run_pipeline, text, oracle_params(dict(stages=64, mask_min_quality=mq, mask_char=ch)))
+        assert got == exp
+        exp = _ref(text, [["fastx_artifacts_filter"]])
+        got, r = text_through(fo.run_pipeline, text, oracle_params(dict(stages=128)))
+        assert got == exp
+    assert int(r["counters"][16]) > 0
+
+
 def test_clipper_vs_reference_fixed_and_ragged():
     rng = np.random.default_rng(3)
     ads = [b"AGATCGGAAGAGC", b"CCTTAAGG", b"CAATTGGTTAATCCCCCTATATA", b"ACGT", b"ANNTCGNA"]
