@@ -12,7 +12,7 @@ stream-compacts the kept, trimmed reads in input order.  One "step" = one such p
            bench.py --gpus N --steps K --warmup W
 
 Multi-GPU: reads shard by contiguous index range (rank g owns reads [g*R, (g+1)*R) of the global set),
-no data-path collective; each step ends with one 128-byte all-gather of the counter blocks (RCCL) from
+no data-path collective; each step ends with one 192-byte all-gather of the counter blocks (RCCL) from
 which every rank derives the job totals and its offset in the global output.  scaling = weak.
 """
 import argparse
@@ -97,10 +97,12 @@ def main():
     outs = eng.alloc_outputs(R, L, compact=compact, meta=False)
     torch.cuda.synchronize()
 
+    gathered = [None]
+
     def step():
         r = eng.run(bases, qual, params, fixed_len=L, compact=compact, meta=False, outputs=outs)
         if world > 1:
-            fxd.epilogue(outs["counters"])        # 128-byte all-gather -> totals + this rank's output offsets
+            gathered[0] = fxd.gather_counters(outs["counters"])   # 192-byte all-gather, enqueued after the kernels, no host sync
         return r
 
     for _ in range(args.warmup):
@@ -124,6 +126,9 @@ def main():
 
     counters = res.counters
     kept, kept_bytes = int(counters[1]), int(counters[2])
+    if world > 1:                                  # job totals and this rank's offsets in the global output, from the last step's gather
+        totals, read_off, byte_off, _ = fxd.offsets_from_gathered(gathered[0], rank)
+        assert int(totals[0]) == R * world
 
     # kernel-level time of the dominant kernel: HIP events on the launch stream, one launch at a time
     eng.set_profiling(True)

@@ -33,29 +33,40 @@ def init_from_env(backend=None):
     return rank, local, world
 
 
-def epilogue(counters, group=None):
-    """counters: int64[16] tensor of this rank (device tensor for RCCL, CPU tensor for gloo).
-
-    Returns (totals uint64[16], kept_read_offset, kept_byte_offset, per_rank uint64[world, 16]).
-    """
+def gather_counters(counters, group=None):
+    """One all-gather of every rank's counter block (NCOUNTERS x int64 = 192 bytes).  Asynchronous for RCCL:
+    the result stays on the device, nothing is copied to the host.  Returns a [world, NCOUNTERS] tensor."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        c = counters.detach().cpu().numpy().view(np.uint64)
-        return c.copy(), 0, 0, c.reshape(1, -1).copy()
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
+        return counters.reshape(1, -1)
+    world = dist.get_world_size(group)
     if dist.get_backend(group) == "gloo":      # CPU tests / shared-GPU smoke runs: stage through host memory
         counters = counters.detach().cpu()
-    gathered = torch.empty((world, NCOUNTERS), dtype=counters.dtype, device=counters.device)
     if counters.is_cuda:
+        gathered = torch.empty((world, NCOUNTERS), dtype=counters.dtype, device=counters.device)
         dist.all_gather_into_tensor(gathered, counters.contiguous(), group=group)
-    else:
-        parts = [torch.empty(NCOUNTERS, dtype=counters.dtype) for _ in range(world)]
-        dist.all_gather(parts, counters.contiguous(), group=group)
-        gathered = torch.stack(parts)
-    per_rank = gathered.cpu().numpy().view(np.uint64).reshape(world, NCOUNTERS)
+        return gathered
+    parts = [torch.empty(NCOUNTERS, dtype=counters.dtype) for _ in range(world)]
+    dist.all_gather(parts, counters.contiguous(), group=group)
+    return torch.stack(parts)
+
+
+def offsets_from_gathered(gathered, rank):
+    """(totals uint64[NCOUNTERS], kept_read_offset, kept_byte_offset, per_rank) from gather_counters' result (host side)."""
+    per_rank = gathered.detach().cpu().numpy().view(np.uint64).reshape(-1, NCOUNTERS)
     totals = per_rank.sum(axis=0, dtype=np.uint64)
     totals[C_ERRORS] = np.bitwise_or.reduce(per_rank[:, C_ERRORS])
     read_off = int(per_rank[:rank, C_KEPT].sum(dtype=np.uint64))
     byte_off = int(per_rank[:rank, C_KEPT_BASES].sum(dtype=np.uint64))
     return totals, read_off, byte_off, per_rank
+
+
+def epilogue(counters, group=None):
+    """counters: int64[NCOUNTERS] tensor of this rank (device tensor for RCCL, CPU tensor for gloo).
+
+    Returns (totals uint64[NCOUNTERS], kept_read_offset, kept_byte_offset, per_rank uint64[world, NCOUNTERS]).
+    """
+    import torch.distributed as dist
+    rank = dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
+    return offsets_from_gathered(gather_counters(counters, group), rank)
