@@ -5,7 +5,7 @@ host/.  This Python package is the harness around it: build helpers, a ctypes vi
 and bench.py, and the one-process-per-GPU sharding glue over torch.distributed (RCCL).
 """
 from .engine import (Engine, FxgError, make_params, load_library,  # noqa: F401
-                     STAGE_CLIP, STAGE_QTRIM, STAGE_QFILTER, STAGE_REVCOMP, STAGE_FTRIM, STAGE_FTRIM_END, STAGE_MASK, STAGE_ARTIFACTS,
+                     STAGE_CLIP, STAGE_QTRIM, STAGE_QFILTER, STAGE_REVCOMP, STAGE_FTRIM, STAGE_FTRIM_END, STAGE_MASK, STAGE_ARTIFACTS, STAGE_NFILTER,
                      CLIP_DISCARD_NON_CLIPPED, CLIP_DISCARD_CLIPPED, CLIP_KEEP_N, CLIP_ADAPTER_ONLY)
 
 __all__ = ["Engine", "FxgError", "make_params", "load_library"]

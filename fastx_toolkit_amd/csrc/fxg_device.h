@@ -72,6 +72,7 @@ struct FxgKArgs {
     int  ft_first, ft_last;
     u32  ft_trim_end, ft_min_len;
     u32  mask_char;         // fastq_masker -r; the mask threshold shares `fq` (byte < fq is masked)
+    u32  nf_keep_n;         // fastq_to_fasta -n
     u64 *extra;             // [0] masked reads, [1] masked nucleotides (fastq_masker report)
     char adapter[100];
 };

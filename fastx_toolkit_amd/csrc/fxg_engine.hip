@@ -267,7 +267,7 @@ extern "C" int fxg_run_pipeline(fxg_ctx *c, const fxg_batch *in, const fxg_param
         }
     }
     if (pl.mask) return fxg_launch_tiles(c, fxg_kernel_tiles<0, 3>, "fxg_kernel_tiles<0,3> mask", pl.ka, pl.lds, ctr);
-    if (pl.artifacts) return fxg_launch_tiles(c, fxg_kernel_tiles<0, 4>, "fxg_kernel_tiles<0,4> artifacts", pl.ka, pl.lds, ctr);
+    if (pl.artifacts) return fxg_launch_tiles(c, fxg_kernel_tiles<0, 4>, "fxg_kernel_tiles<0,4> base census", pl.ka, pl.lds, ctr);
     if (pl.rev) return fxg_launch_tiles(c, fxg_kernel_tiles<0, 2>, "fxg_kernel_tiles<0,2> revcomp[+ftrim]", pl.ka, pl.lds, ctr);
     return fxg_launch_tiles(c, fxg_kernel_tiles<0, 1>, "fxg_kernel_tiles<0,1> ftrim", pl.ka, pl.lds, ctr);
 #undef FXG_TILES_A

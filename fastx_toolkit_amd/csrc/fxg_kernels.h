@@ -351,8 +351,10 @@ FXG_HD void fxg_decide_mask(const FxgKArgs &a, const u32 *bm_l, u32 r0, u32 tid,
     *keep_out = 1u; *len_out = rl;
 }
 
-// fastx_artifacts_filter (fastx_artifacts_filter.c:56-112): drop a read when one of A/C/G/T fills all but <= 3 positions
-FXG_HD void fxg_decide_artifacts(const FxgKArgs &a, const uint8_t *row, u32 r0, u32 tid, u32 *keep_out, u32 *len_out, u32 *bad)
+// base census of one read from its LDS row, shared by
+//   fastx_artifacts_filter (fastx_artifacts_filter.c:56-112): drop when one of A/C/G/T fills all but <= 3 positions
+//   fastq_to_fasta N-discard (fastq_to_fasta.c:79-82)        : drop when the read contains an N (unless -n)
+FXG_HD void fxg_decide_census(const FxgKArgs &a, const uint8_t *row, u32 r0, u32 tid, u32 *keep_out, u32 *len_out, u32 *bad)
 {
     const u32 rl = a.len ? (u32)a.len[r0 + tid] : a.fixed_len;
     u32 ca = 0, cc = 0, cg = 0, ct = 0, cn = 0;
@@ -361,10 +363,13 @@ FXG_HD void fxg_decide_artifacts(const FxgKArgs &a, const uint8_t *row, u32 r0, 
         ca += (b == 'A'); cc += (b == 'C'); cg += (b == 'G'); ct += (b == 'T'); cn += (b == 'N');
     }
     if (ca + cc + cg + ct + cn != rl) *bad = 1u;          // "invalid nucleotide value" in the reference
-    const int lim = (int)rl - 3;
-    const u32 art = ((int)ca >= lim) | ((int)cc >= lim) | ((int)cg >= lim) | ((int)ct >= lim);
-    const u32 keep = art ^ 1u;
-    a.res[r0 + tid] = (rl & 0xFFFFu) | (keep << 16) | ((art ? (u32)FXG_R_ARTIFACT : 0u) << 17);
+    u32 keep = 1u, why = FXG_R_KEPT;
+    if (a.stages & FXG_STAGE_ARTIFACTS) {
+        const int lim = (int)rl - 3;
+        if (((int)ca >= lim) | ((int)cc >= lim) | ((int)cg >= lim) | ((int)ct >= lim)) { keep = 0u; why = FXG_R_ARTIFACT; }
+    }
+    if ((a.stages & FXG_STAGE_NFILTER) && !a.nf_keep_n && cn != 0u) { keep = 0u; why = FXG_R_HAS_N; }
+    a.res[r0 + tid] = (rl & 0xFFFFu) | (keep << 16) | (why << 17);
     *keep_out = keep; *len_out = rl;
 }
 
@@ -379,7 +384,7 @@ FXG_HD void fxg_write_kept_meta(const FxgKArgs &a, u64 rank, u32 olen, u32 read_
 #ifndef FXG_HOST_EMULATION   // everything below is device code proper (wave intrinsics, __global__)
 
 // MODE 0: [clip][qtrim][qfilter] (AMAX = adapter bucket, 0 = no clip); MODE 1: fixed trim; MODE 2: reverse-complement [+ fixed trim];
-// MODE 3: fastq_masker; MODE 4: fastx_artifacts_filter
+// MODE 3: fastq_masker; MODE 4: base census (fastx_artifacts_filter, fastq_to_fasta N-discard)
 #ifndef FXG_MIN_WAVES
 #define FXG_MIN_WAVES 5   // __launch_bounds__ 2nd argument (waves per SIMD) for the streaming instances: 5 workgroups/CU measured best
 #endif
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(FXG_BLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void fx
             if (tid < nreads) {
                 if constexpr (MODE == 0) fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen);
                 else if constexpr (MODE == 3) { u32 nl; fxg_decide_mask(a, bm_l, r0, tid, &keep, &olen, &nl); m_nt += nl; m_reads += (nl != 0u); }
-                else if constexpr (MODE == 4) fxg_decide_artifacts(a, sb + tid * stride, r0, tid, &keep, &olen, &art_bad);
+                else if constexpr (MODE == 4) fxg_decide_census(a, sb + tid * stride, r0, tid, &keep, &olen, &art_bad);
                 else fxg_decide_b<REV>(a, r0, tid, &keep, &olen, &anchor);
             }
             u32 exc, exb, totc, totb;

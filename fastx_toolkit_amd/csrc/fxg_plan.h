@@ -36,9 +36,9 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     const u32 st = p->stages;
     const bool ga = (st & (FXG_STAGE_CLIP | FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0;
     const bool gb = (st & (FXG_STAGE_REVCOMP | FXG_STAGE_FTRIM | FXG_STAGE_FTRIM_END)) != 0;
-    const bool gm = (st & FXG_STAGE_MASK) != 0, gf = (st & FXG_STAGE_ARTIFACTS) != 0;
-    if ((int)ga + (int)gb + (int)gm + (int)gf != 1)
-        FXG_PLAN_FAIL("unsupported stage chain 0x%x: use [CLIP][QTRIM][QFILTER], [REVCOMP][FTRIM|FTRIM_END], [MASK] or [ARTIFACTS]", st);
+    const bool gm = (st & FXG_STAGE_MASK) != 0, gf = (st & (FXG_STAGE_ARTIFACTS | FXG_STAGE_NFILTER)) != 0;
+    if ((int)ga + (int)gb + (int)gm + (int)gf != 1 || (st & (FXG_STAGE_ARTIFACTS | FXG_STAGE_NFILTER)) == (FXG_STAGE_ARTIFACTS | FXG_STAGE_NFILTER))
+        FXG_PLAN_FAIL("unsupported stage chain 0x%x: use [CLIP][QTRIM][QFILTER], [REVCOMP][FTRIM|FTRIM_END], [MASK], [ARTIFACTS] or [NFILTER]", st);
     if (gm && !in->qual) FXG_PLAN_FAIL("fastq_masker needs qualities");
     if ((st & FXG_STAGE_FTRIM) && (st & FXG_STAGE_FTRIM_END))
         FXG_PLAN_FAIL("[-t], [-f] and [-l] options can not be used together");   // fastx_trimmer.c:112-113
@@ -62,6 +62,7 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     ka.tq = (u32)fxg_clampi((long long)p->qt_threshold + p->qoffset, 0, 128);
     ka.fq = (u32)fxg_clampi((long long)(gm ? p->mask_min_quality : p->qf_min_quality) + p->qoffset, 0, 128);
     ka.mask_char = p->mask_char & 0xFFu;
+    ka.nf_keep_n = p->nf_keep_n;
     ka.qt_min_len = p->qt_min_len;
     ka.qf_keep_pct = 100 - p->qf_min_percent;
     ka.qf_drop_all = (p->qf_min_percent == 0 && p->qf_min_quality > 93) ? 1u : 0u;   // quirk F2

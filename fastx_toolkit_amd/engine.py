@@ -11,7 +11,7 @@ import numpy as np
 
 from . import build as _build
 
-STAGE_CLIP, STAGE_QTRIM, STAGE_QFILTER, STAGE_REVCOMP, STAGE_FTRIM, STAGE_FTRIM_END, STAGE_MASK, STAGE_ARTIFACTS = 1, 2, 4, 8, 16, 32, 64, 128
+STAGE_CLIP, STAGE_QTRIM, STAGE_QFILTER, STAGE_REVCOMP, STAGE_FTRIM, STAGE_FTRIM_END, STAGE_MASK, STAGE_ARTIFACTS, STAGE_NFILTER = 1, 2, 4, 8, 16, 32, 64, 128, 256
 CLIP_DISCARD_NON_CLIPPED, CLIP_DISCARD_CLIPPED, CLIP_KEEP_N, CLIP_ADAPTER_ONLY = 1, 2, 4, 8
 NCOUNTERS = 24
 (C_INPUT, C_KEPT, C_KEPT_BASES, C_CLIP_TOO_SHORT, C_CLIP_ADAPTER_ONLY, C_CLIP_NO_ADAPTER, C_CLIP_ADAPTER_FOUND,
@@ -36,7 +36,7 @@ class FxgParams(C.Structure):
         ("adapter", C.c_char * 100), ("clip_min_len", C.c_uint32), ("clip_keep_delta", C.c_int32),
         ("clip_min_adapter_len", C.c_int32), ("clip_flags", C.c_uint32),
         ("ft_first", C.c_int32), ("ft_last", C.c_int32), ("ft_trim_end", C.c_uint32), ("ft_min_len", C.c_uint32),
-        ("mask_min_quality", C.c_int32), ("mask_char", C.c_uint32),
+        ("mask_min_quality", C.c_int32), ("mask_char", C.c_uint32), ("nf_keep_n", C.c_uint32),
     ]
 
 
@@ -57,7 +57,7 @@ class FxgOut(C.Structure):
 
 def make_params(stages=0, qoffset=33, qt_threshold=0, qt_min_len=0, qf_min_quality=0, qf_min_percent=0,
                 adapter=b"CCTTAAGG", clip_min_len=5, clip_keep_delta=0, clip_min_adapter_len=0, clip_flags=0,
-                ft_first=1, ft_last=0, ft_trim_end=0, ft_min_len=0, mask_min_quality=10, mask_char="N"):
+                ft_first=1, ft_last=0, ft_trim_end=0, ft_min_len=0, mask_min_quality=10, mask_char="N", nf_keep_n=0):
     """fxg_params with the reference tools' defaults (fastx_args.c:43, fastx_clipper.cpp:68-69)."""
     if isinstance(adapter, str):
         adapter = adapter.encode()
@@ -71,6 +71,7 @@ def make_params(stages=0, qoffset=33, qt_threshold=0, qt_min_len=0, qf_min_quali
     p.ft_first, p.ft_last, p.ft_trim_end, p.ft_min_len = ft_first, ft_last, ft_trim_end, ft_min_len
     p.mask_min_quality = mask_min_quality
     p.mask_char = mask_char if isinstance(mask_char, int) else ord(mask_char)
+    p.nf_keep_n = nf_keep_n
     return p
 
 

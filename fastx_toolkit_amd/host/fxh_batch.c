@@ -107,13 +107,23 @@ static void fxh_grow(fxh_state *st, size_t reads, size_t bytes, int revcomp)
 
 /* Size (dst == NULL) or write one kept record; seq/qual point at `len` output bytes; qual bytes are either raw input
  * characters (raw_qual) or Phred+33 codes (engine output / numeric input).  Returns the number of bytes. */
-static size_t fxh_emit(const FASTX *fx, const fxh_rec *r, const uint8_t *seq, const uint8_t *qual, size_t len, int raw_qual, char *d)
+static int g_rename_ids = 0;
+void fxh_set_rename_ids(int on) { g_rename_ids = on; }
+
+static size_t fxh_emit(const FASTX *fx, const fxh_rec *r, const uint8_t *seq, const uint8_t *qual, size_t len, int raw_qual, char *d, size_t out_index)
 {
     size_t k = 0;
 #define PUTC(ch) do { if (d) d[k] = (char)(ch); k++; } while (0)
 #define PUTS(ptr, n_) do { if (d) memcpy(d + k, (ptr), (n_)); k += (n_); } while (0)
     PUTC(fx->output_sequence_id_prefix);
-    PUTS(r->name, r->name_len); PUTC('\n');
+    if (g_rename_ids) {                      /* the record's 1-based position in the output replaces its name */
+        char num[24];
+        int nd = 0;
+        size_t v = out_index;
+        do { num[nd++] = (char)('0' + v % 10); v /= 10; } while (v);
+        while (nd) { --nd; PUTC(num[nd]); }      /* no side effects inside PUTC's argument: it is not evaluated when sizing */
+    } else PUTS(r->name, r->name_len);
+    PUTC('\n');
     PUTS(seq, len); PUTC('\n');
     if (fx->write_fastq) {
         const int ascii = fx->copy_input_fastq_format_to_output ? r->is_ascii : fx->write_fastq_ascii;   /* R6 */
@@ -162,6 +172,7 @@ typedef struct fxh_worker {
     long bad_q;                            /* local index of the first record with an invalid quality line, or -1 */
     size_t rec0, use;                      /* global index of rec[0]; how many of this worker's records are in the batch */
     size_t out_bytes, out_off, kept_bytes, kept_off;
+    size_t kept_count, kept_base;          /* kept records in this range; output index of its first kept record (1-based) */
     fxh_totals tot;
 } fxh_worker;
 
@@ -264,6 +275,14 @@ static void fxh_phase_pack(fxh_worker *w)
     }
 }
 
+static void fxh_phase_count(fxh_worker *w)
+{
+    const fxh_state *st = w->job->st;
+    size_t kept = 0;
+    for (size_t k = 0; k < w->use; ++k) kept += FXG_RES_KEEP(st->h_res[w->rec0 + k]);
+    w->kept_count = kept;
+}
+
 /* bytes this worker will write and the report totals of its records */
 static void fxh_phase_size(fxh_worker *w)
 {
@@ -271,7 +290,7 @@ static void fxh_phase_size(fxh_worker *w)
     fxh_state *st = job->st;
     const FASTX *fx = job->fx;
     memset(&w->tot, 0, sizeof w->tot);
-    size_t bytes = 0, kept_bytes = 0;
+    size_t bytes = 0, kept_bytes = 0, oidx = w->kept_base;
     for (size_t k = 0; k < w->use; ++k) {
         const fxh_rec *r = &w->rec[k];
         const size_t i = w->rec0 + k;
@@ -292,7 +311,7 @@ static void fxh_phase_size(fxh_worker *w)
         kept_bytes += len;
         /* only numeric-quality output depends on the values (digit counts); reversal does not change their multiset */
         const uint8_t *qv = st->h_qual ? st->h_qual + i * job->stride + (job->revcomp ? r->seq_len - job->fwd_start - len : job->fwd_start) : NULL;
-        bytes += fxh_emit(fx, r, (const uint8_t *)r->seq, r->is_ascii ? (const uint8_t *)r->seq : qv, len, 0, NULL);
+        bytes += fxh_emit(fx, r, (const uint8_t *)r->seq, r->is_ascii ? (const uint8_t *)r->seq : qv, len, 0, NULL, oidx++);
     }
     w->out_bytes = bytes; w->kept_bytes = kept_bytes;
 }
@@ -303,19 +322,19 @@ static void fxh_phase_format(fxh_worker *w)
     fxh_state *st = job->st;
     const FASTX *fx = job->fx;
     char *d = job->out_dst + w->out_off;
-    size_t k2 = 0, opos = w->kept_off;
+    size_t k2 = 0, opos = w->kept_off, oidx = w->kept_base;
     for (size_t k = 0; k < w->use; ++k) {
         const fxh_rec *r = &w->rec[k];
         const size_t i = w->rec0 + k;
         const uint32_t x = st->h_res[i], len = FXG_RES_LEN(x);
         if (!FXG_RES_KEEP(x)) continue;
         if (job->revcomp) {
-            k2 += fxh_emit(fx, r, st->h_out_bases + opos, st->h_out_qual ? st->h_out_qual + opos : NULL, len, 0, d + k2);
+            k2 += fxh_emit(fx, r, st->h_out_bases + opos, st->h_out_qual ? st->h_out_qual + opos : NULL, len, 0, d + k2, oidx++);
             opos += len;
         } else if (r->is_ascii) {
-            k2 += fxh_emit(fx, r, (const uint8_t *)r->seq + job->fwd_start, (const uint8_t *)r->qual + job->fwd_start, len, 1, d + k2);
+            k2 += fxh_emit(fx, r, (const uint8_t *)r->seq + job->fwd_start, (const uint8_t *)r->qual + job->fwd_start, len, 1, d + k2, oidx++);
         } else {
-            k2 += fxh_emit(fx, r, (const uint8_t *)r->seq + job->fwd_start, st->h_qual + i * job->stride + job->fwd_start, len, 0, d + k2);
+            k2 += fxh_emit(fx, r, (const uint8_t *)r->seq + job->fwd_start, st->h_qual + i * job->stride + job->fwd_start, len, 0, d + k2, oidx++);
         }
     }
     w->out_bytes = k2;
@@ -616,7 +635,7 @@ int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *tot)
     size_t wr_spare_cap = 0;
     const int overlap = getenv("FXH_NO_OVERLAP") == NULL;
     /* device-side parse/format for FASTQ; FXH_HOST_PARSE=1 forces the host parser */
-    const int gpu_text = fx->read_fastq && getenv("FXH_HOST_PARSE") == NULL;
+    const int gpu_text = fx->read_fastq && fx->write_fastq && !g_rename_ids && getenv("FXH_HOST_PARSE") == NULL;
     unsigned long n_fallback = 0;
 
     while (!at_eof && !have_err) {
@@ -747,6 +766,11 @@ int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *tot)
             t_gpu += fxh_now() - t0; t0 = fxh_now();
 
             /* ---- 4. format the kept records in input order (each worker its own slice), tally the report counters ---- */
+            fxh_parallel(&job, fxh_phase_count);
+            {
+                size_t base = tot->output_sequences + 1;
+                for (int i = 0; i < T; ++i) { job.w[i].kept_base = base; base += job.w[i].kept_count; }
+            }
             fxh_parallel(&job, fxh_phase_size);
             size_t total = 0, kept_total = 0;
             for (int i = 0; i < T; ++i) {

@@ -33,6 +33,9 @@ typedef struct fxh_totals {
  * inside fastx_read_next_record).  Returns 0. */
 int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *totals);
 
+/* fastq_to_fasta -r: kept records are renamed to their 1-based output index (fastq_to_fasta.c:83-84).  Set before fxh_run_tool. */
+void fxh_set_rename_ids(int on);
+
 /* fxg_params with the reference tools' defaults (qoffset from -Q). */
 void fxh_default_params(fxg_params *p, int qoffset);
 

@@ -40,7 +40,7 @@ extern "C" {
 #define FXG_E_NOMEM      -3
 #define FXG_E_DEVICE     -4   /* device-side failure flag (scan time-out, invalid nucleotide, ...) */
 
-/* ---- pipeline stages.  Supported chains: [CLIP][QTRIM][QFILTER], [REVCOMP][FTRIM|FTRIM_END], [MASK], [ARTIFACTS] ---- */
+/* ---- pipeline stages.  Supported chains: [CLIP][QTRIM][QFILTER], [REVCOMP][FTRIM|FTRIM_END], [MASK], [ARTIFACTS], [NFILTER] ---- */
 #define FXG_STAGE_CLIP      0x01u  /* fastx_clipper            */
 #define FXG_STAGE_QTRIM     0x02u  /* fastq_quality_trimmer    */
 #define FXG_STAGE_QFILTER   0x04u  /* fastq_quality_filter     */
@@ -49,6 +49,7 @@ extern "C" {
 #define FXG_STAGE_FTRIM_END 0x20u  /* fastx_trimmer -t/-m      */
 #define FXG_STAGE_MASK      0x40u  /* fastq_masker             (reference src/fastq_masker/fastq_masker.c:92-108) */
 #define FXG_STAGE_ARTIFACTS 0x80u  /* fastx_artifacts_filter   (src/fastx_artifacts_filter/fastx_artifacts_filter.c:56-112) */
+#define FXG_STAGE_NFILTER   0x100u /* fastq_to_fasta's N-discard (src/fastq_to_fasta/fastq_to_fasta.c:79-82) */
 
 /* fastx_clipper switches (fastx_clipper.cpp:90-146) */
 #define FXG_CLIP_DISCARD_NON_CLIPPED 0x1u /* -c */
@@ -82,7 +83,8 @@ enum fxg_reason {
     FXG_R_QFILTER = 7,            /* fastq_quality_filter.c:155 */
     FXG_R_FTRIM = 8,              /* fastx_trimmer.c:127,137,140 */
     FXG_R_CLIP_K_MODE = 9,        /* fastx_clipper.cpp:317 (-k: only adapter-only reads are written) */
-    FXG_R_ARTIFACT = 10           /* fastx_artifacts_filter.c:101-109 */
+    FXG_R_ARTIFACT = 10,          /* fastx_artifacts_filter.c:101-109 */
+    FXG_R_HAS_N = 11              /* fastq_to_fasta.c:80-81 */
 };
 
 /* slots of the u64 counter block (feeds the tools' -v reports, a12) */
@@ -128,6 +130,7 @@ typedef struct fxg_params {
     uint32_t ft_min_len;          /* fastx_trimmer -m */
     int32_t  mask_min_quality;    /* fastq_masker -q (default 10) */
     uint32_t mask_char;           /* fastq_masker -r (default 'N') */
+    uint32_t nf_keep_n;           /* fastq_to_fasta -n: keep reads with N (the stage then only checks the alphabet) */
 } fxg_params;
 
 /* Input batch (replaces the one-record FASTX struct, fastx.h:62-117): row r of bases/qual starts at

@@ -289,8 +289,8 @@ int fxo_run_pipeline(const fxo_batch *in, const fxo_params *p, fxo_out *out)
     const uint32_t st = p->stages;
     const int group_a = (st & (FXO_STAGE_CLIP | FXO_STAGE_QTRIM | FXO_STAGE_QFILTER)) != 0;
     const int group_b = (st & (FXO_STAGE_REVCOMP | FXO_STAGE_FTRIM | FXO_STAGE_FTRIM_END)) != 0;
-    const int group_c = (st & FXO_STAGE_MASK) != 0, group_d = (st & FXO_STAGE_ARTIFACTS) != 0;
-    if (group_a + group_b + group_c + group_d != 1) return -1;
+    const int group_c = (st & FXO_STAGE_MASK) != 0, group_d = (st & FXO_STAGE_ARTIFACTS) != 0, group_e = (st & FXO_STAGE_NFILTER) != 0;
+    if (group_a + group_b + group_c + group_d + group_e != 1) return -1;
     if (group_c && !in->qual) return -1;
     if ((st & FXO_STAGE_FTRIM) && (st & FXO_STAGE_FTRIM_END)) return -1;   /* fastx_trimmer.c:112-113 */
     if ((st & (FXO_STAGE_QTRIM | FXO_STAGE_QFILTER)) && !in->qual) return -1;
@@ -362,6 +362,9 @@ int fxo_run_pipeline(const fxo_batch *in, const fxo_params *p, fxo_out *out)
             if (cnt[0] >= total - 3 || cnt[1] >= total - 3 || cnt[2] >= total - 3 || cnt[3] >= total - 3) {
                 keep = 0; reason = FXO_R_ARTIFACT; out->counters[FXO_C_ARTIFACT_DROPPED]++;
             }
+        }
+        if ((st & FXO_STAGE_NFILTER) && !p->nf_keep_n && memchr(b, 'N', (size_t)len) != NULL) {   /* fastq_to_fasta.c:80-81 */
+            keep = 0; reason = FXO_R_HAS_N;
         }
         int masked = 0;
         if (st & FXO_STAGE_MASK) {               /* fastq_masker.c:92-103: every read is written, low-quality bases replaced */

@@ -33,6 +33,7 @@ extern "C" {
 #define FXO_STAGE_FTRIM_END 0x20u  /* fastx_trimmer -t/-m      */
 #define FXO_STAGE_MASK      0x40u  /* fastq_masker             */
 #define FXO_STAGE_ARTIFACTS 0x80u  /* fastx_artifacts_filter   */
+#define FXO_STAGE_NFILTER   0x100u /* fastq_to_fasta N-discard */
 
 #define FXO_CLIP_DISCARD_NON_CLIPPED 0x1u /* -c */
 #define FXO_CLIP_DISCARD_CLIPPED     0x2u /* -C */
@@ -51,7 +52,8 @@ enum {
     FXO_R_QFILTER = 7,
     FXO_R_FTRIM = 8,
     FXO_R_CLIP_K_MODE = 9, /* -k given and the read is not adapter-only */
-    FXO_R_ARTIFACT = 10
+    FXO_R_ARTIFACT = 10,
+    FXO_R_HAS_N = 11
 };
 
 /* counters[] slots */
@@ -103,6 +105,7 @@ typedef struct {
     /* fastq_masker */
     int32_t  mask_min_quality;   /* -q */
     uint32_t mask_char;          /* -r */
+    uint32_t nf_keep_n;          /* fastq_to_fasta -n */
 } fxo_params;
 
 /* Structure-of-arrays batch: row r lives at bases + r*stride, length len[r] (or fixed_len if len==NULL).

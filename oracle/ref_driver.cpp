@@ -328,6 +328,32 @@ static int run_artifacts(int argc, char **argv)
     return 0;
 }
 
+/* ---- fastq_to_fasta.c:49-103 ---- */
+static int f2a_rename = 0, f2a_discard_n = 1;
+static int f2a_args(int, int c, char *)
+{
+    if (c == 'n') f2a_discard_n = 0; else if (c == 'r') f2a_rename = 1; else errx(1, "Unknown argument (%c)", c);
+    return 1;
+}
+static int run_fastq_to_fasta(int argc, char **argv)
+{
+    fastx_parse_cmdline(argc, argv, "rn", f2a_args);
+    fastx_init_reader(&fx, get_input_filename(), FASTQ_ONLY, ALLOW_N, REQUIRE_UPPERCASE, get_fastq_ascii_quality_offset());
+    fastx_init_writer(&fx, get_output_filename(), OUTPUT_FASTA, compress_output_flag());
+    while (fastx_read_next_record(&fx)) {
+        if (f2a_discard_n && strchr(fx.nucleotides, 'N') != NULL) continue;          /* :80-81 */
+        if (f2a_rename) snprintf(fx.name, sizeof(fx.name), "%zu", num_output_reads(&fx) + 1);   /* :83-84 */
+        fastx_write_record(&fx);
+    }
+    if (verbose_flag()) {                                                           /* :90-100 */
+        FILE *rf = get_report_file();
+        size_t in = num_input_reads(&fx), out = num_output_reads(&fx);
+        fprintf(rf, "Input: %zu reads.\nOutput: %zu reads.\n", in, out);
+        if (f2a_discard_n) fprintf(rf, "discarded %zu (%zu%%) low-quality reads.\n", in - out, ((in - out) * 100) / in);
+    }
+    return 0;
+}
+
 /* debugging aid for the parity tests: "fxref align QUERY TARGET" prints the 7 result fields */
 static int run_align(int argc, char **argv)
 {
@@ -348,6 +374,7 @@ int main(int argc, char **argv)
     if (!strcmp(tool, "fastx_trimmer")) return run_trimmer(argc, argv);
     if (!strcmp(tool, "fastx_reverse_complement")) return run_revcomp(argc, argv);
     if (!strcmp(tool, "fastx_clipper")) return run_clipper(argc, argv);
+    if (!strcmp(tool, "fastq_to_fasta")) return run_fastq_to_fasta(argc, argv);
     if (!strcmp(tool, "fastq_masker")) return run_masker(argc, argv);
     if (!strcmp(tool, "fastx_artifacts_filter")) return run_artifacts(argc, argv);
     if (!strcmp(tool, "align")) return run_align(argc, argv);

@@ -10,7 +10,7 @@ nproc >> gpurun_out/gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"
 tail -3 gpurun_out/smoke.log
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
-timeout 1500 python -m pytest tests -x -q -m gpu --durations=12 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+timeout 900 python -m pytest tests -x -q -m gpu --durations=12 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
 tail -25 gpurun_out/pytest_gpu.log
 fi
 timeout 600 python bench.py --steps ${STEPS:-20} --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"

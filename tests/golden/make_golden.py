@@ -116,6 +116,10 @@ GALAXY = [  # SURVEY.md section 4 (XML <tests> blocks)
          cmd=["fastq_masker", "-Q", "64", "-q", "29", "-r", "x"], params=P(stages=64, qoffset=64, mask_min_quality=29, mask_char="x")),
     dict(name="galaxy_artifacts_fasta", input="fastx_artifacts1.fasta", expect="fastx_artifacts1.out",
          cmd=["fastx_artifacts_filter"], params=P(stages=128)),
+    dict(name="galaxy_fastq_to_fasta_a", input="fastq_to_fasta1.fastq", expect="fastq_to_fasta1a.out",
+         cmd=["fastq_to_fasta", "-Q", "64"], params=P(stages=256, qoffset=64), fasta_out=True),
+    dict(name="galaxy_fastq_to_fasta_b", input="fastq_to_fasta1.fastq", expect="fastq_to_fasta1b.out",
+         cmd=["fastq_to_fasta", "-Q", "64", "-n", "-r"], params=P(stages=256, qoffset=64, nf_keep_n=1), fasta_out=True, rename=True),
     dict(name="galaxy_artifacts_numeric", input="fastx_artifacts2.fastq", expect="fastx_artifacts2.out",
          cmd=["fastx_artifacts_filter"], params=P(stages=128)),
 ]

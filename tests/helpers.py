@@ -96,6 +96,7 @@ def fuzz_cases(seed, trials, clip_trials):
             b2[i, :] = ord("ACGT"[i % 4])
             b2[i, :min(stride, int(rng.integers(0, 6)))] = ord("ACGTN"[int(rng.integers(0, 5))])
         yield ("t%d.artifacts.s%d" % (trial, stride), b2, q, lens, fl, dict(stages=128))
+        yield ("t%d.nfilter.s%d" % (trial, stride), b, q, lens, fl, dict(stages=256, nf_keep_n=trial % 3 == 0))
     adapters = [b"AGATCGGAAGAGC", b"CCTTAAGG", b"CAATTGGTTAATCCCCCTATATA", b"ACGT", b"TGGAATTCTCGGGTGCCAAGGAACTCCAGTCAC",
                 b"ANNTCGNA", b"A" * 40 + b"CGT" * 8, b"ACGTTGCA" * 9]
     for trial in range(clip_trials):

@@ -31,7 +31,7 @@ PARSE_ENV = {}          # set per test run by the `parse_mode` fixture: {} = dev
 
 def _run(cmd, data, env=None):
     env = dict(env or os.environ, **PARSE_ENV)
-    p = subprocess.run(cmd, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    p = subprocess.run(cmd, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=180)   # a hang must fail fast
     return p.returncode, p.stdout, p.stderr
 
 
@@ -123,6 +123,7 @@ def test_fuzz_cli_vs_reference(tools):
                  ["fastx_reverse_complement", "-v"],
                  ["fastq_masker", "-q", str(int(rng.integers(0, 45))), "-r", str(rng.choice(list("N.x"))), "-v"],
                  ["fastx_artifacts_filter", "-v"],
+                 ["fastq_to_fasta", "-v"] + (["-r"] if trial % 2 else []) + (["-n"] if trial % 3 == 0 else []),
                  ["fastx_clipper", "-a", ad.decode(), "-l", str(int(rng.integers(0, 25))), "-v"] + list(rng.choice(["-n", "-c", "-C", "-k"], size=2, replace=False))]
         for argv in argvs:
             env = dict(os.environ, FXH_THREADS=str([16, 1, 3, 7][trial % 4]), FXH_READ_BUFFER_MB="1")

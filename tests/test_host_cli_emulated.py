@@ -1,0 +1,115 @@
+"""CPU tier: the complete host layer of the command-line tools (flag parsing, block reader, worker threads, batch packing,
+formatting, reports, error handling) against the reference driver, WITHOUT a GPU.
+
+The tools are run with tests/emu/stub/libfxg.so first on LD_LIBRARY_PATH: a test-only stand-in for the engine library that
+executes the kernels' per-thread code through the serial CPU emulator.  The product library has no CPU path; this stub is
+never installed next to it.  The same comparisons run against the real GPU engine in tests/test_gpu_cli.py.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from helpers import GOLDEN, md5
+from oracle import fxoracle_py as fo
+
+HOST = os.path.join(ROOT, "fastx_toolkit_amd", "host")
+STUB_DIR = os.path.join(ROOT, "tests", "emu", "stub")
+REF = fo.ref_binary()
+
+
+@pytest.fixture(scope="module")
+def tools():
+    import emu_py
+    emu_py.build()
+    os.makedirs(STUB_DIR, exist_ok=True)
+    so = os.path.join(STUB_DIR, "libfxg.so")
+    srcs = [os.path.join(ROOT, "tests", "emu", f) for f in ("fxg_stub.cpp", "fxg_emu.cpp")]
+    deps = srcs + [os.path.join(ROOT, "fastx_toolkit_amd", "csrc", f) for f in ("fxg_device.h", "fxg_kernels.h", "fxg_plan.h")] + [os.path.join(ROOT, "include", "fxg.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["hipcc", "--cuda-host-only", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-pass-failed",
+                               "-DFXG_HOST_EMULATION"] + srcs + ["-o", so])
+    from fastx_toolkit_amd import build as b
+    b.build_engine()          # the tools link against the real library's soname; the stub replaces it at run time only
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    return os.path.join(HOST, "bin")
+
+
+def _run(cmd, data, threads="4", buf_mb=None):
+    env = dict(os.environ, LD_LIBRARY_PATH=STUB_DIR, FXH_THREADS=threads)
+    if buf_mb:
+        env["FXH_READ_BUFFER_MB"] = buf_mb
+    p = subprocess.run(cmd, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+    return p.returncode, p.stdout, p.stderr
+
+
+def _msg(err):
+    return err.split(b": ", 1)[-1]
+
+
+def test_galaxy_known_answers_through_the_host_layer(tools, cases):
+    for g in cases["galaxy"]:
+        inp = open(os.path.join(GOLDEN, "galaxy", g["input"]), "rb").read()
+        exp = open(os.path.join(GOLDEN, "galaxy", g["expect"]), "rb").read()
+        rc, out, err = _run([os.path.join(tools, g["cmd"][0])] + g["cmd"][1:], inp)
+        assert rc == 0, err
+        assert out == exp, g["name"]
+
+
+def test_small_synthetic_cases_md5(tools, cases):
+    for c in cases["synthetic"]:
+        if c["n"] > 3000:
+            continue
+        text = fo.synth_fastq(c["seed"], 0, c["n"], c["L"], c["adapter"])
+        for cmd in c["chain"]:
+            rc, text, err = _run([os.path.join(tools, cmd[0])] + cmd[1:], text)
+            assert rc == 0, err
+        assert md5(text) == c["output_md5"], c["name"]
+
+
+@pytest.mark.skipif(REF is None, reason="oracle/_ref/fxref not built")
+def test_fuzz_every_tool_vs_reference(tools):
+    rng = np.random.default_rng(21)
+    ad = b"AGATCGGAAGAGC"
+    for trial in range(12):
+        L = int(rng.integers(20, 70))
+        recs = []
+        for i in range(int(rng.integers(30, 250))):
+            s = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=L, p=[.24, .24, .24, .24, .04])
+            if rng.random() < 0.5:
+                pos = int(rng.integers(0, L + 1)); k = min(len(ad), L - pos)
+                s[pos:pos + k] = np.frombuffer(ad, np.uint8)[:k]
+            if i % 9 == 0:
+                s[:] = ord("ACGT"[i % 4]); s[:int(rng.integers(0, 5))] = ord("C")
+            q = rng.integers(33, 75, size=L, dtype=np.uint8); q[int(rng.integers(0, L + 1)):] = 36
+            recs.append(b"@r%d some text\n%s\n+\n%s\n" % (i, s.tobytes(), q.tobytes()))
+        data = b"".join(recs)
+        if trial % 4 == 3:      # malformed record in the middle: earlier output must still appear, exit code 1
+            k = len(b"".join(recs[:len(recs) // 2])) + 12
+            data = data[:k] + b"!" + data[k + 1:]
+        argvs = [["fastq_quality_trimmer", "-t", str(int(rng.integers(5, 40))), "-l", str(int(rng.integers(0, 50))), "-v"],
+                 ["fastq_quality_filter", "-q", str(int(rng.integers(5, 40))), "-p", str(int(rng.integers(1, 101))), "-v"],
+                 ["fastx_trimmer", "-f", str(int(rng.integers(1, 30))), "-l", str(int(rng.integers(30, 100))), "-v"],
+                 ["fastx_trimmer", "-t", str(int(rng.integers(1, 30))), "-m", str(int(rng.integers(1, 60))), "-v"],
+                 ["fastx_reverse_complement", "-v"],
+                 ["fastq_masker", "-q", str(int(rng.integers(0, 45))), "-r", str(rng.choice(list("N.x"))), "-v"],
+                 ["fastx_artifacts_filter", "-v"],
+                 ["fastq_to_fasta", "-v"] + (["-r"] if trial % 2 else []) + (["-n"] if trial % 3 == 0 else []),
+                 ["fastx_clipper", "-a", ad.decode(), "-l", str(int(rng.integers(0, 25))), "-v"] + list(rng.choice(["-n", "-c", "-C", "-k"], size=2, replace=False))]
+        for argv in argvs:
+            rc, out, err = _run([os.path.join(tools, argv[0])] + argv[1:], data, threads=str([4, 1, 3][trial % 3]), buf_mb="1" if trial % 2 else None)
+            rrc, rout, rerr = _run([REF] + argv, data)
+            assert (rc, out) == (rrc, rout), (trial, argv)
+            assert _msg(err) == _msg(rerr), (trial, argv)
+
+
+def test_flag_errors_and_usage(tools):
+    assert _run([os.path.join(tools, "fastq_quality_trimmer")], b"@r\nA\n+\nI\n")[0] == 1          # missing -t
+    assert _run([os.path.join(tools, "fastq_quality_filter"), "-p", "0"], b"")[0] == 1
+    assert _run([os.path.join(tools, "fastx_trimmer"), "-f", "2", "-t", "3"], b"@r\nA\n+\nI\n")[0] == 1
+    rc, out, _ = _run([os.path.join(tools, "fastx_clipper"), "-h"], b"")
+    assert rc == 1 and out.startswith(b"usage: fastx_clipper")                                     # -h exits 1 (F5)
+    assert _run([os.path.join(tools, "fastq_quality_trimmer"), "-t", "20"], b"")[0] == 1          # empty input is an error (R1)
+    assert _run([os.path.join(tools, "fastq_quality_trimmer"), "-t", "20"], b">fa\nAC\n")[0] == 1  # FASTQ only

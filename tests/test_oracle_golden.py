@@ -63,7 +63,18 @@ def test_galaxy_known_answers(cases):
         inp, exp = _read(g["input"]), _read(g["expect"])
         p = oracle_params(g["params"])
         ascii_fastq = inp[:1] == b"@" and len(inp.split(b"\n")[3]) == len(inp.split(b"\n")[1])
-        if ascii_fastq:
+        if ascii_fastq and g.get("fasta_out"):          # fastq_to_fasta: FASTA writer, optional renaming to the output index
+            pr = fo.parse_fastq(inp, g["params"].get("qoffset", 33))
+            r = fo.run_pipeline(pr["bases"], pr["qual"], pr["lens"], p)
+            no, nl = pr["names"][0], pr["names"][1]
+            out, pos = [], 0
+            for k, idx in enumerate(r["kept_index"]):
+                l = int(r["out_len"][k])
+                name = str(k + 1).encode() if g.get("rename") else inp[int(no[idx]):int(no[idx]) + int(nl[idx])]
+                out.append(b">" + name + b"\n" + r["out_bases"][pos:pos + l].tobytes() + b"\n")
+                pos += l
+            got = b"".join(out)
+        elif ascii_fastq:
             got, _ = text_through(fo.run_pipeline, inp, p, qoffset=g["params"].get("qoffset", 33))
         else:
             got = _run_records(_fasta_or_numeric(inp), p)
