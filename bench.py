@@ -32,33 +32,46 @@ SEED = 2
 PARAMS = dict(stages=2 | 4, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80)
 
 
-def cpu_baseline(sample_reads=1_000_000):
-    """Reference CPU path on this box's host cores, bounded sample of the same workload (rank 0, N=1 only)."""
+def cpu_baseline(reads_per_pipe=250_000, max_pipes=16):
+    """Reference CPU path on this box's host cores, bounded sample of the same workload (rank 0, N=1 only).
+
+    SURVEY 8d: the reference is single-threaded, so the input is split at record boundaries into P chunks and P
+    `trimmer | filter` shell pipes (2 processes each) run concurrently; the aggregate rate over 2P cores is reported.
+    """
     from oracle import fxoracle_py as fo
     ref = fo.ref_binary()
     try:
         fo.lib()
     except Exception:
         return None
+    ncpu = os.cpu_count() or 2
+    pipes = max(1, min(max_pipes, ncpu // 2))
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
         if ref:
-            text = fo.synth_fastq(SEED, 0, sample_reads, READ_LEN, False)
-            inp, outp = os.path.join(td, "in.fq"), os.path.join(td, "out.fq")
-            with open(inp, "wb") as f:
-                f.write(text)
+            files = []
+            for k in range(pipes):
+                inp = os.path.join(td, "in%d.fq" % k)
+                with open(inp, "wb") as f:
+                    f.write(fo.synth_fastq(SEED, k * reads_per_pipe, reads_per_pipe, READ_LEN, False))
+                files.append(inp)
             t0 = time.perf_counter()
-            p1 = subprocess.Popen([ref, "fastq_quality_trimmer", "-t", "20", "-l", "30", "-i", inp], stdout=subprocess.PIPE)
-            p2 = subprocess.Popen([ref, "fastq_quality_filter", "-q", "20", "-p", "80", "-o", outp], stdin=p1.stdout)
-            p1.stdout.close()
-            p2.wait(); p1.wait()
+            procs = []
+            for k, inp in enumerate(files):
+                p1 = subprocess.Popen([ref, "fastq_quality_trimmer", "-t", "20", "-l", "30", "-i", inp], stdout=subprocess.PIPE)
+                p2 = subprocess.Popen([ref, "fastq_quality_filter", "-q", "20", "-p", "80", "-o", os.path.join(td, "out%d.fq" % k)], stdin=p1.stdout)
+                p1.stdout.close()
+                procs += [p1, p2]
+            ok = all(p.wait() == 0 for p in procs)
             dt = time.perf_counter() - t0
-            if p1.returncode == 0 and p2.returncode == 0:
-                return dict(value=round(sample_reads / dt / 1e6, 4), unit="Mreads/s", cores=2, kind="reference",
-                            sample="first %d reads of the same seed-2 150 bp set as FASTQ text on tmpfs, piped through the reference "
-                                   "libfastx reader/writer (compiled -O3 from /root/reference/src/libfastx) with the trimmer|filter "
-                                   "loop bodies of oracle/ref_driver.cpp; two single-threaded processes = 2 cores" % sample_reads)
+            if ok:
+                n = pipes * reads_per_pipe
+                return dict(value=round(n / dt / 1e6, 4), unit="Mreads/s", cores=2 * pipes, kind="reference",
+                            sample="first %d reads of the same seed-2 150 bp set as FASTQ text on tmpfs, split into %d chunks; each chunk piped "
+                                   "through the reference libfastx reader/writer (compiled -O3 from /root/reference/src/libfastx) with the "
+                                   "trimmer|filter loop bodies of oracle/ref_driver.cpp; %d concurrent single-threaded processes = %d cores"
+                                   % (n, pipes, 2 * pipes, 2 * pipes))
         # fall back to the plain-C port (SoA in memory, no text I/O), 1 thread
-        n = sample_reads * 4
+        n = 4_000_000
         b, q = fo.synth_batch(SEED, 0, n, READ_LEN)
         t0 = time.perf_counter()
         fo.run_pipeline(b, q, None, fo.make_params(**PARAMS))
