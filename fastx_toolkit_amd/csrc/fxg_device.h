@@ -24,7 +24,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define FXG_BLOCK 256           // threads per workgroup = 4 wave64
 #define FXG_WAVES (FXG_BLOCK / 64)
-#define FXG_MAX_TILE 256        // reads per tile (one thread decides one read)
+#ifndef FXG_TBLOCK
+#define FXG_TBLOCK 256          // threads per workgroup of the tile kernels
+#endif
+#define FXG_TWAVES (FXG_TBLOCK / 64)
+#define FXG_MAX_TILE FXG_TBLOCK  // reads per tile (one thread decides one read)
 #define FXG_TICKET_GROUPS 8      // a single device-scope counter saturates near 88 tickets/us; shard it (one per XCD)
 #define FXG_TICKET_STRIDE 32     // u32 words between dispensers (128 B: one cache line each)
 
@@ -107,6 +111,25 @@ FXG_HD u32x4 fxg_ld16(const uint8_t *p)
     u32x4 v;
     __builtin_memcpy(&v, p, 16);
     return v;
+}
+// Streaming forms for data touched exactly once by the gather (source windows read for the last time, packed output):
+// the `nt` hint keeps them from displacing the quality tiles that stage B re-reads out of L2 / Infinity Cache.
+typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));
+FXG_HD u32x4 fxg_ld16_stream(const uint8_t *p)
+{
+#if !defined(FXG_V_NO_NT) && !defined(FXG_HOST_EMULATION)
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned *>(p));
+#else
+    return fxg_ld16(p);
+#endif
+}
+FXG_HD void fxg_st16_stream(uint8_t *p, u32x4 v)
+{
+#if !defined(FXG_V_NO_NT) && !defined(FXG_HOST_EMULATION)
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
+#else
+    *reinterpret_cast<u32x4 *>(p) = v;
+#endif
 }
 
 // bytes [vlo, vhi) of a 16-byte window starting at absolute offset off; the rest is zero.
@@ -250,7 +273,19 @@ __device__ __forceinline__ void fxg_publish_aggregate(const FxgKArgs &a, u32 til
 // a full prefix is met; then publish this tile's inclusive prefix.  Tiles are handed out by a global
 // ticket, so every predecessor is owned by a workgroup that is already running: the wait terminates
 // whatever the residency or placement.  Returns the exclusive prefix in every lane.
-__device__ __forceinline__ void fxg_resolve_prefix(const FxgKArgs &a, u32 tile, u64 agg_cnt, u64 agg_bytes,
+//
+// fxg_peek_window issues the loads of the first 32-tile window early (the kernel calls it before stage A of the next
+// tile, one pipeline step after the aggregates were published) and fxg_resolve_prefix consumes them as its first poll,
+// so that the memory round trip of the common one-poll case is spent under stage A instead of in front of the gather.
+__device__ __forceinline__ u64 fxg_peek_window(const FxgKArgs &a, u32 tile)
+{
+    const u32 lane = fxg_lane();
+    u64 *st = (lane >> 5) ? a.status_bytes : a.status_cnt;
+    const long long pos = (long long)tile - 1 - (long long)(lane & 31u);
+    return pos >= 0 ? fxg_granule_load(st + pos) : (FXG_ST_PREFIX << 62);
+}
+
+__device__ __forceinline__ void fxg_resolve_prefix(const FxgKArgs &a, u32 tile, u64 agg_cnt, u64 agg_bytes, u64 peek,
                                                    u64 *base_cnt, u64 *base_bytes)
 {
     const u32 lane = fxg_lane();
@@ -263,9 +298,12 @@ __device__ __forceinline__ void fxg_resolve_prefix(const FxgKArgs &a, u32 tile, 
         bool done = false;
         const u64 t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
         u32 spins = 0;
+        bool first = true;
         for (;;) {
             u64 v = (FXG_ST_PREFIX << 62);                  // virtual tile -1: prefix 0
-            if (!done && pos >= 0) v = fxg_granule_load(st + pos);
+            if (first) v = peek;
+            else if (!done && pos >= 0) v = fxg_granule_load(st + pos);
+            first = false;
             const u32 s = (u32)(v >> 62);
             const u64 b_inv = __ballot(s == FXG_ST_INVALID);
             const u64 b_pfx = __ballot(s == FXG_ST_PREFIX);
@@ -298,7 +336,7 @@ __device__ __forceinline__ void fxg_resolve_prefix(const FxgKArgs &a, u32 tile, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// workgroup exclusive scan of (keep, out_len) over FXG_BLOCK threads.  scratch: u32[2*FXG_WAVES + 2]
+// workgroup exclusive scan of (keep, out_len) over FXG_TBLOCK threads.  scratch: u32[2*FXG_TWAVES]
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void fxg_block_scan2(u32 c, u32 b, u32 *scratch, u32 *ex_c, u32 *ex_b, u32 *tot_c, u32 *tot_b)
 {
@@ -309,12 +347,12 @@ __device__ __forceinline__ void fxg_block_scan2(u32 c, u32 b, u32 *scratch, u32 
         u32 tc = __shfl_up(ic, d, 64), tb = __shfl_up(ib, d, 64);
         if ((int)lane >= d) { ic += tc; ib += tb; }
     }
-    if (lane == 63) { scratch[wave] = ic; scratch[FXG_WAVES + wave] = ib; }
+    if (lane == 63) { scratch[wave] = ic; scratch[FXG_TWAVES + wave] = ib; }
     __syncthreads();
     u32 oc = 0, ob = 0, sc = 0, sb = 0;
 #pragma unroll
-    for (int w = 0; w < FXG_WAVES; ++w) {
-        const u32 wc = scratch[w], wb = scratch[FXG_WAVES + w];
+    for (int w = 0; w < FXG_TWAVES; ++w) {
+        const u32 wc = scratch[w], wb = scratch[FXG_TWAVES + w];
         if (w < (int)wave) { oc += wc; ob += wb; }
         sc += wc; sb += wb;
     }
@@ -323,148 +361,163 @@ __device__ __forceinline__ void fxg_block_scan2(u32 c, u32 b, u32 *scratch, u32 
 
 // ------------------------------------------------------------------------------------------------
 // order-preserving gather of one tile's kept reads into the packed output.
-//   v_off[0..nreads] : exclusive prefix of kept lengths inside the tile (LDS)
-//   v_src[r]         : tile-relative source byte of output byte 0 of read r (LDS)
-//   REV              : output byte k comes from source byte v_src[r] - k, complemented (bases)
-// Work item = one 16-byte aligned chunk of the GLOBAL output; consecutive lanes write consecutive
-// chunks (1 KiB per wave store).  A chunk that straddles reads is assembled from one window per read.
+// Stage A leaves the tile's KEPT reads, in input order, in LDS (index = rank of the read among the tile's kept reads):
+//   k_off[0..nk] : exclusive prefix of kept lengths (tile-relative output offset of each kept read; k_off[nk] = S)
+//   k_src[k]     : tile-relative source byte of output byte 0 of kept read k
+//   k_tab[g]     : rank of the read that owns tile-relative output byte 16*g (g < ceil(S/16))
+//   REV          : output byte j of a read comes from source byte k_src[k] - j, complemented (bases)
+// Work item = one 16-byte aligned chunk of the GLOBAL output; consecutive lanes write consecutive chunks (1 KiB per
+// wave store).  A chunk takes one unaligned 16-byte source window per array, two when it straddles two reads; the
+// (rare) bytes of a third and later read inside one chunk, the partial chunks at either end of the tile (shared with
+// the neighbouring tiles) and the first/last tile of the batch (where a window could leave the arrays) go byte by byte.
+// Everything per lane is 32-bit and tile-relative; the 64-bit bases are wave-uniform and stay in SGPRs.
 // ------------------------------------------------------------------------------------------------
-// One source segment of an output chunk: chunk bytes [blo, bhi) come from the 16-byte window that starts
-// `src` bytes after the tile's first input byte (read backwards when REV).  Everything per lane is 32-bit and
-// tile-relative; the 64-bit bases are wave-uniform and stay in SGPRs.
-struct FxgSeg { int src; int blo, bhi; };
-
-template <bool REV>
-FXG_HD FxgSeg fxg_make_seg(const u32 *v_off, const u32 *v_src, u32 r, u32 o, u32 seg_end, int cs)
+FXG_HD void fxg_tab_fill(uint16_t *k_tab, u32 rank, u32 off, u32 len)
 {
-    FxgSeg g;
-    g.blo = (int)o - cs;
-    g.bhi = (int)seg_end - cs;
-    const int j0 = (int)(o - v_off[r]);
-    g.src = REV ? (int)v_src[r] - j0 + g.blo - 15 : (int)v_src[r] + j0 - g.blo;
-    return g;
+    for (u32 g = (off + 15u) >> 4; (g << 4) < off + len; ++g) k_tab[g] = (uint16_t)rank;
 }
 
-// The 16-byte window of one array for one segment, reversed/complemented/validated when REV, masked to
-// [blo, bhi).  tile_ptr = array + tile_in_base (uniform); [lo_ok, hi_ok) = tile-relative range of the array.
-template <bool REV, bool BASES, bool MASK = false>
-FXG_HD u32x4 fxg_seg_bytes(const uint8_t *tile_ptr, int lo_ok, int hi_ok, const FxgSeg &g, u32 *bad, const uint8_t *tile_q = nullptr,
-                           u32 Kmask = 0u, u32 mask4 = 0u)
+// largest k with k_off[k] <= o   (k_off[0] = 0 <= o < S = k_off[nk]); that read is never empty
+FXG_HD u32 fxg_rank_of(const u32 *k_off, const uint16_t *k_tab, u32 nk, u32 S, u32 o)
 {
-    const int vlo = REV ? 16 - g.bhi : g.blo, vhi = REV ? 16 - g.blo : g.bhi;
-    const bool inside = g.src >= lo_ok && g.src + 16 <= hi_ok;
-    u32x4 w, wq = {0u, 0u, 0u, 0u};
-    if (inside) { w = fxg_ld16(tile_ptr + g.src); if (MASK) wq = fxg_ld16(tile_q + g.src); }
-    else {                                         // window pokes out of the array: touch only the needed bytes
-        u64 lo = 0, hi = 0, qlo = 0, qhi = 0;
-        for (int i = vlo; i < vhi; ++i) {
-            const u64 b = tile_ptr[g.src + i];
-            if (i < 8) lo |= b << (8 * i); else hi |= b << (8 * (i - 8));
-            if (MASK) { const u64 q = tile_q[g.src + i]; if (i < 8) qlo |= q << (8 * i); else qhi |= q << (8 * (i - 8)); }
-        }
-        w = (u32x4){(u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32)};
-        if (MASK) wq = (u32x4){(u32)qlo, (u32)(qlo >> 32), (u32)qhi, (u32)(qhi >> 32)};
+    u32 lo = 0, hi = nk;
+    if (k_tab) {                                            // o lies between the owners of its granule's first byte and of the next granule's
+        const u32 g = o >> 4;
+        lo = k_tab[g];
+        hi = ((g + 1u) << 4) < S ? (u32)k_tab[g + 1u] + 1u : nk;
     }
-    if (MASK) {                                    // fastq_masker.c:94-99: base := mask character where quality < threshold
-        const u32 ws[4] = {w.x, w.y, w.z, w.w}, qs[4] = {wq.x, wq.y, wq.z, wq.w};
-        u32 o[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u32 low = (fxg_ge_flags(qs[i], Kmask) ^ 0x80808080u) >> 7;     // 0x01 per byte with quality below the threshold
-            const u32 m = low * 0xFFu;
-            o[i] = (ws[i] & ~m) | (mask4 & m);
-        }
-        w = (u32x4){o[0], o[1], o[2], o[3]};
+    while (hi - lo > 1u) {
+        const u32 mid = (lo + hi) >> 1;
+        if (k_off[mid] <= o) lo = mid; else hi = mid;
     }
-    if (REV) {
-        w = fxg_reverse16(w);
-        if (BASES) {
-            const u32x4 m = fxg_keep_bytes((u32x4){~0u, ~0u, ~0u, ~0u}, g.blo, g.bhi);
-            *bad |= fxg_invalid_bases4(w.x, m.x) | fxg_invalid_bases4(w.y, m.y) | fxg_invalid_bases4(w.z, m.z) | fxg_invalid_bases4(w.w, m.w);
-            w.x = fxg_complement4(w.x); w.y = fxg_complement4(w.y); w.z = fxg_complement4(w.z); w.w = fxg_complement4(w.w);
-        }
-    }
-    return fxg_keep_bytes(w, g.blo, g.bhi);
+    return lo;
 }
 
-// one array of one chunk: both candidate windows in flight, then the (rare) tail of further segments
-template <bool REV, bool BASES, bool MASK = false>
-FXG_HD void fxg_gather_array(const uint8_t *tile_ptr, int lo_ok, int hi_ok, uint8_t *out_chunk, const u32 *v_off, const u32 *v_src,
-                             const FxgSeg &s1, const FxgSeg &s2, bool two, bool more, u32 r_next, u32 o_next, u32 o_end, int cs,
-                             int lo_c, int hi_c, u32 *bad, const uint8_t *tile_q = nullptr, u32 Kmask = 0u, u32 mask4 = 0u)
+// x in [0, 4]: low x bytes set
+FXG_HD u32 fxg_lowbytes32(int x) { return x >= 4 ? 0xFFFFFFFFu : ((1u << (8 * x)) - 1u); }
+// e in [0, 16]: low e bytes of a 16-byte value set
+FXG_HD u32x4 fxg_lowmask16(int e)
 {
-    u32x4 acc = fxg_seg_bytes<REV, BASES, MASK>(tile_ptr, lo_ok, hi_ok, s1, bad, tile_q, Kmask, mask4);
-    if (two) acc |= fxg_seg_bytes<REV, BASES, MASK>(tile_ptr, lo_ok, hi_ok, s2, bad, tile_q, Kmask, mask4);
-    if (more) {
-        u32 r = r_next, o = o_next;
-        while (o < o_end) {
-            const u32 e = v_off[r + 1];
-            if (e > o) {
-                const u32 se = e < o_end ? e : o_end;
-                const FxgSeg g = fxg_make_seg<REV>(v_off, v_src, r, o, se, cs);
-                acc |= fxg_seg_bytes<REV, BASES, MASK>(tile_ptr, lo_ok, hi_ok, g, bad, tile_q, Kmask, mask4);
-                o = se;
-            }
-            ++r;
-        }
+    const int e0 = e < 4 ? e : 4, e1 = e < 4 ? 0 : (e < 8 ? e - 4 : 4), e2 = e < 8 ? 0 : (e < 12 ? e - 8 : 4), e3 = e < 12 ? 0 : e - 12;
+    return (u32x4){fxg_lowbytes32(e0), fxg_lowbytes32(e1), fxg_lowbytes32(e2), fxg_lowbytes32(e3)};
+}
+FXG_HD u32x4 fxg_select16(u32x4 m, u32x4 x, u32x4 y) { return (x & m) | (y & ~m); }
+
+// one output byte: tile-relative output offset o of kept read `anchor` at position j
+template <bool REV, bool MASK>
+FXG_HD void fxg_gather_byte(const FxgKArgs &a, const uint8_t *src_b, const uint8_t *src_q, uint8_t *dst_b, uint8_t *dst_q,
+                            u32 anchor, u32 j, u32 o, u32 *bad)
+{
+    const u32 s = REV ? anchor - j : anchor + j;
+    u32 b = src_b[s];
+    if (MASK) { if ((u32)src_q[s] < a.fq) b = a.mask_char & 0xFFu; }      // fastq_masker.c:94-99
+    if (REV) { *bad |= fxg_invalid_bases4(b, 0xFFu); b = fxg_complement4(b) & 0xFFu; }
+    dst_b[o] = (uint8_t)b;
+    if (dst_q) dst_q[o] = src_q[s];
+}
+
+// One 16-byte output chunk in flight: bytes [0, e) come from kept read k (window wb/wq, first forward byte at chunk byte 0),
+// bytes [e, e2) from read k + 1 (window vb/vq), bytes [e2, 16) from later reads.  e = 0 marks an unused slot.
+#ifndef FXG_GATHER_K
+#define FXG_GATHER_K 2   // measured: 1 and 2 tie at 5 workgroups/CU, 2..4 win when fewer are resident; 3 needs > 96 VGPRs
+#endif
+struct FxgChunk { u32 o, k; int e, e2; u32x4 wb, wq, vb, vq; };
+
+template <bool REV, bool MASK>
+FXG_HD void fxg_chunk_load(FxgChunk &c, const uint8_t *src_b, const uint8_t *src_q, bool want_q, const u32 *k_off, const u32 *k_src,
+                           const uint16_t *k_tab, u32 nk, u32 S, u32 o)
+{
+    const u32 k = fxg_rank_of(k_off, k_tab, nk, S, o);
+    const u32 e1 = k_off[k + 1u];
+    const int j0 = (int)(o - k_off[k]);
+    const int e = e1 - o < 16u ? (int)(e1 - o) : 16;
+    const int p1 = REV ? (int)k_src[k] - j0 - 15 : (int)k_src[k] + j0;
+    c.o = o; c.k = k; c.e = e; c.e2 = 16;
+    c.wb = fxg_ld16_stream(src_b + p1);
+    c.wq = (u32x4){0u, 0u, 0u, 0u};
+    if (want_q) c.wq = fxg_ld16_stream(src_q + p1);
+    c.vb = c.vq = (u32x4){0u, 0u, 0u, 0u};
+    if (e < 16) {                                                         // the chunk continues in the next kept read
+        const u32 n2 = k_off[k + 2u] - e1;
+        c.e2 = n2 < (u32)(16 - e) ? e + (int)n2 : 16;
+        const int p2 = REV ? (int)k_src[k + 1u] + e - 15 : (int)k_src[k + 1u] - e;
+        c.vb = fxg_ld16_stream(src_b + p2);
+        if (want_q) c.vq = fxg_ld16_stream(src_q + p2);
     }
-    if (lo_c == 0 && hi_c == 16) { *reinterpret_cast<u32x4 *>(out_chunk) = acc; return; }
-    // first / last chunk of the tile: the neighbouring tile owns the other bytes
-    const u64 b0 = ((u64)acc.y << 32) | acc.x, b1 = ((u64)acc.w << 32) | acc.z;
-    for (int i = lo_c; i < hi_c; ++i) out_chunk[i] = (uint8_t)((i < 8 ? b0 : b1) >> (8 * (i & 7)));
 }
 
 template <bool REV, bool MASK = false>
-FXG_HD u32 fxg_tile_gather(const FxgKArgs &a, const u32 *v_off, const u32 *v_src, u32 nreads,
-                           u64 tile_in_base, u64 B, u32 S, u32 tid, u32 nthreads)
+FXG_HD u32 fxg_tile_gather(const FxgKArgs &a, const u32 *k_off, const u32 *k_src, const uint16_t *k_tab, u32 nk,
+                           u64 tile_in_base, u32 tile_bytes, u64 B, u32 S, u32 tid, u32 nthreads)
 {
     if (S == 0) return 0u;
-    const u32 Kmask = (128u - a.fq) * 0x01010101u, mask4 = (a.mask_char & 0xFFu) * 0x01010101u;
     const bool has_q = a.qual != nullptr && a.out_qual != nullptr && !FXG_DBG(a, 4u);
-    // wave-uniform 64-bit quantities
-    const u64 c_first = B >> 4;
-    const u32 nchunks = (u32)(((B + S - 1) >> 4) - c_first) + 1u;
-    const int head = (int)(B & 15u);                                   // chunk 0 starts `head` bytes before the tile's output
-    const uint8_t *src_b = a.bases + tile_in_base, *src_q = has_q ? a.qual + tile_in_base : nullptr;
-    uint8_t *out_b = a.out_bases + (c_first << 4), *out_q = has_q ? a.out_qual + (c_first << 4) : nullptr;
-    const int lo_ok = tile_in_base > 0x3FFFFFFFull ? -0x3FFFFFFF : -(int)tile_in_base;
-    const u64 after = a.total_bytes - tile_in_base;
-    const int hi_ok = after > 0x3FFFFFFFull ? 0x3FFFFFFF : (int)after;
+    // wave-uniform 64-bit quantities; tile-relative output byte o lives at dst[o], tile-relative source byte s at src[s]
+    const uint8_t *src_b = a.bases + tile_in_base, *src_q = (has_q || MASK) ? a.qual + tile_in_base : nullptr;
+    uint8_t *dst_b = a.out_bases + B, *dst_q = has_q ? a.out_qual + B : nullptr;
+    // a window covers up to 15 bytes either side of the rows it serves: whole windows only where that stays inside the arrays
+    const bool interior = tile_in_base >= 15u && tile_in_base + tile_bytes + 15u <= a.total_bytes;
+    u32 o_lo = 0, nfull = 0;
+    if (interior) {
+        const u32 head = (16u - (u32)(B & 15u)) & 15u;                   // output bytes before the first aligned chunk
+        o_lo = head < S ? head : S;
+        nfull = (S - o_lo) >> 4;
+    }
+    const u32 o_hi = o_lo + (nfull << 4);
+    const u32 Kmask = (128u - a.fq) * 0x01010101u, mask4 = (a.mask_char & 0xFFu) * 0x01010101u;
     u32 bad = 0;
-    for (u32 ci = tid; ci < nchunks; ci += nthreads) {
-        const int cs = (int)(ci << 4) - head;                          // tile-relative output offset of chunk byte 0
-        const int lo_c = cs < 0 ? -cs : 0;
-        const int rem = (int)S - cs;
-        const int hi_c = rem >= 16 ? 16 : rem;
-        const u32 o = (u32)(cs + lo_c), o_end = (u32)(cs + hi_c);
-        // largest r with v_off[r] <= o   (v_off[0] = 0 <= o < S = v_off[nreads]); that read is never empty
-        u32 lo = 0, hi = nreads;
-        while (hi - lo > 1) {
-            const u32 mid = (lo + hi) >> 1;
-            if (v_off[mid] <= o) lo = mid; else hi = mid;
+
+    // FXG_GATHER_K chunks per lane and trip: the source windows of all of them are requested before any is consumed
+    for (u32 c0 = tid; c0 < nfull; c0 += nthreads * FXG_GATHER_K) {
+        FxgChunk ch[FXG_GATHER_K];
+#pragma unroll
+        for (int u = 0; u < FXG_GATHER_K; ++u) {
+            const u32 ci = c0 + (u32)u * nthreads;
+            ch[u].e = 0;
+            if (ci < nfull) fxg_chunk_load<REV, MASK>(ch[u], src_b, src_q, has_q || MASK, k_off, k_src, k_tab, nk, S, o_lo + (ci << 4));
         }
-        const u32 e1 = v_off[lo + 1];
-        const u32 end1 = e1 < o_end ? e1 : o_end;
-        const FxgSeg s1 = fxg_make_seg<REV>(v_off, v_src, lo, o, end1, cs);
-        FxgSeg s2 = s1;
-        bool two = false, more = false;
-        u32 r_next = 0, o_next = 0;
-        if (end1 < o_end) {                                            // the chunk continues in the next non-empty read
-            u32 r = lo + 1;
-            while (v_off[r + 1] == end1) ++r;
-            const u32 e2 = v_off[r + 1];
-            const u32 end2 = e2 < o_end ? e2 : o_end;
-            s2 = fxg_make_seg<REV>(v_off, v_src, r, end1, end2, cs);
-            two = true;
-            more = end2 < o_end;
-            r_next = r + 1; o_next = end2;
+#pragma unroll
+        for (int u = 0; u < FXG_GATHER_K; ++u) {
+            if (ch[u].e == 0) continue;
+            FxgChunk &c = ch[u];
+            if (REV) { c.wb = fxg_reverse16(c.wb); c.wq = fxg_reverse16(c.wq); }
+            if (c.e < 16) {
+                if (REV) { c.vb = fxg_reverse16(c.vb); c.vq = fxg_reverse16(c.vq); }
+                const u32x4 m = fxg_lowmask16(c.e);
+                c.wb = fxg_select16(m, c.wb, c.vb);
+                c.wq = fxg_select16(m, c.wq, c.vq);
+            }
+            if (MASK) {                                                   // fastq_masker.c:94-99: base := mask character where quality < threshold
+                u32 *pb = reinterpret_cast<u32 *>(&c.wb);
+                const u32 *pq = reinterpret_cast<const u32 *>(&c.wq);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u32 sel = ((fxg_ge_flags(pq[i], Kmask) ^ 0x80808080u) >> 7) * 0xFFu;   // 0xFF per byte with quality below the threshold
+                    pb[i] = (pb[i] & ~sel) | (mask4 & sel);
+                }
+            }
+            if (REV) {
+                const u32x4 mv = fxg_lowmask16(c.e2);
+                bad |= fxg_invalid_bases4(c.wb.x, mv.x) | fxg_invalid_bases4(c.wb.y, mv.y) | fxg_invalid_bases4(c.wb.z, mv.z) | fxg_invalid_bases4(c.wb.w, mv.w);
+                c.wb.x = fxg_complement4(c.wb.x); c.wb.y = fxg_complement4(c.wb.y); c.wb.z = fxg_complement4(c.wb.z); c.wb.w = fxg_complement4(c.wb.w);
+            }
+            fxg_st16_stream(dst_b + c.o, c.wb);
+            if (has_q) fxg_st16_stream(dst_q + c.o, c.wq);
+            if (c.e2 < 16) {                                              // third and later reads of this chunk: overwrite byte by byte (same lane, program order)
+                u32 r = c.k + 2u;
+                for (u32 x = c.o + (u32)c.e2; x < c.o + 16u; ++x) {
+                    while (k_off[r + 1u] <= x) ++r;
+                    fxg_gather_byte<REV, MASK>(a, src_b, src_q, dst_b, dst_q, k_src[r], x - k_off[r], x, &bad);
+                }
+            }
         }
-        fxg_gather_array<REV, true, MASK>(src_b, lo_ok, hi_ok, out_b + (ci << 4), v_off, v_src, s1, s2, two, more, r_next, o_next, o_end, cs, lo_c, hi_c, &bad,
-                                          a.qual + tile_in_base, Kmask, mask4);
-        if (has_q) {
-            u32 dummy = 0;
-            fxg_gather_array<REV, false>(src_q, lo_ok, hi_ok, out_q + (ci << 4), v_off, v_src, s1, s2, two, more, r_next, o_next, o_end, cs, lo_c, hi_c, &dummy);
-        }
+    }
+    // bytes outside the full chunks: [0, o_lo) and [o_hi, S)
+    const u32 nb = o_lo + (S - o_hi);
+    for (u32 x = tid; x < nb; x += nthreads) {
+        const u32 o = x < o_lo ? x : o_hi + (x - o_lo);
+        const u32 k = fxg_rank_of(k_off, k_tab, nk, S, o);
+        fxg_gather_byte<REV, MASK>(a, src_b, src_q, dst_b, dst_q, k_src[k], o - k_off[k], o, &bad);
     }
     return bad;   // nonzero: a byte outside ACGTN/acgtn reached the complement (REV only)
 }

@@ -174,7 +174,7 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
     FXG_HIP(c, hipSetDevice(c->device));
     FXG_HIP(c, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0;
-    FXG_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, FXG_BLOCK, lds));
+    FXG_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, FXG_TBLOCK, lds));
     if (per_cu < 1) return fxg_fail(c, FXG_E_INVALID, "%s does not fit on a CU (lds=%u)", kname, lds);
     // Tiles are dispensed by ticket, so nothing depends on every workgroup being resident: fill the chip.
     int use = per_cu > 8 ? 8 : per_cu;
@@ -214,7 +214,7 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
     FXG_HIP(c, hipMemsetAsync(c->errflag, 0, (FXG_TICKET_GROUPS + 1) * FXG_TICKET_STRIDE * sizeof(u32), c->stream));
 
     if (c->profiling) FXG_HIP(c, hipEventRecord(c->kev0, c->stream));
-    hipLaunchKernelGGL(kernel, dim3((u32)grid), dim3(FXG_BLOCK), lds, c->stream, ka);
+    hipLaunchKernelGGL(kernel, dim3((u32)grid), dim3(FXG_TBLOCK), lds, c->stream, ka);
     FXG_HIP(c, hipGetLastError());
     if (c->profiling) { FXG_HIP(c, hipEventRecord(c->kev1, c->stream)); c->kev_valid = 1; }
     // -v report counters: one pass over res[] (4 B/read), then fold the partial rows
@@ -227,7 +227,7 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
                        (const u32 *)c->errflag, (const u64 *)(c->errflag + 2), counters ? counters : c->counters_scratch);
     FXG_HIP(c, hipGetLastError());
     snprintf(c->last_kernel, sizeof c->last_kernel, "%s", kname);
-    c->last_grid = (u32)grid; c->last_block = FXG_BLOCK; c->last_lds = lds; c->last_tile = ka.tile_reads;
+    c->last_grid = (u32)grid; c->last_block = FXG_TBLOCK; c->last_lds = lds; c->last_tile = ka.tile_reads;
     return FXG_OK;
 }
 

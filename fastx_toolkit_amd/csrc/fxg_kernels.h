@@ -19,18 +19,22 @@
 #define FXG_INVALID_TUPLE 0xFFFFFFFFu
 
 // LDS carve-up shared by host (size) and device (pointers); every region is 16-byte aligned (G17).
-// v_off / v_src / v_rank are double buffered: stage B of tile i reads slot s while stage A of tile i+1 fills slot s^1.
+// k_off / k_src / k_idx / k_tab (the tile's kept reads, see fxg_tile_gather) are double buffered: stage B of tile i reads
+// slot s while stage A of tile i+1 fills slot s^1.
 struct FxgLds {
-    u32 slot_bytes, so_vsrc, so_vrank;   // slot k lives at k * slot_bytes: v_off at +0, v_src at +so_vsrc, v_rank at +so_vrank
+    u32 slot_bytes, so_ksrc, so_kidx, so_ktab;   // slot k lives at k * slot_bytes: k_off at +0, k_src at +so_ksrc, k_idx at +so_kidx, k_tab at +so_ktab
     u32 off_scratch, off_bm_g, off_bm_l, off_bases, total;
+    u32 has_tab;                                 // kernels that stage a tile of bases in LDS (clipper, census) spend no LDS on k_tab
 };
 __host__ __device__ inline u32 fxg_r16(u32 x) { return (x + 15u) & ~15u; }
 __host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, bool bitmaps, bool stage_bases)
 {
     FxgLds l;
-    l.so_vsrc = fxg_r16((T + 1) * 4);
-    l.so_vrank = l.so_vsrc + fxg_r16(T * 4);
-    l.slot_bytes = l.so_vrank + fxg_r16(T * 2);
+    l.so_ksrc = fxg_r16((T + 1) * 4);
+    l.so_kidx = l.so_ksrc + fxg_r16(T * 4);
+    l.so_ktab = l.so_kidx + fxg_r16(T * 2);
+    l.has_tab = stage_bases ? 0u : 1u;
+    l.slot_bytes = l.so_ktab + (l.has_tab ? fxg_r16(((T * stride + 15) / 16 + 1) * 2) : 0u);
     u32 o = 2 * l.slot_bytes;
     l.off_scratch = o; o += fxg_r16(48 * 4);
     const u32 words = (T * stride + 31) / 32 + 2;
@@ -247,6 +251,9 @@ FXG_HD void fxg_counts_to_slots(const FxgCounts &c, u32 stages, u64 *slot)
 
 // ---- per-thread phase bodies (host+device so tests/emu can run them serially) ----
 
+#ifndef FXG_BITMAP_U
+#define FXG_BITMAP_U 5
+#endif
 // phase 1: quality rows of the tile -> two bitmaps.  Full in-range tiles take the batched path: five
 // independent 16-byte loads per lane are issued before any is consumed.
 FXG_HD void fxg_phase_bitmaps(const FxgKArgs &a, u64 tb, u32 tbytes, u32 *bm_g, u32 *bm_l, u32 tid, u32 nthreads)
@@ -256,7 +263,7 @@ FXG_HD void fxg_phase_bitmaps(const FxgKArgs &a, u64 tb, u32 tbytes, u32 *bm_g, 
     uint16_t *g16 = reinterpret_cast<uint16_t *>(bm_g), *l16 = reinterpret_cast<uint16_t *>(bm_l);
     const uint8_t *src = a.qual + tb;
     if ((tbytes & 15u) == 0u && tb + tbytes <= a.total_bytes) {
-        constexpr u32 U = 5;
+        constexpr u32 U = FXG_BITMAP_U;
         for (u32 c0 = tid; c0 < nchunks; c0 += nthreads * U) {
             u32x4 v[U];
 #pragma unroll
@@ -389,7 +396,7 @@ FXG_HD void fxg_write_kept_meta(const FxgKArgs &a, u64 rank, u32 olen, u32 read_
 #define FXG_MIN_WAVES 5   // __launch_bounds__ 2nd argument (waves per SIMD) for the streaming instances: 5 workgroups/CU measured best
 #endif
 template <int AMAX, int MODE>
-__global__ __launch_bounds__(FXG_BLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void fxg_kernel_tiles(const FxgKArgs a)
+__global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void fxg_kernel_tiles(const FxgKArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool REV = (MODE == 2);
@@ -400,9 +407,9 @@ __global__ __launch_bounds__(FXG_BLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void fx
     u32 *bm_g = reinterpret_cast<u32 *>(smem + L.off_bm_g);
     u32 *bm_l = reinterpret_cast<u32 *>(smem + L.off_bm_l);
     uint8_t *sb = smem + L.off_bases;
-    u32 *scratch = reinterpret_cast<u32 *>(smem + L.off_scratch);   // [0,8) scan, [8,12) tile totals per slot, [12,14) tickets
-    u64 *bc = reinterpret_cast<u64 *>(scratch + 16);                // [0,2) broadcast of the resolved bases
-    u32 *s_tot = scratch + 8, *s_ticket = scratch + 12;
+    u32 *scratch = reinterpret_cast<u32 *>(smem + L.off_scratch);   // [0,2W) scan, then 4 words tile totals per slot, 2 tickets, 2 pad
+    u32 *s_tot = scratch + 2 * FXG_TWAVES, *s_ticket = s_tot + 4;
+    u64 *bc = reinterpret_cast<u64 *>(s_tot + 8);                   // [0,2) broadcast of the resolved bases
 
     // Sharded dispenser: workgroup b draws from counter g = b % groups, which hands out tiles g, g+groups, ...
     // The smallest unfinished tile is always either owned by a running workgroup or the next ticket of its
@@ -416,6 +423,10 @@ __global__ __launch_bounds__(FXG_BLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void fx
     u32 pend = 0xFFFFFFFFu;
     u32 slot = 0, tk = 0;
     for (;;) {
+        u64 peek = 0;                                    // first look-back window of `pend`, in flight during stage A
+#ifndef FXG_V_NO_PEEK
+        if (tid < 64 && pend != 0xFFFFFFFFu && a.compact && !FXG_DBG(a, 2u)) peek = fxg_peek_window(a, pend);
+#endif
         // ------------------------------ stage A: tile `cur` into slot `slot` ------------------------------
         if (cur < a.ntiles) {
             if (tid == 0) s_ticket[tk ^ 1u] = atomicAdd(my_ticket, 1u);   // next ticket: in flight while this tile is decided
@@ -425,8 +436,8 @@ __global__ __launch_bounds__(FXG_BLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void fx
             const u64 tb = (u64)r0 * stride;
             const u32 tbytes = nreads * stride;
             if constexpr (MODE == 0 || MODE == 3 || MODE == 4) {
-                if (use_q && !FXG_DBG(a, 8u)) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, FXG_BLOCK);
-                if constexpr ((MODE == 0 && AMAX != 0) || MODE == 4) fxg_phase_stage_bases(a, tb, tbytes, sb, tid, FXG_BLOCK);
+                if (use_q && !FXG_DBG(a, 8u)) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, FXG_TBLOCK);
+                if constexpr ((MODE == 0 && AMAX != 0) || MODE == 4) fxg_phase_stage_bases(a, tb, tbytes, sb, tid, FXG_TBLOCK);
                 __syncthreads();
             }
             u32 keep = 0, olen = 0, anchor = tid * stride;
@@ -440,11 +451,14 @@ __global__ __launch_bounds__(FXG_BLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void fx
             fxg_block_scan2(keep, keep ? olen : 0u, scratch, &exc, &exb, &totc, &totb);   // one __syncthreads inside
             if (a.compact) {
                 unsigned char *sl = smem + slot * L.slot_bytes;
-                u32 *v_off = reinterpret_cast<u32 *>(sl);
-                u32 *v_src = reinterpret_cast<u32 *>(sl + L.so_vsrc);
-                uint16_t *v_rank = reinterpret_cast<uint16_t *>(sl + L.so_vrank);
-                if (tid < nreads) { v_off[tid] = exb; v_src[tid] = anchor; v_rank[tid] = (uint16_t)exc; }
-                if (tid == 0) { v_off[nreads] = totb; s_tot[2 * slot] = totc; s_tot[2 * slot + 1] = totb; }
+                u32 *k_off = reinterpret_cast<u32 *>(sl);
+                if (tid < nreads && keep) {                          // kept reads only, indexed by their rank inside the tile
+                    k_off[exc] = exb;
+                    reinterpret_cast<u32 *>(sl + L.so_ksrc)[exc] = anchor;
+                    reinterpret_cast<uint16_t *>(sl + L.so_kidx)[exc] = (uint16_t)tid;
+                    if (L.has_tab) fxg_tab_fill(reinterpret_cast<uint16_t *>(sl + L.so_ktab), exc, exb, olen);
+                }
+                if (tid == 0) { k_off[totc] = totb; s_tot[2 * slot] = totc; s_tot[2 * slot + 1] = totb; }
                 if (tid < 64 && !FXG_DBG(a, 2u)) fxg_publish_aggregate(a, cur, totc, totb);
             }
         }
@@ -455,23 +469,24 @@ __global__ __launch_bounds__(FXG_BLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void fx
             const u64 left = a.n - (u64)r0;
             const u32 nreads = left < (u64)T ? (u32)left : T;
             const unsigned char *sl = smem + ps * L.slot_bytes;
-            const u32 *v_off = reinterpret_cast<const u32 *>(sl);
-            const u32 *v_src = reinterpret_cast<const u32 *>(sl + L.so_vsrc);
-            const uint16_t *v_rank = reinterpret_cast<const uint16_t *>(sl + L.so_vrank);
+            const u32 *k_off = reinterpret_cast<const u32 *>(sl);
+            const u32 *k_src = reinterpret_cast<const u32 *>(sl + L.so_ksrc);
+            const uint16_t *k_idx = reinterpret_cast<const uint16_t *>(sl + L.so_kidx);
+            const uint16_t *k_tab = L.has_tab ? reinterpret_cast<const uint16_t *>(sl + L.so_ktab) : nullptr;
             if (tid < 64) {
                 u64 base_c = 0, base_b = 0;
-                if (!FXG_DBG(a, 2u)) fxg_resolve_prefix(a, pend, s_tot[2 * ps], s_tot[2 * ps + 1], &base_c, &base_b);
+#ifdef FXG_V_NO_PEEK
+                peek = fxg_peek_window(a, pend);
+#endif
+                if (!FXG_DBG(a, 2u)) fxg_resolve_prefix(a, pend, s_tot[2 * ps], s_tot[2 * ps + 1], peek, &base_c, &base_b);
                 if (tid == 0) { bc[0] = base_c; bc[1] = base_b; }
             }
             __syncthreads();
             const u64 base_c = bc[0], base_b = bc[1];
-            const u32 totb = v_off[nreads];
-            if (tid < nreads) {
-                const u32 olen = v_off[tid + 1] - v_off[tid];      // kept reads are never empty
-                if (olen) fxg_write_kept_meta(a, base_c + v_rank[tid], olen, r0 + tid, base_b + v_off[tid]);
-            }
+            const u32 nk = s_tot[2 * ps], totb = s_tot[2 * ps + 1];
+            if (tid < nk) fxg_write_kept_meta(a, base_c + tid, k_off[tid + 1] - k_off[tid], r0 + k_idx[tid], base_b + k_off[tid]);
             if (!FXG_DBG(a, 1u)) {
-                const u32 bad = fxg_tile_gather<REV, MODE == 3>(a, v_off, v_src, nreads, (u64)r0 * stride, base_b, totb, tid, FXG_BLOCK);
+                const u32 bad = fxg_tile_gather<REV, MODE == 3>(a, k_off, k_src, k_tab, nk, (u64)r0 * stride, nreads * stride, base_b, totb, tid, FXG_TBLOCK);
                 if (REV && bad) atomicOr(a.errflag, FXG_DEV_ERR_BAD_BASE);
             }
         }

@@ -9,9 +9,10 @@ sys.path.insert(0, ROOT)
 import subprocess  # noqa: E402
 from fastx_toolkit_amd import build as _b  # noqa: E402
 
-ABL = os.path.join(_b.PKG, "libfxg_ablation.so")   # separate build: the product library has no ablation switches
-subprocess.check_call([_b.hipcc()] + _b.HIPCC_FLAGS + ["-DFXG_ABLATION", os.path.join(_b.CSRC, "fxg_engine.hip"), "-o", ABL])
-os.environ["FXG_LIB"] = ABL
+if not os.environ.get("FXG_LIB"):                  # FXG_LIB preset: time that (prebuilt variant) library as is
+    ABL = os.path.join(_b.PKG, "libfxg_ablation.so")   # separate build: the product library has no ablation switches
+    subprocess.check_call([_b.hipcc()] + _b.HIPCC_FLAGS + ["-DFXG_ABLATION", os.path.join(_b.CSRC, "fxg_engine.hip"), "-o", ABL])
+    os.environ["FXG_LIB"] = ABL
 from fastx_toolkit_amd import Engine, make_params  # noqa: E402
 
 R = int(os.environ.get("READS", "50000000"))

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""A/B compile-time kernel variants: `build` (here, hipcc cross-compiles) then `run` (GPU box) times cfg2 with each library.
+
+    python scripts/variants.py build            # fastx_toolkit_amd/libfxg_v_<name>.so, git-ignored, travel with gpurun
+    python scripts/variants.py run              # one JSON line per variant (scripts/ablate.py in a subprocess each)
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fastx_toolkit_amd import build as _b  # noqa: E402
+
+VARIANTS = {
+    "base": [],
+    "u10k4w3": ["-DFXG_BITMAP_U=10", "-DFXG_GATHER_K=4", "-DFXG_MIN_WAVES=3"],
+    "u10k3w4": ["-DFXG_BITMAP_U=10", "-DFXG_GATHER_K=3", "-DFXG_MIN_WAVES=4"],
+    "u10k2": ["-DFXG_BITMAP_U=10", "-DFXG_GATHER_K=2"],
+}
+
+
+def lib(name):
+    return os.path.join(_b.PKG, "libfxg_v_%s.so" % name)
+
+
+if sys.argv[1] == "build":
+    procs = [(n, subprocess.Popen([_b.hipcc()] + _b.HIPCC_FLAGS + d + [os.path.join(_b.CSRC, "fxg_engine.hip"), "-o", lib(n)])) for n, d in VARIANTS.items()]
+    for n, p in procs:
+        print(n, "rc", p.wait())
+else:
+    cfgs = os.environ.get("ABLATE") or json.dumps([["full", {}], ["decision-only", {}, False]])
+    for n in (os.environ.get("VARIANTS", "").split() or VARIANTS):
+        if not os.path.exists(lib(n)):
+            continue
+        env = dict(os.environ, FXG_LIB=lib(n), ABLATE=cfgs)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ablate.py")], env=env, capture_output=True, text=True, timeout=300)
+        for line in out.stdout.splitlines():
+            print(n, line, flush=True)
+        if out.returncode:
+            print(n, "FAILED", out.stderr[-400:], flush=True)

@@ -15,13 +15,14 @@ template <int AMAX, bool REV, int MODE = 0>
 static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
 {
     const FxgKArgs &a = pl.ka;
-    const u32 T = a.tile_reads, stride = a.stride, NT = FXG_BLOCK;
+    const u32 T = a.tile_reads, stride = a.stride, NT = FXG_TBLOCK;
     std::vector<unsigned char> lds(pl.lds + 64, 0);
     unsigned char *smem = lds.data();
     const FxgLds L = pl.group_a ? fxg_lds_layout(T, stride, pl.use_q, pl.clip) : fxg_lds_layout(T, stride, MODE == 3, MODE == 4);
     u64 m_reads = 0, m_nt = 0;
-    u32 *v_off = reinterpret_cast<u32 *>(smem);
-    u32 *v_src = reinterpret_cast<u32 *>(smem + L.so_vsrc);
+    u32 *k_off = reinterpret_cast<u32 *>(smem);
+    u32 *k_src = reinterpret_cast<u32 *>(smem + L.so_ksrc);
+    uint16_t *k_tab = L.has_tab ? reinterpret_cast<uint16_t *>(smem + L.so_ktab) : nullptr;
     u32 *bm_g = reinterpret_cast<u32 *>(smem + L.off_bm_g);
     u32 *bm_l = reinterpret_cast<u32 *>(smem + L.off_bm_l);
     uint8_t *sb = smem + L.off_bases;
@@ -60,11 +61,14 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
         if (!a.compact) continue;
         u32 exb = 0, exc = 0;
         for (u32 tid = 0; tid < nreads; ++tid) {
-            v_off[tid] = exb; v_src[tid] = anchor[tid];
-            if (keep[tid]) { fxg_write_kept_meta(a, base_c + exc, olen[tid], r0 + tid, base_b + exb); exb += olen[tid]; exc++; }
+            if (!keep[tid]) continue;
+            k_off[exc] = exb; k_src[exc] = anchor[tid];
+            if (k_tab) fxg_tab_fill(k_tab, exc, exb, olen[tid]);
+            fxg_write_kept_meta(a, base_c + exc, olen[tid], r0 + tid, base_b + exb);
+            exb += olen[tid]; exc++;
         }
-        v_off[nreads] = exb;
-        for (u32 tid = 0; tid < NT; ++tid) bad |= fxg_tile_gather<REV, MODE == 3>(a, v_off, v_src, nreads, tb, base_b, exb, tid, NT);
+        k_off[exc] = exb;
+        for (u32 tid = 0; tid < NT; ++tid) bad |= fxg_tile_gather<REV, MODE == 3>(a, k_off, k_src, k_tab, exc, tb, tbytes, base_b, exb, tid, NT);
         base_c += exc; base_b += exb;
     }
     for (u64 i = 0; i < a.n; ++i) fxg_count_res(a.res[i], cnt);   // same reduction the counting kernel performs
