@@ -112,12 +112,13 @@ FXG_HD u32x4 fxg_ld16(const uint8_t *p)
     __builtin_memcpy(&v, p, 16);
     return v;
 }
-// Streaming forms for data touched exactly once by the gather (source windows read for the last time, packed output):
-// the `nt` hint keeps them from displacing the quality tiles that stage B re-reads out of L2 / Infinity Cache.
+// Streaming forms for data touched exactly once by the gather.  Measured on cfg2 / cfg4: `nt` on the packed-output stores
+// is worth 4 % / -2 %; `nt` on the source windows costs 4 % / 7 % (neighbouring lanes' unaligned windows share lines), so
+// the loads stay plain unless FXG_V_NTL is defined.
 typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));
 FXG_HD u32x4 fxg_ld16_stream(const uint8_t *p)
 {
-#if !defined(FXG_V_NO_NT) && !defined(FXG_HOST_EMULATION)
+#if defined(FXG_V_NTL) && !defined(FXG_HOST_EMULATION)
     return __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned *>(p));
 #else
     return fxg_ld16(p);
@@ -125,7 +126,7 @@ FXG_HD u32x4 fxg_ld16_stream(const uint8_t *p)
 }
 FXG_HD void fxg_st16_stream(uint8_t *p, u32x4 v)
 {
-#if !defined(FXG_V_NO_NT) && !defined(FXG_HOST_EMULATION)
+#if !defined(FXG_V_NO_NTS) && !defined(FXG_HOST_EMULATION)
     __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
 #else
     *reinterpret_cast<u32x4 *>(p) = v;
@@ -419,7 +420,7 @@ FXG_HD void fxg_gather_byte(const FxgKArgs &a, const uint8_t *src_b, const uint8
 // One 16-byte output chunk in flight: bytes [0, e) come from kept read k (window wb/wq, first forward byte at chunk byte 0),
 // bytes [e, e2) from read k + 1 (window vb/vq), bytes [e2, 16) from later reads.  e = 0 marks an unused slot.
 #ifndef FXG_GATHER_K
-#define FXG_GATHER_K 2   // measured: 1 and 2 tie at 5 workgroups/CU, 2..4 win when fewer are resident; 3 needs > 96 VGPRs
+#define FXG_GATHER_K 1   // measured: 1 and 2 tie on cfg2 at 5 workgroups/CU (2..4 only win when fewer are resident); cfg4 prefers 1 (7 workgroups/CU)
 #endif
 struct FxgChunk { u32 o, k; int e, e2; u32x4 wb, wq, vb, vq; };
 

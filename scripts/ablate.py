@@ -15,10 +15,12 @@ if not os.environ.get("FXG_LIB"):                  # FXG_LIB preset: time that (
     os.environ["FXG_LIB"] = ABL
 from fastx_toolkit_amd import Engine, make_params  # noqa: E402
 
-R = int(os.environ.get("READS", "50000000"))
+CFG = os.environ.get("CFG", "cfg2")
+R = int(os.environ.get("READS", "200000000" if CFG == "cfg4" else "50000000"))
 eng = Engine(0)
 b, q = eng.synth(2, 0, R, 150)
-P = make_params(stages=6, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80)
+P = (make_params(stages=24, ft_first=5, ft_last=145) if CFG == "cfg4"
+     else make_params(stages=6, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80))
 outs = eng.alloc_outputs(R, 150, compact=True, meta=False)
 eng.set_profiling(True)
 

@@ -15,9 +15,10 @@ from fastx_toolkit_amd import build as _b  # noqa: E402
 
 VARIANTS = {
     "base": [],
-    "u10k4w3": ["-DFXG_BITMAP_U=10", "-DFXG_GATHER_K=4", "-DFXG_MIN_WAVES=3"],
-    "u10k3w4": ["-DFXG_BITMAP_U=10", "-DFXG_GATHER_K=3", "-DFXG_MIN_WAVES=4"],
-    "u10k2": ["-DFXG_BITMAP_U=10", "-DFXG_GATHER_K=2"],
+    "w6": ["-DFXG_MIN_WAVES=6"],
+    "w8": ["-DFXG_MIN_WAVES=8"],
+    "nonts": ["-DFXG_V_NO_NTS"],
+    "w8nonts": ["-DFXG_MIN_WAVES=8", "-DFXG_V_NO_NTS"],
 }
 
 
