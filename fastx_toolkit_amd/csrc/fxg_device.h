@@ -78,6 +78,11 @@ struct FxgKArgs {
     u32  mask_char;         // fastq_masker -r; the mask threshold shares `fq` (byte < fq is masked)
     u32  nf_keep_n;         // fastq_to_fasta -n
     u64 *extra;             // [0] masked reads, [1] masked nucleotides (fastq_masker report)
+    // what the clipper's DP reads: the batch itself, or (clip history, fxg_history.h) the queries extended by the stale tail
+    const uint8_t  *clip_src;
+    u64  clip_total;        // n * clip_stride
+    u32  clip_stride;
+    const uint16_t *wlen;   // DP rows per read (null: the read's own length)
     char adapter[100];
 };
 

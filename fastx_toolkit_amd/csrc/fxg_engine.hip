@@ -8,6 +8,7 @@
 
 #include "fxg_plan.h"
 #include "fxg_text.h"
+#include "fxg_history.h"
 
 struct fxg_ctx {
     int device;
@@ -26,6 +27,14 @@ struct fxg_ctx {
     u64 *text_ws;           // newline census / scan levels / format items
     size_t text_ws_cap;     // in u64 words
     FxgTextState *text_state;
+    // clip history (fxg_set_clip_history): the reference aligner's query buffer, carried from batch to batch
+    int hist_on;
+    u32 hist_wcap;          // host-side upper bound of the buffer width (the exact width lives on the device)
+    int hist_cur;           // which of hist_buf[2] / hist_w[2] is current
+    uint8_t *hist_buf[2];
+    u32 *hist_w;            // [2]
+    uint8_t *hist_ws;       // M, BT, ext, wlen
+    size_t hist_ws_cap;
     char err[512];
     char last_kernel[96];
     u32 last_grid, last_block, last_lds, last_tile;
@@ -83,6 +92,7 @@ extern "C" void fxg_ctx_destroy(fxg_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->status); (void)hipFree(c->partial); (void)hipFree(c->errflag); (void)hipFree(c->counters_scratch);
     (void)hipFree(c->text_ws); (void)hipFree(c->text_state);
+    (void)hipFree(c->hist_buf[0]); (void)hipFree(c->hist_buf[1]); (void)hipFree(c->hist_w); (void)hipFree(c->hist_ws);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipEventDestroy(c->kev0); (void)hipEventDestroy(c->kev1);
     (void)hipStreamDestroy(c->own_stream);
@@ -231,15 +241,90 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
     return FXG_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// clip history: the stale tail of the reference aligner's query buffer (fxg_history.h)
+// ------------------------------------------------------------------------------------------------
+extern "C" int fxg_set_clip_history(fxg_ctx *c, int on)
+{
+    if (!c) return FXG_E_INVALID;
+    FXG_HIP(c, hipSetDevice(c->device));
+    if (on && !c->hist_buf[0]) {
+        FXG_HIP(c, hipMalloc((void **)&c->hist_buf[0], FXG_HIST_CAP));
+        FXG_HIP(c, hipMalloc((void **)&c->hist_buf[1], FXG_HIST_CAP));
+        FXG_HIP(c, hipMalloc((void **)&c->hist_w, 2 * sizeof(u32)));
+    }
+    if (on) {                                               // a fresh aligner: empty buffer, width 0
+        FXG_HIP(c, hipMemsetAsync(c->hist_buf[0], 0, FXG_HIST_CAP, c->stream));
+        FXG_HIP(c, hipMemsetAsync(c->hist_buf[1], 0, FXG_HIST_CAP, c->stream));
+        FXG_HIP(c, hipMemsetAsync(c->hist_w, 0, 2 * sizeof(u32), c->stream));
+    }
+    c->hist_on = on ? 1 : 0; c->hist_wcap = 0; c->hist_cur = 0;
+    return FXG_OK;
+}
+
+// Builds the extended queries of one batch and moves the buffer on.  Returns FXG_OK with *use = 0 when the batch cannot see a
+// stale tail (fixed length, nothing longer before it): the clip kernel then reads the batch itself.
+static int fxg_hist_prepass(fxg_ctx *c, const fxg_batch *in, u32 T, u32 estride, FxgKArgs *ka, int *use)
+{
+    const u32 lmax = in->len ? in->stride : in->fixed_len;
+    const int cur = c->hist_cur;
+    *use = 0;
+    if (!in->len && c->hist_wcap <= in->fixed_len) {
+        hipLaunchKernelGGL(fxg_kernel_hist_fixed, dim3((FXG_HIST_CAP + FXG_BLOCK - 1) / FXG_BLOCK), dim3(FXG_BLOCK), 0, c->stream,
+                           (const uint8_t *)in->bases, (u64)in->n, in->fixed_len, in->stride, (const uint8_t *)c->hist_buf[cur], (const u32 *)(c->hist_w + cur),
+                           c->hist_buf[cur ^ 1], c->hist_w + (cur ^ 1));
+        FXG_HIP(c, hipGetLastError());
+    } else {
+        const u32 S2 = in->stride + 2u;
+        const u32 ntiles = (u32)((in->n + T - 1) / T), nblk = (ntiles + FXG_HIST_BLOCK - 1) / FXG_HIST_BLOCK;
+        const size_t bM = (((size_t)ntiles * S2 * 4) + 255) & ~(size_t)255, bBT = (((size_t)nblk * S2 * 4) + 255) & ~(size_t)255;
+        const size_t bExt = (((size_t)in->n * estride + 16) + 255) & ~(size_t)255, bW = (((size_t)in->n * 2) + 255) & ~(size_t)255;
+        const size_t need = bM + bBT + bExt + bW;
+        if (c->hist_ws_cap < need) {
+            FXG_HIP(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(c->hist_ws);
+            c->hist_ws = nullptr; c->hist_ws_cap = 0;
+            FXG_HIP(c, hipMalloc((void **)&c->hist_ws, need + need / 8));
+            c->hist_ws_cap = need + need / 8;
+        }
+        FxgHist h;
+        h.bases = in->bases; h.len = in->len; h.fixed_len = in->fixed_len; h.stride = in->stride; h.n = in->n;
+        h.tile_reads = T; h.ntiles = ntiles;
+        h.M = (u32 *)c->hist_ws; h.BT = (u32 *)(c->hist_ws + bM);
+        h.ext = c->hist_ws + bM + bBT; h.estride = estride; h.wlen = (uint16_t *)(c->hist_ws + bM + bBT + bExt);
+        h.hist_in = c->hist_buf[cur]; h.w_in = c->hist_w + cur; h.hist_out = c->hist_buf[cur ^ 1]; h.w_out = c->hist_w + (cur ^ 1);
+        hipLaunchKernelGGL(fxg_kernel_hist_tiles, dim3(ntiles), dim3(FXG_BLOCK), 0, c->stream, h);
+        hipLaunchKernelGGL(fxg_kernel_hist_blocks, dim3(nblk), dim3(FXG_BLOCK), 0, c->stream, h);
+        hipLaunchKernelGGL(fxg_kernel_hist_top, dim3((S2 + FXG_BLOCK - 1) / FXG_BLOCK), dim3(FXG_BLOCK), 0, c->stream, h, nblk);
+        hipLaunchKernelGGL(fxg_kernel_hist_extend, dim3(ntiles), dim3(FXG_BLOCK), 0, c->stream, h);
+        FXG_HIP(c, hipGetLastError());
+        ka->clip_src = h.ext; ka->clip_stride = estride; ka->clip_total = (u64)in->n * estride; ka->wlen = h.wlen;
+        *use = 1;
+    }
+    c->hist_cur = cur ^ 1;
+    if (lmax > c->hist_wcap) c->hist_wcap = lmax;
+    return FXG_OK;
+}
+
 extern "C" int fxg_run_pipeline(fxg_ctx *c, const fxg_batch *in, const fxg_params *p, const fxg_out *out)
 {
     if (!c || !in || !p || !out) return FXG_E_INVALID;
     FxgPlan pl;
-    const int rc = fxg_make_plan(in, p, out, &pl, c->err, sizeof c->err);
+    // clip history: the DP may have to run over rows as wide as anything seen so far
+    const bool hist = c->hist_on && (p->stages & FXG_STAGE_CLIP) && in->n != 0;
+    const u32 estride = hist && c->hist_wcap > in->stride ? c->hist_wcap : in->stride;
+    const int rc = fxg_make_plan(in, p, out, &pl, c->err, sizeof c->err, hist ? estride : 0u);
     if (rc != FXG_OK) return rc;
     if (in->n == 0) {
         if (out->counters) FXG_HIP(c, hipMemsetAsync(out->counters, 0, FXG_NCOUNTERS * sizeof(u64), c->stream));
         return FXG_OK;
+    }
+    if (hist) {
+        int use = 0;
+        FXG_HIP(c, hipSetDevice(c->device));
+        const int hrc = fxg_hist_prepass(c, in, pl.ka.tile_reads, estride, &pl.ka, &use);
+        if (hrc != FXG_OK) return hrc;
+        if (!use) { pl.ka.clip_src = in->bases; pl.ka.clip_stride = in->stride; pl.ka.clip_total = in->n * (u64)in->stride; pl.ka.wlen = nullptr; pl.lds = fxg_plan_lds(&pl); }
     }
     u64 *ctr = (u64 *)out->counters;
 #define FXG_TILES_A(N) (fxg_kernel_tiles<N, 0>)

@@ -27,20 +27,20 @@ struct FxgLds {
     u32 has_tab;                                 // kernels that stage a tile of bases in LDS (clipper, census) spend no LDS on k_tab
 };
 __host__ __device__ inline u32 fxg_r16(u32 x) { return (x + 15u) & ~15u; }
-__host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, bool bitmaps, bool stage_bases)
+__host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, bool bitmaps, u32 stage_stride)   // stage_stride: row stride of the LDS copy of the tile's bases, 0 = none
 {
     FxgLds l;
     l.so_ksrc = fxg_r16((T + 1) * 4);
     l.so_kidx = l.so_ksrc + fxg_r16(T * 4);
     l.so_ktab = l.so_kidx + fxg_r16(T * 2);
-    l.has_tab = stage_bases ? 0u : 1u;
+    l.has_tab = stage_stride ? 0u : 1u;
     l.slot_bytes = l.so_ktab + (l.has_tab ? fxg_r16(((T * stride + 15) / 16 + 1) * 2) : 0u);
     u32 o = 2 * l.slot_bytes;
     l.off_scratch = o; o += fxg_r16(48 * 4);
     const u32 words = (T * stride + 31) / 32 + 2;
     l.off_bm_g = o;    o += bitmaps ? fxg_r16(words * 4) : 0;
     l.off_bm_l = o;    o += bitmaps ? fxg_r16(words * 4) : 0;
-    l.off_bases = o;   o += stage_bases ? fxg_r16(T * stride + 16) : 0;
+    l.off_bases = o;   o += stage_stride ? fxg_r16(T * stage_stride + 16) : 0;
     l.total = o;
     return l;
 }
@@ -80,7 +80,7 @@ FXG_HD void fxg_clip_finish(const FxgKArgs &a, int len, int qs, int ts, int mism
 // General form: w0 = query_start<<16 | target_start<<8 | mismatches, w1 = path_len<<16 | matches.
 // Every select is written as a ternary on values (no control flow) so that the cell is ~30 straight VALU ops.
 template <int AMAX>
-FXG_HD void fxg_clip_read(const FxgKArgs &a, const uint8_t *rd, int len,
+FXG_HD void fxg_clip_read(const FxgKArgs &a, const uint8_t *rd, int len, int rows,
                           u32 *out_len, u32 *keep, u32 *reason, u32 *clipped, u32 *adapter_only)
 {
     float S[AMAX];
@@ -95,10 +95,10 @@ FXG_HD void fxg_clip_read(const FxgKArgs &a, const uint8_t *rd, int len,
     u32 bw0 = FXG_INVALID_TUPLE, bw1 = 0u, bq = 0u;
     int first_n = len;
 #pragma unroll 1
-    for (int q = 0; q < len; ++q) {
+    for (int q = 0; q < rows; ++q) {                       // rows == len unless the stale tail of earlier reads is emulated
         const u32 c = rd[q];
         const bool qn = (c == (u32)'N');
-        first_n = (qn && first_n == len) ? q : first_n;
+        first_n = (qn && first_n == len && q < len) ? q : first_n;
         float dS = 0.0f, uS = 0.0f;                        // S[q-1][-1] and S[q][-1]: query_border = 0 (N1 for q == 0)
         u32 dW0 = FXG_INVALID_TUPLE, dW1 = 0u, uW0 = FXG_INVALID_TUPLE, uW1 = 0u;
 #pragma unroll
@@ -181,7 +181,7 @@ FXG_HD void fxg_clip_row_packed(const FxgKArgs &a, int A, u32 c, int q, float (&
 }
 
 template <int AMAX>
-FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len,
+FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len, int rows,
                                  u32 *out_len, u32 *keep, u32 *reason, u32 *clipped, u32 *adapter_only)
 {
     float S[AMAX];
@@ -192,18 +192,18 @@ FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len,
     float best = -1000000.0f;
     u32 bw = FXG_INVALID_TUPLE, bq = 0u;
     int first_n = len;
-    const int early_rows = (A - 4 < len) ? (A - 4 > 0 ? A - 4 : 0) : len;    // rows where "t - 3 > q" can still hold for some t < A
+    const int early_rows = (A - 4 < rows) ? (A - 4 > 0 ? A - 4 : 0) : rows;  // rows where "t - 3 > q" can still hold for some t < A
     int q = 0;
 #pragma unroll 1
     for (; q < early_rows; ++q) {
         const u32 c = rd[q];
-        first_n = (c == (u32)'N' && first_n == len) ? q : first_n;
+        first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
         fxg_clip_row_packed<AMAX, true>(a, A, c, q, S, W, best, bw, bq);
     }
 #pragma unroll 1
-    for (; q < len; ++q) {
+    for (; q < rows; ++q) {
         const u32 c = rd[q];
-        first_n = (c == (u32)'N' && first_n == len) ? q : first_n;
+        first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
         fxg_clip_row_packed<AMAX, false>(a, A, c, q, S, W, best, bw, bq);
     }
     fxg_clip_finish(a, len, (int)(bw >> 24), (int)((bw >> 19) & 31u), (int)((bw >> 14) & 31u), (int)(bw & 511u), (int)((bw >> 9) & 31u),
@@ -287,13 +287,21 @@ FXG_HD void fxg_phase_bitmaps(const FxgKArgs &a, u64 tb, u32 tbytes, u32 *bm_g, 
     }
 }
 
-// phase 1 (clipper only): bases rows of the tile -> LDS, so that one thread can walk one read
-FXG_HD void fxg_phase_stage_bases(const FxgKArgs &a, u64 tb, u32 tbytes, uint8_t *sb, u32 tid, u32 nthreads)
+// phase 1 (clipper, census): rows of the tile -> LDS, so that one thread can walk one read.  tb/tbytes/total are in bytes of `src`
+FXG_HD void fxg_phase_stage_bases(const uint8_t *src, u64 total, u64 tb, u32 tbytes, uint8_t *sb, u32 tid, u32 nthreads)
 {
     const u32 nchunks = (tbytes + 15u) >> 4;
     for (u32 c = tid; c < nchunks; c += nthreads) {
         const u32 o = c << 4;
-        const u32x4 v = fxg_window(a.bases, (long long)(tb + o), a.total_bytes, 0, (int)(tbytes - o < 16u ? tbytes - o : 16u));
+        const u64 at = tb + o;
+        u32x4 v;
+        if ((at & 15u) == 0u) v = fxg_window(src, (long long)at, total, 0, (int)(tbytes - o < 16u ? tbytes - o : 16u));
+        else {                                             // rows of an extended-query array need not start 16-byte aligned
+            u64 lo = 0, hi = 0;
+            const int nb = (int)(tbytes - o < 16u ? tbytes - o : 16u);
+            for (int i = 0; i < nb; ++i) { const u64 b = src[at + i]; if (i < 8) lo |= b << (8 * i); else hi |= b << (8 * (i - 8)); }
+            v = (u32x4){(u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32)};
+        }
         *reinterpret_cast<u32x4 *>(sb + o) = v;
     }
 }
@@ -307,8 +315,9 @@ FXG_HD void fxg_decide_a(const FxgKArgs &a, const u32 *bm_g, const u32 *bm_l, co
     const u32 stride = a.stride;
     const u32 rl = a.len ? (u32)a.len[r0 + tid] : a.fixed_len;
     u32 reason = FXG_R_KEPT, clipped = 0, keep = 1, curlen = rl, ao = 0;
-    if constexpr (AMAX > 0) fxg_clip_read<AMAX>(a, sb + tid * stride, (int)rl, &curlen, &keep, &reason, &clipped, &ao);
-    if constexpr (AMAX < 0) fxg_clip_read_packed<-AMAX>(a, sb + tid * stride, (int)rl, &curlen, &keep, &reason, &clipped, &ao);
+    const int rows = a.wlen ? (int)a.wlen[r0 + tid] : (int)rl;      // clip history: the DP also runs over the stale tail (fxg_history.h)
+    if constexpr (AMAX > 0) fxg_clip_read<AMAX>(a, sb + tid * a.clip_stride, (int)rl, rows, &curlen, &keep, &reason, &clipped, &ao);
+    if constexpr (AMAX < 0) fxg_clip_read_packed<-AMAX>(a, sb + tid * a.clip_stride, (int)rl, rows, &curlen, &keep, &reason, &clipped, &ao);
     if (keep && (a.stages & FXG_STAGE_QTRIM)) {             // fastq_quality_trimmer.c:94-101
         const u32 k = fxg_bits_last(bm_g, tid * stride, curlen);
         curlen = k;
@@ -402,7 +411,7 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void f
     constexpr bool REV = (MODE == 2);
     const u32 T = a.tile_reads, stride = a.stride, tid = threadIdx.x;
     const bool use_q = (MODE == 0 && (a.stages & (FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0) || MODE == 3;
-    const FxgLds L = fxg_lds_layout(T, stride, use_q, (MODE == 0 && AMAX != 0) || MODE == 4);
+    const FxgLds L = fxg_lds_layout(T, stride, use_q, (MODE == 0 && AMAX != 0) ? a.clip_stride : (MODE == 4 ? stride : 0u));
     u32 m_reads = 0, m_nt = 0, art_bad = 0;      // MODE 3 report counters / MODE 4 alphabet check, folded once at the end
     u32 *bm_g = reinterpret_cast<u32 *>(smem + L.off_bm_g);
     u32 *bm_l = reinterpret_cast<u32 *>(smem + L.off_bm_l);
@@ -437,7 +446,8 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void f
             const u32 tbytes = nreads * stride;
             if constexpr (MODE == 0 || MODE == 3 || MODE == 4) {
                 if (use_q && !FXG_DBG(a, 8u)) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, FXG_TBLOCK);
-                if constexpr ((MODE == 0 && AMAX != 0) || MODE == 4) fxg_phase_stage_bases(a, tb, tbytes, sb, tid, FXG_TBLOCK);
+                if constexpr (MODE == 0 && AMAX != 0) fxg_phase_stage_bases(a.clip_src, a.clip_total, (u64)r0 * a.clip_stride, nreads * a.clip_stride, sb, tid, FXG_TBLOCK);
+                if constexpr (MODE == 4) fxg_phase_stage_bases(a.bases, a.total_bytes, tb, tbytes, sb, tid, FXG_TBLOCK);
                 __syncthreads();
             }
             u32 keep = 0, olen = 0, anchor = tid * stride;

@@ -29,9 +29,18 @@ static inline u32 fxg_pick_tile(u32 stride, bool clip)
     return T;
 }
 
+static inline u32 fxg_plan_lds(const FxgPlan *pl)
+{
+    const FxgKArgs &ka = pl->ka;
+    return pl->group_a ? fxg_lds_layout(ka.tile_reads, ka.stride, pl->use_q, pl->clip ? ka.clip_stride : 0u).total
+         : pl->mask ? fxg_lds_layout(ka.tile_reads, ka.stride, true, 0u).total
+         : pl->artifacts ? fxg_lds_layout(ka.tile_reads, ka.stride, false, ka.stride).total : fxg_lds_layout(ka.tile_reads, ka.stride, false, 0u).total;
+}
+
 #define FXG_PLAN_FAIL(...) do { snprintf(err, cap, __VA_ARGS__); return FXG_E_INVALID; } while (0)
 
-static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const fxg_out *out, FxgPlan *pl, char *err, size_t cap)
+// clip_stride: row stride of the array the clipper's DP reads when it is not the batch itself (clip history), else 0
+static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const fxg_out *out, FxgPlan *pl, char *err, size_t cap, u32 clip_stride = 0)
 {
     const u32 st = p->stages;
     const bool ga = (st & (FXG_STAGE_CLIP | FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0;
@@ -53,6 +62,7 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     FxgKArgs &ka = pl->ka;
     memset(&ka, 0, sizeof ka);
     ka.bases = in->bases; ka.qual = in->qual; ka.len = in->len;
+    ka.clip_src = in->bases; ka.clip_stride = clip_stride ? clip_stride : in->stride; ka.clip_total = in->n * (u64)ka.clip_stride; ka.wlen = nullptr;
     ka.n = in->n; ka.total_bytes = in->n * (u64)in->stride;
     ka.fixed_len = in->fixed_len; ka.stride = in->stride;
     ka.res = out->res; ka.out_bases = out->out_bases; ka.out_qual = out->out_qual;
@@ -79,22 +89,20 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     pl->use_q = (st & (FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0;
     pl->rev = (st & FXG_STAGE_REVCOMP) != 0;
     if (pl->clip && (ka.alen < 1 || ka.alen > FXG_MAX_ADAPTER)) FXG_PLAN_FAIL("adapter length %d out of range", ka.alen);
-    if (pl->clip && in->stride > 65000u) FXG_PLAN_FAIL("clip: reads longer than 65000 are not supported");
+    if (pl->clip && ka.clip_stride > 65000u) FXG_PLAN_FAIL("clip: reads longer than 65000 are not supported");
     if ((st & FXG_STAGE_FTRIM) && p->ft_first < 1) FXG_PLAN_FAIL("-f must be >= 1");
     pl->amax = !pl->clip ? 0 : ka.alen <= 16 ? 16 : ka.alen <= 32 ? 32 : ka.alen <= 64 ? 64 : 100;
-    if (pl->clip && ka.alen <= 31 && in->stride <= 255u && !getenv("FXG_NO_PACKED_CLIP")) {
+    if (pl->clip && ka.alen <= 31 && ka.clip_stride <= 255u && !getenv("FXG_NO_PACKED_CLIP")) {
         // packed path summary (one u32 per cell); buckets are fine-grained because every padded column costs a full cell
         static const int pk[] = {4, 8, 9, 10, 11, 12, 13, 14, 15, 16, 20, 24, 28, 32};
         int b = 32;
         for (unsigned i = 0; i < sizeof pk / sizeof pk[0]; ++i) if (ka.alen <= pk[i]) { b = pk[i]; break; }
         pl->amax = -b;
     }
-    const u32 T = fxg_pick_tile(in->stride, pl->clip || gf);
+    const u32 T = fxg_pick_tile(pl->clip ? ka.clip_stride : in->stride, pl->clip || gf);
     const u64 ntiles = (in->n + T - 1) / T;
     if (ntiles > 0x7FFFFFFFull || in->n > 0xFFFFFFFFull) FXG_PLAN_FAIL("batch too large (%llu reads): split it", (unsigned long long)in->n);
     ka.tile_reads = T; ka.ntiles = (u32)ntiles;
-    pl->lds = ga ? fxg_lds_layout(T, in->stride, pl->use_q, pl->clip).total
-               : gm ? fxg_lds_layout(T, in->stride, true, false).total
-               : gf ? fxg_lds_layout(T, in->stride, false, true).total : fxg_lds_layout(T, in->stride, false, false).total;
+    pl->lds = fxg_plan_lds(pl);
     return FXG_OK;
 }

@@ -23,7 +23,7 @@ EXPORTS = [
     "fxg_device_info", "fxg_malloc_device", "fxg_free_device", "fxg_malloc_host", "fxg_free_host", "fxg_memcpy_h2d",
     "fxg_memcpy_d2h", "fxg_memset_device", "fxg_timer_start", "fxg_timer_stop", "fxg_run_pipeline",
     "fxg_run_qtrim_qfilter", "fxg_run_clip", "fxg_run_revcomp_trim", "fxg_read_counters", "fxg_synth_generate",
-    "fxg_last_launch_info", "fxg_set_profiling", "fxg_last_kernel_ms",
+    "fxg_last_launch_info", "fxg_set_profiling", "fxg_last_kernel_ms", "fxg_set_clip_history",
     "fxg_fastq_index", "fxg_fastq_pack", "fxg_fastq_format", "fxg_host_register", "fxg_host_unregister",
 ]
 
@@ -119,6 +119,7 @@ def load_library(path=None):
     L.fxg_host_register.argtypes = [vp, vp, C.c_size_t]
     L.fxg_host_unregister.argtypes = [vp, vp]
     L.fxg_set_profiling.argtypes = [vp, i32]
+    L.fxg_set_clip_history.argtypes = [vp, i32]
     L.fxg_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     if path is None:
         _LIB = L
@@ -218,6 +219,10 @@ class Engine:
         g, b, l, t = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
         self._check(self.lib.fxg_last_launch_info(self.ctx, name, 128, C.byref(g), C.byref(b), C.byref(l), C.byref(t)))
         return dict(kernel=name.value.decode(), grid=g.value, block=b.value, lds=l.value, tile_reads=t.value)
+
+    def set_clip_history(self, on=True):
+        """Reference-exact clipping of variable-length input: reads form one sequence across run() calls (fxg.h)."""
+        self._check(self.lib.fxg_set_clip_history(self.ctx, int(on)))
 
     def set_profiling(self, on=True):
         self._check(self.lib.fxg_set_profiling(self.ctx, int(on)))

@@ -597,6 +597,9 @@ int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *tot)
         if (rc != 0) errx(1, "no usable MI355X/HIP device (fxg_ctx_create = %d); this build has no CPU path", rc);
     }
     FXG_CHECK(&st, fxg_malloc_device(st.ctx, FXG_NCOUNTERS * sizeof(uint64_t), (void **)&st.d_counters));
+    /* one fastx_clipper process = one aligner whose query buffer survives from read to read (sequence_alignment.cpp:135-136,
+     * SURVEY N3): the engine reproduces that across the batches of this run */
+    if (p->stages & FXG_STAGE_CLIP) FXG_CHECK(&st, fxg_set_clip_history(st.ctx, 1));
     t_init = fxh_now() - t_init;
     struct fxh_reader *rd = fx->reader;
     if (!getenv("FXH_READ_BUFFER_MB")) fxh_reader_reserve(rd, (size_t)64 << 20);   /* one engine call per 64 MB of text */

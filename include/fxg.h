@@ -244,6 +244,16 @@ int  fxg_fastq_format(fxg_ctx *ctx, const uint8_t *d_text, const uint32_t *d_lin
 int  fxg_host_register(fxg_ctx *ctx, void *ptr, size_t bytes);     /* page-lock an existing host buffer for async copies */
 int  fxg_host_unregister(fxg_ctx *ctx, void *ptr);
 
+/* fastx_clipper on variable-length input.  The reference aligner keeps ONE query buffer and one matrix for the whole run: the
+ * matrix never shrinks (sequence_alignment.cpp:135-136), every loop runs to the width of the longest read so far (:157, :375,
+ * sequence_alignment.h:109), and set_sequences assigns each read into the same std::string -- so a read shorter than an earlier
+ * one is aligned together with the stale tail that earlier reads left behind it, and can be clipped or discarded because of
+ * it.  With history on (on != 0; the call also resets the buffer to that of a fresh process) the CLIP stage
+ * reproduces this: the reads of a batch, and of successive fxg_run_* calls on this context, form one sequence in call order.
+ * Off (the default), every read is aligned on its own, which is identical for input of one fixed length.  Sharding a
+ * variable-length clipper job over several contexts is only exact with history off on both sides. */
+int  fxg_set_clip_history(fxg_ctx *ctx, int on);
+
 /* Kernel-level timing: when enabled, every fxg_run_pipeline brackets its dominant kernel (not the
  * memset / counter-reduce helpers) with HIP events on the launch stream; fxg_last_kernel_ms waits for
  * that launch and returns its duration. */

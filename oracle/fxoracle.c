@@ -284,7 +284,7 @@ static int fxo_comp(uint8_t c)  /* fastx_reverse_complement.c:43-72 */
     }
 }
 
-int fxo_run_pipeline(const fxo_batch *in, const fxo_params *p, fxo_out *out)
+int fxo_run_pipeline_h(const fxo_batch *in, const fxo_params *p, fxo_out *out, fxo_aligner *shared)
 {
     const uint32_t st = p->stages;
     const int group_a = (st & (FXO_STAGE_CLIP | FXO_STAGE_QTRIM | FXO_STAGE_QFILTER)) != 0;
@@ -296,7 +296,8 @@ int fxo_run_pipeline(const fxo_batch *in, const fxo_params *p, fxo_out *out)
     if ((st & (FXO_STAGE_QTRIM | FXO_STAGE_QFILTER)) && !in->qual) return -1;
 
     memset(out->counters, 0, sizeof out->counters);
-    fxo_aligner *al = (st & FXO_STAGE_CLIP) ? fxo_aligner_new() : NULL;
+    /* shared: the caller's aligner, i.e. one fastx_clipper process working through several batches (N3 history) */
+    fxo_aligner *al = shared ? shared : ((st & FXO_STAGE_CLIP) ? fxo_aligner_new() : NULL);
     const int alen = (int)strnlen(p->adapter, sizeof p->adapter);
     uint64_t kept = 0, obytes = 0;
     uint8_t *tmpb = (uint8_t *)malloc(70000), *tmpq = (uint8_t *)malloc(70000);
@@ -420,7 +421,7 @@ int fxo_run_pipeline(const fxo_batch *in, const fxo_params *p, fxo_out *out)
     out->counters[FXO_C_KEPT_BASES] = obytes;
 done:
     free(tmpb); free(tmpq);
-    fxo_aligner_free(al);
+    if (!shared) fxo_aligner_free(al);
     return rc;
 }
 
@@ -510,3 +511,5 @@ size_t fxo_format_fastq(const char *text, const uint64_t *name_off, const uint32
     }
     return w;
 }
+
+int fxo_run_pipeline(const fxo_batch *in, const fxo_params *p, fxo_out *out) { return fxo_run_pipeline_h(in, p, out, NULL); }

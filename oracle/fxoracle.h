@@ -157,6 +157,8 @@ int          fxo_adapter_cutoff_index(const fxo_align_res *r, int min_adapter_le
 /* ---- batch pipeline: supported chains are [CLIP][QTRIM][QFILTER], [REVCOMP][FTRIM|FTRIM_END], [MASK], [ARTIFACTS] ---- */
 /* returns 0, or -1 on unsupported stage combination, -2 on invalid base for REVCOMP */
 int fxo_run_pipeline(const fxo_batch *in, const fxo_params *p, fxo_out *out);
+/* same, with the caller's aligner: successive batches of ONE clipper run share its query buffer and matrix (N3) */
+int fxo_run_pipeline_h(const fxo_batch *in, const fxo_params *p, fxo_out *out, fxo_aligner *shared);
 
 /* ---- FASTQ text <-> SoA (reader rules R1-R9, writer a3), ASCII qualities only ---- */
 /* Parses up to max_reads records from text; fills rows; names[] gets offsets into text of each '@' line.

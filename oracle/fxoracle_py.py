@@ -83,6 +83,7 @@ def lib():
         L.fxo_synth_fastq.restype = C.c_size_t
         L.fxo_synth_fastq.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p]
         L.fxo_run_pipeline.argtypes = [C.POINTER(Batch), C.POINTER(Params), C.POINTER(Out)]
+        L.fxo_run_pipeline_h.argtypes = [C.POINTER(Batch), C.POINTER(Params), C.POINTER(Out), C.c_void_p]
         L.fxo_aligner_new.restype = C.c_void_p
         L.fxo_aligner_free.argtypes = [C.c_void_p]
         L.fxo_align.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(AlignRes)]
@@ -120,7 +121,16 @@ def synth_fastq(seed, first, n, L, with_adapter=False):
     return buf.raw[:sz]
 
 
-def run_pipeline(bases, qual, lens, params, fixed_len=None):
+def aligner_new():
+    """One reference aligner = one fastx_clipper process (its query buffer survives from batch to batch, N3)."""
+    return lib().fxo_aligner_new()
+
+
+def aligner_free(a):
+    lib().fxo_aligner_free(a)
+
+
+def run_pipeline(bases, qual, lens, params, fixed_len=None, aligner=None):
     """bases/qual: uint8 [n, stride]; lens: uint16 [n] or None (then fixed_len). Returns a dict of numpy arrays."""
     n, stride = bases.shape
     assert bases.flags.c_contiguous and (qual is None or qual.flags.c_contiguous)
@@ -133,7 +143,7 @@ def run_pipeline(bases, qual, lens, params, fixed_len=None):
     ol = np.zeros(n, dtype=np.uint16)
     ki = np.zeros(n, dtype=np.uint32)
     o = Out(_ptr(res), _ptr(ob), _ptr(oq), _ptr(ol), _ptr(ki))
-    rc = lib().fxo_run_pipeline(C.byref(b), C.byref(params), C.byref(o))
+    rc = lib().fxo_run_pipeline_h(C.byref(b), C.byref(params), C.byref(o), aligner)
     if rc != 0:
         raise ValueError("fxo_run_pipeline rc=%d" % rc)
     counters = np.array(list(o.counters), dtype=np.uint64)

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../fastx_toolkit_amd/csrc/fxg_plan.h"
+#include "../../fastx_toolkit_amd/csrc/fxg_history.h"
 
 template <int AMAX, bool REV, int MODE = 0>
 static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
@@ -18,7 +19,7 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
     const u32 T = a.tile_reads, stride = a.stride, NT = FXG_TBLOCK;
     std::vector<unsigned char> lds(pl.lds + 64, 0);
     unsigned char *smem = lds.data();
-    const FxgLds L = pl.group_a ? fxg_lds_layout(T, stride, pl.use_q, pl.clip) : fxg_lds_layout(T, stride, MODE == 3, MODE == 4);
+    const FxgLds L = pl.group_a ? fxg_lds_layout(T, stride, pl.use_q, pl.clip ? a.clip_stride : 0u) : fxg_lds_layout(T, stride, MODE == 3, MODE == 4 ? stride : 0u);
     u64 m_reads = 0, m_nt = 0;
     u32 *k_off = reinterpret_cast<u32 *>(smem);
     u32 *k_src = reinterpret_cast<u32 *>(smem + L.so_ksrc);
@@ -39,7 +40,7 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
         if (pl.group_a) {
             for (u32 tid = 0; tid < NT; ++tid) {
                 if (pl.use_q) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, NT);
-                if constexpr (AMAX != 0) fxg_phase_stage_bases(a, tb, tbytes, sb, tid, NT);
+                if constexpr (AMAX != 0) fxg_phase_stage_bases(a.clip_src, a.clip_total, (u64)r0 * a.clip_stride, nreads * a.clip_stride, sb, tid, NT);
             }
             for (u32 tid = 0; tid < nreads; ++tid) {
                 fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid]);
@@ -53,7 +54,7 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
                 anchor[tid] = tid * stride; m_nt += nl; m_reads += (nl != 0u);
             }
         } else if (MODE == 4) {
-            for (u32 tid = 0; tid < NT; ++tid) fxg_phase_stage_bases(a, tb, tbytes, sb, tid, NT);
+            for (u32 tid = 0; tid < NT; ++tid) fxg_phase_stage_bases(a.bases, a.total_bytes, tb, tbytes, sb, tid, NT);
             for (u32 tid = 0; tid < nreads; ++tid) { fxg_decide_census(a, sb + tid * stride, r0, tid, &keep[tid], &olen[tid], &bad); anchor[tid] = tid * stride; }
         } else {
             for (u32 tid = 0; tid < nreads; ++tid) fxg_decide_b<REV>(a, r0, tid, &keep[tid], &olen[tid], &anchor[tid]);
@@ -83,12 +84,70 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
     return FXG_OK;
 }
 
-extern "C" int fxg_emu_run_pipeline(const fxg_batch *in, const fxg_params *p, const fxg_out *out, char *err, size_t cap)
+// clip history (fxg_history.h): the same per-column bodies the pre-pass kernels run, serially
+struct fxg_emu_hist {
+    std::vector<uint8_t> buf[2];
+    u32 w[2];
+    int cur;
+    u32 wcap;
+    std::vector<u32> M, BT;
+    std::vector<uint8_t> ext;
+    std::vector<uint16_t> wlen;
+};
+extern "C" fxg_emu_hist *fxg_emu_hist_new(void)
+{
+    fxg_emu_hist *h = new fxg_emu_hist();
+    h->buf[0].assign(FXG_HIST_CAP, 0); h->buf[1].assign(FXG_HIST_CAP, 0);
+    h->w[0] = h->w[1] = 0; h->cur = 0; h->wcap = 0;
+    return h;
+}
+extern "C" void fxg_emu_hist_free(fxg_emu_hist *h) { delete h; }
+
+static void emu_hist_prepass(fxg_emu_hist *hs, const fxg_batch *in, u32 T, u32 estride, FxgKArgs *ka, int *use)
+{
+    const u32 lmax = in->len ? in->stride : in->fixed_len;
+    const int cur = hs->cur;
+    *use = 0;
+    if (!in->len && hs->wcap <= in->fixed_len) {
+        const u32 L = in->fixed_len;
+        for (u32 x = 0; x < FXG_HIST_CAP; ++x)
+            hs->buf[cur ^ 1][x] = x < L ? in->bases[(in->n - 1u) * in->stride + x] : (x == L ? (uint8_t)0 : hs->buf[cur][x]);
+        hs->w[cur ^ 1] = hs->w[cur] > L ? hs->w[cur] : L;
+    } else {
+        const u32 S2 = in->stride + 2u;
+        const u32 ntiles = (u32)((in->n + T - 1) / T), nblk = (ntiles + FXG_HIST_BLOCK - 1) / FXG_HIST_BLOCK;
+        hs->M.assign((size_t)ntiles * S2, 0); hs->BT.assign((size_t)nblk * S2, 0);
+        hs->ext.assign((size_t)in->n * estride + 16, 0xEE); hs->wlen.assign(in->n, 0);
+        FxgHist h;
+        h.bases = in->bases; h.len = in->len; h.fixed_len = in->fixed_len; h.stride = in->stride; h.n = in->n;
+        h.tile_reads = T; h.ntiles = ntiles; h.M = hs->M.data(); h.BT = hs->BT.data();
+        h.ext = hs->ext.data(); h.estride = estride; h.wlen = hs->wlen.data();
+        h.hist_in = hs->buf[cur].data(); h.w_in = &hs->w[cur]; h.hist_out = hs->buf[cur ^ 1].data(); h.w_out = &hs->w[cur ^ 1];
+        for (u32 t = 0; t < ntiles; ++t) for (u32 x = 0; x < S2; ++x) fxg_hist_tile_column(h, t, x);
+        for (u32 b = 0; b < nblk; ++b) for (u32 x = 0; x < S2; ++x) fxg_hist_block_column(h, b, x);
+        for (u32 x = 0; x < S2; ++x) fxg_hist_top_column(h, nblk, x);
+        const u32 ncol = fxg_hist_columns(h);
+        for (u32 t = 0; t < ntiles; ++t) for (u32 x = 0; x < ncol; ++x) fxg_hist_extend_column(h, t, x);
+        ka->clip_src = h.ext; ka->clip_stride = estride; ka->clip_total = (u64)in->n * estride; ka->wlen = h.wlen;
+        *use = 1;
+    }
+    hs->cur = cur ^ 1;
+    if (lmax > hs->wcap) hs->wcap = lmax;
+}
+
+extern "C" int fxg_emu_run_pipeline_hist(const fxg_batch *in, const fxg_params *p, const fxg_out *out, char *err, size_t cap, fxg_emu_hist *hs)
 {
     FxgPlan pl;
-    const int rc = fxg_make_plan(in, p, out, &pl, err, cap);
+    const bool hist = hs && (p->stages & FXG_STAGE_CLIP) && in->n != 0;
+    const u32 estride = hist && hs->wcap > in->stride ? hs->wcap : in->stride;
+    const int rc = fxg_make_plan(in, p, out, &pl, err, cap, hist ? estride : 0u);
     if (rc != FXG_OK) return rc;
     if (in->n == 0) return FXG_OK;
+    if (hist) {
+        int use = 0;
+        emu_hist_prepass(hs, in, pl.ka.tile_reads, estride, &pl.ka, &use);
+        if (!use) { pl.ka.clip_src = in->bases; pl.ka.clip_stride = in->stride; pl.ka.clip_total = in->n * (u64)in->stride; pl.ka.wlen = nullptr; pl.lds = fxg_plan_lds(&pl); }
+    }
     uint64_t *ctr = out->counters;
     if (pl.group_a) {
         switch (pl.amax) {
@@ -116,6 +175,11 @@ extern "C" int fxg_emu_run_pipeline(const fxg_batch *in, const fxg_params *p, co
     if (pl.mask) return emu_run<0, false, 3>(pl, ctr, err, cap);
     if (pl.artifacts) return emu_run<0, false, 4>(pl, ctr, err, cap);
     return pl.rev ? emu_run<0, true>(pl, ctr, err, cap) : emu_run<0, false>(pl, ctr, err, cap);
+}
+
+extern "C" int fxg_emu_run_pipeline(const fxg_batch *in, const fxg_params *p, const fxg_out *out, char *err, size_t cap)
+{
+    return fxg_emu_run_pipeline_hist(in, p, out, err, cap, nullptr);
 }
 
 extern "C" unsigned fxg_emu_tile_reads(unsigned stride, int clip) { return fxg_pick_tile(stride, clip != 0); }

@@ -9,14 +9,18 @@
 
 #include "../../include/fxg.h"
 
-extern "C" int fxg_emu_run_pipeline(const fxg_batch *in, const fxg_params *p, const fxg_out *out, char *err, size_t cap);
+struct fxg_emu_hist;
+extern "C" int fxg_emu_run_pipeline_hist(const fxg_batch *in, const fxg_params *p, const fxg_out *out, char *err, size_t cap, fxg_emu_hist *h);
+extern "C" fxg_emu_hist *fxg_emu_hist_new(void);
+extern "C" void fxg_emu_hist_free(fxg_emu_hist *h);
 
-struct fxg_ctx { char err[512]; uint64_t scratch[FXG_NCOUNTERS]; };
+struct fxg_ctx { char err[512]; uint64_t scratch[FXG_NCOUNTERS]; fxg_emu_hist *hist; };
 
 extern "C" {
 int fxg_abi_version(void) { return FXG_ABI_VERSION; }
 int fxg_ctx_create(int, fxg_ctx **out) { *out = (fxg_ctx *)calloc(1, sizeof(fxg_ctx)); return *out ? 0 : FXG_E_NOMEM; }
-void fxg_ctx_destroy(fxg_ctx *c) { free(c); }
+void fxg_ctx_destroy(fxg_ctx *c) { if (c) fxg_emu_hist_free(c->hist); free(c); }
+int fxg_set_clip_history(fxg_ctx *c, int on) { fxg_emu_hist_free(c->hist); c->hist = on ? fxg_emu_hist_new() : nullptr; return 0; }
 const char *fxg_last_error(const fxg_ctx *c) { return c ? c->err : "null"; }
 int fxg_set_stream(fxg_ctx *, void *) { return 0; }
 int fxg_sync(fxg_ctx *) { return 0; }
@@ -35,7 +39,7 @@ int fxg_run_pipeline(fxg_ctx *c, const fxg_batch *in, const fxg_params *p, const
 {
     fxg_out o = *out;
     if (!o.counters) o.counters = c->scratch;
-    return fxg_emu_run_pipeline(in, p, &o, c->err, sizeof c->err);
+    return fxg_emu_run_pipeline_hist(in, p, &o, c->err, sizeof c->err, c->hist);
 }
 int fxg_run_qtrim_qfilter(fxg_ctx *, const fxg_batch *, int, int, int, int, int, int, int, const fxg_out *) { return FXG_E_INVALID; }
 int fxg_run_clip(fxg_ctx *, const fxg_batch *, const char *, uint32_t, int, int, uint32_t, const fxg_out *) { return FXG_E_INVALID; }

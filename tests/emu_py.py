@@ -39,6 +39,9 @@ def lib():
         _LIB = C.CDLL(build())
         _LIB.fxg_emu_run_pipeline.argtypes = [C.POINTER(Batch), C.c_void_p, C.POINTER(Out), C.c_char_p, C.c_size_t]
         _LIB.fxg_emu_tile_reads.restype = C.c_uint
+        _LIB.fxg_emu_run_pipeline_hist.argtypes = [C.POINTER(Batch), C.c_void_p, C.POINTER(Out), C.c_char_p, C.c_size_t, C.c_void_p]
+        _LIB.fxg_emu_hist_new.restype = C.c_void_p
+        _LIB.fxg_emu_hist_free.argtypes = [C.c_void_p]
     return _LIB
 
 
@@ -50,7 +53,15 @@ def _aligned(n, dtype=np.uint8):
     return raw[off:off + n * item].view(dtype)
 
 
-def run_pipeline(bases, qual, lens, params, fixed_len=None, compact=True):
+def hist_new():
+    return lib().fxg_emu_hist_new()
+
+
+def hist_free(h):
+    lib().fxg_emu_hist_free(h)
+
+
+def run_pipeline(bases, qual, lens, params, fixed_len=None, compact=True, hist=None):
     n, stride = bases.shape
     b = _aligned(n * stride); b[:] = bases.reshape(-1)
     q = None
@@ -67,7 +78,7 @@ def run_pipeline(bases, qual, lens, params, fixed_len=None, compact=True):
     o = Out(res.ctypes.data, ob.ctypes.data if compact else None, oq.ctypes.data if (compact and q is not None) else None,
             ol.ctypes.data, ki.ctypes.data, oo.ctypes.data, ctr.ctypes.data)
     err = C.create_string_buffer(512)
-    rc = lib().fxg_emu_run_pipeline(C.byref(bt), C.addressof(params), C.byref(o), err, 512)
+    rc = lib().fxg_emu_run_pipeline_hist(C.byref(bt), C.addressof(params), C.byref(o), err, 512, hist)
     if rc != 0:
         raise ValueError("emu rc=%d: %s" % (rc, err.value.decode()))
     kept, nbytes = int(ctr[1]), int(ctr[2])

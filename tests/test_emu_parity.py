@@ -52,3 +52,29 @@ def test_emulated_decision_only_and_bad_base():
     assert int(e["counters"][15]) & 2          # fastx_reverse_complement.c:67-68
     e = emu.run_pipeline(b2, q, None, oracle_params(dict(stages=16, ft_first=2)))
     assert int(e["counters"][15]) == 0         # the fixed trimmer never looks at the alphabet
+
+
+def test_emulated_clip_history_across_batches():
+    """N3: the pre-pass that rebuilds the reference aligner's stale query tail, against the oracle's shared aligner."""
+    from helpers import random_batch
+    rng = np.random.default_rng(5)
+    ad = b"AGATCGGAAGAGC"
+    differs = 0
+    for trial in range(24):
+        stride = int(rng.choice([20, 36, 50, 75, 100, 151, 300]))
+        al, hs = fo.aligner_new(), emu.hist_new()
+        for batch in range(3):
+            n = int(rng.integers(1, 900))
+            st = stride if batch != 1 else max(5, stride // 2)          # a later batch narrower than the buffer
+            b, q, lens = random_batch(rng, n, st, 1, st, False, adapter=ad)
+            p = oracle_params(dict(stages=1 if trial % 2 else 7, adapter=ad if trial % 4 else ad * 3, clip_min_len=int(rng.integers(0, 10)),
+                                   clip_flags=int(rng.integers(0, 16)), qt_threshold=20, qt_min_len=5, qf_min_quality=10, qf_min_percent=30))
+            use_len = None if (batch == 2 and trial % 3 == 0) else lens  # a fixed-length batch after ragged ones still sees the tail
+            fl = st if use_len is None else None
+            o = fo.run_pipeline(b, q, use_len, p, fixed_len=fl, aligner=al)
+            e = emu.run_pipeline(b, q, use_len, p, fixed_len=fl, hist=hs)
+            assert_same(o, e, "hist.t%d.b%d" % (trial, batch))
+            differs += int((emu.run_pipeline(b, q, use_len, p, fixed_len=fl)["res"] != o["res"]).sum())
+        fo.aligner_free(al)
+        emu.hist_free(hs)
+    assert differs > 1000          # reads aligned on their own would have come out differently

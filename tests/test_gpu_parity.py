@@ -54,13 +54,40 @@ def test_variable_length_inputs(engine, cases):
     import os
     from helpers import GOLDEN
     for c in cases["varlen"]:
-        if c["name"] == "var_clip_history":
-            continue   # note N3: the reference clipper is history dependent on ragged input; engine contract = fixed length
         text = open(os.path.join(GOLDEN, "synthetic", c["name"] + ".fq"), "rb").read()
         exp = open(os.path.join(GOLDEN, "synthetic", c["name"] + ".out"), "rb").read()
         p = fo.parse_fastq(text)
+        engine.set_clip_history(c["name"] == "var_clip_history")   # note N3: the reference clipper is history dependent on ragged input
         e = _run(engine, p["bases"], p["qual"], p["lens"], c["params"])
+        engine.set_clip_history(False)
         assert fo.format_fastq(text, p["names"], e["out_bases"], e["out_qual"], e["out_len"], e["kept_index"]) == exp, c["name"]
+
+
+def test_clip_history_across_batches(engine):
+    """N3: one aligner per run -- ragged batches, a batch with a smaller stride, a fixed-length batch -- vs the oracle's shared aligner."""
+    import numpy as np
+    from helpers import random_batch
+    rng = np.random.default_rng(5)
+    ad = b"AGATCGGAAGAGC"
+    differs = 0
+    for trial in range(12):
+        stride = int(rng.choice([20, 36, 50, 75, 100, 151, 300]))
+        al = fo.aligner_new()
+        engine.set_clip_history(True)
+        for batch in range(3):
+            n = int(rng.integers(1, 3000))
+            st = stride if batch != 1 else max(5, stride // 2)
+            b, q, lens = random_batch(rng, n, st, 1, st, False, adapter=ad)
+            pd = dict(stages=1, adapter=ad if trial % 4 else ad * 3, clip_min_len=int(rng.integers(0, 10)), clip_flags=int(rng.integers(0, 16)))
+            use_len = None if (batch == 2 and trial % 3 == 0) else lens
+            fl = st if use_len is None else None
+            o = fo.run_pipeline(b, q, use_len, oracle_params(pd), fixed_len=fl, aligner=al)
+            e = _run(engine, b, q, use_len, pd, fixed_len=fl)
+            assert_same(o, e, "hist.t%d.b%d" % (trial, batch))
+            differs += int((fo.run_pipeline(b, q, use_len, oracle_params(pd), fixed_len=fl)["res"] != o["res"]).sum())
+        fo.aligner_free(al)
+        engine.set_clip_history(False)
+    assert differs > 100          # the history really mattered on this data
 
 
 def test_fuzz_vs_oracle(engine):
