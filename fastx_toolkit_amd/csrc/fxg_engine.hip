@@ -9,6 +9,7 @@
 #include "fxg_plan.h"
 #include "fxg_text.h"
 #include "fxg_history.h"
+#include "fxg_stats.h"
 
 struct fxg_ctx {
     int device;
@@ -356,6 +357,39 @@ extern "C" int fxg_run_pipeline(fxg_ctx *c, const fxg_batch *in, const fxg_param
     if (pl.rev) return fxg_launch_tiles(c, fxg_kernel_tiles<0, 2>, "fxg_kernel_tiles<0,2> revcomp[+ftrim]", pl.ka, pl.lds, ctr);
     return fxg_launch_tiles(c, fxg_kernel_tiles<0, 1>, "fxg_kernel_tiles<0,1> ftrim", pl.ka, pl.lds, ctr);
 #undef FXG_TILES_A
+}
+
+extern "C" int fxg_run_quality_stats(fxg_ctx *c, const fxg_batch *in, uint64_t *d_hist, uint32_t hist_cols)
+{
+    if (!c || !in || !d_hist) return FXG_E_INVALID;
+    if (!in->bases || in->stride == 0 || in->stride > FXG_MAX_READ_LEN || (!in->len && (in->fixed_len == 0 || in->fixed_len > in->stride)))
+        return fxg_fail(c, FXG_E_INVALID, "quality_stats: bad batch (stride %u, fixed_len %u)", in->stride, in->fixed_len);
+    if (hist_cols < in->stride) return fxg_fail(c, FXG_E_INVALID, "quality_stats: histogram has %u columns, batch stride is %u", hist_cols, in->stride);
+    if (in->n == 0) return FXG_OK;
+    FXG_HIP(c, hipSetDevice(c->device));
+    FxgStatsArgs a;
+    a.bases = in->bases; a.qual = in->qual; a.len = in->len; a.n = in->n; a.total_bytes = in->n * (u64)in->stride;
+    a.fixed_len = in->fixed_len; a.stride = in->stride; a.hist = (u64 *)d_hist; a.hist_cols = hist_cols;
+    a.nstrips = (in->stride + FXG_QS_STRIP - 1) / FXG_QS_STRIP;
+    // enough chunks to fill the chip a few times over, but few enough that the global flush (10 240 atomics per workgroup) stays small
+    u64 chunks = ((u64)c->cus * 8 + a.nstrips - 1) / a.nstrips;
+    if (chunks < 1) chunks = 1;
+    u64 rpc = (in->n + chunks - 1) / chunks;
+    if (rpc < 4096) rpc = 4096;
+    if (rpc > 0x40000000ull) rpc = 0x40000000ull;
+    a.reads_per_chunk = (u32)rpc;
+    chunks = (in->n + rpc - 1) / rpc;
+    chunks = (chunks + 7) / 8 * 8;                          // XCD-major launch order (fxg_kernel_quality_stats); surplus workgroups exit
+    if (chunks * a.nstrips > 0x7FFFFFFFull) return fxg_fail(c, FXG_E_INVALID, "quality_stats: batch too large");
+    const u32 lds = FXG_QS_LDS_WORDS * sizeof(u32);
+    FXG_HIP(c, hipFuncSetAttribute((const void *)fxg_kernel_quality_stats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (c->profiling) FXG_HIP(c, hipEventRecord(c->kev0, c->stream));
+    hipLaunchKernelGGL(fxg_kernel_quality_stats, dim3((u32)(chunks * a.nstrips)), dim3(FXG_BLOCK), lds, c->stream, a);
+    FXG_HIP(c, hipGetLastError());
+    if (c->profiling) { FXG_HIP(c, hipEventRecord(c->kev1, c->stream)); c->kev_valid = 1; }
+    snprintf(c->last_kernel, sizeof c->last_kernel, "fxg_kernel_quality_stats");
+    c->last_grid = (u32)(chunks * a.nstrips); c->last_block = FXG_BLOCK; c->last_lds = lds; c->last_tile = a.reads_per_chunk;
+    return FXG_OK;
 }
 
 static void fxg_params_default(fxg_params *p)

@@ -23,7 +23,7 @@ EXPORTS = [
     "fxg_device_info", "fxg_malloc_device", "fxg_free_device", "fxg_malloc_host", "fxg_free_host", "fxg_memcpy_h2d",
     "fxg_memcpy_d2h", "fxg_memset_device", "fxg_timer_start", "fxg_timer_stop", "fxg_run_pipeline",
     "fxg_run_qtrim_qfilter", "fxg_run_clip", "fxg_run_revcomp_trim", "fxg_read_counters", "fxg_synth_generate",
-    "fxg_last_launch_info", "fxg_set_profiling", "fxg_last_kernel_ms", "fxg_set_clip_history",
+    "fxg_last_launch_info", "fxg_set_profiling", "fxg_last_kernel_ms", "fxg_set_clip_history", "fxg_run_quality_stats",
     "fxg_fastq_index", "fxg_fastq_pack", "fxg_fastq_format", "fxg_host_register", "fxg_host_unregister",
 ]
 
@@ -120,6 +120,7 @@ def load_library(path=None):
     L.fxg_host_unregister.argtypes = [vp, vp]
     L.fxg_set_profiling.argtypes = [vp, i32]
     L.fxg_set_clip_history.argtypes = [vp, i32]
+    L.fxg_run_quality_stats.argtypes = [vp, C.POINTER(FxgBatch), vp, C.c_uint32]
     L.fxg_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     if path is None:
         _LIB = L
@@ -219,6 +220,20 @@ class Engine:
         g, b, l, t = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
         self._check(self.lib.fxg_last_launch_info(self.ctx, name, 128, C.byref(g), C.byref(b), C.byref(l), C.byref(t)))
         return dict(kernel=name.value.decode(), grid=g.value, block=b.value, lds=l.value, tile_reads=t.value)
+
+    def quality_stats(self, bases, qual, lens=None, fixed_len=None, hist=None, cols=None, sync=True):
+        """fastx_quality_stats: adds the batch to hist[cols][5][128] (int64 device tensor, created zeroed when None) and returns it.
+        sync=False leaves the kernel in flight on the engine's stream (call sync() before torch reads the tensor)."""
+        n, stride = bases.shape
+        if hist is None:
+            hist = self.torch.zeros((cols or stride, 5, 128), dtype=self.torch.int64, device=self.device)
+            self.torch.cuda.current_stream(self.device).synchronize()   # the fill ran on torch's stream; the engine may be on its own
+        b = FxgBatch(bases.data_ptr(), qual.data_ptr() if qual is not None else None,
+                     lens.data_ptr() if lens is not None else None, int(fixed_len or stride), stride, n)
+        self._check(self.lib.fxg_run_quality_stats(self.ctx, C.byref(b), hist.data_ptr(), hist.shape[0]))
+        if sync:
+            self.sync()
+        return hist
 
     def set_clip_history(self, on=True):
         """Reference-exact clipping of variable-length input: reads form one sequence across run() calls (fxg.h)."""

@@ -584,7 +584,35 @@ static int fxh_block_gpu_text(FASTX *fx, fxh_state *st, const fxg_params *p, fxh
     return 1;
 }
 
-int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *tot)
+/* fastx_quality_stats mode of the run loop: batches feed fxg_run_quality_stats instead of the pipeline, nothing is written */
+typedef struct fxh_stats_run {
+    uint64_t *d_hist;
+    uint32_t cols;
+} fxh_stats_run;
+
+static void fxh_stats_reserve(fxh_state *st, fxh_stats_run *sr, uint32_t need_cols)
+{
+    if (need_cols <= sr->cols) return;
+    uint32_t ncols = sr->cols ? sr->cols * 2 : 256;
+    while (ncols < need_cols) ncols *= 2;
+    const size_t per_col = (size_t)FXG_QS_CLASSES * FXG_QS_BINS * sizeof(uint64_t);
+    uint64_t *nh = NULL;
+    FXG_CHECK(st, fxg_malloc_device(st->ctx, (size_t)ncols * per_col, (void **)&nh));
+    FXG_CHECK(st, fxg_memset_device(st->ctx, nh, 0, (size_t)ncols * per_col));
+    if (sr->d_hist) {                       /* a later block has longer reads: carry the columns over (rare, via the host) */
+        void *tmp = malloc((size_t)sr->cols * per_col);
+        if (!tmp) err(1, "out of memory");
+        FXG_CHECK(st, fxg_memcpy_d2h(st->ctx, tmp, sr->d_hist, (size_t)sr->cols * per_col));
+        FXG_CHECK(st, fxg_sync(st->ctx));
+        FXG_CHECK(st, fxg_memcpy_h2d(st->ctx, nh, tmp, (size_t)sr->cols * per_col));
+        FXG_CHECK(st, fxg_sync(st->ctx));
+        free(tmp);
+        fxg_free_device(st->ctx, sr->d_hist);
+    }
+    sr->d_hist = nh; sr->cols = ncols;
+}
+
+static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_stats_run *stats, uint64_t **hist_out, uint32_t *cols_out)
 {
     fxh_state st;
     memset(&st, 0, sizeof st);
@@ -638,7 +666,7 @@ int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *tot)
     size_t wr_spare_cap = 0;
     const int overlap = getenv("FXH_NO_OVERLAP") == NULL;
     /* device-side parse/format for FASTQ; FXH_HOST_PARSE=1 forces the host parser */
-    const int gpu_text = fx->read_fastq && fx->write_fastq && !g_rename_ids && getenv("FXH_HOST_PARSE") == NULL;
+    const int gpu_text = !stats && fx->read_fastq && fx->write_fastq && !g_rename_ids && getenv("FXH_HOST_PARSE") == NULL;
     unsigned long n_fallback = 0;
 
     while (!at_eof && !have_err) {
@@ -749,6 +777,15 @@ int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *tot)
             if (job.has_q) FXG_CHECK(&st, fxg_memcpy_h2d(st.ctx, st.d_qual, st.h_qual, bytes));
             if (!fixed) FXG_CHECK(&st, fxg_memcpy_h2d(st.ctx, st.d_len, st.h_len, n * sizeof(uint16_t)));
             fxg_batch in = {st.d_bases, job.has_q ? st.d_qual : NULL, fixed ? NULL : st.d_len, (uint32_t)maxlen, stride, n};
+            if (stats) {                            /* fastx_quality_stats: reduce, nothing to write */
+                fxh_stats_reserve(&st, stats, stride);
+                FXG_CHECK(&st, fxg_run_quality_stats(st.ctx, &in, stats->d_hist, stats->cols));
+                FXG_CHECK(&st, fxg_sync(st.ctx));
+                tot->input_sequences += n; tot->input_reads += n;
+                fx->num_input_sequences = tot->input_sequences; fx->num_input_reads = tot->input_reads;
+                t_gpu += fxh_now() - t0;
+                continue;
+            }
             fxg_out out = {st.d_res, job.revcomp ? st.d_out_bases : NULL, (job.revcomp && job.has_q) ? st.d_out_qual : NULL, NULL, NULL, NULL, st.d_counters};
             fxg_params pp = *p;
             pp.qoffset = 33;                        /* rows hold Phred+33 codes whatever -Q was */
@@ -799,8 +836,18 @@ int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *tot)
     fxh_awriter_stop(&aw);
     fxh_prefetch_stop(&pf);
     if (have_err) {
-        fxh_writer_flush(fx->writer);   /* every record before the bad one has been written, like the reference */
+        if (!stats) fxh_writer_flush(fx->writer);   /* every record before the bad one has been written, like the reference */
         errx(1, "%s", errmsg);
+    }
+    if (stats) {
+        const size_t per_col = (size_t)FXG_QS_CLASSES * FXG_QS_BINS * sizeof(uint64_t);
+        *cols_out = stats->cols;
+        *hist_out = (uint64_t *)calloc(stats->cols ? stats->cols : 1, per_col);
+        if (!*hist_out) err(1, "out of memory");
+        if (stats->d_hist) {
+            FXG_CHECK(&st, fxg_memcpy_d2h(st.ctx, *hist_out, stats->d_hist, (size_t)stats->cols * per_col));
+            FXG_CHECK(&st, fxg_sync(st.ctx));
+        }
     }
     if (timing)
         fprintf(stderr, "fxh timing (%d threads, %s parse, %lu host-parsed blocks): init %.3f read %.3f index %.3f pack %.3f gpu(h2d+kernel+d2h) %.3f format+write %.3f s\n",
@@ -809,4 +856,14 @@ int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *tot)
     for (int i = 0; i < job.nworkers; ++i) { free(job.w[i].rec); free(job.w[i].shadow); }
     free(job.w);
     return 0;
+}
+
+int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *tot) { return fxh_run_impl(fx, p, tot, NULL, NULL, NULL); }
+
+int fxh_run_quality_stats(FASTX *fx, uint64_t **hist, uint32_t *cols, fxh_totals *tot)
+{
+    fxg_params p;
+    fxh_stats_run sr = {NULL, 0};
+    fxh_default_params(&p, fx->fastq_ascii_quality_offset);
+    return fxh_run_impl(fx, &p, tot, &sr, hist, cols);
 }

@@ -33,6 +33,11 @@ typedef struct fxh_totals {
  * inside fastx_read_next_record).  Returns 0. */
 int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *totals);
 
+/* fastx_quality_stats over the whole FASTQ input of `fx` (reader initialised, no writer needed): the per-column histogram of
+ * include/fxg.h's fxg_run_quality_stats summed over all batches, copied to a malloc'ed array hist[cols][FXG_QS_CLASSES][FXG_QS_BINS]
+ * whose bin index is quality value + 33 whatever -Q was.  Malformed input ends the process like fxh_run_tool. */
+int fxh_run_quality_stats(FASTX *fx, uint64_t **hist, uint32_t *cols, fxh_totals *totals);
+
 /* fastq_to_fasta -r: kept records are renamed to their 1-based output index (fastq_to_fasta.c:83-84).  Set before fxh_run_tool. */
 void fxh_set_rename_ids(int on);
 

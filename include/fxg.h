@@ -244,6 +244,15 @@ int  fxg_fastq_format(fxg_ctx *ctx, const uint8_t *d_text, const uint32_t *d_lin
 int  fxg_host_register(fxg_ctx *ctx, void *ptr, size_t bytes);     /* page-lock an existing host buffer for async copies */
 int  fxg_host_unregister(fxg_ctx *ctx, void *ptr);
 
+/* fastx_quality_stats (src/fastx_quality_stats/fastx_quality_stats.c:166-216, read_file): adds the batch to
+ *     d_hist[column][class][byte]      uint64, hist_cols x FXG_QS_CLASSES x FXG_QS_BINS, hist_cols >= batch stride
+ * = how many reads have a base of class A,C,G,T,N (0..4) at that column with that quality byte (the byte stored in `qual`,
+ * i.e. quality value + the offset the rows were packed with; 0 when the batch has no qualities).  Count, sum, min, max and
+ * the quartiles the tool prints (:218-340) are functions of this histogram.  The caller zeroes d_hist before the first batch. */
+#define FXG_QS_CLASSES 5
+#define FXG_QS_BINS 128
+int  fxg_run_quality_stats(fxg_ctx *ctx, const fxg_batch *in, uint64_t *d_hist, uint32_t hist_cols);
+
 /* fastx_clipper on variable-length input.  The reference aligner keeps ONE query buffer and one matrix for the whole run: the
  * matrix never shrinks (sequence_alignment.cpp:135-136), every loop runs to the width of the longest read so far (:157, :375,
  * sequence_alignment.h:109), and set_sequences assigns each read into the same std::string -- so a read shorter than an earlier

@@ -513,3 +513,142 @@ size_t fxo_format_fastq(const char *text, const uint64_t *name_off, const uint32
 }
 
 int fxo_run_pipeline(const fxo_batch *in, const fxo_params *p, fxo_out *out) { return fxo_run_pipeline_h(in, p, out, NULL); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* fastx_quality_stats -- src/fastx_quality_stats/fastx_quality_stats.c                         */
+/* ------------------------------------------------------------------------------------------ */
+struct fxo_nucdata {            /* struct nucleotide_data, :115-127 */
+    int min, max, count;
+    unsigned long long sum;
+    int values[FXO_QS_RANGE + 1];   /* +1: quality 93 indexes one past the reference's array (N2); parity is defined below that */
+};
+struct fxo_qstats {
+    struct fxo_nucdata (*cycles)[6];   /* [column][ALL,A,C,G,T,N], :130-133 */
+    int ncols;
+    int sequences;
+};
+
+static void fxo_qstats_grow(fxo_qstats *s, int ncols)
+{
+    if (ncols <= s->ncols) return;
+    s->cycles = (struct fxo_nucdata (*)[6])realloc(s->cycles, (size_t)ncols * sizeof *s->cycles);
+    for (int i = s->ncols; i < ncols; ++i)
+        for (int j = 0; j < 6; ++j) {                     /* init_values, :138-163 */
+            memset(&s->cycles[i][j], 0, sizeof s->cycles[i][j]);
+            s->cycles[i][j].min = 100; s->cycles[i][j].max = -100;
+        }
+    s->ncols = ncols;
+}
+
+fxo_qstats *fxo_qstats_new(void) { return (fxo_qstats *)calloc(1, sizeof(fxo_qstats)); }
+void fxo_qstats_free(fxo_qstats *s) { if (s) { free(s->cycles); free(s); } }
+
+static int fxo_nuc_index(int c)   /* nuc_to_index, :142-155: anything else maps to 0 = ALL */
+{
+    switch (c) {
+    case 'A': case 'a': return 1; case 'C': case 'c': return 2; case 'G': case 'g': return 3;
+    case 'T': case 't': return 4; case 'N': case 'n': return 5; default: return 0;
+    }
+}
+
+void fxo_qstats_add(fxo_qstats *s, const fxo_batch *in, int qoffset)
+{
+    fxo_qstats_grow(s, (int)in->stride);
+    for (uint64_t r = 0; r < in->n; ++r) {
+        const uint8_t *b = in->bases + r * in->stride;
+        const uint8_t *q = in->qual ? in->qual + r * in->stride : NULL;
+        const int len = in->len ? in->len[r] : (int)in->fixed_len;
+        const int reads_count = 1;                        /* get_reads_count(): 1 unless a collapsed FASTA name says otherwise */
+        for (int i = 0; i < len; ++i) {                   /* :179-207 */
+            const int k = fxo_nuc_index(b[i]);
+            s->cycles[i][0].count += reads_count;
+            s->cycles[i][k].count += reads_count;
+            if (q) {
+                const int v = (int)q[i] - qoffset;
+                struct fxo_nucdata *d[2] = { &s->cycles[i][0], &s->cycles[i][k] };
+                for (int t = 0; t < 2; ++t) {
+                    if (v < d[t]->min) d[t]->min = v;
+                    if (v > d[t]->max) d[t]->max = v;
+                    d[t]->sum += (unsigned long long)(long long)v;
+                    d[t]->values[v - FXO_QS_MINQ] += reads_count;
+                }
+            }
+        }
+        s->sequences++;
+    }
+}
+
+static int fxo_qs_nth(const fxo_qstats *s, int cycle, int nuc, int n)   /* get_nth_value, :218-247 */
+{
+    const struct fxo_nucdata *d = &s->cycles[cycle][nuc];
+    if (n == 0) return d->min;
+    int pos = 0;
+    while (n > 0) {
+        if (d->values[pos] > n) break;
+        n -= d->values[pos];
+        pos++;
+        while (pos < FXO_QS_RANGE && d->values[pos] == 0) pos++;
+    }
+    return pos + FXO_QS_MINQ;
+}
+
+static void fxo_qs_box(const fxo_qstats *s, int c, int nuc, int *Q1, int *med, int *Q3, int *IQR, int *lw, int *rw)   /* :276-291, :357-372 */
+{
+    const struct fxo_nucdata *d = &s->cycles[c][nuc];
+    *Q1 = fxo_qs_nth(s, c, nuc, d->count / 4);
+    *Q3 = fxo_qs_nth(s, c, nuc, d->count * 3 / 4);
+    *med = fxo_qs_nth(s, c, nuc, d->count / 2);
+    *IQR = *Q3 - *Q1;
+    *lw = (*Q1 - *IQR * 3 / 2) < d->min ? d->min : (*Q1 - *IQR * 3 / 2);
+    *rw = (*Q3 + *IQR * 3 / 2) > d->max ? d->max : (*Q3 + *IQR * 3 / 2);
+}
+
+#define FXO_EMIT(...) do { int k__ = snprintf(dst ? dst + w : NULL, dst ? (size_t)1 << 20 : 0, __VA_ARGS__); w += (size_t)k__; } while (0)
+
+size_t fxo_qstats_format(const fxo_qstats *s, int new_format, char *dst)
+{
+    size_t w = 0;
+    static const char *nuc_name[6] = {"ALL", "A", "C", "G", "T", "N"};
+    static const char *hdr[] = {"count", "min", "max", "sum", "mean", "Q1", "med", "Q3", "IQR", "lW", "rW"};
+    int Q1, med, Q3, IQR, lw, rw;
+    if (new_format) {                                                  /* print_statistics, :296-334 */
+        FXO_EMIT("cycle\tmax_count");
+        for (int n = 0; n < 6; ++n) for (int h = 0; h < 11; ++h) FXO_EMIT("\t%s_%s", nuc_name[n], hdr[h]);
+        FXO_EMIT("\n");
+        const int max_count = s->ncols ? s->cycles[0][0].count : 0;
+        for (int c = 0; c < s->ncols; ++c) {
+            if (s->cycles[c][0].count == 0) break;
+            FXO_EMIT("%d\t%d", c + 1, max_count);
+            for (int n = 0; n < 6; ++n) {                              /* print_nucleotide_statistics, :271-294 */
+                const struct fxo_nucdata *d = &s->cycles[c][n];
+                fxo_qs_box(s, c, n, &Q1, &med, &Q3, &IQR, &lw, &rw);
+                FXO_EMIT("\t%d\t%d\t%d\t%lld\t", d->count, d->min, d->max, (long long)d->sum);
+                FXO_EMIT("%3.2f\t%d\t%d\t%d\t", ((double)d->sum) / ((double)d->count), Q1, med, Q3);
+                FXO_EMIT("%d\t%d\t%d", IQR, lw, rw);
+            }
+            FXO_EMIT("\n");
+        }
+        return w;
+    }
+    FXO_EMIT("column\tcount\tmin\tmax\tsum\tmean\tQ1\tmed\tQ3\tIQR\tlW\trW\tA_Count\tC_Count\tG_Count\tT_Count\tN_Count\tMax_count\n");   /* :347-352 */
+    for (int c = 0; c < s->ncols; ++c) {
+        const struct fxo_nucdata *d = &s->cycles[c][0];
+        if (d->count == 0) break;
+        fxo_qs_box(s, c, 0, &Q1, &med, &Q3, &IQR, &lw, &rw);
+        FXO_EMIT("%d\t", c + 1);
+        FXO_EMIT("%d\t%d\t%d\t%lld\t", d->count, d->min, d->max, (long long)d->sum);
+        FXO_EMIT("%3.2f\t%d\t%d\t%d\t", ((double)d->sum) / ((double)d->count), Q1, med, Q3);
+        FXO_EMIT("%d\t%d\t%d\t", IQR, lw, rw);
+        FXO_EMIT("%d\t%d\t%d\t%d\t%d\t", s->cycles[c][1].count, s->cycles[c][2].count, s->cycles[c][3].count, s->cycles[c][4].count, s->cycles[c][5].count);
+        FXO_EMIT("%d\n", s->cycles[0][0].count);
+    }
+    return w;
+}
+
+long long fxo_qstats_hist(const fxo_qstats *s, int col, int cls, int hist[FXO_QS_RANGE])
+{
+    memset(hist, 0, FXO_QS_RANGE * sizeof(int));
+    if (col >= s->ncols) return 0;
+    memcpy(hist, s->cycles[col][cls].values, FXO_QS_RANGE * sizeof(int));
+    return s->cycles[col][cls].count;
+}

@@ -160,6 +160,19 @@ int fxo_run_pipeline(const fxo_batch *in, const fxo_params *p, fxo_out *out);
 /* same, with the caller's aligner: successive batches of ONE clipper run share its query buffer and matrix (N3) */
 int fxo_run_pipeline_h(const fxo_batch *in, const fxo_params *p, fxo_out *out, fxo_aligner *shared);
 
+/* ---- fastx_quality_stats (src/fastx_quality_stats/fastx_quality_stats.c) ---- */
+#define FXO_QS_MINQ   (-15)   /* fastx.h:28 MIN_QUALITY_VALUE */
+#define FXO_QS_RANGE  108     /* fastx.h:30 QUALITY_VALUES_RANGE */
+typedef struct fxo_qstats fxo_qstats;
+fxo_qstats *fxo_qstats_new(void);
+void        fxo_qstats_free(fxo_qstats *s);
+/* read_file (:166-216) over a batch; qual rows hold quality value + qoffset; qual == NULL = FASTA (counts only) */
+void        fxo_qstats_add(fxo_qstats *s, const fxo_batch *in, int qoffset);
+/* print_old_statistics (:340-414) / print_statistics (:296-334); dst == NULL returns the size only */
+size_t      fxo_qstats_format(const fxo_qstats *s, int new_format, char *dst);
+/* counts of nucleotide class cls (0 ALL, 1 A, 2 C, 3 G, 4 T, 5 N) at column col, by quality value - FXO_QS_MINQ; returns the class count */
+long long   fxo_qstats_hist(const fxo_qstats *s, int col, int cls, int hist[FXO_QS_RANGE]);
+
 /* ---- FASTQ text <-> SoA (reader rules R1-R9, writer a3), ASCII qualities only ---- */
 /* Parses up to max_reads records from text; fills rows; names[] gets offsets into text of each '@' line.
  * Returns number of records, or -(line number) on the first invalid record. */

@@ -92,6 +92,13 @@ def lib():
         L.fxo_parse_fastq.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_uint64, C.c_uint32] + [C.c_void_p] * 7
         L.fxo_format_fastq.restype = C.c_size_t
         L.fxo_format_fastq.argtypes = [C.c_char_p] + [C.c_void_p] * 8 + [C.c_uint64, C.c_void_p]
+        L.fxo_qstats_new.restype = C.c_void_p
+        L.fxo_qstats_free.argtypes = [C.c_void_p]
+        L.fxo_qstats_add.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_int]
+        L.fxo_qstats_format.restype = C.c_size_t
+        L.fxo_qstats_format.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.fxo_qstats_hist.restype = C.c_longlong
+        L.fxo_qstats_hist.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -189,3 +196,43 @@ def format_fastq(text, names, out_bases, out_qual, out_len, kept_index):
     ki = np.ascontiguousarray(kept_index, dtype=np.uint32)
     w = lib().fxo_format_fastq(text, _ptr(no), _ptr(nl), _ptr(n2o), _ptr(n2l), _ptr(ob), _ptr(oq), _ptr(ol), _ptr(ki), kept, dst)
     return dst.raw[:w]
+
+
+QS_MINQ, QS_RANGE = -15, 108
+
+
+class QStats:
+    """fastx_quality_stats restated: add() batches, then text() / hist()."""
+
+    def __init__(self):
+        self.h = lib().fxo_qstats_new()
+
+    def close(self):
+        if self.h:
+            lib().fxo_qstats_free(self.h)
+            self.h = None
+
+    def add(self, bases, qual, lens, qoffset=33, fixed_len=None):
+        n, stride = bases.shape
+        if lens is not None:
+            lens = np.ascontiguousarray(lens, dtype=np.uint16)
+        b = Batch(_ptr(bases), _ptr(qual), _ptr(lens), int(fixed_len or stride), stride, n)
+        lib().fxo_qstats_add(self.h, C.byref(b), qoffset)
+
+    def text(self, new_format=False):
+        sz = lib().fxo_qstats_format(self.h, int(new_format), None)
+        buf = C.create_string_buffer(sz + 1)
+        lib().fxo_qstats_format(self.h, int(new_format), buf)
+        return buf.raw[:sz]
+
+    def device_layout(self, ncols, qoffset=33, classes=5, bins=128):
+        """hist[col][A,C,G,T,N][quality byte] as include/fxg.h's fxg_run_quality_stats defines it."""
+        out = np.zeros((ncols, classes, bins), dtype=np.uint64)
+        h = (C.c_int * QS_RANGE)()
+        for c in range(ncols):
+            for k in range(classes):
+                lib().fxo_qstats_hist(self.h, c, k + 1, h)
+                for v in range(QS_RANGE):
+                    if h[v]:
+                        out[c, k, v + QS_MINQ + qoffset] = h[v]
+        return out

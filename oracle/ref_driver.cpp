@@ -11,7 +11,7 @@
  * reference's own object code.
  *
  * usage:  fxref <tool> [tool flags]      tool = fastq_quality_trimmer | fastq_quality_filter | fastx_clipper | fastx_trimmer |
- *                                               fastx_reverse_complement | fastq_masker | fastx_artifacts_filter
+ *                                               fastx_reverse_complement | fastq_masker | fastx_artifacts_filter | fastq_to_fasta | fastx_quality_stats
  */
 #include <err.h>
 #include <cstdio>
@@ -364,6 +364,98 @@ static int run_align(int argc, char **argv)
     return 0;
 }
 
+
+/* ---- fastx_quality_stats.c:115-463 (struct nucleotide_data, read_file, get_nth_value, both print functions) ---- */
+struct qs_nuc { int min, max, count; unsigned long long sum; int values[QUALITY_VALUES_RANGE]; };
+static std::vector<qs_nuc> qs_cycles;       /* [column * 6 + nucleotide]; the reference has a static [MAX_SEQ_LINE_LENGTH][6] */
+static int qs_new_format = 0;
+static qs_nuc &qs_at(size_t col, int nuc)
+{
+    const size_t need = (col + 1) * 6;
+    while (qs_cycles.size() < need) { qs_nuc z; memset(&z, 0, sizeof z); z.min = 100; z.max = -100; qs_cycles.push_back(z); }   /* init_values :158-163 */
+    return qs_cycles[col * 6 + (size_t)nuc];
+}
+static int qs_nuc_index(int c)              /* :142-155 */
+{
+    switch (c) { case 'A': case 'a': return 1; case 'C': case 'c': return 2; case 'G': case 'g': return 3;
+                 case 'T': case 't': return 4; case 'N': case 'n': return 5; default: return 0; }
+}
+static int qs_nth(size_t col, int nuc, int n)   /* :218-247 */
+{
+    const qs_nuc &d = qs_at(col, nuc);
+    if (n == 0) return d.min;
+    if (n < 0 || n >= d.count) { fprintf(stderr, "Internal error at get_nth_value\n"); exit(1); }
+    int pos = 0;
+    while (n > 0) {
+        if (d.values[pos] > n) break;
+        n -= d.values[pos];
+        pos++;
+        while (d.values[pos] == 0) pos++;
+    }
+    return pos + MIN_QUALITY_VALUE;
+}
+static void qs_print_nuc(FILE *o, size_t col, int nuc, bool old_layout)   /* :271-294 and :357-392 */
+{
+    const qs_nuc &d = qs_at(col, nuc);
+    const int Q1 = qs_nth(col, nuc, d.count / 4), Q3 = qs_nth(col, nuc, d.count * 3 / 4), IQR = Q3 - Q1;
+    const int lw = (Q1 - IQR * 3 / 2) < d.min ? d.min : (Q1 - IQR * 3 / 2);
+    const int rw = (Q3 + IQR * 3 / 2) > d.max ? d.max : (Q3 + IQR * 3 / 2);
+    fprintf(o, old_layout ? "%d\t%d\t%d\t%lld\t" : "\t%d\t%d\t%d\t%lld\t", d.count, d.min, d.max, (long long)d.sum);
+    fprintf(o, "%3.2f\t%d\t%d\t%d\t", ((double)d.sum) / ((double)d.count), Q1, qs_nth(col, nuc, d.count / 2), Q3);
+    fprintf(o, old_layout ? "%d\t%d\t%d\t" : "%d\t%d\t%d", IQR, lw, rw);
+}
+static int qs_args(int, int c, char *) { if (c == 'N') qs_new_format = 1; else errx(1, "Unknown argument (%c)", c); return 1; }
+static int run_quality_stats(int argc, char **argv)
+{
+    fastx_parse_cmdline(argc, argv, "N", qs_args);                                  /* :426-441 */
+    fastx_init_reader(&fx, get_input_filename(), FASTA_OR_FASTQ, ALLOW_N, REQUIRE_UPPERCASE, get_fastq_ascii_quality_offset());
+    FILE *o = stdout;
+    if (strcmp(get_output_filename(), "-") != 0) { o = fopen(get_output_filename(), "w+"); if (!o) err(1, "Failed to create output file (%s)", get_output_filename()); }
+    while (fastx_read_next_record(&fx)) {                                           /* read_file :166-216 */
+        const size_t L = strlen(fx.nucleotides);
+        for (size_t i = 0; i < L; ++i) {
+            const int k = qs_nuc_index(fx.nucleotides[i]);
+            const int rc = get_reads_count(&fx);
+            qs_at(i, 0).count += rc; qs_at(i, k).count += rc;
+            if (fx.read_fastq) {
+                const int v = fx.quality[i];
+                qs_nuc *d[2] = { &qs_at(i, 0), &qs_at(i, k) };
+                for (int t = 0; t < 2; ++t) {
+                    if (v < d[t]->min) d[t]->min = v;
+                    if (v > d[t]->max) d[t]->max = v;
+                    d[t]->sum += v;
+                    d[t]->values[v - MIN_QUALITY_VALUE] += rc;
+                }
+            }
+        }
+    }
+    const size_t ncols = qs_cycles.size() / 6;
+    if (qs_new_format) {                                                            /* print_statistics :296-334 */
+        static const char *nn[6] = {"ALL", "A", "C", "G", "T", "N"};
+        static const char *hd[11] = {"count", "min", "max", "sum", "mean", "Q1", "med", "Q3", "IQR", "lW", "rW"};
+        fprintf(o, "cycle\tmax_count");
+        for (int n = 0; n < 6; ++n) for (int h = 0; h < 11; ++h) fprintf(o, "\t%s_%s", nn[n], hd[h]);
+        fprintf(o, "\n");
+        const int max_count = ncols ? qs_at(0, 0).count : 0;
+        for (size_t c = 0; c < ncols; ++c) {
+            if (qs_at(c, 0).count == 0) break;
+            fprintf(o, "%d\t%d", (int)c + 1, max_count);
+            for (int n = 0; n < 6; ++n) qs_print_nuc(o, c, n, false);
+            fprintf(o, "\n");
+        }
+    } else {                                                                        /* print_old_statistics :340-414 */
+        fprintf(o, "column\tcount\tmin\tmax\tsum\tmean\tQ1\tmed\tQ3\tIQR\tlW\trW\tA_Count\tC_Count\tG_Count\tT_Count\tN_Count\tMax_count\n");
+        for (size_t c = 0; c < ncols; ++c) {
+            if (qs_at(c, 0).count == 0) break;
+            fprintf(o, "%d\t", (int)c + 1);
+            qs_print_nuc(o, c, 0, true);
+            fprintf(o, "%d\t%d\t%d\t%d\t%d\t", qs_at(c, 1).count, qs_at(c, 2).count, qs_at(c, 3).count, qs_at(c, 4).count, qs_at(c, 5).count);
+            fprintf(o, "%d\n", qs_at(0, 0).count);
+        }
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) { fputs(usage, stderr); return 2; }
@@ -377,6 +469,7 @@ int main(int argc, char **argv)
     if (!strcmp(tool, "fastq_to_fasta")) return run_fastq_to_fasta(argc, argv);
     if (!strcmp(tool, "fastq_masker")) return run_masker(argc, argv);
     if (!strcmp(tool, "fastx_artifacts_filter")) return run_artifacts(argc, argv);
+    if (!strcmp(tool, "fastx_quality_stats")) return run_quality_stats(argc, argv);
     if (!strcmp(tool, "align")) return run_align(argc, argv);
     fputs(usage, stderr);
     return 2;

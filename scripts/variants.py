@@ -14,11 +14,9 @@ sys.path.insert(0, ROOT)
 from fastx_toolkit_amd import build as _b  # noqa: E402
 
 VARIANTS = {
-    "base": [],
-    "w6": ["-DFXG_MIN_WAVES=6"],
-    "w8": ["-DFXG_MIN_WAVES=8"],
-    "nonts": ["-DFXG_V_NO_NTS"],
-    "w8nonts": ["-DFXG_MIN_WAVES=8", "-DFXG_V_NO_NTS"],
+    "plain": ["-DFXG_QS_TEST_PLAIN"],
+    "none": ["-DFXG_QS_TEST_NONE"],
+    "norot": ["-DFXG_QS_NOROT"],
 }
 
 

@@ -11,6 +11,7 @@
 
 #include "../../fastx_toolkit_amd/csrc/fxg_plan.h"
 #include "../../fastx_toolkit_amd/csrc/fxg_history.h"
+#include "../../fastx_toolkit_amd/csrc/fxg_stats.h"
 
 template <int AMAX, bool REV, int MODE = 0>
 static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
@@ -183,3 +184,29 @@ extern "C" int fxg_emu_run_pipeline(const fxg_batch *in, const fxg_params *p, co
 }
 
 extern "C" unsigned fxg_emu_tile_reads(unsigned stride, int clip) { return fxg_pick_tile(stride, clip != 0); }
+
+// fastx_quality_stats: the strip bodies of fxg_kernel_quality_stats, one "workgroup" after the other
+extern "C" int fxg_emu_run_quality_stats(const fxg_batch *in, uint64_t *hist, uint32_t hist_cols)
+{
+    if (!in || !hist || !in->bases || in->stride == 0 || hist_cols < in->stride) return FXG_E_INVALID;
+    if (in->n == 0) return FXG_OK;
+    FxgStatsArgs a;
+    a.bases = in->bases; a.qual = in->qual; a.len = in->len; a.n = in->n; a.total_bytes = in->n * (u64)in->stride;
+    a.fixed_len = in->fixed_len; a.stride = in->stride; a.hist = (u64 *)hist; a.hist_cols = hist_cols;
+    a.nstrips = (in->stride + FXG_QS_STRIP - 1) / FXG_QS_STRIP;
+    a.reads_per_chunk = 1000;
+    std::vector<u32> h(FXG_QS_LDS_WORDS);
+    const u64 chunks = (in->n + a.reads_per_chunk - 1) / a.reads_per_chunk;
+    for (u64 c = 0; c < chunks; ++c)
+        for (u32 s = 0; s < a.nstrips; ++s) {
+            std::fill(h.begin(), h.end(), 0u);
+            const u64 lo = c * a.reads_per_chunk, hi = lo + a.reads_per_chunk < a.n ? lo + a.reads_per_chunk : a.n;
+            for (u64 r = lo; r < hi; ++r) fxg_stats_read_strip(a, r, s, (u32)((r - lo) % FXG_BLOCK), h.data());
+            for (u32 i = 0; i < FXG_QS_STRIP * FXG_QS_CLASSES * FXG_QS_BINS; ++i) {
+                const u32 row = i / FXG_QS_BINS, bin = i % FXG_QS_BINS, v = h[row * FXG_QS_ROW + bin];
+                const u32 col = s * FXG_QS_STRIP + row / FXG_QS_CLASSES;
+                if (v && col < hist_cols) a.hist[((u64)col * FXG_QS_CLASSES + row % FXG_QS_CLASSES) * FXG_QS_BINS + bin] += v;
+            }
+        }
+    return FXG_OK;
+}

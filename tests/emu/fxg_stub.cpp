@@ -12,6 +12,7 @@
 struct fxg_emu_hist;
 extern "C" int fxg_emu_run_pipeline_hist(const fxg_batch *in, const fxg_params *p, const fxg_out *out, char *err, size_t cap, fxg_emu_hist *h);
 extern "C" fxg_emu_hist *fxg_emu_hist_new(void);
+extern "C" int fxg_emu_run_quality_stats(const fxg_batch *in, uint64_t *hist, uint32_t hist_cols);
 extern "C" void fxg_emu_hist_free(fxg_emu_hist *h);
 
 struct fxg_ctx { char err[512]; uint64_t scratch[FXG_NCOUNTERS]; fxg_emu_hist *hist; };
@@ -41,6 +42,7 @@ int fxg_run_pipeline(fxg_ctx *c, const fxg_batch *in, const fxg_params *p, const
     if (!o.counters) o.counters = c->scratch;
     return fxg_emu_run_pipeline_hist(in, p, &o, c->err, sizeof c->err, c->hist);
 }
+int fxg_run_quality_stats(fxg_ctx *, const fxg_batch *in, uint64_t *h, uint32_t cols) { return fxg_emu_run_quality_stats(in, h, cols); }
 int fxg_run_qtrim_qfilter(fxg_ctx *, const fxg_batch *, int, int, int, int, int, int, int, const fxg_out *) { return FXG_E_INVALID; }
 int fxg_run_clip(fxg_ctx *, const fxg_batch *, const char *, uint32_t, int, int, uint32_t, const fxg_out *) { return FXG_E_INVALID; }
 int fxg_run_revcomp_trim(fxg_ctx *, const fxg_batch *, int, int, int, const fxg_out *) { return FXG_E_INVALID; }

@@ -42,6 +42,7 @@ def lib():
         _LIB.fxg_emu_run_pipeline_hist.argtypes = [C.POINTER(Batch), C.c_void_p, C.POINTER(Out), C.c_char_p, C.c_size_t, C.c_void_p]
         _LIB.fxg_emu_hist_new.restype = C.c_void_p
         _LIB.fxg_emu_hist_free.argtypes = [C.c_void_p]
+        _LIB.fxg_emu_run_quality_stats.argtypes = [C.POINTER(Batch), C.c_void_p, C.c_uint32]
     return _LIB
 
 
@@ -84,3 +85,23 @@ def run_pipeline(bases, qual, lens, params, fixed_len=None, compact=True, hist=N
     kept, nbytes = int(ctr[1]), int(ctr[2])
     return dict(res=res, out_bases=ob[:nbytes].copy(), out_qual=oq[:nbytes].copy() if q is not None else None,
                 out_len=ol[:kept], kept_index=ki[:kept], out_off=oo[:kept], counters=ctr)
+
+
+def run_quality_stats(bases, qual, lens, fixed_len=None, hist=None, cols=None):
+    """Adds the batch to hist[cols][5][128] (uint64) and returns it."""
+    n, stride = bases.shape
+    cols = cols or stride
+    if hist is None:
+        hist = np.zeros((cols, 5, 128), dtype=np.uint64)
+    b = _aligned(n * stride); b[:] = bases.reshape(-1)
+    q = None
+    if qual is not None:
+        q = _aligned(n * stride); q[:] = qual.reshape(-1)
+    if lens is not None:
+        lens = np.ascontiguousarray(lens, dtype=np.uint16)
+    bt = Batch(b.ctypes.data, q.ctypes.data if q is not None else None, lens.ctypes.data if lens is not None else None,
+               int(fixed_len or stride), stride, n)
+    rc = lib().fxg_emu_run_quality_stats(C.byref(bt), hist.ctypes.data, hist.shape[0])
+    if rc != 0:
+        raise ValueError("emu quality_stats rc=%d" % rc)
+    return hist

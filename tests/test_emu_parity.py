@@ -78,3 +78,29 @@ def test_emulated_clip_history_across_batches():
         fo.aligner_free(al)
         emu.hist_free(hs)
     assert differs > 1000          # reads aligned on their own would have come out differently
+
+
+def test_emulated_quality_stats_histogram():
+    """fastx_quality_stats: the strip bodies of the reduction kernel against the oracle's per-cycle records, two batches of different width."""
+    import ctypes as C
+    from helpers import random_batch
+    rng = np.random.default_rng(3)
+    for trial in range(20):
+        stride = int(rng.choice([1, 7, 16, 17, 36, 100, 150, 151, 300]))
+        cols = stride + int(rng.integers(0, 20))
+        hist, qs = None, fo.QStats()
+        for batch in range(2):
+            n = int(rng.integers(1, 3000))
+            st = stride if batch == 0 else max(1, stride - int(rng.integers(0, min(stride, 10))))
+            b, q, lens = random_batch(rng, n, st, 1, st, rng.random() < 0.4)
+            use_q = q if trial % 5 else None                         # every fifth trial: FASTA-like batch, bin 0 counts
+            hist = emu.run_quality_stats(b, use_q, lens, hist=hist, cols=cols)
+            qs.add(b, use_q, lens, qoffset=33)
+        if trial % 5:
+            assert np.array_equal(hist, qs.device_layout(cols, 33)), (trial, stride)
+        else:
+            h = (C.c_int * fo.QS_RANGE)()
+            for c in range(cols):
+                for k in range(5):
+                    assert int(hist[c, k, 0]) == fo.lib().fxo_qstats_hist(qs.h, c, k + 1, h) and int(hist[c, k, 1:].sum()) == 0
+        qs.close()

@@ -124,7 +124,8 @@ def test_fuzz_cli_vs_reference(tools):
                  ["fastq_masker", "-q", str(int(rng.integers(0, 45))), "-r", str(rng.choice(list("N.x"))), "-v"],
                  ["fastx_artifacts_filter", "-v"],
                  ["fastq_to_fasta", "-v"] + (["-r"] if trial % 2 else []) + (["-n"] if trial % 3 == 0 else []),
-                 ["fastx_clipper", "-a", ad.decode(), "-l", str(int(rng.integers(0, 25))), "-v"] + list(rng.choice(["-n", "-c", "-C", "-k"], size=2, replace=False))]
+                 ["fastx_clipper", "-a", ad.decode(), "-l", str(int(rng.integers(0, 25))), "-v"] + list(rng.choice(["-n", "-c", "-C", "-k"], size=2, replace=False)),
+                 ["fastx_quality_stats"] + (["-N"] if trial % 2 else [])]
         for argv in argvs:
             env = dict(os.environ, FXH_THREADS=str([16, 1, 3, 7][trial % 4]), FXH_READ_BUFFER_MB="1")
             rc, out, err = _run([os.path.join(tools, argv[0])] + argv[1:], data, env)

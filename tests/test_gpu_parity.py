@@ -233,3 +233,41 @@ def test_bench_two_ranks_on_one_gpu_via_gloo():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
     assert d["config"]["reads_per_gpu"] == 2000000
+
+
+def test_quality_stats_vs_oracle_and_full_size(engine):
+    """fxg_run_quality_stats: histogram vs the oracle's per-cycle records on ragged batches; at 50 M x 150 against torch.bincount."""
+    import torch
+    from helpers import random_batch
+    rng = np.random.default_rng(3)
+    for trial in range(10):
+        stride = int(rng.choice([1, 7, 16, 17, 36, 100, 150, 151, 300]))
+        cols = stride + int(rng.integers(0, 20))
+        hist, qs = None, fo.QStats()
+        for batch in range(2):
+            n = int(rng.integers(1, 20000))
+            st = stride if batch == 0 else max(1, stride - int(rng.integers(0, min(stride, 10))))
+            fixed = rng.random() < 0.4
+            b, q, lens = random_batch(rng, n, st, 1, st, fixed)
+            db, dq = engine.upload(b).view(b.shape), engine.upload(q).view(q.shape)
+            dl = torch.from_numpy(np.ascontiguousarray(lens).view(np.int16)).to(engine.device) if lens is not None else None
+            hist = engine.quality_stats(db, dq, lens=dl, hist=hist, cols=cols)
+            qs.add(b, q, lens, qoffset=33)
+        assert np.array_equal(hist.cpu().numpy().astype(np.uint64), qs.device_layout(cols, 33)), (trial, stride)
+        qs.close()
+    n, L = 50_000_000, 150
+    b, q = engine.synth(2, 0, n, L, False)
+    engine.set_profiling(True)
+    h = engine.quality_stats(b, q, fixed_len=L, sync=False)
+    ms = engine.last_kernel_ms()
+    engine.set_profiling(False)
+    engine.sync()
+    assert int(h.sum()) == n * L
+    cls = torch.tensor([0] * 256, dtype=torch.int64, device=engine.device)
+    for ch, k in ((65, 0), (67, 1), (71, 2), (84, 3), (78, 4)):
+        cls[ch] = k
+    for col in (0, 15, 16, 77, 149):
+        key = cls[b[:, col].long()] * 128 + q[:, col].long()
+        exp = torch.bincount(key, minlength=5 * 128).view(5, 128)
+        assert torch.equal(h[col], exp), col
+    print("quality_stats 50M x 150: %.3f ms = %.0f GB/s of rows" % (ms, 2 * n * L / ms / 1e6))

@@ -27,7 +27,7 @@ def tools():
     os.makedirs(STUB_DIR, exist_ok=True)
     so = os.path.join(STUB_DIR, "libfxg.so")
     srcs = [os.path.join(ROOT, "tests", "emu", f) for f in ("fxg_stub.cpp", "fxg_emu.cpp")]
-    deps = srcs + [os.path.join(ROOT, "fastx_toolkit_amd", "csrc", f) for f in ("fxg_device.h", "fxg_kernels.h", "fxg_plan.h")] + [os.path.join(ROOT, "include", "fxg.h")]
+    deps = srcs + [os.path.join(ROOT, "fastx_toolkit_amd", "csrc", f) for f in ("fxg_device.h", "fxg_kernels.h", "fxg_plan.h", "fxg_history.h", "fxg_stats.h")] + [os.path.join(ROOT, "include", "fxg.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["hipcc", "--cuda-host-only", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-pass-failed",
                                "-DFXG_HOST_EMULATION"] + srcs + ["-o", so])
@@ -99,7 +99,8 @@ def test_fuzz_every_tool_vs_reference(tools):
                  ["fastq_masker", "-q", str(int(rng.integers(0, 45))), "-r", str(rng.choice(list("N.x"))), "-v"],
                  ["fastx_artifacts_filter", "-v"],
                  ["fastq_to_fasta", "-v"] + (["-r"] if trial % 2 else []) + (["-n"] if trial % 3 == 0 else []),
-                 ["fastx_clipper", "-a", ad.decode(), "-l", str(int(rng.integers(0, 25))), "-v"] + list(rng.choice(["-n", "-c", "-C", "-k"], size=2, replace=False))]
+                 ["fastx_clipper", "-a", ad.decode(), "-l", str(int(rng.integers(0, 25))), "-v"] + list(rng.choice(["-n", "-c", "-C", "-k"], size=2, replace=False)),
+                 ["fastx_quality_stats"] + (["-N"] if trial % 2 else [])]
         for argv in argvs:
             rc, out, err = _run([os.path.join(tools, argv[0])] + argv[1:], data, threads=str([4, 1, 3][trial % 3]), buf_mb="1" if trial % 2 else None)
             rrc, rout, rerr = _run([REF] + argv, data)
@@ -115,3 +116,20 @@ def test_flag_errors_and_usage(tools):
     assert rc == 1 and out.startswith(b"usage: fastx_clipper")                                     # -h exits 1 (F5)
     assert _run([os.path.join(tools, "fastq_quality_trimmer"), "-t", "20"], b"")[0] == 1          # empty input is an error (R1)
     assert _run([os.path.join(tools, "fastq_quality_trimmer"), "-t", "20"], b">fa\nAC\n")[0] == 1  # FASTQ only
+
+
+def test_quality_stats_golden_fasta_and_offsets(tools):
+    """fastx_quality_stats: Galaxy known answer (-Q 64), FASTA input (record API, collapsed-read weights), -o file, both formats."""
+    from helpers import GOLDEN
+    inp = open(os.path.join(GOLDEN, "galaxy", "fastq_stats1.fastq"), "rb").read()
+    exp = open(os.path.join(GOLDEN, "galaxy", "fastq_stats1.out"), "rb").read()
+    rc, out, err = _run([os.path.join(tools, "fastx_quality_stats"), "-Q", "64"], inp)
+    assert (rc, out) == (0, exp), err
+    fasta = b">1-5\nACGTNACGT\n>2-3\nTTGCA\n>x\nGGGGGGGGGGGG\n"
+    for extra in ([], ["-N"]):
+        rc, out, err = _run([os.path.join(tools, "fastx_quality_stats")] + extra, fasta)
+        rrc, rout, rerr = _run([REF, "fastx_quality_stats"] + extra, fasta)
+        assert (rc, out) == (rrc, rout), (extra, err, rerr)
+        rc, out, err = _run([os.path.join(tools, "fastx_quality_stats"), "-Q", "64"] + extra, inp, threads="3", buf_mb="1")
+        rrc, rout, rerr = _run([REF, "fastx_quality_stats", "-Q", "64"] + extra, inp)
+        assert (rc, out) == (rrc, rout), (extra, err, rerr)

@@ -112,3 +112,16 @@ def test_reader_rules():
                 b"@r\nAC\n+\nII\n\n", b"@r\nAC\n+\nI\x05\n", b"@r\nAC\n+\n"):
         with pytest.raises(ValueError):
             fo.parse_fastq(bad)
+
+
+def test_quality_stats_galaxy_known_answer():
+    """fastx_quality_stats restatement vs galaxy/test-data/fastq_stats1.{fastq,out} (Illumina-1.3 qualities: -Q 64)."""
+    from helpers import GOLDEN
+    import os
+    text = open(os.path.join(GOLDEN, "galaxy", "fastq_stats1.fastq"), "rb").read()
+    p = fo.parse_fastq(text, qoffset=64)
+    qs = fo.QStats()
+    qs.add(p["bases"], p["qual"], p["lens"], qoffset=64)
+    assert qs.text(False) == open(os.path.join(GOLDEN, "galaxy", "fastq_stats1.out"), "rb").read()
+    assert qs.text(True).startswith(b"cycle\tmax_count\tALL_count")
+    qs.close()

@@ -119,3 +119,17 @@ def test_aligner_fields_vs_reference():
         r = fo.align(q, t)
         assert [int(x) for x in out] == [r.query_start, r.query_end, r.target_start, r.target_end, r.matches, r.mismatches,
                                          r.neutral_matches, r.gaps]
+
+
+def test_quality_stats_vs_reference():
+    """fastx_quality_stats: the restatement's two report formats against the real reader + the driver's restated tool body."""
+    rng = np.random.default_rng(4)
+    for trial in range(8):
+        text = _fastq(rng, int(rng.integers(1, 400)), 1, int(rng.integers(1, 130)))
+        p = fo.parse_fastq(text)
+        qs = fo.QStats()
+        qs.add(p["bases"], p["qual"], p["lens"], qoffset=33)
+        for new in (False, True):
+            exp = _ref(text, [["fastx_quality_stats"] + (["-N"] if new else [])])
+            assert qs.text(new) == exp, (trial, new)
+        qs.close()
