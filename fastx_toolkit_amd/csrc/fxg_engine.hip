@@ -36,6 +36,8 @@ struct fxg_ctx {
     u32 *hist_w;            // [2]
     uint8_t *hist_ws;       // M, BT, ext, wlen
     size_t hist_ws_cap;
+    u32 *stats_ws;          // fxg_run_quality_stats: one u32 partial histogram per workgroup
+    size_t stats_ws_cap;
     char err[512];
     char last_kernel[96];
     u32 last_grid, last_block, last_lds, last_tile;
@@ -93,7 +95,7 @@ extern "C" void fxg_ctx_destroy(fxg_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->status); (void)hipFree(c->partial); (void)hipFree(c->errflag); (void)hipFree(c->counters_scratch);
     (void)hipFree(c->text_ws); (void)hipFree(c->text_state);
-    (void)hipFree(c->hist_buf[0]); (void)hipFree(c->hist_buf[1]); (void)hipFree(c->hist_w); (void)hipFree(c->hist_ws);
+    (void)hipFree(c->hist_buf[0]); (void)hipFree(c->hist_buf[1]); (void)hipFree(c->hist_w); (void)hipFree(c->hist_ws); (void)hipFree(c->stats_ws);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipEventDestroy(c->kev0); (void)hipEventDestroy(c->kev1);
     (void)hipStreamDestroy(c->own_stream);
@@ -370,25 +372,34 @@ extern "C" int fxg_run_quality_stats(fxg_ctx *c, const fxg_batch *in, uint64_t *
     FxgStatsArgs a;
     a.bases = in->bases; a.qual = in->qual; a.len = in->len; a.n = in->n; a.total_bytes = in->n * (u64)in->stride;
     a.fixed_len = in->fixed_len; a.stride = in->stride; a.hist = (u64 *)d_hist; a.hist_cols = hist_cols;
-    a.nstrips = (in->stride + FXG_QS_STRIP - 1) / FXG_QS_STRIP;
-    // enough chunks to fill the chip a few times over, but few enough that the global flush (10 240 atomics per workgroup) stays small
-    u64 chunks = ((u64)c->cus * 8 + a.nstrips - 1) / a.nstrips;
-    if (chunks < 1) chunks = 1;
-    u64 rpc = (in->n + chunks - 1) / chunks;
-    if (rpc < 4096) rpc = 4096;
-    if (rpc > 0x40000000ull) rpc = 0x40000000ull;
-    a.reads_per_chunk = (u32)rpc;
-    chunks = (in->n + rpc - 1) / rpc;
-    chunks = (chunks + 7) / 8 * 8;                          // XCD-major launch order (fxg_kernel_quality_stats); surplus workgroups exit
-    if (chunks * a.nstrips > 0x7FFFFFFFull) return fxg_fail(c, FXG_E_INVALID, "quality_stats: batch too large");
+    // one workgroup per CU (its LDS holds the 100 KB block histogram); fewer when the batch is small
+    u64 nwg = (in->n + 255) / 256;
+    if (nwg > (u64)c->cus) nwg = (u64)c->cus;
+    a.nwg = (u32)nwg;
+    const size_t need = (size_t)a.nwg * FXG_QS_PART_WORDS * sizeof(u32);
+    if (c->stats_ws_cap < need) {
+        FXG_HIP(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->stats_ws);
+        c->stats_ws = nullptr; c->stats_ws_cap = 0;
+        FXG_HIP(c, hipMalloc((void **)&c->stats_ws, need));
+        c->stats_ws_cap = need;
+    }
+    a.partial = c->stats_ws;
     const u32 lds = FXG_QS_LDS_WORDS * sizeof(u32);
     FXG_HIP(c, hipFuncSetAttribute((const void *)fxg_kernel_quality_stats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (c->profiling) FXG_HIP(c, hipEventRecord(c->kev0, c->stream));
-    hipLaunchKernelGGL(fxg_kernel_quality_stats, dim3((u32)(chunks * a.nstrips)), dim3(FXG_BLOCK), lds, c->stream, a);
-    FXG_HIP(c, hipGetLastError());
-    if (c->profiling) { FXG_HIP(c, hipEventRecord(c->kev1, c->stream)); c->kev_valid = 1; }
+    const u32 nstrips = (in->stride + FXG_QS_STRIP - 1) / FXG_QS_STRIP;
+    for (u32 s0 = 0; s0 < nstrips; s0 += FXG_QS_WAVES) {       // one pass per block of 160 columns (one pass for reads up to 160)
+        a.strip0 = s0;
+        const bool timed = c->profiling && s0 == 0;
+        if (timed) FXG_HIP(c, hipEventRecord(c->kev0, c->stream));
+        hipLaunchKernelGGL(fxg_kernel_quality_stats, dim3(a.nwg), dim3(FXG_QS_TBLOCK), lds, c->stream, a);
+        FXG_HIP(c, hipGetLastError());
+        if (timed) { FXG_HIP(c, hipEventRecord(c->kev1, c->stream)); c->kev_valid = 1; }
+        hipLaunchKernelGGL(fxg_kernel_quality_stats_fold, dim3((FXG_QS_PART_WORDS + FXG_BLOCK - 1) / FXG_BLOCK), dim3(FXG_BLOCK), 0, c->stream, a);
+        FXG_HIP(c, hipGetLastError());
+    }
     snprintf(c->last_kernel, sizeof c->last_kernel, "fxg_kernel_quality_stats");
-    c->last_grid = (u32)(chunks * a.nstrips); c->last_block = FXG_BLOCK; c->last_lds = lds; c->last_tile = a.reads_per_chunk;
+    c->last_grid = a.nwg; c->last_block = FXG_QS_TBLOCK; c->last_lds = lds; c->last_tile = 64u * FXG_QS_UNROLL;
     return FXG_OK;
 }
 

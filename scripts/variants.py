@@ -14,9 +14,9 @@ sys.path.insert(0, ROOT)
 from fastx_toolkit_amd import build as _b  # noqa: E402
 
 VARIANTS = {
-    "plain": ["-DFXG_QS_TEST_PLAIN"],
-    "none": ["-DFXG_QS_TEST_NONE"],
-    "norot": ["-DFXG_QS_NOROT"],
+    "u1": ["-DFXG_QS_UNROLL=1u"],
+    "u2": ["-DFXG_QS_UNROLL=2u"],
+    "u4": ["-DFXG_QS_UNROLL=4u"],
 }
 
 

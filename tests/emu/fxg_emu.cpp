@@ -185,7 +185,7 @@ extern "C" int fxg_emu_run_pipeline(const fxg_batch *in, const fxg_params *p, co
 
 extern "C" unsigned fxg_emu_tile_reads(unsigned stride, int clip) { return fxg_pick_tile(stride, clip != 0); }
 
-// fastx_quality_stats: the strip bodies of fxg_kernel_quality_stats, one "workgroup" after the other
+// fastx_quality_stats: the per-thread bodies of fxg_kernel_quality_stats / _fold, one "workgroup" after the other
 extern "C" int fxg_emu_run_quality_stats(const fxg_batch *in, uint64_t *hist, uint32_t hist_cols)
 {
     if (!in || !hist || !in->bases || in->stride == 0 || hist_cols < in->stride) return FXG_E_INVALID;
@@ -193,20 +193,41 @@ extern "C" int fxg_emu_run_quality_stats(const fxg_batch *in, uint64_t *hist, ui
     FxgStatsArgs a;
     a.bases = in->bases; a.qual = in->qual; a.len = in->len; a.n = in->n; a.total_bytes = in->n * (u64)in->stride;
     a.fixed_len = in->fixed_len; a.stride = in->stride; a.hist = (u64 *)hist; a.hist_cols = hist_cols;
-    a.nstrips = (in->stride + FXG_QS_STRIP - 1) / FXG_QS_STRIP;
-    a.reads_per_chunk = 1000;
-    std::vector<u32> h(FXG_QS_LDS_WORDS);
-    const u64 chunks = (in->n + a.reads_per_chunk - 1) / a.reads_per_chunk;
-    for (u64 c = 0; c < chunks; ++c)
-        for (u32 s = 0; s < a.nstrips; ++s) {
-            std::fill(h.begin(), h.end(), 0u);
-            const u64 lo = c * a.reads_per_chunk, hi = lo + a.reads_per_chunk < a.n ? lo + a.reads_per_chunk : a.n;
-            for (u64 r = lo; r < hi; ++r) fxg_stats_read_strip(a, r, s, (u32)((r - lo) % FXG_BLOCK), h.data());
-            for (u32 i = 0; i < FXG_QS_STRIP * FXG_QS_CLASSES * FXG_QS_BINS; ++i) {
-                const u32 row = i / FXG_QS_BINS, bin = i % FXG_QS_BINS, v = h[row * FXG_QS_ROW + bin];
-                const u32 col = s * FXG_QS_STRIP + row / FXG_QS_CLASSES;
-                if (v && col < hist_cols) a.hist[((u64)col * FXG_QS_CLASSES + row % FXG_QS_CLASSES) * FXG_QS_BINS + bin] += v;
+    a.nwg = (u32)((in->n + 255) / 256 < 3 ? (in->n + 255) / 256 : 3);
+    std::vector<u32> partial((size_t)a.nwg * FXG_QS_PART_WORDS), lds(FXG_QS_LDS_WORDS);
+    a.partial = partial.data();
+    const u32 nstrips = (in->stride + FXG_QS_STRIP - 1) / FXG_QS_STRIP;
+    const u32 trip_reads = (FXG_QS_TBLOCK * FXG_QS_UNROLL + FXG_QS_WAVES - 1u) / FXG_QS_WAVES + 1u;
+    for (u32 s0 = 0; s0 < nstrips; s0 += FXG_QS_WAVES) {
+        a.strip0 = s0;
+        std::fill(partial.begin(), partial.end(), 0u);
+        for (u32 g = 0; g < a.nwg; ++g) {
+            std::fill(lds.begin(), lds.end(), 0u);
+            u32 *part = a.partial + (u64)g * FXG_QS_PART_WORDS;
+            u64 lo, hi;
+            fxg_stats_slice(a, g, &lo, &hi);
+            const u64 nitems = (hi - lo) * FXG_QS_WAVES;
+            u32 since = 0;
+            for (u64 g0 = 0; g0 < nitems; g0 += (u64)FXG_QS_TBLOCK * FXG_QS_UNROLL) {
+                if (since + trip_reads > (getenv("FXG_EMU_QS_FLUSH") ? 600u : 65535u)) {      // the env knob exercises the wrap guard on small inputs
+                    for (u32 t = 0; t < FXG_QS_TBLOCK; ++t) fxg_stats_flush(lds.data(), part, t, FXG_QS_TBLOCK);
+                    since = 0;
+                }
+                for (u32 t = 0; t < FXG_QS_TBLOCK; ++t)
+                    for (u32 u = 0; u < FXG_QS_UNROLL; ++u) {
+                        const u64 it = g0 + (u64)u * FXG_QS_TBLOCK + t;
+                        if (it >= nitems) continue;
+                        u64 r; u32 sl;
+                        FxgStripRow row;
+                        fxg_stats_item(lo, it, &r, &sl);
+                        fxg_stats_load(a, r, s0 + sl, row);
+                        fxg_stats_accumulate(a, row, sl, (s0 + sl) * FXG_QS_STRIP, lds.data());
+                    }
+                since += trip_reads;
             }
+            for (u32 t = 0; t < FXG_QS_TBLOCK; ++t) fxg_stats_flush(lds.data(), part, t, FXG_QS_TBLOCK);
         }
+        for (u32 e = 0; e < FXG_QS_PART_WORDS; ++e) fxg_stats_fold(a, e);
+    }
     return FXG_OK;
 }

@@ -93,6 +93,8 @@ def test_emulated_quality_stats_histogram():
             n = int(rng.integers(1, 3000))
             st = stride if batch == 0 else max(1, stride - int(rng.integers(0, min(stride, 10))))
             b, q, lens = random_batch(rng, n, st, 1, st, rng.random() < 0.4)
+            if trial % 4 == 2:
+                q = rng.integers(18, 126, size=q.shape, dtype=np.uint8)   # the whole legal range (-15 .. 92 at offset 33): also outside the LDS window
             use_q = q if trial % 5 else None                         # every fifth trial: FASTA-like batch, bin 0 counts
             hist = emu.run_quality_stats(b, use_q, lens, hist=hist, cols=cols)
             qs.add(b, use_q, lens, qoffset=33)

@@ -249,6 +249,8 @@ def test_quality_stats_vs_oracle_and_full_size(engine):
             st = stride if batch == 0 else max(1, stride - int(rng.integers(0, min(stride, 10))))
             fixed = rng.random() < 0.4
             b, q, lens = random_batch(rng, n, st, 1, st, fixed)
+            if trial % 4 == 2:
+                q = rng.integers(18, 126, size=q.shape, dtype=np.uint8)   # the whole legal range: also outside the LDS window
             db, dq = engine.upload(b).view(b.shape), engine.upload(q).view(q.shape)
             dl = torch.from_numpy(np.ascontiguousarray(lens).view(np.int16)).to(engine.device) if lens is not None else None
             hist = engine.quality_stats(db, dq, lens=dl, hist=hist, cols=cols)
