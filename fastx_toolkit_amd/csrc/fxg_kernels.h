@@ -144,7 +144,9 @@ FXG_HD void fxg_clip_read(const FxgKArgs &a, const uint8_t *rd, int len, int row
 #define FXG_PK_SZ1   1u
 #define FXG_PK_MAT1  (1u << 9)
 #define FXG_PK_MIS1  (1u << 14)
-template <int AMAX, bool EARLY>
+// FIRST: row q == 0.  The "path enters the matrix here" test (w == FXG_INVALID_TUPLE) can only fire where a predecessor lies
+// outside the matrix: anywhere in row 0, and in column 0 of the other rows -- so rows q >= 1 test it at t == 0 only.
+template <int AMAX, bool EARLY, bool FIRST>
 FXG_HD void fxg_clip_row_packed(const FxgKArgs &a, int A, u32 c, int q, float (&S)[AMAX], u32 (&W)[AMAX], float &best, u32 &bw, u32 &bq)
 {
     const bool qn = (c == (u32)'N');
@@ -170,7 +172,7 @@ FXG_HD void fxg_clip_row_packed(const FxgKArgs &a, int A, u32 c, int q, float (&
         sc = g2 ? left : sc;
         w = g2 ? W[t] : w;
         inc = g2 ? FXG_PK_SZ1 : inc;
-        w = (w == FXG_INVALID_TUPLE) ? (((u32)q << 24) | ((u32)t << 19)) : w;                // the path enters the matrix here
+        if (FIRST || t == 0) w = (w == FXG_INVALID_TUPLE) ? (((u32)q << 24) | ((u32)t << 19)) : w;   // the path enters the matrix here
         w += inc;
         dS = S[t]; dW = W[t];
         S[t] = sc; W[t] = w;
@@ -194,17 +196,24 @@ FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len, 
     int first_n = len;
     const int early_rows = (A - 4 < rows) ? (A - 4 > 0 ? A - 4 : 0) : rows;  // rows where "t - 3 > q" can still hold for some t < A
     int q = 0;
+    if (rows > 0) {                                                           // row 0: every cell may start a path
+        const u32 c = rd[0];
+        first_n = (c == (u32)'N' && 0 < len) ? 0 : first_n;
+        if (early_rows > 0) fxg_clip_row_packed<AMAX, true, true>(a, A, c, 0, S, W, best, bw, bq);
+        else fxg_clip_row_packed<AMAX, false, true>(a, A, c, 0, S, W, best, bw, bq);
+        q = 1;
+    }
 #pragma unroll 1
     for (; q < early_rows; ++q) {
         const u32 c = rd[q];
         first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
-        fxg_clip_row_packed<AMAX, true>(a, A, c, q, S, W, best, bw, bq);
+        fxg_clip_row_packed<AMAX, true, false>(a, A, c, q, S, W, best, bw, bq);
     }
 #pragma unroll 1
     for (; q < rows; ++q) {
         const u32 c = rd[q];
         first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
-        fxg_clip_row_packed<AMAX, false>(a, A, c, q, S, W, best, bw, bq);
+        fxg_clip_row_packed<AMAX, false, false>(a, A, c, q, S, W, best, bw, bq);
     }
     fxg_clip_finish(a, len, (int)(bw >> 24), (int)((bw >> 19) & 31u), (int)((bw >> 14) & 31u), (int)(bw & 511u), (int)((bw >> 9) & 31u),
                     (int)bq, first_n, out_len, keep, reason, clipped, adapter_only);
