@@ -69,6 +69,7 @@ struct FxgKArgs {
     int  qf_keep_pct;       // 100 - p
     u32  qf_drop_all;       // quirk F2: -p omitted and -q > 93
     int  alen;
+    u32  adapter_has_n;     // the adapter contains 'N' (the clip kernels then keep the per-column neutral-match selects)
     u32  clip_min_len;
     int  clip_keep_delta;
     int  clip_min_adapter_len;

@@ -146,20 +146,28 @@ FXG_HD void fxg_clip_read(const FxgKArgs &a, const uint8_t *rd, int len, int row
 #define FXG_PK_MIS1  (1u << 14)
 // FIRST: row q == 0.  The "path enters the matrix here" test (w == FXG_INVALID_TUPLE) can only fire where a predecessor lies
 // outside the matrix: anywhere in row 0, and in column 0 of the other rows -- so rows q >= 1 test it at t == 0 only.
-template <int AMAX, bool EARLY, bool FIRST>
+// TN: the adapter may contain 'N'.  Without it the pair score and the summary increment of a cell are one select each on
+// "read base == adapter base" between two values fixed per row (an 'N' in the read makes both 0.1 / neutral).
+template <int AMAX, bool EARLY, bool FIRST, bool TN>
 FXG_HD void fxg_clip_row_packed(const FxgKArgs &a, int A, u32 c, int q, float (&S)[AMAX], u32 (&W)[AMAX], float &best, u32 &bw, u32 &bq)
 {
     const bool qn = (c == (u32)'N');
+    const float pair_eq = qn ? 0.1f : 1.0f, pair_ne = qn ? 0.1f : -1.0f;                 // sequence_alignment.h:157-169 for a target base that is not N
+    const u32 inc_eq = qn ? FXG_PK_SZ1 : (FXG_PK_SZ1 + FXG_PK_MAT1), inc_ne = qn ? FXG_PK_SZ1 : (FXG_PK_SZ1 + FXG_PK_MIS1);
     float dS = 0.0f, uS = 0.0f;                            // S[q-1][-1] and S[q][-1]: query_border = 0 (N1 for q == 0)
     u32 dW = FXG_INVALID_TUPLE, uW = FXG_INVALID_TUPLE;
+    const float best_in = best;
 #pragma unroll
     for (int t = 0; t < AMAX; ++t) {
         const u32 tc = (u32)(uint8_t)a.adapter[t];    // straight-line body, see fxg_clip_read
-        const bool tn = (tc == (u32)'N');
         const bool eq = (c == tc);
-        const bool neutral = qn || tn;
-        const float pair = neutral ? ((qn && tn) ? 0.0f : 0.1f) : (eq ? 1.0f : -1.0f);      // sequence_alignment.h:157-169
-        const u32 dinc = neutral ? FXG_PK_SZ1 : (eq ? (FXG_PK_SZ1 + FXG_PK_MAT1) : (FXG_PK_SZ1 + FXG_PK_MIS1));   // if the diagonal wins
+        float pair = eq ? pair_eq : pair_ne;
+        u32 dinc = eq ? inc_eq : inc_ne;                                                     // if the diagonal wins
+        if (TN) {
+            const bool tn = (tc == (u32)'N');
+            pair = tn ? (qn ? 0.0f : 0.1f) : pair;
+            dinc = tn ? FXG_PK_SZ1 : dinc;
+        }
         const float ul = dS + pair;
         const float up = uS + -5.0f;
         float left = S[t] + -5.0f;
@@ -178,7 +186,39 @@ FXG_HD void fxg_clip_row_packed(const FxgKArgs &a, int A, u32 c, int q, float (&
         S[t] = sc; W[t] = w;
         uS = sc; uW = w;
         const bool gb = (sc > best) && (t < A);                                              // first maximum in query-major order
-        best = gb ? sc : best; bw = gb ? w : bw; bq = gb ? (u32)q : bq;
+        best = gb ? sc : best; bw = gb ? w : bw;
+    }
+    bq = (best > best_in) ? (u32)q : bq;                   // the best cell moved into this row (best only ever grows)
+}
+
+template <int AMAX, bool TN>
+FXG_HD void fxg_clip_rows_packed(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float &best, u32 &bw, u32 &bq, int &first_n)
+{
+    float S[AMAX];
+    u32 W[AMAX];
+    const int A = a.alen;
+#pragma unroll
+    for (int t = 0; t < AMAX; ++t) { S[t] = (t <= 3) ? 0.0f : -5.0f * (float)(t - 3); W[t] = FXG_INVALID_TUPLE; }
+    const int early_rows = (A - 4 < rows) ? (A - 4 > 0 ? A - 4 : 0) : rows;  // rows where "t - 3 > q" can still hold for some t < A
+    int q = 0;
+    if (rows > 0) {                                                           // row 0: every cell may start a path
+        const u32 c = rd[0];
+        first_n = (c == (u32)'N' && 0 < len) ? 0 : first_n;
+        if (early_rows > 0) fxg_clip_row_packed<AMAX, true, true, TN>(a, A, c, 0, S, W, best, bw, bq);
+        else fxg_clip_row_packed<AMAX, false, true, TN>(a, A, c, 0, S, W, best, bw, bq);
+        q = 1;
+    }
+#pragma unroll 1
+    for (; q < early_rows; ++q) {
+        const u32 c = rd[q];
+        first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
+        fxg_clip_row_packed<AMAX, true, false, TN>(a, A, c, q, S, W, best, bw, bq);
+    }
+#pragma unroll 1
+    for (; q < rows; ++q) {
+        const u32 c = rd[q];
+        first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
+        fxg_clip_row_packed<AMAX, false, false, TN>(a, A, c, q, S, W, best, bw, bq);
     }
 }
 
@@ -186,35 +226,11 @@ template <int AMAX>
 FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len, int rows,
                                  u32 *out_len, u32 *keep, u32 *reason, u32 *clipped, u32 *adapter_only)
 {
-    float S[AMAX];
-    u32 W[AMAX];
-    const int A = a.alen;
-#pragma unroll
-    for (int t = 0; t < AMAX; ++t) { S[t] = (t <= 3) ? 0.0f : -5.0f * (float)(t - 3); W[t] = FXG_INVALID_TUPLE; }
     float best = -1000000.0f;
     u32 bw = FXG_INVALID_TUPLE, bq = 0u;
     int first_n = len;
-    const int early_rows = (A - 4 < rows) ? (A - 4 > 0 ? A - 4 : 0) : rows;  // rows where "t - 3 > q" can still hold for some t < A
-    int q = 0;
-    if (rows > 0) {                                                           // row 0: every cell may start a path
-        const u32 c = rd[0];
-        first_n = (c == (u32)'N' && 0 < len) ? 0 : first_n;
-        if (early_rows > 0) fxg_clip_row_packed<AMAX, true, true>(a, A, c, 0, S, W, best, bw, bq);
-        else fxg_clip_row_packed<AMAX, false, true>(a, A, c, 0, S, W, best, bw, bq);
-        q = 1;
-    }
-#pragma unroll 1
-    for (; q < early_rows; ++q) {
-        const u32 c = rd[q];
-        first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
-        fxg_clip_row_packed<AMAX, true, false>(a, A, c, q, S, W, best, bw, bq);
-    }
-#pragma unroll 1
-    for (; q < rows; ++q) {
-        const u32 c = rd[q];
-        first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
-        fxg_clip_row_packed<AMAX, false, false>(a, A, c, q, S, W, best, bw, bq);
-    }
+    if (a.adapter_has_n) fxg_clip_rows_packed<AMAX, true>(a, rd, len, rows, best, bw, bq, first_n);    // uniform branch
+    else fxg_clip_rows_packed<AMAX, false>(a, rd, len, rows, best, bw, bq, first_n);
     fxg_clip_finish(a, len, (int)(bw >> 24), (int)((bw >> 19) & 31u), (int)((bw >> 14) & 31u), (int)(bw & 511u), (int)((bw >> 9) & 31u),
                     (int)bq, first_n, out_len, keep, reason, clipped, adapter_only);
 }

@@ -82,6 +82,7 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     memcpy(ka.adapter, p->adapter, sizeof ka.adapter);
     ka.adapter[sizeof ka.adapter - 1] = 0;
     ka.alen = (int)strlen(ka.adapter);
+    ka.adapter_has_n = strchr(ka.adapter, 'N') != nullptr;
 
     pl->group_a = ga;
     pl->mask = gm; pl->artifacts = gf;
