@@ -148,25 +148,28 @@ FXG_HD void fxg_clip_read(const FxgKArgs &a, const uint8_t *rd, int len, int row
 // outside the matrix: anywhere in row 0, and in column 0 of the other rows -- so rows q >= 1 test it at t == 0 only.
 // TN: the adapter may contain 'N'.  Without it the pair score and the summary increment of a cell are one select each on
 // "read base == adapter base" between two values fixed per row (an 'N' in the read makes both 0.1 / neutral).
+// W holds every cell's summary ALREADY extended by one gap step (w + SZ1): that is what both the cell below (up) and the cell to
+// the right in the next row (left) need, so the step is added once per cell instead of once per use; the diagonal adds the
+// difference (match / mismatch bits).  "No predecessor" is therefore FXG_INVALID_TUPLE + SZ1 = 0, which no real summary can be.
 template <int AMAX, bool EARLY, bool FIRST, bool TN>
 FXG_HD void fxg_clip_row_packed(const FxgKArgs &a, int A, u32 c, int q, float (&S)[AMAX], u32 (&W)[AMAX], float &best, u32 &bw, u32 &bq)
 {
     const bool qn = (c == (u32)'N');
     const float pair_eq = qn ? 0.1f : 1.0f, pair_ne = qn ? 0.1f : -1.0f;                 // sequence_alignment.h:157-169 for a target base that is not N
-    const u32 inc_eq = qn ? FXG_PK_SZ1 : (FXG_PK_SZ1 + FXG_PK_MAT1), inc_ne = qn ? FXG_PK_SZ1 : (FXG_PK_SZ1 + FXG_PK_MIS1);
+    const u32 dx_eq = qn ? 0u : FXG_PK_MAT1, dx_ne = qn ? 0u : FXG_PK_MIS1;             // what a diagonal step adds beyond the length
     float dS = 0.0f, uS = 0.0f;                            // S[q-1][-1] and S[q][-1]: query_border = 0 (N1 for q == 0)
-    u32 dW = FXG_INVALID_TUPLE, uW = FXG_INVALID_TUPLE;
+    u32 dW = 0u, uW = 0u;                                  // no predecessor left of column 0
     const float best_in = best;
 #pragma unroll
     for (int t = 0; t < AMAX; ++t) {
         const u32 tc = (u32)(uint8_t)a.adapter[t];    // straight-line body, see fxg_clip_read
         const bool eq = (c == tc);
         float pair = eq ? pair_eq : pair_ne;
-        u32 dinc = eq ? inc_eq : inc_ne;                                                     // if the diagonal wins
+        u32 dx = eq ? dx_eq : dx_ne;
         if (TN) {
             const bool tn = (tc == (u32)'N');
             pair = tn ? (qn ? 0.0f : 0.1f) : pair;
-            dinc = tn ? FXG_PK_SZ1 : dinc;
+            dx = tn ? 0u : dx;
         }
         const float ul = dS + pair;
         const float up = uS + -5.0f;
@@ -174,17 +177,22 @@ FXG_HD void fxg_clip_row_packed(const FxgKArgs &a, int A, u32 c, int q, float (&
         if (EARLY && t > 3) left = (t - 3 > q) ? -100000.0f : left;                          // :387-389, only rows q < A-4
         const bool g1 = up > ul;                                                             // diag > up > left on ties
         float sc = g1 ? up : ul;
-        u32 w = g1 ? uW : dW;
-        u32 inc = g1 ? FXG_PK_SZ1 : dinc;
         const bool g2 = left > sc;
         sc = g2 ? left : sc;
-        w = g2 ? W[t] : w;
-        inc = g2 ? FXG_PK_SZ1 : inc;
-        if (FIRST || t == 0) w = (w == FXG_INVALID_TUPLE) ? (((u32)q << 24) | ((u32)t << 19)) : w;   // the path enters the matrix here
-        w += inc;
+        u32 w;
+        if (FIRST || t == 0) {                                                               // a predecessor may lie outside the matrix
+            u32 src = g1 ? uW : dW;
+            src = g2 ? W[t] : src;
+            const u32 step = (g1 || g2) ? 0u : dx;
+            w = (src == 0u) ? ((((u32)q << 24) | ((u32)t << 19)) + FXG_PK_SZ1 + step) : (src + step);   // the path enters the matrix here
+        } else {
+            w = g1 ? uW : dW + dx;
+            w = g2 ? W[t] : w;
+        }
         dS = S[t]; dW = W[t];
-        S[t] = sc; W[t] = w;
-        uS = sc; uW = w;
+        const u32 wp = w + FXG_PK_SZ1;
+        S[t] = sc; W[t] = wp;
+        uS = sc; uW = wp;
         const bool gb = (sc > best) && (t < A);                                              // first maximum in query-major order
         best = gb ? sc : best; bw = gb ? w : bw;
     }
@@ -198,7 +206,7 @@ FXG_HD void fxg_clip_rows_packed(const FxgKArgs &a, const uint8_t *rd, int len, 
     u32 W[AMAX];
     const int A = a.alen;
 #pragma unroll
-    for (int t = 0; t < AMAX; ++t) { S[t] = (t <= 3) ? 0.0f : -5.0f * (float)(t - 3); W[t] = FXG_INVALID_TUPLE; }
+    for (int t = 0; t < AMAX; ++t) { S[t] = (t <= 3) ? 0.0f : -5.0f * (float)(t - 3); W[t] = 0u; }   // 0 = no predecessor (see fxg_clip_row_packed)
     const int early_rows = (A - 4 < rows) ? (A - 4 > 0 ? A - 4 : 0) : rows;  // rows where "t - 3 > q" can still hold for some t < A
     int q = 0;
     if (rows > 0) {                                                           // row 0: every cell may start a path
