@@ -101,6 +101,9 @@ def main():
     if os.environ.get("FXG_BENCH_SHARED_GPU"):      # smoke-testing the N>1 path on a 1-GPU box (with FXG_DIST_BACKEND=gloo)
         local = 0
     torch.cuda.set_device(local)
+    # One stream for everything: torch allocations/fills, the engine's kernels (it adopts torch's current stream) and the
+    # RCCL all-gather, which orders itself after that stream -- so the gather reads the counters of the pass just enqueued.
+    torch.cuda.set_stream(torch.cuda.Stream(device=local))
     eng = Engine(local)
     R, L = args.reads, READ_LEN
     lo = rank * R                                  # weak scaling: rank g owns reads [g*R, (g+1)*R) of the global set
