@@ -106,3 +106,23 @@ def test_emulated_quality_stats_histogram():
                 for k in range(5):
                     assert int(hist[c, k, 0]) == fo.lib().fxo_qstats_hist(qs.h, c, k + 1, h) and int(hist[c, k, 1:].sum()) == 0
         qs.close()
+
+
+def test_emulated_long_reads():
+    """Reads up to the reference reader's line limit (24 999): tiles of a few reads, 157 column blocks in the statistics kernel."""
+    from helpers import random_batch
+    rng = np.random.default_rng(8)
+    ad = b"AGATCGGAAGAGC"
+    for stride in (24999, 1000):
+        b, q, lens = random_batch(rng, 7, stride, stride // 2, stride, False, adapter=ad)
+        for pd in (dict(stages=6, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80), dict(stages=24, ft_first=5, ft_last=stride - 7),
+                   dict(stages=8), dict(stages=64, mask_min_quality=20), dict(stages=128), dict(stages=1, adapter=ad, clip_min_len=15, clip_flags=4)):
+            p = oracle_params(pd)
+            hs = emu.hist_new() if pd["stages"] & 1 else None          # ragged clipper input: the oracle carries the aligner's history (N3)
+            assert_same(fo.run_pipeline(b, q, lens, p), emu.run_pipeline(b, q, lens, p, hist=hs), "long.%d.%d" % (stride, pd["stages"]))
+            if hs:
+                emu.hist_free(hs)
+        qs = fo.QStats()
+        qs.add(b, q, lens, qoffset=33)
+        assert np.array_equal(emu.run_quality_stats(b, q, lens), qs.device_layout(stride, 33))
+        qs.close()

@@ -273,3 +273,24 @@ def test_quality_stats_vs_oracle_and_full_size(engine):
         exp = torch.bincount(key, minlength=5 * 128).view(5, 128)
         assert torch.equal(h[col], exp), col
     print("quality_stats 50M x 150: %.3f ms = %.0f GB/s of rows" % (ms, 2 * n * L / ms / 1e6))
+
+
+def test_long_reads(engine):
+    """Reads up to the reference reader's line limit (24 999) through every kernel family."""
+    import torch
+    from helpers import random_batch
+    rng = np.random.default_rng(8)
+    ad = b"AGATCGGAAGAGC"
+    for stride in (24999, 1000):
+        b, q, lens = random_batch(rng, 40, stride, stride // 2, stride, False, adapter=ad)
+        for pd in (dict(stages=6, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80), dict(stages=24, ft_first=5, ft_last=stride - 7),
+                   dict(stages=8), dict(stages=64, mask_min_quality=20), dict(stages=128), dict(stages=1, adapter=ad, clip_min_len=15, clip_flags=4)):
+            engine.set_clip_history(bool(pd["stages"] & 1))
+            assert_same(fo.run_pipeline(b, q, lens, oracle_params(pd)), _run(engine, b, q, lens, pd), "long.%d.%d" % (stride, pd["stages"]))
+            engine.set_clip_history(False)
+        qs = fo.QStats()
+        qs.add(b, q, lens, qoffset=33)
+        dl = torch.from_numpy(np.ascontiguousarray(lens).view(np.int16)).to(engine.device)
+        h = engine.quality_stats(engine.upload(b).view(b.shape), engine.upload(q).view(q.shape), lens=dl)
+        assert np.array_equal(h.cpu().numpy().astype(np.uint64), qs.device_layout(stride, 33))
+        qs.close()
