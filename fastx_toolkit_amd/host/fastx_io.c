@@ -14,12 +14,15 @@
 #include <err.h>
 #include <errno.h>
 #include <fcntl.h>
+#include <pthread.h>
+#include <stdint.h>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/types.h>
 #include <sys/wait.h>
 #include <unistd.h>
+#include <zlib.h>
 
 /* ---------------------------------------------------------------------------------------------- */
 /* reader                                                                                         */
@@ -281,14 +284,84 @@ static void fxh_flush_all(void)
         if (g_writers[i]) fxh_writer_close(g_writers[i]);
 }
 
-void fxh_writer_flush(struct fxh_writer *w)
+static void fxh_write_all(int fd, const char *buf, size_t n)
 {
     size_t off = 0;
-    while (off < w->len) {
-        ssize_t k = write(w->fd, w->buf + off, w->len - off);
+    while (off < n) {
+        ssize_t k = write(fd, buf + off, n - off);
         if (k < 0) { if (errno == EINTR) continue; err(1, "writing output failed"); }
         off += (size_t)k;
     }
+}
+
+/* -z.  The reference pipes its output through a `gzip` child (fastx.c:214-248): one core, however fast the tool is.  Here the
+ * buffer is cut into 1 MiB chunks, worker threads deflate them independently (zlib, level 6 like gzip's default) and the
+ * results are written in order as consecutive gzip members -- a valid gzip stream (RFC 1952 2.2) that gunzip/zcat
+ * decompress to exactly the bytes the reference's pipe would have carried. */
+#define FXH_GZ_CHUNK ((size_t)1 << 20)
+struct fxh_gz_job {
+    const char *in; size_t n, nchunks;
+    char **out; size_t *outlen;
+    int nthreads;
+};
+struct fxh_gz_arg { struct fxh_gz_job *job; int id; };
+
+static void fxh_gz_member(const char *in, size_t n, char **out, size_t *outlen)
+{
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, 6, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) errx(1, "deflateInit2 failed");
+    const size_t cap = deflateBound(&zs, (uLong)n) + 64;
+    char *o = (char *)malloc(cap);
+    if (!o) err(1, "out of memory");
+    zs.next_in = (Bytef *)(uintptr_t)in; zs.avail_in = (uInt)n;
+    zs.next_out = (Bytef *)o; zs.avail_out = (uInt)cap;
+    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) errx(1, "deflate failed");
+    *out = o; *outlen = cap - zs.avail_out;
+    deflateEnd(&zs);
+}
+
+static void *fxh_gz_worker(void *p)
+{
+    struct fxh_gz_arg *a = (struct fxh_gz_arg *)p;
+    struct fxh_gz_job *j = a->job;
+    for (size_t c = (size_t)a->id; c < j->nchunks; c += (size_t)j->nthreads) {
+        const size_t off = c * FXH_GZ_CHUNK, len = j->n - off < FXH_GZ_CHUNK ? j->n - off : FXH_GZ_CHUNK;
+        fxh_gz_member(j->in + off, len, &j->out[c], &j->outlen[c]);
+    }
+    return NULL;
+}
+
+void fxh_writer_emit(struct fxh_writer *w, const char *buf, size_t n)
+{
+    if (!w->gz) { fxh_write_all(w->fd, buf, n); return; }
+    if (n == 0) return;
+    struct fxh_gz_job job;
+    job.in = buf; job.n = n; job.nchunks = (n + FXH_GZ_CHUNK - 1) / FXH_GZ_CHUNK;
+    job.out = (char **)calloc(job.nchunks, sizeof(char *));
+    job.outlen = (size_t *)calloc(job.nchunks, sizeof(size_t));
+    if (!job.out || !job.outlen) err(1, "out of memory");
+    const char *te = getenv("FXH_THREADS");
+    long nt = te ? atol(te) : 16, ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    if (nt < 1) nt = 1;
+    if (nt > 64) nt = 64;
+    if (ncpu > 0 && nt > ncpu) nt = ncpu;
+    if ((size_t)nt > job.nchunks) nt = (long)job.nchunks;
+    job.nthreads = (int)nt;
+    pthread_t th[64];
+    struct fxh_gz_arg arg[64];
+    for (int i = 0; i < job.nthreads; ++i) { arg[i].job = &job; arg[i].id = i; }
+    for (int i = 1; i < job.nthreads; ++i) if (pthread_create(&th[i], NULL, fxh_gz_worker, &arg[i]) != 0) err(1, "pthread_create");
+    fxh_gz_worker(&arg[0]);
+    for (int i = 1; i < job.nthreads; ++i) pthread_join(th[i], NULL);
+    for (size_t c = 0; c < job.nchunks; ++c) { fxh_write_all(w->fd, job.out[c], job.outlen[c]); free(job.out[c]); }
+    w->gz_members += job.nchunks;
+    free(job.out); free(job.outlen);
+}
+
+void fxh_writer_flush(struct fxh_writer *w)
+{
+    fxh_writer_emit(w, w->buf, w->len);
     w->len = 0;
 }
 
@@ -309,9 +382,14 @@ void fxh_writer_close(struct fxh_writer *w)
 {
     if (!w || w->fd < 0) return;
     fxh_writer_flush(w);
-    if (w->fd != STDOUT_FILENO || w->child > 0) close(w->fd);
+    if (w->gz && w->gz_members == 0) {           /* nothing was written: still a valid (empty) gzip file, as `gzip < /dev/null` gives */
+        char *o; size_t on;
+        fxh_gz_member("", 0, &o, &on);
+        fxh_write_all(w->fd, o, on);
+        free(o);
+    }
+    if (w->fd != STDOUT_FILENO) close(w->fd);
     w->fd = -1;
-    if (w->child > 0) { int st; (void)waitpid(w->child, &st, 0); w->child = 0; }   /* the reference never waits (N4) */
 }
 
 static int fxh_open_output(const char *filename)
@@ -329,24 +407,8 @@ static struct fxh_writer *fxh_writer_open(const char *filename, int gzip)
     w->cap = 8u << 20;
     w->buf = (char *)malloc(w->cap);
     if (!w->buf) err(1, "out of memory");
-    if (!gzip) w->fd = fxh_open_output(filename);
-    else {                                       /* pipe through a gzip child whose stdout is the output file */
-        int pp[2];
-        if (pipe(pp) != 0) err(1, "pipe (for gzip) failed");
-        pid_t pid = fork();
-        if (pid < 0) err(1, "fork (for gzip) failed");
-        if (pid == 0) {
-            dup2(pp[0], STDIN_FILENO);
-            close(pp[1]);
-            int fd = fxh_open_output(filename);
-            dup2(fd, STDOUT_FILENO);
-            execlp("gzip", "gzip", (char *)NULL);
-            err(1, "execlp(gzip) failed");
-        }
-        close(pp[0]);
-        w->fd = pp[1];
-        w->child = pid;
-    }
+    w->fd = fxh_open_output(filename);
+    w->gz = gzip ? 1 : 0;
     static int registered;
     if (!registered) { atexit(fxh_flush_all); registered = 1; }
     for (size_t i = 0; i < sizeof g_writers / sizeof g_writers[0]; ++i)

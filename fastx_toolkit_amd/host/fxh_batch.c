@@ -438,7 +438,8 @@ typedef struct {
     pthread_t th;
     pthread_mutex_t mu;
     pthread_cond_t cv;
-    int fd, started;
+    struct fxh_writer *w;
+    int started;
     const char *buf; size_t len;
     int state;                         /* 0 idle, 1 pending, 3 quit */
 } fxh_awriter;
@@ -452,12 +453,7 @@ static void *fxh_awriter_main(void *arg)
         if (aw->state == 3) break;
         const char *b = aw->buf; size_t n = aw->len;
         pthread_mutex_unlock(&aw->mu);
-        size_t off = 0;
-        while (off < n) {
-            ssize_t k = write(aw->fd, b + off, n - off);
-            if (k < 0) { if (errno == EINTR) continue; err(1, "writing output failed"); }
-            off += (size_t)k;
-        }
+        fxh_writer_emit(aw->w, b, n);       /* raw write, or parallel gzip members with -z */
         pthread_mutex_lock(&aw->mu);
         aw->state = 0;
         pthread_cond_broadcast(&aw->cv);
@@ -479,7 +475,7 @@ static void fxh_awriter_submit(fxh_awriter *aw, struct fxh_writer *w, char **spa
 {
     if (!aw->started) {
         pthread_mutex_init(&aw->mu, NULL); pthread_cond_init(&aw->cv, NULL);
-        aw->fd = w->fd; aw->state = 0; aw->started = 1;
+        aw->w = w; aw->state = 0; aw->started = 1;
         if (pthread_create(&aw->th, NULL, fxh_awriter_main, aw) != 0) err(1, "pthread_create");
     }
     fxh_awriter_wait(aw);              /* the other buffer is free again */

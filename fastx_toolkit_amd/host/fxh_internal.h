@@ -17,7 +17,8 @@ struct fxh_writer {
     int fd;
     char *buf;
     size_t cap, len;
-    pid_t child;            /* gzip child, if any */
+    int gz;                 /* -z: the output is a gzip stream, compressed here in parallel (one member per chunk) */
+    unsigned long gz_members;
 };
 
 /* one record as slices of the reader's buffer (valid until the next fill) */
@@ -42,6 +43,7 @@ int    fxh_decode_quality(FASTX *fx, struct fxh_rawrec *rec, int *out_i32, unsig
 int    fxh_reads_count(const FASTX *fx, const char *name, size_t name_len);
 size_t fxh_format_numeric(char *dst, const int *q, const unsigned char *phred33, size_t n);
 void   fxh_writer_flush(struct fxh_writer *w);
+void   fxh_writer_emit(struct fxh_writer *w, const char *buf, size_t n);   /* raw bytes to the file, or gzip members when w->gz */
 char  *fxh_writer_reserve(struct fxh_writer *w, size_t n);
 void   fxh_writer_close(struct fxh_writer *w);
 #endif

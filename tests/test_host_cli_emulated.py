@@ -133,3 +133,23 @@ def test_quality_stats_golden_fasta_and_offsets(tools):
         rc, out, err = _run([os.path.join(tools, "fastx_quality_stats"), "-Q", "64"] + extra, inp, threads="3", buf_mb="1")
         rrc, rout, rerr = _run([REF, "fastx_quality_stats", "-Q", "64"] + extra, inp)
         assert (rc, out) == (rrc, rout), (extra, err, rerr)
+
+
+def test_gzip_output_is_parallel_members(tools, tmp_path):
+    """-z: the tools deflate their output themselves, one gzip member per MiB on worker threads; zcat must give the plain output."""
+    import gzip
+    text = fo.synth_fastq(31, 0, 40000, 100, False)                     # ~9 MB of FASTQ: several members, several threads
+    plain = _run([os.path.join(tools, "fastq_quality_trimmer"), "-t", "20", "-l", "30"], text)
+    for threads in ("1", "5"):
+        rc, out, err = _run([os.path.join(tools, "fastq_quality_trimmer"), "-t", "20", "-l", "30", "-z"], text, threads=threads)
+        assert rc == 0, err
+        assert out[:2] == b"\x1f\x8b" and out.count(b"\x1f\x8b\x08") >= 3
+        assert gzip.decompress(out) == plain[1]
+    p = subprocess.run(["zcat"], input=out, stdout=subprocess.PIPE, timeout=60)
+    assert p.returncode == 0 and p.stdout == plain[1]
+    outp = tmp_path / "o.fq.gz"
+    rc, out, err = _run([os.path.join(tools, "fastq_quality_filter"), "-q", "93", "-p", "100", "-z", "-o", str(outp)], text)   # nothing passes
+    assert rc == 0 and gzip.decompress(outp.read_bytes()) == b""       # still a valid, empty gzip file
+    head = b"\n".join(text.split(b"\n")[:4000]) + b"\n"                                                                       # 1000 whole records
+    rc, out, err = _run([os.path.join(tools, "fastx_copy"), "-z"], head)                                                       # record API path
+    assert rc == 0 and gzip.decompress(out) == _run([os.path.join(tools, "fastx_copy")], head)[1] == head
