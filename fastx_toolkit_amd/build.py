@@ -34,7 +34,7 @@ def build_engine(force=False):
 
 
 def build_host(force=False):
-    """C host layer: libfastx-compatible record API + the five command-line tools (links libfxg.so)."""
+    """C host layer: libfastx-compatible record API + the command-line tools (links libfxg.so and zlib)."""
     mk = os.path.join(HOST, "Makefile")
     if os.path.exists(mk):
         subprocess.check_call(["make", "-s", "-C", HOST] + (["-B"] if force else []))

@@ -13,10 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from fastx_toolkit_amd import build as _b  # noqa: E402
 
-VARIANTS = {
-    "u1": ["-DFXG_QS_UNROLL=1u"],
-    "u2": ["-DFXG_QS_UNROLL=2u"],
-    "u4": ["-DFXG_QS_UNROLL=4u"],
+VARIANTS = {            # edit freely: every entry becomes fastx_toolkit_amd/libfxg_v_<name>.so
+    "base": [],
+    "ntl": ["-DFXG_V_NTL"],                 # nt on the gather's source windows too
+    "nonts": ["-DFXG_V_NO_NTS"],            # plain stores of the packed output
+    "nopeek": ["-DFXG_V_NO_PEEK"],          # look-back window requested at resolve time
+    "k2": ["-DFXG_GATHER_K=2"],             # two output chunks in flight per lane
 }
 
 
