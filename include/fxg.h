@@ -10,15 +10,20 @@
  *   fastx_reverse_complement  (src/fastx_reverse_complement/fastx_reverse_complement.c:43-104)
  * run as batched HIP kernels over a Structure-of-Arrays batch instead of once per
  * fastx_read_next_record() (src/libfastx/fastx.h:120-142).  The reference has no FFI of its own; the
- * host-side C layer that keeps the libfastx record API and the five command lines on top of these
- * entry points lives in fastx_toolkit_amd/host/ (see INTEGRATION.md).
+ * host-side C layer that keeps the libfastx record API and the tools' command lines on top of these
+ * entry points lives in fastx_toolkit_amd/host/ (see INTEGRATION.md).  Further down: the neighbouring per-read
+ * tools (fastq_masker, fastx_artifacts_filter, fastq_to_fasta), fastx_quality_stats as a reduction, the
+ * clipper's read-to-read history, and FASTQ text parsed/formatted on the device.
  *
  * Conventions
  *  - extern "C", plain pointers and sizes only.  Every function returns 0 on success or a negative
  *    FXG_E_* code; fxg_last_error(ctx) describes the most recent failure on that context.
  *  - All fxg_batch / fxg_out pointers are DEVICE pointers (hipMalloc'ed by the caller or through
  *    fxg_malloc_device).  bases/qual/res/out_bases/out_qual must be 16-byte aligned.
- *  - Work is enqueued on the context's HIP stream and is asynchronous; fxg_sync() waits for it.
+ *  - Work is enqueued on the context's HIP stream and is asynchronous; fxg_sync() waits for it.  The
+ *    context owns a stream of its own (non-blocking: NOT ordered with the legacy default stream);
+ *    fxg_set_stream() makes it use the caller's, which is how to order it with other device work.
+ *  - A context is not thread-safe: one thread at a time per context; contexts are independent.
  *  - There is no CPU fallback anywhere: without a usable HIP device fxg_ctx_create() fails.
  */
 #ifndef FXG_H
