@@ -132,3 +132,21 @@ def test_fuzz_cli_vs_reference(tools):
             rrc, rout, rerr = _run([REF] + argv, data)
             assert (rc, out) == (rrc, rout), (trial, argv)
             assert _msg(err) == _msg(rerr), (trial, argv)
+
+
+def test_reader_rules_through_the_batch_path(tools):
+    """R1-R9 on the GPU build: CRLF, no final newline, numeric qualities, FASTA with collapsed ids -- every tool against the reference driver."""
+    from test_host_cli_emulated import _odd_inputs
+    rng = np.random.default_rng(78)
+    ad = "AGATCGGAAGAGC"
+    for kind, data in _odd_inputs(rng).items():
+        fasta = kind.startswith("fasta")
+        argvs = [["fastx_trimmer", "-f", "3", "-l", "20"], ["fastx_reverse_complement"], ["fastx_clipper", "-a", ad, "-l", "5", "-n", "-v"], ["fastx_artifacts_filter", "-v"]]
+        if not fasta:
+            argvs += [["fastq_quality_trimmer", "-t", "18", "-l", "8", "-v"], ["fastq_quality_filter", "-q", "15", "-p", "60", "-v"],
+                      ["fastq_masker", "-q", "12"], ["fastq_to_fasta", "-r"], ["fastx_quality_stats"]]
+        for argv in argvs:
+            rc, out, err = _run([os.path.join(tools, argv[0])] + argv[1:], data, dict(os.environ, FXH_THREADS="5", FXH_READ_BUFFER_MB="1"))
+            rrc, rout, rerr = _run([REF] + argv, data)
+            assert (rc, out) == (rrc, rout), (kind, argv, err[-200:], rerr[-200:])
+            assert _msg(err) == _msg(rerr), (kind, argv)

@@ -153,3 +153,37 @@ def test_gzip_output_is_parallel_members(tools, tmp_path):
     head = b"\n".join(text.split(b"\n")[:4000]) + b"\n"                                                                       # 1000 whole records
     rc, out, err = _run([os.path.join(tools, "fastx_copy"), "-z"], head)                                                       # record API path
     assert rc == 0 and gzip.decompress(out) == _run([os.path.join(tools, "fastx_copy")], head)[1] == head
+
+
+def _odd_inputs(rng):
+    """Reader rules R1-R9 through the batch path: FASTA, numeric qualities, CRLF, no final newline, collapsed ids."""
+    L = int(rng.integers(12, 60))
+    recs_fq, recs_num, recs_fa = [], [], []
+    for i in range(int(rng.integers(20, 300))):
+        n = L if rng.random() < 0.6 else int(rng.integers(6, L + 1))
+        s = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=n, p=[.24, .24, .24, .24, .04]).tobytes()
+        q = rng.integers(0, 41, size=n)
+        recs_fq.append(b"@r%d x\n%s\n+r%d\n%s\n" % (i, s, i, bytes((q + 33).astype(np.uint8))))
+        recs_num.append(b"@r%d\n%s\n+\n%s\n" % (i, s, b" ".join(b"%d" % (int(v) - 5) for v in q)))
+        recs_fa.append(b">%d-%d\n%s\n" % (i, int(rng.integers(1, 9)), s))
+    fq, num, fa = b"".join(recs_fq), b"".join(recs_num), b"".join(recs_fa)
+    return {"crlf": fq.replace(b"\n", b"\r\n"), "nofinalnl": fq[:-1], "numeric": num, "fasta": fa, "fasta_crlf_nonl": fa.replace(b"\n", b"\r\n")[:-2]}
+
+
+def test_reader_rules_through_the_batch_path(tools):
+    rng = np.random.default_rng(77)
+    ad = "AGATCGGAAGAGC"
+    for trial in range(4):
+        inputs = _odd_inputs(rng)
+        for kind, data in inputs.items():
+            fasta = kind.startswith("fasta")
+            argvs = [["fastx_trimmer", "-f", "3", "-l", "20"], ["fastx_trimmer", "-t", "4", "-m", "5"], ["fastx_reverse_complement"],
+                     ["fastx_clipper", "-a", ad, "-l", "5", "-n", "-v"], ["fastx_artifacts_filter", "-v"]]
+            if not fasta:
+                argvs += [["fastq_quality_trimmer", "-t", "18", "-l", "8", "-v"], ["fastq_quality_filter", "-q", "15", "-p", "60", "-v"],
+                          ["fastq_masker", "-q", "12"], ["fastq_to_fasta", "-r"], ["fastx_quality_stats"]]
+            for argv in argvs:
+                rc, out, err = _run([os.path.join(tools, argv[0])] + argv[1:], data, threads=str([3, 1, 8][trial % 3]), buf_mb="1" if trial % 2 else None)
+                rrc, rout, rerr = _run([REF] + argv, data)
+                assert (rc, out) == (rrc, rout), (trial, kind, argv, err[-200:], rerr[-200:])
+                assert _msg(err) == _msg(rerr), (trial, kind, argv)
