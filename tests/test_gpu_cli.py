@@ -150,3 +150,15 @@ def test_reader_rules_through_the_batch_path(tools):
             rrc, rout, rerr = _run([REF] + argv, data)
             assert (rc, out) == (rrc, rout), (kind, argv, err[-200:], rerr[-200:])
             assert _msg(err) == _msg(rerr), (kind, argv)
+
+
+def test_minimal_c_caller_of_the_abi(tools):
+    """host/examples/abi_minimal.c: plain C against include/fxg.h -- its counters are the oracle's."""
+    from helpers import oracle_params
+    n, L = 200000, 150
+    rc, out, err = _run([os.path.join(tools, "abi_minimal"), str(n), str(L)], b"")
+    assert rc == 0, err
+    b, q = fo.synth_batch(2, 0, n, L)
+    c = fo.run_pipeline(b, q, None, oracle_params(dict(stages=6, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80)))["counters"]
+    assert out.decode().split() == ["input", str(n), "kept", str(int(c[1])), "kept_bases", str(int(c[2])), "qtrim_dropped", str(int(c[8])),
+                                   "qfilter_dropped", str(int(c[9]))]
