@@ -162,3 +162,10 @@ def test_minimal_c_caller_of_the_abi(tools):
     c = fo.run_pipeline(b, q, None, oracle_params(dict(stages=6, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80)))["counters"]
     assert out.decode().split() == ["input", str(n), "kept", str(int(c[1])), "kept_bases", str(int(c[2])), "qtrim_dropped", str(int(c[8])),
                                    "qfilter_dropped", str(int(c[9]))]
+
+
+def test_quality_stats_galaxy_known_answer(tools):
+    inp = open(os.path.join(GOLDEN, "galaxy", "fastq_stats1.fastq"), "rb").read()
+    exp = open(os.path.join(GOLDEN, "galaxy", "fastq_stats1.out"), "rb").read()
+    rc, out, err = _run([os.path.join(tools, "fastx_quality_stats"), "-Q", "64"], inp)
+    assert (rc, out) == (0, exp), err
