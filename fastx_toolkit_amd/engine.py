@@ -202,9 +202,19 @@ class Engine:
             raise FxgError("fxg error %d: %s" % (rc, self.lib.fxg_last_error(self.ctx).decode(errors="replace")))
 
     def use_torch_stream(self):
-        """Enqueue on torch's current stream so tensors allocated by torch are ordered with the kernels."""
+        """Enqueue on torch's current stream so tensors allocated by torch are ordered with the kernels.
+
+        torch's DEFAULT stream has the null handle, for which the C-ABI keeps the context's own (non-blocking) stream: the
+        two are then NOT ordered by the runtime.  In that case every launch below first waits for torch's stream on the
+        host (`_after_torch`), and results must be read through Result (which synchronises the engine) or after sync().
+        Run under `torch.cuda.stream(side_stream)` / `torch.cuda.set_stream` (as bench.py does) to share one stream."""
         s = self.torch.cuda.current_stream(self.device).cuda_stream
+        self._own_stream = not s
         self._check(self.lib.fxg_set_stream(self.ctx, C.c_void_p(s)))
+
+    def _after_torch(self):
+        if getattr(self, "_own_stream", False):
+            self.torch.cuda.current_stream(self.device).synchronize()
 
     def sync(self):
         self._check(self.lib.fxg_sync(self.ctx))
@@ -227,7 +237,7 @@ class Engine:
         n, stride = bases.shape
         if hist is None:
             hist = self.torch.zeros((cols or stride, 5, 128), dtype=self.torch.int64, device=self.device)
-            self.torch.cuda.current_stream(self.device).synchronize()   # the fill ran on torch's stream; the engine may be on its own
+        self._after_torch()                                   # e.g. the fill above ran on torch's stream
         b = FxgBatch(bases.data_ptr(), qual.data_ptr() if qual is not None else None,
                      lens.data_ptr() if lens is not None else None, int(fixed_len or stride), stride, n)
         self._check(self.lib.fxg_run_quality_stats(self.ctx, C.byref(b), hist.data_ptr(), hist.shape[0]))
@@ -287,6 +297,7 @@ class Engine:
         n, stride = bases.shape
         if outputs is None:
             outputs = self.alloc_outputs(n, stride, compact, meta, qual is not None)
+        self._after_torch()
         o = outputs
         b = FxgBatch(bases.data_ptr(), qual.data_ptr() if qual is not None else None,
                      lens.data_ptr() if lens is not None else None, int(fixed_len or stride), stride, n)
