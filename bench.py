@@ -1,15 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X FASTQ engine (driver contract in the task statement).
+"""bench.py -- benchmark of the MI355X FASTQ engine (driver contract in the task statement).
 
-Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
+Default workload (BASELINE.json configs[1], the configuration the metric is quoted on):
     fastq_quality_trimmer -t 20 -l 30 | fastq_quality_filter -q 20 -p 80
 on 50 M synthetic 150 bp Phred+33 reads PER GPU (seed 2, SURVEY.md 8d generator, generated on the
 device so inputs are resident in HBM when the timed region starts), fused into ONE pass that also
 stream-compacts the kept, trimmed reads in input order.  One "step" = one such pass over the batch.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--config cfg2|cfg3|cfg4|cfg5shard|stats]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
+
+--config selects another BASELINE.json configuration (same JSON shape, its own roofline object):
+    cfg3       fastx_clipper -a AGATCGGAAGAGC -l 15 -n, 50 M x 100 bp                (VALU-bound: GCUPS)
+    cfg4       fastx_reverse_complement | fastx_trimmer -f 5 -l 145 fused, 200 M x 150 bp
+    cfg5shard  clip -> quality-trim -> filter in one pass, 125 M x 150 bp per GPU (1 B reads over 8 GPUs)
+    stats      fastx_quality_stats histogram reduction, 50 M x 150 bp
 
 Multi-GPU: reads shard by contiguous index range (rank g owns reads [g*R, (g+1)*R) of the global set),
 no data-path collective; each step ends with one 192-byte all-gather of the counter blocks (RCCL) from
@@ -27,57 +33,166 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
-READ_LEN = 150
-SEED = 2
-PARAMS = dict(stages=2 | 4, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80)
+# VALU issue peak for the clip kernel's instruction mix: 256 CUs x 4 SIMDs, one wave64 instruction per VALU_CYCLES cycles at 2.4 GHz
+# (scripts/ubench/valu_rate.hip measures the cycles per instruction class; profiles/r02_valu_rate.txt)
+VALU_CYCLES = 4.0
+VALU_PEAK_GLANEOPS = 256 * 4 * 64 / VALU_CYCLES * 2.4
+ADAPTER = b"AGATCGGAAGAGC"
+QTF = dict(qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80)
+
+CONFIGS = {
+    "cfg2": dict(seed=2, reads=50_000_000, L=150, adapter=False, params=dict(stages=2 | 4, **QTF),
+                 metric="Mreads/s (150 bp) quality-trim+filter", bound="hbm",
+                 what="fastq_quality_trimmer -t 20 -l 30 | fastq_quality_filter -q 20 -p 80"),
+    "cfg3": dict(seed=3, reads=50_000_000, L=100, adapter=True, params=dict(stages=1, adapter=ADAPTER, clip_min_len=15, clip_flags=4),
+                 metric="Mreads/s (100 bp) adapter clip", bound="valu", what="fastx_clipper -a AGATCGGAAGAGC -l 15 -n"),
+    "cfg4": dict(seed=2, reads=200_000_000, L=150, adapter=False, params=dict(stages=8 | 16, ft_first=5, ft_last=145),
+                 metric="Mreads/s (150 bp) reverse-complement+trim", bound="hbm",
+                 what="fastx_reverse_complement | fastx_trimmer -f 5 -l 145"),
+    "cfg5shard": dict(seed=5, reads=125_000_000, L=150, adapter=True,
+                      params=dict(stages=1 | 2 | 4, adapter=ADAPTER, clip_min_len=15, clip_flags=4, **QTF),
+                      metric="Mreads/s (150 bp) clip+quality-trim+filter", bound="valu",
+                      what="fastx_clipper -a AGATCGGAAGAGC -l 15 -n | fastq_quality_trimmer -t 20 -l 30 | fastq_quality_filter -q 20 -p 80"),
+    "stats": dict(seed=2, reads=50_000_000, L=150, adapter=False, params=None,
+                  metric="Mreads/s (150 bp) quality statistics", bound="hbm", what="fastx_quality_stats (per-cycle histogram reduction)"),
+}
+# static VALU instruction count per DP cell of fxg_kernel_tiles<-13,0>'s row loop (llvm-objdump of the shipped code object)
+CLIP_VALU_PER_CELL = 15.3
 
 
-def cpu_baseline(reads_per_pipe=250_000, max_pipes=16):
-    """Reference CPU path on this box's host cores, bounded sample of the same workload (rank 0, N=1 only).
+def physical_cores():
+    try:
+        sibs = set()
+        base = "/sys/devices/system/cpu"
+        for d in os.listdir(base):
+            p = os.path.join(base, d, "topology", "thread_siblings_list")
+            if d.startswith("cpu") and d[3:].isdigit() and os.path.exists(p):
+                sibs.add(open(p).read().strip())
+        return len(sibs) or (os.cpu_count() or 1)
+    except OSError:
+        return os.cpu_count() or 1
 
-    SURVEY 8d: the reference is single-threaded, so the input is split at record boundaries into P chunks and P
-    `trimmer | filter` shell pipes (2 processes each) run concurrently; the aggregate rate over 2P cores is reported.
+
+def _pipe_cmds(ref, inp, out):
+    return ([ref, "fastq_quality_trimmer", "-t", "20", "-l", "30", "-i", inp],
+            [ref, "fastq_quality_filter", "-q", "20", "-p", "80", "-o", out])
+
+
+def cpu_baseline(reads_per_pipe=250_000, max_pipes=64):
+    """Reference CPU path on this box's host cores, bounded sample of the cfg2 workload (rank 0, N=1 only).
+
+    SURVEY 8d: the reference is single-threaded, so (i) one `trimmer | filter` shell pipe (2 processes) is timed alone and
+    (ii) the input is split at record boundaries into P/2 chunks and P/2 pipes run concurrently (P = physical cores);
+    the aggregate rate is reported with the core counts next to it.
     """
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import fxoracle_py as fo
     ref = fo.ref_binary()
     try:
         fo.lib()
     except Exception:
         return None
-    ncpu = os.cpu_count() or 2
-    pipes = max(1, min(max_pipes, ncpu // 2))
+    logical, phys = os.cpu_count() or 2, physical_cores()
+    pipes = max(1, min(max_pipes, phys // 2))
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
         if ref:
-            files = []
-            for k in range(pipes):
-                inp = os.path.join(td, "in%d.fq" % k)
-                with open(inp, "wb") as f:
-                    f.write(fo.synth_fastq(SEED, k * reads_per_pipe, reads_per_pipe, READ_LEN, False))
-                files.append(inp)
-            t0 = time.perf_counter()
-            procs = []
-            for k, inp in enumerate(files):
-                p1 = subprocess.Popen([ref, "fastq_quality_trimmer", "-t", "20", "-l", "30", "-i", inp], stdout=subprocess.PIPE)
-                p2 = subprocess.Popen([ref, "fastq_quality_filter", "-q", "20", "-p", "80", "-o", os.path.join(td, "out%d.fq" % k)], stdin=p1.stdout)
-                p1.stdout.close()
-                procs += [p1, p2]
-            ok = all(p.wait() == 0 for p in procs)
-            dt = time.perf_counter() - t0
-            if ok:
+            files = [os.path.join(td, "in%d.fq" % k) for k in range(pipes)]
+
+            def gen(k):
+                with open(files[k], "wb") as f:
+                    f.write(fo.synth_fastq(2, k * reads_per_pipe, reads_per_pipe, 150, False))
+            with ThreadPoolExecutor(max_workers=min(logical, 32)) as ex:     # the generator is C (ctypes releases the GIL)
+                list(ex.map(gen, range(pipes)))
+
+            def run(ks):
+                t0 = time.perf_counter()
+                procs = []
+                for k in ks:
+                    c1, c2 = _pipe_cmds(ref, files[k], os.path.join(td, "out%d.fq" % k))
+                    p1 = subprocess.Popen(c1, stdout=subprocess.PIPE)
+                    p2 = subprocess.Popen(c2, stdin=p1.stdout)
+                    p1.stdout.close()
+                    procs += [p1, p2]
+                ok = all(p.wait() == 0 for p in procs)
+                return ok, time.perf_counter() - t0
+            ok1, dt1 = run([0])
+            okp, dtp = run(range(pipes))
+            if ok1 and okp:
                 n = pipes * reads_per_pipe
-                return dict(value=round(n / dt / 1e6, 4), unit="Mreads/s", cores=2 * pipes, kind="reference",
+                return dict(value=round(n / dtp / 1e6, 4), unit="Mreads/s", cores=2 * pipes, kind="reference",
+                            one_pipe_value=round(reads_per_pipe / dt1 / 1e6, 4), one_pipe_cores=2,
+                            host_logical_cpus=logical, host_physical_cores=phys,
                             sample="first %d reads of the same seed-2 150 bp set as FASTQ text on tmpfs, split into %d chunks; each chunk piped "
                                    "through the reference libfastx reader/writer (compiled -O3 from /root/reference/src/libfastx) with the "
-                                   "trimmer|filter loop bodies of oracle/ref_driver.cpp; %d concurrent single-threaded processes = %d cores"
-                                   % (n, pipes, 2 * pipes, 2 * pipes))
+                                   "trimmer|filter loop bodies of oracle/ref_driver.cpp; %d concurrent single-threaded processes = %d cores "
+                                   "(the box has %d physical cores / %d logical CPUs); one_pipe_value = one pipe (2 processes) alone"
+                                   % (n, pipes, 2 * pipes, 2 * pipes, phys, logical))
         # fall back to the plain-C port (SoA in memory, no text I/O), 1 thread
         n = 4_000_000
-        b, q = fo.synth_batch(SEED, 0, n, READ_LEN)
+        b, q = fo.synth_batch(2, 0, n, 150)
         t0 = time.perf_counter()
-        fo.run_pipeline(b, q, None, fo.make_params(**PARAMS))
+        fo.run_pipeline(b, q, None, fo.make_params(**CONFIGS["cfg2"]["params"]))
         dt = time.perf_counter() - t0
-        return dict(value=round(n / dt / 1e6, 4), unit="Mreads/s", cores=1, kind="port",
+        return dict(value=round(n / dt / 1e6, 4), unit="Mreads/s", cores=1, kind="port", host_logical_cpus=logical, host_physical_cores=phys,
                     sample="oracle/fxoracle.c on %d in-memory SoA reads (no FASTQ text parsing/formatting), 1 thread" % n)
+
+
+def e2e_leg(reads=4_000_000):
+    """End to end on one GPU: FASTQ text on tmpfs -> the C tools (host/bin) -> FASTQ text; the same seed-2 reads the CPU baseline uses.
+
+    `pipe`  = fastq_quality_trimmer -t 20 -l 30 | fastq_quality_filter -q 20 -p 80 (two processes, both on the GPU, as a user would type it)
+    `fused` = fastq_quality_trim_filter -t 20 -l 30 -q 20 -p 80 (one process, one pass; byte-identical output)
+    Wall time of the command, file to file; Mreads/s and Gbases/s of INPUT."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import fxoracle_py as fo
+    import hashlib
+    bindir = os.path.join(ROOT, "fastx_toolkit_amd", "host", "bin")
+    trimmer, filt, fused = (os.path.join(bindir, t) for t in ("fastq_quality_trimmer", "fastq_quality_filter", "fastq_quality_trim_filter"))
+    if not (os.path.exists(trimmer) and os.path.exists(filt)):
+        return None
+    chunk = 250_000
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+        inp = os.path.join(td, "in.fq")
+        with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 2, 32)) as ex:
+            parts = list(ex.map(lambda k: fo.synth_fastq(2, k * chunk, chunk, 150, False), range(reads // chunk)))
+        with open(inp, "wb") as f:
+            for p in parts:
+                f.write(p)
+        del parts
+        out = {"reads": reads, "input_bytes": os.path.getsize(inp)}
+
+        def md5(path):
+            h = hashlib.md5()
+            with open(path, "rb") as f:
+                for blk in iter(lambda: f.read(1 << 24), b""):
+                    h.update(blk)
+            return h.hexdigest()
+
+        def timed(name, fn):
+            best = None
+            for _ in range(2):                             # the first run pays the library load and context creation from cold caches
+                t0 = time.perf_counter()
+                ok = fn()
+                dt = time.perf_counter() - t0
+                if not ok:
+                    return
+                best = dt if best is None else min(best, dt)
+            out[name] = dict(wall_s=round(best, 3), mreads_s=round(reads / best / 1e6, 2), gbases_s=round(reads * 150 / best / 1e9, 3))
+
+        def pipe():
+            p1 = subprocess.Popen([trimmer, "-t", "20", "-l", "30", "-i", inp], stdout=subprocess.PIPE)
+            p2 = subprocess.Popen([filt, "-q", "20", "-p", "80", "-o", os.path.join(td, "pipe.fq")], stdin=p1.stdout)
+            p1.stdout.close()
+            return p1.wait() == 0 and p2.wait() == 0
+        timed("pipe", pipe)
+        if os.path.exists(fused):
+            timed("fused", lambda: subprocess.call([fused, "-t", "20", "-l", "30", "-q", "20", "-p", "80", "-i", inp, "-o", os.path.join(td, "fused.fq")]) == 0)
+        for k in ("pipe", "fused"):
+            if k in out:
+                out[k]["output_md5"] = md5(os.path.join(td, k + ".fq"))
+        if reads == 1_000_000 and "pipe" in out:           # SURVEY 8d records the reference's md5 for the first 1 M reads
+            out["matches_reference_md5"] = out["pipe"]["output_md5"] == "605f8d07d0f745186bc25a8d6f894284"
+        return out
 
 
 def main():
@@ -85,10 +200,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reads", type=int, default=50_000_000, help="reads per GPU")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the configuration's size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--decision-only", action="store_true", help="no compaction: 154 B/read variant (not the headline)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
     import torch
     import torch.distributed as dist
@@ -105,17 +223,26 @@ def main():
     # RCCL all-gather, which orders itself after that stream -- so the gather reads the counters of the pass just enqueued.
     torch.cuda.set_stream(torch.cuda.Stream(device=local))
     eng = Engine(local)
-    R, L = args.reads, READ_LEN
+    R, L = (args.reads or cfg["reads"]), cfg["L"]
     lo = rank * R                                  # weak scaling: rank g owns reads [g*R, (g+1)*R) of the global set
-    bases, qual = eng.synth(SEED, lo, R, L, False)
-    params = make_params(**PARAMS)
-    compact = not args.decision_only
-    outs = eng.alloc_outputs(R, L, compact=compact, meta=False)
+    bases, qual = eng.synth(cfg["seed"], lo, R, L, cfg["adapter"])
+    is_stats = cfg["params"] is None
+    compact = not args.decision_only and not is_stats
+    if is_stats:
+        hist = torch.zeros((L, 5, 128), dtype=torch.int64, device=eng.device)
+        counters_dev = torch.zeros(24, dtype=torch.int64, device=eng.device)
+    else:
+        params = make_params(**cfg["params"])
+        # per-kept-read metadata (out_len / kept_index / out_off, 14 B per kept read) is not requested: the packed stream and res[] are
+        outs = eng.alloc_outputs(R, L, compact=compact, meta=False)
     torch.cuda.synchronize()
 
     gathered = [None]
 
     def step():
+        if is_stats:
+            eng.quality_stats(bases, qual, fixed_len=L, hist=hist, sync=False)
+            return None
         r = eng.run(bases, qual, params, fixed_len=L, compact=compact, meta=False, outputs=outs)
         if world > 1:
             gathered[0] = fxd.gather_counters(outs["counters"])   # 192-byte all-gather, enqueued after the kernels, no host sync
@@ -140,60 +267,88 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    counters = res.counters
-    kept, kept_bytes = int(counters[1]), int(counters[2])
-    if world > 1:                                  # job totals and this rank's offsets in the global output, from the last step's gather
-        totals, read_off, byte_off, _ = fxd.offsets_from_gathered(gathered[0], rank)
-        assert int(totals[0]) == R * world
+    if is_stats:
+        kept, kept_bytes = R, R * L
+        assert int(hist.sum().item()) == R * L * (args.warmup + args.steps)
+    else:
+        counters = res.counters
+        kept, kept_bytes = int(counters[1]), int(counters[2])
+        if world > 1:                              # job totals and this rank's offsets in the global output, from the last step's gather
+            totals, read_off, byte_off, _ = fxd.offsets_from_gathered(gathered[0], rank)
+            assert int(totals[0]) == R * world
 
     # kernel-level time of the dominant kernel: HIP events on the launch stream, one launch at a time
     eng.set_profiling(True)
     kms = []
     for _ in range(max(5, min(args.steps, 20))):
-        eng.run(bases, qual, params, fixed_len=L, compact=compact, meta=False, outputs=outs)
+        step()
         kms.append(eng.last_kernel_ms())
     eng.set_profiling(False)
     kavg = sum(kms) / len(kms)
     launch = eng.last_launch()
     # algorithmic bytes per launch: read 2L per read, write 4 B result per read + 2*new_len per kept read
-    alg_bytes = R * (2 * L + 4) + 2 * kept_bytes if compact else R * (L + 4)
+    if is_stats:
+        alg_bytes = R * 2 * L
+    else:
+        alg_bytes = R * (2 * L + 4) + 2 * kept_bytes if compact else R * (L + 4)
     achieved = alg_bytes / (kavg * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_source = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
+    if args.config == "cfg2" and os.path.exists(pmc):
         try:
             pj = json.load(open(pmc))
-            traffic = pj.get("hbm_bytes_per_launch") if (pj.get("reads_per_launch") == R and compact) else None
+            if pj.get("reads_per_launch") == R and compact:
+                traffic = pj.get("hbm_bytes_per_launch")
+                traffic_source = "replayed from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of %s, kernel %s); not measured in this run" % (
+                    pj.get("command", "scripts/pmc_run.py"), pj.get("kernel_version", "as committed"))
         except Exception:
             traffic = None
 
     if rank == 0:
         total_reads = R * world * args.steps
         out = {
-            "metric": "Mreads/s (150 bp) quality-trim+filter",
+            "metric": cfg["metric"],
             "value": round(total_reads / dt / 1e6, 2),
             "unit": "Mreads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
+            "dtype": "f32" if cfg["bound"] == "valu" else "u8", "data": "synthetic",
             "config": {
-                "workload": "cfg2: fastq_quality_trimmer -t 20 -l 30 | fastq_quality_filter -q 20 -p 80, %d x %d bp Phred+33 reads per GPU, "
-                            "%s" % (R, L, "one fused pass with order-preserving compaction of the kept trimmed reads" if compact
-                                    else "decision-only pass (no compaction)"),
-                "reads_per_gpu": R, "read_len": L, "seed": SEED, "kept_reads_per_gpu": kept, "kept_bases_per_gpu": kept_bytes,
+                "workload": "%s: %s, %d x %d bp Phred+33 reads per GPU, %s" % (
+                    args.config, cfg["what"], R, L,
+                    "histogram hist[column][A,C,G,T,N][quality] accumulated on the device" if is_stats else
+                    "one fused pass with order-preserving compaction of the kept trimmed reads (packed bases + qualities and the 4-byte per-read "
+                    "result res[]; the optional per-kept-read out_len/kept_index/out_off arrays are not requested)" if compact
+                    else "decision-only pass (no compaction)"),
+                "reads_per_gpu": R, "read_len": L, "seed": cfg["seed"], "kept_reads_per_gpu": kept, "kept_bases_per_gpu": kept_bytes,
                 "gbases_per_s_in": round(total_reads * L / dt / 1e9, 2), "parallelism": "reads sharded x%d, no data-path collective" % world,
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": launch["kernel"], "kernel_ms_avg": round(kavg, 4), "kernel_ms_min": round(min(kms), 4),
                 "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_read": round(alg_bytes / R, 2),
                 "grid": launch["grid"], "block": launch["block"], "lds_bytes": launch["lds"], "tile_reads": launch["tile_reads"],
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if cfg["bound"] == "valu":
+            # the aligner is a per-thread fp32 dynamic program: L x 13 cells per read, bounded by VALU issue, not by HBM
+            cells = R * L * len(ADAPTER)
+            gcups = cells / (kavg * 1e-3) / 1e9
+            out["roofline"]["valu"] = {
+                "gcups": round(gcups, 1), "cells_per_launch": cells, "valu_instr_per_cell": CLIP_VALU_PER_CELL,
+                "achieved_glaneops": round(gcups * CLIP_VALU_PER_CELL, 1), "peak_glaneops": round(VALU_PEAK_GLANEOPS, 1),
+                "issue_frac": round(gcups * CLIP_VALU_PER_CELL / VALU_PEAK_GLANEOPS, 4),
+                "note": "bound is VALU issue (the `hbm` numbers above are low by construction); peak = 256 CUs x 4 SIMDs x 64 lanes / %.0f cycles x 2.4 GHz" % VALU_CYCLES,
+            }
+        if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
             out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_e2e and args.config == "cfg2":
+            try:
+                out["e2e"] = e2e_leg()
+            except Exception as e:                         # the end-to-end leg must never take the headline line down
+                out["e2e"] = {"error": repr(e)[:200]}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -53,8 +53,13 @@ struct FxgKArgs {
     u32      *kept_index;
     u64      *out_off;
     // engine state
-    u64 *status_cnt;        // [ntiles] decoupled look-back granules (kept reads)
+    u64 *status_cnt;        // [ntiles] decoupled look-back granules (kept reads)            -- FXG_SCANNER == 0 builds only
     u64 *status_bytes;      // [ntiles] decoupled look-back granules (kept bytes)
+    u64 *agg;               // [ntiles]   tile totals   {tag:8 | kept reads:16 << 32 | kept bytes:32}, published by the tile's workgroup
+    u64 *pfx;               // [2*ntiles] exclusive prefixes {tag:8 | value:56}: [2t] kept reads before tile t, [2t+1] kept bytes before it (scanner)
+    u32 *role;              // the workgroup that draws 0 here becomes the scanner
+    u32  tag;               // launch epoch 1..255: granules of earlier launches are invalid without a memset
+    u32  qlds;              // the tile's quality rows stay in LDS between stage A and the gather (no second HBM read)
     u64 *partial;           // [count grid][FXG_NCOUNTERS]
     u32 *ticket;            // dynamic tile dispensers, FXG_TICKET_STRIDE words apart (zeroed before every launch)
     u32  ticket_groups;     // number of dispensers (<= 8): dispenser g hands out tiles g, g+groups, g+2*groups, ...
@@ -246,6 +251,10 @@ __device__ __forceinline__ void fxg_granule_store(u64 *g, u64 status, u64 value)
 {
     __hip_atomic_store(g, (status << 62) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void fxg_granule_store_raw(u64 *g, u64 v)
+{
+    __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ u64 fxg_granule_load(u64 *g)
 {
     return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -343,6 +352,104 @@ __device__ __forceinline__ void fxg_resolve_prefix(const FxgKArgs &a, u32 tile, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Central scanner (FXG_SCANNER builds).  The tiles' (kept reads, kept bytes) totals must be turned into exclusive prefixes in
+// tile order.  Instead of every tile walking back over its predecessors (1 000+ tiles are in flight, so a walk is dozens of
+// dependent memory round trips), ONE wave does nothing else: it polls the totals in tile order, 64 * FXG_SCAN_K granules per
+// round trip, prefix-sums whatever contiguous run has been published and writes the prefixes back; a tile then needs ONE load
+// of its own prefix.  The scanner is whichever workgroup draws 0 from a role counter at kernel start, so it is running by
+// construction; it only ever waits for totals of tiles whose tickets were drawn (their owners are running and publish before
+// they wait for anything), and a tile only waits for the scanner: progress is independent of residency, dispatch order and
+// placement.  Granules carry the launch's epoch tag, are written by ONE relaxed agent-scope store and polled with relaxed
+// agent-scope loads (the data is its own flag: no fences).
+// ------------------------------------------------------------------------------------------------
+#ifndef FXG_SCAN_K
+#define FXG_SCAN_K 8
+#endif
+#define FXG_TAG_SHIFT 56
+#define FXG_TAG_VALUE(x) ((x) & ((1ull << FXG_TAG_SHIFT) - 1ull))
+
+__device__ __forceinline__ void fxg_publish_total(const FxgKArgs &a, u32 tile, u32 cnt, u32 bytes)
+{
+    fxg_granule_store_raw(a.agg + tile, ((u64)a.tag << FXG_TAG_SHIFT) | ((u64)cnt << 32) | (u64)bytes);
+}
+
+// bounded spin shared by the scanner and the tiles: 2 s without progress, or somebody else already gave up
+__device__ __forceinline__ bool fxg_spin_expired(const FxgKArgs &a, u64 t0)
+{
+    const bool late = __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull;   // 100 MHz
+    const u32 flagged = __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & FXG_DEV_ERR_SCAN_TIMEOUT;
+    if (late || flagged) { atomicOr(a.errflag, FXG_DEV_ERR_SCAN_TIMEOUT); return true; }
+    return false;
+}
+
+// executed by ONE wave
+__device__ __forceinline__ void fxg_scanner(const FxgKArgs &a)
+{
+    const u32 lane = fxg_lane();
+    const u64 tagw = (u64)a.tag << FXG_TAG_SHIFT;
+    __builtin_amdgcn_s_setprio(3);                          // every tile waits for this wave: do not queue it behind its CU's streaming waves
+    u64 run_c = 0, run_b = 0;                               // exclusive prefix of tile t0
+    u32 t0 = 0, spins = 0;
+    u64 tlast = __builtin_amdgcn_s_memrealtime();
+    while (t0 < a.ntiles) {
+        u64 v[FXG_SCAN_K];
+#pragma unroll
+        for (u32 k = 0; k < FXG_SCAN_K; ++k) {              // all loads of the round are in flight together
+            const u64 idx = (u64)t0 + k * 64u + lane;
+            v[k] = idx < a.ntiles ? fxg_granule_load(a.agg + idx) : 0ull;
+        }
+        u32 adv = 0;
+        bool open = true;
+#pragma unroll
+        for (u32 k = 0; k < FXG_SCAN_K; ++k) {
+            if (!open) continue;                            // wave-uniform
+            const u64 idx = (u64)t0 + k * 64u + lane;
+            const bool valid = idx < a.ntiles && (u32)(v[k] >> FXG_TAG_SHIFT) == a.tag;
+            const u64 bal = __ballot(valid);
+            const u32 m = bal == ~0ull ? 64u : (u32)__builtin_ctzll(~bal);      // leading run of published totals
+            const u32 c = lane < m ? (u32)(v[k] >> 32) & 0xFFFFu : 0u, b = lane < m ? (u32)v[k] : 0u;
+            u32 ic = c, ib = b;                             // 64 tiles: at most 64 * 256 reads, 64 * 2^24 bytes
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const u32 tc = __shfl_up(ic, d, 64), tb = __shfl_up(ib, d, 64);
+                if ((int)lane >= d) { ic += tc; ib += tb; }
+            }
+            if (lane < m) {
+                fxg_granule_store_raw(a.pfx + 2 * idx, tagw | (run_c + (ic - c)));
+                fxg_granule_store_raw(a.pfx + 2 * idx + 1, tagw | (run_b + (ib - b)));
+            }
+            run_c += __shfl(ic, 63, 64); run_b += __shfl(ib, 63, 64);
+            adv += m;
+            open = (m == 64u);
+        }
+        t0 += adv;
+        if (adv) { spins = 0; tlast = __builtin_amdgcn_s_memrealtime(); continue; }
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 255u) == 0u && fxg_spin_expired(a, tlast)) return;   // never hang the GPU
+    }
+}
+
+// executed by wave 0 of a tile's workgroup: lanes 0 / 1 fetch the tile's (reads, bytes) prefix; `peek` is an earlier load of it
+__device__ __forceinline__ u64 fxg_peek_prefix(const FxgKArgs &a, u32 tile)
+{
+    const u32 lane = fxg_lane();
+    return lane < 2u ? fxg_granule_load(a.pfx + 2 * (u64)tile + lane) : ((u64)a.tag << FXG_TAG_SHIFT);
+}
+__device__ __forceinline__ void fxg_wait_prefix(const FxgKArgs &a, u32 tile, u64 peek, u64 *bc)
+{
+    const u32 lane = fxg_lane();
+    u64 v = peek;
+    u32 spins = 0;
+    const u64 t0 = __builtin_amdgcn_s_memrealtime();
+    while (__ballot((u32)(v >> FXG_TAG_SHIFT) != a.tag) != 0ull) {
+        __builtin_amdgcn_s_sleep(1);
+        if (lane < 2u) v = fxg_granule_load(a.pfx + 2 * (u64)tile + lane);
+        if ((++spins & 255u) == 0u && fxg_spin_expired(a, t0)) break;
+    }
+    if (lane < 2u) bc[lane] = FXG_TAG_VALUE(v);
+}
+
+// ------------------------------------------------------------------------------------------------
 // workgroup exclusive scan of (keep, out_len) over FXG_TBLOCK threads.  scratch: u32[2*FXG_TWAVES]
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void fxg_block_scan2(u32 c, u32 b, u32 *scratch, u32 *ex_c, u32 *ex_b, u32 *tot_c, u32 *tot_b)
@@ -430,6 +537,7 @@ FXG_HD void fxg_gather_byte(const FxgKArgs &a, const uint8_t *src_b, const uint8
 #endif
 struct FxgChunk { u32 o, k; int e, e2; u32x4 wb, wq, vb, vq; };
 
+// src_q: where the quality windows come from -- the batch in HBM, or (lq) the tile's quality rows kept in LDS by stage A
 template <bool REV, bool MASK>
 FXG_HD void fxg_chunk_load(FxgChunk &c, const uint8_t *src_b, const uint8_t *src_q, bool want_q, const u32 *k_off, const u32 *k_src,
                            const uint16_t *k_tab, u32 nk, u32 S, u32 o)
@@ -442,7 +550,7 @@ FXG_HD void fxg_chunk_load(FxgChunk &c, const uint8_t *src_b, const uint8_t *src
     c.o = o; c.k = k; c.e = e; c.e2 = 16;
     c.wb = fxg_ld16_stream(src_b + p1);
     c.wq = (u32x4){0u, 0u, 0u, 0u};
-    if (want_q) c.wq = fxg_ld16_stream(src_q + p1);
+    if (want_q) c.wq = fxg_ld16_stream(src_q + p1);      // LDS rows: ds_read_b128 at any byte offset (gfx950 has unaligned DS access)
     c.vb = c.vq = (u32x4){0u, 0u, 0u, 0u};
     if (e < 16) {                                                         // the chunk continues in the next kept read
         const u32 n2 = k_off[k + 2u] - e1;
@@ -453,9 +561,12 @@ FXG_HD void fxg_chunk_load(FxgChunk &c, const uint8_t *src_b, const uint8_t *src
     }
 }
 
-template <bool REV, bool MASK = false>
+// lq: the tile's quality rows in LDS (tile byte 0 at lq[0], 16 readable bytes either side), or null: read them from HBM again
+// LQ says at compile time whether lq is used, so that its loads are LDS instructions (a run-time choice between an LDS and an
+// HBM pointer would make them flat loads).
+template <bool REV, bool MASK = false, bool LQ = false>
 FXG_HD u32 fxg_tile_gather(const FxgKArgs &a, const u32 *k_off, const u32 *k_src, const uint16_t *k_tab, u32 nk,
-                           u64 tile_in_base, u32 tile_bytes, u64 B, u32 S, u32 tid, u32 nthreads)
+                           u64 tile_in_base, u32 tile_bytes, u64 B, u32 S, u32 tid, u32 nthreads, const uint8_t *lq = nullptr)
 {
     if (S == 0) return 0u;
     const bool has_q = a.qual != nullptr && a.out_qual != nullptr && !FXG_DBG(a, 4u);
@@ -481,7 +592,7 @@ FXG_HD u32 fxg_tile_gather(const FxgKArgs &a, const u32 *k_off, const u32 *k_src
         for (int u = 0; u < FXG_GATHER_K; ++u) {
             const u32 ci = c0 + (u32)u * nthreads;
             ch[u].e = 0;
-            if (ci < nfull) fxg_chunk_load<REV, MASK>(ch[u], src_b, src_q, has_q || MASK, k_off, k_src, k_tab, nk, S, o_lo + (ci << 4));
+            if (ci < nfull) fxg_chunk_load<REV, MASK>(ch[u], src_b, LQ ? lq : src_q, has_q || MASK, k_off, k_src, k_tab, nk, S, o_lo + (ci << 4));
         }
 #pragma unroll
         for (int u = 0; u < FXG_GATHER_K; ++u) {

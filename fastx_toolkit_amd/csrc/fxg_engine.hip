@@ -19,8 +19,13 @@ struct fxg_ctx {
     hipEvent_t ev0, ev1;
     hipEvent_t kev0, kev1;  // around the dominant kernel when profiling
     int profiling, kev_valid;
-    u64 *status;            // 2 * status_cap granules
+    u64 *status;            // 3 * status_cap granules: tile totals [cap], prefixes [2 * cap] (look-back builds: two arrays of [cap])
     size_t status_cap;      // in tiles
+    u32 epoch;              // tag of the granules of the current launch (1..255); 0 = never valid
+    void *attr_kernel[8];   // kernels whose launch attributes were set, with the LDS size and the occupancy answer
+    u32 attr_lds[8];
+    int attr_per_cu[8];
+    int env_blocks_per_cu, env_ticket_groups;   // tuning knobs, read once
     u64 *partial;           // partial_cap rows of FXG_NCOUNTERS
     size_t partial_cap;
     u32 *errflag;           // [0] device error bits; tile dispensers start at word FXG_TICKET_STRIDE
@@ -77,6 +82,8 @@ extern "C" int fxg_ctx_create(int device_id, fxg_ctx **out)
     c->cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { free(c); return FXG_E_HIP; }
     c->stream = c->own_stream;
+    { const char *e = getenv("FXG_BLOCKS_PER_CU"); c->env_blocks_per_cu = (e && atoi(e) > 0 && atoi(e) <= 16) ? atoi(e) : 0; }
+    { const char *e = getenv("FXG_TICKET_GROUPS"); c->env_ticket_groups = (e && atoi(e) > 0 && atoi(e) <= FXG_TICKET_GROUPS) ? atoi(e) : 0; }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreate(&c->kev0) != hipSuccess || hipEventCreate(&c->kev1) != hipSuccess ||
         hipMalloc((void **)&c->errflag, (FXG_TICKET_GROUPS + 1) * FXG_TICKET_STRIDE * sizeof(u32)) != hipSuccess ||
@@ -181,34 +188,61 @@ extern "C" int fxg_timer_stop(fxg_ctx *c, float *ms)
 // ------------------------------------------------------------------------------------------------
 #define FXG_COUNT_GRID 512u
 
+// dynamic-LDS attribute and occupancy of a kernel: asked once per (kernel, LDS size), not per launch
+template <typename K>
+static int fxg_kernel_fit(fxg_ctx *c, K kernel, const char *kname, u32 lds, int *per_cu)
+{
+    for (int i = 0; i < 8; ++i)
+        if (c->attr_kernel[i] == (void *)kernel && c->attr_lds[i] == lds) { *per_cu = c->attr_per_cu[i]; return FXG_OK; }
+    FXG_HIP(c, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FXG_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kernel, FXG_TBLOCK, lds));
+    if (*per_cu < 1) return fxg_fail(c, FXG_E_INVALID, "%s does not fit on a CU (lds=%u)", kname, lds);
+    int slot = 0;
+    for (int i = 0; i < 8; ++i) if (!c->attr_kernel[i]) { slot = i; break; }
+    c->attr_kernel[slot] = (void *)kernel; c->attr_lds[slot] = lds; c->attr_per_cu[slot] = *per_cu;
+    return FXG_OK;
+}
+
 template <typename K>
 static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &ka, u32 lds, u64 *counters)
 {
     FXG_HIP(c, hipSetDevice(c->device));
-    FXG_HIP(c, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0;
-    FXG_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, FXG_TBLOCK, lds));
-    if (per_cu < 1) return fxg_fail(c, FXG_E_INVALID, "%s does not fit on a CU (lds=%u)", kname, lds);
+    const int frc = fxg_kernel_fit(c, kernel, kname, lds, &per_cu);
+    if (frc != FXG_OK) return frc;
     // Tiles are dispensed by ticket, so nothing depends on every workgroup being resident: fill the chip.
     int use = per_cu > 8 ? 8 : per_cu;
-    const char *env = getenv("FXG_BLOCKS_PER_CU");
-    if (env && atoi(env) > 0 && atoi(env) <= 16) use = atoi(env);
-    u64 grid = (u64)c->cus * (u64)use;
-    if (grid > ka.ntiles) grid = ka.ntiles;
-    if (grid < 1) grid = 1;
+    if (c->env_blocks_per_cu > 0) use = c->env_blocks_per_cu;
+    u64 workers = (u64)c->cus * (u64)use;
+    if (workers > ka.ntiles) workers = ka.ntiles;
+    if (workers < 1) workers = 1;
+    const bool scan = FXG_SCANNER && ka.compact;            // one more workgroup: the scanner (fxg_device.h)
+    const u64 grid = workers + (scan ? 1u : 0u);
 
     if (ka.compact) {
+        bool fresh = false;
         if (c->status_cap < ka.ntiles) {
             (void)hipFree(c->status);
             c->status = nullptr; c->status_cap = 0;
             size_t cap = (size_t)ka.ntiles + (size_t)ka.ntiles / 4 + 1024;
-            FXG_HIP(c, hipMalloc((void **)&c->status, 2 * cap * sizeof(u64)));
+            FXG_HIP(c, hipMalloc((void **)&c->status, 3 * cap * sizeof(u64)));
             c->status_cap = cap;
+            fresh = true;
         }
+#if FXG_SCANNER
+        // granules carry the launch's epoch, so the arrays are only cleared when they are new or the 8-bit epoch wraps
+        c->epoch = c->epoch >= 255u ? 1u : c->epoch + 1u;
+        if (fresh || c->epoch == 1u) FXG_HIP(c, hipMemsetAsync(c->status, 0, 3 * c->status_cap * sizeof(u64), c->stream));
+        ka.agg = c->status;
+        ka.pfx = c->status + c->status_cap;
+        ka.tag = c->epoch;
+#else
+        (void)fresh;
         ka.status_cnt = c->status;
         ka.status_bytes = c->status + c->status_cap;
         FXG_HIP(c, hipMemsetAsync(ka.status_cnt, 0, (size_t)ka.ntiles * sizeof(u64), c->stream));
         FXG_HIP(c, hipMemsetAsync(ka.status_bytes, 0, (size_t)ka.ntiles * sizeof(u64), c->stream));
+#endif
     }
     if (c->partial_cap < FXG_COUNT_GRID) {
         (void)hipFree(c->partial);
@@ -220,10 +254,13 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
 #ifdef FXG_ABLATION
     { const char *dbg = getenv("FXG_DEBUG"); ka.debug = dbg ? (u32)atoi(dbg) : 0u; }
 #endif
-    ka.errflag = c->errflag;
+    ka.errflag = c->errflag;                     // control block (zeroed before every launch): [0] error bits, [2..5] masker sums, [8] scanner role
     ka.ticket = c->errflag + FXG_TICKET_STRIDE;
-    ka.extra = (u64 *)(c->errflag + 2);          // words 2..5 of the (zeroed) control block
-    { const char *tg = getenv("FXG_TICKET_GROUPS"); u32 g = (tg && atoi(tg) > 0 && atoi(tg) <= FXG_TICKET_GROUPS) ? (u32)atoi(tg) : FXG_TICKET_GROUPS; ka.ticket_groups = g < grid ? g : (u32)grid; }
+    ka.extra = (u64 *)(c->errflag + 2);
+    ka.role = c->errflag + 8;
+    // Dispenser g serves the workgroups with blockIdx % groups == g, so every group needs a worker even if the scanner role
+    // falls to one of its members: eight groups only when each has at least two workgroups.
+    { u32 g = c->env_ticket_groups > 0 ? (u32)c->env_ticket_groups : FXG_TICKET_GROUPS; ka.ticket_groups = grid >= 2u * g ? g : 1u; }
     FXG_HIP(c, hipMemsetAsync(c->errflag, 0, (FXG_TICKET_GROUPS + 1) * FXG_TICKET_STRIDE * sizeof(u32), c->stream));
 
     if (c->profiling) FXG_HIP(c, hipEventRecord(c->kev0, c->stream));

@@ -19,23 +19,36 @@
 #define FXG_INVALID_TUPLE 0xFFFFFFFFu
 
 // LDS carve-up shared by host (size) and device (pointers); every region is 16-byte aligned (G17).
-// k_off / k_src / k_idx / k_tab (the tile's kept reads, see fxg_tile_gather) are double buffered: stage B of tile i reads
-// slot s while stage A of tile i+1 fills slot s^1.
+// A slot holds what the gather of one tile needs: k_off / k_src / k_idx / k_tab (the tile's kept reads, see fxg_tile_gather)
+// and, when the quality rows are retained (qlds), the tile's quality rows themselves with 16 spare bytes either side (a
+// 16-byte window may start up to 15 bytes before the first row and end up to 15 bytes after the last).
+// FXG_SLOTS == 2: stage B of tile i reads slot s while stage A of tile i+1 fills slot s^1.  FXG_SLOTS == 1 (FXG_SAMESTEP):
+// a tile is gathered in the step that decided it.
+#ifndef FXG_SAMESTEP
+#define FXG_SAMESTEP 0
+#endif
+#ifndef FXG_SCANNER
+#define FXG_SCANNER 1
+#endif
+#define FXG_SLOTS (FXG_SAMESTEP ? 1u : 2u)
 struct FxgLds {
-    u32 slot_bytes, so_ksrc, so_kidx, so_ktab;   // slot k lives at k * slot_bytes: k_off at +0, k_src at +so_ksrc, k_idx at +so_kidx, k_tab at +so_ktab
+    u32 slot_bytes, so_ksrc, so_kidx, so_ktab, so_qrows;   // slot k lives at k * slot_bytes: k_off at +0, k_src at +so_ksrc, k_idx at +so_kidx, k_tab at +so_ktab, quality rows at +so_qrows
     u32 off_scratch, off_bm_g, off_bm_l, off_bases, total;
     u32 has_tab;                                 // kernels that stage a tile of bases in LDS (clipper, census) spend no LDS on k_tab
+    u32 has_qrows;
 };
 __host__ __device__ inline u32 fxg_r16(u32 x) { return (x + 15u) & ~15u; }
-__host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, bool bitmaps, u32 stage_stride)   // stage_stride: row stride of the LDS copy of the tile's bases, 0 = none
+__host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, bool bitmaps, u32 stage_stride, bool qrows = false)   // stage_stride: row stride of the LDS copy of the tile's bases, 0 = none
 {
     FxgLds l;
     l.so_ksrc = fxg_r16((T + 1) * 4);
     l.so_kidx = l.so_ksrc + fxg_r16(T * 4);
     l.so_ktab = l.so_kidx + fxg_r16(T * 2);
     l.has_tab = stage_stride ? 0u : 1u;
-    l.slot_bytes = l.so_ktab + (l.has_tab ? fxg_r16(((T * stride + 15) / 16 + 1) * 2) : 0u);
-    u32 o = 2 * l.slot_bytes;
+    l.has_qrows = (qrows && bitmaps) ? 1u : 0u;
+    l.so_qrows = l.so_ktab + (l.has_tab ? fxg_r16(((T * stride + 15) / 16 + 1) * 2) : 0u);
+    l.slot_bytes = l.so_qrows + (l.has_qrows ? 16u + fxg_r16(T * stride) + 16u : 0u);
+    u32 o = FXG_SLOTS * l.slot_bytes;
     l.off_scratch = o; o += fxg_r16(48 * 4);
     const u32 words = (T * stride + 31) / 32 + 2;
     l.off_bm_g = o;    o += bitmaps ? fxg_r16(words * 4) : 0;
@@ -139,60 +152,75 @@ FXG_HD void fxg_clip_read(const FxgKArgs &a, const uint8_t *rd, int len, int row
 }
 
 // Packed form for reads <= 255 and adapters <= 31 (every BASELINE config): the whole path summary is ONE u32
-//   w = query_start:8 | target_start:5 | mismatches:5 | matches:5 | path_len:9      (path_len <= L + A <= 286)
-// which halves the selects and the registers of the general form.  0xFFFFFFFF cannot occur (query_start <= 254).
-#define FXG_PK_SZ1   1u
-#define FXG_PK_MAT1  (1u << 9)
-#define FXG_PK_MIS1  (1u << 14)
-// FIRST: row q == 0.  The "path enters the matrix here" test (w == FXG_INVALID_TUPLE) can only fire where a predecessor lies
-// outside the matrix: anywhere in row 0, and in column 0 of the other rows -- so rows q >= 1 test it at t == 0 only.
-// TN: the adapter may contain 'N'.  Without it the pair score and the summary increment of a cell are one select each on
-// "read base == adapter base" between two values fixed per row (an 'N' in the read makes both 0.1 / neutral).
+//   w = query_start:8 | target_start:5 | diagonal:5 | path_len:9 | matches:5      (path_len <= L + A <= 286)
+// `diagonal` counts the non-neutral diagonal steps (matches + mismatches): it grows by a constant of the row (0 when the read
+// base is 'N'), and `matches` sits in the lowest bits so that "+1 where read base == adapter base" is the carry-in of that
+// same addition (v_addc_co_u32): a diagonal step is ONE instruction.  mismatches = diagonal - matches at the end.
+#define FXG_PK_MAT1  1u
+#define FXG_PK_SZ1   (1u << 5)
+#define FXG_PK_DIA1  (1u << 14)
+// FIRST: row q == 0.  The "path enters the matrix here" test can only fire where a predecessor lies outside the matrix:
+// anywhere in row 0, and in column 0 of the other rows -- so rows q >= 1 test it at t == 0 only.
+// TN: the adapter may contain 'N'.  Without it the pair score of a cell is one select on "read base == adapter base" between
+// two values fixed per row (an 'N' in the read makes both 0.1 / neutral, and can never equal an adapter base).
 // W holds every cell's summary ALREADY extended by one gap step (w + SZ1): that is what both the cell below (up) and the cell to
 // the right in the next row (left) need, so the step is added once per cell instead of once per use; the diagonal adds the
-// difference (match / mismatch bits).  "No predecessor" is therefore FXG_INVALID_TUPLE + SZ1 = 0, which no real summary can be.
+// difference.  "No predecessor" is the value 0, which no extended summary can be (its path_len is >= 2).
+// Sm holds every cell's score minus the gap penalty for the same reason (one subtraction serves `up` and `left`).
+// Cell rule (sequence_alignment.cpp:380-417): strict '>' from diag to up to left, i.e. the maximum with ties going to diag, then up:
+//   score = max3(ul, up, left); diag iff score == ul; else up iff score == up; else left.
 template <int AMAX, bool EARLY, bool FIRST, bool TN>
-FXG_HD void fxg_clip_row_packed(const FxgKArgs &a, int A, u32 c, int q, float (&S)[AMAX], u32 (&W)[AMAX], float &best, u32 &bw, u32 &bq)
+FXG_HD void fxg_clip_row_packed(const FxgKArgs &a, int A, u32 c, int q, float (&S)[AMAX], float (&Sm)[AMAX], u32 (&W)[AMAX], float &best, u32 &bw, u32 &bq)
 {
     const bool qn = (c == (u32)'N');
     const float pair_eq = qn ? 0.1f : 1.0f, pair_ne = qn ? 0.1f : -1.0f;                 // sequence_alignment.h:157-169 for a target base that is not N
-    const u32 dx_eq = qn ? 0u : FXG_PK_MAT1, dx_ne = qn ? 0u : FXG_PK_MIS1;             // what a diagonal step adds beyond the length
-    float dS = 0.0f, uS = 0.0f;                            // S[q-1][-1] and S[q][-1]: query_border = 0 (N1 for q == 0)
-    u32 dW = 0u, uW = 0u;                                  // no predecessor left of column 0
+    const u32 dxr = qn ? 0u : FXG_PK_DIA1;                                               // what a diagonal step adds besides a match
     const float best_in = best;
+    // pass 1: everything a cell takes from the row above -- the diagonal candidates ul = S[q-1][t-1] + pair and their summaries.
+    // Done for the whole row first so that the old S / W values are dead before pass 2 overwrites them in place (no register
+    // rotation in the rolled row loop) and so that only the up/left chain is left on the dependent path.
+    float ul[AMAX];
+    u32 wd[AMAX], dWv[AMAX];
 #pragma unroll
     for (int t = 0; t < AMAX; ++t) {
         const u32 tc = (u32)(uint8_t)a.adapter[t];    // straight-line body, see fxg_clip_read
         const bool eq = (c == tc);
         float pair = eq ? pair_eq : pair_ne;
-        u32 dx = eq ? dx_eq : dx_ne;
+        const float dS = t ? S[t - 1] : 0.0f;              // S[q-1][-1]: query_border = 0 (N1 for q == 0)
+        const u32 dW = t ? W[t - 1] : 0u;                  // no predecessor left of column 0
         if (TN) {
             const bool tn = (tc == (u32)'N');
             pair = tn ? (qn ? 0.0f : 0.1f) : pair;
-            dx = tn ? 0u : dx;
+            wd[t] = dW + (tn ? 0u : dxr + (eq ? FXG_PK_MAT1 : 0u));
+        } else {
+            wd[t] = (dW + dxr) + (u32)eq;
         }
-        const float ul = dS + pair;
-        const float up = uS + -5.0f;
-        float left = S[t] + -5.0f;
+        ul[t] = dS + pair;
+        dWv[t] = dW;
+    }
+    // pass 2: the chain along the row
+    float uSm = -5.0f;                                     // S[q][-1] - 5
+    u32 uW = 0u;
+#pragma unroll
+    for (int t = 0; t < AMAX; ++t) {
+        const float up = uSm;
+        float left = Sm[t];
         if (EARLY && t > 3) left = (t - 3 > q) ? -100000.0f : left;                          // :387-389, only rows q < A-4
-        const bool g1 = up > ul;                                                             // diag > up > left on ties
-        float sc = g1 ? up : ul;
-        const bool g2 = left > sc;
-        sc = g2 ? left : sc;
+        const float sc = fmaxf(fmaxf(ul[t], up), left);
+        const bool isd = (sc == ul[t]), isu = (sc == up);
         u32 w;
         if (FIRST || t == 0) {                                                               // a predecessor may lie outside the matrix
-            u32 src = g1 ? uW : dW;
-            src = g2 ? W[t] : src;
-            const u32 step = (g1 || g2) ? 0u : dx;
+            const u32 src = isd ? dWv[t] : (isu ? uW : W[t]);
+            const u32 step = isd ? wd[t] - dWv[t] : 0u;
             w = (src == 0u) ? ((((u32)q << 24) | ((u32)t << 19)) + FXG_PK_SZ1 + step) : (src + step);   // the path enters the matrix here
         } else {
-            w = g1 ? uW : dW + dx;
-            w = g2 ? W[t] : w;
+            w = isu ? uW : W[t];
+            w = isd ? wd[t] : w;
         }
-        dS = S[t]; dW = W[t];
         const u32 wp = w + FXG_PK_SZ1;
-        S[t] = sc; W[t] = wp;
-        uS = sc; uW = wp;
+        const float scm = sc + -5.0f;
+        S[t] = sc; Sm[t] = scm; W[t] = wp;
+        uSm = scm; uW = wp;
         const bool gb = (sc > best) && (t < A);                                              // first maximum in query-major order
         best = gb ? sc : best; bw = gb ? w : bw;
     }
@@ -202,31 +230,31 @@ FXG_HD void fxg_clip_row_packed(const FxgKArgs &a, int A, u32 c, int q, float (&
 template <int AMAX, bool TN>
 FXG_HD void fxg_clip_rows_packed(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float &best, u32 &bw, u32 &bq, int &first_n)
 {
-    float S[AMAX];
+    float S[AMAX], Sm[AMAX];
     u32 W[AMAX];
     const int A = a.alen;
 #pragma unroll
-    for (int t = 0; t < AMAX; ++t) { S[t] = (t <= 3) ? 0.0f : -5.0f * (float)(t - 3); W[t] = 0u; }   // 0 = no predecessor (see fxg_clip_row_packed)
+    for (int t = 0; t < AMAX; ++t) { S[t] = (t <= 3) ? 0.0f : -5.0f * (float)(t - 3); Sm[t] = S[t] + -5.0f; W[t] = 0u; }   // 0 = no predecessor (see fxg_clip_row_packed)
     const int early_rows = (A - 4 < rows) ? (A - 4 > 0 ? A - 4 : 0) : rows;  // rows where "t - 3 > q" can still hold for some t < A
     int q = 0;
     if (rows > 0) {                                                           // row 0: every cell may start a path
         const u32 c = rd[0];
         first_n = (c == (u32)'N' && 0 < len) ? 0 : first_n;
-        if (early_rows > 0) fxg_clip_row_packed<AMAX, true, true, TN>(a, A, c, 0, S, W, best, bw, bq);
-        else fxg_clip_row_packed<AMAX, false, true, TN>(a, A, c, 0, S, W, best, bw, bq);
+        if (early_rows > 0) fxg_clip_row_packed<AMAX, true, true, TN>(a, A, c, 0, S, Sm, W, best, bw, bq);
+        else fxg_clip_row_packed<AMAX, false, true, TN>(a, A, c, 0, S, Sm, W, best, bw, bq);
         q = 1;
     }
 #pragma unroll 1
     for (; q < early_rows; ++q) {
         const u32 c = rd[q];
         first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
-        fxg_clip_row_packed<AMAX, true, false, TN>(a, A, c, q, S, W, best, bw, bq);
+        fxg_clip_row_packed<AMAX, true, false, TN>(a, A, c, q, S, Sm, W, best, bw, bq);
     }
 #pragma unroll 1
     for (; q < rows; ++q) {
         const u32 c = rd[q];
         first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
-        fxg_clip_row_packed<AMAX, false, false, TN>(a, A, c, q, S, W, best, bw, bq);
+        fxg_clip_row_packed<AMAX, false, false, TN>(a, A, c, q, S, Sm, W, best, bw, bq);
     }
 }
 
@@ -239,7 +267,8 @@ FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len, 
     int first_n = len;
     if (a.adapter_has_n) fxg_clip_rows_packed<AMAX, true>(a, rd, len, rows, best, bw, bq, first_n);    // uniform branch
     else fxg_clip_rows_packed<AMAX, false>(a, rd, len, rows, best, bw, bq, first_n);
-    fxg_clip_finish(a, len, (int)(bw >> 24), (int)((bw >> 19) & 31u), (int)((bw >> 14) & 31u), (int)(bw & 511u), (int)((bw >> 9) & 31u),
+    const int matches = (int)(bw & 31u), diag = (int)((bw >> 14) & 31u);
+    fxg_clip_finish(a, len, (int)(bw >> 24), (int)((bw >> 19) & 31u), diag - matches, (int)((bw >> 5) & 511u), matches,
                     (int)bq, first_n, out_len, keep, reason, clipped, adapter_only);
 }
 
@@ -289,7 +318,8 @@ FXG_HD void fxg_counts_to_slots(const FxgCounts &c, u32 stages, u64 *slot)
 #endif
 // phase 1: quality rows of the tile -> two bitmaps.  Full in-range tiles take the batched path: five
 // independent 16-byte loads per lane are issued before any is consumed.
-FXG_HD void fxg_phase_bitmaps(const FxgKArgs &a, u64 tb, u32 tbytes, u32 *bm_g, u32 *bm_l, u32 tid, u32 nthreads)
+// qrows (optional): LDS copy of the tile's quality rows, written as the 16-byte pieces go by (for the gather, see FxgLds)
+FXG_HD void fxg_phase_bitmaps(const FxgKArgs &a, u64 tb, u32 tbytes, u32 *bm_g, u32 *bm_l, u32 tid, u32 nthreads, uint8_t *qrows = nullptr)
 {
     const u32 Kg = (128u - a.tq) * 0x01010101u, Kf = (128u - a.fq) * 0x01010101u;
     const u32 nchunks = (tbytes + 15u) >> 4;
@@ -307,7 +337,10 @@ FXG_HD void fxg_phase_bitmaps(const FxgKArgs &a, u64 tb, u32 tbytes, u32 *bm_g, 
 #pragma unroll
             for (u32 u = 0; u < U; ++u) {
                 const u32 c = c0 + u * nthreads;
-                if (c < nchunks) { g16[c] = (uint16_t)fxg_mask16(v[u], Kg); l16[c] = (uint16_t)(~fxg_mask16(v[u], Kf)); }
+                if (c < nchunks) {
+                    g16[c] = (uint16_t)fxg_mask16(v[u], Kg); l16[c] = (uint16_t)(~fxg_mask16(v[u], Kf));
+                    if (qrows) *reinterpret_cast<u32x4 *>(qrows + ((size_t)c << 4)) = v[u];
+                }
             }
         }
         return;
@@ -317,6 +350,7 @@ FXG_HD void fxg_phase_bitmaps(const FxgKArgs &a, u64 tb, u32 tbytes, u32 *bm_g, 
         const u32x4 v = fxg_window(a.qual, (long long)(tb + o), a.total_bytes, 0, (int)(tbytes - o < 16u ? tbytes - o : 16u));
         g16[c] = (uint16_t)fxg_mask16(v, Kg);
         l16[c] = (uint16_t)(~fxg_mask16(v, Kf));
+        if (qrows) *reinterpret_cast<u32x4 *>(qrows + o) = v;
     }
 }
 
@@ -437,6 +471,7 @@ FXG_HD void fxg_write_kept_meta(const FxgKArgs &a, u64 rank, u32 olen, u32 read_
 #ifndef FXG_MIN_WAVES
 #define FXG_MIN_WAVES 5   // __launch_bounds__ 2nd argument (waves per SIMD) for the streaming instances: 5 workgroups/CU measured best
 #endif
+#define FXG_NO_TILE 0xFFFFFFFFu
 template <int AMAX, int MODE>
 __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void fxg_kernel_tiles(const FxgKArgs a)
 {
@@ -444,7 +479,7 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void f
     constexpr bool REV = (MODE == 2);
     const u32 T = a.tile_reads, stride = a.stride, tid = threadIdx.x;
     const bool use_q = (MODE == 0 && (a.stages & (FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0) || MODE == 3;
-    const FxgLds L = fxg_lds_layout(T, stride, use_q, (MODE == 0 && AMAX != 0) ? a.clip_stride : (MODE == 4 ? stride : 0u));
+    const FxgLds L = fxg_lds_layout(T, stride, use_q, (MODE == 0 && AMAX != 0) ? a.clip_stride : (MODE == 4 ? stride : 0u), a.qlds != 0u);
     u32 m_reads = 0, m_nt = 0, art_bad = 0;      // MODE 3 report counters / MODE 4 alphabet check, folded once at the end
     u32 *bm_g = reinterpret_cast<u32 *>(smem + L.off_bm_g);
     u32 *bm_l = reinterpret_cast<u32 *>(smem + L.off_bm_l);
@@ -453,6 +488,16 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void f
     u32 *s_tot = scratch + 2 * FXG_TWAVES, *s_ticket = s_tot + 4;
     u64 *bc = reinterpret_cast<u64 *>(s_tot + 8);                   // [0,2) broadcast of the resolved bases
 
+#if FXG_SCANNER
+    // One workgroup turns the tiles' totals into prefixes (fxg_scanner); the others process tiles.
+    if (a.compact) {
+        if (tid == 0) s_ticket[0] = atomicAdd(a.role, 1u);
+        __syncthreads();
+        const bool scanner = (s_ticket[0] == 0u);
+        __syncthreads();
+        if (scanner) { if (tid < 64) fxg_scanner(a); return; }
+    }
+#endif
     // Sharded dispenser: workgroup b draws from counter g = b % groups, which hands out tiles g, g+groups, ...
     // The smallest unfinished tile is always either owned by a running workgroup or the next ticket of its
     // counter (whose earlier tiles are all finished, so a workgroup of that group is about to draw it):
@@ -462,12 +507,16 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void f
     if (tid == 0) s_ticket[0] = atomicAdd(my_ticket, 1u);
     __syncthreads();
     u32 cur = s_ticket[0] * G + grp;
-    u32 pend = 0xFFFFFFFFu;
+    u32 pend = FXG_NO_TILE;
     u32 slot = 0, tk = 0;
     for (;;) {
-        u64 peek = 0;                                    // first look-back window of `pend`, in flight during stage A
-#ifndef FXG_V_NO_PEEK
-        if (tid < 64 && pend != 0xFFFFFFFFu && a.compact && !FXG_DBG(a, 2u)) peek = fxg_peek_window(a, pend);
+        u64 peek = 0;                                    // first look at the prefix of `pend`, in flight during stage A
+#if !FXG_SAMESTEP && !defined(FXG_V_NO_PEEK)
+#if FXG_SCANNER
+        if (tid < 64 && pend != FXG_NO_TILE && a.compact) peek = fxg_peek_prefix(a, pend);
+#else
+        if (tid < 64 && pend != FXG_NO_TILE && a.compact && !FXG_DBG(a, 2u)) peek = fxg_peek_window(a, pend);
+#endif
 #endif
         // ------------------------------ stage A: tile `cur` into slot `slot` ------------------------------
         if (cur < a.ntiles) {
@@ -477,8 +526,9 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void f
             const u32 nreads = left < (u64)T ? (u32)left : T;
             const u64 tb = (u64)r0 * stride;
             const u32 tbytes = nreads * stride;
+            unsigned char *sl = smem + slot * L.slot_bytes;
             if constexpr (MODE == 0 || MODE == 3 || MODE == 4) {
-                if (use_q && !FXG_DBG(a, 8u)) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, FXG_TBLOCK);
+                if (use_q && !FXG_DBG(a, 8u)) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, FXG_TBLOCK, L.has_qrows ? sl + L.so_qrows + 16u : nullptr);
                 if constexpr (MODE == 0 && AMAX != 0) fxg_phase_stage_bases(a.clip_src, a.clip_total, (u64)r0 * a.clip_stride, nreads * a.clip_stride, sb, tid, FXG_TBLOCK);
                 if constexpr (MODE == 4) fxg_phase_stage_bases(a.bases, a.total_bytes, tb, tbytes, sb, tid, FXG_TBLOCK);
                 __syncthreads();
@@ -493,7 +543,9 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void f
             u32 exc, exb, totc, totb;
             fxg_block_scan2(keep, keep ? olen : 0u, scratch, &exc, &exb, &totc, &totb);   // one __syncthreads inside
             if (a.compact) {
-                unsigned char *sl = smem + slot * L.slot_bytes;
+#if FXG_SCANNER
+                if (tid == 0) fxg_publish_total(a, cur, totc, totb);     // as early as possible: the scanner and every later tile wait for it
+#endif
                 u32 *k_off = reinterpret_cast<u32 *>(sl);
                 if (tid < nreads && keep) {                          // kept reads only, indexed by their rank inside the tile
                     k_off[exc] = exb;
@@ -502,13 +554,20 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void f
                     if (L.has_tab) fxg_tab_fill(reinterpret_cast<uint16_t *>(sl + L.so_ktab), exc, exb, olen);
                 }
                 if (tid == 0) { k_off[totc] = totb; s_tot[2 * slot] = totc; s_tot[2 * slot + 1] = totb; }
+#if !FXG_SCANNER
                 if (tid < 64 && !FXG_DBG(a, 2u)) fxg_publish_aggregate(a, cur, totc, totb);
+#endif
             }
         }
-        // ------------------------------ stage B: tile `pend` from slot `slot ^ 1` ------------------------------
-        if (pend != 0xFFFFFFFFu && a.compact) {
-            const u32 ps = slot ^ 1u;
-            const u32 r0 = pend * T;
+        // ------------------------------ stage B: gather a decided tile ------------------------------
+        // two slots: the tile of the previous step (its prefix has had a whole stage A to arrive); one slot: this step's tile
+#if FXG_SAMESTEP
+        const u32 bt = cur < a.ntiles ? cur : FXG_NO_TILE, ps = 0u;
+#else
+        const u32 bt = pend, ps = slot ^ 1u;
+#endif
+        if (bt != FXG_NO_TILE && a.compact) {
+            const u32 r0 = bt * T;
             const u64 left = a.n - (u64)r0;
             const u32 nreads = left < (u64)T ? (u32)left : T;
             const unsigned char *sl = smem + ps * L.slot_bytes;
@@ -517,28 +576,41 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void f
             const uint16_t *k_idx = reinterpret_cast<const uint16_t *>(sl + L.so_kidx);
             const uint16_t *k_tab = L.has_tab ? reinterpret_cast<const uint16_t *>(sl + L.so_ktab) : nullptr;
             if (tid < 64) {
+#if FXG_SCANNER
+#if FXG_SAMESTEP || defined(FXG_V_NO_PEEK)
+                peek = fxg_peek_prefix(a, bt);
+#endif
+                fxg_wait_prefix(a, bt, peek, bc);
+#else
                 u64 base_c = 0, base_b = 0;
 #ifdef FXG_V_NO_PEEK
-                peek = fxg_peek_window(a, pend);
+                peek = fxg_peek_window(a, bt);
 #endif
-                if (!FXG_DBG(a, 2u)) fxg_resolve_prefix(a, pend, s_tot[2 * ps], s_tot[2 * ps + 1], peek, &base_c, &base_b);
+                if (!FXG_DBG(a, 2u)) fxg_resolve_prefix(a, bt, s_tot[2 * ps], s_tot[2 * ps + 1], peek, &base_c, &base_b);
                 if (tid == 0) { bc[0] = base_c; bc[1] = base_b; }
+#endif
             }
-            __syncthreads();
+            __syncthreads();                             // bc; in one-slot builds also the slot just filled by stage A
             const u64 base_c = bc[0], base_b = bc[1];
             const u32 nk = s_tot[2 * ps], totb = s_tot[2 * ps + 1];
             if (tid < nk) fxg_write_kept_meta(a, base_c + tid, k_off[tid + 1] - k_off[tid], r0 + k_idx[tid], base_b + k_off[tid]);
             if (!FXG_DBG(a, 1u)) {
-                const u32 bad = fxg_tile_gather<REV, MODE == 3>(a, k_off, k_src, k_tab, nk, (u64)r0 * stride, nreads * stride, base_b, totb, tid, FXG_TBLOCK);
+                u32 bad;
+                if ((MODE == 0 || MODE == 3) && L.has_qrows)        // uniform branch: quality windows from the slot's rows in LDS
+                    bad = fxg_tile_gather<REV, MODE == 3, true>(a, k_off, k_src, k_tab, nk, (u64)r0 * stride, nreads * stride, base_b, totb, tid, FXG_TBLOCK, sl + L.so_qrows + 16u);
+                else
+                    bad = fxg_tile_gather<REV, MODE == 3, false>(a, k_off, k_src, k_tab, nk, (u64)r0 * stride, nreads * stride, base_b, totb, tid, FXG_TBLOCK);
                 if (REV && bad) atomicOr(a.errflag, FXG_DEV_ERR_BAD_BASE);
             }
         }
         if (cur >= a.ntiles) break;
-        __syncthreads();            // ticket written by thread 0 in stage A; also fences slot reuse two iterations apart
+        __syncthreads();            // ticket written by thread 0 in stage A; also fences slot reuse (two steps apart with two slots)
         pend = cur;
         tk ^= 1u;
         cur = s_ticket[tk] * G + grp;
+#if !FXG_SAMESTEP
         slot ^= 1u;
+#endif
     }
     if constexpr (MODE == 3) {                       // masked reads / nucleotides: wave sums, one atomic pair per wave, once
         for (int d = 32; d >= 1; d >>= 1) { m_reads += __shfl_xor(m_reads, d, 64); m_nt += __shfl_xor(m_nt, d, 64); }

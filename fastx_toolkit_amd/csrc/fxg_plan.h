@@ -7,6 +7,13 @@
 
 #include "fxg_kernels.h"
 
+#ifndef FXG_QLDS_DEFAULT
+#define FXG_QLDS_DEFAULT 1
+#endif
+#ifndef FXG_QLDS_BUDGET
+#define FXG_QLDS_BUDGET (52u * 1024u)
+#endif
+
 struct FxgPlan {
     FxgKArgs ka;
     bool group_a;   // [CLIP][QTRIM][QFILTER] chain (else [REVCOMP][FTRIM*] unless mode3/mode4)
@@ -29,13 +36,14 @@ static inline u32 fxg_pick_tile(u32 stride, bool clip)
     return T;
 }
 
-static inline u32 fxg_plan_lds(const FxgPlan *pl)
+static inline FxgLds fxg_plan_layout(const FxgPlan *pl)
 {
     const FxgKArgs &ka = pl->ka;
-    return pl->group_a ? fxg_lds_layout(ka.tile_reads, ka.stride, pl->use_q, pl->clip ? ka.clip_stride : 0u).total
-         : pl->mask ? fxg_lds_layout(ka.tile_reads, ka.stride, true, 0u).total
-         : pl->artifacts ? fxg_lds_layout(ka.tile_reads, ka.stride, false, ka.stride).total : fxg_lds_layout(ka.tile_reads, ka.stride, false, 0u).total;
+    return pl->group_a ? fxg_lds_layout(ka.tile_reads, ka.stride, pl->use_q, pl->clip ? ka.clip_stride : 0u, ka.qlds != 0u)
+         : pl->mask ? fxg_lds_layout(ka.tile_reads, ka.stride, true, 0u, ka.qlds != 0u)
+         : pl->artifacts ? fxg_lds_layout(ka.tile_reads, ka.stride, false, ka.stride) : fxg_lds_layout(ka.tile_reads, ka.stride, false, 0u);
 }
+static inline u32 fxg_plan_lds(const FxgPlan *pl) { return fxg_plan_layout(pl).total; }
 
 #define FXG_PLAN_FAIL(...) do { snprintf(err, cap, __VA_ARGS__); return FXG_E_INVALID; } while (0)
 
@@ -100,7 +108,22 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
         for (unsigned i = 0; i < sizeof pk / sizeof pk[0]; ++i) if (ka.alen <= pk[i]) { b = pk[i]; break; }
         pl->amax = -b;
     }
-    const u32 T = fxg_pick_tile(pl->clip ? ka.clip_stride : in->stride, pl->clip || gf);
+    u32 T = fxg_pick_tile(pl->clip ? ka.clip_stride : in->stride, pl->clip || gf);
+    // Quality rows retained in LDS for the gather (no second pass over them in HBM): streaming kernels that build the quality
+    // bitmaps and compact.  The tile shrinks until FXG_QLDS_BUDGET bytes of LDS hold a workgroup (3 workgroups per CU by default).
+    ka.qlds = 0u;
+    if (ka.compact && !pl->clip && (pl->use_q || gm)) {
+        const char *e = getenv("FXG_QLDS");
+        ka.qlds = (e ? atoi(e) : FXG_QLDS_DEFAULT) ? 1u : 0u;
+        if (ka.qlds) {
+            const char *be = getenv("FXG_QLDS_BUDGET");
+            const u32 budget = (be && atoi(be) >= 4096) ? (u32)atoi(be) : FXG_QLDS_BUDGET;
+            u32 Tq = T;
+            while (Tq > 16 && fxg_lds_layout(Tq, in->stride, true, 0u, true).total > budget) Tq >>= 1;
+            if (fxg_lds_layout(Tq, in->stride, true, 0u, true).total > budget + budget / 2) ka.qlds = 0u;   // long reads: read the rows twice instead
+            else T = Tq;
+        }
+    }
     const u64 ntiles = (in->n + T - 1) / T;
     if (ntiles > 0x7FFFFFFFull || in->n > 0xFFFFFFFFull) FXG_PLAN_FAIL("batch too large (%llu reads): split it", (unsigned long long)in->n);
     ka.tile_reads = T; ka.ntiles = (u32)ntiles;

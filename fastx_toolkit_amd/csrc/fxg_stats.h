@@ -6,30 +6,38 @@
 // order statistics of print_statistics (:218-340) follow from it on the host -- so the device only builds that.
 //
 // Work decomposition: every row is read from HBM once.  A workgroup owns a contiguous slice of the reads and the block
-// histogram of up to 160 columns -- 10 strips of 16 columns x 6 rows (A C G T N, other) x a 64-value window of the quality
-// byte, 16-bit counters, the two columns of a pair in one word, rows padded to 65 words so that the LDS bank depends on
-// strip, column and class as well as on the quality: 122 KB of LDS, updated with ds_add.  A work item is one 16-byte
-// piece (strip) of one row; consecutive lanes take consecutive pieces, so a wave reads 1 KB of contiguous rows per load
-// and its lanes spread over all ten strips (few same-bank, fewer same-address updates).  Before a counter could wrap
-// (65 535 reads) the workgroup adds the block to ITS OWN u32 partial in HBM (no atomics) and clears it.  Quality bytes
-// outside the window (Phred+33 codes 33..96 are inside) go straight to the result with a global atomic.  A second kernel
-// folds the partials into the caller's u64 histogram.  Reads longer than 160 take one pass per column block.
-// HBM-bound by design (2 bytes per base in, nothing out); measured limiter: VALU + LDS update issue, see DESIGN.md.
+// histogram of up to 160 columns -- 10 strips of 16 columns x 6 rows (A C G T N + a spare row for padding) x a 64-value
+// window of the quality byte, 16-bit counters, the two columns of a pair in one word: 120 KB of LDS, updated with ds_add.
+// A work item is one 16-byte piece (strip) of one row; consecutive lanes take consecutive pieces, so a wave reads 1 KB of
+// contiguous rows per load.  The workgroup is 960 threads wide -- a multiple of the 10 strips -- so a lane keeps ITS strip
+// for the whole kernel: the strip's LDS base, its swizzle and (fixed-length batches) the mask of its bytes past the end
+// of the read are loop invariants, and the read index advances by a constant.
+// Per-base work on the fast path (16 valid bases, qualities inside the window) is SWAR on dwords: one v_perm_b32 looks the
+// class of four bases up in an 8-entry table indexed by the low three bits of the letter (1 3 7 4 6 for A C G T N), a second
+// one yields the letter those bits should belong to (the validity test), qualities are rebased, scaled to byte offsets and
+// XOR-swizzled four at a time, and a third perm pairs class and offset into the 16-bit LDS address of each base
+// (row = class * 256 B), leaving one address add and one ds_add per base.
+// The swizzle (offset ^= 16 * class ^ 12 * strip, within the 256-byte row) makes the LDS bank depend on class and strip
+// as well as on the quality: reads of one wave share most of their quality values.
+// Before a counter could wrap (65 535 reads) the workgroup adds the block to ITS OWN u32 partial in HBM (no atomics) and
+// clears it.  Quality bytes outside the window (Phred+33 codes 33..96 are inside) go straight to the result with a global
+// atomic.  A second kernel folds the partials into the caller's u64 histogram.  Reads longer than 160 take one pass per
+// column block.  HBM-bound by design (2 bytes per base in, nothing out).
 #pragma once
 #include "fxg_device.h"
 
 #define FXG_QS_STRIP 16u
-#define FXG_QS_WAVES 10u                                   // strips per column block (the name is historic: not tied to waves any more)
-#define FXG_QS_TBLOCK 1024u                                // one workgroup per CU (LDS), so make it as wide as a workgroup gets
+#define FXG_QS_WAVES 10u                                   // strips per column block (the name is historic: not tied to waves)
+#define FXG_QS_TBLOCK 960u                                 // one workgroup per CU (LDS); a multiple of the strips per block AND of the wave size
 #define FXG_QS_BLOCK_COLS (FXG_QS_WAVES * FXG_QS_STRIP)    // 160 columns per pass
 #define FXG_QS_WBASE 33u                                   // first quality byte of the LDS window
 #define FXG_QS_WBINS 64u
 #define FXG_QS_PART_WORDS (FXG_QS_BLOCK_COLS * FXG_QS_CLASSES * FXG_QS_WBINS)   // one workgroup's partial (u32) = 51 200 counters
-#define FXG_QS_LROWS 6u                                    // LDS rows per column pair: A C G T N + one for bytes that are none of them (never flushed)
-#define FXG_QS_LROW_WORDS (FXG_QS_WBINS + 1u)              // +1: bank = f(strip, column pair, row, quality), not of the quality alone
+#define FXG_QS_LROWS 6u                                    // LDS rows per column pair: A C G T N + the spare row (bytes past the end of a read; never flushed)
+#define FXG_QS_LROW_WORDS FXG_QS_WBINS                     // 256 bytes: class k of a pair lives at byte k << 8 of the pair's block
 #define FXG_QS_LDS_WORDS ((FXG_QS_BLOCK_COLS / 2u) * FXG_QS_LROWS * FXG_QS_LROW_WORDS)   // word = two u16 counters: even column low, odd column high
 #ifndef FXG_QS_UNROLL
-#define FXG_QS_UNROLL 2u                                   // reads per lane and trip
+#define FXG_QS_UNROLL 2u                                   // items per lane and trip
 #endif
 
 struct FxgStatsArgs {
@@ -51,6 +59,19 @@ struct FxgStatsArgs {
 #define FXG_LDS_ADD(p, v) ((void)atomicAdd((p), (v)))
 #define FXG_GLOBAL_INC64(p) ((void)atomicAdd((p), 1ull))
 #endif
+
+// v_perm_b32: byte i of the result is byte sel[i] of the 8-byte value {hi:lo} (selectors 0..3 -> lo, 4..7 -> hi)
+FXG_HD u32 fxg_perm(u32 hi, u32 lo, u32 sel)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    const u64 v = ((u64)hi << 32) | lo;
+    u32 r = 0;
+    for (int i = 0; i < 4; ++i) r |= (u32)((v >> (8u * ((sel >> (8 * i)) & 7u))) & 0xFFu) << (8 * i);
+    return r;
+#endif
+}
 
 // class of a base: A C G T N -> 0..4 (either case, fastx_quality_stats.c:142-155), anything else -> 5 (not counted)
 FXG_HD u32 fxg_stats_class(u32 c)
@@ -77,55 +98,73 @@ FXG_HD void fxg_stats_load(const FxgStatsArgs &a, u64 r, u32 strip, FxgStripRow 
     else { o.vb = fxg_window(a.bases, (long long)at, a.total_bytes, 0, (int)o.nb); if (a.qual) o.vq = fxg_window(a.qual, (long long)at, a.total_bytes, 0, (int)o.nb); }
 }
 
-// LDS word of (column j of strip `wave`, row k, window bin w); the counter is its low half for even j, its high half for odd j
-FXG_HD u32 fxg_stats_word(u32 wave, u32 j, u32 k, u32 w) { return (((wave * (FXG_QS_STRIP / 2u) + (j >> 1)) * FXG_QS_LROWS + k) * FXG_QS_LROW_WORDS) + w; }
+// LDS layout.  Byte offset of the counter word of (strip s of the block, column j of the strip, class k, window bin w):
+//   block of the column pair  (s * 8 + j / 2) * 6 * 256
+//   row of the class          k * 256
+//   swizzled bin              (4 * w) ^ fxg_stats_swz(s, k)
+// the counter is the word's low half for even j, its high half for odd j.
+FXG_HD u32 fxg_stats_swz(u32 s, u32 k) { return ((k << 4) ^ (s * 12u)) & 0xFCu; }
+FXG_HD u32 fxg_stats_pair_base(u32 s, u32 j) { return (s * (FXG_QS_STRIP / 2u) + (j >> 1)) * (FXG_QS_LROWS * FXG_QS_LROW_WORDS * 4u); }
+FXG_HD u32 fxg_stats_byte(u32 s, u32 j, u32 k, u32 w) { return fxg_stats_pair_base(s, j) + (k << 8) + ((w << 2) ^ fxg_stats_swz(s, k)); }
 
-// row of a base that is known to be a letter (bit 6 set, bit 7 clear): A C G T N -> 0..4 in either case, any other letter -> 5.
-// The low five bits of the five letters are 1, 3, 7, 20, 14; their low three bits (1, 3, 7, 4, 6) index a 3-bit table.
-FXG_HD u32 fxg_stats_row_of_letter(u32 b)
+// masks of the bytes of a 16-byte strip piece that lie inside a read with nb bytes in this strip
+FXG_HD void fxg_stats_masks(u32 nb, u32 (&m)[4])
 {
-    const u32 x = b & 31u;
-    const u32 valid = (((1u << 1) | (1u << 3) | (1u << 7) | (1u << 20) | (1u << 14)) >> x) & 1u;
-    const u32 k = (0x503200u >> (3u * (x & 7u))) & 7u;
-    return valid ? k : 5u;
+#pragma unroll
+    for (u32 d = 0; d < 4u; ++d) {
+        const int keep = (int)nb - (int)(4u * d);
+        m[d] = fxg_lowbytes32(keep < 0 ? 0 : (keep > 4 ? 4 : keep));
+    }
 }
 
-FXG_HD void fxg_stats_accumulate(const FxgStatsArgs &a, const FxgStripRow &o, u32 wave, u32 col0, u32 *lds)
+// table of the fast path, indexed by the low three bits of a letter: '@' 0, A 1, C 3, T 4, N 6, G 7 (2 and 5 belong to no base)
+//   expected upper-case letter:  40 41 00 43 54 00 4E 47        class row:  5 0 - 1 3 - 4 2
+#define FXG_QS_EXP_LO 0x43004140u
+#define FXG_QS_EXP_HI 0x474E0054u
+#define FXG_QS_ROW_LO 0x01070005u
+#define FXG_QS_ROW_HI 0x02040703u
+
+// sl: strip of the block (LDS position); m: fxg_stats_masks(o.nb)
+FXG_HD void fxg_stats_accumulate(const FxgStatsArgs &a, const FxgStripRow &o, u32 sl, u32 col0, const u32 (&m)[4], u32 *lds)
 {
     if (o.nb == 0u) return;
     u32 wb[4] = {o.vb.x, o.vb.y, o.vb.z, o.vb.w}, wq[4] = {o.vq.x, o.vq.y, o.vq.z, o.vq.w};
-    // Fast path: 16 letters whose quality bytes all lie in the window -- no per-base test, no branch.  Bytes past the end of
-    // the read (the last strip of a row, ragged reads) are first replaced by '@' (a letter that is no base: counted in the
-    // spare row) with quality WBASE, so that short strips take the fast path as well: in this item order every wave holds
-    // some, and a wave that has ONE lane on the slow path executes the slow path.
-    const u32 K_lo = (128u - FXG_QS_WBASE) * 0x01010101u, K_hi = (128u - (FXG_QS_WBASE + FXG_QS_WBINS)) * 0x01010101u;
-    u32 bad = 0u;
+    // Fast path: 16 bases A C G T N (either case) whose quality bytes all lie in the window -- no per-base test, no branch.
+    // Bytes past the end of the read (the last strip of a row, ragged reads) are first replaced by '@' (counted in the spare
+    // row) with quality WBASE, so that short strips take the fast path as well: every wave holds some, and a wave that has
+    // ONE lane on the slow path executes the slow path.
+    u32 bad = 0u, k4[4], o4[4];
+    const u32 sw = (sl * 12u) & 0xFCu;
 #pragma unroll
     for (u32 d = 0; d < 4u; ++d) {
-        const int keep = (int)o.nb - (int)(4u * d);
-        const u32 m = fxg_lowbytes32(keep < 0 ? 0 : (keep > 4 ? 4 : keep));
-        wb[d] = (wb[d] & m) | (0x40404040u & ~m);
-        wq[d] = (wq[d] & m) | ((FXG_QS_WBASE * 0x01010101u) & ~m);
-        bad |= (wb[d] & 0xC0C0C0C0u) ^ 0x40404040u;                                     // not a letter
-        bad |= (fxg_ge_flags(wq[d], K_lo) ^ 0x80808080u) | fxg_ge_flags(wq[d], K_hi);   // below / above the window (also catches bytes >= 128)
+        const u32 b = (wb[d] & m[d]) | (0x40404040u & ~m[d]);
+        const u32 q = (wq[d] & m[d]) | ((FXG_QS_WBASE * 0x01010101u) & ~m[d]);
+        const u32 sel = b & 0x07070707u;
+        bad |= fxg_perm(FXG_QS_EXP_HI, FXG_QS_EXP_LO, sel) ^ (b & 0xDFDFDFDFu);          // not one of @ A C G T N a c g t n
+        k4[d] = fxg_perm(FXG_QS_ROW_HI, FXG_QS_ROW_LO, sel);
+        const u32 w4 = q - FXG_QS_WBASE * 0x01010101u;                                   // a byte below the window borrows: its own result is then >= 0xDF
+        bad |= w4 & 0xC0C0C0C0u;                                                         // below / above the window
+        o4[d] = (w4 << 2) ^ (k4[d] << 4) ^ (sw * 0x01010101u);                           // fxg_stats_byte's swizzled bin offsets (k <= 5, so k << 4 stays inside its byte)
     }
     if (!bad) {
+        unsigned char *base = reinterpret_cast<unsigned char *>(lds) + fxg_stats_pair_base(sl, 0u);
 #pragma unroll
-        for (u32 j = 0; j < FXG_QS_STRIP; ++j) {
-            const u32 sh = 8u * (j & 3u);
-            const u32 k = fxg_stats_row_of_letter((wb[j >> 2] >> sh) & 0xFFu);
-            const u32 w = ((wq[j >> 2] >> sh) & 0xFFu) - FXG_QS_WBASE;
-            FXG_LDS_ADD(&lds[fxg_stats_word(wave, j, k, w)], (j & 1u) ? 0x10000u : 1u);
+        for (u32 j = 0; j < FXG_QS_STRIP; j += 2u) {
+            // halves of h: class << 8 | offset of base j (low) and of base j + 1 (high) = byte offset inside the pair's block
+            const u32 h = fxg_perm(k4[j >> 2], o4[j >> 2], (j & 2u) ? 0x07030602u : 0x05010400u);
+            unsigned char *pb = base + (j >> 1) * (FXG_QS_LROWS * FXG_QS_LROW_WORDS * 4u);
+            FXG_LDS_ADD(reinterpret_cast<u32 *>(pb + (h & 0xFFFFu)), 1u);
+            FXG_LDS_ADD(reinterpret_cast<u32 *>(pb + (h >> 16)), 0x10000u);
         }
         return;
     }
 #pragma unroll 1
-    for (u32 j = 0; j < o.nb; ++j) {                                                     // ragged ends, odd bytes, rare qualities: one base at a time
+    for (u32 j = 0; j < o.nb; ++j) {                                                     // odd bytes, rare qualities: one base at a time
         const u32 b = (wb[j >> 2] >> (8u * (j & 3u))) & 0xFFu, q = (wq[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
         const u32 k = fxg_stats_class(b);
         if (k >= FXG_QS_CLASSES || q >= FXG_QS_BINS) continue;
         const u32 w = q - FXG_QS_WBASE;
-        if (w < FXG_QS_WBINS) FXG_LDS_ADD(&lds[fxg_stats_word(wave, j, k, w)], (j & 1u) ? 0x10000u : 1u);
+        if (w < FXG_QS_WBINS) FXG_LDS_ADD(reinterpret_cast<u32 *>(reinterpret_cast<unsigned char *>(lds) + fxg_stats_byte(sl, j, k, w)), (j & 1u) ? 0x10000u : 1u);
         else if (col0 + j < a.hist_cols) FXG_GLOBAL_INC64(&a.hist[((u64)(col0 + j) * FXG_QS_CLASSES + k) * FXG_QS_BINS + q]);
     }
 }
@@ -141,13 +180,13 @@ FXG_HD void fxg_stats_slice(const FxgStatsArgs &a, u32 g, u64 *lo, u64 *hi)
 // thread `t` of `nt`: add the LDS block to the workgroup's partial ([column-in-block][class][window bin], u32) and clear it
 FXG_HD void fxg_stats_flush(u32 *lds, u32 *part, u32 t, u32 nt)
 {
-    for (u32 i = t; i < (FXG_QS_BLOCK_COLS / 2u) * FXG_QS_LROWS * FXG_QS_WBINS; i += nt) {
-        const u32 w = i % FXG_QS_WBINS, pk = i / FXG_QS_WBINS, k = pk % FXG_QS_LROWS, pair = pk / FXG_QS_LROWS;
-        u32 *l = lds + pk * FXG_QS_LROW_WORDS + w;
-        const u32 v = *l;
+    for (u32 i = t; i < FXG_QS_LDS_WORDS; i += nt) {
+        const u32 x = i % FXG_QS_LROW_WORDS, pk = i / FXG_QS_LROW_WORDS, k = pk % FXG_QS_LROWS, pair = pk / FXG_QS_LROWS;
+        const u32 v = lds[i];
         if (v == 0u) continue;
-        *l = 0u;
-        if (k >= FXG_QS_CLASSES) continue;                                   // the row of bytes that are not A C G T N
+        lds[i] = 0u;
+        if (k >= FXG_QS_CLASSES) continue;                                   // the spare row
+        const u32 w = x ^ (fxg_stats_swz(pair / (FXG_QS_STRIP / 2u), k) >> 2);   // undo the swizzle
         u32 *p = part + ((2u * pair) * FXG_QS_CLASSES + k) * FXG_QS_WBINS + w;
         p[0] += v & 0xFFFFu;
         p[FXG_QS_CLASSES * FXG_QS_WBINS] += v >> 16;
@@ -180,9 +219,15 @@ __global__ __launch_bounds__(FXG_QS_TBLOCK) void fxg_kernel_quality_stats(const 
     u64 lo, hi;
     fxg_stats_slice(a, blockIdx.x, &lo, &hi);
     const u64 nitems = (hi - lo) * FXG_QS_WAVES;
-    const u32 trip_reads = (FXG_QS_TBLOCK * FXG_QS_UNROLL + FXG_QS_WAVES - 1u) / FXG_QS_WAVES + 1u;   // reads a trip can touch
+    // FXG_QS_TBLOCK is a multiple of the strips per block: item g0 + u * TBLOCK + tid is strip tid % 10 of read lo + g / 10
+    const u32 sl = tid % FXG_QS_WAVES, rl = tid / FXG_QS_WAVES;
+    const u32 reads_per_step = FXG_QS_TBLOCK / FXG_QS_WAVES;                                           // 96
+    const u32 trip_reads = reads_per_step * FXG_QS_UNROLL;                                             // reads a trip touches
+    u32 mfix[4];                                                                                        // fixed-length batches: the lane's tail mask never changes
+    { const u32 c0 = (a.strip0 + sl) * FXG_QS_STRIP; fxg_stats_masks(a.fixed_len > c0 ? (a.fixed_len - c0 < FXG_QS_STRIP ? a.fixed_len - c0 : FXG_QS_STRIP) : 0u, mfix); }
     u32 since = 0;                                            // reads added to the LDS block since it was last cleared
-    for (u64 g0 = 0; g0 < nitems; g0 += (u64)FXG_QS_TBLOCK * FXG_QS_UNROLL) {
+    u64 r0 = lo + rl;
+    for (u64 g0 = 0; g0 < nitems; g0 += (u64)FXG_QS_TBLOCK * FXG_QS_UNROLL, r0 += trip_reads) {
         if (since + trip_reads > 65535u) {                    // a 16-bit counter could wrap: move the block out (uniform branch)
             __syncthreads();
             fxg_stats_flush(qs_h, part, tid, FXG_QS_TBLOCK);
@@ -190,16 +235,17 @@ __global__ __launch_bounds__(FXG_QS_TBLOCK) void fxg_kernel_quality_stats(const 
             since = 0;
         }
         FxgStripRow row[FXG_QS_UNROLL];
-        u32 sl[FXG_QS_UNROLL];
 #pragma unroll
         for (u32 u = 0; u < FXG_QS_UNROLL; ++u) {
-            const u64 g = g0 + (u64)u * FXG_QS_TBLOCK + tid;
-            u64 r = 0;
-            row[u].nb = 0u; sl[u] = 0u;
-            if (g < nitems) { fxg_stats_item(lo, g, &r, &sl[u]); fxg_stats_load(a, r, a.strip0 + sl[u], row[u]); }
+            const u64 r = r0 + (u64)u * reads_per_step;
+            row[u].nb = 0u;
+            if (r < hi) fxg_stats_load(a, r, a.strip0 + sl, row[u]);
         }
 #pragma unroll
-        for (u32 u = 0; u < FXG_QS_UNROLL; ++u) fxg_stats_accumulate(a, row[u], sl[u], (a.strip0 + sl[u]) * FXG_QS_STRIP, qs_h);
+        for (u32 u = 0; u < FXG_QS_UNROLL; ++u) {
+            if (a.len) { u32 m[4]; fxg_stats_masks(row[u].nb, m); fxg_stats_accumulate(a, row[u], sl, (a.strip0 + sl) * FXG_QS_STRIP, m, qs_h); }
+            else fxg_stats_accumulate(a, row[u], sl, (a.strip0 + sl) * FXG_QS_STRIP, mfix, qs_h);
+        }
         since += trip_reads;
     }
     __syncthreads();

@@ -204,17 +204,23 @@ class Engine:
     def use_torch_stream(self):
         """Enqueue on torch's current stream so tensors allocated by torch are ordered with the kernels.
 
-        torch's DEFAULT stream has the null handle, for which the C-ABI keeps the context's own (non-blocking) stream: the
-        two are then NOT ordered by the runtime.  In that case every launch below first waits for torch's stream on the
-        host (`_after_torch`), and results must be read through Result (which synchronises the engine) or after sync().
-        Run under `torch.cuda.stream(side_stream)` / `torch.cuda.set_stream` (as bench.py does) to share one stream."""
-        s = self.torch.cuda.current_stream(self.device).cuda_stream
-        self._own_stream = not s
+        torch's DEFAULT stream has the null handle, which the C-ABI cannot adopt.  The engine then runs on a torch SIDE stream
+        and every launch is bracketed by stream waits in both directions (`_after_torch` / `_before_torch`): the kernels see what
+        torch enqueued before them, and whatever torch enqueues afterwards (including frees and reuse of the tensors by the
+        caching allocator, which follow the order of torch's stream) comes after the kernels.  No host synchronisation either way.
+        Run under `torch.cuda.stream(s)` / `torch.cuda.set_stream` (as bench.py does) to share one stream outright."""
+        cur = self.torch.cuda.current_stream(self.device)
+        self._side = None if cur.cuda_stream else self.torch.cuda.Stream(device=self.device)
+        s = (self._side or cur).cuda_stream
         self._check(self.lib.fxg_set_stream(self.ctx, C.c_void_p(s)))
 
     def _after_torch(self):
-        if getattr(self, "_own_stream", False):
-            self.torch.cuda.current_stream(self.device).synchronize()
+        if self._side is not None:
+            self._side.wait_stream(self.torch.cuda.current_stream(self.device))
+
+    def _before_torch(self):
+        if self._side is not None:
+            self.torch.cuda.current_stream(self.device).wait_stream(self._side)
 
     def sync(self):
         self._check(self.lib.fxg_sync(self.ctx))
@@ -233,7 +239,7 @@ class Engine:
 
     def quality_stats(self, bases, qual, lens=None, fixed_len=None, hist=None, cols=None, sync=True):
         """fastx_quality_stats: adds the batch to hist[cols][5][128] (int64 device tensor, created zeroed when None) and returns it.
-        sync=False leaves the kernel in flight on the engine's stream (call sync() before torch reads the tensor)."""
+        sync=False leaves the kernel in flight (torch work enqueued afterwards is still ordered behind it)."""
         n, stride = bases.shape
         if hist is None:
             hist = self.torch.zeros((cols or stride, 5, 128), dtype=self.torch.int64, device=self.device)
@@ -241,6 +247,7 @@ class Engine:
         b = FxgBatch(bases.data_ptr(), qual.data_ptr() if qual is not None else None,
                      lens.data_ptr() if lens is not None else None, int(fixed_len or stride), stride, n)
         self._check(self.lib.fxg_run_quality_stats(self.ctx, C.byref(b), hist.data_ptr(), hist.shape[0]))
+        self._before_torch()
         if sync:
             self.sync()
         return hist
@@ -274,8 +281,10 @@ class Engine:
         stride = stride or read_len
         bases = self.torch.empty((n, stride), dtype=self.torch.uint8, device=self.device)
         qual = self.torch.empty((n, stride), dtype=self.torch.uint8, device=self.device) if want_qual else None
+        self._after_torch()
         self._check(self.lib.fxg_synth_generate(self.ctx, seed, first, n, read_len, int(with_adapter), bases.data_ptr(),
                                                 qual.data_ptr() if want_qual else None, stride))
+        self._before_torch()
         return bases, qual
 
     def upload(self, arr):
@@ -304,6 +313,7 @@ class Engine:
         ptr = lambda k: (o[k].data_ptr() if o.get(k) is not None else None)
         fo = FxgOut(ptr("res"), ptr("out_bases"), ptr("out_qual"), ptr("out_len"), ptr("kept_index"), ptr("out_off"), ptr("counters"))
         self._check(self.lib.fxg_run_pipeline(self.ctx, C.byref(b), C.byref(params), C.byref(fo)))
+        self._before_torch()
         return Result(self, o["res"], o.get("out_bases"), o.get("out_qual"), o.get("out_len"), o.get("kept_index"),
                       o.get("out_off"), o["counters"])
 
@@ -321,6 +331,7 @@ class Engine:
         ls = self.torch.empty(4 * cap_records + 1, dtype=self.torch.int32, device=self.device)
         lens = self.torch.empty(cap_records, dtype=self.torch.int16, device=self.device)
         info = FxgTextInfo()
+        self._after_torch()
         self._check(self.lib.fxg_fastq_index(self.ctx, d_text.data_ptr(), text_len, int(at_eof), ls.data_ptr(), ls.numel(), lens.data_ptr(), C.byref(info)))
         return ls, lens, info
 
@@ -329,6 +340,7 @@ class Engine:
         bases = self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.device)
         qual = self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.device) if want_qual else None
         irr = C.c_uint32()
+        self._after_torch()
         self._check(self.lib.fxg_fastq_pack(self.ctx, d_text.data_ptr(), text_len, ls.data_ptr(), n, stride, qoffset, bases.data_ptr(),
                                             qual.data_ptr() if want_qual else None, C.byref(irr)))
         return bases[:n * stride].view(n, stride), (qual[:n * stride].view(n, stride) if want_qual else None), irr.value
@@ -337,6 +349,7 @@ class Engine:
         out = self.torch.empty(text_len + 16, dtype=self.torch.uint8, device=self.device)
         nb = C.c_uint64()
         pb, pq, po = (packed[0].data_ptr(), packed[1].data_ptr(), packed[2].data_ptr()) if packed else (None, None, None)
+        self._after_torch()
         self._check(self.lib.fxg_fastq_format(self.ctx, d_text.data_ptr(), ls.data_ptr(), n, res.data_ptr(), fwd_start, pb, pq, po, qoffset,
                                               out.data_ptr(), C.byref(nb)))
         return out[:nb.value]

@@ -22,36 +22,33 @@ b, q = eng.synth(2, 0, R, 150)
 P = (make_params(stages=24, ft_first=5, ft_last=145) if CFG == "cfg4"
      else make_params(stages=6, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80))
 outs = eng.alloc_outputs(R, 150, compact=True, meta=False)
-eng.set_profiling(True)
+eng.sync()
+KNOBS = ("FXG_DEBUG", "FXG_TILE", "FXG_BLOCKS_PER_CU", "FXG_TICKET_GROUPS", "FXG_QLDS", "FXG_QLDS_BUDGET")
 
 
 def t(label, env, compact=True, reps=4):
-    for k in ("FXG_DEBUG", "FXG_TILE", "FXG_BLOCKS_PER_CU", "FXG_TICKET_GROUPS"):
+    for k in KNOBS:
         os.environ.pop(k, None)
     os.environ.update(env)
+    e = Engine(0)                                  # the context reads its tuning knobs when it is created
+    e.set_profiling(True)
     ms = []
     for _ in range(reps):
-        eng.run(b, q, P, fixed_len=150, compact=compact, meta=False, outputs=outs if compact else None)
-        ms.append(eng.last_kernel_ms())
-    li = eng.last_launch()
-    print(json.dumps(dict(label=label, ms_min=round(min(ms), 3), ms_avg=round(sum(ms) / len(ms), 3), grid=li["grid"], tile=li["tile_reads"], lds=li["lds"])), flush=True)
+        r = e.run(b, q, P, fixed_len=150, compact=compact, meta=False, outputs=outs if compact else None)
+        ms.append(e.last_kernel_ms())
+    c = r.counters
+    li = e.last_launch()
+    print(json.dumps(dict(label=label, ms_min=round(min(ms), 3), ms_avg=round(sum(ms) / len(ms), 3), grid=li["grid"], tile=li["tile_reads"], lds=li["lds"],
+                          kept=int(c[1]), kept_bases=int(c[2]), err=int(c[15]))), flush=True)
+    e.close()
 
 
 cfgs = json.loads(os.environ.get("ABLATE", "null")) or [
     ["full", {}],
     ["decision-only", {}, False],
-    ["no-gather", {"FXG_DEBUG": "1"}],
-    ["no-lookback", {"FXG_DEBUG": "2"}],
-    ["no-qual-gather", {"FXG_DEBUG": "4"}],
-    ["no-bitmaps", {"FXG_DEBUG": "8"}],
-    ["no-gather,no-lookback", {"FXG_DEBUG": "3"}],
-    ["no-gather,no-lookback,no-bitmaps", {"FXG_DEBUG": "11"}],
-    ["tile128", {"FXG_TILE": "128"}],
-    ["tile64", {"FXG_TILE": "64"}],
-    ["bpc4", {"FXG_BLOCKS_PER_CU": "4"}],
-    ["bpc2", {"FXG_BLOCKS_PER_CU": "2"}],
-    ["bpc1", {"FXG_BLOCKS_PER_CU": "1"}],
-    ["tile128 bpc4", {"FXG_TILE": "128", "FXG_BLOCKS_PER_CU": "4"}],
+    ["qlds0 t256", {"FXG_QLDS": "0"}],
+    ["qlds1 52K", {"FXG_QLDS": "1", "FXG_QLDS_BUDGET": "53248"}],
+    ["qlds1 26K", {"FXG_QLDS": "1", "FXG_QLDS_BUDGET": "26624"}],
 ]
 for c in cfgs:
     t(c[0], c[1], *(c[2:] or [True]))

@@ -20,7 +20,8 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
     const u32 T = a.tile_reads, stride = a.stride, NT = FXG_TBLOCK;
     std::vector<unsigned char> lds(pl.lds + 64, 0);
     unsigned char *smem = lds.data();
-    const FxgLds L = pl.group_a ? fxg_lds_layout(T, stride, pl.use_q, pl.clip ? a.clip_stride : 0u) : fxg_lds_layout(T, stride, MODE == 3, MODE == 4 ? stride : 0u);
+    const FxgLds L = fxg_plan_layout(&pl);
+    uint8_t *qrows = L.has_qrows ? smem + L.so_qrows + 16u : nullptr;      // slot 0: the emulator runs one tile at a time
     u64 m_reads = 0, m_nt = 0;
     u32 *k_off = reinterpret_cast<u32 *>(smem);
     u32 *k_src = reinterpret_cast<u32 *>(smem + L.so_ksrc);
@@ -40,7 +41,7 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
         const u32 tbytes = nreads * stride;
         if (pl.group_a) {
             for (u32 tid = 0; tid < NT; ++tid) {
-                if (pl.use_q) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, NT);
+                if (pl.use_q) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, NT, qrows);
                 if constexpr (AMAX != 0) fxg_phase_stage_bases(a.clip_src, a.clip_total, (u64)r0 * a.clip_stride, nreads * a.clip_stride, sb, tid, NT);
             }
             for (u32 tid = 0; tid < nreads; ++tid) {
@@ -48,7 +49,7 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
                 anchor[tid] = tid * stride;
             }
         } else if (MODE == 3) {
-            for (u32 tid = 0; tid < NT; ++tid) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, NT);
+            for (u32 tid = 0; tid < NT; ++tid) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, NT, qrows);
             for (u32 tid = 0; tid < nreads; ++tid) {
                 u32 nl;
                 fxg_decide_mask(a, bm_l, r0, tid, &keep[tid], &olen[tid], &nl);
@@ -70,7 +71,9 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
             exb += olen[tid]; exc++;
         }
         k_off[exc] = exb;
-        for (u32 tid = 0; tid < NT; ++tid) bad |= fxg_tile_gather<REV, MODE == 3>(a, k_off, k_src, k_tab, exc, tb, tbytes, base_b, exb, tid, NT);
+        for (u32 tid = 0; tid < NT; ++tid)
+            bad |= qrows ? fxg_tile_gather<REV, MODE == 3, true>(a, k_off, k_src, k_tab, exc, tb, tbytes, base_b, exb, tid, NT, qrows)
+                         : fxg_tile_gather<REV, MODE == 3, false>(a, k_off, k_src, k_tab, exc, tb, tbytes, base_b, exb, tid, NT);
         base_c += exc; base_b += exb;
     }
     for (u64 i = 0; i < a.n; ++i) fxg_count_res(a.res[i], cnt);   // same reduction the counting kernel performs
@@ -221,7 +224,9 @@ extern "C" int fxg_emu_run_quality_stats(const fxg_batch *in, uint64_t *hist, ui
                         FxgStripRow row;
                         fxg_stats_item(lo, it, &r, &sl);
                         fxg_stats_load(a, r, s0 + sl, row);
-                        fxg_stats_accumulate(a, row, sl, (s0 + sl) * FXG_QS_STRIP, lds.data());
+                        u32 m[4];
+                        fxg_stats_masks(row.nb, m);
+                        fxg_stats_accumulate(a, row, sl, (s0 + sl) * FXG_QS_STRIP, m, lds.data());
                     }
                 since += trip_reads;
             }

@@ -183,9 +183,12 @@ def _window_check(engine, seed, N, L, ad, pd, K=40000):
     assert np.array_equal(r.out_qual[nbytes - n1:nbytes].cpu().numpy(), o["out_qual"])
     assert np.array_equal(r.kept_index[kept - k1:kept].cpu().numpy().view(np.uint32), o["kept_index"] + np.uint32(N - K))
     # determinism of the whole packed stream
+    del res, keepmask, lens, ol, off
     r2 = engine.run(b, q, _engine_params(pd), fixed_len=L)
     assert int(r2.counters[1]) == kept
     assert torch.equal(r2.out_bases[:nbytes], r.out_bases[:nbytes]) and torch.equal(r2.out_qual[:nbytes], r.out_qual[:nbytes])
+    del r, r2, b, q
+    torch.cuda.empty_cache()
     return kept, nbytes
 
 
@@ -197,9 +200,9 @@ def test_full_size_cfg2_quality_trim_filter(engine):
 
 
 def test_full_size_cfg4_revcomp_trim(engine):
-    """BASELINE config 4 (scaled to 100 M reads to bound test time): fastx_reverse_complement | fastx_trimmer -f 5 -l 145."""
-    kept, nbytes = _window_check(engine, 2, 100_000_000, 150, False, dict(stages=24, ft_first=5, ft_last=145), K=20000)
-    assert kept == 100_000_000 and nbytes == 141 * kept
+    """BASELINE config 4 at its stated size: 200 M x 150 bp, fastx_reverse_complement | fastx_trimmer -f 5 -l 145."""
+    kept, nbytes = _window_check(engine, 2, 200_000_000, 150, False, dict(stages=24, ft_first=5, ft_last=145), K=20000)
+    assert kept == 200_000_000 and nbytes == 141 * kept
 
 
 def test_full_size_cfg3_clipper(engine):
@@ -208,8 +211,8 @@ def test_full_size_cfg3_clipper(engine):
 
 
 def test_cfg5_pipeline_shard(engine):
-    """BASELINE config 5, one rank's shard of 1 B / 8 reads: clip -> quality-trim -> filter in one pass."""
-    _window_check(engine, 5, 125_000_000 // 5, 150, True,
+    """BASELINE config 5, one rank's shard (1 B / 8 = 125 M reads x 150 bp): clip -> quality-trim -> filter in one pass."""
+    _window_check(engine, 5, 125_000_000, 150, True,
                   dict(stages=7, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=4, qt_threshold=20, qt_min_len=30,
                        qf_min_quality=20, qf_min_percent=80), K=20000)
 
