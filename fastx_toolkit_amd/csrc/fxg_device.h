@@ -537,8 +537,28 @@ FXG_HD void fxg_gather_byte(const FxgKArgs &a, const uint8_t *src_b, const uint8
 #endif
 struct FxgChunk { u32 o, k; int e, e2; u32x4 wb, wq, vb, vq; };
 
-// src_q: where the quality windows come from -- the batch in HBM, or (lq) the tile's quality rows kept in LDS by stage A
-template <bool REV, bool MASK>
+// 16 bytes at ANY byte offset p (>= -16) of an LDS array whose byte 0 is 16-byte aligned.  gfx950 executes a misaligned
+// ds_read_b128 correctly but 16x slower than an aligned one (measured: 163-256 vs 10-16 cycles per wave instruction,
+// profiles/r02_valu_rate_*.txt), so the window is five naturally aligned dword reads funnel-shifted with v_alignbyte_b32.
+// The reads are volatile so that the compiler cannot fuse them back into one wide, misaligned access.
+FXG_HD u32x4 fxg_lds_window16(const uint8_t *base, int p)
+{
+    const int a = p & ~3;
+    const u32 sh = (u32)p & 3u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const volatile u32 __attribute__((address_space(3))) fxg_lds_u32;   // explicitly LDS: ds_read_b32, never a flat access
+    fxg_lds_u32 *w = (fxg_lds_u32 *)(base + a);
+    const u32 d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
+    return (u32x4){__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                   __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
+#else
+    (void)a; (void)sh;
+    return fxg_ld16(base + p);
+#endif
+}
+
+// LQ: the quality windows come from the tile's quality rows kept in LDS by stage A (src_q = their byte 0) instead of the batch in HBM
+template <bool REV, bool MASK, bool LQ>
 FXG_HD void fxg_chunk_load(FxgChunk &c, const uint8_t *src_b, const uint8_t *src_q, bool want_q, const u32 *k_off, const u32 *k_src,
                            const uint16_t *k_tab, u32 nk, u32 S, u32 o)
 {
@@ -550,14 +570,14 @@ FXG_HD void fxg_chunk_load(FxgChunk &c, const uint8_t *src_b, const uint8_t *src
     c.o = o; c.k = k; c.e = e; c.e2 = 16;
     c.wb = fxg_ld16_stream(src_b + p1);
     c.wq = (u32x4){0u, 0u, 0u, 0u};
-    if (want_q) c.wq = fxg_ld16_stream(src_q + p1);      // LDS rows: ds_read_b128 at any byte offset (gfx950 has unaligned DS access)
+    if (want_q) c.wq = LQ ? fxg_lds_window16(src_q, p1) : fxg_ld16_stream(src_q + p1);
     c.vb = c.vq = (u32x4){0u, 0u, 0u, 0u};
     if (e < 16) {                                                         // the chunk continues in the next kept read
         const u32 n2 = k_off[k + 2u] - e1;
         c.e2 = n2 < (u32)(16 - e) ? e + (int)n2 : 16;
         const int p2 = REV ? (int)k_src[k + 1u] + e - 15 : (int)k_src[k + 1u] - e;
         c.vb = fxg_ld16_stream(src_b + p2);
-        if (want_q) c.vq = fxg_ld16_stream(src_q + p2);
+        if (want_q) c.vq = LQ ? fxg_lds_window16(src_q, p2) : fxg_ld16_stream(src_q + p2);
     }
 }
 
@@ -592,7 +612,7 @@ FXG_HD u32 fxg_tile_gather(const FxgKArgs &a, const u32 *k_off, const u32 *k_src
         for (int u = 0; u < FXG_GATHER_K; ++u) {
             const u32 ci = c0 + (u32)u * nthreads;
             ch[u].e = 0;
-            if (ci < nfull) fxg_chunk_load<REV, MASK>(ch[u], src_b, LQ ? lq : src_q, has_q || MASK, k_off, k_src, k_tab, nk, S, o_lo + (ci << 4));
+            if (ci < nfull) fxg_chunk_load<REV, MASK, LQ>(ch[u], src_b, LQ ? lq : src_q, has_q || MASK, k_off, k_src, k_tab, nk, S, o_lo + (ci << 4));
         }
 #pragma unroll
         for (int u = 0; u < FXG_GATHER_K; ++u) {

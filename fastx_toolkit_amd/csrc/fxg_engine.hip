@@ -1,10 +1,12 @@
 // fxg_engine.hip -- host side of the C-ABI declared in include/fxg.h (gfx950 only).
 #include <hip/hip_runtime.h>
 
+#include <cerrno>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 
 #include "fxg_plan.h"
 #include "fxg_text.h"
@@ -658,6 +660,46 @@ extern "C" int fxg_host_unregister(fxg_ctx *c, void *ptr)
 {
     if (!c || !ptr) return FXG_E_INVALID;
     FXG_HIP(c, hipHostUnregister(ptr));
+    return FXG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// several GPUs: shard ranges, the epilogue arithmetic and the concatenation (host only)
+// ------------------------------------------------------------------------------------------------
+extern "C" int fxg_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi)
+{
+    if (!lo || !hi || world == 0 || rank >= world) return FXG_E_INVALID;
+    *lo = (uint64_t)(((unsigned __int128)n * rank) / world);
+    *hi = (uint64_t)(((unsigned __int128)n * (rank + 1u)) / world);
+    return FXG_OK;
+}
+
+extern "C" int fxg_epilogue(const uint64_t *gathered, uint32_t world, uint32_t rank, uint64_t totals[FXG_NCOUNTERS],
+                            uint64_t *read_off, uint64_t *byte_off)
+{
+    if (!gathered || world == 0 || rank >= world) return FXG_E_INVALID;
+    uint64_t ro = 0, bo = 0;
+    if (totals) memset(totals, 0, FXG_NCOUNTERS * sizeof(uint64_t));
+    for (uint32_t g = 0; g < world; ++g) {
+        const uint64_t *c = gathered + (size_t)g * FXG_NCOUNTERS;
+        if (g < rank) { ro += c[FXG_C_KEPT]; bo += c[FXG_C_KEPT_BASES]; }
+        if (totals)
+            for (int i = 0; i < FXG_NCOUNTERS; ++i) { if (i == FXG_C_ERRORS) totals[i] |= c[i]; else totals[i] += c[i]; }
+    }
+    if (read_off) *read_off = ro;
+    if (byte_off) *byte_off = bo;
+    return FXG_OK;
+}
+
+extern "C" int fxg_concat_pwrite(int fd, const void *host_buf, uint64_t bytes, uint64_t offset)
+{
+    if (fd < 0 || (!host_buf && bytes)) return FXG_E_INVALID;
+    const char *p = (const char *)host_buf;
+    while (bytes) {
+        const ssize_t k = pwrite(fd, p, bytes > ((uint64_t)1 << 30) ? ((size_t)1 << 30) : (size_t)bytes, (off_t)offset);
+        if (k < 0) { if (errno == EINTR) continue; return FXG_E_INVALID; }
+        p += k; offset += (uint64_t)k; bytes -= (uint64_t)k;
+    }
     return FXG_OK;
 }
 

@@ -221,8 +221,18 @@ FXG_HD void fxg_clip_row_packed(const FxgKArgs &a, int A, u32 c, int q, float (&
         const float scm = sc + -5.0f;
         S[t] = sc; Sm[t] = scm; W[t] = wp;
         uSm = scm; uW = wp;
-        const bool gb = (sc > best) && (t < A);                                              // first maximum in query-major order
-        best = gb ? sc : best; bw = gb ? w : bw;
+        // first maximum in query-major order.  Columns past the adapter (t >= A) do not count; the smallest adapter of this
+        // bucket has AMIN bases, so only columns t >= AMIN need the test (none for the exact buckets 9..16) -- a mask that went
+        // through a scalar AND costs a v_cndmask several times what a mask straight from a v_cmp does (scripts/ubench/valu_rate.hip).
+        constexpr int AMIN = AMAX <= 4 ? 1 : (AMAX <= 8 ? 5 : (AMAX <= 16 ? AMAX : AMAX - 3));
+        if (t < AMIN) {
+            const bool gb = sc > best;
+            bw = gb ? w : bw;
+            best = fmaxf(best, sc);
+        } else {
+            const bool gb = (sc > best) && (t < A);
+            best = gb ? sc : best; bw = gb ? w : bw;
+        }
     }
     bq = (best > best_in) ? (u32)q : bq;                   // the best cell moved into this row (best only ever grows)
 }
@@ -520,7 +530,9 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void f
 #endif
         // ------------------------------ stage A: tile `cur` into slot `slot` ------------------------------
         if (cur < a.ntiles) {
+#if !FXG_SAMESTEP
             if (tid == 0) s_ticket[tk ^ 1u] = atomicAdd(my_ticket, 1u);   // next ticket: in flight while this tile is decided
+#endif
             const u32 r0 = cur * T;
             const u64 left = a.n - (u64)r0;
             const u32 nreads = left < (u64)T ? (u32)left : T;
@@ -604,11 +616,19 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void f
             }
         }
         if (cur >= a.ntiles) break;
+#if FXG_SAMESTEP
+        // One slot: a ticket must not be held across the wait for this tile's prefix (every later tile waits for the totals of
+        // the ticket's tile), so the next one is drawn only now.
+        __syncthreads();
+        if (tid == 0) s_ticket[0] = atomicAdd(my_ticket, 1u);
+        __syncthreads();
+        pend = cur;
+        cur = s_ticket[0] * G + grp;
+#else
         __syncthreads();            // ticket written by thread 0 in stage A; also fences slot reuse (two steps apart with two slots)
         pend = cur;
         tk ^= 1u;
         cur = s_ticket[tk] * G + grp;
-#if !FXG_SAMESTEP
         slot ^= 1u;
 #endif
     }

@@ -8,12 +8,17 @@ import os
 
 import numpy as np
 
-from .engine import C_ERRORS, C_KEPT, C_KEPT_BASES, NCOUNTERS
+import ctypes as C
+
+from .engine import NCOUNTERS, load_library
 
 
 def shard_range(n_total, rank, world):
-    """Reads [lo, hi) owned by `rank`: g*N/G .. (g+1)*N/G."""
-    return (n_total * rank) // world, (n_total * (rank + 1)) // world
+    """Reads [lo, hi) owned by `rank`: g*N/G .. (g+1)*N/G (fxg_shard_range of the C-ABI)."""
+    lo, hi = C.c_uint64(), C.c_uint64()
+    if load_library().fxg_shard_range(n_total, rank, world, C.byref(lo), C.byref(hi)) != 0:
+        raise ValueError("shard_range(%r, %r, %r)" % (n_total, rank, world))
+    return lo.value, hi.value
 
 
 def init_from_env(backend=None):
@@ -54,12 +59,20 @@ def gather_counters(counters, group=None):
 
 def offsets_from_gathered(gathered, rank):
     """(totals uint64[NCOUNTERS], kept_read_offset, kept_byte_offset, per_rank) from gather_counters' result (host side)."""
-    per_rank = gathered.detach().cpu().numpy().view(np.uint64).reshape(-1, NCOUNTERS)
-    totals = per_rank.sum(axis=0, dtype=np.uint64)
-    totals[C_ERRORS] = np.bitwise_or.reduce(per_rank[:, C_ERRORS])
-    read_off = int(per_rank[:rank, C_KEPT].sum(dtype=np.uint64))
-    byte_off = int(per_rank[:rank, C_KEPT_BASES].sum(dtype=np.uint64))
-    return totals, read_off, byte_off, per_rank
+    per_rank = np.ascontiguousarray(gathered.detach().cpu().numpy().view(np.uint64).reshape(-1, NCOUNTERS))
+    totals = np.zeros(NCOUNTERS, dtype=np.uint64)
+    read_off, byte_off = C.c_uint64(), C.c_uint64()
+    rc = load_library().fxg_epilogue(per_rank.ctypes.data, per_rank.shape[0], rank, totals.ctypes.data, C.byref(read_off), C.byref(byte_off))
+    if rc != 0:
+        raise ValueError("fxg_epilogue failed (%d ranks, rank %d)" % (per_rank.shape[0], rank))
+    return totals, read_off.value, byte_off.value, per_rank
+
+
+def concat_pwrite(fd, arr, offset):
+    """Write this rank's packed slice (a contiguous numpy array) at its offset of the job's output file (fxg_concat_pwrite)."""
+    arr = np.ascontiguousarray(arr)
+    if load_library().fxg_concat_pwrite(fd, arr.ctypes.data, arr.nbytes, offset) != 0:
+        raise OSError("fxg_concat_pwrite failed")
 
 
 def epilogue(counters, group=None):

@@ -155,6 +155,9 @@ int fxh_next_raw(FASTX *fx, struct fxh_rawrec *rec, int may_refill)
     rec->prefix = p[0];
     rec->name = p + 1;
     rec->name_len = fxh_chomp_len(p + 1, raw - 1);
+    /* the reference reads lines with fgets(.., 25000) and silently splits longer ones; here they are rejected (the FASTX record
+     * buffers of the per-record API hold MAX_SEQ_LINE_LENGTH bytes) */
+    if (rec->name_len >= MAX_SEQ_LINE_LENGTH - 1) { fxh_fail(fx, rec, "identifier line longer than %d on line %lld\n", MAX_SEQ_LINE_LENGTH - 2, fx->input_line_number); return -2; }
     if (fx->read_fastq && rec->prefix != '@') {
         fxh_fail(fx, rec, "Invalid input: expecting FASTQ prefix character '@' on line %lld. Is this a valid FASTQ file?\n", fx->input_line_number);
         return -2;
@@ -193,6 +196,7 @@ int fxh_next_raw(FASTX *fx, struct fxh_rawrec *rec, int may_refill)
         if (rc == 0) { fxh_fail(fx, rec, "Failed to read complete record, missing 3rd line (name-2), on line %lld\n", fx->input_line_number); return -2; }
         rec->name2 = p + 1;                                  /* first byte dropped whatever it is (R5) */
         rec->name2_len = raw > 0 ? fxh_chomp_len(p + 1, raw - 1) : 0;
+        if (rec->name2_len >= MAX_SEQ_LINE_LENGTH - 1) { fxh_fail(fx, rec, "identifier line longer than %d on line %lld\n", MAX_SEQ_LINE_LENGTH - 2, fx->input_line_number); return -2; }
         fx->input_line_number++;
         rc = fxh_reader_line(r, &p, &raw, 0);
         if (rc < 0) goto incomplete;
@@ -226,26 +230,32 @@ int fxh_decode_quality(FASTX *fx, struct fxh_rawrec *rec, int *out_i32, unsigned
         }
         return 0;
     }
-    /* numeric scores separated by blanks (fastx.c:137-167) */
+    /* numeric scores (fastx.c:137-167): the reference calls strtol() on the rest of the line until the rest is empty, so a token
+     * is whatever strtol takes -- leading isspace() bytes, one optional sign, digits -- and "10-5" is two values */
     {
-        char tmp[64];
         size_t idx = 0, pos = 0;
         const char *s = rec->qual;
         const size_t n = rec->qual_len;
         do {
-            size_t k = 0, j = pos;
-            while (j < n && (s[j] == ' ' || s[j] == '\t')) j++;
-            while (j < n && k < sizeof tmp - 1 && (s[j] == '-' || s[j] == '+' || (s[j] >= '0' && s[j] <= '9'))) tmp[k++] = s[j++];
-            tmp[k] = 0;
-            char *end;
-            long v = strtol(tmp, &end, 10);
-            if (end == tmp) {
+            size_t j = pos;
+            while (j < n && (s[j] == ' ' || (s[j] >= '\t' && s[j] <= '\r'))) j++;
+            int neg = 0;
+            if (j < n && (s[j] == '-' || s[j] == '+')) { neg = (s[j] == '-'); j++; }
+            const size_t d0 = j;
+            unsigned long long mag = 0;
+            int sat = 0;
+            for (; j < n && s[j] >= '0' && s[j] <= '9'; ++j) {
+                if (mag > (0x7FFFFFFFFFFFFFFFull - 9) / 10) sat = 1; else mag = mag * 10 + (unsigned long long)(s[j] - '0');
+            }
+            if (j == d0) {                                     /* endptr == quality_tok */
                 fxh_fail(fx, rec, "Error: invalid quality score data on line %lld (quality_tok = \"%.*s\"", fx->input_line_number, (int)(n - pos), s + pos);
                 return -1;
             }
-            if (v > 93 || v < -15) { fxh_fail(fx, rec, "invalid quality score value (%d) in line %lld.", (int)v, fx->input_line_number); return -1; }
+            const long lv = sat ? (neg ? (-0x7FFFFFFFFFFFFFFFL - 1) : 0x7FFFFFFFFFFFFFFFL) : (neg ? -(long)mag : (long)mag);
+            const int v = (int)lv;                             /* the reference stores strtol's long in an int */
+            if (v > 93 || v < -15) { fxh_fail(fx, rec, "invalid quality score value (%d) in line %lld.", v, fx->input_line_number); return -1; }
             if (idx < rec->seq_len) {
-                if (out_i32) out_i32[idx] = (int)v;
+                if (out_i32) out_i32[idx] = v;
                 if (out_phred33) out_phred33[idx] = (unsigned char)(v + 33);
             }
             idx++;

@@ -268,6 +268,23 @@ int  fxg_run_quality_stats(fxg_ctx *ctx, const fxg_batch *in, uint64_t *d_hist, 
  * variable-length clipper job over several contexts is only exact with history off on both sides. */
 int  fxg_set_clip_history(fxg_ctx *ctx, int on);
 
+/* ---- several GPUs.  The reference is one process over one stream of reads (e.g.
+ * fastq_quality_trimmer.c:76-124); here reads shard by contiguous index range, one context per GPU, and the ONLY exchange is each
+ * shard's counter block: concatenating the shards' packed outputs in shard order reproduces the single-GPU output.  These three
+ * helpers are host arithmetic / I/O; they need no context and no device.  How the counter blocks travel is the caller's
+ * business: an RCCL all-gather between processes (fastx_toolkit_amd/distributed.py), plain memory between the threads of one
+ * process (host/fxh_batch.c). ---- */
+/* reads [*lo, *hi) of an n-read job owned by shard `rank` of `world`:  rank * n / world  ..  (rank + 1) * n / world */
+int  fxg_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi);
+/* gathered: world counter blocks in shard order (world * FXG_NCOUNTERS values).  totals (optional): the job's counters (sums;
+ * the device error words are OR-ed).  read_off / byte_off (optional): kept reads / kept bytes of the shards before `rank`,
+ * i.e. where this shard's kept_index / out_off entries and its packed bytes start in the job's output. */
+int  fxg_epilogue(const uint64_t *gathered, uint32_t world, uint32_t rank, uint64_t totals[FXG_NCOUNTERS],
+                  uint64_t *read_off, uint64_t *byte_off);
+/* The concatenation: write this shard's `bytes` bytes of packed output (host memory) at `offset` of the open file `fd`
+ * (pwrite until done; shards may write concurrently, in any order). */
+int  fxg_concat_pwrite(int fd, const void *host_buf, uint64_t bytes, uint64_t offset);
+
 /* Kernel-level timing: when enabled, every fxg_run_pipeline brackets its dominant kernel (not the
  * memset / counter-reduce helpers) with HIP events on the launch stream; fxg_last_kernel_ms waits for
  * that launch and returns its duration. */

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(1024) void k(unsigned long long *out, unsigned *sin
     float f0 = threadIdx.x, f1 = 1.5f, f2 = 2.5f, f3 = 3.5f, f4 = 4.5f, f5 = 5.5f, f6 = 6.5f, f7 = 7.5f;
     unsigned u0 = threadIdx.x, u1 = 11, u2 = 12, u3 = 13, u4 = 14, u5 = 15, u6 = 16, u7 = 17;
     double d0 = 1.0, d1 = 2.0, d2 = 3.0, d3 = 4.0;
-    unsigned a0 = (threadIdx.x * 4u) & 32764u, a1 = ((threadIdx.x * 37u) & 8191u) * 4u;
+    unsigned a0 = (threadIdx.x * 4u) & 32764u, a1 = ((threadIdx.x * 32u) & 8191u) * 4u;   // a1: every lane of a 32-lane group on bank 0, different words
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int r = 0; r < reps; ++r) {
         if (OP == 0) asm volatile(X8("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n")
@@ -59,11 +59,34 @@ __global__ __launch_bounds__(1024) void k(unsigned long long *out, unsigned *sin
         if (OP == 15) asm volatile(X8("ds_add_u32 %0, %2\n ds_add_u32 %0, %2 offset:4096\n ds_add_u32 %0, %2 offset:8192\n ds_add_u32 %0, %2 offset:12288\n ds_add_u32 %0, %2 offset:16384\n ds_add_u32 %0, %2 offset:20480\n ds_add_u32 %0, %2 offset:24576\n ds_add_u32 %0, %2 offset:28672\n") "s_waitcnt lgkmcnt(0)\n"
                                    : : "v"(a0 & 4095u), "v"(a1), "v"(1u) : "memory");     // conflict-free: lane i -> word i
         if (OP == 16) asm volatile(X8("ds_add_u32 %1, %2\n ds_add_u32 %1, %2 offset:4\n ds_add_u32 %1, %2 offset:8\n ds_add_u32 %1, %2 offset:12\n ds_add_u32 %1, %2 offset:16\n ds_add_u32 %1, %2 offset:20\n ds_add_u32 %1, %2 offset:24\n ds_add_u32 %1, %2 offset:28\n") "s_waitcnt lgkmcnt(0)\n"
-                                   : : "v"(a0), "v"(a1 & 32764u), "v"(1u) : "memory");    // scattered: lane i -> word (37 i) mod 8192
+                                   : : "v"(a0), "v"(a1 & 32764u), "v"(1u) : "memory");    // same bank, different words: the worst bank conflict
         if (OP == 17) asm volatile(X8("ds_read_b128 %0, %4\n ds_read_b128 %1, %4 offset:1024\n ds_read_b128 %2, %4 offset:2048\n ds_read_b128 %3, %4 offset:3072\n ds_read_b128 %0, %4 offset:4096\n ds_read_b128 %1, %4 offset:5120\n ds_read_b128 %2, %4 offset:6144\n ds_read_b128 %3, %4 offset:7168\n") "s_waitcnt lgkmcnt(0)\n"
                                    : "=v"(*(uint4 *)&d0), "=v"(*(uint4 *)&d2), "=v"(*(uint4 *)&f0), "=v"(*(uint4 *)&f4) : "v"((threadIdx.x & 63u) * 16u) : "memory");   // aligned 16 B per lane
         if (OP == 18) asm volatile(X8("ds_read_b128 %0, %4\n ds_read_b128 %1, %4 offset:1024\n ds_read_b128 %2, %4 offset:2048\n ds_read_b128 %3, %4 offset:3072\n ds_read_b128 %0, %4 offset:4096\n ds_read_b128 %1, %4 offset:5120\n ds_read_b128 %2, %4 offset:6144\n ds_read_b128 %3, %4 offset:7168\n") "s_waitcnt lgkmcnt(0)\n"
                                    : "=v"(*(uint4 *)&d0), "=v"(*(uint4 *)&d2), "=v"(*(uint4 *)&f0), "=v"(*(uint4 *)&f4) : "v"((threadIdx.x & 63u) * 16u + 5u) : "memory");   // the same, 5 bytes off alignment
+        // ---- lane masks: where the mask of a v_cndmask comes from decides what it costs ----
+        if (OP == 20) asm volatile(X8("v_cmp_gt_f32_e64 s[20:21], %0, %8\n v_cndmask_b32_e64 %1, %1, %8, s[20:21]\n v_cmp_gt_f32_e64 s[22:23], %2, %8\n v_cndmask_b32_e64 %3, %3, %8, s[22:23]\n v_cmp_gt_f32_e64 s[24:25], %4, %8\n v_cndmask_b32_e64 %5, %5, %8, s[24:25]\n v_cmp_gt_f32_e64 s[26:27], %6, %8\n v_cndmask_b32_e64 %7, %7, %8, s[26:27]\n")
+                                   : "+v"(f0), "+v"(u1), "+v"(f2), "+v"(u3), "+v"(f4), "+v"(u5), "+v"(f6), "+v"(u7) : "v"(1.0f) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+        if (OP == 21) asm volatile(X8("v_cmp_gt_f32_e64 s[20:21], %0, %8\n v_cmp_gt_f32_e64 s[22:23], %2, %8\n v_cmp_gt_f32_e64 s[24:25], %4, %8\n v_cmp_gt_f32_e64 s[26:27], %6, %8\n v_cndmask_b32_e64 %1, %1, %8, s[20:21]\n v_cndmask_b32_e64 %3, %3, %8, s[22:23]\n v_cndmask_b32_e64 %5, %5, %8, s[24:25]\n v_cndmask_b32_e64 %7, %7, %8, s[26:27]\n")
+                                   : "+v"(f0), "+v"(u1), "+v"(f2), "+v"(u3), "+v"(f4), "+v"(u5), "+v"(f6), "+v"(u7) : "v"(1.0f) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+        if (OP == 22) asm volatile(X8("v_cmp_gt_f32 vcc, %0, %8\n s_and_b64 vcc, vcc, s[40:41]\n v_cndmask_b32 %1, %1, %8, vcc\n v_cmp_gt_f32 vcc, %2, %8\n s_and_b64 vcc, vcc, s[40:41]\n v_cndmask_b32 %3, %3, %8, vcc\n v_cmp_gt_f32 vcc, %4, %8\n v_cndmask_b32 %5, %5, %8, vcc\n")
+                                   : "+v"(f0), "+v"(u1), "+v"(f2), "+v"(u3), "+v"(f4), "+v"(u5) : "v"(f6), "v"(u7), "v"(1.0f) : "vcc", "s40", "s41");
+        if (OP == 23) asm volatile(X8("v_cndmask_b32_e64 %0, %0, %8, s[40:41]\n v_cndmask_b32_e64 %1, %1, %8, s[40:41]\n v_cndmask_b32_e64 %2, %2, %8, s[42:43]\n v_cndmask_b32_e64 %3, %3, %8, s[42:43]\n v_cndmask_b32_e64 %4, %4, %8, s[40:41]\n v_cndmask_b32_e64 %5, %5, %8, s[42:43]\n v_cndmask_b32_e64 %6, %6, %8, s[40:41]\n v_cndmask_b32_e64 %7, %7, %8, s[42:43]\n")
+                                   : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(3u) : "s40", "s41", "s42", "s43");
+        if (OP == 24) asm volatile(X8("v_cmp_gt_f32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cmp_gt_f32 vcc, %2, %8\n v_cndmask_b32 %7, %7, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n")
+                                   : "+v"(f0), "+v"(u1), "+v"(f2), "+v"(u3), "+v"(f4), "+v"(u5), "+v"(f6), "+v"(u7) : "v"(1.0f) : "vcc");
+        if (OP == 25) asm volatile(X8("v_cmp_gt_f32 vcc, %0, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %4, %4, %8\n v_add_f32 %6, %6, %8\n v_cndmask_b32 %1, %1, %8, vcc\n v_add_f32 %2, %2, %8\n v_add_f32 %4, %4, %8\n v_cndmask_b32 %3, %3, %8, vcc\n")
+                                   : "+v"(f0), "+v"(u1), "+v"(f2), "+v"(u3), "+v"(f4), "+v"(u5), "+v"(f6), "+v"(u7) : "v"(1.0f) : "vcc");
+        if (OP == 26) asm volatile(X8("v_cmp_eq_f32 vcc, %0, %8\n v_addc_co_u32 %1, vcc, %1, %8, vcc\n v_cmp_eq_f32 vcc, %2, %8\n v_addc_co_u32 %3, vcc, %3, %8, vcc\n v_cmp_eq_f32 vcc, %4, %8\n v_addc_co_u32 %5, vcc, %5, %8, vcc\n v_cmp_eq_f32 vcc, %6, %8\n v_addc_co_u32 %7, vcc, %7, %8, vcc\n")
+                                   : "+v"(f0), "+v"(u1), "+v"(f2), "+v"(u3), "+v"(f4), "+v"(u5), "+v"(f6), "+v"(u7) : "v"(1.0f) : "vcc");
+        if (OP == 27) asm volatile(X8("ds_read_b32 %0, %4\n ds_read_b32 %1, %4 offset:4\n ds_read_b32 %2, %4 offset:8\n ds_read_b32 %3, %4 offset:12\n ds_read_b32 %0, %4 offset:16\n ds_read_b32 %1, %4 offset:1028\n ds_read_b32 %2, %4 offset:1032\n ds_read_b32 %3, %4 offset:1036\n") "s_waitcnt lgkmcnt(0)\n"
+                                   : "=v"(u0), "=v"(u1), "=v"(u2), "=v"(u3) : "v"((threadIdx.x & 63u) * 16u + 4u) : "memory");   // dword reads, 16 B stride between lanes
+        if (OP == 28) asm volatile(X8("ds_read2_b32 %0, %4 offset1:1\n ds_read2_b32 %1, %4 offset0:2 offset1:3\n ds_read2_b32 %2, %4 offset0:4 offset1:5\n ds_read2_b32 %3, %4 offset0:6 offset1:7\n ds_read2_b32 %0, %4 offset0:8 offset1:9\n ds_read2_b32 %1, %4 offset0:10 offset1:11\n ds_read2_b32 %2, %4 offset0:12 offset1:13\n ds_read2_b32 %3, %4 offset0:14 offset1:15\n") "s_waitcnt lgkmcnt(0)\n"
+                                   : "=v"(d0), "=v"(d1), "=v"(d2), "=v"(d3) : "v"((threadIdx.x & 63u) * 16u + 4u) : "memory");
+        if (OP == 29) asm volatile(X8("ds_read_b64 %0, %4\n ds_read_b64 %1, %4 offset:1024\n ds_read_b64 %2, %4 offset:2048\n ds_read_b64 %3, %4 offset:3072\n ds_read_b64 %0, %4 offset:4096\n ds_read_b64 %1, %4 offset:5120\n ds_read_b64 %2, %4 offset:6144\n ds_read_b64 %3, %4 offset:7168\n") "s_waitcnt lgkmcnt(0)\n"
+                                   : "=v"(d0), "=v"(d1), "=v"(d2), "=v"(d3) : "v"((threadIdx.x & 63u) * 16u + 4u) : "memory");   // 8-byte reads at 4-byte alignment
+        if (OP == 30) asm volatile(X8("v_alignbyte_b32 %0, %1, %0, %8\n v_alignbyte_b32 %1, %2, %1, %8\n v_alignbyte_b32 %2, %3, %2, %8\n v_alignbyte_b32 %3, %4, %3, %8\n v_alignbyte_b32 %4, %5, %4, %8\n v_alignbyte_b32 %5, %6, %5, %8\n v_alignbyte_b32 %6, %7, %6, %8\n v_alignbyte_b32 %7, %0, %7, %8\n")
+                                   : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(threadIdx.x & 3u));
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if ((threadIdx.x & 63u) == 0u) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
@@ -99,6 +122,10 @@ int main()
     run<0>("v_add_f32", 64); run<1>("v_max_f32", 64); run<2>("v_max3_f32", 64); run<3>("v_cndmask_b32", 64); run<4>("v_cmp_gt_f32", 64);
     run<5>("v_add_u32", 64); run<6>("v_addc_co_u32", 64); run<7>("v_and_b32", 64); run<8>("v_perm_b32", 64); run<9>("v_pk_add_f32 (2 adds each)", 64);
     run<10>("v_add3_u32", 64); run<11>("v_bfe_u32", 64); run<12>("v_mad_u32_u24", 64); run<13>("v_add_u32_sdwa", 64); run<14>("v_cmp_eq_u32 + v_cndmask (pairs)", 64);
-    run<15>("ds_add_u32 conflict-free", 64); run<16>("ds_add_u32 scattered", 64); run<17>("ds_read_b128 aligned", 64); run<18>("ds_read_b128 unaligned (+5 B)", 64);
+    run<20>("v_cmp_e64 s[] ; v_cndmask_e64 s[] (adjacent)", 64); run<21>("4 x v_cmp_e64 s[] then 4 x v_cndmask_e64 s[]", 64);
+    run<22>("v_cmp vcc ; s_and_b64 vcc ; v_cndmask vcc", 64); run<23>("v_cndmask_e64 with loop-invariant s[] masks", 64);
+    run<24>("v_cmp vcc ; 3 x v_cndmask vcc", 64); run<25>("v_cmp vcc ; 3 VALU ; v_cndmask vcc ; 2 VALU ; v_cndmask", 64); run<26>("v_cmp vcc ; v_addc vcc (pairs)", 64);
+    run<27>("ds_read_b32 (dword-aligned windows)", 64); run<28>("ds_read2_b32 (dword-aligned)", 64); run<29>("ds_read_b64 at 4-byte alignment", 64); run<30>("v_alignbyte_b32", 64);
+    run<15>("ds_add_u32 conflict-free", 64); run<16>("ds_add_u32 all lanes on one bank", 64); run<17>("ds_read_b128 aligned", 64); run<18>("ds_read_b128 unaligned (+5 B)", 64);
     return 0;
 }

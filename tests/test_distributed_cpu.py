@@ -1,8 +1,9 @@
 """CPU tier: the N>1 path (contiguous shards + one all-gather of the counter blocks) under gloo, world_size 2.
 
 Each rank runs the checker on its shard (standing in for the GPU engine, which needs a device), calls the
-product's epilogue, and writes its packed slice at the offset the epilogue returned; the assembled file
-must equal the single-process result.
+product's epilogue (fxg_shard_range / fxg_epilogue of the C-ABI under torch.distributed's all-gather), and writes its
+packed slice with the product's fxg_concat_pwrite at the offset the epilogue returned; the assembled file must equal the
+single-process result.
 """
 import os
 import socket
@@ -29,10 +30,13 @@ def _worker(rank, world, port, tmp):
     o = fo.run_pipeline(b, q, None, fo.make_params(**PD))
     counters = torch.from_numpy(o["counters"].view(np.int64).copy())
     totals, read_off, byte_off, per_rank = fxd.epilogue(counters)
-    with open(os.path.join(tmp, "bases.bin"), "r+b") as f:
-        f.seek(byte_off); f.write(o["out_bases"].tobytes())
-    with open(os.path.join(tmp, "kept.bin"), "r+b") as f:
-        f.seek(read_off * 4); f.write((o["kept_index"] + np.uint32(lo)).tobytes())
+    # the concatenation is product code too: every rank writes its slice at the offset the epilogue returned
+    fd = os.open(os.path.join(tmp, "bases.bin"), os.O_WRONLY)
+    fxd.concat_pwrite(fd, o["out_bases"], byte_off)
+    os.close(fd)
+    fd = os.open(os.path.join(tmp, "kept.bin"), os.O_WRONLY)
+    fxd.concat_pwrite(fd, o["kept_index"] + np.uint32(lo), read_off * 4)
+    os.close(fd)
     np.save(os.path.join(tmp, "totals%d.npy" % rank), totals)
     dist.barrier()
     dist.destroy_process_group()

@@ -43,11 +43,13 @@ CASES = [
     b">s1\nACGTNNACGT\n>s2-17\nAC\n",                                                 # FASTA incl. collapsed id
     b"@r1\nACGT\nXthird line junk\nIIII\n",                                           # line 3 is not validated (R5)
     b"@r\rjunk\nACGT\rjunk\n+\rjunk\nIIII\rjunk\n",                                   # chomp cuts at the first CR
+    b"@r1\nACGT\n+\n1 2 3 4294967297\n",                                               # strtol's long lands in an int: 1
+    b"@r1\nACGT\n+\n10-5 3+4\n@r2\nACG\n+\n\t1 \x0b2  +3\n",                           # strtol tokens: a sign starts a new value, any isspace() separates
 ]
 BAD = [
     b"", b"ACGT\n", b"@r1\nACGX\n+\nIIII\n", b"@r1\nacgt\n+\nIIII\n", b"@r1\n\n+\n\n", b"@r1\nACGT\n+\nIIII\n\n",
     b"@r1\nACGT\n+\nIII\x07\n", b"@r1\nACGT\n+\n", b"@r1\nACGT\n", b"@r1\nACGT\n+\n1 2 3\n", b"@r1\nACGT\n+\n1 2 x 4\n",
-    b"@r1\nACGT\n+\n1 2 3 99\n", b">s1\nACGT\nACGT\n", b">s1\nACGT\n@r\nAC\n", b"@ok\nAC\n+\nII\n@r1\nAC\n+\nI\n",
+    b"@r1\nACGT\n+\n1 2 3 99\n", b"@r1\nACGT\n+\n1 2 3 4 \n", b"@r1\nACGT\n+\n1 2 3 --4\n", b">s1\nACGT\nACGT\n", b">s1\nACGT\n@r\nAC\n", b"@ok\nAC\n+\nII\n@r1\nAC\n+\nI\n",
 ]
 
 
@@ -108,3 +110,15 @@ def test_fuzz_text_vs_reference(copy_tool):
         assert (rc, out) == (rrc, rout), trial
         if rc == 0:
             assert err == rerr
+
+
+def test_overlong_identifier_lines_are_rejected_not_overflowed(copy_tool):
+    """Lines of 24 999+ characters: the reference's fgets() would split them silently; this layer refuses them -- for the
+    identifier and '+' lines too, whose FASTX buffers hold MAX_SEQ_LINE_LENGTH bytes."""
+    long_id = b"x" * 30000
+    for data in (b"@" + long_id + b"\nACGT\n+\nIIII\n", b"@r\nACGT\n+" + long_id + b"\nIIII\n", b">" + long_id + b"\nACGT\n",
+                 b"@ok\nAC\n+\nII\n@" + long_id + b"\nACGT\n+\nIIII\n"):
+        rc, out, err = _run([copy_tool], data)
+        assert rc == 1 and b"longer than" in err
+    rc, out, err = _run([copy_tool], b"@" + b"x" * 24000 + b"\nACGT\n+" + b"y" * 24000 + b"\nIIII\n")
+    assert rc == 0 and out == b"@" + b"x" * 24000 + b"\nACGT\n+" + b"y" * 24000 + b"\nIIII\n"
