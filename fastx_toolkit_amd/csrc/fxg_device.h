@@ -59,7 +59,8 @@ struct FxgKArgs {
     u64 *pfx;               // [2*ntiles] exclusive prefixes {tag:8 | value:56}: [2t] kept reads before tile t, [2t+1] kept bytes before it (scanner)
     u32 *role;              // the workgroup that draws 0 here becomes the scanner
     u32  tag;               // launch epoch 1..255: granules of earlier launches are invalid without a memset
-    u32  qlds;              // the tile's quality rows stay in LDS between stage A and the gather (no second HBM read)
+    u32  qlds;              // rows that stay in LDS between stage A and the gather: 1 = the tile's quality rows (no second HBM read of them),
+                            // 2 = quality and base rows (the gather reads no HBM at all: traffic = input + output)
     u64 *partial;           // [count grid][FXG_NCOUNTERS]
     u32 *ticket;            // dynamic tile dispensers, FXG_TICKET_STRIDE words apart (zeroed before every launch)
     u32  ticket_groups;     // number of dispensers (<= 8): dispenser g hands out tiles g, g+groups, g+2*groups, ...
@@ -363,7 +364,7 @@ __device__ __forceinline__ void fxg_resolve_prefix(const FxgKArgs &a, u32 tile, 
 // agent-scope loads (the data is its own flag: no fences).
 // ------------------------------------------------------------------------------------------------
 #ifndef FXG_SCAN_K
-#define FXG_SCAN_K 8
+#define FXG_SCAN_K 16
 #endif
 #define FXG_TAG_SHIFT 56
 #define FXG_TAG_VALUE(x) ((x) & ((1ull << FXG_TAG_SHIFT) - 1ull))
@@ -557,8 +558,8 @@ FXG_HD u32x4 fxg_lds_window16(const uint8_t *base, int p)
 #endif
 }
 
-// LQ: the quality windows come from the tile's quality rows kept in LDS by stage A (src_q = their byte 0) instead of the batch in HBM
-template <bool REV, bool MASK, bool LQ>
+// LQ / LB: the quality / base windows come from the tile's rows kept in LDS by stage A (src_q / src_b = their byte 0) instead of the batch in HBM
+template <bool REV, bool MASK, bool LQ, bool LB>
 FXG_HD void fxg_chunk_load(FxgChunk &c, const uint8_t *src_b, const uint8_t *src_q, bool want_q, const u32 *k_off, const u32 *k_src,
                            const uint16_t *k_tab, u32 nk, u32 S, u32 o)
 {
@@ -568,7 +569,7 @@ FXG_HD void fxg_chunk_load(FxgChunk &c, const uint8_t *src_b, const uint8_t *src
     const int e = e1 - o < 16u ? (int)(e1 - o) : 16;
     const int p1 = REV ? (int)k_src[k] - j0 - 15 : (int)k_src[k] + j0;
     c.o = o; c.k = k; c.e = e; c.e2 = 16;
-    c.wb = fxg_ld16_stream(src_b + p1);
+    c.wb = LB ? fxg_lds_window16(src_b, p1) : fxg_ld16_stream(src_b + p1);
     c.wq = (u32x4){0u, 0u, 0u, 0u};
     if (want_q) c.wq = LQ ? fxg_lds_window16(src_q, p1) : fxg_ld16_stream(src_q + p1);
     c.vb = c.vq = (u32x4){0u, 0u, 0u, 0u};
@@ -576,7 +577,7 @@ FXG_HD void fxg_chunk_load(FxgChunk &c, const uint8_t *src_b, const uint8_t *src
         const u32 n2 = k_off[k + 2u] - e1;
         c.e2 = n2 < (u32)(16 - e) ? e + (int)n2 : 16;
         const int p2 = REV ? (int)k_src[k + 1u] + e - 15 : (int)k_src[k + 1u] - e;
-        c.vb = fxg_ld16_stream(src_b + p2);
+        c.vb = LB ? fxg_lds_window16(src_b, p2) : fxg_ld16_stream(src_b + p2);
         if (want_q) c.vq = LQ ? fxg_lds_window16(src_q, p2) : fxg_ld16_stream(src_q + p2);
     }
 }
@@ -584,9 +585,9 @@ FXG_HD void fxg_chunk_load(FxgChunk &c, const uint8_t *src_b, const uint8_t *src
 // lq: the tile's quality rows in LDS (tile byte 0 at lq[0], 16 readable bytes either side), or null: read them from HBM again
 // LQ says at compile time whether lq is used, so that its loads are LDS instructions (a run-time choice between an LDS and an
 // HBM pointer would make them flat loads).
-template <bool REV, bool MASK = false, bool LQ = false>
+template <bool REV, bool MASK = false, bool LQ = false, bool LB = false>
 FXG_HD u32 fxg_tile_gather(const FxgKArgs &a, const u32 *k_off, const u32 *k_src, const uint16_t *k_tab, u32 nk,
-                           u64 tile_in_base, u32 tile_bytes, u64 B, u32 S, u32 tid, u32 nthreads, const uint8_t *lq = nullptr)
+                           u64 tile_in_base, u32 tile_bytes, u64 B, u32 S, u32 tid, u32 nthreads, const uint8_t *lq = nullptr, const uint8_t *lb = nullptr)
 {
     if (S == 0) return 0u;
     const bool has_q = a.qual != nullptr && a.out_qual != nullptr && !FXG_DBG(a, 4u);
@@ -612,7 +613,7 @@ FXG_HD u32 fxg_tile_gather(const FxgKArgs &a, const u32 *k_off, const u32 *k_src
         for (int u = 0; u < FXG_GATHER_K; ++u) {
             const u32 ci = c0 + (u32)u * nthreads;
             ch[u].e = 0;
-            if (ci < nfull) fxg_chunk_load<REV, MASK, LQ>(ch[u], src_b, LQ ? lq : src_q, has_q || MASK, k_off, k_src, k_tab, nk, S, o_lo + (ci << 4));
+            if (ci < nfull) fxg_chunk_load<REV, MASK, LQ, LB>(ch[u], LB ? lb : src_b, LQ ? lq : src_q, has_q || MASK, k_off, k_src, k_tab, nk, S, o_lo + (ci << 4));
         }
 #pragma unroll
         for (int u = 0; u < FXG_GATHER_K; ++u) {

@@ -32,22 +32,25 @@
 #endif
 #define FXG_SLOTS (FXG_SAMESTEP ? 1u : 2u)
 struct FxgLds {
-    u32 slot_bytes, so_ksrc, so_kidx, so_ktab, so_qrows;   // slot k lives at k * slot_bytes: k_off at +0, k_src at +so_ksrc, k_idx at +so_kidx, k_tab at +so_ktab, quality rows at +so_qrows
+    u32 slot_bytes, so_ksrc, so_kidx, so_ktab, so_qrows, so_brows;   // slot k lives at k * slot_bytes: k_off at +0, k_src at +so_ksrc, k_idx at +so_kidx, k_tab at +so_ktab, quality rows at +so_qrows, base rows at +so_brows
     u32 off_scratch, off_bm_g, off_bm_l, off_bases, total;
     u32 has_tab;                                 // kernels that stage a tile of bases in LDS (clipper, census) spend no LDS on k_tab
-    u32 has_qrows;
+    u32 has_qrows, has_brows;                    // rows kept in LDS: 0 none, qualities only, or qualities and bases (the gather then reads no HBM at all)
 };
 __host__ __device__ inline u32 fxg_r16(u32 x) { return (x + 15u) & ~15u; }
-__host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, bool bitmaps, u32 stage_stride, bool qrows = false)   // stage_stride: row stride of the LDS copy of the tile's bases, 0 = none
+__host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, bool bitmaps, u32 stage_stride, u32 rows = 0)   // stage_stride: row stride of the LDS copy of the tile's bases, 0 = none; rows: FxgKArgs::qlds
 {
     FxgLds l;
     l.so_ksrc = fxg_r16((T + 1) * 4);
     l.so_kidx = l.so_ksrc + fxg_r16(T * 4);
     l.so_ktab = l.so_kidx + fxg_r16(T * 2);
     l.has_tab = stage_stride ? 0u : 1u;
-    l.has_qrows = (qrows && bitmaps) ? 1u : 0u;
+    l.has_qrows = (rows >= 1u && bitmaps) ? 1u : 0u;
+    l.has_brows = (rows >= 2u && bitmaps) ? 1u : 0u;
+    const u32 rows_bytes = 16u + fxg_r16(T * stride) + 16u;
     l.so_qrows = l.so_ktab + (l.has_tab ? fxg_r16(((T * stride + 15) / 16 + 1) * 2) : 0u);
-    l.slot_bytes = l.so_qrows + (l.has_qrows ? 16u + fxg_r16(T * stride) + 16u : 0u);
+    l.so_brows = l.so_qrows + (l.has_qrows ? rows_bytes : 0u);
+    l.slot_bytes = l.so_brows + (l.has_brows ? rows_bytes : 0u);
     u32 o = FXG_SLOTS * l.slot_bytes;
     l.off_scratch = o; o += fxg_r16(48 * 4);
     const u32 words = (T * stride + 31) / 32 + 2;
@@ -364,6 +367,23 @@ FXG_HD void fxg_phase_bitmaps(const FxgKArgs &a, u64 tb, u32 tbytes, u32 *bm_g, 
     }
 }
 
+// phase 1 (rows kept in LDS): the tile's base rows -> LDS, 16 bytes per lane, several loads in flight (full in-range tiles;
+// other tiles are gathered byte by byte from HBM and never look at the copy)
+FXG_HD void fxg_phase_copy_rows(const uint8_t *src, u64 total, u64 tb, u32 tbytes, uint8_t *rows, u32 tid, u32 nthreads)
+{
+    if ((tbytes & 15u) != 0u || tb + tbytes > total) return;
+    constexpr u32 U = FXG_BITMAP_U;
+    const u32 nchunks = tbytes >> 4;
+    const uint8_t *p = src + tb;
+    for (u32 c0 = tid; c0 < nchunks; c0 += nthreads * U) {
+        u32x4 v[U];
+#pragma unroll
+        for (u32 u = 0; u < U; ++u) { const u32 c = c0 + u * nthreads; if (c < nchunks) v[u] = fxg_ld16(p + ((u64)c << 4)); }
+#pragma unroll
+        for (u32 u = 0; u < U; ++u) { const u32 c = c0 + u * nthreads; if (c < nchunks) *reinterpret_cast<u32x4 *>(rows + ((size_t)c << 4)) = v[u]; }
+    }
+}
+
 // phase 1 (clipper, census): rows of the tile -> LDS, so that one thread can walk one read.  tb/tbytes/total are in bytes of `src`
 FXG_HD void fxg_phase_stage_bases(const uint8_t *src, u64 total, u64 tb, u32 tbytes, uint8_t *sb, u32 tid, u32 nthreads)
 {
@@ -489,7 +509,7 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void f
     constexpr bool REV = (MODE == 2);
     const u32 T = a.tile_reads, stride = a.stride, tid = threadIdx.x;
     const bool use_q = (MODE == 0 && (a.stages & (FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0) || MODE == 3;
-    const FxgLds L = fxg_lds_layout(T, stride, use_q, (MODE == 0 && AMAX != 0) ? a.clip_stride : (MODE == 4 ? stride : 0u), a.qlds != 0u);
+    const FxgLds L = fxg_lds_layout(T, stride, use_q, (MODE == 0 && AMAX != 0) ? a.clip_stride : (MODE == 4 ? stride : 0u), a.qlds);
     u32 m_reads = 0, m_nt = 0, art_bad = 0;      // MODE 3 report counters / MODE 4 alphabet check, folded once at the end
     u32 *bm_g = reinterpret_cast<u32 *>(smem + L.off_bm_g);
     u32 *bm_l = reinterpret_cast<u32 *>(smem + L.off_bm_l);
@@ -541,6 +561,7 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void f
             unsigned char *sl = smem + slot * L.slot_bytes;
             if constexpr (MODE == 0 || MODE == 3 || MODE == 4) {
                 if (use_q && !FXG_DBG(a, 8u)) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, FXG_TBLOCK, L.has_qrows ? sl + L.so_qrows + 16u : nullptr);
+                if constexpr (MODE == 0 && AMAX == 0) { if (L.has_brows) fxg_phase_copy_rows(a.bases, a.total_bytes, tb, tbytes, sl + L.so_brows + 16u, tid, FXG_TBLOCK); }
                 if constexpr (MODE == 0 && AMAX != 0) fxg_phase_stage_bases(a.clip_src, a.clip_total, (u64)r0 * a.clip_stride, nreads * a.clip_stride, sb, tid, FXG_TBLOCK);
                 if constexpr (MODE == 4) fxg_phase_stage_bases(a.bases, a.total_bytes, tb, tbytes, sb, tid, FXG_TBLOCK);
                 __syncthreads();
@@ -608,7 +629,9 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void f
             if (tid < nk) fxg_write_kept_meta(a, base_c + tid, k_off[tid + 1] - k_off[tid], r0 + k_idx[tid], base_b + k_off[tid]);
             if (!FXG_DBG(a, 1u)) {
                 u32 bad;
-                if ((MODE == 0 || MODE == 3) && L.has_qrows)        // uniform branch: quality windows from the slot's rows in LDS
+                if (MODE == 0 && AMAX == 0 && L.has_brows)          // uniform branches: windows from the slot's rows in LDS
+                    bad = fxg_tile_gather<REV, false, true, true>(a, k_off, k_src, k_tab, nk, (u64)r0 * stride, nreads * stride, base_b, totb, tid, FXG_TBLOCK, sl + L.so_qrows + 16u, sl + L.so_brows + 16u);
+                else if ((MODE == 0 || MODE == 3) && L.has_qrows)
                     bad = fxg_tile_gather<REV, MODE == 3, true>(a, k_off, k_src, k_tab, nk, (u64)r0 * stride, nreads * stride, base_b, totb, tid, FXG_TBLOCK, sl + L.so_qrows + 16u);
                 else
                     bad = fxg_tile_gather<REV, MODE == 3, false>(a, k_off, k_src, k_tab, nk, (u64)r0 * stride, nreads * stride, base_b, totb, tid, FXG_TBLOCK);

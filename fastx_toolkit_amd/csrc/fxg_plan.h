@@ -39,8 +39,8 @@ static inline u32 fxg_pick_tile(u32 stride, bool clip)
 static inline FxgLds fxg_plan_layout(const FxgPlan *pl)
 {
     const FxgKArgs &ka = pl->ka;
-    return pl->group_a ? fxg_lds_layout(ka.tile_reads, ka.stride, pl->use_q, pl->clip ? ka.clip_stride : 0u, ka.qlds != 0u)
-         : pl->mask ? fxg_lds_layout(ka.tile_reads, ka.stride, true, 0u, ka.qlds != 0u)
+    return pl->group_a ? fxg_lds_layout(ka.tile_reads, ka.stride, pl->use_q, pl->clip ? ka.clip_stride : 0u, ka.qlds)
+         : pl->mask ? fxg_lds_layout(ka.tile_reads, ka.stride, true, 0u, ka.qlds)
          : pl->artifacts ? fxg_lds_layout(ka.tile_reads, ka.stride, false, ka.stride) : fxg_lds_layout(ka.tile_reads, ka.stride, false, 0u);
 }
 static inline u32 fxg_plan_lds(const FxgPlan *pl) { return fxg_plan_layout(pl).total; }
@@ -114,14 +114,15 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     ka.qlds = 0u;
     if (ka.compact && !pl->clip && (pl->use_q || gm)) {
         const char *e = getenv("FXG_QLDS");
-        ka.qlds = (e ? atoi(e) : FXG_QLDS_DEFAULT) ? 1u : 0u;
+        ka.qlds = (u32)fxg_clampi(e ? atoi(e) : FXG_QLDS_DEFAULT, 0, gm ? 1 : 2);    // the masker needs the base rows only through the gather's select: qualities at most
         if (ka.qlds) {
             const char *be = getenv("FXG_QLDS_BUDGET");
             const u32 budget = (be && atoi(be) >= 4096) ? (u32)atoi(be) : FXG_QLDS_BUDGET;
             u32 Tq = T;
-            while (Tq > 16 && fxg_lds_layout(Tq, in->stride, true, 0u, true).total > budget) Tq >>= 1;
-            if (fxg_lds_layout(Tq, in->stride, true, 0u, true).total > budget + budget / 2) ka.qlds = 0u;   // long reads: read the rows twice instead
+            while (Tq > 16 && fxg_lds_layout(Tq, in->stride, true, 0u, ka.qlds).total > budget) Tq >>= 1;
+            if (fxg_lds_layout(Tq, in->stride, true, 0u, ka.qlds).total > budget + budget / 2) ka.qlds = 0u;   // long reads: read the rows twice instead
             else T = Tq;
+            if (ka.qlds == 2u && ((u64)T * in->stride) % 16u != 0u) ka.qlds = 1u;      // the base rows are copied 16 bytes at a time
         }
     }
     const u64 ntiles = (in->n + T - 1) / T;

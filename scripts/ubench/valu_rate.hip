@@ -4,6 +4,7 @@
 // shader cycles (s_memtime) per wave-instruction, for 1, 2 and 4 waves per SIMD.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -117,15 +118,18 @@ static void run(const char *name, int per_rep)
     hipFree(out); hipFree(sink);
 }
 
-int main()
+#define RUN(id, name) if (only < 0 || only == id) run<id>(name, 64)
+int main(int argc, char **argv)
 {
-    run<0>("v_add_f32", 64); run<1>("v_max_f32", 64); run<2>("v_max3_f32", 64); run<3>("v_cndmask_b32", 64); run<4>("v_cmp_gt_f32", 64);
-    run<5>("v_add_u32", 64); run<6>("v_addc_co_u32", 64); run<7>("v_and_b32", 64); run<8>("v_perm_b32", 64); run<9>("v_pk_add_f32 (2 adds each)", 64);
-    run<10>("v_add3_u32", 64); run<11>("v_bfe_u32", 64); run<12>("v_mad_u32_u24", 64); run<13>("v_add_u32_sdwa", 64); run<14>("v_cmp_eq_u32 + v_cndmask (pairs)", 64);
-    run<20>("v_cmp_e64 s[] ; v_cndmask_e64 s[] (adjacent)", 64); run<21>("4 x v_cmp_e64 s[] then 4 x v_cndmask_e64 s[]", 64);
-    run<22>("v_cmp vcc ; s_and_b64 vcc ; v_cndmask vcc", 64); run<23>("v_cndmask_e64 with loop-invariant s[] masks", 64);
-    run<24>("v_cmp vcc ; 3 x v_cndmask vcc", 64); run<25>("v_cmp vcc ; 3 VALU ; v_cndmask vcc ; 2 VALU ; v_cndmask", 64); run<26>("v_cmp vcc ; v_addc vcc (pairs)", 64);
-    run<27>("ds_read_b32 (dword-aligned windows)", 64); run<28>("ds_read2_b32 (dword-aligned)", 64); run<29>("ds_read_b64 at 4-byte alignment", 64); run<30>("v_alignbyte_b32", 64);
-    run<15>("ds_add_u32 conflict-free", 64); run<16>("ds_add_u32 all lanes on one bank", 64); run<17>("ds_read_b128 aligned", 64); run<18>("ds_read_b128 unaligned (+5 B)", 64);
+    setvbuf(stdout, nullptr, _IOLBF, 0);
+    const int only = argc > 1 ? atoi(argv[1]) : -1;      // one test per process: `for i in $(seq 0 30); do timeout 20 ./valu_rate $i; done`
+    RUN(0, "v_add_f32"); RUN(1, "v_max_f32"); RUN(2, "v_max3_f32"); RUN(3, "v_cndmask_b32 (vcc never written in the loop)"); RUN(4, "v_cmp_gt_f32");
+    RUN(5, "v_add_u32"); RUN(6, "v_addc_co_u32"); RUN(7, "v_and_b32"); RUN(8, "v_perm_b32"); RUN(9, "v_pk_add_f32 (2 adds each)");
+    RUN(10, "v_add3_u32"); RUN(11, "v_bfe_u32"); RUN(12, "v_mad_u32_u24"); RUN(13, "v_add_u32_sdwa"); RUN(14, "v_cmp_eq_u32 + v_cndmask (pairs)");
+    RUN(20, "v_cmp_e64 s[] ; v_cndmask_e64 s[] (adjacent)"); RUN(21, "4 x v_cmp_e64 s[] then 4 x v_cndmask_e64 s[]");
+    RUN(22, "v_cmp vcc ; s_and_b64 vcc ; v_cndmask vcc"); RUN(23, "v_cndmask_e64 with loop-invariant s[] masks");
+    RUN(24, "v_cmp vcc ; 3 x v_cndmask vcc"); RUN(25, "v_cmp vcc ; 3 VALU ; v_cndmask vcc ; 2 VALU ; v_cndmask"); RUN(26, "v_cmp vcc ; v_addc vcc (pairs)");
+    RUN(27, "ds_read_b32 (dword-aligned windows)"); RUN(28, "ds_read2_b32 (dword-aligned)"); RUN(29, "ds_read_b64 at 4-byte alignment"); RUN(30, "v_alignbyte_b32");
+    RUN(15, "ds_add_u32 conflict-free"); RUN(16, "ds_add_u32 all lanes on one bank"); RUN(17, "ds_read_b128 aligned"); RUN(18, "ds_read_b128 unaligned (+5 B)");
     return 0;
 }
