@@ -53,14 +53,10 @@ struct FxgKArgs {
     u32      *kept_index;
     u64      *out_off;
     // engine state
-    u64 *status_cnt;        // [ntiles] decoupled look-back granules (kept reads)            -- FXG_SCANNER == 0 builds only
-    u64 *status_bytes;      // [ntiles] decoupled look-back granules (kept bytes)
     u64 *agg;               // [ntiles]   tile totals   {tag:8 | kept reads:16 << 32 | kept bytes:32}, published by the tile's workgroup
     u64 *pfx;               // [2*ntiles] exclusive prefixes {tag:8 | value:56}: [2t] kept reads before tile t, [2t+1] kept bytes before it (scanner)
     u32 *role;              // the workgroup that draws 0 here becomes the scanner
     u32  tag;               // launch epoch 1..255: granules of earlier launches are invalid without a memset
-    u32  qlds;              // rows that stay in LDS between stage A and the gather: 1 = the tile's quality rows (no second HBM read of them),
-                            // 2 = quality and base rows (the gather reads no HBM at all: traffic = input + output)
     u64 *partial;           // [count grid][FXG_NCOUNTERS]
     u32 *ticket;            // dynamic tile dispensers, FXG_TICKET_STRIDE words apart (zeroed before every launch)
     u32  ticket_groups;     // number of dispensers (<= 8): dispenser g hands out tiles g, g+groups, g+2*groups, ...
@@ -239,19 +235,10 @@ FXG_HD u32 fxg_bits_count(const u32 *bm, u32 s0, u32 n)
 }
 
 // ------------------------------------------------------------------------------------------------
-// inter-workgroup granules (decoupled look-back).  One naturally aligned u64 = {status:2, value:62},
-// written by ONE relaxed agent-scope store (sc1) and polled with relaxed agent-scope loads: the data
-// is its own flag, so no fence is needed and nothing depends on workgroup placement.
+// inter-workgroup granules.  One naturally aligned u64 = {tag:8, value:56}, written by ONE relaxed agent-scope store
+// (sc1) and polled with relaxed agent-scope loads: the data is its own flag, so no fence is needed and nothing depends on
+// workgroup placement.
 // ------------------------------------------------------------------------------------------------
-#define FXG_ST_INVALID 0ull
-#define FXG_ST_AGG     1ull
-#define FXG_ST_PREFIX  2ull
-#define FXG_ST_VALUE(x) ((x) & 0x3FFFFFFFFFFFFFFFull)
-
-__device__ __forceinline__ void fxg_granule_store(u64 *g, u64 status, u64 value)
-{
-    __hip_atomic_store(g, (status << 62) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ __forceinline__ void fxg_granule_store_raw(u64 *g, u64 v)
 {
     __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -261,110 +248,20 @@ __device__ __forceinline__ u64 fxg_granule_load(u64 *g)
     return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// sum over the 32 lanes of each half-wave, result in every lane of that half
-__device__ __forceinline__ u64 fxg_half_sum(u64 v)
-{
-#pragma unroll
-    for (int d = 16; d >= 1; d >>= 1) {
-        u32 lo = __shfl_xor((u32)v, d, 64), hi = __shfl_xor((u32)(v >> 32), d, 64);
-        v += ((u64)hi << 32) | lo;
-    }
-    return v;
-}
-
-// Both helpers are executed by wave 0 only.  Lanes 0..31 handle the kept-read count, lanes 32..63 the
-// kept-byte count.
-//
-// fxg_publish_aggregate: as soon as a tile knows its own totals it publishes them (tile 0 publishes its
-// inclusive prefix right away).  It never waits, so every running workgroup always makes progress.
-__device__ __forceinline__ void fxg_publish_aggregate(const FxgKArgs &a, u32 tile, u64 agg_cnt, u64 agg_bytes)
-{
-    const u32 lane = fxg_lane();
-    if ((lane & 31u) == 0u) {
-        u64 *st = (lane >> 5) ? a.status_bytes : a.status_cnt;
-        fxg_granule_store(st + tile, tile == 0 ? FXG_ST_PREFIX : FXG_ST_AGG, (lane >> 5) ? agg_bytes : agg_cnt);
-    }
-}
-
-// fxg_resolve_prefix: walk back over predecessor tiles, 32 per step, summing aggregates until a tile with
-// a full prefix is met; then publish this tile's inclusive prefix.  Tiles are handed out by a global
-// ticket, so every predecessor is owned by a workgroup that is already running: the wait terminates
-// whatever the residency or placement.  Returns the exclusive prefix in every lane.
-//
-// fxg_peek_window issues the loads of the first 32-tile window early (the kernel calls it before stage A of the next
-// tile, one pipeline step after the aggregates were published) and fxg_resolve_prefix consumes them as its first poll,
-// so that the memory round trip of the common one-poll case is spent under stage A instead of in front of the gather.
-__device__ __forceinline__ u64 fxg_peek_window(const FxgKArgs &a, u32 tile)
-{
-    const u32 lane = fxg_lane();
-    u64 *st = (lane >> 5) ? a.status_bytes : a.status_cnt;
-    const long long pos = (long long)tile - 1 - (long long)(lane & 31u);
-    return pos >= 0 ? fxg_granule_load(st + pos) : (FXG_ST_PREFIX << 62);
-}
-
-__device__ __forceinline__ void fxg_resolve_prefix(const FxgKArgs &a, u32 tile, u64 agg_cnt, u64 agg_bytes, u64 peek,
-                                                   u64 *base_cnt, u64 *base_bytes)
-{
-    const u32 lane = fxg_lane();
-    const u32 half = lane >> 5, hl = lane & 31u;
-    u64 *st = half ? a.status_bytes : a.status_cnt;
-    const u64 agg = half ? agg_bytes : agg_cnt;
-    u64 running = 0;
-    if (tile != 0) {
-        long long pos = (long long)tile - 1 - (long long)hl;
-        bool done = false;
-        const u64 t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
-        u32 spins = 0;
-        bool first = true;
-        for (;;) {
-            u64 v = (FXG_ST_PREFIX << 62);                  // virtual tile -1: prefix 0
-            if (first) v = peek;
-            else if (!done && pos >= 0) v = fxg_granule_load(st + pos);
-            first = false;
-            const u32 s = (u32)(v >> 62);
-            const u64 b_inv = __ballot(s == FXG_ST_INVALID);
-            const u64 b_pfx = __ballot(s == FXG_ST_PREFIX);
-            const u32 inv = (u32)(b_inv >> (32 * half)), pfx = (u32)(b_pfx >> (32 * half));
-            const u32 fp = pfx ? (u32)__builtin_ctz(pfx) : 32u;          // nearest predecessor with a full prefix
-            const u32 need = (fp >= 31u) ? 0xFFFFFFFFu : ((2u << fp) - 1u);
-            const bool ready = !done && ((inv & need) == 0u);
-            // every lane takes part in the shuffles; only ready halves consume the sum
-            const u64 contrib = (ready && hl <= fp) ? FXG_ST_VALUE(v) : 0ull;
-            const u64 sum = fxg_half_sum(contrib);
-            if (ready) {
-                running += sum;
-                if (fp < 32u) done = true; else pos -= 32;
-            }
-            if (__ballot(!done) == 0ull) break;
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 255u) == 0u) {   // never hang the GPU: 2 s without progress, or another workgroup already gave up
-                const bool late = __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull;
-                const u32 flagged = __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & FXG_DEV_ERR_SCAN_TIMEOUT;
-                if (late || flagged) {
-                    if (lane == 0) atomicOr(a.errflag, FXG_DEV_ERR_SCAN_TIMEOUT);
-                    break;
-                }
-            }
-        }
-        if (hl == 0) fxg_granule_store(st + tile, FXG_ST_PREFIX, running + agg);
-    }
-    *base_cnt = ((u64)__shfl((u32)(running >> 32), 0, 64) << 32) | __shfl((u32)running, 0, 64);
-    *base_bytes = ((u64)__shfl((u32)(running >> 32), 32, 64) << 32) | __shfl((u32)running, 32, 64);
-}
-
 // ------------------------------------------------------------------------------------------------
-// Central scanner (FXG_SCANNER builds).  The tiles' (kept reads, kept bytes) totals must be turned into exclusive prefixes in
+// Central scanner.  The tiles' (kept reads, kept bytes) totals must be turned into exclusive prefixes in
 // tile order.  Instead of every tile walking back over its predecessors (1 000+ tiles are in flight, so a walk is dozens of
 // dependent memory round trips), ONE wave does nothing else: it polls the totals in tile order, 64 * FXG_SCAN_K granules per
 // round trip, prefix-sums whatever contiguous run has been published and writes the prefixes back; a tile then needs ONE load
-// of its own prefix.  The scanner is whichever workgroup draws 0 from a role counter at kernel start, so it is running by
+// of its own prefix.  (Round 1 used decoupled look-back: 4.31 ms against 4.13 ms for cfg2, and 4.94 against 4.15 with 128-read
+// tiles, profiles/r02/variants_a.txt.)  The scanner is whichever workgroup draws 0 from a role counter at kernel start, so it is running by
 // construction; it only ever waits for totals of tiles whose tickets were drawn (their owners are running and publish before
 // they wait for anything), and a tile only waits for the scanner: progress is independent of residency, dispatch order and
 // placement.  Granules carry the launch's epoch tag, are written by ONE relaxed agent-scope store and polled with relaxed
 // agent-scope loads (the data is its own flag: no fences).
 // ------------------------------------------------------------------------------------------------
 #ifndef FXG_SCAN_K
-#define FXG_SCAN_K 16
+#define FXG_SCAN_K 8      // 512 tiles per round trip; the batch lives in registers of every instance of the tile kernel (16 cost the streaming kernels a wave per SIMD)
 #endif
 #define FXG_TAG_SHIFT 56
 #define FXG_TAG_VALUE(x) ((x) & ((1ull << FXG_TAG_SHIFT) - 1ull))
@@ -538,28 +435,7 @@ FXG_HD void fxg_gather_byte(const FxgKArgs &a, const uint8_t *src_b, const uint8
 #endif
 struct FxgChunk { u32 o, k; int e, e2; u32x4 wb, wq, vb, vq; };
 
-// 16 bytes at ANY byte offset p (>= -16) of an LDS array whose byte 0 is 16-byte aligned.  gfx950 executes a misaligned
-// ds_read_b128 correctly but 16x slower than an aligned one (measured: 163-256 vs 10-16 cycles per wave instruction,
-// profiles/r02_valu_rate_*.txt), so the window is five naturally aligned dword reads funnel-shifted with v_alignbyte_b32.
-// The reads are volatile so that the compiler cannot fuse them back into one wide, misaligned access.
-FXG_HD u32x4 fxg_lds_window16(const uint8_t *base, int p)
-{
-    const int a = p & ~3;
-    const u32 sh = (u32)p & 3u;
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef const volatile u32 __attribute__((address_space(3))) fxg_lds_u32;   // explicitly LDS: ds_read_b32, never a flat access
-    fxg_lds_u32 *w = (fxg_lds_u32 *)(base + a);
-    const u32 d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
-    return (u32x4){__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
-                   __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
-#else
-    (void)a; (void)sh;
-    return fxg_ld16(base + p);
-#endif
-}
-
-// LQ / LB: the quality / base windows come from the tile's rows kept in LDS by stage A (src_q / src_b = their byte 0) instead of the batch in HBM
-template <bool REV, bool MASK, bool LQ, bool LB>
+template <bool REV, bool MASK>
 FXG_HD void fxg_chunk_load(FxgChunk &c, const uint8_t *src_b, const uint8_t *src_q, bool want_q, const u32 *k_off, const u32 *k_src,
                            const uint16_t *k_tab, u32 nk, u32 S, u32 o)
 {
@@ -569,25 +445,22 @@ FXG_HD void fxg_chunk_load(FxgChunk &c, const uint8_t *src_b, const uint8_t *src
     const int e = e1 - o < 16u ? (int)(e1 - o) : 16;
     const int p1 = REV ? (int)k_src[k] - j0 - 15 : (int)k_src[k] + j0;
     c.o = o; c.k = k; c.e = e; c.e2 = 16;
-    c.wb = LB ? fxg_lds_window16(src_b, p1) : fxg_ld16_stream(src_b + p1);
+    c.wb = fxg_ld16_stream(src_b + p1);
     c.wq = (u32x4){0u, 0u, 0u, 0u};
-    if (want_q) c.wq = LQ ? fxg_lds_window16(src_q, p1) : fxg_ld16_stream(src_q + p1);
+    if (want_q) c.wq = fxg_ld16_stream(src_q + p1);
     c.vb = c.vq = (u32x4){0u, 0u, 0u, 0u};
     if (e < 16) {                                                         // the chunk continues in the next kept read
         const u32 n2 = k_off[k + 2u] - e1;
         c.e2 = n2 < (u32)(16 - e) ? e + (int)n2 : 16;
         const int p2 = REV ? (int)k_src[k + 1u] + e - 15 : (int)k_src[k + 1u] - e;
-        c.vb = LB ? fxg_lds_window16(src_b, p2) : fxg_ld16_stream(src_b + p2);
-        if (want_q) c.vq = LQ ? fxg_lds_window16(src_q, p2) : fxg_ld16_stream(src_q + p2);
+        c.vb = fxg_ld16_stream(src_b + p2);
+        if (want_q) c.vq = fxg_ld16_stream(src_q + p2);
     }
 }
 
-// lq: the tile's quality rows in LDS (tile byte 0 at lq[0], 16 readable bytes either side), or null: read them from HBM again
-// LQ says at compile time whether lq is used, so that its loads are LDS instructions (a run-time choice between an LDS and an
-// HBM pointer would make them flat loads).
-template <bool REV, bool MASK = false, bool LQ = false, bool LB = false>
+template <bool REV, bool MASK = false>
 FXG_HD u32 fxg_tile_gather(const FxgKArgs &a, const u32 *k_off, const u32 *k_src, const uint16_t *k_tab, u32 nk,
-                           u64 tile_in_base, u32 tile_bytes, u64 B, u32 S, u32 tid, u32 nthreads, const uint8_t *lq = nullptr, const uint8_t *lb = nullptr)
+                           u64 tile_in_base, u32 tile_bytes, u64 B, u32 S, u32 tid, u32 nthreads)
 {
     if (S == 0) return 0u;
     const bool has_q = a.qual != nullptr && a.out_qual != nullptr && !FXG_DBG(a, 4u);
@@ -613,7 +486,7 @@ FXG_HD u32 fxg_tile_gather(const FxgKArgs &a, const u32 *k_off, const u32 *k_src
         for (int u = 0; u < FXG_GATHER_K; ++u) {
             const u32 ci = c0 + (u32)u * nthreads;
             ch[u].e = 0;
-            if (ci < nfull) fxg_chunk_load<REV, MASK, LQ, LB>(ch[u], LB ? lb : src_b, LQ ? lq : src_q, has_q || MASK, k_off, k_src, k_tab, nk, S, o_lo + (ci << 4));
+            if (ci < nfull) fxg_chunk_load<REV, MASK>(ch[u], src_b, src_q, has_q || MASK, k_off, k_src, k_tab, nk, S, o_lo + (ci << 4));
         }
 #pragma unroll
         for (int u = 0; u < FXG_GATHER_K; ++u) {

@@ -21,7 +21,7 @@ struct fxg_ctx {
     hipEvent_t ev0, ev1;
     hipEvent_t kev0, kev1;  // around the dominant kernel when profiling
     int profiling, kev_valid;
-    u64 *status;            // 3 * status_cap granules: tile totals [cap], prefixes [2 * cap] (look-back builds: two arrays of [cap])
+    u64 *status;            // 3 * status_cap granules: tile totals [cap], prefixes [2 * cap]
     size_t status_cap;      // in tiles
     u32 epoch;              // tag of the granules of the current launch (1..255); 0 = never valid
     void *attr_kernel[8];   // kernels whose launch attributes were set, with the LDS size and the occupancy answer
@@ -218,8 +218,7 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
     u64 workers = (u64)c->cus * (u64)use;
     if (workers > ka.ntiles) workers = ka.ntiles;
     if (workers < 1) workers = 1;
-    const bool scan = FXG_SCANNER && ka.compact;            // one more workgroup: the scanner (fxg_device.h)
-    const u64 grid = workers + (scan ? 1u : 0u);
+    const u64 grid = workers + (ka.compact ? 1u : 0u);     // one more workgroup: the scanner (fxg_device.h)
 
     if (ka.compact) {
         bool fresh = false;
@@ -231,20 +230,12 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
             c->status_cap = cap;
             fresh = true;
         }
-#if FXG_SCANNER
         // granules carry the launch's epoch, so the arrays are only cleared when they are new or the 8-bit epoch wraps
         c->epoch = c->epoch >= 255u ? 1u : c->epoch + 1u;
         if (fresh || c->epoch == 1u) FXG_HIP(c, hipMemsetAsync(c->status, 0, 3 * c->status_cap * sizeof(u64), c->stream));
         ka.agg = c->status;
         ka.pfx = c->status + c->status_cap;
         ka.tag = c->epoch;
-#else
-        (void)fresh;
-        ka.status_cnt = c->status;
-        ka.status_bytes = c->status + c->status_cap;
-        FXG_HIP(c, hipMemsetAsync(ka.status_cnt, 0, (size_t)ka.ntiles * sizeof(u64), c->stream));
-        FXG_HIP(c, hipMemsetAsync(ka.status_bytes, 0, (size_t)ka.ntiles * sizeof(u64), c->stream));
-#endif
     }
     if (c->partial_cap < FXG_COUNT_GRID) {
         (void)hipFree(c->partial);

@@ -8,8 +8,8 @@
 //                      2. one thread per read: (clip DP over LDS-staged bases,) trim point = highest set
 //                         bit, filter count = popcount of the trimmed prefix -> res[]            [HBM write 4 B/read]
 //                      3. workgroup scan of (keep, new_len); publish the tile's totals (never waits)
-//   stage B(tile i)    4. resolve the tile's global offsets by decoupled look-back (predecessors have had a
-//                         whole stage A to publish, so the hand-off latency is off the critical path)
+//   stage B(tile i)    4. fetch the tile's global offsets: one dedicated workgroup (the scanner, fxg_device.h) turns the
+//                         published totals into prefixes in tile order; it has had a whole stage A to do so
 //                      5. order-preserving gather of the kept prefixes into the packed output, one 16 B
 //                         aligned output chunk per lane                    [HBM read <= 2L, write 2*new_len / kept read]
 // The -v report counters are not kept in this kernel: a second tiny pass reduces res[] (4 B/read).
@@ -19,39 +19,23 @@
 #define FXG_INVALID_TUPLE 0xFFFFFFFFu
 
 // LDS carve-up shared by host (size) and device (pointers); every region is 16-byte aligned (G17).
-// A slot holds what the gather of one tile needs: k_off / k_src / k_idx / k_tab (the tile's kept reads, see fxg_tile_gather)
-// and, when the quality rows are retained (qlds), the tile's quality rows themselves with 16 spare bytes either side (a
-// 16-byte window may start up to 15 bytes before the first row and end up to 15 bytes after the last).
-// FXG_SLOTS == 2: stage B of tile i reads slot s while stage A of tile i+1 fills slot s^1.  FXG_SLOTS == 1 (FXG_SAMESTEP):
-// a tile is gathered in the step that decided it.
-#ifndef FXG_SAMESTEP
-#define FXG_SAMESTEP 0
-#endif
-#ifndef FXG_SCANNER
-#define FXG_SCANNER 1
-#endif
-#define FXG_SLOTS (FXG_SAMESTEP ? 1u : 2u)
+// k_off / k_src / k_idx / k_tab (the tile's kept reads, see fxg_tile_gather) are double buffered: stage B of tile i reads
+// slot s while stage A of tile i+1 fills slot s^1.
 struct FxgLds {
-    u32 slot_bytes, so_ksrc, so_kidx, so_ktab, so_qrows, so_brows;   // slot k lives at k * slot_bytes: k_off at +0, k_src at +so_ksrc, k_idx at +so_kidx, k_tab at +so_ktab, quality rows at +so_qrows, base rows at +so_brows
+    u32 slot_bytes, so_ksrc, so_kidx, so_ktab;   // slot k lives at k * slot_bytes: k_off at +0, k_src at +so_ksrc, k_idx at +so_kidx, k_tab at +so_ktab
     u32 off_scratch, off_bm_g, off_bm_l, off_bases, total;
     u32 has_tab;                                 // kernels that stage a tile of bases in LDS (clipper, census) spend no LDS on k_tab
-    u32 has_qrows, has_brows;                    // rows kept in LDS: 0 none, qualities only, or qualities and bases (the gather then reads no HBM at all)
 };
 __host__ __device__ inline u32 fxg_r16(u32 x) { return (x + 15u) & ~15u; }
-__host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, bool bitmaps, u32 stage_stride, u32 rows = 0)   // stage_stride: row stride of the LDS copy of the tile's bases, 0 = none; rows: FxgKArgs::qlds
+__host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, bool bitmaps, u32 stage_stride)   // stage_stride: row stride of the LDS copy of the tile's bases, 0 = none
 {
     FxgLds l;
     l.so_ksrc = fxg_r16((T + 1) * 4);
     l.so_kidx = l.so_ksrc + fxg_r16(T * 4);
     l.so_ktab = l.so_kidx + fxg_r16(T * 2);
     l.has_tab = stage_stride ? 0u : 1u;
-    l.has_qrows = (rows >= 1u && bitmaps) ? 1u : 0u;
-    l.has_brows = (rows >= 2u && bitmaps) ? 1u : 0u;
-    const u32 rows_bytes = 16u + fxg_r16(T * stride) + 16u;
-    l.so_qrows = l.so_ktab + (l.has_tab ? fxg_r16(((T * stride + 15) / 16 + 1) * 2) : 0u);
-    l.so_brows = l.so_qrows + (l.has_qrows ? rows_bytes : 0u);
-    l.slot_bytes = l.so_brows + (l.has_brows ? rows_bytes : 0u);
-    u32 o = FXG_SLOTS * l.slot_bytes;
+    l.slot_bytes = l.so_ktab + (l.has_tab ? fxg_r16(((T * stride + 15) / 16 + 1) * 2) : 0u);
+    u32 o = 2 * l.slot_bytes;
     l.off_scratch = o; o += fxg_r16(48 * 4);
     const u32 words = (T * stride + 31) / 32 + 2;
     l.off_bm_g = o;    o += bitmaps ? fxg_r16(words * 4) : 0;
@@ -331,8 +315,7 @@ FXG_HD void fxg_counts_to_slots(const FxgCounts &c, u32 stages, u64 *slot)
 #endif
 // phase 1: quality rows of the tile -> two bitmaps.  Full in-range tiles take the batched path: five
 // independent 16-byte loads per lane are issued before any is consumed.
-// qrows (optional): LDS copy of the tile's quality rows, written as the 16-byte pieces go by (for the gather, see FxgLds)
-FXG_HD void fxg_phase_bitmaps(const FxgKArgs &a, u64 tb, u32 tbytes, u32 *bm_g, u32 *bm_l, u32 tid, u32 nthreads, uint8_t *qrows = nullptr)
+FXG_HD void fxg_phase_bitmaps(const FxgKArgs &a, u64 tb, u32 tbytes, u32 *bm_g, u32 *bm_l, u32 tid, u32 nthreads)
 {
     const u32 Kg = (128u - a.tq) * 0x01010101u, Kf = (128u - a.fq) * 0x01010101u;
     const u32 nchunks = (tbytes + 15u) >> 4;
@@ -350,10 +333,7 @@ FXG_HD void fxg_phase_bitmaps(const FxgKArgs &a, u64 tb, u32 tbytes, u32 *bm_g, 
 #pragma unroll
             for (u32 u = 0; u < U; ++u) {
                 const u32 c = c0 + u * nthreads;
-                if (c < nchunks) {
-                    g16[c] = (uint16_t)fxg_mask16(v[u], Kg); l16[c] = (uint16_t)(~fxg_mask16(v[u], Kf));
-                    if (qrows) *reinterpret_cast<u32x4 *>(qrows + ((size_t)c << 4)) = v[u];
-                }
+                if (c < nchunks) { g16[c] = (uint16_t)fxg_mask16(v[u], Kg); l16[c] = (uint16_t)(~fxg_mask16(v[u], Kf)); }
             }
         }
         return;
@@ -363,24 +343,6 @@ FXG_HD void fxg_phase_bitmaps(const FxgKArgs &a, u64 tb, u32 tbytes, u32 *bm_g, 
         const u32x4 v = fxg_window(a.qual, (long long)(tb + o), a.total_bytes, 0, (int)(tbytes - o < 16u ? tbytes - o : 16u));
         g16[c] = (uint16_t)fxg_mask16(v, Kg);
         l16[c] = (uint16_t)(~fxg_mask16(v, Kf));
-        if (qrows) *reinterpret_cast<u32x4 *>(qrows + o) = v;
-    }
-}
-
-// phase 1 (rows kept in LDS): the tile's base rows -> LDS, 16 bytes per lane, several loads in flight (full in-range tiles;
-// other tiles are gathered byte by byte from HBM and never look at the copy)
-FXG_HD void fxg_phase_copy_rows(const uint8_t *src, u64 total, u64 tb, u32 tbytes, uint8_t *rows, u32 tid, u32 nthreads)
-{
-    if ((tbytes & 15u) != 0u || tb + tbytes > total) return;
-    constexpr u32 U = FXG_BITMAP_U;
-    const u32 nchunks = tbytes >> 4;
-    const uint8_t *p = src + tb;
-    for (u32 c0 = tid; c0 < nchunks; c0 += nthreads * U) {
-        u32x4 v[U];
-#pragma unroll
-        for (u32 u = 0; u < U; ++u) { const u32 c = c0 + u * nthreads; if (c < nchunks) v[u] = fxg_ld16(p + ((u64)c << 4)); }
-#pragma unroll
-        for (u32 u = 0; u < U; ++u) { const u32 c = c0 + u * nthreads; if (c < nchunks) *reinterpret_cast<u32x4 *>(rows + ((size_t)c << 4)) = v[u]; }
     }
 }
 
@@ -499,17 +461,20 @@ FXG_HD void fxg_write_kept_meta(const FxgKArgs &a, u64 rank, u32 olen, u32 read_
 // MODE 0: [clip][qtrim][qfilter] (AMAX = adapter bucket, 0 = no clip); MODE 1: fixed trim; MODE 2: reverse-complement [+ fixed trim];
 // MODE 3: fastq_masker; MODE 4: base census (fastx_artifacts_filter, fastq_to_fasta N-discard)
 #ifndef FXG_MIN_WAVES
-#define FXG_MIN_WAVES 5   // __launch_bounds__ 2nd argument (waves per SIMD) for the streaming instances: 5 workgroups/CU measured best
+#define FXG_MIN_WAVES 5   // __launch_bounds__ 2nd argument (waves per SIMD) for the streaming instances
+#endif
+#ifndef FXG_CLIP_WAVES
+#define FXG_CLIP_WAVES 4  // the same for the packed clip instances up to 16 adapter columns (S, S-5 and the path summary of every column live in registers)
 #endif
 #define FXG_NO_TILE 0xFFFFFFFFu
 template <int AMAX, int MODE>
-__global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void fxg_kernel_tiles(const FxgKArgs a)
+__global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : ((AMAX < 0 && AMAX >= -16) ? FXG_CLIP_WAVES : 1))) void fxg_kernel_tiles(const FxgKArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool REV = (MODE == 2);
     const u32 T = a.tile_reads, stride = a.stride, tid = threadIdx.x;
     const bool use_q = (MODE == 0 && (a.stages & (FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0) || MODE == 3;
-    const FxgLds L = fxg_lds_layout(T, stride, use_q, (MODE == 0 && AMAX != 0) ? a.clip_stride : (MODE == 4 ? stride : 0u), a.qlds);
+    const FxgLds L = fxg_lds_layout(T, stride, use_q, (MODE == 0 && AMAX != 0) ? a.clip_stride : (MODE == 4 ? stride : 0u));
     u32 m_reads = 0, m_nt = 0, art_bad = 0;      // MODE 3 report counters / MODE 4 alphabet check, folded once at the end
     u32 *bm_g = reinterpret_cast<u32 *>(smem + L.off_bm_g);
     u32 *bm_l = reinterpret_cast<u32 *>(smem + L.off_bm_l);
@@ -518,7 +483,6 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void f
     u32 *s_tot = scratch + 2 * FXG_TWAVES, *s_ticket = s_tot + 4;
     u64 *bc = reinterpret_cast<u64 *>(s_tot + 8);                   // [0,2) broadcast of the resolved bases
 
-#if FXG_SCANNER
     // One workgroup turns the tiles' totals into prefixes (fxg_scanner); the others process tiles.
     if (a.compact) {
         if (tid == 0) s_ticket[0] = atomicAdd(a.role, 1u);
@@ -527,7 +491,6 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void f
         __syncthreads();
         if (scanner) { if (tid < 64) fxg_scanner(a); return; }
     }
-#endif
     // Sharded dispenser: workgroup b draws from counter g = b % groups, which hands out tiles g, g+groups, ...
     // The smallest unfinished tile is always either owned by a running workgroup or the next ticket of its
     // counter (whose earlier tiles are all finished, so a workgroup of that group is about to draw it):
@@ -541,18 +504,12 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void f
     u32 slot = 0, tk = 0;
     for (;;) {
         u64 peek = 0;                                    // first look at the prefix of `pend`, in flight during stage A
-#if !FXG_SAMESTEP && !defined(FXG_V_NO_PEEK)
-#if FXG_SCANNER
         if (tid < 64 && pend != FXG_NO_TILE && a.compact) peek = fxg_peek_prefix(a, pend);
-#else
-        if (tid < 64 && pend != FXG_NO_TILE && a.compact && !FXG_DBG(a, 2u)) peek = fxg_peek_window(a, pend);
-#endif
-#endif
         // ------------------------------ stage A: tile `cur` into slot `slot` ------------------------------
         if (cur < a.ntiles) {
-#if !FXG_SAMESTEP
-            if (tid == 0) s_ticket[tk ^ 1u] = atomicAdd(my_ticket, 1u);   // next ticket: in flight while this tile is decided
-#endif
+            // The next ticket is in flight while this tile is decided.  (Holding a ticket is only harmless because nothing in
+            // this step waits for a tile later than `pend`: a one-slot variant that gathered `cur` itself serialised the chip.)
+            if (tid == 0) s_ticket[tk ^ 1u] = atomicAdd(my_ticket, 1u);
             const u32 r0 = cur * T;
             const u64 left = a.n - (u64)r0;
             const u32 nreads = left < (u64)T ? (u32)left : T;
@@ -560,8 +517,7 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void f
             const u32 tbytes = nreads * stride;
             unsigned char *sl = smem + slot * L.slot_bytes;
             if constexpr (MODE == 0 || MODE == 3 || MODE == 4) {
-                if (use_q && !FXG_DBG(a, 8u)) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, FXG_TBLOCK, L.has_qrows ? sl + L.so_qrows + 16u : nullptr);
-                if constexpr (MODE == 0 && AMAX == 0) { if (L.has_brows) fxg_phase_copy_rows(a.bases, a.total_bytes, tb, tbytes, sl + L.so_brows + 16u, tid, FXG_TBLOCK); }
+                if (use_q && !FXG_DBG(a, 8u)) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, FXG_TBLOCK);
                 if constexpr (MODE == 0 && AMAX != 0) fxg_phase_stage_bases(a.clip_src, a.clip_total, (u64)r0 * a.clip_stride, nreads * a.clip_stride, sb, tid, FXG_TBLOCK);
                 if constexpr (MODE == 4) fxg_phase_stage_bases(a.bases, a.total_bytes, tb, tbytes, sb, tid, FXG_TBLOCK);
                 __syncthreads();
@@ -576,9 +532,7 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void f
             u32 exc, exb, totc, totb;
             fxg_block_scan2(keep, keep ? olen : 0u, scratch, &exc, &exb, &totc, &totb);   // one __syncthreads inside
             if (a.compact) {
-#if FXG_SCANNER
                 if (tid == 0) fxg_publish_total(a, cur, totc, totb);     // as early as possible: the scanner and every later tile wait for it
-#endif
                 u32 *k_off = reinterpret_cast<u32 *>(sl);
                 if (tid < nreads && keep) {                          // kept reads only, indexed by their rank inside the tile
                     k_off[exc] = exb;
@@ -587,20 +541,13 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void f
                     if (L.has_tab) fxg_tab_fill(reinterpret_cast<uint16_t *>(sl + L.so_ktab), exc, exb, olen);
                 }
                 if (tid == 0) { k_off[totc] = totb; s_tot[2 * slot] = totc; s_tot[2 * slot + 1] = totb; }
-#if !FXG_SCANNER
-                if (tid < 64 && !FXG_DBG(a, 2u)) fxg_publish_aggregate(a, cur, totc, totb);
-#endif
             }
         }
-        // ------------------------------ stage B: gather a decided tile ------------------------------
-        // two slots: the tile of the previous step (its prefix has had a whole stage A to arrive); one slot: this step's tile
-#if FXG_SAMESTEP
-        const u32 bt = cur < a.ntiles ? cur : FXG_NO_TILE, ps = 0u;
-#else
-        const u32 bt = pend, ps = slot ^ 1u;
-#endif
-        if (bt != FXG_NO_TILE && a.compact) {
-            const u32 r0 = bt * T;
+        // ------------------------------ stage B: tile `pend` from slot `slot ^ 1` ------------------------------
+        // (one step behind stage A: the scanner has had a whole stage A to deliver the prefix, so the wait is off the critical path)
+        if (pend != FXG_NO_TILE && a.compact) {
+            const u32 ps = slot ^ 1u;
+            const u32 r0 = pend * T;
             const u64 left = a.n - (u64)r0;
             const u32 nreads = left < (u64)T ? (u32)left : T;
             const unsigned char *sl = smem + ps * L.slot_bytes;
@@ -608,52 +555,22 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : 1)) void f
             const u32 *k_src = reinterpret_cast<const u32 *>(sl + L.so_ksrc);
             const uint16_t *k_idx = reinterpret_cast<const uint16_t *>(sl + L.so_kidx);
             const uint16_t *k_tab = L.has_tab ? reinterpret_cast<const uint16_t *>(sl + L.so_ktab) : nullptr;
-            if (tid < 64) {
-#if FXG_SCANNER
-#if FXG_SAMESTEP || defined(FXG_V_NO_PEEK)
-                peek = fxg_peek_prefix(a, bt);
-#endif
-                fxg_wait_prefix(a, bt, peek, bc);
-#else
-                u64 base_c = 0, base_b = 0;
-#ifdef FXG_V_NO_PEEK
-                peek = fxg_peek_window(a, bt);
-#endif
-                if (!FXG_DBG(a, 2u)) fxg_resolve_prefix(a, bt, s_tot[2 * ps], s_tot[2 * ps + 1], peek, &base_c, &base_b);
-                if (tid == 0) { bc[0] = base_c; bc[1] = base_b; }
-#endif
-            }
-            __syncthreads();                             // bc; in one-slot builds also the slot just filled by stage A
+            if (tid < 64 && !FXG_DBG(a, 2u)) fxg_wait_prefix(a, pend, peek, bc);
+            __syncthreads();
             const u64 base_c = bc[0], base_b = bc[1];
             const u32 nk = s_tot[2 * ps], totb = s_tot[2 * ps + 1];
             if (tid < nk) fxg_write_kept_meta(a, base_c + tid, k_off[tid + 1] - k_off[tid], r0 + k_idx[tid], base_b + k_off[tid]);
             if (!FXG_DBG(a, 1u)) {
-                u32 bad;
-                if (MODE == 0 && AMAX == 0 && L.has_brows)          // uniform branches: windows from the slot's rows in LDS
-                    bad = fxg_tile_gather<REV, false, true, true>(a, k_off, k_src, k_tab, nk, (u64)r0 * stride, nreads * stride, base_b, totb, tid, FXG_TBLOCK, sl + L.so_qrows + 16u, sl + L.so_brows + 16u);
-                else if ((MODE == 0 || MODE == 3) && L.has_qrows)
-                    bad = fxg_tile_gather<REV, MODE == 3, true>(a, k_off, k_src, k_tab, nk, (u64)r0 * stride, nreads * stride, base_b, totb, tid, FXG_TBLOCK, sl + L.so_qrows + 16u);
-                else
-                    bad = fxg_tile_gather<REV, MODE == 3, false>(a, k_off, k_src, k_tab, nk, (u64)r0 * stride, nreads * stride, base_b, totb, tid, FXG_TBLOCK);
+                const u32 bad = fxg_tile_gather<REV, MODE == 3>(a, k_off, k_src, k_tab, nk, (u64)r0 * stride, nreads * stride, base_b, totb, tid, FXG_TBLOCK);
                 if (REV && bad) atomicOr(a.errflag, FXG_DEV_ERR_BAD_BASE);
             }
         }
         if (cur >= a.ntiles) break;
-#if FXG_SAMESTEP
-        // One slot: a ticket must not be held across the wait for this tile's prefix (every later tile waits for the totals of
-        // the ticket's tile), so the next one is drawn only now.
-        __syncthreads();
-        if (tid == 0) s_ticket[0] = atomicAdd(my_ticket, 1u);
-        __syncthreads();
-        pend = cur;
-        cur = s_ticket[0] * G + grp;
-#else
-        __syncthreads();            // ticket written by thread 0 in stage A; also fences slot reuse (two steps apart with two slots)
+        __syncthreads();            // ticket written by thread 0 in stage A; also fences slot reuse two iterations apart
         pend = cur;
         tk ^= 1u;
         cur = s_ticket[tk] * G + grp;
         slot ^= 1u;
-#endif
     }
     if constexpr (MODE == 3) {                       // masked reads / nucleotides: wave sums, one atomic pair per wave, once
         for (int d = 32; d >= 1; d >>= 1) { m_reads += __shfl_xor(m_reads, d, 64); m_nt += __shfl_xor(m_nt, d, 64); }

@@ -7,13 +7,6 @@
 
 #include "fxg_kernels.h"
 
-#ifndef FXG_QLDS_DEFAULT
-#define FXG_QLDS_DEFAULT 1
-#endif
-#ifndef FXG_QLDS_BUDGET
-#define FXG_QLDS_BUDGET (52u * 1024u)
-#endif
-
 struct FxgPlan {
     FxgKArgs ka;
     bool group_a;   // [CLIP][QTRIM][QFILTER] chain (else [REVCOMP][FTRIM*] unless mode3/mode4)
@@ -27,11 +20,14 @@ static inline int fxg_clampi(long long v, int lo, int hi) { return v < lo ? lo :
 
 static inline u32 fxg_pick_tile(u32 stride, bool clip)
 {
-    // keep the LDS footprint around 64 KiB or less so that at least two workgroups share a CU
-    const u64 budget = clip ? 60ull * 1024 : 192ull * 1024;   // bytes of tile rows one workgroup may cover
+    // Rows one workgroup covers per tile.  Streaming kernels: about 20 KB (128 reads of 150 bases) -- with the central scanner the
+    // per-tile cost is small enough that the shorter pipeline step wins (cfg2: 4.13 ms at 128 reads, 4.19-4.31 at 256, 5.9 at 64;
+    // profiles/r02/variants_*.txt).  Kernels that stage the tile's bases in LDS (clipper, census): up to 60 KB so that two or
+    // more workgroups share a CU.
+    const u64 budget = clip ? 60ull * 1024 : 20ull * 1024;
     u32 T = FXG_MAX_TILE;
     const char *env = getenv("FXG_TILE");   // tuning knob: 1..256, power of two
-    if (env && atoi(env) >= 1 && atoi(env) <= FXG_MAX_TILE && (atoi(env) & (atoi(env) - 1)) == 0) T = (u32)atoi(env);
+    if (env && atoi(env) >= 1 && atoi(env) <= FXG_MAX_TILE && (atoi(env) & (atoi(env) - 1)) == 0) return (u32)atoi(env);
     while (T > 1 && (u64)T * stride > budget) T >>= 1;
     return T;
 }
@@ -39,8 +35,8 @@ static inline u32 fxg_pick_tile(u32 stride, bool clip)
 static inline FxgLds fxg_plan_layout(const FxgPlan *pl)
 {
     const FxgKArgs &ka = pl->ka;
-    return pl->group_a ? fxg_lds_layout(ka.tile_reads, ka.stride, pl->use_q, pl->clip ? ka.clip_stride : 0u, ka.qlds)
-         : pl->mask ? fxg_lds_layout(ka.tile_reads, ka.stride, true, 0u, ka.qlds)
+    return pl->group_a ? fxg_lds_layout(ka.tile_reads, ka.stride, pl->use_q, pl->clip ? ka.clip_stride : 0u)
+         : pl->mask ? fxg_lds_layout(ka.tile_reads, ka.stride, true, 0u)
          : pl->artifacts ? fxg_lds_layout(ka.tile_reads, ka.stride, false, ka.stride) : fxg_lds_layout(ka.tile_reads, ka.stride, false, 0u);
 }
 static inline u32 fxg_plan_lds(const FxgPlan *pl) { return fxg_plan_layout(pl).total; }
@@ -108,23 +104,7 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
         for (unsigned i = 0; i < sizeof pk / sizeof pk[0]; ++i) if (ka.alen <= pk[i]) { b = pk[i]; break; }
         pl->amax = -b;
     }
-    u32 T = fxg_pick_tile(pl->clip ? ka.clip_stride : in->stride, pl->clip || gf);
-    // Quality rows retained in LDS for the gather (no second pass over them in HBM): streaming kernels that build the quality
-    // bitmaps and compact.  The tile shrinks until FXG_QLDS_BUDGET bytes of LDS hold a workgroup (3 workgroups per CU by default).
-    ka.qlds = 0u;
-    if (ka.compact && !pl->clip && (pl->use_q || gm)) {
-        const char *e = getenv("FXG_QLDS");
-        ka.qlds = (u32)fxg_clampi(e ? atoi(e) : FXG_QLDS_DEFAULT, 0, gm ? 1 : 2);    // the masker needs the base rows only through the gather's select: qualities at most
-        if (ka.qlds) {
-            const char *be = getenv("FXG_QLDS_BUDGET");
-            const u32 budget = (be && atoi(be) >= 4096) ? (u32)atoi(be) : FXG_QLDS_BUDGET;
-            u32 Tq = T;
-            while (Tq > 16 && fxg_lds_layout(Tq, in->stride, true, 0u, ka.qlds).total > budget) Tq >>= 1;
-            if (fxg_lds_layout(Tq, in->stride, true, 0u, ka.qlds).total > budget + budget / 2) ka.qlds = 0u;   // long reads: read the rows twice instead
-            else T = Tq;
-            if (ka.qlds == 2u && ((u64)T * in->stride) % 16u != 0u) ka.qlds = 1u;      // the base rows are copied 16 bytes at a time
-        }
-    }
+    const u32 T = fxg_pick_tile(pl->clip ? ka.clip_stride : in->stride, pl->clip || gf);
     const u64 ntiles = (in->n + T - 1) / T;
     if (ntiles > 0x7FFFFFFFull || in->n > 0xFFFFFFFFull) FXG_PLAN_FAIL("batch too large (%llu reads): split it", (unsigned long long)in->n);
     ka.tile_reads = T; ka.ntiles = (u32)ntiles;

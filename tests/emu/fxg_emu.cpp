@@ -21,8 +21,6 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
     std::vector<unsigned char> lds(pl.lds + 64, 0);
     unsigned char *smem = lds.data();
     const FxgLds L = fxg_plan_layout(&pl);
-    uint8_t *qrows = L.has_qrows ? smem + L.so_qrows + 16u : nullptr;      // slot 0: the emulator runs one tile at a time
-    uint8_t *brows = L.has_brows ? smem + L.so_brows + 16u : nullptr;
     u64 m_reads = 0, m_nt = 0;
     u32 *k_off = reinterpret_cast<u32 *>(smem);
     u32 *k_src = reinterpret_cast<u32 *>(smem + L.so_ksrc);
@@ -42,8 +40,7 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
         const u32 tbytes = nreads * stride;
         if (pl.group_a) {
             for (u32 tid = 0; tid < NT; ++tid) {
-                if (pl.use_q) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, NT, qrows);
-                if (brows) fxg_phase_copy_rows(a.bases, a.total_bytes, tb, tbytes, brows, tid, NT);
+                if (pl.use_q) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, NT);
                 if constexpr (AMAX != 0) fxg_phase_stage_bases(a.clip_src, a.clip_total, (u64)r0 * a.clip_stride, nreads * a.clip_stride, sb, tid, NT);
             }
             for (u32 tid = 0; tid < nreads; ++tid) {
@@ -51,7 +48,7 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
                 anchor[tid] = tid * stride;
             }
         } else if (MODE == 3) {
-            for (u32 tid = 0; tid < NT; ++tid) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, NT, qrows);
+            for (u32 tid = 0; tid < NT; ++tid) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, NT);
             for (u32 tid = 0; tid < nreads; ++tid) {
                 u32 nl;
                 fxg_decide_mask(a, bm_l, r0, tid, &keep[tid], &olen[tid], &nl);
@@ -73,10 +70,7 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
             exb += olen[tid]; exc++;
         }
         k_off[exc] = exb;
-        for (u32 tid = 0; tid < NT; ++tid)
-            bad |= brows ? fxg_tile_gather<REV, false, true, true>(a, k_off, k_src, k_tab, exc, tb, tbytes, base_b, exb, tid, NT, qrows, brows)
-                 : qrows ? fxg_tile_gather<REV, MODE == 3, true>(a, k_off, k_src, k_tab, exc, tb, tbytes, base_b, exb, tid, NT, qrows)
-                         : fxg_tile_gather<REV, MODE == 3, false>(a, k_off, k_src, k_tab, exc, tb, tbytes, base_b, exb, tid, NT);
+        for (u32 tid = 0; tid < NT; ++tid) bad |= fxg_tile_gather<REV, MODE == 3>(a, k_off, k_src, k_tab, exc, tb, tbytes, base_b, exb, tid, NT);
         base_c += exc; base_b += exb;
     }
     for (u64 i = 0; i < a.n; ++i) fxg_count_res(a.res[i], cnt);   // same reduction the counting kernel performs
