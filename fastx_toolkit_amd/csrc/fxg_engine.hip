@@ -149,7 +149,7 @@ extern "C" int fxg_free_device(fxg_ctx *c, void *p) { if (!c) return FXG_E_INVAL
 extern "C" int fxg_malloc_host(fxg_ctx *c, size_t bytes, void **p)
 {
     if (!c || !p) return FXG_E_INVALID;
-    FXG_HIP(c, hipHostMalloc(p, bytes ? bytes : 16, hipHostMallocDefault));
+    FXG_HIP(c, hipHostMalloc(p, bytes ? bytes : 16, hipHostMallocPortable));   // usable by every GPU of a multi-GPU run
     return FXG_OK;
 }
 extern "C" int fxg_free_host(fxg_ctx *c, void *p) { if (!c) return FXG_E_INVALID; FXG_HIP(c, hipHostFree(p)); return FXG_OK; }
@@ -644,7 +644,7 @@ extern "C" int fxg_fastq_format(fxg_ctx *c, const uint8_t *d_text, const uint32_
 extern "C" int fxg_host_register(fxg_ctx *c, void *ptr, size_t bytes)
 {
     if (!c || !ptr) return FXG_E_INVALID;
-    FXG_HIP(c, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    FXG_HIP(c, hipHostRegister(ptr, bytes, hipHostRegisterPortable));
     return FXG_OK;
 }
 extern "C" int fxg_host_unregister(fxg_ctx *c, void *ptr)
@@ -657,6 +657,12 @@ extern "C" int fxg_host_unregister(fxg_ctx *c, void *ptr)
 // ------------------------------------------------------------------------------------------------
 // several GPUs: shard ranges, the epilogue arithmetic and the concatenation (host only)
 // ------------------------------------------------------------------------------------------------
+extern "C" int fxg_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 extern "C" int fxg_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi)
 {
     if (!lo || !hi || world == 0 || rank >= world) return FXG_E_INVALID;

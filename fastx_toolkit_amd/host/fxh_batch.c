@@ -65,6 +65,29 @@ void fxh_default_params(fxg_params *p, int qoffset)
     p->mask_char = 'N';               /* fastq_masker.c:48 */
 }
 
+static void fxh_grow_device(fxh_state *st, size_t reads, size_t bytes, int revcomp)
+{
+    if (reads > st->d_cap_reads || bytes > st->d_cap_bytes) {
+        if (st->d_bases) {
+            fxg_free_device(st->ctx, st->d_bases); fxg_free_device(st->ctx, st->d_qual); fxg_free_device(st->ctx, st->d_len);
+            fxg_free_device(st->ctx, st->d_res);
+            if (st->d_out_bases) { fxg_free_device(st->ctx, st->d_out_bases); fxg_free_device(st->ctx, st->d_out_qual); }
+        }
+        st->d_cap_reads = reads + reads / 4 + 1024;
+        st->d_cap_bytes = bytes + bytes / 4 + 4096;
+        FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_cap_bytes, (void **)&st->d_bases));
+        FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_cap_bytes, (void **)&st->d_qual));
+        FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_cap_reads * sizeof(uint16_t), (void **)&st->d_len));
+        FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_cap_reads * sizeof(uint32_t), (void **)&st->d_res));
+        st->d_out_bases = st->d_out_qual = NULL;
+        if (revcomp) {
+            FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_cap_bytes + 16, (void **)&st->d_out_bases));
+            FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_cap_bytes + 16, (void **)&st->d_out_qual));
+        }
+    }
+}
+
+/* host-parser path: pinned staging rows as well as the device rows */
 static void fxh_grow(fxh_state *st, size_t reads, size_t bytes, int revcomp)
 {
     if (reads > st->h_cap_reads || bytes > st->h_cap_bytes) {
@@ -85,24 +108,7 @@ static void fxh_grow(fxh_state *st, size_t reads, size_t bytes, int revcomp)
             FXG_CHECK(st, fxg_malloc_host(st->ctx, st->h_cap_bytes + 16, (void **)&st->h_out_qual));
         }
     }
-    if (reads > st->d_cap_reads || bytes > st->d_cap_bytes) {
-        if (st->d_bases) {
-            fxg_free_device(st->ctx, st->d_bases); fxg_free_device(st->ctx, st->d_qual); fxg_free_device(st->ctx, st->d_len);
-            fxg_free_device(st->ctx, st->d_res);
-            if (st->d_out_bases) { fxg_free_device(st->ctx, st->d_out_bases); fxg_free_device(st->ctx, st->d_out_qual); }
-        }
-        st->d_cap_reads = st->h_cap_reads;
-        st->d_cap_bytes = st->h_cap_bytes;
-        FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_cap_bytes, (void **)&st->d_bases));
-        FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_cap_bytes, (void **)&st->d_qual));
-        FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_cap_reads * sizeof(uint16_t), (void **)&st->d_len));
-        FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_cap_reads * sizeof(uint32_t), (void **)&st->d_res));
-        st->d_out_bases = st->d_out_qual = NULL;
-        if (revcomp) {
-            FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_cap_bytes + 16, (void **)&st->d_out_bases));
-            FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_cap_bytes + 16, (void **)&st->d_out_qual));
-        }
-    }
+    fxh_grow_device(st, reads, bytes, revcomp);
 }
 
 /* Size (dst == NULL) or write one kept record; seq/qual point at `len` output bytes; qual bytes are either raw input
@@ -304,6 +310,7 @@ static void fxh_phase_size(fxh_worker *w)
         case FXG_R_CLIP_NO_ADAPTER: t->clip_no_adapter += rc_; break;
         case FXG_R_CLIP_ADAPTER_FOUND: t->clip_adapter_found += rc_; break;
         case FXG_R_CLIP_N: t->clip_n += rc_; break;
+        case FXG_R_QTRIM: t->qtrim_dropped += rc_; break;
         default: break;
         }
         if (!FXG_RES_KEEP(x)) continue;
@@ -423,6 +430,34 @@ static void fxh_next_block(fxh_prefetch *pf, struct fxh_reader *rd, char **spare
     if (!eof) fxh_prefetch_request(pf, old, rd->cap);
 }
 
+/* The same for the lanes loop, where the previous buffers may still be in use: the read-ahead for the FOLLOWING block goes
+ * to `target` (a buffer no block in flight refers to). */
+static void fxh_next_block_ring(fxh_prefetch *pf, struct fxh_reader *rd, char *target)
+{
+    if (!pf->started) {                /* first block: synchronous, then start reading ahead */
+        fxh_reader_fill(rd);
+        if (!rd->eof) {
+            pthread_mutex_init(&pf->mu, NULL); pthread_cond_init(&pf->cv, NULL);
+            pf->fd = rd->fd; pf->state = 0; pf->started = 1;
+            pf->gap = rd->cap / 4 < FXH_GAP_MAX ? rd->cap / 4 : FXH_GAP_MAX;
+            if (pthread_create(&pf->th, NULL, fxh_prefetch_main, pf) != 0) err(1, "pthread_create");
+            fxh_prefetch_request(pf, target, rd->cap);
+        }
+        return;
+    }
+    if (rd->eof) return;               /* everything has been read already; only the tail remains in rd */
+    pthread_mutex_lock(&pf->mu);
+    while (pf->state != 2) pthread_cond_wait(&pf->cv, &pf->mu);
+    pf->state = 0;
+    char *nb = pf->buf; const size_t filled = pf->filled; const int eof = pf->eof;
+    pthread_mutex_unlock(&pf->mu);
+    const size_t tail = rd->end - rd->beg;
+    if (tail > pf->gap) errx(1, "input record longer than %zu bytes", pf->gap);
+    memcpy(nb + pf->gap - tail, rd->buf + rd->beg, tail);
+    rd->buf = nb; rd->beg = pf->gap - tail; rd->end = pf->gap + filled; rd->eof = eof;
+    if (!eof) fxh_prefetch_request(pf, target, rd->cap);
+}
+
 static void fxh_prefetch_stop(fxh_prefetch *pf)
 {
     if (!pf->started) return;
@@ -500,49 +535,84 @@ static void fxh_awriter_stop(fxh_awriter *aw)
     pthread_join(aw->th, NULL);
 }
 
-/* ---------------------------------------------------------------------------------------------- */
-/* device text path: the block is indexed, checked, packed and formatted on the GPU.   */
-/* Returns 1 if the block was handled, 0 if it is irregular in any way (the caller then uses the     */
-/* host parser for this block, which owns the reference's messages and corner cases).               */
-/* ---------------------------------------------------------------------------------------------- */
-static void fxh_register_once(fxh_state *st, void *ptr, size_t bytes)
+/* hand a buffer owned by somebody else (a lane's output block) to the writer thread; it must stay untouched until a
+ * LATER submit / wait has returned */
+static void fxh_awriter_submit_ext(fxh_awriter *aw, struct fxh_writer *w, const char *buf, size_t len)
 {
-    for (int i = 0; i < 4; ++i) if (st->registered[i] == ptr) return;
-    for (int i = 0; i < 4; ++i)
-        if (!st->registered[i]) { if (fxg_host_register(st->ctx, ptr, bytes) == 0) st->registered[i] = ptr; return; }
+    if (!aw->started) {
+        pthread_mutex_init(&aw->mu, NULL); pthread_cond_init(&aw->cv, NULL);
+        aw->w = w; aw->state = 0; aw->started = 1;
+        if (pthread_create(&aw->th, NULL, fxh_awriter_main, aw) != 0) err(1, "pthread_create");
+    }
+    fxh_awriter_wait(aw);
+    pthread_mutex_lock(&aw->mu);
+    aw->buf = buf; aw->len = len; aw->state = 1;
+    pthread_cond_broadcast(&aw->cv);
+    pthread_mutex_unlock(&aw->mu);
 }
 
-static int fxh_block_gpu_text(FASTX *fx, fxh_state *st, const fxg_params *p, fxh_totals *tot, struct fxh_writer *wr, int revcomp, uint32_t fwd_start)
+/* ---------------------------------------------------------------------------------------------- */
+/* device text path: a block of FASTQ text is indexed, checked, packed, run through    */
+/* the pipeline and formatted on a GPU.  Blocks are cut on the host at record boundaries (a record   */
+/* is four lines counted from the start of the input, exactly as the reference reads them,           */
+/* fastx.c:314-404) and dealt round-robin to LANES: one thread + one engine context (own stream,     */
+/* own device buffers) each, FXH_LANES per GPU over the GPUs of FXG_DEVICES.  Lanes overlap one      */
+/* another's upload, kernels and download; the main thread collects the blocks in input order, so    */
+/* the output is the concatenation a single GPU would have produced.  A block that is irregular in   */
+/* any way is only DETECTED on the device: it then goes through the host parser (fxh_host_block),    */
+/* which owns the reference's messages and corner cases, at its turn in the output order.            */
+/* ---------------------------------------------------------------------------------------------- */
+typedef struct fxh_lane {
+    int id, device;
+    pthread_t th;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    int state;                             /* 0 idle, 1 job posted, 2 done, 3 quit */
+    fxh_state st;
+    const fxg_params *p;                   /* configuration, read-only */
+    int revcomp, qoffset;
+    uint32_t fwd_start;
+    const char *text; size_t len;          /* job: whole records, every line '\n'-terminated */
+    uint64_t records;
+    int clip_history;                      /* this lane is the one aligner of a fastx_clipper run */
+    int slot;                              /* which of out[] receives the text (the other may still be with the writer) */
+    int handled;                           /* result: 0 = irregular block, parse it on the host */
+    char *out[2]; size_t out_cap[2]; size_t out_len;
+    uint64_t ctr[FXG_NCOUNTERS];
+    double t_busy, t_init;
+} fxh_lane;
+
+static void fxh_lane_run(fxh_lane *ln)
 {
-    struct fxh_reader *rd = fx->reader;
-    size_t len = rd->end - rd->beg;
-    if (len == 0) return 0;
-    if (rd->eof && rd->buf[rd->end - 1] != '\n') rd->buf[rd->end] = '\n', len += 1;     /* the buffer has one spare byte */
+    fxh_state *st = &ln->st;
+    const size_t len = ln->len;
+    const int revcomp = ln->revcomp;
+    ln->handled = 0; ln->out_len = 0;
     if (st->d_text_cap < len + 32) {
         if (st->d_text) { fxg_free_device(st->ctx, st->d_text); fxg_free_device(st->ctx, st->d_out_text); }
         st->d_text_cap = len + len / 8 + 4096;
         FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_text_cap, (void **)&st->d_text));
-        FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_text_cap, (void **)&st->d_out_text));
+        /* the output can be longer than the input: an empty third line still gets its '+' (fastx.c:460), one byte per record */
+        FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_text_cap + st->d_text_cap / 7 + 64, (void **)&st->d_out_text));
     }
-    const size_t cap_lines = len / 2 + 16;                  /* the shortest record "@\nA\n+\nI\n" has 8 bytes and 4 lines */
+    const size_t cap_lines = len / 2 + 16;                  /* the shortest record "@\nA\n\nI\n" has 7 bytes and 4 lines */
     if (st->d_ls_cap < cap_lines) {
         if (st->d_ls) { fxg_free_device(st->ctx, st->d_ls); fxg_free_device(st->ctx, st->d_len16); }
         st->d_ls_cap = cap_lines + cap_lines / 8;
         FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_ls_cap * sizeof(uint32_t), (void **)&st->d_ls));
         FXG_CHECK(st, fxg_malloc_device(st->ctx, (st->d_ls_cap / 4 + 4) * sizeof(uint16_t), (void **)&st->d_len16));
     }
-    fxh_register_once(st, rd->buf, rd->cap + 1);
-    FXG_CHECK(st, fxg_memcpy_h2d(st->ctx, st->d_text, rd->buf + rd->beg, len));
+    FXG_CHECK(st, fxg_memcpy_h2d(st->ctx, st->d_text, ln->text, len));
     fxg_text_info info;
-    FXG_CHECK(st, fxg_fastq_index(st->ctx, st->d_text, len, rd->eof, st->d_ls, st->d_ls_cap, st->d_len16, &info));
-    if (info.irregular || info.records == 0) return 0;
+    FXG_CHECK(st, fxg_fastq_index(st->ctx, st->d_text, len, 1, st->d_ls, st->d_ls_cap, st->d_len16, &info));
+    if (info.irregular || info.records == 0 || info.records != ln->records || info.consumed != len) return;
     const uint64_t n = info.records;
     const uint32_t stride = info.max_len;
-    if ((uint64_t)n * stride > (uint64_t)8 * len + (1u << 20)) return 0;   /* ragged beyond reason: let the host path split it */
-    fxh_grow(st, n, (size_t)n * stride + 16, revcomp);
+    if ((uint64_t)n * stride > (uint64_t)8 * len + (1u << 20)) return;   /* ragged beyond reason: the host path handles it */
+    fxh_grow_device(st, n, (size_t)n * stride + 16, revcomp);
     uint32_t irr = 0;
-    FXG_CHECK(st, fxg_fastq_pack(st->ctx, st->d_text, len, st->d_ls, n, stride, fx->fastq_ascii_quality_offset, st->d_bases, st->d_qual, &irr));
-    if (irr) return 0;
+    FXG_CHECK(st, fxg_fastq_pack(st->ctx, st->d_text, len, st->d_ls, n, stride, ln->qoffset, st->d_bases, st->d_qual, &irr));
+    if (irr) return;
     if (revcomp && st->d_off_cap < n) {
         if (st->d_out_off) fxg_free_device(st->ctx, st->d_out_off);
         st->d_off_cap = n + n / 8 + 1024;
@@ -551,33 +621,86 @@ static int fxh_block_gpu_text(FASTX *fx, fxh_state *st, const fxg_params *p, fxh
     const int fixed = info.min_len == info.max_len;
     fxg_batch in = {st->d_bases, st->d_qual, fixed ? NULL : st->d_len16, stride, stride, n};
     fxg_out out = {st->d_res, revcomp ? st->d_out_bases : NULL, revcomp ? st->d_out_qual : NULL, NULL, NULL, revcomp ? st->d_out_off : NULL, st->d_counters};
-    fxg_params pp = *p;
+    fxg_params pp = *ln->p;
     pp.qoffset = 33;
     FXG_CHECK(st, fxg_run_pipeline(st->ctx, &in, &pp, &out));
-    uint64_t ctr[FXG_NCOUNTERS];
     {
-        int rc = fxg_read_counters(st->ctx, st->d_counters, ctr);
-        if (rc == FXG_E_DEVICE && (ctr[FXG_C_ERRORS] & FXG_DEV_ERR_BAD_BASE)) errx(1, "%s", fxg_last_error(st->ctx));
+        int rc = fxg_read_counters(st->ctx, st->d_counters, ln->ctr);
+        if (rc == FXG_E_DEVICE && (ln->ctr[FXG_C_ERRORS] & FXG_DEV_ERR_BAD_BASE)) return;   /* the host parser prints the reference's message at its turn */
         if (rc != 0) errx(1, "GPU engine error %d: %s", rc, fxg_last_error(st->ctx));
     }
     uint64_t out_bytes = 0;
-    FXG_CHECK(st, fxg_fastq_format(st->ctx, st->d_text, st->d_ls, n, st->d_res, revcomp ? 0u : fwd_start, revcomp ? st->d_out_bases : NULL,
-                                   revcomp ? st->d_out_qual : NULL, revcomp ? st->d_out_off : NULL, fx->fastq_ascii_quality_offset, st->d_out_text, &out_bytes));
-    char *dst = fxh_writer_reserve(wr, out_bytes + 16);
-    FXG_CHECK(st, fxg_memcpy_d2h(st->ctx, dst, st->d_out_text, out_bytes));
+    FXG_CHECK(st, fxg_fastq_format(st->ctx, st->d_text, st->d_ls, n, st->d_res, revcomp ? 0u : ln->fwd_start, revcomp ? st->d_out_bases : NULL,
+                                   revcomp ? st->d_out_qual : NULL, revcomp ? st->d_out_off : NULL, ln->qoffset, st->d_out_text, &out_bytes));
+    const int s = ln->slot;
+    if (ln->out_cap[s] < out_bytes + 16) {
+        if (ln->out[s]) fxg_free_host(st->ctx, ln->out[s]);
+        ln->out_cap[s] = (size_t)out_bytes + (size_t)out_bytes / 8 + 4096;
+        FXG_CHECK(st, fxg_malloc_host(st->ctx, ln->out_cap[s], (void **)&ln->out[s]));
+    }
+    FXG_CHECK(st, fxg_memcpy_d2h(st->ctx, ln->out[s], st->d_out_text, out_bytes));
     FXG_CHECK(st, fxg_sync(st->ctx));
-    wr->len += out_bytes;
-    /* FASTQ ids are never collapsed: every record counts as one read (fastx.c:480-481) */
-    tot->input_sequences += n; tot->input_reads += n;
-    tot->output_sequences += ctr[FXG_C_KEPT]; tot->output_reads += ctr[FXG_C_KEPT];
-    tot->clip_input += (unsigned)n;
-    tot->clip_too_short += (unsigned)ctr[FXG_C_CLIP_TOO_SHORT]; tot->clip_adapter_only += (unsigned)ctr[FXG_C_CLIP_ADAPTER_ONLY];
-    tot->clip_no_adapter += (unsigned)ctr[FXG_C_CLIP_NO_ADAPTER]; tot->clip_adapter_found += (unsigned)ctr[FXG_C_CLIP_ADAPTER_FOUND];
-    tot->clip_n += (unsigned)ctr[FXG_C_CLIP_N];
-    tot->masked_reads += ctr[FXG_C_MASKED_READS]; tot->masked_nucleotides += ctr[FXG_C_MASKED_NT];
-    rd->beg += (size_t)info.consumed > rd->end - rd->beg ? rd->end - rd->beg : (size_t)info.consumed;
-    fx->input_line_number += 4ull * n;
-    return 1;
+    ln->out_len = (size_t)out_bytes;
+    ln->handled = 1;
+}
+
+static void *fxh_lane_main(void *arg)
+{
+    fxh_lane *ln = (fxh_lane *)arg;
+    double t0;
+    pthread_mutex_lock(&ln->mu);
+    for (;;) {
+        while (ln->state != 1 && ln->state != 3) pthread_cond_wait(&ln->cv, &ln->mu);
+        if (ln->state == 3) break;
+        pthread_mutex_unlock(&ln->mu);
+        t0 = fxh_now();
+        fxh_lane_run(ln);
+        ln->t_busy += fxh_now() - t0;
+        pthread_mutex_lock(&ln->mu);
+        ln->state = 2;
+        pthread_cond_broadcast(&ln->cv);
+    }
+    pthread_mutex_unlock(&ln->mu);
+    return NULL;
+}
+
+static void fxh_lane_post(fxh_lane *ln, const char *text, size_t len, uint64_t records, int slot)
+{
+    pthread_mutex_lock(&ln->mu);
+    ln->text = text; ln->len = len; ln->records = records; ln->slot = slot; ln->state = 1;
+    pthread_cond_broadcast(&ln->cv);
+    pthread_mutex_unlock(&ln->mu);
+}
+
+static void fxh_lane_wait(fxh_lane *ln)
+{
+    pthread_mutex_lock(&ln->mu);
+    while (ln->state == 1) pthread_cond_wait(&ln->cv, &ln->mu);
+    ln->state = 0;
+    pthread_mutex_unlock(&ln->mu);
+}
+
+/* FXG_DEVICES = "0,1,3" | "all" | unset (then FXG_DEVICE, default 0) */
+static int fxh_device_list(int *dev, int cap)
+{
+    const char *e = getenv("FXG_DEVICES");
+    int n = 0;
+    if (e && strcmp(e, "all") == 0) {
+        int nd = fxg_device_count();
+        for (int i = 0; i < nd && n < cap; ++i) dev[n++] = i;
+    } else if (e && *e) {
+        const char *q = e;
+        while (*q && n < cap) {
+            char *end;
+            long v = strtol(q, &end, 10);
+            if (end == q) break;
+            dev[n++] = (int)v;
+            q = (*end == ',') ? end + 1 : end;
+            if (*end != ',') break;
+        }
+    }
+    if (n == 0) { const char *d = getenv("FXG_DEVICE"); dev[n++] = d ? atoi(d) : 0; }
+    return n;
 }
 
 /* fastx_quality_stats mode of the run loop: batches feed fxg_run_quality_stats instead of the pipeline, nothing is written */
@@ -608,232 +731,478 @@ static void fxh_stats_reserve(fxh_state *st, fxh_stats_run *sr, uint32_t need_co
     sr->d_hist = nh; sr->cols = ncols;
 }
 
-static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_stats_run *stats, uint64_t **hist_out, uint32_t *cols_out)
+/* everything one run of a tool shares between its blocks */
+typedef struct fxh_run {
+    FASTX *fx;
+    const fxg_params *p;
+    fxh_totals *tot;
+    fxh_stats_run *stats;
+    fxh_state st;                          /* the host-parser path's own context and buffers (created on first use) */
+    int st_device, st_shared;              /* st_shared: the context belongs to lane 0 (serial clipper run) */
+    fxh_job job;
+    fxh_awriter aw;
+    char *wr_spare; size_t wr_spare_cap;
+    int overlap;
+    char errmsg[768];
+    int have_err, at_eof;
+    unsigned long n_fallback;
+    double t_index, t_pack, t_gpu, t_fmt, t_init;
+} fxh_run;
+
+static void fxh_run_ctx(fxh_run *R)
 {
-    fxh_state st;
-    memset(&st, 0, sizeof st);
-    memset(tot, 0, sizeof *tot);
-    const int timing = getenv("FXH_TIMING") != NULL;
-    double t_init = fxh_now(), t_read = 0, t_index = 0, t_pack = 0, t_gpu = 0, t_fmt = 0, t0;
-    {
-        const char *dev = getenv("FXG_DEVICE");
-        int rc = fxg_ctx_create(dev ? atoi(dev) : 0, &st.ctx);
-        if (rc != 0) errx(1, "no usable MI355X/HIP device (fxg_ctx_create = %d); this build has no CPU path", rc);
-    }
-    FXG_CHECK(&st, fxg_malloc_device(st.ctx, FXG_NCOUNTERS * sizeof(uint64_t), (void **)&st.d_counters));
+    if (R->st.ctx) return;
+    const double t0 = fxh_now();
+    int rc = fxg_ctx_create(R->st_device, &R->st.ctx);
+    if (rc != 0) errx(1, "no usable MI355X/HIP device (fxg_ctx_create = %d); this build has no CPU path", rc);
+    FXG_CHECK(&R->st, fxg_malloc_device(R->st.ctx, FXG_NCOUNTERS * sizeof(uint64_t), (void **)&R->st.d_counters));
     /* one fastx_clipper process = one aligner whose query buffer survives from read to read (sequence_alignment.cpp:135-136,
      * SURVEY N3): the engine reproduces that across the batches of this run */
-    if (p->stages & FXG_STAGE_CLIP) FXG_CHECK(&st, fxg_set_clip_history(st.ctx, 1));
-    t_init = fxh_now() - t_init;
+    if (R->p->stages & FXG_STAGE_CLIP) FXG_CHECK(&R->st, fxg_set_clip_history(R->st.ctx, 1));
+    R->t_init += fxh_now() - t0;
+}
+
+/* Host-parser path for the unread part [rd->beg, rd->end) of the current block: index + validate in parallel, pack the SoA rows,
+ * run the engine, format the kept records.  Consumes whole records (rd->beg moves on), sets have_err / at_eof. */
+static void fxh_host_block(fxh_run *R)
+{
+    FASTX *fx = R->fx;
+    fxh_job *job = &R->job;
+    fxh_state *st = &R->st;
+    fxh_totals *tot = R->tot;
+    const fxg_params *p = R->p;
+    struct fxh_reader *rd = fx->reader;
+    double t0 = fxh_now();
+    fxh_run_ctx(R);
+    const size_t beg = rd->beg, end = rd->end;
+    const int T = job->nworkers;
+    for (int i = 0; i < T; ++i) {
+        job->w[i].a0 = beg + (size_t)((unsigned long long)(end - beg) * (unsigned)i / (unsigned)T);
+        job->w[i].a1 = beg + (size_t)((unsigned long long)(end - beg) * (unsigned)(i + 1) / (unsigned)T);
+    }
+    fxh_parallel(job, fxh_phase_census);
+    {
+        /* worker i starts at the first record boundary at or after a0: lines are counted from the block start,
+         * which is itself a record boundary (the previous block stopped at one) */
+        unsigned long long lines_before = 0;          /* complete lines in [beg, a0) */
+        for (int i = 0; i < T; ++i) {
+            fxh_worker *w = &job->w[i];
+            size_t s;
+            unsigned long long ls;                    /* complete lines in [beg, s) */
+            if (i == 0) { s = beg; ls = 0; }
+            else if (w->first_nl == (size_t)-1) { s = (size_t)-1; ls = 0; }       /* no line starts here: same boundary as the next range */
+            else {
+                s = w->first_nl + 1; ls = lines_before + 1;
+                while (ls % (unsigned)job->lpr != 0) {         /* walk to the next record boundary */
+                    const char *q = s < end ? (const char *)memchr(rd->buf + s, '\n', end - s) : NULL;
+                    if (!q) { s = end; break; }
+                    s = (size_t)(q - rd->buf) + 1; ls++;
+                }
+            }
+            if (s != (size_t)-1 && s > end) s = end;
+            w->start = s;
+            w->start_line = fx->input_line_number + ls;
+            lines_before += w->nl_count;
+        }
+        for (int i = T - 1; i >= 0; --i)                      /* ranges without a line start are empty */
+            if (job->w[i].start == (size_t)-1) job->w[i].start = (i + 1 < T) ? job->w[i + 1].start : end;
+        for (int i = 0; i < T; ++i) {
+            fxh_worker *w = &job->w[i];
+            w->view.buf = rd->buf; w->view.cap = rd->cap; w->view.fd = -1;
+            w->view.beg = w->start;
+            w->view.end = (i + 1 < T) ? job->w[i + 1].start : end;
+            w->view.eof = 0;
+        }
+        /* the last non-empty range owns the end-of-input / incomplete-tail semantics */
+        for (int i = T - 1; i >= 0; --i)
+            if (job->w[i].view.beg < end || i == 0) { job->w[i].view.end = end; job->w[i].view.eof = rd->eof; break; }
+    }
+    fxh_parallel(job, fxh_phase_index);
+    /* merge in input order; the first error / end condition wins */
+    size_t n = 0, maxlen = 0, minlen = (size_t)-1;
+    int stop = -1;                                   /* worker at which the batch ends */
+    for (int i = 0; i < T; ++i) {
+        fxh_worker *w = &job->w[i];
+        w->rec0 = n; w->use = w->nrec;
+        n += w->nrec;
+        if (w->nrec) { if (w->maxlen > maxlen) maxlen = w->maxlen; if (w->minlen < minlen) minlen = w->minlen; }
+        const int is_last = (w->view.end == end);
+        if (w->rc_end == -2) { R->have_err = 1; memcpy(R->errmsg, w->errmsg, sizeof R->errmsg); stop = i; }
+        else if (w->rc_end == 0) { R->at_eof = 1; stop = i; }
+        else if (is_last) stop = i;
+        if (stop >= 0) { rd->beg = w->end_pos; fx->input_line_number = w->end_line; break; }
+    }
+    for (int i = stop + 1; i < T; ++i) { job->w[i].use = 0; job->w[i].rec0 = n; }
+    if (n == 0) {
+        if (!R->have_err && !R->at_eof) errx(1, "input record does not fit in the %zu MB read buffer", rd->cap >> 20);
+        return;
+    }
+    /* One long read among short ones must not blow the rows up (rows are n * longest): cut the batch at a record boundary when
+     * the SoA would exceed ~16x the text of the block; the rest of the block is the next call's business. */
+    {
+        const size_t budget = (size_t)16 * (end - beg) + ((size_t)64 << 20);
+        if (n * maxlen > budget && n > 1) {
+            size_t keep_n = 0, run_max = 0;
+            int cut_w = -1; size_t cut_k = 0;
+            for (int i = 0; i <= stop && cut_w < 0; ++i) {
+                fxh_worker *w = &job->w[i];
+                for (size_t k = 0; k < w->use; ++k) {
+                    const size_t L = w->rec[k].seq_len;
+                    const size_t m = L > run_max ? L : run_max;
+                    if ((keep_n + 1) * m > budget && keep_n > 0) { cut_w = i; cut_k = k; break; }
+                    run_max = m; keep_n++;
+                }
+            }
+            if (cut_w >= 0) {
+                fxh_worker *w = &job->w[cut_w];
+                rd->beg = (size_t)((w->rec[cut_k].name - 1) - rd->buf);           /* the record's first byte ('@' / '>') */
+                fx->input_line_number = w->start_line + (unsigned long long)job->lpr * cut_k;
+                w->use = cut_k;
+                for (int j = cut_w + 1; j < T; ++j) job->w[j].use = 0;
+                n = keep_n; maxlen = run_max;
+                minlen = (size_t)-1;
+                for (int i = 0; i <= cut_w; ++i) for (size_t k = 0; k < job->w[i].use; ++k) if (job->w[i].rec[k].seq_len < minlen) minlen = job->w[i].rec[k].seq_len;
+                stop = cut_w;
+                R->have_err = 0; R->at_eof = 0;          /* whatever ended the block lies beyond the cut */
+            }
+        }
+    }
+    R->t_index += fxh_now() - t0; t0 = fxh_now();
+
+    /* ---- 2. pack the SoA rows (qualities normalised to Phred+33 codes) ---- */
+    job->stride = (uint32_t)maxlen;
+    fxh_grow(st, n, n * (size_t)job->stride, job->revcomp);
+    fxh_parallel(job, fxh_phase_pack);
+    for (int i = 0; i <= stop; ++i) {
+        fxh_worker *w = &job->w[i];
+        if (w->bad_q >= 0) {                       /* first bad record wins: drop it and everything after it */
+            R->have_err = 1; R->at_eof = 0;
+            memcpy(R->errmsg, w->errmsg, sizeof R->errmsg);
+            n = w->rec0 + (size_t)w->bad_q;
+            w->use = (size_t)w->bad_q;
+            for (int j = i + 1; j < T; ++j) job->w[j].use = 0;
+            break;
+        }
+    }
+    R->t_pack += fxh_now() - t0; t0 = fxh_now();
+    if (n == 0) return;
+    /* ---- 3. engine ---- */
+    const uint32_t stride = job->stride;
+    const size_t bytes = n * (size_t)stride;
+    const int fixed = (minlen == maxlen);
+    FXG_CHECK(st, fxg_memcpy_h2d(st->ctx, st->d_bases, st->h_bases, bytes));
+    if (job->has_q) FXG_CHECK(st, fxg_memcpy_h2d(st->ctx, st->d_qual, st->h_qual, bytes));
+    if (!fixed) FXG_CHECK(st, fxg_memcpy_h2d(st->ctx, st->d_len, st->h_len, n * sizeof(uint16_t)));
+    fxg_batch in = {st->d_bases, job->has_q ? st->d_qual : NULL, fixed ? NULL : st->d_len, (uint32_t)maxlen, stride, n};
+    if (R->stats) {                            /* fastx_quality_stats: reduce, nothing to write */
+        fxh_stats_reserve(st, R->stats, stride);
+        FXG_CHECK(st, fxg_run_quality_stats(st->ctx, &in, R->stats->d_hist, R->stats->cols));
+        FXG_CHECK(st, fxg_sync(st->ctx));
+        tot->input_sequences += n; tot->input_reads += n;
+        fx->num_input_sequences = tot->input_sequences; fx->num_input_reads = tot->input_reads;
+        R->t_gpu += fxh_now() - t0;
+        return;
+    }
+    fxg_out out = {st->d_res, job->revcomp ? st->d_out_bases : NULL, (job->revcomp && job->has_q) ? st->d_out_qual : NULL, NULL, NULL, NULL, st->d_counters};
+    fxg_params pp = *p;
+    pp.qoffset = 33;                        /* rows hold Phred+33 codes whatever -Q was */
+    FXG_CHECK(st, fxg_run_pipeline(st->ctx, &in, &pp, &out));
+    FXG_CHECK(st, fxg_memcpy_d2h(st->ctx, st->h_res, st->d_res, n * sizeof(uint32_t)));
+    uint64_t ctr[FXG_NCOUNTERS];
+    {
+        int rc = fxg_read_counters(st->ctx, st->d_counters, ctr);   /* synchronises */
+        if (rc == FXG_E_DEVICE && (ctr[FXG_C_ERRORS] & FXG_DEV_ERR_BAD_BASE)) errx(1, "%s", fxg_last_error(st->ctx));
+        if (rc != 0) errx(1, "GPU engine error %d: %s", rc, fxg_last_error(st->ctx));
+    }
+    tot->masked_reads += ctr[FXG_C_MASKED_READS]; tot->masked_nucleotides += ctr[FXG_C_MASKED_NT];
+    if (job->revcomp) {
+        FXG_CHECK(st, fxg_memcpy_d2h(st->ctx, st->h_out_bases, st->d_out_bases, ctr[FXG_C_KEPT_BASES]));
+        if (job->has_q) FXG_CHECK(st, fxg_memcpy_d2h(st->ctx, st->h_out_qual, st->d_out_qual, ctr[FXG_C_KEPT_BASES]));
+        FXG_CHECK(st, fxg_sync(st->ctx));
+    }
+    R->t_gpu += fxh_now() - t0; t0 = fxh_now();
+
+    /* ---- 4. format the kept records in input order (each worker its own slice), tally the report counters ---- */
+    fxh_parallel(job, fxh_phase_count);
+    {
+        size_t base = tot->output_sequences + 1;
+        for (int i = 0; i < T; ++i) { job->w[i].kept_base = base; base += job->w[i].kept_count; }
+    }
+    fxh_parallel(job, fxh_phase_size);
+    size_t total = 0, kept_total = 0;
+    for (int i = 0; i < T; ++i) {
+        fxh_worker *w = &job->w[i];
+        w->out_off = total; w->kept_off = kept_total;
+        total += w->out_bytes; kept_total += w->kept_bytes;
+        tot->input_sequences += w->tot.input_sequences; tot->input_reads += w->tot.input_reads;
+        tot->output_sequences += w->tot.output_sequences; tot->output_reads += w->tot.output_reads;
+        tot->clip_input += w->tot.clip_input; tot->clip_too_short += w->tot.clip_too_short;
+        tot->clip_adapter_only += w->tot.clip_adapter_only; tot->clip_no_adapter += w->tot.clip_no_adapter;
+        tot->clip_adapter_found += w->tot.clip_adapter_found; tot->clip_n += w->tot.clip_n;
+        tot->qtrim_dropped += w->tot.qtrim_dropped;
+    }
+    struct fxh_writer *wr = fx->writer;
+    job->out_dst = fxh_writer_reserve(wr, total + 16);
+    fxh_parallel(job, fxh_phase_format);
+    wr->len += total;
+    if (R->overlap) fxh_awriter_submit(&R->aw, wr, &R->wr_spare, &R->wr_spare_cap); else fxh_writer_flush(wr);
+    fx->num_input_sequences = tot->input_sequences; fx->num_input_reads = tot->input_reads;
+    fx->num_output_sequences = tot->output_sequences; fx->num_output_reads = tot->output_reads;
+    R->t_fmt += fxh_now() - t0;
+}
+
+static void fxh_add_counters(fxh_totals *tot, const uint64_t *ctr, uint64_t n)
+{
+    /* FASTQ ids are never collapsed: every record counts as one read (fastx.c:480-481) */
+    tot->input_sequences += n; tot->input_reads += n;
+    tot->output_sequences += ctr[FXG_C_KEPT]; tot->output_reads += ctr[FXG_C_KEPT];
+    tot->clip_input += (unsigned)n;
+    tot->clip_too_short += (unsigned)ctr[FXG_C_CLIP_TOO_SHORT]; tot->clip_adapter_only += (unsigned)ctr[FXG_C_CLIP_ADAPTER_ONLY];
+    tot->clip_no_adapter += (unsigned)ctr[FXG_C_CLIP_NO_ADAPTER]; tot->clip_adapter_found += (unsigned)ctr[FXG_C_CLIP_ADAPTER_FOUND];
+    tot->clip_n += (unsigned)ctr[FXG_C_CLIP_N];
+    tot->masked_reads += ctr[FXG_C_MASKED_READS]; tot->masked_nucleotides += ctr[FXG_C_MASKED_NT];
+    tot->qtrim_dropped += ctr[FXG_C_QTRIM_DROPPED];
+}
+
+/* the blocks in flight: where their text lives and what the host parser needs if a lane hands one back */
+typedef struct fxh_block {
+    char *buf; size_t beg, end;            /* whole records; buf[end - 1] == '\n' */
+    int eof;                               /* the input ends with this block */
+    unsigned long long line0;              /* lines read before it */
+    uint64_t records;
+    int lane;                              /* -1: not given to a lane (ragged end of input, oversized record): host parser */
+} fxh_block;
+
+#define FXH_MAX_LANES 32
+
+/* The lanes loop (device text path).  Returns when the input is exhausted or an error is pending in R. */
+static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *lane_dev, double *t_read, double *t_lane_init)
+{
+    FASTX *fx = R->fx;
+    struct fxh_reader *rd = fx->reader;
+    struct fxh_writer *wr = fx->writer;
+    fxh_lane *lanes = (fxh_lane *)calloc((size_t)nlanes, sizeof(fxh_lane));
+    const int NB = nlanes + 2;             /* input buffers: nlanes blocks in flight + the one being cut + the one being read */
+    char **inbuf = (char **)calloc((size_t)NB, sizeof(char *));
+    fxh_block *blk = (fxh_block *)calloc((size_t)NB, sizeof(fxh_block));
+    if (!lanes || !inbuf || !blk) err(1, "out of memory");
+    for (int i = 0; i < nlanes; ++i) {
+        fxh_lane *ln = &lanes[i];
+        ln->id = i; ln->device = lane_dev[i]; ln->p = R->p; ln->revcomp = R->job.revcomp; ln->fwd_start = R->job.fwd_start;
+        ln->qoffset = fx->fastq_ascii_quality_offset;
+        const double t0 = fxh_now();
+        int rc = fxg_ctx_create(ln->device, &ln->st.ctx);
+        if (rc != 0) errx(1, "no usable MI355X/HIP device %d (fxg_ctx_create = %d); this build has no CPU path", ln->device, rc);
+        FXG_CHECK(&ln->st, fxg_malloc_device(ln->st.ctx, FXG_NCOUNTERS * sizeof(uint64_t), (void **)&ln->st.d_counters));
+        if ((R->p->stages & FXG_STAGE_CLIP) && nlanes == 1) {
+            /* one fastx_clipper process = one aligner whose query buffer survives from read to read (sequence_alignment.cpp:135-136,
+             * SURVEY N3): every block of the run, host-parsed ones included, goes through this one context in input order */
+            FXG_CHECK(&ln->st, fxg_set_clip_history(ln->st.ctx, 1));
+            ln->clip_history = 1;
+            R->st.ctx = ln->st.ctx; R->st.d_counters = ln->st.d_counters; R->st_shared = 1;
+        }
+        ln->t_init = fxh_now() - t0;
+        pthread_mutex_init(&ln->mu, NULL); pthread_cond_init(&ln->cv, NULL);
+        if (pthread_create(&ln->th, NULL, fxh_lane_main, ln) != 0) err(1, "pthread_create");
+    }
+    inbuf[0] = rd->buf;
+    (void)fxg_host_register(lanes[0].st.ctx, rd->buf, rd->cap + 1);
+    size_t nblocks = 0, next_emit = 0;
+    size_t lane_uses[FXH_MAX_LANES] = {0};
+    int input_done = 0;
+
+    while (!R->have_err) {
+        /* ---- collect finished blocks in input order until a lane and an input buffer are free ---- */
+        while (next_emit < nblocks && (nblocks - next_emit >= (size_t)nlanes || input_done)) {
+            fxh_block *b = &blk[next_emit % (size_t)NB];
+            int handled = 0;
+            if (b->lane >= 0) {
+                fxh_lane *ln = &lanes[b->lane];
+                fxh_lane_wait(ln);
+                if (ln->handled) {
+                    handled = 1;
+                    fxh_awriter_submit_ext(&R->aw, wr, ln->out[ln->slot], ln->out_len);
+                    if (!R->overlap) fxh_awriter_wait(&R->aw);
+                    fxh_add_counters(R->tot, ln->ctr, b->records);
+                }
+            }
+            if (!handled) {                /* this block goes through the host parser, at its place in the output order */
+                R->n_fallback++;
+                struct fxh_reader save = *rd;
+                const unsigned long long save_line = fx->input_line_number;
+                rd->buf = b->buf; rd->beg = b->beg; rd->end = b->end; rd->eof = b->eof;
+                fx->input_line_number = b->line0;
+                while (rd->beg < rd->end && !R->have_err) {
+                    const size_t before = rd->beg;
+                    fxh_host_block(R);
+                    if (rd->beg == before) break;
+                }
+                if (!R->have_err && rd->beg < rd->end) errx(1, "internal error: host parser left %zu bytes of a block", rd->end - rd->beg);
+                *rd = save;
+                fx->input_line_number = save_line;
+                R->at_eof = 0;
+            }
+            fx->num_input_sequences = R->tot->input_sequences; fx->num_input_reads = R->tot->input_reads;
+            fx->num_output_sequences = R->tot->output_sequences; fx->num_output_reads = R->tot->output_reads;
+            next_emit++;
+            if (R->have_err) break;
+        }
+        if (R->have_err || input_done) { if (next_emit >= nblocks) break; else continue; }
+
+        /* ---- next block of text: [unread tail of the previous block | prefetched data] ---- */
+        double t0 = fxh_now();
+        {
+            char *target = NULL;           /* where the read-ahead for the block after this one goes */
+            const size_t nxt = (nblocks + 1) % (size_t)NB;
+            if (!inbuf[nxt]) {             /* page-locked once, so that the uploads are real DMA */
+                inbuf[nxt] = (char *)malloc(rd->cap + 1);
+                if (!inbuf[nxt]) err(1, "out of memory");
+                (void)fxg_host_register(lanes[0].st.ctx, inbuf[nxt], rd->cap + 1);
+            }
+            target = inbuf[nxt];
+            fxh_next_block_ring(pf, rd, target);
+        }
+        *t_read += fxh_now() - t0;
+        if (rd->beg == rd->end && rd->eof) { input_done = 1; continue; }
+
+        /* ---- cut it at a record boundary: records are groups of four lines counted from the start of the input ---- */
+        t0 = fxh_now();
+        size_t end = rd->end;
+        if (rd->eof && rd->buf[end - 1] != '\n') { rd->buf[end] = '\n'; end += 1; }       /* the buffer has one spare byte */
+        fxh_job *job = &R->job;
+        const int T = job->nworkers;
+        for (int i = 0; i < T; ++i) {
+            job->w[i].a0 = rd->beg + (size_t)((unsigned long long)(end - rd->beg) * (unsigned)i / (unsigned)T);
+            job->w[i].a1 = rd->beg + (size_t)((unsigned long long)(end - rd->beg) * (unsigned)(i + 1) / (unsigned)T);
+        }
+        fxh_parallel(job, fxh_phase_census);
+        unsigned long long lines = 0;
+        for (int i = 0; i < T; ++i) lines += job->w[i].nl_count;
+        const uint64_t records = lines / 4;
+        size_t cut = end;
+        if (!rd->eof || lines % 4 != 0) {  /* drop the incomplete last line and the lines of the incomplete record in front of it */
+            unsigned drop = (unsigned)(lines % 4);
+            const char *q = (const char *)memrchr(rd->buf + rd->beg, '\n', end - rd->beg);
+            cut = q ? (size_t)(q - rd->buf) + 1 : rd->beg;
+            while (drop-- && cut > rd->beg) {
+                q = (const char *)memrchr(rd->buf + rd->beg, '\n', cut - 1 - rd->beg);
+                cut = q ? (size_t)(q - rd->buf) + 1 : rd->beg;
+            }
+        }
+        R->t_index += fxh_now() - t0;
+        fxh_block *b = &blk[nblocks % (size_t)NB];
+        b->buf = rd->buf; b->beg = rd->beg; b->line0 = fx->input_line_number; b->records = records; b->lane = -1;
+        if (rd->eof && (lines % 4 != 0 || records == 0)) {
+            /* ragged end of input: the host parser owns the message; hand it everything that is left */
+            b->end = end; b->eof = 1;
+            rd->beg = rd->end; input_done = 1;
+        } else if (records == 0) {
+            errx(1, "input record does not fit in the %zu MB read buffer", rd->cap >> 20);
+        } else {
+            b->end = cut; b->eof = (rd->eof && cut == end);
+            const int li = (int)(nblocks % (size_t)nlanes);
+            b->lane = li;
+            fxh_lane_post(&lanes[li], rd->buf + rd->beg, cut - rd->beg, records, (int)(lane_uses[li]++ & 1u));
+            rd->beg = cut < rd->end ? cut : rd->end;
+            fx->input_line_number += 4ull * records;
+            if (rd->eof && cut == end) input_done = 1;
+        }
+        nblocks++;
+    }
+    /* an error is pending: blocks after the bad record are abandoned, like everything after an errx() in the reference */
+    for (int i = 0; i < nlanes; ++i) {
+        fxh_lane *ln = &lanes[i];
+        pthread_mutex_lock(&ln->mu);
+        while (ln->state == 1) pthread_cond_wait(&ln->cv, &ln->mu);
+        ln->state = 3;
+        pthread_cond_broadcast(&ln->cv);
+        pthread_mutex_unlock(&ln->mu);
+        pthread_join(ln->th, NULL);
+        *t_lane_init += ln->t_init;
+        R->t_gpu += ln->t_busy;
+    }
+    fxh_awriter_wait(&R->aw);              /* the last lane buffer must be on its way out before the contexts go */
+    if (R->st_shared) { fxg_sync(R->st.ctx); R->st.ctx = NULL; }
+    for (int i = 0; i < nlanes; ++i) fxg_ctx_destroy(lanes[i].st.ctx);
+    for (int k = 1; k < NB; ++k) if (inbuf[k] && inbuf[k] != rd->buf) free(inbuf[k]);
+    free(inbuf); free(blk); free(lanes);
+}
+
+static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_stats_run *stats, uint64_t **hist_out, uint32_t *cols_out)
+{
+    fxh_run R;
+    memset(&R, 0, sizeof R);
+    memset(tot, 0, sizeof *tot);
+    R.fx = fx; R.p = p; R.tot = tot; R.stats = stats;
+    const int timing = getenv("FXH_TIMING") != NULL;
+    double t_read = 0, t_lane_init = 0, t0;
+    int dev[FXH_MAX_LANES];
+    const int ndev = fxh_device_list(dev, FXH_MAX_LANES);
+    R.st_device = dev[0];
     struct fxh_reader *rd = fx->reader;
     if (!getenv("FXH_READ_BUFFER_MB")) fxh_reader_reserve(rd, (size_t)64 << 20);   /* one engine call per 64 MB of text */
-    fxh_job job;
-    memset(&job, 0, sizeof job);
-    job.fx = fx; job.st = &st; job.p = p;
-    job.revcomp = (p->stages & (FXG_STAGE_REVCOMP | FXG_STAGE_MASK)) != 0;   /* stages whose output is not a slice of the input text */
-    job.has_q = fx->read_fastq;
-    job.lpr = fx->read_fastq ? 4 : 2;
-    job.fwd_start = (p->stages & FXG_STAGE_FTRIM) && p->ft_first > 1 ? (uint32_t)p->ft_first - 1u : 0u;
+    fxh_job *job = &R.job;
+    job->fx = fx; job->st = &R.st; job->p = p;
+    job->revcomp = (p->stages & (FXG_STAGE_REVCOMP | FXG_STAGE_MASK)) != 0;   /* stages whose output is not a slice of the input text */
+    job->has_q = fx->read_fastq;
+    job->lpr = fx->read_fastq ? 4 : 2;
+    job->fwd_start = (p->stages & FXG_STAGE_FTRIM) && p->ft_first > 1 ? (uint32_t)p->ft_first - 1u : 0u;
     {
         const char *te = getenv("FXH_THREADS");
         long nt = te ? atol(te) : 16, ncpu = sysconf(_SC_NPROCESSORS_ONLN);
         if (nt < 1) nt = 1;
         if (nt > 64) nt = 64;
         if (ncpu > 0 && nt > ncpu) nt = ncpu;
-        job.nworkers = (int)nt;
+        job->nworkers = (int)nt;
     }
-    job.w = (fxh_worker *)calloc((size_t)job.nworkers, sizeof(fxh_worker));
-    if (!job.w) err(1, "out of memory");
-    for (int i = 0; i < job.nworkers; ++i) {
-        fxh_worker *w = &job.w[i];
-        w->id = i; w->job = &job;
+    job->w = (fxh_worker *)calloc((size_t)job->nworkers, sizeof(fxh_worker));
+    if (!job->w) err(1, "out of memory");
+    for (int i = 0; i < job->nworkers; ++i) {
+        fxh_worker *w = &job->w[i];
+        w->id = i; w->job = job;
         w->shadow = (FASTX *)malloc(sizeof(FASTX));
         if (!w->shadow) err(1, "out of memory");
         memcpy(w->shadow, fx, sizeof(FASTX));
         w->raw.defer_errors = 1;
     }
-    char errmsg[768];
-    int have_err = 0, at_eof = 0;
     fxh_prefetch pf;
-    fxh_awriter aw;
     memset(&pf, 0, sizeof pf);
-    memset(&aw, 0, sizeof aw);
-    char *rd_spare = NULL, *wr_spare = NULL;
-    size_t wr_spare_cap = 0;
-    const int overlap = getenv("FXH_NO_OVERLAP") == NULL;
+    char *rd_spare = NULL;
+    R.overlap = getenv("FXH_NO_OVERLAP") == NULL;
     /* device-side parse/format for FASTQ; FXH_HOST_PARSE=1 forces the host parser */
     const int gpu_text = !stats && fx->read_fastq && fx->write_fastq && !g_rename_ids && getenv("FXH_HOST_PARSE") == NULL;
-    unsigned long n_fallback = 0;
+    int nlanes = 0;
+    int lane_dev[FXH_MAX_LANES];
+    if (gpu_text) {
+        /* The clipper's aligner carries state from read to read: its blocks must pass through ONE context in order,
+         * unless the caller knows the input has one fixed length (FXH_CLIP_PARALLEL=1). */
+        const int serial = (p->stages & FXG_STAGE_CLIP) && getenv("FXH_CLIP_PARALLEL") == NULL;
+        const char *le = getenv("FXH_LANES");
+        int per = le ? atoi(le) : 2;
+        if (per < 1) per = 1;
+        if (serial) per = 1;
+        for (int d = 0; d < (serial ? 1 : ndev); ++d)
+            for (int k = 0; k < per && nlanes < FXH_MAX_LANES; ++k) lane_dev[nlanes++] = dev[d];
+        /* interleave the devices: consecutive blocks go to different GPUs */
+        if (!serial && ndev > 1) { nlanes = 0; for (int k = 0; k < per; ++k) for (int d = 0; d < ndev && nlanes < FXH_MAX_LANES; ++d) lane_dev[nlanes++] = dev[d]; }
+    }
 
-    while (!at_eof && !have_err) {
-        /* ---- 1. fill the block, split it into record-aligned ranges, index + validate them in parallel ---- */
-        t0 = fxh_now();
-        if (overlap) fxh_next_block(&pf, rd, &rd_spare); else fxh_reader_fill(rd);
-        t_read += fxh_now() - t0; t0 = fxh_now();
-        if (rd->beg == rd->end && rd->eof) break;
-        if (gpu_text) {
-            struct fxh_writer *wr0 = fx->writer;
-            if (fxh_block_gpu_text(fx, &st, p, tot, wr0, job.revcomp, job.fwd_start)) {
-                t_gpu += fxh_now() - t0;
-                if (overlap) fxh_awriter_submit(&aw, wr0, &wr_spare, &wr_spare_cap); else fxh_writer_flush(wr0);
-                fx->num_input_sequences = tot->input_sequences; fx->num_input_reads = tot->input_reads;
-                fx->num_output_sequences = tot->output_sequences; fx->num_output_reads = tot->output_reads;
-                if (rd->eof && rd->beg >= rd->end) at_eof = 1;
-                continue;
-            }
-            n_fallback++;
-        }
-        const size_t beg = rd->beg, end = rd->end;
-        const int T = job.nworkers;
-        for (int i = 0; i < T; ++i) {
-            job.w[i].a0 = beg + (size_t)((unsigned long long)(end - beg) * (unsigned)i / (unsigned)T);
-            job.w[i].a1 = beg + (size_t)((unsigned long long)(end - beg) * (unsigned)(i + 1) / (unsigned)T);
-        }
-        fxh_parallel(&job, fxh_phase_census);
-        {
-            /* worker i starts at the first record boundary at or after a0: lines are counted from the block start,
-             * which is itself a record boundary (the previous block stopped at one) */
-            unsigned long long lines_before = 0;          /* complete lines in [beg, a0) */
-            for (int i = 0; i < T; ++i) {
-                fxh_worker *w = &job.w[i];
-                size_t s;
-                unsigned long long ls;                    /* complete lines in [beg, s) */
-                if (i == 0) { s = beg; ls = 0; }
-                else if (w->first_nl == (size_t)-1) { s = (size_t)-1; ls = 0; }       /* no line starts here: same boundary as the next range */
-                else {
-                    s = w->first_nl + 1; ls = lines_before + 1;
-                    while (ls % (unsigned)job.lpr != 0) {         /* walk to the next record boundary */
-                        const char *q = s < end ? (const char *)memchr(rd->buf + s, '\n', end - s) : NULL;
-                        if (!q) { s = end; break; }
-                        s = (size_t)(q - rd->buf) + 1; ls++;
-                    }
-                }
-                if (s != (size_t)-1 && s > end) s = end;
-                w->start = s;
-                w->start_line = fx->input_line_number + ls;
-                lines_before += w->nl_count;
-            }
-            for (int i = T - 1; i >= 0; --i)                      /* ranges without a line start are empty */
-                if (job.w[i].start == (size_t)-1) job.w[i].start = (i + 1 < T) ? job.w[i + 1].start : end;
-            for (int i = 0; i < T; ++i) {
-                fxh_worker *w = &job.w[i];
-                w->view.buf = rd->buf; w->view.cap = rd->cap; w->view.fd = -1;
-                w->view.beg = w->start;
-                w->view.end = (i + 1 < T) ? job.w[i + 1].start : end;
-                w->view.eof = 0;
-            }
-            /* the last non-empty range owns the end-of-input / incomplete-tail semantics */
-            for (int i = T - 1; i >= 0; --i)
-                if (job.w[i].view.beg < end || i == 0) { job.w[i].view.end = end; job.w[i].view.eof = rd->eof; break; }
-        }
-        fxh_parallel(&job, fxh_phase_index);
-        /* merge in input order; the first error / end condition wins */
-        size_t n = 0, maxlen = 0, minlen = (size_t)-1;
-        int stop = -1;                                   /* worker at which the batch ends */
-        for (int i = 0; i < T; ++i) {
-            fxh_worker *w = &job.w[i];
-            w->rec0 = n; w->use = w->nrec;
-            n += w->nrec;
-            if (w->nrec) { if (w->maxlen > maxlen) maxlen = w->maxlen; if (w->minlen < minlen) minlen = w->minlen; }
-            const int is_last = (w->view.end == end);
-            if (w->rc_end == -2) { have_err = 1; memcpy(errmsg, w->errmsg, sizeof errmsg); stop = i; }
-            else if (w->rc_end == 0) { at_eof = 1; stop = i; }
-            else if (is_last) stop = i;
-            if (stop >= 0) { rd->beg = w->end_pos; fx->input_line_number = w->end_line; break; }
-        }
-        for (int i = stop + 1; i < T; ++i) { job.w[i].use = 0; job.w[i].rec0 = n; }
-        if (n == 0) {
-            if (!have_err && !at_eof) errx(1, "input record does not fit in the %zu MB read buffer", rd->cap >> 20);
-            break;
-        }
-        t_index += fxh_now() - t0; t0 = fxh_now();
-
-        /* ---- 2. pack the SoA rows (qualities normalised to Phred+33 codes) ---- */
-        job.stride = (uint32_t)maxlen;
-        fxh_grow(&st, n, n * (size_t)job.stride, job.revcomp);
-        fxh_parallel(&job, fxh_phase_pack);
-        for (int i = 0; i <= stop; ++i) {
-            fxh_worker *w = &job.w[i];
-            if (w->bad_q >= 0) {                       /* first bad record wins: drop it and everything after it */
-                have_err = 1; at_eof = 0;
-                memcpy(errmsg, w->errmsg, sizeof errmsg);
-                n = w->rec0 + (size_t)w->bad_q;
-                w->use = (size_t)w->bad_q;
-                for (int j = i + 1; j < T; ++j) job.w[j].use = 0;
-                break;
-            }
-        }
-        t_pack += fxh_now() - t0; t0 = fxh_now();
-        if (n > 0) {
-            /* ---- 3. engine ---- */
-            const uint32_t stride = job.stride;
-            const size_t bytes = n * (size_t)stride;
-            const int fixed = (minlen == maxlen);
-            FXG_CHECK(&st, fxg_memcpy_h2d(st.ctx, st.d_bases, st.h_bases, bytes));
-            if (job.has_q) FXG_CHECK(&st, fxg_memcpy_h2d(st.ctx, st.d_qual, st.h_qual, bytes));
-            if (!fixed) FXG_CHECK(&st, fxg_memcpy_h2d(st.ctx, st.d_len, st.h_len, n * sizeof(uint16_t)));
-            fxg_batch in = {st.d_bases, job.has_q ? st.d_qual : NULL, fixed ? NULL : st.d_len, (uint32_t)maxlen, stride, n};
-            if (stats) {                            /* fastx_quality_stats: reduce, nothing to write */
-                fxh_stats_reserve(&st, stats, stride);
-                FXG_CHECK(&st, fxg_run_quality_stats(st.ctx, &in, stats->d_hist, stats->cols));
-                FXG_CHECK(&st, fxg_sync(st.ctx));
-                tot->input_sequences += n; tot->input_reads += n;
-                fx->num_input_sequences = tot->input_sequences; fx->num_input_reads = tot->input_reads;
-                t_gpu += fxh_now() - t0;
-                continue;
-            }
-            fxg_out out = {st.d_res, job.revcomp ? st.d_out_bases : NULL, (job.revcomp && job.has_q) ? st.d_out_qual : NULL, NULL, NULL, NULL, st.d_counters};
-            fxg_params pp = *p;
-            pp.qoffset = 33;                        /* rows hold Phred+33 codes whatever -Q was */
-            FXG_CHECK(&st, fxg_run_pipeline(st.ctx, &in, &pp, &out));
-            FXG_CHECK(&st, fxg_memcpy_d2h(st.ctx, st.h_res, st.d_res, n * sizeof(uint32_t)));
-            uint64_t ctr[FXG_NCOUNTERS];
-            {
-                int rc = fxg_read_counters(st.ctx, st.d_counters, ctr);   /* synchronises */
-                if (rc == FXG_E_DEVICE && (ctr[FXG_C_ERRORS] & FXG_DEV_ERR_BAD_BASE)) errx(1, "%s", fxg_last_error(st.ctx));
-                if (rc != 0) errx(1, "GPU engine error %d: %s", rc, fxg_last_error(st.ctx));
-            }
-            tot->masked_reads += ctr[FXG_C_MASKED_READS]; tot->masked_nucleotides += ctr[FXG_C_MASKED_NT];
-            if (job.revcomp) {
-                FXG_CHECK(&st, fxg_memcpy_d2h(st.ctx, st.h_out_bases, st.d_out_bases, ctr[FXG_C_KEPT_BASES]));
-                if (job.has_q) FXG_CHECK(&st, fxg_memcpy_d2h(st.ctx, st.h_out_qual, st.d_out_qual, ctr[FXG_C_KEPT_BASES]));
-                FXG_CHECK(&st, fxg_sync(st.ctx));
-            }
-            t_gpu += fxh_now() - t0; t0 = fxh_now();
-
-            /* ---- 4. format the kept records in input order (each worker its own slice), tally the report counters ---- */
-            fxh_parallel(&job, fxh_phase_count);
-            {
-                size_t base = tot->output_sequences + 1;
-                for (int i = 0; i < T; ++i) { job.w[i].kept_base = base; base += job.w[i].kept_count; }
-            }
-            fxh_parallel(&job, fxh_phase_size);
-            size_t total = 0, kept_total = 0;
-            for (int i = 0; i < T; ++i) {
-                fxh_worker *w = &job.w[i];
-                w->out_off = total; w->kept_off = kept_total;
-                total += w->out_bytes; kept_total += w->kept_bytes;
-                tot->input_sequences += w->tot.input_sequences; tot->input_reads += w->tot.input_reads;
-                tot->output_sequences += w->tot.output_sequences; tot->output_reads += w->tot.output_reads;
-                tot->clip_input += w->tot.clip_input; tot->clip_too_short += w->tot.clip_too_short;
-                tot->clip_adapter_only += w->tot.clip_adapter_only; tot->clip_no_adapter += w->tot.clip_no_adapter;
-                tot->clip_adapter_found += w->tot.clip_adapter_found; tot->clip_n += w->tot.clip_n;
-            }
-            struct fxh_writer *wr = fx->writer;
-            job.out_dst = fxh_writer_reserve(wr, total + 16);
-            fxh_parallel(&job, fxh_phase_format);
-            wr->len += total;
-            if (overlap) fxh_awriter_submit(&aw, wr, &wr_spare, &wr_spare_cap); else fxh_writer_flush(wr);
-            fx->num_input_sequences = tot->input_sequences; fx->num_input_reads = tot->input_reads;
-            fx->num_output_sequences = tot->output_sequences; fx->num_output_reads = tot->output_reads;
-            t_fmt += fxh_now() - t0;
+    if (nlanes > 0) {
+        fxh_run_lanes(&R, &pf, nlanes, lane_dev, &t_read, &t_lane_init);
+    } else {
+        while (!R.at_eof && !R.have_err) {
+            t0 = fxh_now();
+            if (R.overlap) fxh_next_block(&pf, rd, &rd_spare); else fxh_reader_fill(rd);
+            t_read += fxh_now() - t0;
+            if (rd->beg == rd->end && rd->eof) break;
+            fxh_host_block(&R);
         }
     }
-    fxh_awriter_stop(&aw);
+    fxh_awriter_stop(&R.aw);
     fxh_prefetch_stop(&pf);
-    if (have_err) {
+    if (R.have_err) {
         if (!stats) fxh_writer_flush(fx->writer);   /* every record before the bad one has been written, like the reference */
-        errx(1, "%s", errmsg);
+        errx(1, "%s", R.errmsg);
     }
     if (stats) {
         const size_t per_col = (size_t)FXG_QS_CLASSES * FXG_QS_BINS * sizeof(uint64_t);
@@ -841,16 +1210,16 @@ static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_sta
         *hist_out = (uint64_t *)calloc(stats->cols ? stats->cols : 1, per_col);
         if (!*hist_out) err(1, "out of memory");
         if (stats->d_hist) {
-            FXG_CHECK(&st, fxg_memcpy_d2h(st.ctx, *hist_out, stats->d_hist, (size_t)stats->cols * per_col));
-            FXG_CHECK(&st, fxg_sync(st.ctx));
+            FXG_CHECK(&R.st, fxg_memcpy_d2h(R.st.ctx, *hist_out, stats->d_hist, (size_t)stats->cols * per_col));
+            FXG_CHECK(&R.st, fxg_sync(R.st.ctx));
         }
     }
     if (timing)
-        fprintf(stderr, "fxh timing (%d threads, %s parse, %lu host-parsed blocks): init %.3f read %.3f index %.3f pack %.3f gpu(h2d+kernel+d2h) %.3f format+write %.3f s\n",
-                job.nworkers, gpu_text ? "device" : "host", n_fallback, t_init, t_read, t_index, t_pack, t_gpu, t_fmt);
-    fxg_ctx_destroy(st.ctx);
-    for (int i = 0; i < job.nworkers; ++i) { free(job.w[i].rec); free(job.w[i].shadow); }
-    free(job.w);
+        fprintf(stderr, "fxh timing (%d threads, %s parse, %d lanes on %d GPU(s), %lu host-parsed blocks): init %.3f read %.3f index %.3f pack %.3f gpu(h2d+kernel+d2h, summed over lanes) %.3f format+write %.3f s\n",
+                job->nworkers, gpu_text ? "device" : "host", nlanes, nlanes ? ndev : 1, R.n_fallback, R.t_init + t_lane_init, t_read, R.t_index, R.t_pack, R.t_gpu, R.t_fmt);
+    if (R.st.ctx) fxg_ctx_destroy(R.st.ctx);
+    for (int i = 0; i < job->nworkers; ++i) { free(job->w[i].rec); free(job->w[i].shadow); }
+    free(job->w);
     return 0;
 }
 

@@ -25,6 +25,8 @@ typedef struct fxh_totals {
     unsigned int clip_input, clip_too_short, clip_adapter_only, clip_no_adapter, clip_adapter_found, clip_n;
     /* fastq_masker.c:78-79 */
     size_t masked_reads, masked_nucleotides;
+    /* chains of quality stages in one pass (fastq_quality_trim_filter): reads the trimmer stage dropped */
+    size_t qtrim_dropped;
 } fxh_totals;
 
 /* Runs the whole input of `fx` (reader and writer already initialised) through the engine with the stage

@@ -274,6 +274,7 @@ int  fxg_set_clip_history(fxg_ctx *ctx, int on);
  * helpers are host arithmetic / I/O; they need no context and no device.  How the counter blocks travel is the caller's
  * business: an RCCL all-gather between processes (fastx_toolkit_amd/distributed.py), plain memory between the threads of one
  * process (host/fxh_batch.c). ---- */
+int  fxg_device_count(void);   /* HIP devices visible to this process (0 if none) */
 /* reads [*lo, *hi) of an n-read job owned by shard `rank` of `world`:  rank * n / world  ..  (rank + 1) * n / world */
 int  fxg_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi);
 /* gathered: world counter blocks in shard order (world * FXG_NCOUNTERS values).  totals (optional): the job's counters (sums;

@@ -56,6 +56,10 @@ int fxg_synth_generate(fxg_ctx *, uint64_t, uint64_t, uint64_t, uint32_t, int, u
 int fxg_fastq_index(fxg_ctx *, const uint8_t *, uint64_t, int, uint32_t *, uint64_t, uint16_t *, fxg_text_info *info) { memset(info, 0, sizeof *info); info->irregular = FXG_TEXT_IRR_CR; return 0; }
 int fxg_fastq_pack(fxg_ctx *, const uint8_t *, uint64_t, const uint32_t *, uint64_t, uint32_t, int, uint8_t *, uint8_t *, uint32_t *irr) { *irr = 1; return 0; }
 int fxg_fastq_format(fxg_ctx *, const uint8_t *, const uint32_t *, uint64_t, const uint32_t *, uint32_t, const uint8_t *, const uint8_t *, const uint64_t *, int, uint8_t *, uint64_t *n) { *n = 0; return FXG_E_INVALID; }
+int fxg_device_count(void) { return 1; }
+int fxg_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi) { *lo = n * rank / world; *hi = n * (rank + 1) / world; return 0; }
+int fxg_epilogue(const uint64_t *, uint32_t, uint32_t, uint64_t *, uint64_t *, uint64_t *) { return FXG_E_INVALID; }
+int fxg_concat_pwrite(int, const void *, uint64_t, uint64_t) { return FXG_E_INVALID; }
 int fxg_host_register(fxg_ctx *, void *, size_t) { return 0; }
 int fxg_host_unregister(fxg_ctx *, void *) { return 0; }
 int fxg_set_profiling(fxg_ctx *, int) { return 0; }

@@ -169,3 +169,59 @@ def test_quality_stats_galaxy_known_answer(tools):
     exp = open(os.path.join(GOLDEN, "galaxy", "fastq_stats1.out"), "rb").read()
     rc, out, err = _run([os.path.join(tools, "fastx_quality_stats"), "-Q", "64"], inp)
     assert (rc, out) == (0, exp), err
+
+
+def test_lanes_devices_and_the_fused_tool(tools, tmp_path):
+    """Multi-GPU front end of the tools: blocks dealt round-robin to lanes (one context each) over FXG_DEVICES and collected in input
+    order.  Two contexts on this box's one GPU stand in for two GPUs (the code path is the same; the driver's 8-GPU node is where
+    they would be different devices).  Output and -v report must be byte-identical to the single-lane run whatever the lane count
+    and block size; a damaged record fails like the reference after everything before it was written.  Also: the one-pass
+    fastq_quality_trim_filter writes what the trimmer | filter pipe writes."""
+    text = fo.synth_fastq(2, 0, 120000, 150, False)                      # ~38 MB
+    argv = ["fastq_quality_trimmer", "-t", "20", "-l", "30", "-v"]
+    base = _run([os.path.join(tools, argv[0])] + argv[1:], text, dict(os.environ, FXH_LANES="1"))
+    assert base[0] == 0
+    for env in ({"FXH_LANES": "3"}, {"FXG_DEVICES": "0,0", "FXH_LANES": "2"}, {"FXG_DEVICES": "all"}):
+        for buf in ("1", "8"):
+            got = _run([os.path.join(tools, argv[0])] + argv[1:], text, dict(os.environ, FXH_READ_BUFFER_MB=buf, **env))
+            assert (got[0], got[1], _msg(got[2])) == (base[0], base[1], _msg(base[2])), (env, buf)
+    k = text.index(b"\n@", 20_000_000) + 1
+    bad = text[:k] + b"#" + text[k + 1:]
+    want = _run([os.path.join(tools, argv[0])] + argv[1:], bad, dict(os.environ, FXH_LANES="1"))
+    assert want[0] == 1 and len(want[1]) > 5_000_000
+    if REF:
+        ref = _run([REF] + argv, bad)
+        assert (want[0], want[1]) == (ref[0], ref[1]) and _msg(want[2]) == _msg(ref[2])
+    got = _run([os.path.join(tools, argv[0])] + argv[1:], bad, dict(os.environ, FXG_DEVICES="0,0", FXH_LANES="2", FXH_READ_BUFFER_MB="2"))
+    assert (got[0], got[1]) == (want[0], want[1]) and _msg(got[2]) == _msg(want[2])
+    # fused one-pass tool == the shell pipe, output and reports
+    t = _run([os.path.join(tools, "fastq_quality_trimmer"), "-t", "20", "-l", "30", "-v"], text)
+    f = _run([os.path.join(tools, "fastq_quality_filter"), "-q", "20", "-p", "80", "-v"], t[1])
+    one = _run([os.path.join(tools, "fastq_quality_trim_filter"), "-t", "20", "-l", "30", "-q", "20", "-p", "80", "-v"], text)
+    assert one[0] == 0 and one[1] == f[1]
+    clean = lambda e: b"\n".join(l for l in e.split(b"\n") if b"amdgpu.ids" not in l)
+    assert clean(one[2]) == clean(t[2]) + clean(f[2])
+
+
+def test_flag_errors_and_usage_on_the_gpu_build(tools):
+    """F1-F6 against the real libfxg.so (the CPU tier runs the same checks against the emulation stub): exit codes, usage text, and the
+    reference's messages where fxref is on the box."""
+    cases = [(["fastq_quality_trimmer"], b"@r\nA\n+\nI\n"), (["fastq_quality_trimmer", "-t", "0"], b"@r\nA\n+\nI\n"),
+             (["fastq_quality_filter", "-p", "0"], b""), (["fastq_quality_filter", "-p", "101", "-q", "5"], b"@r\nA\n+\nI\n"),
+             (["fastx_trimmer", "-f", "2", "-t", "3"], b"@r\nA\n+\nI\n"), (["fastx_trimmer", "-f", "0"], b"@r\nA\n+\nI\n"),
+             (["fastx_trimmer", "-l", "25000"], b"@r\nA\n+\nI\n"), (["fastx_clipper", "-M", "0"], b"@r\nA\n+\nI\n"),
+             (["fastq_masker", "-r", "xy"], b"@r\nA\n+\nI\n"), (["fastq_quality_trimmer", "-t", "20"], b""),
+             (["fastq_quality_trimmer", "-t", "20"], b">fa\nAC\n"), (["fastq_quality_trimmer", "-t", "20", "-Q", "64"], b"@r\nA\n+\nI\n")]
+    for argv, data in cases:
+        rc, out, err = _run([os.path.join(tools, argv[0])] + argv[1:], data)
+        assert rc == 1, argv
+        if REF:
+            rrc, rout, rerr = _run([REF] + argv, data)
+            assert (rc, out) == (rrc, rout), argv
+            assert _msg(err) == _msg(rerr), argv
+    rc, out, _ = _run([os.path.join(tools, "fastx_clipper"), "-h"], b"")
+    assert rc == 1 and out.startswith(b"usage: fastx_clipper")                                     # -h exits 1 (F5)
+    rc, out, err = _run([os.path.join(tools, "fastq_quality_filter"), "-q", "94", "-v"], b"@r\nACGT\n+\nIIII\n")   # F2: -p omitted, -q > 93 drops everything
+    assert rc == 0 and out == b""
+    rc, out, err = _run([os.path.join(tools, "fastq_quality_filter"), "-q", "40"], b"@r\nACGT\n+\n!!!!\n")         # F2: -p omitted, everything passes
+    assert rc == 0 and out == b"@r\nACGT\n+\n!!!!\n"

@@ -37,10 +37,11 @@ def tools():
     return os.path.join(HOST, "bin")
 
 
-def _run(cmd, data, threads="4", buf_mb=None):
+def _run(cmd, data, threads="4", buf_mb=None, extra_env=None):
     env = dict(os.environ, LD_LIBRARY_PATH=STUB_DIR, FXH_THREADS=threads)
     if buf_mb:
         env["FXH_READ_BUFFER_MB"] = buf_mb
+    env.update(extra_env or {})
     p = subprocess.run(cmd, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
     return p.returncode, p.stdout, p.stderr
 
@@ -187,3 +188,49 @@ def test_reader_rules_through_the_batch_path(tools):
                 rrc, rout, rerr = _run([REF] + argv, data)
                 assert (rc, out) == (rrc, rout), (trial, kind, argv, err[-200:], rerr[-200:])
                 assert _msg(err) == _msg(rerr), (trial, kind, argv)
+
+
+def test_lanes_many_blocks_any_lane_count_same_bytes(tools):
+    """The lanes loop of the tools (blocks cut at record boundaries on the host, dealt round-robin to lanes over FXG_DEVICES, collected
+    in input order): output, report and error behaviour must not depend on the number of lanes, devices or on the block size.  (With the
+    stub every block comes back "irregular", so this drives the ordering, the buffer ring and the host-parser hand-back; the GPU tier
+    runs the same matrix against the real engine.)"""
+    text = fo.synth_fastq(41, 0, 30000, 100, False)                     # ~7 MB: seven blocks of 1 MB
+    argv = ["fastq_quality_trimmer", "-t", "20", "-l", "30", "-v"]
+    base = _run([os.path.join(tools, argv[0])] + argv[1:], text)
+    assert base[0] == 0
+    for env in ({"FXH_LANES": "1"}, {"FXH_LANES": "3"}, {"FXG_DEVICES": "0,0,0", "FXH_LANES": "2"}, {"FXH_NO_OVERLAP": "1"}, {"FXH_HOST_PARSE": "1"}):
+        for buf in ("1", "2", None):
+            assert _run([os.path.join(tools, argv[0])] + argv[1:], text, buf_mb=buf, extra_env=env) == base, (env, buf)
+    # a damaged record in the fifth megabyte: everything before it is written, then the reference's message and exit 1
+    k = text.index(b"\n@", 4_500_000) + 1
+    bad = text[:k] + b"#" + text[k + 1:]
+    want = _run([os.path.join(tools, argv[0])] + argv[1:], bad, extra_env={"FXH_HOST_PARSE": "1", "FXH_NO_OVERLAP": "1"})
+    assert want[0] == 1 and len(want[1]) > 1_000_000
+    if REF:
+        ref = _run([REF] + argv, bad)
+        assert (want[0], want[1]) == (ref[0], ref[1]) and _msg(want[2]) == _msg(ref[2])
+    for env in ({"FXH_LANES": "1"}, {"FXH_LANES": "4"}, {"FXG_DEVICES": "0,0", "FXH_LANES": "2"}):
+        got = _run([os.path.join(tools, argv[0])] + argv[1:], bad, buf_mb="1", extra_env=env)
+        assert (got[0], got[1]) == (want[0], want[1]) and _msg(got[2]) == _msg(want[2]), env
+    # ragged end of input (a record cut short) and input without a final newline
+    for tail in (text[:-1], text[:-150], text + b"@x\nAC\n"):
+        want = _run([os.path.join(tools, argv[0])] + argv[1:], tail, extra_env={"FXH_HOST_PARSE": "1"})
+        for env in ({"FXH_LANES": "1"}, {"FXH_LANES": "3"}):
+            got = _run([os.path.join(tools, argv[0])] + argv[1:], tail, buf_mb="1", extra_env=env)
+            assert (got[0], got[1]) == (want[0], want[1]) and _msg(got[2]) == _msg(want[2]), env
+
+
+def test_fused_trim_filter_equals_the_pipe(tools):
+    """fastq_quality_trim_filter (one pass) writes the bytes of fastq_quality_trimmer | fastq_quality_filter, and -v prints both reports."""
+    text = fo.synth_fastq(2, 0, 4000, 150, False)
+    t = _run([os.path.join(tools, "fastq_quality_trimmer"), "-t", "20", "-l", "30", "-v"], text)
+    f = _run([os.path.join(tools, "fastq_quality_filter"), "-q", "20", "-p", "80", "-v"], t[1])
+    one = _run([os.path.join(tools, "fastq_quality_trim_filter"), "-t", "20", "-l", "30", "-q", "20", "-p", "80", "-v"], text)
+    assert one[0] == 0 and one[1] == f[1]
+    assert one[2] == t[2] + f[2]
+    if REF:
+        rt = _run([REF, "fastq_quality_trimmer", "-t", "20", "-l", "30", "-v"], text)
+        rf = _run([REF, "fastq_quality_filter", "-q", "20", "-p", "80", "-v"], rt[1])
+        assert one[1] == rf[1] and one[2] == rt[2] + rf[2]
+    assert _run([os.path.join(tools, "fastq_quality_trim_filter"), "-q", "20"], text)[0] == 1            # -t is mandatory, as for the trimmer
