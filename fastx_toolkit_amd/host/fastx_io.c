@@ -19,6 +19,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <sys/types.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -342,9 +343,42 @@ static void *fxh_gz_worker(void *p)
     return NULL;
 }
 
+/* plain output to a regular file: slices written with pwrite() on several threads (tmpfs / page-cache writes are page
+ * allocation + copy, which scales with threads); pipes, terminals and O_APPEND descriptors keep the single write() stream */
+struct fxh_pw_job { int fd; const char *src; size_t n; off_t off; };
+static void *fxh_pwrite_main(void *arg)
+{
+    struct fxh_pw_job *j = (struct fxh_pw_job *)arg;
+    size_t done = 0;
+    while (done < j->n) {
+        ssize_t k = pwrite(j->fd, j->src + done, j->n - done, j->off + (off_t)done);
+        if (k < 0) { if (errno == EINTR) continue; err(1, "writing output failed"); }
+        done += (size_t)k;
+    }
+    return NULL;
+}
+
+static void fxh_write_parallel(struct fxh_writer *w, const char *buf, size_t n)
+{
+    int nt = w->io_threads;
+    if ((size_t)nt > n / ((size_t)4 << 20)) nt = (int)(n / ((size_t)4 << 20));
+    if (nt <= 1) { struct fxh_pw_job j = {w->fd, buf, n, w->off}; fxh_pwrite_main(&j); w->off += (off_t)n; return; }
+    pthread_t th[16];
+    struct fxh_pw_job job[16];
+    const size_t per = (n + (size_t)nt - 1) / (size_t)nt;
+    for (int i = 0; i < nt; ++i) {
+        const size_t o = (size_t)i * per;
+        job[i].fd = w->fd; job[i].src = buf + o; job[i].off = w->off + (off_t)o; job[i].n = o >= n ? 0 : (n - o < per ? n - o : per);
+    }
+    for (int i = 1; i < nt; ++i) if (pthread_create(&th[i], NULL, fxh_pwrite_main, &job[i]) != 0) err(1, "pthread_create");
+    fxh_pwrite_main(&job[0]);
+    for (int i = 1; i < nt; ++i) pthread_join(th[i], NULL);
+    w->off += (off_t)n;
+}
+
 void fxh_writer_emit(struct fxh_writer *w, const char *buf, size_t n)
 {
-    if (!w->gz) { fxh_write_all(w->fd, buf, n); return; }
+    if (!w->gz) { if (w->positional) fxh_write_parallel(w, buf, n); else fxh_write_all(w->fd, buf, n); return; }
     if (n == 0) return;
     struct fxh_gz_job job;
     job.in = buf; job.n = n; job.nchunks = (n + FXH_GZ_CHUNK - 1) / FXH_GZ_CHUNK;
@@ -398,6 +432,7 @@ void fxh_writer_close(struct fxh_writer *w)
         fxh_write_all(w->fd, o, on);
         free(o);
     }
+    if (w->positional) (void)lseek(w->fd, w->off, SEEK_SET);     /* leave the descriptor where a write() stream would have */
     if (w->fd != STDOUT_FILENO) close(w->fd);
     w->fd = -1;
 }
@@ -419,6 +454,19 @@ static struct fxh_writer *fxh_writer_open(const char *filename, int gzip)
     if (!w->buf) err(1, "out of memory");
     w->fd = fxh_open_output(filename);
     w->gz = gzip ? 1 : 0;
+    {
+        struct stat sb;
+        const off_t pos = lseek(w->fd, 0, SEEK_CUR);
+        const int fl = fcntl(w->fd, F_GETFL);
+        const char *e = getenv("FXH_IO_THREADS");
+        long nt = e ? atol(e) : 8, ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+        if (nt < 1) nt = 1;
+        if (nt > 16) nt = 16;
+        if (ncpu > 0 && nt > ncpu) nt = ncpu;
+        w->io_threads = (int)nt;
+        w->positional = (!w->gz && pos >= 0 && fl >= 0 && !(fl & O_APPEND) && fstat(w->fd, &sb) == 0 && S_ISREG(sb.st_mode)) ? 1 : 0;
+        w->off = pos;
+    }
     static int registered;
     if (!registered) { atexit(fxh_flush_all); registered = 1; }
     for (size_t i = 0; i < sizeof g_writers / sizeof g_writers[0]; ++i)

@@ -19,6 +19,8 @@ struct fxh_writer {
     size_t cap, len;
     int gz;                 /* -z: the output is a gzip stream, compressed here in parallel (one member per chunk) */
     unsigned long gz_members;
+    int positional, io_threads;  /* plain output to a regular file: parallel pwrite() from `off` on */
+    off_t off;
 };
 
 /* one record as slices of the reader's buffer (valid until the next fill) */

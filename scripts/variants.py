@@ -14,11 +14,8 @@ sys.path.insert(0, ROOT)
 from fastx_toolkit_amd import build as _b  # noqa: E402
 
 VARIANTS = {            # edit freely: every entry becomes fastx_toolkit_amd/libfxg_v_<name>.so
-    "scan": [],                                                      # central scanner, two slots (stage B one step behind)
-    "same": ["-DFXG_SAMESTEP=1"],                                    # scanner, one slot: gather in the step that decided the tile
-    "scan_k2w3": ["-DFXG_GATHER_K=2", "-DFXG_MIN_WAVES=3"],          # fewer, fatter waves for the LDS-limited layouts
-    "scan_k2w4": ["-DFXG_GATHER_K=2", "-DFXG_MIN_WAVES=4"],
-    "same_k2w4": ["-DFXG_SAMESTEP=1", "-DFXG_GATHER_K=2", "-DFXG_MIN_WAVES=4"],
+    "base": [],
+    "clipw1": ["-DFXG_CLIP_WAVES=1"],      # clip instances without the 4-waves-per-SIMD register cap
 }
 
 

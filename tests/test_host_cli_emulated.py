@@ -234,3 +234,21 @@ def test_fused_trim_filter_equals_the_pipe(tools):
         rf = _run([REF, "fastq_quality_filter", "-q", "20", "-p", "80", "-v"], rt[1])
         assert one[1] == rf[1] and one[2] == rt[2] + rf[2]
     assert _run([os.path.join(tools, "fastq_quality_trim_filter"), "-q", "20"], text)[0] == 1            # -t is mandatory, as for the trimmer
+
+
+def test_regular_files_use_parallel_io_same_bytes(tools, tmp_path):
+    """-i FILE / -o FILE: blocks are read with several pread() and written with several pwrite() in flight; same bytes as through pipes."""
+    text = fo.synth_fastq(43, 0, 120000, 100, False)                    # ~28 MB
+    argv = ["fastq_quality_trimmer", "-t", "20", "-l", "30"]
+    want = _run([os.path.join(tools, argv[0])] + argv[1:], text)
+    assert want[0] == 0
+    inp, outp = tmp_path / "in.fq", tmp_path / "out.fq"
+    inp.write_bytes(text)
+    for buf, io in (("24", "5"), ("24", "1"), ("9", "2"), (None, "8")):
+        rc, out, err = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", str(outp)], b"", buf_mb=buf, extra_env={"FXH_IO_THREADS": io})
+        assert rc == 0 and outp.read_bytes() == want[1], (buf, io)
+    with open(outp, "wb") as f:                                         # a descriptor that is not at offset 0, and one in append mode
+        f.write(b"HEAD\n")
+    with open(outp, "ab") as f:
+        p = subprocess.run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp)], stdout=f, env=dict(os.environ, LD_LIBRARY_PATH=STUB_DIR, FXH_READ_BUFFER_MB="24"), timeout=120)
+    assert p.returncode == 0 and outp.read_bytes() == b"HEAD\n" + want[1]
