@@ -809,6 +809,7 @@ typedef struct fxh_run {
     int have_err, at_eof;
     unsigned long n_fallback;
     double t_index, t_pack, t_gpu, t_fmt, t_init;
+    double t_wait_lane, t_wait_writer, t_drain;      /* lanes loop: main thread blocked on a lane / on the writer / final drain */
 } fxh_run;
 
 static void fxh_run_ctx(fxh_run *R)
@@ -1080,10 +1081,14 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
             int handled = 0;
             if (b->lane >= 0) {
                 fxh_lane *ln = &lanes[b->lane];
+                double tw = fxh_now();
                 fxh_lane_wait(ln);
+                R->t_wait_lane += fxh_now() - tw;
                 if (ln->handled) {
                     handled = 1;
+                    tw = fxh_now();
                     fxh_awriter_submit_ext(&R->aw, wr, ln->out[ln->slot], ln->out_len);
+                    R->t_wait_writer += fxh_now() - tw;
                     if (!R->overlap) fxh_awriter_wait(&R->aw);
                     fxh_add_counters(R->tot, ln->ctr, b->records);
                 }
@@ -1183,7 +1188,7 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
         *t_lane_init += ln->t_init;
         R->t_gpu += ln->t_busy;
     }
-    fxh_awriter_wait(&R->aw);              /* the last lane buffer must be on its way out before the contexts go */
+    { const double tw = fxh_now(); fxh_awriter_wait(&R->aw); R->t_drain += fxh_now() - tw; }   /* the last lane buffer must be on its way out before the contexts go */
     if (R->st_shared) { fxg_sync(R->st.ctx); R->st.ctx = NULL; }
     for (int i = 0; i < nlanes; ++i) fxg_ctx_destroy(lanes[i].st.ctx);
     for (int k = 1; k < NB; ++k) if (inbuf[k] && inbuf[k] != rd->buf) free(inbuf[k]);
@@ -1197,6 +1202,7 @@ static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_sta
     memset(tot, 0, sizeof *tot);
     R.fx = fx; R.p = p; R.tot = tot; R.stats = stats;
     const int timing = getenv("FXH_TIMING") != NULL;
+    const double t_run0 = fxh_now();
     double t_read = 0, t_lane_init = 0, t0;
     int dev[FXH_MAX_LANES];
     const int ndev = fxh_device_list(dev, FXH_MAX_LANES);
@@ -1277,8 +1283,9 @@ static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_sta
         }
     }
     if (timing)
-        fprintf(stderr, "fxh timing (%d threads, %s parse, %d lanes on %d GPU(s), %lu host-parsed blocks): init %.3f read %.3f index %.3f pack %.3f gpu(h2d+kernel+d2h, summed over lanes) %.3f format+write %.3f s\n",
-                job->nworkers, gpu_text ? "device" : "host", nlanes, nlanes ? ndev : 1, R.n_fallback, R.t_init + t_lane_init, t_read, R.t_index, R.t_pack, R.t_gpu, R.t_fmt);
+        fprintf(stderr, "fxh timing (%d threads, %s parse, %d lanes on %d GPU(s), %lu host-parsed blocks): run %.3f = init %.3f read %.3f index %.3f pack %.3f format+write %.3f wait-lane %.3f wait-writer %.3f drain %.3f; gpu(h2d+kernel+d2h, summed over lanes) %.3f s\n",
+                job->nworkers, gpu_text ? "device" : "host", nlanes, nlanes ? ndev : 1, R.n_fallback, fxh_now() - t_run0, R.t_init + t_lane_init, t_read, R.t_index, R.t_pack, R.t_fmt,
+                R.t_wait_lane, R.t_wait_writer, R.t_drain, R.t_gpu);
     if (R.st.ctx) fxg_ctx_destroy(R.st.ctx);
     for (int i = 0; i < job->nworkers; ++i) { free(job->w[i].rec); free(job->w[i].shadow); }
     free(job->w);

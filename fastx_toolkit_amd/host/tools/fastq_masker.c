@@ -1,15 +1,33 @@
-/* fastq_masker -- same command line, output and -v report as the reference tool (src/fastq_masker/fastq_masker.c);
- * the per-base quality test and replacement run on the GPU (FXG_STAGE_MASK). */
+/* fastq_masker -- command line, output and -v report of the FASTX-Toolkit tool of that name (behaviour: src/fastq_masker/fastq_masker.c);
+ * the substitution happens inside the engine's gather (FXG_STAGE_MASK). */
 #include <err.h>
-#include <stdio.h>
-#include <stdlib.h>
+#include <limits.h>
 #include <string.h>
 
-#include "../fastx.h"
-#include "../fastx_args.h"
-#include "../fxh_batch.h"
+#include "../fxh_tool.h"
 
-const char *usage =
+enum { THRESHOLD, MASK_CHAR };
+
+static const fxh_option options[] = {
+    {'q', FXH_K_ATOI, THRESHOLD, 0, "[-q] parameter requires an argument value", 1, -40, INT_MAX, "Invalid minimum length value (-q %s)", -1, 0},
+    {'r', FXH_K_CHAR1, MASK_CHAR, 0, "[-r] parameter requires an argument value", 0, 0, 0, "[-r] parameter requires a single character as value", -1, 0},
+};
+static const fxh_report_line report[] = {
+    {FXH_W_ALWAYS, 0, 0, {{"Minimum Quality Threshold: ", FXH_V_SLOT_D, THRESHOLD}, {"\n", FXH_V_NONE, 0}}},
+    {FXH_W_ALWAYS, 0, 0, {{"Low-quality nucleotides replaced with '", FXH_V_SLOT_C, MASK_CHAR}, {"'\n", FXH_V_NONE, 0}}},
+    {FXH_W_ALWAYS, 0, 0, {{"Input: ", FXH_V_IN, 0}, {" reads.\n", FXH_V_NONE, 0}}},
+    {FXH_W_ALWAYS, 0, 0, {{"Output: ", FXH_V_OUT, 0}, {" reads.\n", FXH_V_NONE, 0}}},
+    {FXH_W_ALWAYS, 0, 0, {{"Masked reads: ", FXH_V_MASKED_READS, 0}, {"\n", FXH_V_NONE, 0}}},
+    {FXH_W_ALWAYS, 0, 0, {{"Masked nucleotides: ", FXH_V_MASKED_NT, 0}, {"\n", FXH_V_NONE, 0}}},
+};
+static void configure(const long *v, const char *s, fxg_params *p)
+{
+    (void)s;
+    p->stages = FXG_STAGE_MASK;
+    p->mask_min_quality = (int)v[THRESHOLD];
+    p->mask_char = (uint32_t)(unsigned char)v[MASK_CHAR];
+}
+static const fxh_tool tool = {
     "usage: fastq_masker [-h] [-v] [-q N] [-r C] [-z] [-i INFILE] [-o OUTFILE]\n"
     "MI355X build of the FASTX-Toolkit quality masker (same flags as FASTX Toolkit 0.0.14).\n\n"
     "   -h          this help\n"
@@ -18,53 +36,7 @@ const char *usage =
     "   -z          compress output with gzip\n"
     "   -i INFILE   FASTQ input, default stdin\n"
     "   -o OUTFILE  FASTQ output, default stdout\n"
-    "   -v          verbose report (to stdout if -o is given, else to stderr)\n\n";
-
-static int min_quality_threshold = 10;
-static char mask_character = 'N';
-
-static int parse_program_args(int optind_, int optc, char *optarg_)
-{
-    (void)optind_;
-    switch (optc) {
-    case 'q':
-        if (optarg_ == NULL) errx(1, "[-q] parameter requires an argument value");
-        min_quality_threshold = atoi(optarg_);
-        if (min_quality_threshold < -40) errx(1, "Invalid minimum length value (-q %s)", optarg_);
-        break;
-    case 'r':
-        if (optarg_ == NULL) errx(1, "[-r] parameter requires an argument value");
-        if (strlen(optarg_) != 1) errx(1, "[-r] parameter requires a single character as value");
-        mask_character = optarg_[0];
-        break;
-    default:
-        errx(1, __FILE__ ":%d: Unknown argument (%c)", __LINE__, optc);
-    }
-    return 1;
-}
-
-int main(int argc, char *argv[])
-{
-    static FASTX fastx;
-    fxh_totals tot;
-    fxg_params p;
-    fastx_parse_cmdline(argc, argv, "q:r:", parse_program_args);
-    fastx_init_reader(&fastx, get_input_filename(), FASTQ_ONLY, ALLOW_N, REQUIRE_UPPERCASE, get_fastq_ascii_quality_offset());
-    fastx_init_writer(&fastx, get_output_filename(), OUTPUT_SAME_AS_INPUT, compress_output_flag());
-    fxh_default_params(&p, get_fastq_ascii_quality_offset());
-    p.stages = FXG_STAGE_MASK;
-    p.mask_min_quality = min_quality_threshold;
-    p.mask_char = (unsigned char)mask_character;
-    fxh_run_tool(&fastx, &p, &tot);
-    if (verbose_flag()) {
-        FILE *rf = get_report_file();
-        fprintf(rf, "Minimum Quality Threshold: %d\n", min_quality_threshold);
-        fprintf(rf, "Low-quality nucleotides replaced with '%c'\n", mask_character);
-        fprintf(rf, "Input: %zu reads.\n", tot.input_reads);
-        fprintf(rf, "Output: %zu reads.\n", tot.output_reads);
-        fprintf(rf, "Masked reads: %zu\n", tot.masked_reads);
-        fprintf(rf, "Masked nucleotides: %zu\n", tot.masked_nucleotides);
-    }
-    fastx_finish(&fastx);
-    return 0;
-}
+    "   -v          verbose report (to stdout if -o is given, else to stderr)\n\n",
+    "q:r:", options, 2, NULL, {10, 'N'}, NULL, FASTQ_ONLY, OUTPUT_SAME_AS_INPUT, NULL, configure, report, 6,
+};
+int main(int argc, char *argv[]) { return fxh_tool_main(&tool, argc, argv); }

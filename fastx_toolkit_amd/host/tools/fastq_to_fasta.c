@@ -1,14 +1,30 @@
-/* fastq_to_fasta -- same command line, output and -v report as the reference tool (src/fastq_to_fasta/fastq_to_fasta.c);
- * the N-discard test (and the alphabet check) runs on the GPU (FXG_STAGE_NFILTER); FASTA formatting and the optional
- * renaming are host work, as in the reference. */
+/* fastq_to_fasta -- command line, output and -v report of the FASTX-Toolkit tool of that name (behaviour:
+ * src/fastq_to_fasta/fastq_to_fasta.c); the N-discard is the engine's base census (FXG_STAGE_NFILTER), the writer emits FASTA. */
 #include <err.h>
-#include <stdio.h>
+#include <limits.h>
+#include <string.h>
 
-#include "../fastx.h"
-#include "../fastx_args.h"
-#include "../fxh_batch.h"
+#include "../fxh_tool.h"
 
-const char *usage =
+enum { RENAME, KEEP_N };
+
+static const fxh_option options[] = {
+    {'r', FXH_K_FLAG, RENAME, 1, NULL, 0, 0, 0, NULL, -1, 0},
+    {'n', FXH_K_FLAG, KEEP_N, 1, NULL, 0, 0, 0, NULL, -1, 0},
+};
+static const fxh_report_line report[] = {
+    {FXH_W_ALWAYS, 0, 0, {{"Input: ", FXH_V_IN, 0}, {" reads.\n", FXH_V_NONE, 0}}},
+    {FXH_W_ALWAYS, 0, 0, {{"Output: ", FXH_V_OUT, 0}, {" reads.\n", FXH_V_NONE, 0}}},
+    {FXH_W_Z, KEEP_N, 0, {{"discarded ", FXH_V_DISCARDED, 0}, {" (", FXH_V_DISCARDED_PCT, 0}, {"%) low-quality reads.\n", FXH_V_NONE, 0}}},
+};
+static void configure(const long *v, const char *s, fxg_params *p)
+{
+    (void)s;
+    p->stages = FXG_STAGE_NFILTER;
+    p->nf_keep_n = v[KEEP_N] ? 1u : 0u;
+    fxh_set_rename_ids((int)v[RENAME]);           /* kept records are renamed to their 1-based output index (fastq_to_fasta.c:83-84) */
+}
+static const fxh_tool tool = {
     "usage: fastq_to_fasta [-h] [-r] [-n] [-v] [-z] [-i INFILE] [-o OUTFILE]\n"
     "MI355X build of the FASTX-Toolkit FASTQ to FASTA converter (same flags as FASTX Toolkit 0.0.14).\n\n"
     "   -h          this help\n"
@@ -17,43 +33,7 @@ const char *usage =
     "   -v          verbose report (to stdout if -o is given, else to stderr)\n"
     "   -z          compress output with gzip\n"
     "   -i INFILE   FASTQ input, default stdin\n"
-    "   -o OUTFILE  FASTA output, default stdout\n\n";
-
-static int flag_rename_seqid = 0, flag_discard_N = 1;
-
-static int parse_program_args(int optind_, int optc, char *optarg_)
-{
-    (void)optind_; (void)optarg_;
-    switch (optc) {
-    case 'n': flag_discard_N = 0; break;
-    case 'r': flag_rename_seqid = 1; break;
-    default: errx(1, __FILE__ ":%d: Unknown argument (%c)", __LINE__, optc);
-    }
-    return 1;
-}
-
-int main(int argc, char *argv[])
-{
-    static FASTX fastx;
-    fxh_totals tot;
-    fxg_params p;
-    fastx_parse_cmdline(argc, argv, "rn", parse_program_args);
-    fastx_init_reader(&fastx, get_input_filename(), FASTQ_ONLY, ALLOW_N, REQUIRE_UPPERCASE, get_fastq_ascii_quality_offset());
-    fastx_init_writer(&fastx, get_output_filename(), OUTPUT_FASTA, compress_output_flag());
-    fxh_default_params(&p, get_fastq_ascii_quality_offset());
-    p.stages = FXG_STAGE_NFILTER;
-    p.nf_keep_n = flag_discard_N ? 0u : 1u;
-    fxh_set_rename_ids(flag_rename_seqid);
-    fxh_run_tool(&fastx, &p, &tot);
-    if (verbose_flag()) {
-        FILE *rf = get_report_file();
-        fprintf(rf, "Input: %zu reads.\n", tot.input_reads);
-        fprintf(rf, "Output: %zu reads.\n", tot.output_reads);
-        if (flag_discard_N) {
-            const size_t discarded = tot.input_reads - tot.output_reads;
-            fprintf(rf, "discarded %zu (%zu%%) low-quality reads.\n", discarded, (discarded * 100) / tot.input_reads);
-        }
-    }
-    fastx_finish(&fastx);
-    return 0;
-}
+    "   -o OUTFILE  FASTA output, default stdout\n\n",
+    "rn", options, 2, NULL, {0, 0}, NULL, FASTQ_ONLY, OUTPUT_FASTA, NULL, configure, report, 3,
+};
+int main(int argc, char *argv[]) { return fxh_tool_main(&tool, argc, argv); }

@@ -1,19 +1,48 @@
-/* fastx_clipper -- same command line, output and -v report as the reference tool (src/fastx_clipper/fastx_clipper.cpp);
- * the adapter alignment, accept rules and discard cascade run on the GPU (FXG_STAGE_CLIP).
- * Contract note: the reference's aligner is history dependent on variable-length input; this
- * build aligns every read independently, which is identical for fixed-length input. */
+/* fastx_clipper -- command line, output and -v report of the FASTX-Toolkit tool of that name (behaviour:
+ * src/fastx_clipper/fastx_clipper.cpp); alignment, accept rules and the discard cascade run on the GPU (FXG_STAGE_CLIP). */
 #include <err.h>
-#include <stdio.h>
-#include <stdlib.h>
+#include <limits.h>
 #include <string.h>
 
-#include "../fastx.h"
-#include "../fastx_args.h"
-#include "../fxh_batch.h"
+#include "../fxh_tool.h"
 
-#define MAX_ADAPTER_LEN 100
+enum { MIN_LENGTH, KEEP_N, KEEP_DELTA, ONLY_CLIPPED, ONLY_NON_CLIPPED, ADAPTER_ONLY, MIN_ADAPTER, DEBUG_DUMP };
 
-const char *usage =
+static const fxh_option options[] = {
+    {'M', FXH_K_ATOI, MIN_ADAPTER, 0, "[-M] parameter requires an argument value", 1, 1, INT_MAX, "Invalid minimum adapter length (-M %s)", -1, 0},
+    {'k', FXH_K_FLAG, ADAPTER_ONLY, 1, NULL, 0, 0, 0, NULL, -1, 0},
+    {'D', FXH_K_FLAG, DEBUG_DUMP, 1, NULL, 0, 0, 0, NULL, -1, 0},           /* accepted for compatibility: the GPU aligner has no matrix dump */
+    {'c', FXH_K_FLAG, ONLY_CLIPPED, 1, NULL, 0, 0, 0, NULL, -1, 0},
+    {'C', FXH_K_FLAG, ONLY_NON_CLIPPED, 1, NULL, 0, 0, 0, NULL, -1, 0},
+    {'d', FXH_K_STRTOUL_INT, KEEP_DELTA, 0, "[-d] parameter requires an argument value", 1, 0, INT_MAX, "Invalid number bases to keep (-d %s)", -1, 0},
+    {'a', FXH_K_STRING, 0, 0, "[-a] parameter requires an argument value", 0, 0, 0, NULL, -1, 0},
+    {'l', FXH_K_STRTOUL_U32, MIN_LENGTH, 0, "[-l] parameter requires an argument value", 0, 0, 0, NULL, -1, 0},
+    {'n', FXH_K_FLAG, KEEP_N, 1, NULL, 0, 0, 0, NULL, -1, 0},
+};
+static const fxh_report_line report[] = {
+    {FXH_W_ALWAYS, 0, 0, {{"Clipping Adapter: ", FXH_V_STRING, 0}, {"\n", FXH_V_NONE, 0}}},
+    {FXH_W_ALWAYS, 0, 0, {{"Min. Length: ", FXH_V_SLOT_D, MIN_LENGTH}, {"\n", FXH_V_NONE, 0}}},
+    {FXH_W_NZ, ONLY_NON_CLIPPED, 0, {{"Clipped reads - discarded.\n", FXH_V_NONE, 0}}},
+    {FXH_W_NZ, ONLY_CLIPPED, 0, {{"Non-Clipped reads - discarded.\n", FXH_V_NONE, 0}}},
+    {FXH_W_ALWAYS, 0, 0, {{"Input: ", FXH_V_CLIP_IN, 0}, {" reads.\n", FXH_V_NONE, 0}}},
+    {FXH_W_ALWAYS, 0, 0, {{"Output: ", FXH_V_CLIP_OUT, 0}, {" reads.\n", FXH_V_NONE, 0}}},
+    {FXH_W_ALWAYS, 0, 0, {{"discarded ", FXH_V_CLIP_SHORT, 0}, {" too-short reads.\n", FXH_V_NONE, 0}}},
+    {FXH_W_ALWAYS, 0, 0, {{"discarded ", FXH_V_CLIP_ADAPTER_ONLY, 0}, {" adapter-only reads.\n", FXH_V_NONE, 0}}},
+    {FXH_W_NZ, ONLY_CLIPPED, 0, {{"discarded ", FXH_V_CLIP_NON_CLIPPED, 0}, {" non-clipped reads.\n", FXH_V_NONE, 0}}},
+    {FXH_W_NZ, ONLY_NON_CLIPPED, 0, {{"discarded ", FXH_V_CLIP_CLIPPED, 0}, {" clipped reads.\n", FXH_V_NONE, 0}}},
+    {FXH_W_Z, KEEP_N, 0, {{"discarded ", FXH_V_CLIP_N, 0}, {" N reads.\n", FXH_V_NONE, 0}}},
+};
+static void configure(const long *v, const char *s, fxg_params *p)
+{
+    p->stages = FXG_STAGE_CLIP;
+    strncpy(p->adapter, s, sizeof p->adapter - 1);
+    p->clip_min_len = (uint32_t)v[MIN_LENGTH];
+    p->clip_keep_delta = v[KEEP_DELTA] > 0 ? (int)v[KEEP_DELTA] + (int)strlen(s) : (int)v[KEEP_DELTA];       /* fastx_clipper.cpp:153-154 */
+    p->clip_min_adapter_len = (int)v[MIN_ADAPTER];
+    p->clip_flags = (v[ONLY_CLIPPED] ? FXG_CLIP_DISCARD_NON_CLIPPED : 0u) | (v[ONLY_NON_CLIPPED] ? FXG_CLIP_DISCARD_CLIPPED : 0u) |
+                    (v[KEEP_N] ? FXG_CLIP_KEEP_N : 0u) | (v[ADAPTER_ONLY] ? FXG_CLIP_ADAPTER_ONLY : 0u);
+}
+static const fxh_tool tool = {
     "usage: fastx_clipper [-h] [-a ADAPTER] [-D] [-l N] [-n] [-d N] [-c] [-C] [-o] [-v] [-z] [-i INFILE] [-o OUTFILE]\n"
     "MI355X build of the FASTX-Toolkit adapter clipper (same flags as FASTX Toolkit 0.0.14).\n\n"
     "   -h          this help\n"
@@ -29,75 +58,8 @@ const char *usage =
     "   -D          accepted for compatibility (the GPU aligner has no matrix dump)\n"
     "   -M N        require a minimum adapter alignment length of N\n"
     "   -i INFILE   FASTA/Q input, default stdin\n"
-    "   -o OUTFILE  FASTA/Q output, default stdout\n\n";
-
-static char adapter[MAX_ADAPTER_LEN] = "CCTTAAGG";
-static unsigned int min_length = 5;
-static int discard_unknown_bases = 1, keep_delta = 0, discard_non_clipped = 0, discard_clipped = 0, show_adapter_only = 0;
-static int minimum_adapter_length = 0;
-
-static int parse_program_args(int optind_, int optc, char *optarg_)
-{
-    (void)optind_;
-    switch (optc) {
-    case 'M':
-        if (optarg_ == NULL) errx(1, "[-M] parameter requires an argument value");
-        minimum_adapter_length = atoi(optarg_);
-        if (minimum_adapter_length <= 0) errx(1, "Invalid minimum adapter length (-M %s)", optarg_);
-        break;
-    case 'k': show_adapter_only = 1; break;
-    case 'D': break;
-    case 'c': discard_non_clipped = 1; break;
-    case 'C': discard_clipped = 1; break;
-    case 'd':
-        if (optarg_ == NULL) errx(1, "[-d] parameter requires an argument value");
-        keep_delta = (int)strtoul(optarg_, NULL, 10);
-        if (keep_delta < 0) errx(1, "Invalid number bases to keep (-d %s)", optarg_);
-        break;
-    case 'a': strncpy(adapter, optarg_, sizeof(adapter) - 1); break;
-    case 'l':
-        if (optarg_ == NULL) errx(1, "[-l] parameter requires an argument value");
-        min_length = (unsigned int)strtoul(optarg_, NULL, 10);
-        break;
-    case 'n': discard_unknown_bases = 0; break;
-    default: errx(1, "Unknown argument (%c)", optc);     /* includes the reference's unhandled 's' (F3) */
-    }
-    return 1;
-}
-
-int main(int argc, char *argv[])
-{
-    static FASTX fastx;
-    fxh_totals tot;
-    fxg_params p;
-    fastx_parse_cmdline(argc, argv, "M:kDCcd:a:s:l:n", parse_program_args);
-    if (keep_delta > 0) keep_delta += (int)strlen(adapter);       /* fastx_clipper.cpp:153-154 */
-    fastx_init_reader(&fastx, get_input_filename(), FASTA_OR_FASTQ, ALLOW_N, REQUIRE_UPPERCASE, get_fastq_ascii_quality_offset());
-    fastx_init_writer(&fastx, get_output_filename(), OUTPUT_SAME_AS_INPUT, compress_output_flag());
-    fxh_default_params(&p, get_fastq_ascii_quality_offset());
-    p.stages = FXG_STAGE_CLIP;
-    strncpy(p.adapter, adapter, sizeof p.adapter - 1);
-    p.clip_min_len = min_length;
-    p.clip_keep_delta = keep_delta;
-    p.clip_min_adapter_len = minimum_adapter_length;
-    p.clip_flags = (discard_non_clipped ? FXG_CLIP_DISCARD_NON_CLIPPED : 0u) | (discard_clipped ? FXG_CLIP_DISCARD_CLIPPED : 0u) |
-                   (discard_unknown_bases ? 0u : FXG_CLIP_KEEP_N) | (show_adapter_only ? FXG_CLIP_ADAPTER_ONLY : 0u);
-    fxh_run_tool(&fastx, &p, &tot);
-    if (verbose_flag()) {
-        FILE *rf = get_report_file();
-        fprintf(rf, "Clipping Adapter: %s\n", adapter);
-        fprintf(rf, "Min. Length: %d\n", min_length);
-        if (discard_clipped) fprintf(rf, "Clipped reads - discarded.\n");
-        if (discard_non_clipped) fprintf(rf, "Non-Clipped reads - discarded.\n");
-        fprintf(rf, "Input: %u reads.\n", tot.clip_input);
-        fprintf(rf, "Output: %u reads.\n", tot.clip_input - tot.clip_too_short - tot.clip_no_adapter - tot.clip_adapter_found -
-                                               tot.clip_n - tot.clip_adapter_only);
-        fprintf(rf, "discarded %u too-short reads.\n", tot.clip_too_short);
-        fprintf(rf, "discarded %u adapter-only reads.\n", tot.clip_adapter_only);
-        if (discard_non_clipped) fprintf(rf, "discarded %u non-clipped reads.\n", tot.clip_no_adapter);
-        if (discard_clipped) fprintf(rf, "discarded %u clipped reads.\n", tot.clip_adapter_found);
-        if (discard_unknown_bases) fprintf(rf, "discarded %u N reads.\n", tot.clip_n);
-    }
-    fastx_finish(&fastx);
-    return 0;
-}
+    "   -o OUTFILE  FASTA/Q output, default stdout\n\n",
+    "M:kDCcd:a:s:l:n", options, 9, "Unknown argument (%c)",     /* 's' is in the option string but has no handler, there as here (F3) */
+    {5, 0, 0, 0, 0, 0, 0}, "CCTTAAGG", FASTA_OR_FASTQ, OUTPUT_SAME_AS_INPUT, NULL, configure, report, 11,
+};
+int main(int argc, char *argv[]) { return fxh_tool_main(&tool, argc, argv); }

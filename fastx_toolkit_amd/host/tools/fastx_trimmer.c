@@ -1,14 +1,46 @@
-/* fastx_trimmer -- same command line, output and -v report as the reference tool (src/fastx_trimmer/fastx_trimmer.c);
- * the per-read length arithmetic runs on the GPU (FXG_STAGE_FTRIM / FXG_STAGE_FTRIM_END). */
+/* fastx_trimmer -- command line, output and -v report of the FASTX-Toolkit tool of that name (behaviour:
+ * src/fastx_trimmer/fastx_trimmer.c); positions are arithmetic on the read length, done on the GPU (FXG_STAGE_FTRIM / _END). */
 #include <err.h>
-#include <stdio.h>
-#include <stdlib.h>
+#include <limits.h>
+#include <string.h>
 
-#include "../fastx.h"
-#include "../fastx_args.h"
-#include "../fxh_batch.h"
+#include "../fxh_tool.h"
 
-const char *usage =
+enum { FIRST, LAST, BY_POSITION, FROM_END, TRIM_END, MIN_LEN };
+#define MAXLEN (MAX_SEQ_LINE_LENGTH - 1)
+
+static const fxh_option options[] = {
+    {'f', FXH_K_STRTOUL_INT, FIRST, 0, "[-f] parameter requires an argument value", 1, 1, MAXLEN, "Invalid number bases to keep (-f %s)", BY_POSITION, 1},
+    {'l', FXH_K_STRTOUL_INT, LAST, 0, "[-l] parameter requires an argument value", 1, 1, MAXLEN, "Invalid number bases to keep (-l %s)", BY_POSITION, 1},
+    {'t', FXH_K_STRTOUL_U32, TRIM_END, 0, "[-t] parameter requires an argument value", 1, 1, MAXLEN, "Invalid number bases to trim (-t %s)", FROM_END, 1},
+    {'m', FXH_K_STRTOUL_U32, MIN_LEN, 0, "[-t] parameter requires an argument value", 1, 1, MAXLEN, "Invalid minimum length value (-m %s)", -1, 0},   /* "[-t]": the reference's wording */
+};
+static const fxh_report_line report[] = {
+    {FXH_W_RANGE_SET, FIRST, LAST, {{"Trimming: base ", FXH_V_SLOT_D, FIRST}, {" to ", FXH_V_SLOT_D, LAST}, {"\n", FXH_V_NONE, 0}}},
+    {FXH_W_NZ, TRIM_END, 0, {{"Trimming ", FXH_V_SLOT_D, TRIM_END}, {" bases from the end of the reads\n", FXH_V_NONE, 0}}},
+    {FXH_W_NZ_BOTH, TRIM_END, MIN_LEN, {{"Discarding reads shorter than ", FXH_V_SLOT_D, MIN_LEN}, {" bases\n", FXH_V_NONE, 0}}},
+    {FXH_W_ALWAYS, 0, 0, {{"Input: ", FXH_V_IN, 0}, {" reads.\n", FXH_V_NONE, 0}}},
+    {FXH_W_ALWAYS, 0, 0, {{"Output: ", FXH_V_OUT, 0}, {" reads.\n", FXH_V_NONE, 0}}},
+};
+static void check(const long *v, const char *s)
+{
+    (void)s;
+    if (v[BY_POSITION] && v[FROM_END]) errx(1, "[-t], [-f] and [-l] options can not be used together. Use [-t] or [-l,-f]");   /* F4 */
+}
+static void configure(const long *v, const char *s, fxg_params *p)
+{
+    (void)s;
+    if (v[FROM_END]) {
+        p->stages = FXG_STAGE_FTRIM_END;
+        p->ft_trim_end = (uint32_t)v[TRIM_END];
+        p->ft_min_len = (uint32_t)v[MIN_LEN];        /* -m without -t has no effect in the reference either */
+    } else {
+        p->stages = FXG_STAGE_FTRIM;
+        p->ft_first = (int)v[FIRST];
+        p->ft_last = (int)v[LAST];
+    }
+}
+static const fxh_tool tool = {
     "usage: fastx_trimmer [-h] [-f N] [-l N] [-t N] [-m MINLEN] [-z] [-v] [-i INFILE] [-o OUTFILE]\n"
     "MI355X build of the FASTX-Toolkit trimmer (same flags as FASTX Toolkit 0.0.14).\n\n"
     "   -h          this help\n"
@@ -18,74 +50,7 @@ const char *usage =
     "   -m MINLEN   with -t: discard reads shorter than MINLEN\n"
     "   -z          compress output with gzip\n"
     "   -i INFILE   FASTA/Q input, default stdin\n"
-    "   -o OUTFILE  FASTA/Q output, default stdout\n\n";
-
-static int keep_first_base = 1, keep_last_base = 0, trim_by_position = 0, trim_from_end = 0;
-static unsigned int trim_last_bases = 0, minimum_length = 0;
-
-static int parse_program_args(int optind_, int optc, char *optarg_)
-{
-    (void)optind_;
-    switch (optc) {
-    case 'f':
-        if (optarg_ == NULL) errx(1, "[-f] parameter requires an argument value");
-        keep_first_base = (int)strtoul(optarg_, NULL, 10);
-        if (keep_first_base <= 0 || keep_first_base >= MAX_SEQ_LINE_LENGTH) errx(1, "Invalid number bases to keep (-f %s)", optarg_);
-        trim_by_position = 1;
-        break;
-    case 'l':
-        if (optarg_ == NULL) errx(1, "[-l] parameter requires an argument value");
-        keep_last_base = (int)strtoul(optarg_, NULL, 10);
-        if (keep_last_base <= 0 || keep_last_base >= MAX_SEQ_LINE_LENGTH) errx(1, "Invalid number bases to keep (-l %s)", optarg_);
-        trim_by_position = 1;
-        break;
-    case 't':
-        if (optarg_ == NULL) errx(1, "[-t] parameter requires an argument value");
-        trim_last_bases = (unsigned int)strtoul(optarg_, NULL, 10);
-        if (trim_last_bases <= 0 || trim_last_bases >= MAX_SEQ_LINE_LENGTH) errx(1, "Invalid number bases to trim (-t %s)", optarg_);
-        trim_from_end = 1;
-        break;
-    case 'm':
-        if (optarg_ == NULL) errx(1, "[-t] parameter requires an argument value");
-        minimum_length = (unsigned int)strtoul(optarg_, NULL, 10);
-        if (minimum_length <= 0 || minimum_length >= MAX_SEQ_LINE_LENGTH) errx(1, "Invalid minimum length value (-m %s)", optarg_);
-        break;
-    default:
-        errx(1, __FILE__ ":%d: Unknown argument (%c)", __LINE__, optc);
-    }
-    return 1;
-}
-
-int main(int argc, char *argv[])
-{
-    static FASTX fastx;
-    fxh_totals tot;
-    fxg_params p;
-    fastx_parse_cmdline(argc, argv, "l:f:t:m:", parse_program_args);
-    if (trim_by_position && trim_from_end) errx(1, "[-t], [-f] and [-l] options can not be used together. Use [-t] or [-l,-f]");
-    fastx_init_reader(&fastx, get_input_filename(), FASTA_OR_FASTQ, ALLOW_N, REQUIRE_UPPERCASE, get_fastq_ascii_quality_offset());
-    fastx_init_writer(&fastx, get_output_filename(), OUTPUT_SAME_AS_INPUT, compress_output_flag());
-    fxh_default_params(&p, get_fastq_ascii_quality_offset());
-    if (trim_from_end) {
-        p.stages = FXG_STAGE_FTRIM_END;
-        p.ft_trim_end = trim_last_bases;
-        p.ft_min_len = minimum_length;    /* -m without -t has no effect in the reference either */
-    } else {
-        p.stages = FXG_STAGE_FTRIM;
-        p.ft_first = keep_first_base;
-        p.ft_last = keep_last_base;
-    }
-    fxh_run_tool(&fastx, &p, &tot);
-    if (verbose_flag()) {
-        FILE *rf = get_report_file();
-        if (keep_first_base != 1 || keep_last_base != 0) fprintf(rf, "Trimming: base %d to %d\n", keep_first_base, keep_last_base);
-        if (trim_last_bases) {
-            fprintf(rf, "Trimming %d bases from the end of the reads\n", trim_last_bases);
-            if (minimum_length) fprintf(rf, "Discarding reads shorter than %d bases\n", minimum_length);
-        }
-        fprintf(rf, "Input: %zu reads.\n", tot.input_reads);
-        fprintf(rf, "Output: %zu reads.\n", tot.output_reads);
-    }
-    fastx_finish(&fastx);
-    return 0;
-}
+    "   -o OUTFILE  FASTA/Q output, default stdout\n\n",
+    "l:f:t:m:", options, 4, NULL, {1, 0, 0, 0, 0, 0}, NULL, FASTA_OR_FASTQ, OUTPUT_SAME_AS_INPUT, check, configure, report, 5,
+};
+int main(int argc, char *argv[]) { return fxh_tool_main(&tool, argc, argv); }

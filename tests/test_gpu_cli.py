@@ -211,7 +211,7 @@ def test_flag_errors_and_usage_on_the_gpu_build(tools):
              (["fastx_trimmer", "-f", "2", "-t", "3"], b"@r\nA\n+\nI\n"), (["fastx_trimmer", "-f", "0"], b"@r\nA\n+\nI\n"),
              (["fastx_trimmer", "-l", "25000"], b"@r\nA\n+\nI\n"), (["fastx_clipper", "-M", "0"], b"@r\nA\n+\nI\n"),
              (["fastq_masker", "-r", "xy"], b"@r\nA\n+\nI\n"), (["fastq_quality_trimmer", "-t", "20"], b""),
-             (["fastq_quality_trimmer", "-t", "20"], b">fa\nAC\n"), (["fastq_quality_trimmer", "-t", "20", "-Q", "64"], b"@r\nA\n+\nI\n")]
+             (["fastq_quality_trimmer", "-t", "20"], b">fa\nAC\n"), (["fastq_quality_trimmer", "-t", "20", "-Q", "64"], b"@r\nA\n+\n!\n")]
     for argv, data in cases:
         rc, out, err = _run([os.path.join(tools, argv[0])] + argv[1:], data)
         assert rc == 1, argv
