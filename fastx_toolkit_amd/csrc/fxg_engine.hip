@@ -538,18 +538,20 @@ static int fxg_scan_u64(fxg_ctx *c, u64 *data, u64 n, u64 *tmp)
     return FXG_OK;
 }
 
-extern "C" int fxg_fastq_index(fxg_ctx *c, const uint8_t *d_text, uint64_t text_len, int at_eof, uint32_t *d_ls, uint64_t cap_lines,
-                               uint16_t *d_len, fxg_text_info *info)
+extern "C" int fxg_fastq_index(fxg_ctx *c, const uint8_t *d_text, uint64_t text_len, int at_eof, int lines_per_record, uint32_t *d_line,
+                               uint64_t cap_lines, uint16_t *d_len, uint8_t *d_flags, fxg_text_info *info)
 {
-    if (!c || !d_text || !d_ls || !d_len || !info) return FXG_E_INVALID;
+    if (!c || !d_text || !d_line || !d_len || !d_flags || !info || (lines_per_record != 4 && lines_per_record != 2)) return FXG_E_INVALID;
     memset(info, 0, sizeof *info);
     info->first_bad = 0xFFFFFFFFu;
     if (text_len == 0) return FXG_OK;
     if (text_len > 0xFFFFFFF0ull) return fxg_fail(c, FXG_E_INVALID, "text block too large (%llu bytes)", (unsigned long long)text_len);
     FXG_HIP(c, hipSetDevice(c->device));
+    const u64 lpr = (u64)lines_per_record;
     const u64 nseg = (text_len + FXG_TEXT_SEG - 1) / FXG_TEXT_SEG;
     int rc = fxg_text_reserve(c, (size_t)(nseg + nseg / 512 + 4096));
     if (rc != FXG_OK) return rc;
+    u32 *d_ls = d_line, *d_le = d_line + cap_lines;
     FxgTextState init;
     memset(&init, 0, sizeof init);
     init.min_len = 0xFFFFFFFFu; init.first_bad = 0xFFFFFFFFu;
@@ -563,49 +565,58 @@ extern "C" int fxg_fastq_index(fxg_ctx *c, const uint8_t *d_text, uint64_t text_
     rc = fxg_scan_u64(c, seg, nseg, seg + nseg);
     if (rc != FXG_OK) return rc;
     FXG_HIP(c, hipMemcpyAsync(&last_off, seg + (nseg - 1), sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-    hipLaunchKernelGGL(fxg_kernel_nl_scatter, dim3((u32)nseg), dim3(FXG_BLOCK), 0, c->stream, d_text, (u64)text_len, (const u64 *)seg, d_ls, (u64)cap_lines);
+    hipLaunchKernelGGL(fxg_kernel_nl_scatter, dim3((u32)nseg), dim3(FXG_BLOCK), 0, c->stream, d_text, (u64)text_len, (const u64 *)seg, d_ls, d_le, (u64)cap_lines);
     FXG_HIP(c, hipGetLastError());
     FXG_HIP(c, hipStreamSynchronize(c->stream));
     const u64 lines = last_off + last_count;
     info->lines = lines;
-    u64 n = lines / 4;
-    if (4 * n + 1 > cap_lines) n = (cap_lines - 1) / 4;
+    u64 n = lines / lpr;
+    if (lpr * n + 1 > cap_lines) n = (cap_lines - 1) / lpr;
     info->records = n;
-    if (n == 0) { if (at_eof && lines % 4 != 0) info->irregular |= FXG_TEXT_IRR_TAIL; return FXG_OK; }
-    hipLaunchKernelGGL(fxg_kernel_text_records, dim3((u32)((n + FXG_BLOCK - 1) / FXG_BLOCK)), dim3(FXG_BLOCK), 0, c->stream, d_text, (const u32 *)d_ls, n, d_len,
-                       c->text_state);
+    if (n == 0) { if (at_eof && lines % lpr != 0) info->irregular |= FXG_TEXT_IRR_TAIL; return FXG_OK; }
+    const u32 grid = (u32)((n + FXG_BLOCK - 1) / FXG_BLOCK);
+    if (lines_per_record == 4) hipLaunchKernelGGL(fxg_kernel_text_records<4>, dim3(grid), dim3(FXG_BLOCK), 0, c->stream, d_text, (const u32 *)d_ls, d_le, n, d_len, d_flags, c->text_state);
+    else hipLaunchKernelGGL(fxg_kernel_text_records<2>, dim3(grid), dim3(FXG_BLOCK), 0, c->stream, d_text, (const u32 *)d_ls, d_le, n, d_len, d_flags, c->text_state);
     FXG_HIP(c, hipGetLastError());
     FxgTextState st;
     u32 consumed = 0;
     FXG_HIP(c, hipMemcpyAsync(&st, c->text_state, sizeof st, hipMemcpyDeviceToHost, c->stream));
-    FXG_HIP(c, hipMemcpyAsync(&consumed, d_ls + 4 * n, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    FXG_HIP(c, hipMemcpyAsync(&consumed, d_ls + lpr * n, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     FXG_HIP(c, hipStreamSynchronize(c->stream));
     info->consumed = consumed;
     info->max_len = st.max_len; info->min_len = st.min_len;
-    info->irregular = st.irregular | (st.has_cr ? FXG_TEXT_IRR_CR : 0u);
+    info->irregular = st.irregular;
     info->first_bad = st.first_bad;
-    if (at_eof && (lines % 4 != 0 || consumed != text_len)) info->irregular |= FXG_TEXT_IRR_TAIL;
+    info->numeric_records = st.n_numeric;
+    info->has_cr = st.has_cr;
+    if (at_eof && (lines % lpr != 0 || consumed != text_len)) info->irregular |= FXG_TEXT_IRR_TAIL;
     return FXG_OK;
 }
 
-extern "C" int fxg_fastq_pack(fxg_ctx *c, const uint8_t *d_text, uint64_t text_len, const uint32_t *d_ls, uint64_t n, uint32_t stride,
-                              int qoffset, uint8_t *d_bases, uint8_t *d_qual, uint32_t *irregular)
+extern "C" int fxg_fastq_pack(fxg_ctx *c, const uint8_t *d_text, uint64_t text_len, int lines_per_record, const uint32_t *d_line, uint64_t cap_lines,
+                              const uint8_t *d_flags, uint64_t n, uint32_t stride, int qoffset, uint8_t *d_bases, uint8_t *d_qual, uint32_t *irregular)
 {
-    if (!c || !d_text || !d_ls || !d_bases || !irregular || stride == 0) return FXG_E_INVALID;
+    if (!c || !d_text || !d_line || !d_flags || !d_bases || !irregular || stride == 0 || (lines_per_record != 4 && lines_per_record != 2)) return FXG_E_INVALID;
     *irregular = 0;
     if (n == 0) return FXG_OK;
     if ((((uintptr_t)d_bases | (uintptr_t)d_qual) & 15u) != 0) return fxg_fail(c, FXG_E_INVALID, "row arrays must be 16-byte aligned");
+    if (lines_per_record == 2 && d_qual) return fxg_fail(c, FXG_E_INVALID, "FASTA records have no qualities");
     FXG_HIP(c, hipSetDevice(c->device));
+    const u32 *d_ls = d_line, *d_le = d_line + cap_lines;
     const u64 nchunks = (n * (u64)stride + 15) >> 4;
     u64 grid = (nchunks + FXG_BLOCK - 1) / FXG_BLOCK;
     if (grid > 65536) grid = 65536;
     FXG_HIP(c, hipMemsetAsync(&c->text_state->irregular, 0, sizeof(u32), c->stream));
-    hipLaunchKernelGGL(fxg_kernel_text_pack<false>, dim3((u32)grid), dim3(FXG_BLOCK), 0, c->stream, d_text, (u64)text_len, (const u32 *)d_ls, (u64)n, stride,
-                       qoffset, d_bases, c->text_state);
+    if (lines_per_record == 4)
+        hipLaunchKernelGGL((fxg_kernel_text_pack<false, 4>), dim3((u32)grid), dim3(FXG_BLOCK), 0, c->stream, d_text, (u64)text_len, d_ls, d_le, d_flags, (u64)n, stride, qoffset, d_bases, c->text_state);
+    else
+        hipLaunchKernelGGL((fxg_kernel_text_pack<false, 2>), dim3((u32)grid), dim3(FXG_BLOCK), 0, c->stream, d_text, (u64)text_len, d_ls, d_le, d_flags, (u64)n, stride, qoffset, d_bases, c->text_state);
     FXG_HIP(c, hipGetLastError());
     if (d_qual) {
-        hipLaunchKernelGGL(fxg_kernel_text_pack<true>, dim3((u32)grid), dim3(FXG_BLOCK), 0, c->stream, d_text, (u64)text_len, (const u32 *)d_ls, (u64)n, stride,
-                           qoffset, d_qual, c->text_state);
+        hipLaunchKernelGGL((fxg_kernel_text_pack<true, 4>), dim3((u32)grid), dim3(FXG_BLOCK), 0, c->stream, d_text, (u64)text_len, d_ls, d_le, d_flags, (u64)n, stride, qoffset, d_qual, c->text_state);
+        FXG_HIP(c, hipGetLastError());
+        // records with numeric quality lines (rare: one pass over the flags, the parse itself only where a flag is set)
+        hipLaunchKernelGGL(fxg_kernel_text_numeric, dim3((u32)((n + FXG_BLOCK - 1) / FXG_BLOCK)), dim3(FXG_BLOCK), 0, c->stream, d_text, d_ls, d_le, d_flags, (u64)n, stride, d_qual);
         FXG_HIP(c, hipGetLastError());
     }
     FXG_HIP(c, hipMemcpyAsync(irregular, &c->text_state->irregular, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
@@ -613,31 +624,56 @@ extern "C" int fxg_fastq_pack(fxg_ctx *c, const uint8_t *d_text, uint64_t text_l
     return FXG_OK;
 }
 
-extern "C" int fxg_fastq_format(fxg_ctx *c, const uint8_t *d_text, const uint32_t *d_ls, uint64_t n, const uint32_t *d_res, uint32_t fwd_start,
-                                const uint8_t *d_pk_bases, const uint8_t *d_pk_qual, const uint64_t *d_pk_off, int qoffset, uint8_t *d_out,
+extern "C" int fxg_fastq_format(fxg_ctx *c, const uint8_t *d_text, int lines_per_record, const uint32_t *d_line, uint64_t cap_lines, const uint8_t *d_flags,
+                                uint64_t n, const uint32_t *d_res, uint32_t fwd_start, int reverse, const uint8_t *d_pk_bases, const uint8_t *d_pk_qual,
+                                const uint64_t *d_pk_off, const uint8_t *d_rows_qual, uint32_t stride, int qoffset, int out_fasta, uint8_t *d_out,
                                 uint64_t *out_bytes)
 {
-    if (!c || !d_text || !d_ls || !d_res || !d_out || !out_bytes) return FXG_E_INVALID;
+    if (!c || !d_text || !d_line || !d_flags || !d_res || !d_out || !out_bytes || (lines_per_record != 4 && lines_per_record != 2)) return FXG_E_INVALID;
     *out_bytes = 0;
     if (n == 0) return FXG_OK;
-    if (d_pk_bases && (!d_pk_qual || !d_pk_off)) return fxg_fail(c, FXG_E_INVALID, "packed output needs bases, qual and out_off");
+    const bool fastq_out = lines_per_record == 4 && !out_fasta;
+    if (d_pk_bases && (!d_pk_off || (fastq_out && !d_pk_qual))) return fxg_fail(c, FXG_E_INVALID, "packed output needs bases, out_off and (FASTQ) qual");
+    if (fastq_out && !d_rows_qual) return fxg_fail(c, FXG_E_INVALID, "FASTQ output needs the batch's quality rows (numeric records are printed from them)");
     FXG_HIP(c, hipSetDevice(c->device));
     int rc = fxg_text_reserve(c, (size_t)(n + n / 512 + 4096));
     if (rc != FXG_OK) return rc;
     u64 *item = c->text_ws;
+    FxgFormatArgs a;
+    a.text = d_text; a.ls = d_line; a.le = d_line + cap_lines; a.res = d_res; a.flags = d_flags; a.item_scan = item; a.n = n;
+    a.fwd_start = fwd_start; a.rev = reverse ? 1u : 0u; a.pk_bases = d_pk_bases; a.pk_qual = d_pk_qual; a.pk_off = (const u64 *)d_pk_off;
+    a.rows_qual = d_rows_qual; a.stride = stride; a.qoffset = qoffset; a.out_fasta = out_fasta ? 1u : 0u; a.out = d_out;
     const u32 nb = (u32)((n + FXG_BLOCK - 1) / FXG_BLOCK);
-    hipLaunchKernelGGL(fxg_kernel_text_sizes, dim3(nb), dim3(FXG_BLOCK), 0, c->stream, (const u32 *)d_ls, (const u32 *)d_res, (u64)n, item);
+    if (lines_per_record == 4) hipLaunchKernelGGL(fxg_kernel_text_sizes<4>, dim3(nb), dim3(FXG_BLOCK), 0, c->stream, a, item);
+    else hipLaunchKernelGGL(fxg_kernel_text_sizes<2>, dim3(nb), dim3(FXG_BLOCK), 0, c->stream, a, item);
     FXG_HIP(c, hipGetLastError());
     u64 last_item = 0, last_scan = 0;
     FXG_HIP(c, hipMemcpyAsync(&last_item, item + (n - 1), sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     rc = fxg_scan_u64(c, item, n, item + n);
     if (rc != FXG_OK) return rc;
     FXG_HIP(c, hipMemcpyAsync(&last_scan, item + (n - 1), sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-    hipLaunchKernelGGL(fxg_kernel_text_format, dim3((u32)((n * 16 + FXG_BLOCK - 1) / FXG_BLOCK)), dim3(FXG_BLOCK), 0, c->stream, d_text, (const u32 *)d_ls,
-                       (const u32 *)d_res, (const u64 *)item, (u64)n, fwd_start, d_pk_bases, d_pk_qual, (const u64 *)d_pk_off, qoffset, d_out);
+    const u32 fgrid = (u32)((n * 16 + FXG_BLOCK - 1) / FXG_BLOCK);
+    if (lines_per_record == 4) hipLaunchKernelGGL(fxg_kernel_text_format<4>, dim3(fgrid), dim3(FXG_BLOCK), 0, c->stream, a);
+    else hipLaunchKernelGGL(fxg_kernel_text_format<2>, dim3(fgrid), dim3(FXG_BLOCK), 0, c->stream, a);
     FXG_HIP(c, hipGetLastError());
     FXG_HIP(c, hipStreamSynchronize(c->stream));
     *out_bytes = ((last_scan + last_item) & ((1ull << 40) - 1ull));
+    return FXG_OK;
+}
+
+extern "C" int fxg_fasta_weights(fxg_ctx *c, const uint8_t *d_text, const uint32_t *d_line, uint64_t cap_lines, uint64_t n, const uint32_t *d_res,
+                                 uint64_t weighted[8])
+{
+    if (!c || !d_text || !d_line || !d_res || !weighted) return FXG_E_INVALID;
+    memset(weighted, 0, 8 * sizeof(uint64_t));
+    if (n == 0) return FXG_OK;
+    FXG_HIP(c, hipSetDevice(c->device));
+    if (!c->text_state) return fxg_fail(c, FXG_E_INVALID, "fxg_fasta_weights: index the block first");
+    FXG_HIP(c, hipMemsetAsync(c->text_state->weighted, 0, sizeof c->text_state->weighted, c->stream));
+    hipLaunchKernelGGL(fxg_kernel_text_weights, dim3((u32)((n + FXG_BLOCK - 1) / FXG_BLOCK)), dim3(FXG_BLOCK), 0, c->stream, d_text, d_line, d_line + cap_lines, d_res, (u64)n, c->text_state);
+    FXG_HIP(c, hipGetLastError());
+    FXG_HIP(c, hipMemcpyAsync(weighted, c->text_state->weighted, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    FXG_HIP(c, hipStreamSynchronize(c->stream));
     return FXG_OK;
 }
 

@@ -1,23 +1,29 @@
-// fxg_text.h -- FASTQ text <-> Structure-of-Arrays on the device.
+// fxg_text.h -- FASTA/FASTQ text <-> Structure-of-Arrays on the device.
 //
-// Replaces, for the regular case, the reference's record reader (src/libfastx/fastx.c:314-404) and writer
-// (:440-473): a block of FASTQ text already resident in HBM is indexed (newline positions by ballot/popcount +
-// prefix sums), checked, packed into the engine's SoA batch, and after the pipeline the kept records are
-// formatted back to text on the device.  "Regular" = LF line ends, four lines per record, '@' prefix, upper-case
-// ACGTN bases, as many quality characters as bases, qualities inside -15..93 after subtracting -Q.  Anything else
-// (CR bytes, numeric qualities, FASTA, malformed records) is only DETECTED here (info.irregular); the caller then
-// runs that block through the host parser, which owns the reference's exact error messages and corner cases.
+// Replaces the reference's record reader (src/libfastx/fastx.c:314-404) and writer (:440-473): a block of text already
+// resident in HBM is indexed (newline positions by SWAR compare/popcount + prefix sums), checked record by record, packed into
+// the engine's SoA batch, and after the pipeline the kept records are formatted back to text on the device.  Handled here:
+//   * FASTQ (four lines per record, '@') and FASTA (two lines, '>'), fastx.c:86-116;
+//   * line ends: every line is cut at its first CR or LF like chomp() does (chomp.c:36-41), so CRLF input gives LF output;
+//   * quality lines: as many characters as bases = ASCII; otherwise whitespace-separated integers parsed with strtol()'s
+//     rules (fastx.c:137-167), per record; kept records are written in the encoding they came in (fastx.c:393-395);
+//   * collapsed FASTA identifiers (">id-count", fastx.c:475-495): every record's read count, for the -v reports.
+// Anything malformed (wrong prefix, empty or over-long line, bad base or quality, wrong number of values) is only DETECTED
+// (info.irregular); the caller then runs that block through the host parser, which owns the reference's exact messages.
 #pragma once
 #include "fxg_device.h"
 
 #define FXG_TEXT_SEG 4096u            // bytes of text per workgroup in the newline passes (256 lanes x 16 B)
+#define FXG_REC_NUMERIC 1u            // per-record flag: the quality line holds numbers, not characters
 
 struct FxgTextState {                 // device-resident scalars of one block of text
     u32 has_cr;                       // any '\r' byte
     u32 max_len, min_len;
     u32 irregular;                    // FXG_TEXT_IRR_* bits
     u32 first_bad;                    // smallest irregular record index
-    u32 pad[3];
+    u32 n_numeric;                    // records with numeric quality lines
+    u32 pad[2];
+    u64 weighted[8];                  // fxg_kernel_text_weights: read-count weighted tallies (FASTA with collapsed ids)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -113,8 +119,8 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_nl_count(const uint8_t *
     if (threadIdx.x == 0) seg_count[blockIdx.x] = (u64)wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// pass 2: line_start[j + 1] = position after the j-th newline (seg_off = exclusive scan of seg_count)
-__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_nl_scatter(const uint8_t *text, u64 text_len, const u64 *seg_off, u32 *line_start, u64 cap_lines)
+// pass 2: line_end[j] = position of the j-th newline, line_start[j + 1] = the byte after it (seg_off = exclusive scan of seg_count)
+__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_nl_scatter(const uint8_t *text, u64 text_len, const u64 *seg_off, u32 *line_start, u32 *line_end, u64 cap_lines)
 {
     __shared__ u32 wsum[FXG_WAVES];
     const u64 off = (u64)blockIdx.x * FXG_TEXT_SEG + (u64)threadIdx.x * 16;
@@ -135,25 +141,80 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_nl_scatter(const uint8_t
     while (m) {
         const u32 b = (u32)__builtin_ctz(m);
         m &= m - 1u;
-        if (j + 1 < cap_lines) line_start[j + 1] = (u32)(off + b + 1);
+        if (j + 1 < cap_lines) { line_start[j + 1] = (u32)(off + b + 1); line_end[j] = (u32)(off + b); }
         ++j;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// per-record checks on the line index; writes len[] and the batch extrema
+// per-record checks on the line index; chomp; quality-line encoding; writes len[], flags[] and the batch extrema
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_records(const uint8_t *text, const u32 *ls, u64 n, uint16_t *len, FxgTextState *st)
+// first '\r' in text[s, e), or e
+__device__ __forceinline__ u32 fxg_first_cr(const uint8_t *text, u32 s, u32 e)
+{
+    for (u32 p = s; p < e; p += 16u) {
+        u32 m = fxg_eq_mask16(fxg_ld16(text + p), '\r');
+        if (e - p < 16u) m &= (1u << (e - p)) - 1u;
+        if (m) return p + (u32)__builtin_ctz(m);
+    }
+    return e;
+}
+
+// Numeric quality line text[s, e) with the reference's token rules (fastx.c:137-167): strtol() on the rest of the line until the
+// rest is empty -- leading isspace() bytes, one optional sign, digits; the long lands in an int.  Returns the number of values, or
+// -1 if a token is not a number or a value lies outside -15..93.  out (optional) receives value + 33 for the first cap values.
+__device__ __forceinline__ int fxg_parse_numeric(const uint8_t *text, u32 s, u32 e, uint8_t *out, u32 cap)
+{
+    u32 p = s;
+    int cnt = 0;
+    do {
+        while (p < e && (text[p] == ' ' || (text[p] >= '\t' && text[p] <= '\r'))) ++p;
+        bool neg = false;
+        if (p < e && (text[p] == '-' || text[p] == '+')) { neg = (text[p] == '-'); ++p; }
+        const u32 d0 = p;
+        u64 mag = 0;
+        bool sat = false;
+        for (; p < e && text[p] >= '0' && text[p] <= '9'; ++p) {
+            if (mag > (0x7FFFFFFFFFFFFFFFull - 9ull) / 10ull) sat = true; else mag = mag * 10ull + (u64)(text[p] - '0');
+        }
+        if (p == d0) return -1;
+        const long long lv = sat ? (neg ? (-0x7FFFFFFFFFFFFFFFll - 1ll) : 0x7FFFFFFFFFFFFFFFll) : (neg ? -(long long)mag : (long long)mag);
+        const int v = (int)lv;
+        if (v > 93 || v < -15) return -1;
+        if (out && (u32)cnt < cap) out[cnt] = (uint8_t)(v + 33);
+        ++cnt;
+    } while (p < e);
+    return cnt;
+}
+
+// LPR: lines per record (4 FASTQ, 2 FASTA)
+template <int LPR>
+__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_records(const uint8_t *text, const u32 *ls, u32 *le, u64 n, uint16_t *len, uint8_t *flags, FxgTextState *st)
 {
     const u64 r = (u64)blockIdx.x * FXG_BLOCK + threadIdx.x;
     u32 irr = 0, sl = 0;
     if (r < n) {
-        const u32 o0 = ls[4 * r], o1 = ls[4 * r + 1], o2 = ls[4 * r + 2], o3 = ls[4 * r + 3], o4 = ls[4 * r + 4];
-        sl = o2 - o1 - 1u;
-        const u32 ql = o4 - o3 - 1u;
-        if (text[o0] != '@') irr |= FXG_TEXT_IRR_PREFIX;
-        if (sl == 0u || sl >= 24998u) irr |= FXG_TEXT_IRR_SEQLEN;
-        if (ql != sl) irr |= FXG_TEXT_IRR_QUALLEN;
+        const u64 b = (u64)LPR * r;
+        u32 s[LPR], e[LPR];
+#pragma unroll
+        for (int k = 0; k < LPR; ++k) { s[k] = ls[b + k]; e[k] = le[b + k]; }
+        if (st->has_cr) {                                        // chomp: a line ends at its first CR (chomp.c:36-41)
+#pragma unroll
+            for (int k = 0; k < LPR; ++k) { e[k] = fxg_first_cr(text, s[k], e[k]); le[b + k] = e[k]; }
+        }
+        sl = e[1] - s[1];
+        if (s[0] == e[0] || text[s[0]] != (LPR == 4 ? '@' : '>')) irr |= FXG_TEXT_IRR_PREFIX;      // (an empty first line has no prefix either)
+        if (sl == 0u || sl >= 24998u || e[0] - s[0] >= 24999u) irr |= FXG_TEXT_IRR_SEQLEN;
+        u32 fl = 0;
+        if (LPR == 4) {
+            const u32 ql = e[3] - s[3];
+            if (e[2] - s[2] >= 24999u) irr |= FXG_TEXT_IRR_SEQLEN;
+            if (ql != sl && !irr) {                                // R6: not one character per base -> numbers
+                if (fxg_parse_numeric(text, s[3], e[3], nullptr, 0u) == (int)sl) { fl = FXG_REC_NUMERIC; atomicAdd(&st->n_numeric, 1u); }
+                else irr |= FXG_TEXT_IRR_QUALLEN;
+            }
+        }
+        flags[r] = (uint8_t)fl;
         len[r] = (uint16_t)(sl > 65535u ? 65535u : sl);
         if (irr) { atomicOr(&st->irregular, irr); atomicMin(&st->first_bad, (u32)r); }
     }
@@ -175,9 +236,10 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_records(const uint8
 // text -> SoA rows.  One lane owns one 16-byte aligned chunk of the row array and assembles it from the
 // sequence (or quality) lines of the records that intersect it; bytes past a read's length are zero.
 // Qualities are normalised to Phred+33 codes (byte - (Q - 33)) and range-checked; bases are alphabet-checked.
+// Records with numeric quality lines are left zero here and filled by fxg_kernel_text_numeric.
 // ---------------------------------------------------------------------------------------------------------
-template <bool QUAL>
-__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_pack(const uint8_t *text, u64 text_len, const u32 *ls, u64 n, u32 stride,
+template <bool QUAL, int LPR>
+__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_pack(const uint8_t *text, u64 text_len, const u32 *ls, const u32 *le, const uint8_t *flags, u64 n, u32 stride,
                                                                   int qoffset, uint8_t *rows, FxgTextState *st)
 {
     const u64 total = n * (u64)stride;
@@ -194,8 +256,9 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_pack(const uint8_t 
         u32x4 acc = {0u, 0u, 0u, 0u};
         int filled = 0;
         while (filled < 16 && r < n) {
-            const u32 o = QUAL ? ls[4 * r + 3] : ls[4 * r + 1];
-            const u32 rl = ls[4 * r + 2] - ls[4 * r + 1] - 1u;
+            const u64 lb = (u64)LPR * r;
+            const u32 o = QUAL ? ls[lb + 3] : ls[lb + 1];
+            const u32 rl = (QUAL && (flags[r] & FXG_REC_NUMERIC)) ? 0u : le[lb + 1] - ls[lb + 1];
             const int take_row = (int)(stride - pos) < 16 - filled ? (int)(stride - pos) : 16 - filled;    // bytes of this row in the chunk
             const int have = pos < rl ? ((int)(rl - pos) < take_row ? (int)(rl - pos) : take_row) : 0;    // of which real data
             if (have > 0) {
@@ -246,22 +309,101 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_pack(const uint8_t 
     if (bad) atomicOr(&st->irregular, QUAL ? FXG_TEXT_IRR_QUAL : FXG_TEXT_IRR_BASE);
 }
 
+// quality rows of the records whose quality line is numeric (after fxg_kernel_text_pack<true> left them zero)
+__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_numeric(const uint8_t *text, const u32 *ls, const u32 *le, const uint8_t *flags, u64 n, u32 stride, uint8_t *rows)
+{
+    const u64 r = (u64)blockIdx.x * FXG_BLOCK + threadIdx.x;
+    if (r >= n || !(flags[r] & FXG_REC_NUMERIC)) return;
+    (void)fxg_parse_numeric(text, ls[4 * r + 3], le[4 * r + 3], rows + r * (u64)stride, stride);
+}
+
+// read count of a FASTA record: the number after the first '-' of its identifier, 1 if there is none (fastx.c:475-495)
+__device__ __forceinline__ u32 fxg_reads_count(const uint8_t *text, u32 s, u32 e)
+{
+    u32 p = s;
+    while (p < e && text[p] != '-') ++p;
+    if (p >= e) return 1u;
+    ++p;
+    while (p < e && (text[p] == ' ' || (text[p] >= '\t' && text[p] <= '\r'))) ++p;     // atoi skips blanks and takes one sign
+    bool neg = false;
+    if (p < e && (text[p] == '-' || text[p] == '+')) { neg = (text[p] == '-'); ++p; }
+    u64 v = 0;
+    for (u32 k = 0; p < e && text[p] >= '0' && text[p] <= '9' && k < 23u; ++p, ++k) v = v * 10u + (u64)(text[p] - '0');
+    const int c = neg ? -(int)(u32)v : (int)(u32)v;
+    return c > 0 ? (u32)c : 1u;
+}
+
+// -v report tallies weighted by read count (FASTA input): [0] input reads, [1] output reads, then the clipper's five reasons
+__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_weights(const uint8_t *text, const u32 *ls, const u32 *le, const u32 *res, u64 n, FxgTextState *st)
+{
+    const u64 r = (u64)blockIdx.x * FXG_BLOCK + threadIdx.x;
+    u64 v[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (r < n) {
+        const u64 w = fxg_reads_count(text, ls[2 * r] + 1u, le[2 * r]);
+        const u32 x = res[r], why = (x >> 17) & 0xFu;
+        v[0] = w;
+        if ((x >> 16) & 1u) v[1] = w;
+        if (why == FXG_R_CLIP_TOO_SHORT) v[2] = w;
+        if ((x >> FXG_RES_ADAPTER_ONLY_BIT) & 1u) v[3] = w;
+        if (why == FXG_R_CLIP_NO_ADAPTER) v[4] = w;
+        if (why == FXG_R_CLIP_ADAPTER_FOUND) v[5] = w;
+        if (why == FXG_R_CLIP_N) v[6] = w;
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        u64 x = v[i];
+        for (int d = 32; d >= 1; d >>= 1) x += ((u64)__shfl_xor((u32)(x >> 32), d, 64) << 32) | __shfl_xor((u32)x, d, 64);
+        if (fxg_lane() == 0 && x) atomicAdd(&st->weighted[i], x);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // formatting: sizes -> (scan on the host side of this header) -> copy
 // ---------------------------------------------------------------------------------------------------------
+struct FxgFormatArgs {
+    const uint8_t *text;
+    const u32 *ls, *le, *res;
+    const uint8_t *flags;
+    const u64 *item_scan;
+    u64 n;
+    u32 fwd_start;                    // first kept base of forward outputs (fastx_trimmer -f)
+    u32 rev;                          // packed outputs are reverse-complemented: their qualities are those of input positions [rl - fwd_start - len, rl - fwd_start)
+    const uint8_t *pk_bases, *pk_qual; const u64 *pk_off;    // packed (reverse-complemented / masked) outputs, or null
+    const uint8_t *rows_qual; u32 stride;                   // the batch's quality rows (Phred+33 codes): numeric output of forward records
+    int qoffset;
+    u32 out_fasta;                    // write FASTA whatever the input was (fastq_to_fasta)
+    uint8_t *out;
+};
+
+__device__ __forceinline__ u32 fxg_num_width(int v) { return (v < 0 ? 1u : 0u) + ((v <= -10 || v >= 10) ? 2u : 1u); }     // -15..93
+
 // item r = output bytes of record r in the low 40 bits, keep flag above (the scan then yields offset and rank)
-__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_sizes(const u32 *ls, const u32 *res, u64 n, u64 *item)
+template <int LPR>
+__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_sizes(const FxgFormatArgs a, u64 *item)
 {
     const u64 r = (u64)blockIdx.x * FXG_BLOCK + threadIdx.x;
-    if (r >= n) return;
-    const u32 w = res[r];
+    if (r >= a.n) return;
+    const u32 w = a.res[r];
     u64 v = 0;
     if ((w >> 16) & 1u) {
-        const u32 name_len = ls[4 * r + 1] - ls[4 * r] - 2u;                       // without '@' and '\n'
-        const u32 l2 = ls[4 * r + 3] - ls[4 * r + 2] - 1u;                          // line 3 without '\n'
-        const u32 name2_len = l2 ? l2 - 1u : 0u;                                    // first byte dropped (R5)
+        const u64 b = (u64)LPR * r;
+        const u32 name_len = a.le[b] - a.ls[b] - 1u;                                // without the prefix character
         const u32 len = w & 0xFFFFu;
-        v = (u64)(name_len + name2_len + 2u * len + 6u) | (1ull << 40);
+        u64 bytes = (u64)name_len + len + 3u;                                       // prefix, name, LF, bases, LF
+        if (LPR == 4 && !a.out_fasta) {
+            const u32 l2 = a.le[b + 2] - a.ls[b + 2];
+            const u32 name2_len = l2 ? l2 - 1u : 0u;                                // first byte dropped (R5)
+            u32 qbytes = len;
+            if (a.flags[r] & FXG_REC_NUMERIC) {                                     // "%d" joined by blanks: only the digit counts depend on the values
+                const u32 rl = a.le[b + 1] - a.ls[b + 1];
+                const u32 q0 = a.rev ? rl - a.fwd_start - len : (a.pk_bases ? 0u : a.fwd_start);
+                const uint8_t *q = a.rows_qual + r * (u64)a.stride + q0;
+                qbytes = len ? len - 1u : 0u;
+                for (u32 i = 0; i < len; ++i) qbytes += fxg_num_width((int)q[i] - 33);
+            }
+            bytes += (u64)name2_len + qbytes + 3u;                                  // '+', name2, LF, qualities, LF
+        }
+        v = bytes | (1ull << 40);
     }
     item[r] = v;
 }
@@ -280,35 +422,51 @@ __device__ __forceinline__ void fxg_copy_bytes(uint8_t *dst, const uint8_t *src,
     for (u32 i = (full << 4) + l; i < n; i += lanes) dst[i] = (uint8_t)((int)src[i] + add);
 }
 
-// 16 lanes format one kept record: "@name\nSEQ\n+name2\nQUAL\n".
-//   fwd_start : first kept base for forward outputs (fastx_trimmer -f)          packed : reverse-complement outputs come
-//   from the engine's packed arrays at pk_off[rank] and hold Phred+33 codes; otherwise bases/quals are prefixes of the text.
-__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_format(const uint8_t *text, const u32 *ls, const u32 *res, const u64 *item_scan, u64 n,
-                                                                    u32 fwd_start, const uint8_t *pk_bases, const uint8_t *pk_qual, const u64 *pk_off,
-                                                                    int qoffset, uint8_t *out)
+// 16 lanes format one kept record: "@name\nSEQ\n+name2\nQUAL\n" (FASTQ) or ">name\nSEQ\n" (FASTA).
+// Forward outputs are slices of the input lines; reverse-complemented / masked outputs come from the engine's packed arrays at
+// pk_off[rank] and hold Phred+33 codes.  Numeric quality lines are printed from the codes by one lane.
+template <int LPR>
+__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_format(const FxgFormatArgs a)
 {
     const u32 l = threadIdx.x & 15u;
     const u64 r = ((u64)blockIdx.x * FXG_BLOCK + threadIdx.x) >> 4;
-    if (r >= n) return;
-    const u32 w = res[r];
+    if (r >= a.n) return;
+    const u32 w = a.res[r];
     if (!((w >> 16) & 1u)) return;
-    const u64 sc = item_scan[r];
+    const u64 sc = a.item_scan[r];
     const u64 off = sc & ((1ull << 40) - 1ull), rank = sc >> 40;
-    const u32 o0 = ls[4 * r], o1 = ls[4 * r + 1], o2 = ls[4 * r + 2], o3 = ls[4 * r + 3];
-    const u32 name_len = o1 - o0 - 2u;
-    const u32 l2 = o3 - o2 - 1u, name2_len = l2 ? l2 - 1u : 0u;
+    const u64 b = (u64)LPR * r;
+    const u32 o0 = a.ls[b], o1 = a.ls[b + 1];
+    const u32 name_len = a.le[b] - o0 - 1u;
     const u32 len = w & 0xFFFFu;
-    uint8_t *d = out + off;
-    if (l == 0) { d[0] = '@'; d[1 + name_len] = '\n'; d[2 + name_len + len] = '\n'; d[3 + name_len + len] = '+';
-                  d[4 + name_len + len + name2_len] = '\n'; d[5 + name_len + 2 * len + name2_len] = '\n'; }
-    fxg_copy_bytes(d + 1, text + o0 + 1, name_len, l, 16, 0);
-    fxg_copy_bytes(d + 4 + name_len + len, text + o2 + 1, name2_len, l, 16, 0);
-    if (pk_bases) {
-        const u64 po = pk_off[rank];
-        fxg_copy_bytes(d + 2 + name_len, pk_bases + po, len, l, 16, 0);
-        fxg_copy_bytes(d + 5 + name_len + len + name2_len, pk_qual + po, len, l, 16, qoffset - 33);
-    } else {
-        fxg_copy_bytes(d + 2 + name_len, text + o1 + fwd_start, len, l, 16, 0);
-        fxg_copy_bytes(d + 5 + name_len + len + name2_len, text + o3 + fwd_start, len, l, 16, 0);    // R8: q + Q is the input byte
+    const bool fastq = (LPR == 4 && !a.out_fasta);
+    uint8_t *d = a.out + off;
+    const u64 po = a.pk_bases ? a.pk_off[rank] : 0ull;
+    if (l == 0) { d[0] = fastq ? '@' : '>'; d[1 + name_len] = '\n'; d[2 + name_len + len] = '\n'; }
+    fxg_copy_bytes(d + 1, a.text + o0 + 1, name_len, l, 16, 0);
+    if (a.pk_bases) fxg_copy_bytes(d + 2 + name_len, a.pk_bases + po, len, l, 16, 0);
+    else fxg_copy_bytes(d + 2 + name_len, a.text + o1 + a.fwd_start, len, l, 16, 0);
+    if (!fastq) return;
+    const u32 o2 = a.ls[b + 2], o3 = a.ls[b + 3];
+    const u32 l2 = a.le[b + 2] - o2, name2_len = l2 ? l2 - 1u : 0u;
+    uint8_t *q = d + 3 + name_len + len;                 // '+'
+    if (l == 0) { q[0] = '+'; q[1 + name2_len] = '\n'; }
+    fxg_copy_bytes(q + 1, a.text + o2 + 1, name2_len, l, 16, 0);
+    uint8_t *qd = q + 2 + name2_len;
+    if (!(a.flags[r] & FXG_REC_NUMERIC)) {
+        if (a.pk_bases) fxg_copy_bytes(qd, a.pk_qual + po, len, l, 16, a.qoffset - 33);
+        else fxg_copy_bytes(qd, a.text + o3 + a.fwd_start, len, l, 16, 0);    // R8: q + Q is the input byte
+        if (l == 0) qd[len] = '\n';
+    } else if (l == 0) {                                  // numbers separated by blanks, as write_ascii / numeric output does (fastx.c:421-438)
+        const uint8_t *src = a.pk_bases ? a.pk_qual + po : a.rows_qual + r * (u64)a.stride + a.fwd_start;
+        u32 k = 0;
+        for (u32 i = 0; i < len; ++i) {
+            int v = (int)src[i] - 33;
+            if (i) qd[k++] = ' ';
+            if (v < 0) { qd[k++] = '-'; v = -v; }
+            if (v >= 10) qd[k++] = (uint8_t)('0' + v / 10);
+            qd[k++] = (uint8_t)('0' + v % 10);
+        }
+        qd[k] = '\n';
     }
 }

@@ -24,7 +24,7 @@ EXPORTS = [
     "fxg_memcpy_d2h", "fxg_memset_device", "fxg_timer_start", "fxg_timer_stop", "fxg_run_pipeline",
     "fxg_run_qtrim_qfilter", "fxg_run_clip", "fxg_run_revcomp_trim", "fxg_read_counters", "fxg_synth_generate",
     "fxg_last_launch_info", "fxg_set_profiling", "fxg_last_kernel_ms", "fxg_set_clip_history", "fxg_run_quality_stats",
-    "fxg_fastq_index", "fxg_fastq_pack", "fxg_fastq_format", "fxg_host_register", "fxg_host_unregister",
+    "fxg_fastq_index", "fxg_fastq_pack", "fxg_fastq_format", "fxg_fasta_weights", "fxg_host_register", "fxg_host_unregister",
     "fxg_shard_range", "fxg_epilogue", "fxg_concat_pwrite", "fxg_device_count",
 ]
 
@@ -48,7 +48,8 @@ class FxgBatch(C.Structure):
 
 class FxgTextInfo(C.Structure):
     _fields_ = [("lines", C.c_uint64), ("records", C.c_uint64), ("consumed", C.c_uint64), ("max_len", C.c_uint32),
-                ("min_len", C.c_uint32), ("irregular", C.c_uint32), ("first_bad", C.c_uint32)]
+                ("min_len", C.c_uint32), ("irregular", C.c_uint32), ("first_bad", C.c_uint32), ("numeric_records", C.c_uint32),
+                ("has_cr", C.c_uint32)]
 
 
 class FxgOut(C.Structure):
@@ -114,9 +115,10 @@ def load_library(path=None):
     L.fxg_read_counters.argtypes = [vp, vp, C.POINTER(u64 * NCOUNTERS)]
     L.fxg_synth_generate.argtypes = [vp, u64, u64, u64, u32, i32, vp, vp, u32]
     L.fxg_last_launch_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
-    L.fxg_fastq_index.argtypes = [vp, vp, u64, i32, vp, u64, vp, C.POINTER(FxgTextInfo)]
-    L.fxg_fastq_pack.argtypes = [vp, vp, u64, vp, u64, u32, i32, vp, vp, C.POINTER(u32)]
-    L.fxg_fastq_format.argtypes = [vp, vp, vp, u64, vp, u32, vp, vp, vp, i32, vp, C.POINTER(u64)]
+    L.fxg_fastq_index.argtypes = [vp, vp, u64, i32, i32, vp, u64, vp, vp, C.POINTER(FxgTextInfo)]
+    L.fxg_fastq_pack.argtypes = [vp, vp, u64, i32, vp, u64, vp, u64, u32, i32, vp, vp, C.POINTER(u32)]
+    L.fxg_fastq_format.argtypes = [vp, vp, i32, vp, u64, vp, u64, vp, u32, i32, vp, vp, vp, vp, u32, i32, i32, vp, C.POINTER(u64)]
+    L.fxg_fasta_weights.argtypes = [vp, vp, vp, u64, u64, vp, C.POINTER(u64 * 8)]
     L.fxg_host_register.argtypes = [vp, vp, C.c_size_t]
     L.fxg_host_unregister.argtypes = [vp, vp]
     L.fxg_shard_range.argtypes = [u64, u32, u32, C.POINTER(u64), C.POINTER(u64)]
@@ -129,6 +131,21 @@ def load_library(path=None):
     if path is None:
         _LIB = L
     return L
+
+
+class TextIndex:
+    """Device line index of a block of text (fxg_fastq_index): line starts, line ends after chomp, per-record flags."""
+
+    def __init__(self, line, cap_lines, flags, lpr):
+        self.line, self.cap_lines, self.flags, self.lpr = line, cap_lines, flags, lpr
+
+    @property
+    def starts(self):
+        return self.line[:self.cap_lines]
+
+    @property
+    def ends(self):
+        return self.line[self.cap_lines:]
 
 
 class FxgError(RuntimeError):
@@ -330,33 +347,47 @@ class Engine:
         t[:len(text)] = self.torch.frombuffer(bytearray(text), dtype=self.torch.uint8).to(self.device)
         return t, len(text)
 
-    def fastq_index(self, d_text, text_len, at_eof=True, cap_records=None):
-        cap_records = cap_records or (text_len // 8 + 2)
-        ls = self.torch.empty(4 * cap_records + 1, dtype=self.torch.int32, device=self.device)
+    def fastq_index(self, d_text, text_len, at_eof=True, cap_records=None, fasta=False):
+        """Index a block of FASTQ (or two-line FASTA) text.  Returns (TextIndex, lens, info); TextIndex.starts / .ends are the
+        line starts and the line ends after chomp, TextIndex.flags the per-record flags (bit 0: numeric quality line)."""
+        lpr = 2 if fasta else 4
+        cap_records = cap_records or (text_len // (4 if fasta else 7) + 2)
+        cap_lines = lpr * cap_records + 1
+        line = self.torch.zeros(2 * cap_lines, dtype=self.torch.int32, device=self.device)
         lens = self.torch.empty(cap_records, dtype=self.torch.int16, device=self.device)
+        flags = self.torch.zeros(cap_records, dtype=self.torch.uint8, device=self.device)
         info = FxgTextInfo()
         self._after_torch()
-        self._check(self.lib.fxg_fastq_index(self.ctx, d_text.data_ptr(), text_len, int(at_eof), ls.data_ptr(), ls.numel(), lens.data_ptr(), C.byref(info)))
-        return ls, lens, info
+        self._check(self.lib.fxg_fastq_index(self.ctx, d_text.data_ptr(), text_len, int(at_eof), lpr, line.data_ptr(), cap_lines, lens.data_ptr(),
+                                             flags.data_ptr(), C.byref(info)))
+        return TextIndex(line, cap_lines, flags, lpr), lens, info
 
-    def fastq_pack(self, d_text, text_len, ls, n, stride, qoffset=33, want_qual=True):
+    def fastq_pack(self, d_text, text_len, ix, n, stride, qoffset=33, want_qual=True):
         nbytes = (n * stride + 15) // 16 * 16
+        want_qual = want_qual and ix.lpr == 4
         bases = self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.device)
         qual = self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.device) if want_qual else None
         irr = C.c_uint32()
         self._after_torch()
-        self._check(self.lib.fxg_fastq_pack(self.ctx, d_text.data_ptr(), text_len, ls.data_ptr(), n, stride, qoffset, bases.data_ptr(),
-                                            qual.data_ptr() if want_qual else None, C.byref(irr)))
+        self._check(self.lib.fxg_fastq_pack(self.ctx, d_text.data_ptr(), text_len, ix.lpr, ix.line.data_ptr(), ix.cap_lines, ix.flags.data_ptr(), n, stride,
+                                            qoffset, bases.data_ptr(), qual.data_ptr() if want_qual else None, C.byref(irr)))
         return bases[:n * stride].view(n, stride), (qual[:n * stride].view(n, stride) if want_qual else None), irr.value
 
-    def fastq_format(self, d_text, text_len, ls, n, res, fwd_start=0, packed=None, qoffset=33):
-        out = self.torch.empty(text_len + 16, dtype=self.torch.uint8, device=self.device)
+    def fastq_format(self, d_text, text_len, ix, n, res, fwd_start=0, packed=None, reverse=False, rows_qual=None, qoffset=33, out_fasta=False):
+        out = self.torch.empty(text_len + n + 16, dtype=self.torch.uint8, device=self.device)
         nb = C.c_uint64()
-        pb, pq, po = (packed[0].data_ptr(), packed[1].data_ptr(), packed[2].data_ptr()) if packed else (None, None, None)
+        pb, pq, po = (packed[0].data_ptr(), packed[1].data_ptr() if packed[1] is not None else None, packed[2].data_ptr()) if packed else (None, None, None)
         self._after_torch()
-        self._check(self.lib.fxg_fastq_format(self.ctx, d_text.data_ptr(), ls.data_ptr(), n, res.data_ptr(), fwd_start, pb, pq, po, qoffset,
-                                              out.data_ptr(), C.byref(nb)))
+        self._check(self.lib.fxg_fastq_format(self.ctx, d_text.data_ptr(), ix.lpr, ix.line.data_ptr(), ix.cap_lines, ix.flags.data_ptr(), n, res.data_ptr(),
+                                              fwd_start, int(reverse), pb, pq, po, rows_qual.data_ptr() if rows_qual is not None else None,
+                                              rows_qual.shape[1] if rows_qual is not None else 0, qoffset, int(out_fasta), out.data_ptr(), C.byref(nb)))
         return out[:nb.value]
+
+    def fasta_weights(self, d_text, ix, n, res):
+        w = (C.c_uint64 * 8)()
+        self._after_torch()
+        self._check(self.lib.fxg_fasta_weights(self.ctx, d_text.data_ptr(), ix.line.data_ptr(), ix.cap_lines, n, res.data_ptr(), C.byref(w)))
+        return list(w)
 
     def read_counters(self, d_counters):
         host = (C.c_uint64 * NCOUNTERS)()

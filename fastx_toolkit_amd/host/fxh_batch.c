@@ -42,8 +42,8 @@ typedef struct {
     uint64_t *d_counters;
     size_t d_cap_bytes, d_cap_reads;
     /* device text path (8f-1) */
-    uint8_t *d_text, *d_out_text;
-    uint32_t *d_ls;
+    uint8_t *d_text, *d_out_text, *d_flags;
+    uint32_t *d_ls;                        /* line starts [d_ls_cap] then line ends [d_ls_cap] */
     uint16_t *d_len16;
     uint64_t *d_out_off;
     size_t d_text_cap, d_ls_cap, d_off_cap;
@@ -365,6 +365,7 @@ typedef struct {
     size_t gap;                        /* min(1 MB, cap / 4) */
     char *buf; size_t cap;             /* buffer to fill: data goes to buf[gap, cap) */
     size_t filled; int eof;
+    size_t newlines;                   /* '\n' bytes among the `filled` bytes */
     int state;                         /* 0 idle, 1 requested, 2 done, 3 quit */
     int regular, io_threads;           /* regular file: parallel pread() from `offset` on */
     off_t offset;
@@ -372,7 +373,20 @@ typedef struct {
 
 /* Regular files are read with several pread() in flight (page-cache copies scale with threads; one read() stream is ~3 GB/s);
  * pipes and terminals keep the single read() loop. */
-typedef struct { int fd; char *dst; size_t n; off_t off; size_t got; } fxh_pread_job;
+static size_t fxh_count_newlines(const char *p, size_t n)
+{
+    size_t c = 0;
+    const char *e = p + n;
+    while (p < e) {
+        const char *q = (const char *)memchr(p, '\n', (size_t)(e - p));
+        if (!q) break;
+        c++;
+        p = q + 1;
+    }
+    return c;
+}
+
+typedef struct { int fd; char *dst; size_t n; off_t off; size_t got, newlines; } fxh_pread_job;
 static void *fxh_pread_main(void *arg)
 {
     fxh_pread_job *j = (fxh_pread_job *)arg;
@@ -383,6 +397,7 @@ static void *fxh_pread_main(void *arg)
         if (k == 0) break;
         j->got += (size_t)k;
     }
+    j->newlines = fxh_count_newlines(j->dst, j->got);       /* the census the record cutter needs, while the slice is cache-warm */
     return NULL;
 }
 
@@ -405,7 +420,7 @@ static void *fxh_prefetch_main(void *arg)
         if (pf->state == 3) break;
         char *buf = pf->buf; const size_t cap = pf->cap;
         pthread_mutex_unlock(&pf->mu);
-        size_t got = 0; int eof = 0;
+        size_t got = 0, newlines = (size_t)-1; int eof = 0;
         const size_t gap = pf->gap;
         if (pf->regular) {
             const size_t want = cap - gap;
@@ -423,8 +438,10 @@ static void *fxh_prefetch_main(void *arg)
             for (int i = 1; i < nt; ++i) if (pthread_create(&th[i], NULL, fxh_pread_main, &job[i]) != 0) err(1, "pthread_create");
             fxh_pread_main(&job[0]);
             for (int i = 1; i < nt; ++i) pthread_join(th[i], NULL);
-            for (int i = 0; i < nt; ++i) { got += job[i].got; if (job[i].got < job[i].n) { eof = 1; break; } }   /* a short slice is the end of the file */
+            size_t nl = 0;
+            for (int i = 0; i < nt; ++i) { got += job[i].got; nl += job[i].newlines; if (job[i].got < job[i].n) { eof = 1; break; } }   /* a short slice is the end of the file */
             pf->offset += (off_t)got;
+            newlines = nl;
         } else {
             while (gap + got < cap) {
                 ssize_t k = read(pf->fd, buf + gap + got, cap - gap - got);
@@ -433,8 +450,9 @@ static void *fxh_prefetch_main(void *arg)
                 got += (size_t)k;
             }
         }
+        if (newlines == (size_t)-1) newlines = fxh_count_newlines(buf + gap, got);
         pthread_mutex_lock(&pf->mu);
-        pf->filled = got; pf->eof = eof; pf->state = 2;
+        pf->filled = got; pf->eof = eof; pf->newlines = newlines; pf->state = 2;
         pthread_cond_broadcast(&pf->cv);
     }
     pthread_mutex_unlock(&pf->mu);
@@ -493,8 +511,9 @@ static void fxh_next_block(fxh_prefetch *pf, struct fxh_reader *rd, char **spare
 
 /* The same for the lanes loop, where the previous buffers may still be in use: the read-ahead for the FOLLOWING block goes
  * to `target` (a buffer no block in flight refers to). */
-static void fxh_next_block_ring(fxh_prefetch *pf, struct fxh_reader *rd, char *target)
+static void fxh_next_block_ring(fxh_prefetch *pf, struct fxh_reader *rd, char *target, size_t *fresh_newlines)
 {
+    *fresh_newlines = (size_t)-1;      /* unknown: the caller counts */
     if (!pf->started) {                /* first block: synchronous, then start reading ahead */
         fxh_reader_fill(rd);
         if (!rd->eof) {
@@ -512,6 +531,7 @@ static void fxh_next_block_ring(fxh_prefetch *pf, struct fxh_reader *rd, char *t
     while (pf->state != 2) pthread_cond_wait(&pf->cv, &pf->mu);
     pf->state = 0;
     char *nb = pf->buf; const size_t filled = pf->filled; const int eof = pf->eof;
+    *fresh_newlines = pf->newlines;
     pthread_mutex_unlock(&pf->mu);
     const size_t tail = rd->end - rd->beg;
     if (tail > pf->gap) errx(1, "input record longer than %zu bytes", pf->gap);
@@ -624,15 +644,25 @@ static void fxh_awriter_submit_ext(fxh_awriter *aw, struct fxh_writer *w, const 
 /* any way is only DETECTED on the device: it then goes through the host parser (fxh_host_block),    */
 /* which owns the reference's messages and corner cases, at its turn in the output order.            */
 /* ---------------------------------------------------------------------------------------------- */
+#ifndef FXH_MAX_LANES
+#define FXH_MAX_LANES 32
+#endif
+struct fxh_pinned { pthread_mutex_t mu; const void *ptr[FXH_MAX_LANES + 4]; int n; };
+
+#define FXH_MAX_LANES 32
 typedef struct fxh_lane {
     int id, device;
     pthread_t th;
     pthread_mutex_t mu;
     pthread_cond_t cv;
     int state;                             /* 0 idle, 1 job posted, 2 done, 3 quit */
+    int ready;                             /* the context exists (created by the lane's own thread, off the main thread's path) */
     fxh_state st;
+    struct fxh_pinned *pinned;             /* input buffers already page-locked (shared by the lanes) */
+    char *text_base; size_t text_cap;      /* the input buffer the job's text lives in */
     const fxg_params *p;                   /* configuration, read-only */
-    int revcomp, qoffset;
+    int revcomp, qoffset;                  /* revcomp: the output comes from the engine's packed arrays (reverse-complement, masker) */
+    int reverse, lpr, has_q, out_fasta;    /* the packed output is reversed; lines per record; qualities present; write FASTA */
     uint32_t fwd_start;
     const char *text; size_t len;          /* job: whole records, every line '\n'-terminated */
     uint64_t records;
@@ -641,6 +671,7 @@ typedef struct fxh_lane {
     int handled;                           /* result: 0 = irregular block, parse it on the host */
     char *out[2]; size_t out_cap[2]; size_t out_len;
     uint64_t ctr[FXG_NCOUNTERS];
+    uint64_t weighted[8];                  /* FASTA: tallies weighted by the records' read counts (fxg_fasta_weights) */
     double t_busy, t_init;
 } fxh_lane;
 
@@ -657,23 +688,34 @@ static void fxh_lane_run(fxh_lane *ln)
         /* the output can be longer than the input: an empty third line still gets its '+' (fastx.c:460), one byte per record */
         FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_text_cap + st->d_text_cap / 7 + 64, (void **)&st->d_out_text));
     }
-    const size_t cap_lines = len / 2 + 16;                  /* the shortest record "@\nA\n\nI\n" has 7 bytes and 4 lines */
+    const int lpr = ln->lpr;
+    const size_t cap_lines = len * 4 / 7 + 16;              /* the shortest records, "@\nA\n\nI\n" and ">\nA\n", have 1.75 / 2 bytes per line */
     if (st->d_ls_cap < cap_lines) {
-        if (st->d_ls) { fxg_free_device(st->ctx, st->d_ls); fxg_free_device(st->ctx, st->d_len16); }
+        if (st->d_ls) { fxg_free_device(st->ctx, st->d_ls); fxg_free_device(st->ctx, st->d_len16); fxg_free_device(st->ctx, st->d_flags); }
         st->d_ls_cap = cap_lines + cap_lines / 8;
-        FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_ls_cap * sizeof(uint32_t), (void **)&st->d_ls));
-        FXG_CHECK(st, fxg_malloc_device(st->ctx, (st->d_ls_cap / 4 + 4) * sizeof(uint16_t), (void **)&st->d_len16));
+        FXG_CHECK(st, fxg_malloc_device(st->ctx, 2 * st->d_ls_cap * sizeof(uint32_t), (void **)&st->d_ls));
+        FXG_CHECK(st, fxg_malloc_device(st->ctx, (st->d_ls_cap / 2 + 4) * sizeof(uint16_t), (void **)&st->d_len16));
+        FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_ls_cap / 2 + 4, (void **)&st->d_flags));
+    }
+    if (ln->pinned && ln->text_base) {     /* page-lock the input buffer on first use, so that the upload is real DMA */
+        struct fxh_pinned *pn = ln->pinned;
+        int known = 0;
+        pthread_mutex_lock(&pn->mu);
+        for (int i = 0; i < pn->n; ++i) if (pn->ptr[i] == ln->text_base) known = 1;
+        if (!known && pn->n < (int)(sizeof pn->ptr / sizeof pn->ptr[0])) { pn->ptr[pn->n++] = ln->text_base; pthread_mutex_unlock(&pn->mu); (void)fxg_host_register(st->ctx, ln->text_base, ln->text_cap); }
+        else pthread_mutex_unlock(&pn->mu);
     }
     FXG_CHECK(st, fxg_memcpy_h2d(st->ctx, st->d_text, ln->text, len));
     fxg_text_info info;
-    FXG_CHECK(st, fxg_fastq_index(st->ctx, st->d_text, len, 1, st->d_ls, st->d_ls_cap, st->d_len16, &info));
+    FXG_CHECK(st, fxg_fastq_index(st->ctx, st->d_text, len, 1, lpr, st->d_ls, st->d_ls_cap, st->d_len16, st->d_flags, &info));
     if (info.irregular || info.records == 0 || info.records != ln->records || info.consumed != len) return;
     const uint64_t n = info.records;
     const uint32_t stride = info.max_len;
     if ((uint64_t)n * stride > (uint64_t)8 * len + (1u << 20)) return;   /* ragged beyond reason: the host path handles it */
     fxh_grow_device(st, n, (size_t)n * stride + 16, revcomp);
     uint32_t irr = 0;
-    FXG_CHECK(st, fxg_fastq_pack(st->ctx, st->d_text, len, st->d_ls, n, stride, ln->qoffset, st->d_bases, st->d_qual, &irr));
+    FXG_CHECK(st, fxg_fastq_pack(st->ctx, st->d_text, len, lpr, st->d_ls, st->d_ls_cap, st->d_flags, n, stride, ln->qoffset, st->d_bases,
+                                 ln->has_q ? st->d_qual : NULL, &irr));
     if (irr) return;
     if (revcomp && st->d_off_cap < n) {
         if (st->d_out_off) fxg_free_device(st->ctx, st->d_out_off);
@@ -681,8 +723,8 @@ static void fxh_lane_run(fxh_lane *ln)
         FXG_CHECK(st, fxg_malloc_device(st->ctx, st->d_off_cap * sizeof(uint64_t), (void **)&st->d_out_off));
     }
     const int fixed = info.min_len == info.max_len;
-    fxg_batch in = {st->d_bases, st->d_qual, fixed ? NULL : st->d_len16, stride, stride, n};
-    fxg_out out = {st->d_res, revcomp ? st->d_out_bases : NULL, revcomp ? st->d_out_qual : NULL, NULL, NULL, revcomp ? st->d_out_off : NULL, st->d_counters};
+    fxg_batch in = {st->d_bases, ln->has_q ? st->d_qual : NULL, fixed ? NULL : st->d_len16, stride, stride, n};
+    fxg_out out = {st->d_res, revcomp ? st->d_out_bases : NULL, (revcomp && ln->has_q) ? st->d_out_qual : NULL, NULL, NULL, revcomp ? st->d_out_off : NULL, st->d_counters};
     fxg_params pp = *ln->p;
     pp.qoffset = 33;
     FXG_CHECK(st, fxg_run_pipeline(st->ctx, &in, &pp, &out));
@@ -691,9 +733,11 @@ static void fxh_lane_run(fxh_lane *ln)
         if (rc == FXG_E_DEVICE && (ln->ctr[FXG_C_ERRORS] & FXG_DEV_ERR_BAD_BASE)) return;   /* the host parser prints the reference's message at its turn */
         if (rc != 0) errx(1, "GPU engine error %d: %s", rc, fxg_last_error(st->ctx));
     }
+    if (lpr == 2) FXG_CHECK(st, fxg_fasta_weights(st->ctx, st->d_text, st->d_ls, st->d_ls_cap, n, st->d_res, ln->weighted));
     uint64_t out_bytes = 0;
-    FXG_CHECK(st, fxg_fastq_format(st->ctx, st->d_text, st->d_ls, n, st->d_res, revcomp ? 0u : ln->fwd_start, revcomp ? st->d_out_bases : NULL,
-                                   revcomp ? st->d_out_qual : NULL, revcomp ? st->d_out_off : NULL, ln->qoffset, st->d_out_text, &out_bytes));
+    FXG_CHECK(st, fxg_fastq_format(st->ctx, st->d_text, lpr, st->d_ls, st->d_ls_cap, st->d_flags, n, st->d_res, ln->fwd_start, ln->reverse,
+                                   revcomp ? st->d_out_bases : NULL, (revcomp && ln->has_q) ? st->d_out_qual : NULL, revcomp ? st->d_out_off : NULL,
+                                   ln->has_q ? st->d_qual : NULL, stride, ln->qoffset, ln->out_fasta, st->d_out_text, &out_bytes));
     const int s = ln->slot;
     if (ln->out_cap[s] < out_bytes + 16) {
         if (ln->out[s]) fxg_free_host(st->ctx, ln->out[s]);
@@ -709,8 +753,17 @@ static void fxh_lane_run(fxh_lane *ln)
 static void *fxh_lane_main(void *arg)
 {
     fxh_lane *ln = (fxh_lane *)arg;
-    double t0;
+    double t0 = fxh_now();
+    int rc = fxg_ctx_create(ln->device, &ln->st.ctx);
+    if (rc != 0) errx(1, "no usable MI355X/HIP device %d (fxg_ctx_create = %d); this build has no CPU path", ln->device, rc);
+    FXG_CHECK(&ln->st, fxg_malloc_device(ln->st.ctx, FXG_NCOUNTERS * sizeof(uint64_t), (void **)&ln->st.d_counters));
+    /* one fastx_clipper process = one aligner whose query buffer survives from read to read (sequence_alignment.cpp:135-136,
+     * SURVEY N3): every block of the run, host-parsed ones included, goes through this one context in input order */
+    if (ln->clip_history) FXG_CHECK(&ln->st, fxg_set_clip_history(ln->st.ctx, 1));
+    ln->t_init = fxh_now() - t0;
     pthread_mutex_lock(&ln->mu);
+    ln->ready = 1;
+    pthread_cond_broadcast(&ln->cv);
     for (;;) {
         while (ln->state != 1 && ln->state != 3) pthread_cond_wait(&ln->cv, &ln->mu);
         if (ln->state == 3) break;
@@ -726,9 +779,10 @@ static void *fxh_lane_main(void *arg)
     return NULL;
 }
 
-static void fxh_lane_post(fxh_lane *ln, const char *text, size_t len, uint64_t records, int slot)
+static void fxh_lane_post(fxh_lane *ln, char *base, size_t cap, const char *text, size_t len, uint64_t records, int slot)
 {
     pthread_mutex_lock(&ln->mu);
+    ln->text_base = base; ln->text_cap = cap;
     ln->text = text; ln->len = len; ln->records = records; ln->slot = slot; ln->state = 1;
     pthread_cond_broadcast(&ln->cv);
     pthread_mutex_unlock(&ln->mu);
@@ -1014,15 +1068,23 @@ static void fxh_host_block(fxh_run *R)
     R->t_fmt += fxh_now() - t0;
 }
 
-static void fxh_add_counters(fxh_totals *tot, const uint64_t *ctr, uint64_t n)
+static void fxh_add_counters(fxh_totals *tot, const uint64_t *ctr, uint64_t n, const uint64_t *weighted)
 {
-    /* FASTQ ids are never collapsed: every record counts as one read (fastx.c:480-481) */
-    tot->input_sequences += n; tot->input_reads += n;
-    tot->output_sequences += ctr[FXG_C_KEPT]; tot->output_reads += ctr[FXG_C_KEPT];
-    tot->clip_input += (unsigned)n;
-    tot->clip_too_short += (unsigned)ctr[FXG_C_CLIP_TOO_SHORT]; tot->clip_adapter_only += (unsigned)ctr[FXG_C_CLIP_ADAPTER_ONLY];
-    tot->clip_no_adapter += (unsigned)ctr[FXG_C_CLIP_NO_ADAPTER]; tot->clip_adapter_found += (unsigned)ctr[FXG_C_CLIP_ADAPTER_FOUND];
-    tot->clip_n += (unsigned)ctr[FXG_C_CLIP_N];
+    tot->input_sequences += n;
+    tot->output_sequences += ctr[FXG_C_KEPT];
+    if (weighted) {                        /* FASTA: a record ">id-count" stands for `count` reads (fastx.c:475-495) */
+        tot->input_reads += weighted[0]; tot->output_reads += weighted[1];
+        tot->clip_input += (unsigned)weighted[0];
+        tot->clip_too_short += (unsigned)weighted[2]; tot->clip_adapter_only += (unsigned)weighted[3];
+        tot->clip_no_adapter += (unsigned)weighted[4]; tot->clip_adapter_found += (unsigned)weighted[5];
+        tot->clip_n += (unsigned)weighted[6];
+    } else {                               /* FASTQ ids are never collapsed: every record counts as one read (fastx.c:480-481) */
+        tot->input_reads += n; tot->output_reads += ctr[FXG_C_KEPT];
+        tot->clip_input += (unsigned)n;
+        tot->clip_too_short += (unsigned)ctr[FXG_C_CLIP_TOO_SHORT]; tot->clip_adapter_only += (unsigned)ctr[FXG_C_CLIP_ADAPTER_ONLY];
+        tot->clip_no_adapter += (unsigned)ctr[FXG_C_CLIP_NO_ADAPTER]; tot->clip_adapter_found += (unsigned)ctr[FXG_C_CLIP_ADAPTER_FOUND];
+        tot->clip_n += (unsigned)ctr[FXG_C_CLIP_N];
+    }
     tot->masked_reads += ctr[FXG_C_MASKED_READS]; tot->masked_nucleotides += ctr[FXG_C_MASKED_NT];
     tot->qtrim_dropped += ctr[FXG_C_QTRIM_DROPPED];
 }
@@ -1036,14 +1098,14 @@ typedef struct fxh_block {
     int lane;                              /* -1: not given to a lane (ragged end of input, oversized record): host parser */
 } fxh_block;
 
-#define FXH_MAX_LANES 32
-
 /* The lanes loop (device text path).  Returns when the input is exhausted or an error is pending in R. */
 static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *lane_dev, double *t_read, double *t_lane_init)
 {
     FASTX *fx = R->fx;
     struct fxh_reader *rd = fx->reader;
     struct fxh_writer *wr = fx->writer;
+    static struct fxh_pinned pinned;
+    pthread_mutex_init(&pinned.mu, NULL);
     fxh_lane *lanes = (fxh_lane *)calloc((size_t)nlanes, sizeof(fxh_lane));
     const int NB = nlanes + 2;             /* input buffers: nlanes blocks in flight + the one being cut + the one being read */
     char **inbuf = (char **)calloc((size_t)NB, sizeof(char *));
@@ -1053,26 +1115,17 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
         fxh_lane *ln = &lanes[i];
         ln->id = i; ln->device = lane_dev[i]; ln->p = R->p; ln->revcomp = R->job.revcomp; ln->fwd_start = R->job.fwd_start;
         ln->qoffset = fx->fastq_ascii_quality_offset;
-        const double t0 = fxh_now();
-        int rc = fxg_ctx_create(ln->device, &ln->st.ctx);
-        if (rc != 0) errx(1, "no usable MI355X/HIP device %d (fxg_ctx_create = %d); this build has no CPU path", ln->device, rc);
-        FXG_CHECK(&ln->st, fxg_malloc_device(ln->st.ctx, FXG_NCOUNTERS * sizeof(uint64_t), (void **)&ln->st.d_counters));
-        if ((R->p->stages & FXG_STAGE_CLIP) && nlanes == 1) {
-            /* one fastx_clipper process = one aligner whose query buffer survives from read to read (sequence_alignment.cpp:135-136,
-             * SURVEY N3): every block of the run, host-parsed ones included, goes through this one context in input order */
-            FXG_CHECK(&ln->st, fxg_set_clip_history(ln->st.ctx, 1));
-            ln->clip_history = 1;
-            R->st.ctx = ln->st.ctx; R->st.d_counters = ln->st.d_counters; R->st_shared = 1;
-        }
-        ln->t_init = fxh_now() - t0;
+        ln->reverse = (R->p->stages & FXG_STAGE_REVCOMP) != 0; ln->lpr = R->job.lpr; ln->has_q = R->job.has_q; ln->out_fasta = !fx->write_fastq;
+        ln->pinned = &pinned;
+        if ((R->p->stages & FXG_STAGE_CLIP) && nlanes == 1) { ln->clip_history = 1; R->st_shared = 1; }
         pthread_mutex_init(&ln->mu, NULL); pthread_cond_init(&ln->cv, NULL);
         if (pthread_create(&ln->th, NULL, fxh_lane_main, ln) != 0) err(1, "pthread_create");
     }
     inbuf[0] = rd->buf;
-    (void)fxg_host_register(lanes[0].st.ctx, rd->buf, rd->cap + 1);
     size_t nblocks = 0, next_emit = 0;
     size_t lane_uses[FXH_MAX_LANES] = {0};
-    int input_done = 0;
+    int input_done = 0, have_carry = 0;
+    unsigned long long carry_lines = 0;
 
     while (!R->have_err) {
         /* ---- collect finished blocks in input order until a lane and an input buffer are free ---- */
@@ -1090,11 +1143,18 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
                     fxh_awriter_submit_ext(&R->aw, wr, ln->out[ln->slot], ln->out_len);
                     R->t_wait_writer += fxh_now() - tw;
                     if (!R->overlap) fxh_awriter_wait(&R->aw);
-                    fxh_add_counters(R->tot, ln->ctr, b->records);
+                    fxh_add_counters(R->tot, ln->ctr, b->records, ln->lpr == 2 ? ln->weighted : NULL);
                 }
             }
             if (!handled) {                /* this block goes through the host parser, at its place in the output order */
                 R->n_fallback++;
+                if (R->st_shared && !R->st.ctx) {          /* serial clipper run: the host parser works through lane 0's context */
+                    fxh_lane *l0 = &lanes[0];
+                    pthread_mutex_lock(&l0->mu);
+                    while (!l0->ready) pthread_cond_wait(&l0->cv, &l0->mu);
+                    pthread_mutex_unlock(&l0->mu);
+                    R->st.ctx = l0->st.ctx; R->st.d_counters = l0->st.d_counters;
+                }
                 struct fxh_reader save = *rd;
                 const unsigned long long save_line = fx->input_line_number;
                 rd->buf = b->buf; rd->beg = b->beg; rd->end = b->end; rd->eof = b->eof;
@@ -1118,16 +1178,13 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
 
         /* ---- next block of text: [unread tail of the previous block | prefetched data] ---- */
         double t0 = fxh_now();
+        size_t fresh_nl = (size_t)-1;      /* newlines in the freshly read part, when the reader threads counted them */
         {
             char *target = NULL;           /* where the read-ahead for the block after this one goes */
             const size_t nxt = (nblocks + 1) % (size_t)NB;
-            if (!inbuf[nxt]) {             /* page-locked once, so that the uploads are real DMA */
-                inbuf[nxt] = (char *)malloc(rd->cap + 1);
-                if (!inbuf[nxt]) err(1, "out of memory");
-                (void)fxg_host_register(lanes[0].st.ctx, inbuf[nxt], rd->cap + 1);
-            }
+            if (!inbuf[nxt]) { inbuf[nxt] = (char *)malloc(rd->cap + 1); if (!inbuf[nxt]) err(1, "out of memory"); }
             target = inbuf[nxt];
-            fxh_next_block_ring(pf, rd, target);
+            fxh_next_block_ring(pf, rd, target, &fresh_nl);
         }
         *t_read += fxh_now() - t0;
         if (rd->beg == rd->end && rd->eof) { input_done = 1; continue; }
@@ -1142,13 +1199,17 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
             job->w[i].a0 = rd->beg + (size_t)((unsigned long long)(end - rd->beg) * (unsigned)i / (unsigned)T);
             job->w[i].a1 = rd->beg + (size_t)((unsigned long long)(end - rd->beg) * (unsigned)(i + 1) / (unsigned)T);
         }
-        fxh_parallel(job, fxh_phase_census);
         unsigned long long lines = 0;
-        for (int i = 0; i < T; ++i) lines += job->w[i].nl_count;
-        const uint64_t records = lines / 4;
+        if (fresh_nl != (size_t)-1 && have_carry) lines = carry_lines + fresh_nl + (end > rd->end ? 1u : 0u);   /* tail of the last block + fresh data (+ the appended '\n') */
+        else {
+            fxh_parallel(job, fxh_phase_census);
+            for (int i = 0; i < T; ++i) lines += job->w[i].nl_count;
+        }
+        const unsigned lpr = (unsigned)job->lpr;
+        const uint64_t records = lines / lpr;
         size_t cut = end;
-        if (!rd->eof || lines % 4 != 0) {  /* drop the incomplete last line and the lines of the incomplete record in front of it */
-            unsigned drop = (unsigned)(lines % 4);
+        if (!rd->eof || lines % lpr != 0) {  /* drop the incomplete last line and the lines of the incomplete record in front of it */
+            unsigned drop = (unsigned)(lines % lpr);
             const char *q = (const char *)memrchr(rd->buf + rd->beg, '\n', end - rd->beg);
             cut = q ? (size_t)(q - rd->buf) + 1 : rd->beg;
             while (drop-- && cut > rd->beg) {
@@ -1159,7 +1220,7 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
         R->t_index += fxh_now() - t0;
         fxh_block *b = &blk[nblocks % (size_t)NB];
         b->buf = rd->buf; b->beg = rd->beg; b->line0 = fx->input_line_number; b->records = records; b->lane = -1;
-        if (rd->eof && (lines % 4 != 0 || records == 0)) {
+        if (rd->eof && (lines % lpr != 0 || records == 0)) {
             /* ragged end of input: the host parser owns the message; hand it everything that is left */
             b->end = end; b->eof = 1;
             rd->beg = rd->end; input_done = 1;
@@ -1169,9 +1230,10 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
             b->end = cut; b->eof = (rd->eof && cut == end);
             const int li = (int)(nblocks % (size_t)nlanes);
             b->lane = li;
-            fxh_lane_post(&lanes[li], rd->buf + rd->beg, cut - rd->beg, records, (int)(lane_uses[li]++ & 1u));
+            fxh_lane_post(&lanes[li], rd->buf, rd->cap + 1, rd->buf + rd->beg, cut - rd->beg, records, (int)(lane_uses[li]++ & 1u));
             rd->beg = cut < rd->end ? cut : rd->end;
-            fx->input_line_number += 4ull * records;
+            carry_lines = lines - (unsigned long long)lpr * records - (end > rd->end ? 1u : 0u); have_carry = 1;   /* complete lines left in the unread tail */
+            fx->input_line_number += (unsigned long long)lpr * records;
             if (rd->eof && cut == end) input_done = 1;
         }
         nblocks++;
@@ -1189,8 +1251,10 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
         R->t_gpu += ln->t_busy;
     }
     { const double tw = fxh_now(); fxh_awriter_wait(&R->aw); R->t_drain += fxh_now() - tw; }   /* the last lane buffer must be on its way out before the contexts go */
-    if (R->st_shared) { fxg_sync(R->st.ctx); R->st.ctx = NULL; }
-    for (int i = 0; i < nlanes; ++i) fxg_ctx_destroy(lanes[i].st.ctx);
+    /* The process is about to exit: device buffers, streams and page-locked memory go with it, there is nothing to gain from
+     * tearing each context down first (FXH_TEARDOWN=1 does it anyway, for leak checkers). */
+    if (R->st_shared) { if (R->st.ctx) fxg_sync(R->st.ctx); R->st.ctx = NULL; }
+    if (getenv("FXH_TEARDOWN")) for (int i = 0; i < nlanes; ++i) fxg_ctx_destroy(lanes[i].st.ctx);
     for (int k = 1; k < NB; ++k) if (inbuf[k] && inbuf[k] != rd->buf) free(inbuf[k]);
     free(inbuf); free(blk); free(lanes);
 }
@@ -1237,8 +1301,8 @@ static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_sta
     memset(&pf, 0, sizeof pf);
     char *rd_spare = NULL;
     R.overlap = getenv("FXH_NO_OVERLAP") == NULL;
-    /* device-side parse/format for FASTQ; FXH_HOST_PARSE=1 forces the host parser */
-    const int gpu_text = !stats && fx->read_fastq && fx->write_fastq && !g_rename_ids && getenv("FXH_HOST_PARSE") == NULL;
+    /* device-side parse/format (FASTQ or FASTA in; the same, or FASTA, out); FXH_HOST_PARSE=1 forces the host parser */
+    const int gpu_text = !stats && !g_rename_ids && getenv("FXH_HOST_PARSE") == NULL;
     int nlanes = 0;
     int lane_dev[FXH_MAX_LANES];
     if (gpu_text) {

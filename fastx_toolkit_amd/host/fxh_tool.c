@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "fastx_args.h"
 
@@ -110,5 +111,9 @@ int fxh_tool_main(const fxh_tool *tool, int argc, char *argv[])
         }
     }
     fastx_finish(&fastx);
+    /* Everything is written and flushed.  Returning would run the HIP runtime's exit handlers (tens of milliseconds of
+     * teardown for a process that is gone anyway); FXH_SLOW_EXIT=1 takes that path, for leak checkers. */
+    fflush(NULL);
+    if (!getenv("FXH_SLOW_EXIT")) _exit(0);
     return 0;
 }

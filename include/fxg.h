@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FXG_ABI_VERSION 1
+#define FXG_ABI_VERSION 3
 
 /* ---- error codes ---- */
 #define FXG_OK            0
@@ -212,40 +212,52 @@ int  fxg_read_counters(fxg_ctx *ctx, const uint64_t *d_counters, uint64_t host_c
 int  fxg_synth_generate(fxg_ctx *ctx, uint64_t seed, uint64_t first_read, uint64_t n, uint32_t read_len,
                         int with_adapter, uint8_t *d_bases, uint8_t *d_qual, uint32_t stride);
 
-/* ---- FASTQ text on the device: index + check + pack (replaces fastx.c:314-404) and format
- * (replaces fastx.c:440-473) for REGULAR input: LF line ends, four lines per record, '@' prefix, upper-case ACGTN,
- * as many quality characters as bases, qualities within -15..93 after -Q.  Irregular input is only detected
- * (info->irregular != 0); the caller then parses that block with the host reader, which owns the reference's
- * error messages, CR/LF handling and numeric qualities.  All three calls synchronise. ---- */
+/* ---- FASTA / FASTQ text on the device: index + check + pack (replaces fastx.c:314-404) and format
+ * (replaces fastx.c:440-473).  Handled on the device: four-line FASTQ and two-line FASTA records (fastx.c:86-116), lines cut at
+ * their first CR or LF (chomp.c:36-41, so CRLF in gives LF out), ASCII and -- per record -- numeric quality lines
+ * (fastx.c:137-167, :382-390), upper-case ACGTN bases, qualities within -15..93 after -Q, collapsed FASTA ids for the -v
+ * tallies (fastx.c:475-495).  Malformed input is only detected (info->irregular != 0); the caller then parses that block
+ * with the host reader, which owns the reference's error messages.  All calls synchronise. ---- */
 typedef struct fxg_text_info {
     uint64_t lines;          /* complete lines in the block */
-    uint64_t records;        /* complete records = lines / 4 */
+    uint64_t records;        /* complete records = lines / lines_per_record */
     uint64_t consumed;       /* bytes they occupy; the next block starts there */
     uint32_t max_len, min_len;
     uint32_t irregular;      /* 0 = regular; FXG_TEXT_IRR_* bits otherwise */
     uint32_t first_bad;      /* smallest record index flagged by the index pass (0xFFFFFFFF if none) */
+    uint32_t numeric_records;/* records whose quality line holds numbers */
+    uint32_t has_cr;         /* the block contains CR bytes (lines were cut at them) */
 } fxg_text_info;
-#define FXG_TEXT_IRR_CR        0x01u
+#define FXG_TEXT_IRR_CR        0x01u   /* (not raised any more: CR is chomped on the device) */
 #define FXG_TEXT_IRR_PREFIX    0x02u
 #define FXG_TEXT_IRR_SEQLEN    0x04u
 #define FXG_TEXT_IRR_QUALLEN   0x08u
 #define FXG_TEXT_IRR_BASE      0x10u
 #define FXG_TEXT_IRR_QUAL      0x20u
 #define FXG_TEXT_IRR_TAIL      0x40u
+#define FXG_REC_NUMERIC_QUAL   0x01u   /* d_flags[record]: numeric quality line */
 
-/* d_text: device, readable up to text_len + 16 bytes, every line '\n'-terminated (the caller appends one at end of
- * input).  d_line_start: device u32[cap_lines] (needs 4*records + 1 entries); d_len: device u16[cap_lines / 4]. */
-int  fxg_fastq_index(fxg_ctx *ctx, const uint8_t *d_text, uint64_t text_len, int at_eof, uint32_t *d_line_start,
-                     uint64_t cap_lines, uint16_t *d_len, fxg_text_info *info);
-/* rows: device arrays of at least records * stride rounded up to 16 bytes; qualities become Phred+33 codes. */
-int  fxg_fastq_pack(fxg_ctx *ctx, const uint8_t *d_text, uint64_t text_len, const uint32_t *d_line_start, uint64_t records,
-                    uint32_t stride, int qoffset, uint8_t *d_bases, uint8_t *d_qual, uint32_t *irregular);
-/* Writes "@name\nSEQ\n+name2\nQUAL\n" for every kept record (res keep bit) in input order.  Forward outputs are
- * the slice [fwd_start, fwd_start + len) of the input lines; pass the engine's packed arrays + out_off for
- * reverse-complemented output.  d_out needs text_len + 16 bytes. */
-int  fxg_fastq_format(fxg_ctx *ctx, const uint8_t *d_text, const uint32_t *d_line_start, uint64_t records, const uint32_t *d_res,
-                      uint32_t fwd_start, const uint8_t *d_pk_bases, const uint8_t *d_pk_qual, const uint64_t *d_pk_off,
-                      int qoffset, uint8_t *d_out, uint64_t *out_bytes);
+/* d_text: device, readable up to text_len + 16 bytes, every line '\n'-terminated (the caller appends one at end of input).
+ * lines_per_record: 4 = FASTQ, 2 = FASTA.  d_line: device u32[2 * cap_lines] -- line starts in the first half, line ends
+ * (after chomp) in the second; cap_lines >= lines_per_record * records + 1.  d_len: device u16[cap_lines / lines_per_record];
+ * d_flags: device u8[cap_lines / lines_per_record]. */
+int  fxg_fastq_index(fxg_ctx *ctx, const uint8_t *d_text, uint64_t text_len, int at_eof, int lines_per_record, uint32_t *d_line,
+                     uint64_t cap_lines, uint16_t *d_len, uint8_t *d_flags, fxg_text_info *info);
+/* rows: device arrays of at least records * stride rounded up to 16 bytes; qualities become Phred+33 codes (d_qual NULL for FASTA). */
+int  fxg_fastq_pack(fxg_ctx *ctx, const uint8_t *d_text, uint64_t text_len, int lines_per_record, const uint32_t *d_line, uint64_t cap_lines,
+                    const uint8_t *d_flags, uint64_t records, uint32_t stride, int qoffset, uint8_t *d_bases, uint8_t *d_qual, uint32_t *irregular);
+/* Writes "@name\nSEQ\n+name2\nQUAL\n" (or ">name\nSEQ\n": FASTA input, or out_fasta) for every kept record (res keep bit) in input
+ * order.  Forward outputs are the slice [fwd_start, fwd_start + len) of the input lines; pass the engine's packed arrays + out_off
+ * for reverse-complemented / masked output (reverse != 0 when they are reversed).  d_rows_qual / stride: the batch's quality rows
+ * (numeric quality lines are printed from them).  d_out needs text_len + records + 16 bytes (an empty third line still gets its '+'). */
+int  fxg_fastq_format(fxg_ctx *ctx, const uint8_t *d_text, int lines_per_record, const uint32_t *d_line, uint64_t cap_lines, const uint8_t *d_flags,
+                      uint64_t records, const uint32_t *d_res, uint32_t fwd_start, int reverse, const uint8_t *d_pk_bases, const uint8_t *d_pk_qual,
+                      const uint64_t *d_pk_off, const uint8_t *d_rows_qual, uint32_t stride, int qoffset, int out_fasta, uint8_t *d_out,
+                      uint64_t *out_bytes);
+/* FASTA records stand for `count` reads when their identifier is "id-count" (fastx.c:475-495).  weighted[0..6] = read-count
+ * weighted tallies over the block: input, kept, clip too-short, adapter-only, no-adapter, adapter-found, has-N. */
+int  fxg_fasta_weights(fxg_ctx *ctx, const uint8_t *d_text, const uint32_t *d_line, uint64_t cap_lines, uint64_t records, const uint32_t *d_res,
+                       uint64_t weighted[8]);
 int  fxg_host_register(fxg_ctx *ctx, void *ptr, size_t bytes);     /* page-lock an existing host buffer for async copies */
 int  fxg_host_unregister(fxg_ctx *ctx, void *ptr);
 

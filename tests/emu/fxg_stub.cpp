@@ -53,9 +53,10 @@ int fxg_read_counters(fxg_ctx *c, const uint64_t *d, uint64_t host[FXG_NCOUNTERS
     return 0;
 }
 int fxg_synth_generate(fxg_ctx *, uint64_t, uint64_t, uint64_t, uint32_t, int, uint8_t *, uint8_t *, uint32_t) { return FXG_E_INVALID; }
-int fxg_fastq_index(fxg_ctx *, const uint8_t *, uint64_t, int, uint32_t *, uint64_t, uint16_t *, fxg_text_info *info) { memset(info, 0, sizeof *info); info->irregular = FXG_TEXT_IRR_CR; return 0; }
-int fxg_fastq_pack(fxg_ctx *, const uint8_t *, uint64_t, const uint32_t *, uint64_t, uint32_t, int, uint8_t *, uint8_t *, uint32_t *irr) { *irr = 1; return 0; }
-int fxg_fastq_format(fxg_ctx *, const uint8_t *, const uint32_t *, uint64_t, const uint32_t *, uint32_t, const uint8_t *, const uint8_t *, const uint64_t *, int, uint8_t *, uint64_t *n) { *n = 0; return FXG_E_INVALID; }
+int fxg_fastq_index(fxg_ctx *, const uint8_t *, uint64_t, int, int, uint32_t *, uint64_t, uint16_t *, uint8_t *, fxg_text_info *info) { memset(info, 0, sizeof *info); info->irregular = FXG_TEXT_IRR_TAIL; return 0; }
+int fxg_fastq_pack(fxg_ctx *, const uint8_t *, uint64_t, int, const uint32_t *, uint64_t, const uint8_t *, uint64_t, uint32_t, int, uint8_t *, uint8_t *, uint32_t *irr) { *irr = 1; return 0; }
+int fxg_fastq_format(fxg_ctx *, const uint8_t *, int, const uint32_t *, uint64_t, const uint8_t *, uint64_t, const uint32_t *, uint32_t, int, const uint8_t *, const uint8_t *, const uint64_t *, const uint8_t *, uint32_t, int, int, uint8_t *, uint64_t *n) { *n = 0; return FXG_E_INVALID; }
+int fxg_fasta_weights(fxg_ctx *, const uint8_t *, const uint32_t *, uint64_t, uint64_t, const uint32_t *, uint64_t *w) { memset(w, 0, 8 * sizeof(uint64_t)); return FXG_E_INVALID; }
 int fxg_device_count(void) { return 1; }
 int fxg_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi) { *lo = n * rank / world; *hi = n * (rank + 1) / world; return 0; }
 int fxg_epilogue(const uint64_t *, uint32_t, uint32_t, uint64_t *, uint64_t *, uint64_t *) { return FXG_E_INVALID; }

@@ -11,26 +11,28 @@ from oracle import fxoracle_py as fo
 pytestmark = pytest.mark.gpu
 
 
-def _gpu_text_pipeline(engine, text, pd, qoffset=33):
+def _gpu_text_pipeline(engine, text, pd, qoffset=33, fasta=False, out_fasta=False):
     """text -> (device index/pack) -> engine pipeline -> (device format) -> text; returns (out_text, info)."""
     from fastx_toolkit_amd import make_params
     import torch
     d_text, tl = engine.text_upload(text)
-    ls, lens, info = engine.fastq_index(d_text, tl)
+    ix, lens, info = engine.fastq_index(d_text, tl, fasta=fasta)
     assert info.irregular == 0, info.irregular
     n = info.records
     assert info.consumed == tl
     stride = info.max_len
-    bases, qual, irr = engine.fastq_pack(d_text, tl, ls, n, stride, qoffset)
+    bases, qual, irr = engine.fastq_pack(d_text, tl, ix, n, stride, qoffset)
     assert irr == 0
     p = make_params(**dict(pd, qoffset=33))            # rows hold Phred+33 codes
     rev = bool(pd["stages"] & (8 | 64))              # stages whose output is not a slice of the input: use the packed arrays
     fixed = info.min_len == info.max_len
     r = engine.run(bases, qual, p, lens=None if fixed else lens[:n], fixed_len=stride, compact=rev, meta=rev)
     fwd = pd.get("ft_first", 1) - 1 if (pd["stages"] & 16) else 0
-    out = engine.fastq_format(d_text, tl, ls, n, r.res, fwd_start=0 if rev else fwd,
-                              packed=(r.out_bases, r.out_qual, r.out_off) if rev else None, qoffset=qoffset)
+    out = engine.fastq_format(d_text, tl, ix, n, r.res, fwd_start=fwd, packed=(r.out_bases, r.out_qual, r.out_off) if rev else None,
+                              reverse=bool(pd["stages"] & 8), rows_qual=qual, qoffset=qoffset, out_fasta=out_fasta)
     torch.cuda.synchronize()
+    if fasta:
+        info.weights = engine.fasta_weights(d_text, ix, n, r.res)
     return bytes(out.cpu().numpy()), info, (bases, qual, lens)
 
 
@@ -44,15 +46,16 @@ def test_index_and_pack_match_oracle_parser(engine):
         recs.append(b"@r%d %s\n%s\n+%s\n%s\n" % (i, b"x" * int(rng.integers(0, 40)), s, b"" if i % 3 else b"r%d" % i, q))
     text = b"".join(recs)
     d_text, tl = engine.text_upload(text)
-    ls, lens, info = engine.fastq_index(d_text, tl)
+    ix, lens, info = engine.fastq_index(d_text, tl)
     p = fo.parse_fastq(text)
     assert (info.records, info.lines, info.consumed, info.irregular) == (p["n"], 4 * p["n"], len(text), 0)
     assert (info.max_len, info.min_len) == (int(p["lens"].max()), int(p["lens"].min()))
     starts = np.concatenate([[0], np.nonzero(np.frombuffer(text, np.uint8) == 10)[0] + 1]).astype(np.uint32)
-    assert np.array_equal(ls[:4 * info.records + 1].cpu().numpy().view(np.uint32), starts)
+    assert np.array_equal(ix.starts[:4 * info.records + 1].cpu().numpy().view(np.uint32), starts)
+    assert np.array_equal(ix.ends[:4 * info.records].cpu().numpy().view(np.uint32), starts[1:] - 1) and info.numeric_records == 0
     assert np.array_equal(lens[:info.records].cpu().numpy().view(np.uint16), p["lens"])
     for stride in (info.max_len, info.max_len + 5):
-        b, q, irr = engine.fastq_pack(d_text, tl, ls, info.records, stride)
+        b, q, irr = engine.fastq_pack(d_text, tl, ix, info.records, stride)
         pp = fo.parse_fastq(text, stride=stride)
         assert irr == 0 and np.array_equal(b.cpu().numpy(), pp["bases"]) and np.array_equal(q.cpu().numpy(), pp["qual"])
 
@@ -89,19 +92,77 @@ def test_revcomp_trim_and_offsets_text(engine):
 
 def test_irregular_input_is_detected_not_processed(engine):
     ok = b"@r1\nACGT\n+\nIIII\n@r2\nAC\n+\nII\n"
-    for text, bit in ((ok.replace(b"\n", b"\r\n"), 0x01), (b"r1\nACGT\n+\nIIII\n", 0x02), (b"@r1\n\n+\n\n", 0x04),
-                      (b"@r1\nACGT\n+\n40 40 40 40\n", 0x08), (ok + b"@r3\nAC\n+\n", 0x40)):
+    for text, bit in ((b"r1\nACGT\n+\nIIII\n", 0x02), (b"@r1\n\n+\n\n", 0x04), (b"\nACGT\n+\nIIII\n", 0x02),
+                      (b"@r1\nACGT\n+\n40 40 40\n", 0x08), (b"@r1\nACGT\n+\n40 40 x 40\n", 0x08), (b"@r1\nACGT\n+\n40 40 40 94\n", 0x08),
+                      (b"@r1\nACGT\n+\n40 40 40 40 \n", 0x08), (ok + b"@r3\nAC\n+\n", 0x40), (b"@" + b"x" * 30000 + b"\nACGT\n+\nIIII\n", 0x04)):
         d_text, tl = engine.text_upload(text)
         _, _, info = engine.fastq_index(d_text, tl)
-        assert info.irregular & bit, (text, info.irregular)
+        assert info.irregular & bit, (text[:40], info.irregular)
     for text, bit in ((b"@r1\nACGX\n+\nIIII\n", 0x10), (b"@r1\nacgt\n+\nIIII\n", 0x10), (b"@r1\nACGT\n+\nII\x07I\n", 0x20),
                       (b"@r1\nACGT\n+\nII\xc8I\n", 0x20)):
         d_text, tl = engine.text_upload(text)
-        ls, _, info = engine.fastq_index(d_text, tl)
+        ix, _, info = engine.fastq_index(d_text, tl)
         assert info.irregular == 0
-        _, _, irr = engine.fastq_pack(d_text, tl, ls, info.records, info.max_len)
+        _, _, irr = engine.fastq_pack(d_text, tl, ix, info.records, info.max_len)
         assert irr & bit, (text, irr)
     # a block that ends inside a record is not an error unless it is the end of input
     d_text, tl = engine.text_upload(ok + b"@r3\nAC", at_eof=False)
     _, _, info = engine.fastq_index(d_text, tl, at_eof=False)
     assert info.irregular == 0 and info.records == 2 and info.consumed == len(ok)
+    for text in (b">s1\nACGT\nACGT\n", b"s1\nACGT\n", b">s1\n\n"):                 # FASTA: two lines per record, '>' prefix, non-empty sequence
+        d_text, tl = engine.text_upload(text)
+        _, _, info = engine.fastq_index(d_text, tl, fasta=True)
+        assert info.irregular != 0, text
+
+
+def _ref(argv, data):
+    import subprocess
+    p = subprocess.run([fo.ref_binary()] + argv, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 0, p.stderr
+    return p.stdout
+
+
+@pytest.mark.skipif(fo.ref_binary() is None, reason="oracle/_ref/fxref not on this box")
+def test_crlf_numeric_and_fasta_on_the_device_vs_reference(engine):
+    """R2 (chomp at the first CR or LF), R6 (numeric quality lines, per record; output in the record's own encoding) and FASTA
+    (two-line records, collapsed ids) go through the device text path; expected output = the real libfastx around the same stage."""
+    rng = np.random.default_rng(12)
+    fq, num, mixed, fa = [], [], [], []
+    for i in range(3000):
+        L = int(rng.integers(5, 70))
+        s = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=L, p=[.24, .24, .24, .24, .04]).tobytes()
+        q = rng.integers(-5, 41, size=L)
+        a = b"@r%d x\n%s\n+r%d\n%s\n" % (i, s, i, bytes((q.clip(0) + 33).astype(np.uint8)))
+        nline = b" ".join(b"%d" % int(v) for v in q)
+        if len(nline) == L:                                                          # would be read as characters
+            nline = b" " + nline
+        b = b"@r%d\n%s\n+\n%s\n" % (i, s, nline)
+        fq.append(a); num.append(b); mixed.append(a if rng.random() < 0.5 else b)
+        fa.append(b">%d-%d\n%s\n" % (i, int(rng.integers(1, 9)), s) if i % 3 else b">plain%d\n%s\n" % (i, s))
+    fq, num, mixed, fa = b"".join(fq), b"".join(num), b"".join(mixed), b"".join(fa)
+    jobs = [(dict(stages=16, ft_first=3, ft_last=40), ["fastx_trimmer", "-f", "3", "-l", "40"]),
+            (dict(stages=32, ft_trim_end=4, ft_min_len=6), ["fastx_trimmer", "-t", "4", "-m", "6"]),
+            (dict(stages=8), ["fastx_reverse_complement"]),
+            (dict(stages=128), ["fastx_artifacts_filter"])]
+    fq_jobs = jobs + [(dict(stages=2, qt_threshold=18, qt_min_len=8), ["fastq_quality_trimmer", "-t", "18", "-l", "8"]),
+                      (dict(stages=4, qf_min_quality=15, qf_min_percent=60), ["fastq_quality_filter", "-q", "15", "-p", "60"]),
+                      (dict(stages=64, mask_min_quality=12, mask_char="N"), ["fastq_masker", "-q", "12"])]
+    for name, text in (("crlf", fq.replace(b"\n", b"\r\n")), ("cr-junk", fq.replace(b"\n", b"\rjunk\n", 40)), ("numeric", num), ("mixed", mixed),
+                       ("mixed-crlf", mixed.replace(b"\n", b"\r\n"))):
+        for pd, argv in fq_jobs:
+            out, info, _ = _gpu_text_pipeline(engine, text, pd)
+            assert out == _ref(argv, text), (name, argv)
+        if name in ("numeric", "mixed"):
+            assert info.numeric_records > 0
+    out, _, _ = _gpu_text_pipeline(engine, mixed, dict(stages=256, nf_keep_n=0), out_fasta=True)      # fastq_to_fasta: FASTQ in, FASTA out
+    assert out == _ref(["fastq_to_fasta"], mixed)
+    for name, text in (("fasta", fa), ("fasta-crlf", fa.replace(b"\n", b"\r\n"))):
+        for pd, argv in jobs + [(dict(stages=1, adapter=b"ACGTACG", clip_min_len=5, clip_flags=4), ["fastx_clipper", "-a", "ACGTACG", "-l", "5", "-n"])]:
+            out, info, _ = _gpu_text_pipeline(engine, text, pd, fasta=True)
+            assert out == _ref(argv, text), (name, argv)
+    # collapsed identifiers: the -v tallies count reads, not records
+    import subprocess
+    p = subprocess.run([fo.ref_binary(), "fastx_artifacts_filter", "-v"], input=fa, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    rep = p.stderr.decode()
+    out, info, _ = _gpu_text_pipeline(engine, fa, dict(stages=128), fasta=True)
+    assert "Input: %d reads." % info.weights[0] in rep and "Output: %d reads." % info.weights[1] in rep
