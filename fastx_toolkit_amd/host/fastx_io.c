@@ -381,6 +381,9 @@ static void fxh_write_parallel(struct fxh_writer *w, const char *buf, size_t n)
         fxh_pwrite_all(w->fd, buf, n, w->off); w->off += (off_t)n;
         return;
     }
+#ifdef MADV_HUGEPAGE
+    (void)madvise(m, map_len, MADV_HUGEPAGE);                  /* fewer, larger page faults where the file system allows it */
+#endif
     pthread_t th[16];
     struct fxh_cp_job job[16];
     const size_t per = ((n + (size_t)nt - 1) / (size_t)nt + 4095) & ~(size_t)4095;

@@ -26,7 +26,9 @@ def _gpu_text_pipeline(engine, text, pd, qoffset=33, fasta=False, out_fasta=Fals
     p = make_params(**dict(pd, qoffset=33))            # rows hold Phred+33 codes
     rev = bool(pd["stages"] & (8 | 64))              # stages whose output is not a slice of the input: use the packed arrays
     fixed = info.min_len == info.max_len
+    engine.set_clip_history(bool(pd["stages"] & 1))      # the fastx_clipper tool is one aligner over the whole input
     r = engine.run(bases, qual, p, lens=None if fixed else lens[:n], fixed_len=stride, compact=rev, meta=rev)
+    engine.set_clip_history(False)
     fwd = pd.get("ft_first", 1) - 1 if (pd["stages"] & 16) else 0
     out = engine.fastq_format(d_text, tl, ix, n, r.res, fwd_start=fwd, packed=(r.out_bases, r.out_qual, r.out_off) if rev else None,
                               reverse=bool(pd["stages"] & 8), rows_qual=qual, qoffset=qoffset, out_fasta=out_fasta)
