@@ -137,12 +137,15 @@ def cpu_baseline(reads_per_pipe=250_000, max_pipes=64):
                     sample="oracle/fxoracle.c on %d in-memory SoA reads (no FASTQ text parsing/formatting), 1 thread" % n)
 
 
-def e2e_leg(reads=4_000_000):
+def e2e_leg(reads=16_000_000):
     """End to end on one GPU: FASTQ text on tmpfs -> the C tools (host/bin) -> FASTQ text; the same seed-2 reads the CPU baseline uses.
 
-    `pipe`  = fastq_quality_trimmer -t 20 -l 30 | fastq_quality_filter -q 20 -p 80 (two processes, both on the GPU, as a user would type it)
-    `fused` = fastq_quality_trim_filter -t 20 -l 30 -q 20 -p 80 (one process, one pass; byte-identical output)
-    Wall time of the command, file to file; Mreads/s and Gbases/s of INPUT."""
+    `pipe`   = fastq_quality_trimmer -t 20 -l 30 | fastq_quality_filter -q 20 -p 80 (two processes, both on the GPU, as a user would type it)
+    `fused`  = fastq_quality_trim_filter -t 20 -l 30 -q 20 -p 80 (one process, one pass; byte-identical output)
+    `fused_to_devnull` = the same with -o /dev/null: what the tool does when the output file system is not the limit (writing the
+               2.5 GB result to tmpfs runs at ~7 GB/s on this box whatever the number of writer threads)
+    Wall time of the command, file to file, best of two runs (the previous output is removed outside the timed region);
+    Mreads/s and Gbases/s of INPUT."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import fxoracle_py as fo
     import hashlib
@@ -168,9 +171,11 @@ def e2e_leg(reads=4_000_000):
                     h.update(blk)
             return h.hexdigest()
 
-        def timed(name, fn):
+        def timed(name, fn, outfile):
             best = None
             for _ in range(2):                             # the first run pays the library load and context creation from cold caches
+                if outfile and os.path.exists(outfile):
+                    os.unlink(outfile)
                 t0 = time.perf_counter()
                 ok = fn()
                 dt = time.perf_counter() - t0
@@ -178,20 +183,22 @@ def e2e_leg(reads=4_000_000):
                     return
                 best = dt if best is None else min(best, dt)
             out[name] = dict(wall_s=round(best, 3), mreads_s=round(reads / best / 1e6, 2), gbases_s=round(reads * 150 / best / 1e9, 3))
+            if outfile:
+                out[name]["output_bytes"] = os.path.getsize(outfile)
+                out[name]["output_md5"] = md5(outfile)
 
         def pipe():
             p1 = subprocess.Popen([trimmer, "-t", "20", "-l", "30", "-i", inp], stdout=subprocess.PIPE)
             p2 = subprocess.Popen([filt, "-q", "20", "-p", "80", "-o", os.path.join(td, "pipe.fq")], stdin=p1.stdout)
             p1.stdout.close()
             return p1.wait() == 0 and p2.wait() == 0
-        timed("pipe", pipe)
+        timed("pipe", pipe, os.path.join(td, "pipe.fq"))
         if os.path.exists(fused):
-            timed("fused", lambda: subprocess.call([fused, "-t", "20", "-l", "30", "-q", "20", "-p", "80", "-i", inp, "-o", os.path.join(td, "fused.fq")]) == 0)
-        for k in ("pipe", "fused"):
-            if k in out:
-                out[k]["output_md5"] = md5(os.path.join(td, k + ".fq"))
-        if reads == 1_000_000 and "pipe" in out:           # SURVEY 8d records the reference's md5 for the first 1 M reads
-            out["matches_reference_md5"] = out["pipe"]["output_md5"] == "605f8d07d0f745186bc25a8d6f894284"
+            fa = [fused, "-t", "20", "-l", "30", "-q", "20", "-p", "80", "-i", inp]
+            timed("fused", lambda: subprocess.call(fa + ["-o", os.path.join(td, "fused.fq")]) == 0, os.path.join(td, "fused.fq"))
+            timed("fused_to_devnull", lambda: subprocess.call(fa + ["-o", "/dev/null"]) == 0, None)
+        if "pipe" in out and "fused" in out:
+            out["fused_equals_pipe"] = out["pipe"]["output_md5"] == out["fused"]["output_md5"]
         return out
 
 
