@@ -31,6 +31,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define FXG_MAX_TILE FXG_TBLOCK  // reads per tile (one thread decides one read)
 #define FXG_TICKET_GROUPS 8      // a single device-scope counter saturates near 88 tickets/us; shard it (one per XCD)
 #define FXG_TICKET_STRIDE 32     // u32 words between dispensers (128 B: one cache line each)
+#define FXG_CTRL_WORDS 64         // u32 words of the control block in front of the dispensers: [0] error bits, [2..5] masker sums, [8] scanner role, [32..63] tallies
 
 // ------------------------------------------------------------------------------------------------
 // launch arguments (passed by value; adapter bytes therefore live in the kernarg segment / SGPRs)
@@ -57,7 +58,7 @@ struct FxgKArgs {
     u64 *pfx;               // [2*ntiles] exclusive prefixes {tag:8 | value:56}: [2t] kept reads before tile t, [2t+1] kept bytes before it (scanner)
     u32 *role;              // the workgroup that draws 0 here becomes the scanner
     u32  tag;               // launch epoch 1..255: granules of earlier launches are invalid without a memset
-    u64 *partial;           // [count grid][FXG_NCOUNTERS]
+    u64 *tally;             // [FXG_NTALLY] the launch's -v report tallies (zeroed with the control block)
     u32 *ticket;            // dynamic tile dispensers, FXG_TICKET_STRIDE words apart (zeroed before every launch)
     u32  ticket_groups;     // number of dispensers (<= 8): dispenser g hands out tiles g, g+groups, g+2*groups, ...
     u32 *errflag;

@@ -28,8 +28,6 @@ struct fxg_ctx {
     u32 attr_lds[8];
     int attr_per_cu[8];
     int env_blocks_per_cu, env_ticket_groups;   // tuning knobs, read once
-    u64 *partial;           // partial_cap rows of FXG_NCOUNTERS
-    size_t partial_cap;
     u32 *errflag;           // [0] device error bits; tile dispensers start at word FXG_TICKET_STRIDE
     u64 *counters_scratch;  // used when the caller passes no counter block
     u64 *text_ws;           // newline census / scan levels / format items
@@ -88,7 +86,7 @@ extern "C" int fxg_ctx_create(int device_id, fxg_ctx **out)
     { const char *e = getenv("FXG_TICKET_GROUPS"); c->env_ticket_groups = (e && atoi(e) > 0 && atoi(e) <= FXG_TICKET_GROUPS) ? atoi(e) : 0; }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreate(&c->kev0) != hipSuccess || hipEventCreate(&c->kev1) != hipSuccess ||
-        hipMalloc((void **)&c->errflag, (FXG_TICKET_GROUPS + 1) * FXG_TICKET_STRIDE * sizeof(u32)) != hipSuccess ||
+        hipMalloc((void **)&c->errflag, (FXG_CTRL_WORDS + FXG_TICKET_GROUPS * FXG_TICKET_STRIDE) * sizeof(u32)) != hipSuccess ||
         hipMalloc((void **)&c->counters_scratch, FXG_NCOUNTERS * sizeof(u64)) != hipSuccess) {
         free(c);
         return FXG_E_HIP;
@@ -102,7 +100,7 @@ extern "C" void fxg_ctx_destroy(fxg_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->status); (void)hipFree(c->partial); (void)hipFree(c->errflag); (void)hipFree(c->counters_scratch);
+    (void)hipFree(c->status); (void)hipFree(c->errflag); (void)hipFree(c->counters_scratch);
     (void)hipFree(c->text_ws); (void)hipFree(c->text_state);
     (void)hipFree(c->hist_buf[0]); (void)hipFree(c->hist_buf[1]); (void)hipFree(c->hist_w); (void)hipFree(c->hist_ws); (void)hipFree(c->stats_ws);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
@@ -188,7 +186,6 @@ extern "C" int fxg_timer_stop(fxg_ctx *c, float *ms)
 }
 
 // ------------------------------------------------------------------------------------------------
-#define FXG_COUNT_GRID 512u
 
 // dynamic-LDS attribute and occupancy of a kernel: asked once per (kernel, LDS size), not per launch
 template <typename K>
@@ -237,37 +234,26 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
         ka.pfx = c->status + c->status_cap;
         ka.tag = c->epoch;
     }
-    if (c->partial_cap < FXG_COUNT_GRID) {
-        (void)hipFree(c->partial);
-        c->partial = nullptr; c->partial_cap = 0;
-        FXG_HIP(c, hipMalloc((void **)&c->partial, (size_t)FXG_COUNT_GRID * FXG_NCOUNTERS * sizeof(u64)));
-        c->partial_cap = FXG_COUNT_GRID;
-    }
-    ka.partial = c->partial;
 #ifdef FXG_ABLATION
     { const char *dbg = getenv("FXG_DEBUG"); ka.debug = dbg ? (u32)atoi(dbg) : 0u; }
 #endif
-    ka.errflag = c->errflag;                     // control block (zeroed before every launch): [0] error bits, [2..5] masker sums, [8] scanner role
-    ka.ticket = c->errflag + FXG_TICKET_STRIDE;
+    ka.errflag = c->errflag;                     // control block (zeroed before every launch), layout at FXG_CTRL_WORDS
+    ka.ticket = c->errflag + FXG_CTRL_WORDS;
     ka.extra = (u64 *)(c->errflag + 2);
     ka.role = c->errflag + 8;
+    ka.tally = (u64 *)(c->errflag + 32);
     // Dispenser g serves the workgroups with blockIdx % groups == g, so every group needs a worker even if the scanner role
     // falls to one of its members: eight groups only when each has at least two workgroups.
     { u32 g = c->env_ticket_groups > 0 ? (u32)c->env_ticket_groups : FXG_TICKET_GROUPS; ka.ticket_groups = grid >= 2u * g ? g : 1u; }
-    FXG_HIP(c, hipMemsetAsync(c->errflag, 0, (FXG_TICKET_GROUPS + 1) * FXG_TICKET_STRIDE * sizeof(u32), c->stream));
+    FXG_HIP(c, hipMemsetAsync(c->errflag, 0, (FXG_CTRL_WORDS + FXG_TICKET_GROUPS * FXG_TICKET_STRIDE) * sizeof(u32), c->stream));
 
     if (c->profiling) FXG_HIP(c, hipEventRecord(c->kev0, c->stream));
     hipLaunchKernelGGL(kernel, dim3((u32)grid), dim3(FXG_TBLOCK), lds, c->stream, ka);
     FXG_HIP(c, hipGetLastError());
     if (c->profiling) { FXG_HIP(c, hipEventRecord(c->kev1, c->stream)); c->kev_valid = 1; }
-    // -v report counters: one pass over res[] (4 B/read), then fold the partial rows
-    u64 cgrid = (ka.n / 4 + FXG_BLOCK * 16 - 1) / (FXG_BLOCK * 16);
-    if (cgrid > FXG_COUNT_GRID) cgrid = FXG_COUNT_GRID;
-    if (cgrid < 1) cgrid = 1;
-    hipLaunchKernelGGL(fxg_kernel_count_res, dim3((u32)cgrid), dim3(FXG_BLOCK), 0, c->stream, (const u32 *)ka.res, ka.n, ka.stages, c->partial);
-    FXG_HIP(c, hipGetLastError());
-    hipLaunchKernelGGL(fxg_kernel_reduce_counters, dim3(1), dim3(256), 0, c->stream, (const u64 *)c->partial, (u32)cgrid,
-                       (const u32 *)c->errflag, (const u64 *)(c->errflag + 2), counters ? counters : c->counters_scratch);
+    // -v report counters: the tile kernel tallied them; one tiny kernel lays them out
+    hipLaunchKernelGGL(fxg_kernel_finish_counters, dim3(1), dim3(64), 0, c->stream, (const u64 *)ka.tally, ka.stages, (const u32 *)c->errflag,
+                       (const u64 *)(c->errflag + 2), counters ? counters : c->counters_scratch);
     FXG_HIP(c, hipGetLastError());
     snprintf(c->last_kernel, sizeof c->last_kernel, "%s", kname);
     c->last_grid = (u32)grid; c->last_block = FXG_TBLOCK; c->last_lds = lds; c->last_tile = ka.tile_reads;

@@ -21,9 +21,10 @@
 // LDS carve-up shared by host (size) and device (pointers); every region is 16-byte aligned (G17).
 // k_off / k_src / k_idx / k_tab (the tile's kept reads, see fxg_tile_gather) are double buffered: stage B of tile i reads
 // slot s while stage A of tile i+1 fills slot s^1.
+#define FXG_NTALLY 16                            // tally slots: [0] reads seen, [1] kept, [2] kept bases, [3] adapter-only, [4 + reason] dropped for that reason
 struct FxgLds {
     u32 slot_bytes, so_ksrc, so_kidx, so_ktab;   // slot k lives at k * slot_bytes: k_off at +0, k_src at +so_ksrc, k_idx at +so_kidx, k_tab at +so_ktab
-    u32 off_scratch, off_bm_g, off_bm_l, off_bases, total;
+    u32 off_scratch, off_tally, off_bm_g, off_bm_l, off_bases, total;
     u32 has_tab;                                 // kernels that stage a tile of bases in LDS (clipper, census) spend no LDS on k_tab
 };
 __host__ __device__ inline u32 fxg_r16(u32 x) { return (x + 15u) & ~15u; }
@@ -37,6 +38,7 @@ __host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, bool bitmaps
     l.slot_bytes = l.so_ktab + (l.has_tab ? fxg_r16(((T * stride + 15) / 16 + 1) * 2) : 0u);
     u32 o = 2 * l.slot_bytes;
     l.off_scratch = o; o += fxg_r16(48 * 4);
+    l.off_tally = o;   o += FXG_NTALLY * 8;      // the workgroup's -v report tallies (u64), see fxg_tile_tally
     const u32 words = (T * stride + 31) / 32 + 2;
     l.off_bm_g = o;    o += bitmaps ? fxg_r16(words * 4) : 0;
     l.off_bm_l = o;    o += bitmaps ? fxg_r16(words * 4) : 0;
@@ -368,8 +370,8 @@ FXG_HD void fxg_phase_stage_bases(const uint8_t *src, u64 total, u64 tb, u32 tby
 // phase 2, group A: thread tid decides read r0 + tid
 // AMAX > 0: general clipper; AMAX < 0: packed clipper with bucket -AMAX (reads <= 255, adapter <= 31)
 template <int AMAX>
-FXG_HD void fxg_decide_a(const FxgKArgs &a, const u32 *bm_g, const u32 *bm_l, const uint8_t *sb, u32 r0, u32 tid,
-                         u32 *keep_out, u32 *len_out)
+FXG_HD u32 fxg_decide_a(const FxgKArgs &a, const u32 *bm_g, const u32 *bm_l, const uint8_t *sb, u32 r0, u32 tid,
+                        u32 *keep_out, u32 *len_out)
 {
     const u32 stride = a.stride;
     const u32 rl = a.len ? (u32)a.len[r0 + tid] : a.fixed_len;
@@ -388,13 +390,15 @@ FXG_HD void fxg_decide_a(const FxgKArgs &a, const u32 *bm_g, const u32 *bm_l, co
         if (n0 < 0) n0 = 0;
         if (a.qf_drop_all || (int)low > n0) { keep = 0; reason = FXG_R_QFILTER; }
     }
-    a.res[r0 + tid] = (curlen & 0xFFFFu) | (keep << 16) | (reason << 17) | (clipped << 21) | (ao << FXG_RES_ADAPTER_ONLY_BIT);
+    const u32 w = (curlen & 0xFFFFu) | (keep << 16) | (reason << 17) | (clipped << 21) | (ao << FXG_RES_ADAPTER_ONLY_BIT);
+    a.res[r0 + tid] = w;
     *keep_out = keep; *len_out = curlen;
+    return w;
 }
 
 // phase 2, group B: fixed trimming is arithmetic on the length; reverse-complement only moves the anchor
 template <bool REV>
-FXG_HD void fxg_decide_b(const FxgKArgs &a, u32 r0, u32 tid, u32 *keep_out, u32 *len_out, u32 *anchor_out)
+FXG_HD u32 fxg_decide_b(const FxgKArgs &a, u32 r0, u32 tid, u32 *keep_out, u32 *len_out, u32 *anchor_out)
 {
     const u32 rl = a.len ? (u32)a.len[r0 + tid] : a.fixed_len;
     u32 reason = FXG_R_KEPT, start = 0, keep = 1, curlen = rl;
@@ -411,25 +415,28 @@ FXG_HD void fxg_decide_b(const FxgKArgs &a, u32 r0, u32 tid, u32 *keep_out, u32 
         else curlen -= a.ft_trim_end;
     }
     if (!keep) reason = FXG_R_FTRIM;
-    a.res[r0 + tid] = (curlen & 0xFFFFu) | (keep << 16) | (reason << 17);
+    const u32 w = (curlen & 0xFFFFu) | (keep << 16) | (reason << 17);
+    a.res[r0 + tid] = w;
     // output byte k of this read comes from source byte anchor + k (forward) or anchor - k (reverse-complement)
     *anchor_out = REV ? tid * a.stride + (rl - 1u - start) : tid * a.stride + start;
     *keep_out = keep; *len_out = curlen;
+    return w;
 }
 
 // fastq_masker (fastq_masker.c:92-108): every read is kept at full length; n_low = bases below the threshold
-FXG_HD void fxg_decide_mask(const FxgKArgs &a, const u32 *bm_l, u32 r0, u32 tid, u32 *keep_out, u32 *len_out, u32 *n_low)
+FXG_HD u32 fxg_decide_mask(const FxgKArgs &a, const u32 *bm_l, u32 r0, u32 tid, u32 *keep_out, u32 *len_out, u32 *n_low)
 {
     const u32 rl = a.len ? (u32)a.len[r0 + tid] : a.fixed_len;
     *n_low = fxg_bits_count(bm_l, tid * a.stride, rl);
     a.res[r0 + tid] = (rl & 0xFFFFu) | (1u << 16);
     *keep_out = 1u; *len_out = rl;
+    return (rl & 0xFFFFu) | (1u << 16);
 }
 
 // base census of one read from its LDS row, shared by
 //   fastx_artifacts_filter (fastx_artifacts_filter.c:56-112): drop when one of A/C/G/T fills all but <= 3 positions
 //   fastq_to_fasta N-discard (fastq_to_fasta.c:79-82)        : drop when the read contains an N (unless -n)
-FXG_HD void fxg_decide_census(const FxgKArgs &a, const uint8_t *row, u32 r0, u32 tid, u32 *keep_out, u32 *len_out, u32 *bad)
+FXG_HD u32 fxg_decide_census(const FxgKArgs &a, const uint8_t *row, u32 r0, u32 tid, u32 *keep_out, u32 *len_out, u32 *bad)
 {
     const u32 rl = a.len ? (u32)a.len[r0 + tid] : a.fixed_len;
     u32 ca = 0, cc = 0, cg = 0, ct = 0, cn = 0;
@@ -446,6 +453,7 @@ FXG_HD void fxg_decide_census(const FxgKArgs &a, const uint8_t *row, u32 r0, u32
     if ((a.stages & FXG_STAGE_NFILTER) && !a.nf_keep_n && cn != 0u) { keep = 0u; why = FXG_R_HAS_N; }
     a.res[r0 + tid] = (rl & 0xFFFFu) | (keep << 16) | (why << 17);
     *keep_out = keep; *len_out = rl;
+    return (rl & 0xFFFFu) | (keep << 16) | (why << 17);
 }
 
 // per-kept-read side outputs
@@ -457,6 +465,31 @@ FXG_HD void fxg_write_kept_meta(const FxgKArgs &a, u64 rank, u32 olen, u32 read_
 }
 
 #ifndef FXG_HOST_EMULATION   // everything below is device code proper (wave intrinsics, __global__)
+
+// wave-level tally of one tile's res words into the workgroup's LDS slots (FXG_NTALLY): only the reasons the instance can produce
+template <int AMAX, int MODE>
+__device__ __forceinline__ void fxg_tile_tally(u32 w, bool valid, u64 *tally)
+{
+    const u32 why = valid ? (w >> 17) & 0xFu : 0u;
+    const bool lead = fxg_lane() == 0u;
+    auto count = [&](u32 reason) {
+        const u64 b = __ballot(why == reason);
+        if (lead && b) atomicAdd(&tally[4 + reason], (u64)__builtin_popcountll(b));
+    };
+    if constexpr (MODE == 0) {
+        if constexpr (AMAX != 0) {
+            count(FXG_R_CLIP_TOO_SHORT); count(FXG_R_CLIP_ADAPTER_ONLY); count(FXG_R_CLIP_NO_ADAPTER); count(FXG_R_CLIP_ADAPTER_FOUND);
+            count(FXG_R_CLIP_N); count(FXG_R_CLIP_K_MODE);
+            const u64 ao = __ballot(valid && ((w >> FXG_RES_ADAPTER_ONLY_BIT) & 1u));
+            if (lead && ao) atomicAdd(&tally[3], (u64)__builtin_popcountll(ao));
+        }
+        count(FXG_R_QTRIM); count(FXG_R_QFILTER);
+    } else if constexpr (MODE == 1 || MODE == 2) {
+        count(FXG_R_FTRIM);
+    } else if constexpr (MODE == 4) {
+        count(FXG_R_ARTIFACT); count(FXG_R_HAS_N);
+    }
+}
 
 // MODE 0: [clip][qtrim][qfilter] (AMAX = adapter bucket, 0 = no clip); MODE 1: fixed trim; MODE 2: reverse-complement [+ fixed trim];
 // MODE 3: fastq_masker; MODE 4: base census (fastx_artifacts_filter, fastq_to_fasta N-discard)
@@ -482,6 +515,8 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : ((AMAX < 0
     u32 *scratch = reinterpret_cast<u32 *>(smem + L.off_scratch);   // [0,2W) scan, then 4 words tile totals per slot, 2 tickets, 2 pad
     u32 *s_tot = scratch + 2 * FXG_TWAVES, *s_ticket = s_tot + 4;
     u64 *bc = reinterpret_cast<u64 *>(s_tot + 8);                   // [0,2) broadcast of the resolved bases
+    u64 *tally = reinterpret_cast<u64 *>(smem + L.off_tally);       // this workgroup's share of the -v report counters
+    if (tid < FXG_NTALLY) tally[tid] = 0ull;
 
     // One workgroup turns the tiles' totals into prefixes (fxg_scanner); the others process tiles.
     if (a.compact) {
@@ -522,15 +557,19 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : ((AMAX < 0
                 if constexpr (MODE == 4) fxg_phase_stage_bases(a.bases, a.total_bytes, tb, tbytes, sb, tid, FXG_TBLOCK);
                 __syncthreads();
             }
-            u32 keep = 0, olen = 0, anchor = tid * stride;
+            u32 keep = 0, olen = 0, anchor = tid * stride, word = 0;
             if (tid < nreads) {
-                if constexpr (MODE == 0) fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen);
-                else if constexpr (MODE == 3) { u32 nl; fxg_decide_mask(a, bm_l, r0, tid, &keep, &olen, &nl); m_nt += nl; m_reads += (nl != 0u); }
-                else if constexpr (MODE == 4) fxg_decide_census(a, sb + tid * stride, r0, tid, &keep, &olen, &art_bad);
-                else fxg_decide_b<REV>(a, r0, tid, &keep, &olen, &anchor);
+                if constexpr (MODE == 0) word = fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen);
+                else if constexpr (MODE == 3) { u32 nl; word = fxg_decide_mask(a, bm_l, r0, tid, &keep, &olen, &nl); m_nt += nl; m_reads += (nl != 0u); }
+                else if constexpr (MODE == 4) word = fxg_decide_census(a, sb + tid * stride, r0, tid, &keep, &olen, &art_bad);
+                else word = fxg_decide_b<REV>(a, r0, tid, &keep, &olen, &anchor);
             }
+            // the -v report counters (a12) are functions of res[]: tally the drop reasons this instance can produce, per wave, as the
+            // words go by (popcount of a ballot; one LDS add per wave and reason that occurred) instead of a second pass over res[]
+            fxg_tile_tally<AMAX, MODE>(word, tid < nreads, tally);
             u32 exc, exb, totc, totb;
             fxg_block_scan2(keep, keep ? olen : 0u, scratch, &exc, &exb, &totc, &totb);   // one __syncthreads inside
+            if (tid == 0) { tally[0] += nreads; tally[1] += totc; tally[2] += totb; }
             if (a.compact) {
                 if (tid == 0) fxg_publish_total(a, cur, totc, totb);     // as early as possible: the scanner and every later tile wait for it
                 u32 *k_off = reinterpret_cast<u32 *>(sl);
@@ -572,6 +611,8 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : ((AMAX < 0
         cur = s_ticket[tk] * G + grp;
         slot ^= 1u;
     }
+    __syncthreads();
+    if (tid < FXG_NTALLY && tally[tid]) atomicAdd(&a.tally[tid], tally[tid]);     // one global add per workgroup and non-zero slot
     if constexpr (MODE == 3) {                       // masked reads / nucleotides: wave sums, one atomic pair per wave, once
         for (int d = 32; d >= 1; d >>= 1) { m_reads += __shfl_xor(m_reads, d, 64); m_nt += __shfl_xor(m_nt, d, 64); }
         if (fxg_lane() == 0 && (m_reads | m_nt)) { atomicAdd(&a.extra[0], (u64)m_reads); atomicAdd(&a.extra[1], (u64)m_nt); }
@@ -579,58 +620,21 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : ((AMAX < 0
     if constexpr (MODE == 4) { if (art_bad) atomicOr(a.errflag, FXG_DEV_ERR_BAD_BASE); }
 }
 
-// res[] -> per-workgroup partial counters (the -v report inputs, a12)
-__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_count_res(const u32 *res, u64 n, u32 stages, u64 *partial)
+// tally slots of all workgroups -> counters[FXG_NCOUNTERS]; also folds the device error word and the masker sums in
+__global__ void fxg_kernel_finish_counters(const u64 *tally, u32 stages, const u32 *errflag, const u64 *extra, u64 *counters)
 {
-    __shared__ u64 acc[FXG_NCOUNTERS];
-    if (threadIdx.x < FXG_NCOUNTERS) acc[threadIdx.x] = 0ull;
-    __syncthreads();
+    if (threadIdx.x != 0) return;
     FxgCounts c = {};
-    const u64 nvec = n >> 2;                                   // res[] is 16-byte aligned (hipMalloc / torch): 4 words per load
-    const u32x4 *rv = reinterpret_cast<const u32x4 *>(res);
-    const u64 step = (u64)gridDim.x * FXG_BLOCK;
-    u64 i = (u64)blockIdx.x * FXG_BLOCK + threadIdx.x;
-    for (; i + 3 * step < nvec; i += 4 * step) {               // four independent 16-byte loads in flight per lane
-        const u32x4 w0 = rv[i], w1 = rv[i + step], w2 = rv[i + 2 * step], w3 = rv[i + 3 * step];
-        fxg_count_res(w0.x, c); fxg_count_res(w0.y, c); fxg_count_res(w0.z, c); fxg_count_res(w0.w, c);
-        fxg_count_res(w1.x, c); fxg_count_res(w1.y, c); fxg_count_res(w1.z, c); fxg_count_res(w1.w, c);
-        fxg_count_res(w2.x, c); fxg_count_res(w2.y, c); fxg_count_res(w2.z, c); fxg_count_res(w2.w, c);
-        fxg_count_res(w3.x, c); fxg_count_res(w3.y, c); fxg_count_res(w3.z, c); fxg_count_res(w3.w, c);
-    }
-    for (; i < nvec; i += step) {
-        const u32x4 w = rv[i];
-        fxg_count_res(w.x, c); fxg_count_res(w.y, c); fxg_count_res(w.z, c); fxg_count_res(w.w, c);
-    }
-    if (blockIdx.x == 0 && threadIdx.x < (u32)(n & 3u)) fxg_count_res(res[(nvec << 2) + threadIdx.x], c);
+    c.in = tally[0]; c.kept = tally[1]; c.bases = tally[2]; c.adapter_only = tally[3];
+    c.too_short = tally[4 + FXG_R_CLIP_TOO_SHORT]; c.no_adapter = tally[4 + FXG_R_CLIP_NO_ADAPTER]; c.adapter_found = tally[4 + FXG_R_CLIP_ADAPTER_FOUND];
+    c.has_n = tally[4 + FXG_R_CLIP_N]; c.qtrim = tally[4 + FXG_R_QTRIM]; c.qfilter = tally[4 + FXG_R_QFILTER]; c.ftrim = tally[4 + FXG_R_FTRIM];
+    c.k_mode = tally[4 + FXG_R_CLIP_K_MODE]; c.artifact = tally[4 + FXG_R_ARTIFACT];
     u64 slot[FXG_NCOUNTERS];
     fxg_counts_to_slots(c, stages, slot);
-#pragma unroll
-    for (int i = 0; i < FXG_NCOUNTERS; ++i)
-        if (slot[i]) atomicAdd(&acc[i], slot[i]);
-    __syncthreads();
-    if (threadIdx.x < FXG_NCOUNTERS) partial[(u64)blockIdx.x * FXG_NCOUNTERS + threadIdx.x] = acc[threadIdx.x];
-}
-
-// partial[rows][16] -> counters[16]; also folds the device error word into counters[FXG_C_ERRORS]
-__global__ void fxg_kernel_reduce_counters(const u64 *partial, u32 rows, const u32 *errflag, const u64 *extra, u64 *counters)
-{
-    __shared__ u64 acc[FXG_NCOUNTERS];
-    if (threadIdx.x < FXG_NCOUNTERS) acc[threadIdx.x] = 0ull;
-    __syncthreads();
-    if (threadIdx.x < (blockDim.x / FXG_NCOUNTERS) * FXG_NCOUNTERS) {
-        const u32 col = threadIdx.x % FXG_NCOUNTERS;
-        u64 s = 0;
-        for (u32 r = threadIdx.x / FXG_NCOUNTERS; r < rows; r += blockDim.x / FXG_NCOUNTERS) s += partial[(u64)r * FXG_NCOUNTERS + col];
-        if (s) atomicAdd(&acc[col], s);
-    }
-    __syncthreads();
-    if (threadIdx.x < FXG_NCOUNTERS) {
-        u64 v = acc[threadIdx.x];
-        if (threadIdx.x == FXG_C_ERRORS) v = (u64)*errflag;
-        if (threadIdx.x == FXG_C_MASKED_READS) v = extra[0];
-        if (threadIdx.x == FXG_C_MASKED_NT) v = extra[1];
-        counters[threadIdx.x] = v;
-    }
+    slot[FXG_C_ERRORS] = (u64)*errflag;
+    slot[FXG_C_MASKED_READS] = extra[0];
+    slot[FXG_C_MASKED_NT] = extra[1];
+    for (int i = 0; i < FXG_NCOUNTERS; ++i) counters[i] = slot[i];
 }
 
 // ------------------------------------------------------------------------------------------------
