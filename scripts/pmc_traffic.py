@@ -52,6 +52,8 @@ j = {
     "hbm_read_bytes_per_launch": int(rd), "hbm_write_bytes_per_launch": int(wr), "hbm_bytes_per_launch": int(rd + wr),
     "algorithmic_bytes_per_launch": R * 304 + 2 * kept_bytes,
     "tag": tag,
+    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python scripts/pmc_run.py",
+    "kernel_version": os.environ.get("KERNEL_VERSION", tag),
 }
 json.dump(j, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(j, indent=1))
