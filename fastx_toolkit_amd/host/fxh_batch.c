@@ -657,6 +657,7 @@ typedef struct fxh_lane {
     pthread_cond_t cv;
     int state;                             /* 0 idle, 1 job posted, 2 done, 3 quit */
     int ready;                             /* the context exists (created by the lane's own thread, off the main thread's path) */
+    struct fxh_lane *first;                /* lane 0: the others create their contexts after it (two threads inside the runtime's first-use initialisation take twice as long as one after the other) */
     fxh_state st;
     struct fxh_pinned *pinned;             /* input buffers already page-locked (shared by the lanes) */
     char *text_base; size_t text_cap;      /* the input buffer the job's text lives in */
@@ -753,6 +754,11 @@ static void fxh_lane_run(fxh_lane *ln)
 static void *fxh_lane_main(void *arg)
 {
     fxh_lane *ln = (fxh_lane *)arg;
+    if (ln->first && ln->first != ln) {
+        pthread_mutex_lock(&ln->first->mu);
+        while (!ln->first->ready) pthread_cond_wait(&ln->first->cv, &ln->first->mu);
+        pthread_mutex_unlock(&ln->first->mu);
+    }
     double t0 = fxh_now();
     int rc = fxg_ctx_create(ln->device, &ln->st.ctx);
     if (rc != 0) errx(1, "no usable MI355X/HIP device %d (fxg_ctx_create = %d); this build has no CPU path", ln->device, rc);
@@ -1116,7 +1122,7 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
         ln->id = i; ln->device = lane_dev[i]; ln->p = R->p; ln->revcomp = R->job.revcomp; ln->fwd_start = R->job.fwd_start;
         ln->qoffset = fx->fastq_ascii_quality_offset;
         ln->reverse = (R->p->stages & FXG_STAGE_REVCOMP) != 0; ln->lpr = R->job.lpr; ln->has_q = R->job.has_q; ln->out_fasta = !fx->write_fastq;
-        ln->pinned = &pinned;
+        ln->pinned = &pinned; ln->first = &lanes[0];
         if ((R->p->stages & FXG_STAGE_CLIP) && nlanes == 1) { ln->clip_history = 1; R->st_shared = 1; }
         pthread_mutex_init(&ln->mu, NULL); pthread_cond_init(&ln->cv, NULL);
         if (pthread_create(&ln->th, NULL, fxh_lane_main, ln) != 0) err(1, "pthread_create");

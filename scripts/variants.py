@@ -15,7 +15,8 @@ from fastx_toolkit_amd import build as _b  # noqa: E402
 
 VARIANTS = {            # edit freely: every entry becomes fastx_toolkit_amd/libfxg_v_<name>.so
     "base": [],
-    "clipw1": ["-DFXG_CLIP_WAVES=1"],      # clip instances without the 4-waves-per-SIMD register cap
+    "clipw5": ["-DFXG_CLIP_WAVES=5"],      # clip instances capped at 96 VGPRs (spills a little)
+    "clipw3": ["-DFXG_CLIP_WAVES=3"],
 }
 
 

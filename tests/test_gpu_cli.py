@@ -228,3 +228,19 @@ def test_flag_errors_and_usage_on_the_gpu_build(tools):
     assert rc == 0 and out == b""
     rc, out, err = _run([os.path.join(tools, "fastq_quality_filter"), "-q", "40"], b"@r\nACGT\n+\n!!!!\n")         # F2: -p omitted, everything passes
     assert rc == 0 and out == b"@r\nACGT\n+\n!!!!\n"
+
+
+def test_output_longer_than_input_and_ragged_blocks(tools):
+    """An empty third line still gets its '+' on output (fastx.c:460): dense 7-byte records grow by one byte each, so the formatted
+    block is longer than the text it came from; and one long read among short ones must not make the rows explode."""
+    data = b"@\nA\n\nI\n" * 300000
+    rc, out, err = _run([os.path.join(tools, "fastq_quality_trimmer"), "-t", "20", "-l", "1"], data, dict(os.environ, FXH_READ_BUFFER_MB="1"))
+    assert rc == 0 and out == b"@\nA\n+\nI\n" * 300000
+    rng = np.random.default_rng(6)
+    recs = [b"@s%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(100000)]
+    longr = b"@long\n" + rng.choice(np.frombuffer(b"ACGT", np.uint8), size=20000).tobytes() + b"\n+\n" + b"I" * 20000 + b"\n"
+    data = b"".join(recs[:50000]) + longr + b"".join(recs[50000:])
+    rc, out, err = _run([os.path.join(tools, "fastx_reverse_complement")], data)
+    assert rc == 0 and out.count(b"\n") == 4 * 100001
+    if REF:
+        assert out == _run([REF, "fastx_reverse_complement"], data)[1]

@@ -252,3 +252,20 @@ def test_regular_files_use_parallel_io_same_bytes(tools, tmp_path):
     with open(outp, "ab") as f:
         p = subprocess.run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp)], stdout=f, env=dict(os.environ, LD_LIBRARY_PATH=STUB_DIR, FXH_READ_BUFFER_MB="24"), timeout=120)
     assert p.returncode == 0 and outp.read_bytes() == b"HEAD\n" + want[1]
+
+
+def test_one_long_read_among_short_ones_does_not_blow_up_the_rows(tools):
+    """The SoA rows are n x longest read: the host path cuts a batch at a record boundary when one long read would make the rows
+    many times the size of the text (a 20 kb read among 200 k short ones would otherwise ask for gigabytes of pinned memory)."""
+    rng = np.random.default_rng(5)
+    recs = [b"@s%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(150000)]
+    longr = b"@long\n" + rng.choice(np.frombuffer(b"ACGT", np.uint8), size=20000).tobytes() + b"\n+\n" + b"I" * 20000 + b"\n"
+    data = b"".join(recs[:75000]) + longr + b"".join(recs[75000:]) + longr
+    for argv in (["fastq_quality_trimmer", "-t", "20", "-l", "5", "-v"], ["fastx_reverse_complement"]):
+        rc, out, err = _run([os.path.join(tools, argv[0])] + argv[1:], data, extra_env={"FXH_HOST_PARSE": "1", "FXH_TIMING": "1"})
+        assert rc == 0, err[-300:]
+        if REF:
+            rrc, rout, rerr = _run([REF] + argv, data)
+            assert (rc, out) == (rrc, rout)
+        else:
+            assert out.count(b"\n") == (4 * 150002 if argv[0] != "fastq_quality_trimmer" else out.count(b"\n"))
