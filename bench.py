@@ -304,7 +304,8 @@ def main():
     if args.config == "cfg2" and os.path.exists(pmc):
         try:
             pj = json.load(open(pmc))
-            if pj.get("reads_per_launch") == R and compact:
+            same_kernel = launch["kernel"].split(" ")[0].split("<")[0] in pj.get("kernel", "")      # the counters are of THIS kernel family
+            if pj.get("reads_per_launch") == R and compact and same_kernel:
                 traffic = pj.get("hbm_bytes_per_launch")
                 traffic_source = "replayed from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of %s, kernel %s); not measured in this run" % (
                     pj.get("command", "scripts/pmc_run.py"), pj.get("kernel_version", "as committed"))

@@ -56,7 +56,9 @@ struct FxgKArgs {
     // engine state
     u64 *agg;               // [ntiles]   tile totals   {tag:8 | kept reads:16 << 32 | kept bytes:32}, published by the tile's workgroup
     u64 *pfx;               // [2*ntiles] exclusive prefixes {tag:8 | value:56}: [2t] kept reads before tile t, [2t+1] kept bytes before it (scanner)
-    u32 *role;              // the workgroup that draws 0 here becomes the scanner
+    u64 *bbase;             // [2*nbatch] fxg_scanner_multi: (kept reads, kept bytes) of every batch of tiles, tagged like agg
+    u32  nscan;             // scanner waves of fxg_kernel_rows (1 = the single scanner of fxg_kernel_tiles)
+    u32 *role;              // the workgroups that draw the first numbers here become the scanners
     u32  tag;               // launch epoch 1..255: granules of earlier launches are invalid without a memset
     u64 *tally;             // [FXG_NTALLY] the launch's -v report tallies (zeroed with the control block)
     u32 *ticket;            // dynamic tile dispensers, FXG_TICKET_STRIDE words apart (zeroed before every launch)
@@ -110,6 +112,13 @@ FXG_HD u32 fxg_pack4(u32 f)
 
 FXG_HD u32 fxg_mask16(u32x4 v, u32 K)
 {
+#ifndef FXG_HOST_EMULATION
+    // the flags are bytes of 0x80: a dot product with the byte weights (1,2,4,8) / (16,32,64,128) gathers eight of them at a time
+    // (v_dot4_u32_u8 accumulates), 128 x the mask
+    const u32 lo = __builtin_amdgcn_udot4(fxg_ge_flags(v.x, K), 0x08040201u, __builtin_amdgcn_udot4(fxg_ge_flags(v.y, K), 0x80402010u, 0u, false), false);
+    const u32 hi = __builtin_amdgcn_udot4(fxg_ge_flags(v.z, K), 0x08040201u, __builtin_amdgcn_udot4(fxg_ge_flags(v.w, K), 0x80402010u, 0u, false), false);
+    return (lo >> 7) | (hi << 1);
+#endif
     return fxg_pack4(fxg_ge_flags(v.x, K)) | (fxg_pack4(fxg_ge_flags(v.y, K)) << 4) |
            (fxg_pack4(fxg_ge_flags(v.z, K)) << 8) | (fxg_pack4(fxg_ge_flags(v.w, K)) << 12);
 }
@@ -281,8 +290,22 @@ __device__ __forceinline__ bool fxg_spin_expired(const FxgKArgs &a, u64 t0)
     return false;
 }
 
-// executed by ONE wave
-__device__ __forceinline__ void fxg_scanner(const FxgKArgs &a)
+// inclusive prefix sum over the wave's 64 lanes without LDS or address registers: four row shifts, two row broadcasts (DPP)
+__device__ __forceinline__ u32 fxg_wave_scan_dpp(u32 x)
+{
+    u32 v = x;
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8  -> inclusive within rows of 16
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// executed by ONE wave; K = granules per lane and round trip
+template <int K>
+__device__ __forceinline__ void fxg_scanner_k(const FxgKArgs &a)
 {
     const u32 lane = fxg_lane();
     const u64 tagw = (u64)a.tag << FXG_TAG_SHIFT;
@@ -290,43 +313,121 @@ __device__ __forceinline__ void fxg_scanner(const FxgKArgs &a)
     u64 run_c = 0, run_b = 0;                               // exclusive prefix of tile t0
     u32 t0 = 0, spins = 0;
     u64 tlast = __builtin_amdgcn_s_memrealtime();
+#ifdef FXG_ABLATION
+    u64 sc_rounds = 0, sc_load = 0, sc_comp = 0, sc_t = __builtin_amdgcn_s_memrealtime();
+#endif
     while (t0 < a.ntiles) {
-        u64 v[FXG_SCAN_K];
+        u64 v[K];
 #pragma unroll
-        for (u32 k = 0; k < FXG_SCAN_K; ++k) {              // all loads of the round are in flight together
+        for (u32 k = 0; k < (u32)K; ++k) {                  // all loads of the round are in flight together
             const u64 idx = (u64)t0 + k * 64u + lane;
             v[k] = idx < a.ntiles ? fxg_granule_load(a.agg + idx) : 0ull;
         }
+#ifdef FXG_ABLATION
+        { u64 sink = 0; for (u32 k = 0; k < (u32)K; ++k) sink |= v[k]; asm volatile("" :: "v"(sink)); const u64 n_ = __builtin_amdgcn_s_memrealtime(); sc_load += n_ - sc_t; sc_t = n_; ++sc_rounds; }
+#endif
         u32 adv = 0;
         bool open = true;
 #pragma unroll
-        for (u32 k = 0; k < FXG_SCAN_K; ++k) {
+        for (u32 k = 0; k < (u32)K; ++k) {
             if (!open) continue;                            // wave-uniform
             const u64 idx = (u64)t0 + k * 64u + lane;
             const bool valid = idx < a.ntiles && (u32)(v[k] >> FXG_TAG_SHIFT) == a.tag;
             const u64 bal = __ballot(valid);
             const u32 m = bal == ~0ull ? 64u : (u32)__builtin_ctzll(~bal);      // leading run of published totals
             const u32 c = lane < m ? (u32)(v[k] >> 32) & 0xFFFFu : 0u, b = lane < m ? (u32)v[k] : 0u;
-            u32 ic = c, ib = b;                             // 64 tiles: at most 64 * 256 reads, 64 * 2^24 bytes
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const u32 tc = __shfl_up(ic, d, 64), tb = __shfl_up(ib, d, 64);
-                if ((int)lane >= d) { ic += tc; ib += tb; }
-            }
+            // 64 tiles: at most 64 * 256 reads, 64 * 2^24 bytes.  DPP scans: the shuffle form (12 dependent ds_bpermute per 64 tiles,
+            // ~13 000 cycles per 1024 tiles) capped the whole kernel near 140 tiles/us (profiles/r02/k_ablate.txt)
+            const u32 ic = fxg_wave_scan_dpp(c), ib = fxg_wave_scan_dpp(b);
             if (lane < m) {
                 fxg_granule_store_raw(a.pfx + 2 * idx, tagw | (run_c + (ic - c)));
                 fxg_granule_store_raw(a.pfx + 2 * idx + 1, tagw | (run_b + (ib - b)));
             }
-            run_c += __shfl(ic, 63, 64); run_b += __shfl(ib, 63, 64);
+            run_c += (u32)__builtin_amdgcn_readlane((int)ic, 63); run_b += (u32)__builtin_amdgcn_readlane((int)ib, 63);
             adv += m;
             open = (m == 64u);
         }
         t0 += adv;
+#ifdef FXG_ABLATION
+        { const u64 n_ = __builtin_amdgcn_s_memrealtime(); sc_comp += n_ - sc_t; sc_t = n_; }
+#endif
         if (adv) { spins = 0; tlast = __builtin_amdgcn_s_memrealtime(); continue; }
         __builtin_amdgcn_s_sleep(2);
         if ((++spins & 255u) == 0u && fxg_spin_expired(a, tlast)) return;   // never hang the GPU
     }
+#ifdef FXG_ABLATION
+    if (lane == 0) { u64 *d = reinterpret_cast<u64 *>(a.errflag + 10) + 8; d[0] = sc_rounds; d[1] = sc_load; d[2] = sc_comp; }
+#endif
 }
+
+// Several scanner waves (fxg_kernel_rows: 64-read tiles arrive four times as fast, and ONE wave's round trip -- 16 loads of 64
+// granules each behind its CU's streaming traffic, 6-7 us, then 2.3 us of scans -- capped the kernel near 110 tiles/us,
+// profiles/r02/v_ablate.txt).  Wave j of S takes the batches j, j + S, ... of 64 K tiles: it waits until the whole batch has
+// published, scans it locally and publishes the batch's TOTAL at once (bbase[2b], bbase[2b+1]).  The prefix at the start of its
+// batch b is then its own running prefix at the end of batch b - S plus the totals of the S - 1 batches in between, which the other
+// waves publish as soon as THEIR batches are complete: no wave waits for another wave's prefix, so there is no serial chain from
+// batch to batch -- only "every earlier tile has published", which a prefix needs anyway.  Every scanner wave is running by
+// construction (roles are drawn at kernel start) and waits only for totals of drawn tiles: progress as for the single scanner.
+template <int K>
+__device__ __forceinline__ void fxg_scanner_multi(const FxgKArgs &a, u32 j)
+{
+    const u32 lane = fxg_lane();
+    const u64 tagw = (u64)a.tag << FXG_TAG_SHIFT;
+    constexpr u32 BATCH = (u32)K * 64u;
+    const u32 nb = (a.ntiles + BATCH - 1u) / BATCH, S = a.nscan;
+    __builtin_amdgcn_s_setprio(3);
+    u64 end_c = 0, end_b = 0;                                   // this wave's prefix at the END of its previous batch (b - S)
+    for (u32 b = j; b < nb; b += S) {
+        const u32 t0 = b * BATCH;
+        u64 v[K];
+        u32 spins = 0;
+        const u64 tstart = __builtin_amdgcn_s_memrealtime();
+        for (;;) {                                              // until every tile of the batch has published its totals
+            u64 bad = 0;
+#pragma unroll
+            for (u32 k = 0; k < (u32)K; ++k) {
+                const u32 idx = t0 + k * 64u + lane;
+                v[k] = idx < a.ntiles ? fxg_granule_load(a.agg + idx) : tagw;          // past the last tile: published, nothing kept
+            }
+#pragma unroll
+            for (u32 k = 0; k < (u32)K; ++k) bad |= __ballot((u32)(v[k] >> FXG_TAG_SHIFT) != a.tag);
+            if (!bad) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 255u) == 0u && fxg_spin_expired(a, tstart)) return;
+        }
+        u32 exc[K], exb[K], rc = 0, rb = 0;                     // exclusive prefixes inside the batch; 64 K tiles of < 2^20 bytes each
+#pragma unroll
+        for (u32 k = 0; k < (u32)K; ++k) {
+            const u32 c = (u32)(v[k] >> 32) & 0xFFFFu, bb = (u32)v[k];
+            const u32 ic = fxg_wave_scan_dpp(c), ib = fxg_wave_scan_dpp(bb);
+            exc[k] = rc + ic - c; exb[k] = rb + ib - bb;
+            rc += (u32)__builtin_amdgcn_readlane((int)ic, 63); rb += (u32)__builtin_amdgcn_readlane((int)ib, 63);
+        }
+        if (lane < 2u) fxg_granule_store_raw(a.bbase + 2 * (u64)b + lane, tagw | (u64)(lane == 0u ? rc : rb));   // the batch's total: the other waves need it
+        // the totals of the batches between this wave's previous batch and this one (the first S batches: of all earlier ones)
+        const u32 first = b >= S ? b - S + 1u : 0u, cnt = b - first;
+        u64 wc = tagw, wb = tagw;
+        spins = 0;
+        const u64 t1 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            if (lane < cnt) { wc = fxg_granule_load(a.bbase + 2 * (u64)(first + lane)); wb = fxg_granule_load(a.bbase + 2 * (u64)(first + lane) + 1); }
+            if (__ballot((u32)(wc >> FXG_TAG_SHIFT) != a.tag || (u32)(wb >> FXG_TAG_SHIFT) != a.tag) == 0ull) break;
+            if ((++spins & 255u) == 0u && fxg_spin_expired(a, t1)) return;
+        }
+        const u32 sc = fxg_wave_scan_dpp(lane < cnt ? (u32)FXG_TAG_VALUE(wc) : 0u), sb = fxg_wave_scan_dpp(lane < cnt ? (u32)FXG_TAG_VALUE(wb) : 0u);
+        const u64 base_c = end_c + (u32)__builtin_amdgcn_readlane((int)sc, 63), base_b = end_b + (u32)__builtin_amdgcn_readlane((int)sb, 63);
+#pragma unroll
+        for (u32 k = 0; k < (u32)K; ++k) {
+            const u64 idx = (u64)t0 + k * 64u + lane;
+            if (idx < a.ntiles) {
+                fxg_granule_store_raw(a.pfx + 2 * idx, tagw | (base_c + exc[k]));
+                fxg_granule_store_raw(a.pfx + 2 * idx + 1, tagw | (base_b + exb[k]));
+            }
+        }
+        end_c = base_c + rc; end_b = base_b + rb;
+    }
+}
+__device__ __forceinline__ void fxg_scanner(const FxgKArgs &a) { fxg_scanner_k<FXG_SCAN_K>(a); }
 
 // executed by wave 0 of a tile's workgroup: lanes 0 / 1 fetch the tile's (reads, bytes) prefix; `peek` is an earlier load of it
 __device__ __forceinline__ u64 fxg_peek_prefix(const FxgKArgs &a, u32 tile)
@@ -348,18 +449,33 @@ __device__ __forceinline__ void fxg_wait_prefix(const FxgKArgs &a, u32 tile, u64
     if (lane < 2u) bc[lane] = FXG_TAG_VALUE(v);
 }
 
+// the same for a workgroup that IS one wave (fxg_rows.h): the prefix comes back in registers
+#ifndef FXG_POLL_SLEEP
+#define FXG_POLL_SLEEP 1
+#endif
+__device__ __forceinline__ void fxg_wait_prefix_wave(const FxgKArgs &a, u32 tile, u64 *bc)
+{
+    const u32 lane = fxg_lane();
+    u64 v = fxg_peek_prefix(a, tile);
+    u32 spins = 0;
+    const u64 t0 = __builtin_amdgcn_s_memrealtime();
+    while (__ballot((u32)(v >> FXG_TAG_SHIFT) != a.tag) != 0ull) {
+        __builtin_amdgcn_s_sleep(FXG_POLL_SLEEP);
+        if (lane < 2u) v = fxg_granule_load(a.pfx + 2 * (u64)tile + lane);
+        if ((++spins & 255u) == 0u && fxg_spin_expired(a, t0)) break;
+    }
+    v = FXG_TAG_VALUE(v);                                   // scalars from here on
+    bc[0] = ((u64)(u32)__builtin_amdgcn_readlane((int)(v >> 32), 0) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)v, 0);
+    bc[1] = ((u64)(u32)__builtin_amdgcn_readlane((int)(v >> 32), 1) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)v, 1);
+}
+
 // ------------------------------------------------------------------------------------------------
 // workgroup exclusive scan of (keep, out_len) over FXG_TBLOCK threads.  scratch: u32[2*FXG_TWAVES]
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void fxg_block_scan2(u32 c, u32 b, u32 *scratch, u32 *ex_c, u32 *ex_b, u32 *tot_c, u32 *tot_b)
 {
     const u32 lane = fxg_lane(), wave = threadIdx.x >> 6;
-    u32 ic = c, ib = b;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u32 tc = __shfl_up(ic, d, 64), tb = __shfl_up(ib, d, 64);
-        if ((int)lane >= d) { ic += tc; ib += tb; }
-    }
+    const u32 ic = fxg_wave_scan_dpp(c), ib = fxg_wave_scan_dpp(b);
     if (lane == 63) { scratch[wave] = ic; scratch[FXG_TWAVES + wave] = ib; }
     __syncthreads();
     u32 oc = 0, ob = 0, sc = 0, sb = 0;

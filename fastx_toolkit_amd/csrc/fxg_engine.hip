@@ -12,6 +12,7 @@
 #include "fxg_text.h"
 #include "fxg_history.h"
 #include "fxg_stats.h"
+#include "fxg_rows.h"
 
 struct fxg_ctx {
     int device;
@@ -21,7 +22,7 @@ struct fxg_ctx {
     hipEvent_t ev0, ev1;
     hipEvent_t kev0, kev1;  // around the dominant kernel when profiling
     int profiling, kev_valid;
-    u64 *status;            // 3 * status_cap granules: tile totals [cap], prefixes [2 * cap]
+    u64 *status;            // FXG_STATUS_WORDS(status_cap) granules: tile totals [cap], prefixes [2 * cap], batch bases
     size_t status_cap;      // in tiles
     u32 epoch;              // tag of the granules of the current launch (1..255); 0 = never valid
     void *attr_kernel[8];   // kernels whose launch attributes were set, with the LDS size and the occupancy answer
@@ -189,12 +190,12 @@ extern "C" int fxg_timer_stop(fxg_ctx *c, float *ms)
 
 // dynamic-LDS attribute and occupancy of a kernel: asked once per (kernel, LDS size), not per launch
 template <typename K>
-static int fxg_kernel_fit(fxg_ctx *c, K kernel, const char *kname, u32 lds, int *per_cu)
+static int fxg_kernel_fit(fxg_ctx *c, K kernel, const char *kname, u32 lds, int *per_cu, u32 block = FXG_TBLOCK)
 {
     for (int i = 0; i < 8; ++i)
         if (c->attr_kernel[i] == (void *)kernel && c->attr_lds[i] == lds) { *per_cu = c->attr_per_cu[i]; return FXG_OK; }
     FXG_HIP(c, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    FXG_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kernel, FXG_TBLOCK, lds));
+    FXG_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kernel, (int)block, lds));
     if (*per_cu < 1) return fxg_fail(c, FXG_E_INVALID, "%s does not fit on a CU (lds=%u)", kname, lds);
     int slot = 0;
     for (int i = 0; i < 8; ++i) if (!c->attr_kernel[i]) { slot = i; break; }
@@ -202,20 +203,26 @@ static int fxg_kernel_fit(fxg_ctx *c, K kernel, const char *kname, u32 lds, int 
     return FXG_OK;
 }
 
+// u64 words of the inter-workgroup state for `cap` tiles: totals, two prefixes per tile, two per scanner batch (batches of >= 256 tiles)
+#define FXG_STATUS_WORDS(cap) (3 * (size_t)(cap) + 2 * ((size_t)(cap) / 256 + 2))
+
 template <typename K>
-static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &ka, u32 lds, u64 *counters)
+static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &ka, u32 lds, u64 *counters, u32 block = FXG_TBLOCK)
 {
     FXG_HIP(c, hipSetDevice(c->device));
     int per_cu = 0;
-    const int frc = fxg_kernel_fit(c, kernel, kname, lds, &per_cu);
+    const int frc = fxg_kernel_fit(c, kernel, kname, lds, &per_cu, block);
     if (frc != FXG_OK) return frc;
     // Tiles are dispensed by ticket, so nothing depends on every workgroup being resident: fill the chip.
-    int use = per_cu > 8 ? 8 : per_cu;
+    const int most = block == 64u ? 16 : 8;      // single-wave workgroups (fxg_rows.h): the LDS allows sixteen per CU
+    int use = per_cu > most ? most : per_cu;
     if (c->env_blocks_per_cu > 0) use = c->env_blocks_per_cu;
     u64 workers = (u64)c->cus * (u64)use;
     if (workers > ka.ntiles) workers = ka.ntiles;
     if (workers < 1) workers = 1;
-    const u64 grid = workers + (ka.compact ? 1u : 0u);     // one more workgroup: the scanner (fxg_device.h)
+    // more workgroups: the scanner(s) (fxg_device.h); fxg_kernel_rows runs several once there is work for them
+    ka.nscan = !ka.compact ? 0u : (block == 64u && workers >= 64u * FXG_ROWS_NSCAN ? (u32)FXG_ROWS_NSCAN : 1u);
+    const u64 grid = workers + ka.nscan;
 
     if (ka.compact) {
         bool fresh = false;
@@ -223,15 +230,16 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
             (void)hipFree(c->status);
             c->status = nullptr; c->status_cap = 0;
             size_t cap = (size_t)ka.ntiles + (size_t)ka.ntiles / 4 + 1024;
-            FXG_HIP(c, hipMalloc((void **)&c->status, 3 * cap * sizeof(u64)));
+            FXG_HIP(c, hipMalloc((void **)&c->status, FXG_STATUS_WORDS(cap) * sizeof(u64)));
             c->status_cap = cap;
             fresh = true;
         }
         // granules carry the launch's epoch, so the arrays are only cleared when they are new or the 8-bit epoch wraps
         c->epoch = c->epoch >= 255u ? 1u : c->epoch + 1u;
-        if (fresh || c->epoch == 1u) FXG_HIP(c, hipMemsetAsync(c->status, 0, 3 * c->status_cap * sizeof(u64), c->stream));
+        if (fresh || c->epoch == 1u) FXG_HIP(c, hipMemsetAsync(c->status, 0, FXG_STATUS_WORDS(c->status_cap) * sizeof(u64), c->stream));
         ka.agg = c->status;
         ka.pfx = c->status + c->status_cap;
+        ka.bbase = c->status + 3 * c->status_cap;
         ka.tag = c->epoch;
     }
 #ifdef FXG_ABLATION
@@ -243,12 +251,12 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
     ka.role = c->errflag + 8;
     ka.tally = (u64 *)(c->errflag + 32);
     // Dispenser g serves the workgroups with blockIdx % groups == g, so every group needs a worker even if the scanner role
-    // falls to one of its members: eight groups only when each has at least two workgroups.
-    { u32 g = c->env_ticket_groups > 0 ? (u32)c->env_ticket_groups : FXG_TICKET_GROUPS; ka.ticket_groups = grid >= 2u * g ? g : 1u; }
+    // falls to its members: eight groups only when each has more workgroups than there are scanners.
+    { u32 g = c->env_ticket_groups > 0 ? (u32)c->env_ticket_groups : FXG_TICKET_GROUPS; ka.ticket_groups = grid >= (u64)(ka.nscan + 1u) * g ? g : 1u; }
     FXG_HIP(c, hipMemsetAsync(c->errflag, 0, (FXG_CTRL_WORDS + FXG_TICKET_GROUPS * FXG_TICKET_STRIDE) * sizeof(u32), c->stream));
 
     if (c->profiling) FXG_HIP(c, hipEventRecord(c->kev0, c->stream));
-    hipLaunchKernelGGL(kernel, dim3((u32)grid), dim3(FXG_TBLOCK), lds, c->stream, ka);
+    hipLaunchKernelGGL(kernel, dim3((u32)grid), dim3(block), lds, c->stream, ka);
     FXG_HIP(c, hipGetLastError());
     if (c->profiling) { FXG_HIP(c, hipEventRecord(c->kev1, c->stream)); c->kev_valid = 1; }
     // -v report counters: the tile kernel tallied them; one tiny kernel lays them out
@@ -256,7 +264,7 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
                        (const u64 *)(c->errflag + 2), counters ? counters : c->counters_scratch);
     FXG_HIP(c, hipGetLastError());
     snprintf(c->last_kernel, sizeof c->last_kernel, "%s", kname);
-    c->last_grid = (u32)grid; c->last_block = FXG_TBLOCK; c->last_lds = lds; c->last_tile = ka.tile_reads;
+    c->last_grid = (u32)grid; c->last_block = block; c->last_lds = lds; c->last_tile = ka.tile_reads;
     return FXG_OK;
 }
 
@@ -347,6 +355,13 @@ extern "C" int fxg_run_pipeline(fxg_ctx *c, const fxg_batch *in, const fxg_param
     }
     u64 *ctr = (u64 *)out->counters;
 #define FXG_TILES_A(N) (fxg_kernel_tiles<N, 0>)
+    if (pl.rows_nw) {       // reads up to 152 bytes through the quality stages: one lane per read, rows in registers (fxg_rows.h)
+        switch (pl.rows_nw) {
+        case 10: return fxg_launch_tiles(c, fxg_kernel_rows<10>, "fxg_kernel_rows<10> qtrim+qfilter", pl.ka, pl.lds, ctr, 64u);
+        case 26: return fxg_launch_tiles(c, fxg_kernel_rows<26>, "fxg_kernel_rows<26> qtrim+qfilter", pl.ka, pl.lds, ctr, 64u);
+        default: return fxg_launch_tiles(c, fxg_kernel_rows<38>, "fxg_kernel_rows<38> qtrim+qfilter", pl.ka, pl.lds, ctr, 64u);
+        }
+    }
     if (pl.group_a) {
         switch (pl.amax) {
         case 0: return fxg_launch_tiles(c, FXG_TILES_A(0), "fxg_kernel_tiles<0,0> qtrim+qfilter", pl.ka, pl.lds, ctr);
@@ -729,6 +744,17 @@ extern "C" int fxg_set_profiling(fxg_ctx *c, int enabled)
     c->kev_valid = 0;
     return FXG_OK;
 }
+
+#ifdef FXG_ABLATION
+// timing experiments only (scripts/ablate.py): the phase clocks fxg_kernel_rows adds up in the control block, words 10..
+extern "C" int fxg_debug_phase_clocks(fxg_ctx *c, uint64_t out[11])
+{
+    if (!c || !out) return FXG_E_INVALID;
+    FXG_HIP(c, hipStreamSynchronize(c->stream));
+    FXG_HIP(c, hipMemcpy(out, c->errflag + 10, 11 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return FXG_OK;
+}
+#endif
 
 extern "C" int fxg_last_kernel_ms(fxg_ctx *c, float *ms)
 {

@@ -320,6 +320,7 @@ FXG_HD void fxg_counts_to_slots(const FxgCounts &c, u32 stages, u64 *slot)
 FXG_HD void fxg_phase_bitmaps(const FxgKArgs &a, u64 tb, u32 tbytes, u32 *bm_g, u32 *bm_l, u32 tid, u32 nthreads)
 {
     const u32 Kg = (128u - a.tq) * 0x01010101u, Kf = (128u - a.fq) * 0x01010101u;
+    const bool same = a.tq == a.fq;      // trimmer and filter at the same threshold (the usual pipe): "below" is the complement of "at least"
     const u32 nchunks = (tbytes + 15u) >> 4;
     uint16_t *g16 = reinterpret_cast<uint16_t *>(bm_g), *l16 = reinterpret_cast<uint16_t *>(bm_l);
     const uint8_t *src = a.qual + tb;
@@ -335,7 +336,7 @@ FXG_HD void fxg_phase_bitmaps(const FxgKArgs &a, u64 tb, u32 tbytes, u32 *bm_g, 
 #pragma unroll
             for (u32 u = 0; u < U; ++u) {
                 const u32 c = c0 + u * nthreads;
-                if (c < nchunks) { g16[c] = (uint16_t)fxg_mask16(v[u], Kg); l16[c] = (uint16_t)(~fxg_mask16(v[u], Kf)); }
+                if (c < nchunks) { const u32 g = fxg_mask16(v[u], Kg); g16[c] = (uint16_t)g; l16[c] = (uint16_t)(~(same ? g : fxg_mask16(v[u], Kf))); }
             }
         }
         return;

@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "fxg_kernels.h"
+#include "fxg_rows.h"
 
 struct FxgPlan {
     FxgKArgs ka;
@@ -14,6 +15,7 @@ struct FxgPlan {
     bool mask, artifacts;
     int  amax;      // adapter bucket of the clip kernel instance (0 = no clip)
     u32  lds;       // dynamic LDS bytes per workgroup
+    int  rows_nw;   // != 0: the quality stages run as fxg_kernel_rows<rows_nw> (fxg_rows.h): dwords of one read's row
 };
 
 static inline int fxg_clampi(long long v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : (int)v); }
@@ -104,10 +106,14 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
         for (unsigned i = 0; i < sizeof pk / sizeof pk[0]; ++i) if (ka.alen <= pk[i]) { b = pk[i]; break; }
         pl->amax = -b;
     }
-    const u32 T = fxg_pick_tile(pl->clip ? ka.clip_stride : in->stride, pl->clip || gf);
+    // quality trim / filter with compaction over reads of up to 152 bytes: one lane per read, 64 reads per tile (fxg_rows.h)
+    pl->rows_nw = 0;
+    if (ga && !pl->clip && ka.compact && in->stride <= 152u && !(getenv("FXG_ROWS") && atoi(getenv("FXG_ROWS")) == 0))
+        pl->rows_nw = in->stride <= 40u ? 10 : in->stride <= 104u ? 26 : 38;
+    const u32 T = pl->rows_nw ? 64u : fxg_pick_tile(pl->clip ? ka.clip_stride : in->stride, pl->clip || gf);
     const u64 ntiles = (in->n + T - 1) / T;
     if (ntiles > 0x7FFFFFFFull || in->n > 0xFFFFFFFFull) FXG_PLAN_FAIL("batch too large (%llu reads): split it", (unsigned long long)in->n);
     ka.tile_reads = T; ka.ntiles = (u32)ntiles;
-    pl->lds = fxg_plan_lds(pl);
+    pl->lds = pl->rows_nw ? fxg_rows_lds(ka.stride) : fxg_plan_lds(pl);
     return FXG_OK;
 }

@@ -23,7 +23,7 @@ P = (make_params(stages=24, ft_first=5, ft_last=145) if CFG == "cfg4"
      else make_params(stages=6, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80))
 outs = eng.alloc_outputs(R, 150, compact=True, meta=False)
 eng.sync()
-KNOBS = ("FXG_DEBUG", "FXG_TILE", "FXG_BLOCKS_PER_CU", "FXG_TICKET_GROUPS", "FXG_QLDS", "FXG_QLDS_BUDGET")
+KNOBS = ("FXG_DEBUG", "FXG_ROWS", "FXG_TILE", "FXG_BLOCKS_PER_CU", "FXG_TICKET_GROUPS", "FXG_QLDS", "FXG_QLDS_BUDGET")
 
 
 def t(label, env, compact=True, reps=4):
@@ -38,6 +38,17 @@ def t(label, env, compact=True, reps=4):
         ms.append(e.last_kernel_ms())
     c = r.counters
     li = e.last_launch()
+    if hasattr(e.lib, "fxg_debug_phase_clocks") and compact:
+        import ctypes
+        ph = (ctypes.c_uint64 * 11)()
+        e.lib.fxg_debug_phase_clocks(e.ctx, ph)
+        waves = li["grid"] - 1
+        names = ("fetch-q", "decide", "wait", "flush-q", "fetch-b", "flush-b", "pack-q", "read+pack-b")
+        if "rows" in li["kernel"]:
+            print("   per wave, ms: " + "  ".join("%s %.2f" % (nm, x / 1e5 / waves) for nm, x in zip(names, ph)), flush=True)
+        if ph[8]:
+            print("   scanner: %d rounds, %.0f tiles/round, load wait %.2f us/round, scan %.2f us/round, total %.2f ms" %
+                  (ph[8], (R + 63) // 64 / ph[8], ph[9] / 100.0 / ph[8], ph[10] / 100.0 / ph[8], (ph[9] + ph[10]) / 1e5), flush=True)
     print(json.dumps(dict(label=label, ms_min=round(min(ms), 3), ms_avg=round(sum(ms) / len(ms), 3), grid=li["grid"], tile=li["tile_reads"], lds=li["lds"],
                           kept=int(c[1]), kept_bases=int(c[2]), err=int(c[15]))), flush=True)
     e.close()

@@ -22,7 +22,7 @@ R = int(os.environ.get("READS", "50000000"))
 out = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     d = load(os.path.join(src, ctr))
-    tiles = [k for k in d if "fxg_kernel_tiles" in k]
+    tiles = [k for k in d if "fxg_kernel_rows" in k] or [k for k in d if "fxg_kernel_tiles" in k]   # the kernel cfg2 ran as
     clone = [k for k in d if "elementwise" in k.lower() or "copy" in k.lower()]
     assert tiles, list(d)
     v = d[tiles[0]][ctr]

@@ -14,9 +14,10 @@ sys.path.insert(0, ROOT)
 from fastx_toolkit_amd import build as _b  # noqa: E402
 
 VARIANTS = {            # edit freely: every entry becomes fastx_toolkit_amd/libfxg_v_<name>.so
-    "base": [],
-    "clipw5": ["-DFXG_CLIP_WAVES=5"],      # clip instances capped at 96 VGPRs (spills a little)
-    "clipw3": ["-DFXG_CLIP_WAVES=3"],
+    "abl": ["-DFXG_ABLATION"],
+    "abl_nonts": ["-DFXG_ABLATION", "-DFXG_V_NO_NTS"],
+    "abl_ldnt": ["-DFXG_ABLATION", "-DFXG_ROWS_LD_AUX=2"],
+    "abl_ldnt_nonts": ["-DFXG_ABLATION", "-DFXG_ROWS_LD_AUX=2", "-DFXG_V_NO_NTS"],
 }
 
 

@@ -18,7 +18,7 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
 {
     const FxgKArgs &a = pl.ka;
     const u32 T = a.tile_reads, stride = a.stride, NT = FXG_TBLOCK;
-    std::vector<unsigned char> lds(pl.lds + 64, 0);
+    std::vector<unsigned char> lds(fxg_plan_lds(&pl) + 64, 0);   // the general tile layout, also where the engine would pick fxg_kernel_rows
     unsigned char *smem = lds.data();
     const FxgLds L = fxg_plan_layout(&pl);
     u64 m_reads = 0, m_nt = 0;
