@@ -48,7 +48,7 @@ j = {
     "WRITE_SIZE_KB_per_launch": round(out["WRITE_SIZE"]["per_launch_kb"], 1),
     "calibration": {"workload": "1 GiB torch clone in the same rocprofv3 run", "FETCH_SIZE_reported_fraction": round(fcal, 4),
                     "WRITE_SIZE_reported_fraction": round(wcal, 4),
-                    "note": "counters divided by the fraction the 1 GiB clone reports; the read correction is applied to the unaligned 16 B window loads of the gather as well (uncalibrated for that pattern); Infinity-Cache hits are counted"},
+                    "note": "counters divided by the fraction the 1 GiB clone reports" + ("" if "rows" in out["FETCH_SIZE"]["kernel"] else "; the read correction is applied to the unaligned 16 B window loads of the gather as well (uncalibrated for that pattern)") + "; Infinity-Cache hits are counted"},
     "hbm_read_bytes_per_launch": int(rd), "hbm_write_bytes_per_launch": int(wr), "hbm_bytes_per_launch": int(rd + wr),
     "algorithmic_bytes_per_launch": R * 304 + 2 * kept_bytes,
     "tag": tag,
