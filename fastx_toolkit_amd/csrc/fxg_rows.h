@@ -38,6 +38,81 @@
 // staging buffer: the tile's rows + slack (every lane reads and packs a full register row, up to 156 bytes, whatever the stride)
 __host__ __device__ inline u32 fxg_rows_lds(u32 stride) { return fxg_r16(FXG_ROWS_T * stride) + 176u; }
 
+// The lane's row -> its own threshold bitmap, bit i = (byte i >= thr), K = (128 - thr) * 0x01010101 (fxg_ge_flags).  Two dwords at a
+// time: the flags are bytes of 0x80 and a dot product with the byte weights (1,2,4,8) / (16,32,64,128) gathers eight of them
+// (v_dot4_u32_u8 accumulates), 128 x the byte of the bitmap.
+template <int NW>
+FXG_HD void fxg_rows_bits(const u32 (&row)[NW], u32 K, u32 (&M)[(NW * 4 + 31) / 32])
+{
+#pragma unroll
+    for (int p = 0; p < (NW + 1) / 2; ++p) {
+        const u32 f0 = fxg_ge_flags(row[2 * p], K), f1 = 2 * p + 1 < NW ? fxg_ge_flags(row[2 * p + 1], K) : 0u;
+#ifndef FXG_HOST_EMULATION
+        const u32 b = __builtin_amdgcn_udot4(f1, 0x80402010u, __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false), false);
+#else       // the same sum of products, spelled out (tests/emu)
+        u32 b = 0;
+        for (int i = 0; i < 4; ++i) b += ((f0 >> (8 * i)) & 0xFFu) * (1u << i) + ((f1 >> (8 * i)) & 0xFFu) * (16u << i);
+#endif
+        if ((p & 3) == 0) M[p >> 2] = b >> 7;
+        else M[p >> 2] |= b << (8 * (p & 3) - 7);
+    }
+}
+// 1 + the highest set bit below `len`, 0 when there is none (fxg_bits_last on a bitmap that starts at bit 0 and lives in registers)
+template <int NM>
+FXG_HD u32 fxg_rows_last(const u32 (&M)[NM], u32 len)
+{
+    u32 r = 0;
+#pragma unroll
+    for (int w = 0; w < NM; ++w) {
+        const int nb = (int)len - 32 * w;
+        const u32 x = nb >= 32 ? M[w] : nb > 0 ? M[w] & ((1u << nb) - 1u) : 0u;
+        r = x ? 32u * (u32)w + 32u - (u32)__builtin_clz(x | 1u) : r;
+    }
+    return r;
+}
+// set bits below `len` (fxg_bits_count)
+template <int NM>
+FXG_HD u32 fxg_rows_count(const u32 (&M)[NM], u32 len, bool invert)
+{
+    u32 c = 0;
+#pragma unroll
+    for (int w = 0; w < NM; ++w) {
+        const int nb = (int)len - 32 * w;
+        const u32 m = invert ? ~M[w] : M[w];
+        c += (u32)__builtin_popcount(nb >= 32 ? m : nb > 0 ? m & ((1u << nb) - 1u) : 0u);
+    }
+    return c;
+}
+
+// fxg_decide_a<0> for a lane that holds its read's quality row in registers: quality trim, then quality filter.
+template <int NW>
+FXG_HD u32 fxg_rows_decide(const FxgKArgs &a, const u32 (&q)[NW], u32 read, u32 *keep_out, u32 *len_out)
+{
+    constexpr int NM = (NW * 4 + 31) / 32;
+    const u32 rl = a.len ? (u32)a.len[read] : a.fixed_len;
+    u32 reason = FXG_R_KEPT, keep = 1, curlen = rl;
+    u32 G[NM];
+    const bool trim = (a.stages & FXG_STAGE_QTRIM) != 0u, filt = (a.stages & FXG_STAGE_QFILTER) != 0u, same = a.tq == a.fq;
+    if (trim || same) fxg_rows_bits<NW>(q, (128u - a.tq) * 0x01010101u, G);
+    if (trim) {                                               // fastq_quality_trimmer.c:94-101
+        const u32 k = fxg_rows_last<NM>(G, curlen);
+        curlen = k;
+        if (!(k > 0 && (int)k >= a.qt_min_len)) { keep = 0; reason = FXG_R_QTRIM; }
+    }
+    if (filt) {                                               // fastq_quality_filter.c:110-129,155 in closed form
+        u32 low;
+        if (trim || same) { if (same) low = fxg_rows_count<NM>(G, curlen, true); else { u32 F[NM]; fxg_rows_bits<NW>(q, (128u - a.fq) * 0x01010101u, F); low = fxg_rows_count<NM>(F, curlen, true); } }
+        else { u32 F[NM]; fxg_rows_bits<NW>(q, (128u - a.fq) * 0x01010101u, F); low = fxg_rows_count<NM>(F, curlen, true); }
+        int n0 = (int)curlen * a.qf_keep_pct / 100;
+        if (n0 < 0) n0 = 0;
+        if (keep && (a.qf_drop_all || (int)low > n0)) { keep = 0; reason = FXG_R_QFILTER; }
+    }
+    const u32 w = (curlen & 0xFFFFu) | (keep << 16) | (reason << 17);
+    a.res[read] = w;
+    *keep_out = keep; *len_out = curlen;
+    return w;
+}
+
 #ifndef FXG_HOST_EMULATION
 // A workgroup is ONE wave: its LDS accesses execute in order, so "every lane's reads / writes before this point are done" needs no
 // barrier, only the wave's own LDS counter at zero and the compiler kept from moving accesses across the point.
@@ -73,76 +148,6 @@ __device__ __forceinline__ void fxg_rows_landed()
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     FXG_WAVE_SYNC();
-}
-
-// The lane's row -> its own threshold bitmap, bit i = (byte i >= thr), K = (128 - thr) * 0x01010101 (fxg_ge_flags).  Two dwords at a
-// time: the flags are bytes of 0x80 and a dot product with the byte weights (1,2,4,8) / (16,32,64,128) gathers eight of them
-// (v_dot4_u32_u8 accumulates), 128 x the byte of the bitmap.
-template <int NW>
-__device__ __forceinline__ void fxg_rows_bits(const u32 (&row)[NW], u32 K, u32 (&M)[(NW * 4 + 31) / 32])
-{
-#pragma unroll
-    for (int p = 0; p < (NW + 1) / 2; ++p) {
-        const u32 f0 = fxg_ge_flags(row[2 * p], K), f1 = 2 * p + 1 < NW ? fxg_ge_flags(row[2 * p + 1], K) : 0u;
-        const u32 b = __builtin_amdgcn_udot4(f1, 0x80402010u, __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false), false);
-        if ((p & 3) == 0) M[p >> 2] = b >> 7;
-        else M[p >> 2] |= b << (8 * (p & 3) - 7);
-    }
-}
-// 1 + the highest set bit below `len`, 0 when there is none (fxg_bits_last on a bitmap that starts at bit 0 and lives in registers)
-template <int NM>
-__device__ __forceinline__ u32 fxg_rows_last(const u32 (&M)[NM], u32 len)
-{
-    u32 r = 0;
-#pragma unroll
-    for (int w = 0; w < NM; ++w) {
-        const int nb = (int)len - 32 * w;
-        const u32 x = nb >= 32 ? M[w] : nb > 0 ? M[w] & ((1u << nb) - 1u) : 0u;
-        r = x ? 32u * (u32)w + 32u - (u32)__builtin_clz(x) : r;
-    }
-    return r;
-}
-// set bits below `len` (fxg_bits_count)
-template <int NM>
-__device__ __forceinline__ u32 fxg_rows_count(const u32 (&M)[NM], u32 len, bool invert)
-{
-    u32 c = 0;
-#pragma unroll
-    for (int w = 0; w < NM; ++w) {
-        const int nb = (int)len - 32 * w;
-        const u32 m = invert ? ~M[w] : M[w];
-        c += (u32)__builtin_popcount(nb >= 32 ? m : nb > 0 ? m & ((1u << nb) - 1u) : 0u);
-    }
-    return c;
-}
-
-// fxg_decide_a<0> for a lane that holds its read's quality row in registers: quality trim, then quality filter.
-template <int NW>
-__device__ __forceinline__ u32 fxg_rows_decide(const FxgKArgs &a, const u32 (&q)[NW], u32 read, u32 *keep_out, u32 *len_out)
-{
-    constexpr int NM = (NW * 4 + 31) / 32;
-    const u32 rl = a.len ? (u32)a.len[read] : a.fixed_len;
-    u32 reason = FXG_R_KEPT, keep = 1, curlen = rl;
-    u32 G[NM];
-    const bool trim = (a.stages & FXG_STAGE_QTRIM) != 0u, filt = (a.stages & FXG_STAGE_QFILTER) != 0u, same = a.tq == a.fq;
-    if (trim || same) fxg_rows_bits<NW>(q, (128u - a.tq) * 0x01010101u, G);
-    if (trim) {                                               // fastq_quality_trimmer.c:94-101
-        const u32 k = fxg_rows_last<NM>(G, curlen);
-        curlen = k;
-        if (!(k > 0 && (int)k >= a.qt_min_len)) { keep = 0; reason = FXG_R_QTRIM; }
-    }
-    if (filt) {                                               // fastq_quality_filter.c:110-129,155 in closed form
-        u32 low;
-        if (trim || same) { if (same) low = fxg_rows_count<NM>(G, curlen, true); else { u32 F[NM]; fxg_rows_bits<NW>(q, (128u - a.fq) * 0x01010101u, F); low = fxg_rows_count<NM>(F, curlen, true); } }
-        else { u32 F[NM]; fxg_rows_bits<NW>(q, (128u - a.fq) * 0x01010101u, F); low = fxg_rows_count<NM>(F, curlen, true); }
-        int n0 = (int)curlen * a.qf_keep_pct / 100;
-        if (n0 < 0) n0 = 0;
-        if (keep && (a.qf_drop_all || (int)low > n0)) { keep = 0; reason = FXG_R_QFILTER; }
-    }
-    const u32 w = (curlen & 0xFFFFu) | (keep << 16) | (reason << 17);
-    a.res[read] = w;
-    *keep_out = keep; *len_out = curlen;
-    return w;
 }
 
 // staging buffer -> row[] of the lane's own read: dwords from the 4-byte aligned address below its first byte, shifted down by the odd bytes

@@ -11,8 +11,6 @@ echo "== gpu tests"
 timeout 1500 python -m pytest tests -m gpu -q --durations=5 2>&1 | tail -12 | tee $O/pytest.txt
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu.ids | tail -3 | tee $O/smoke.txt
-echo "== rows vs tiles"
-timeout 300 python scripts/rows_vs_tiles.py 2>&1 | grep -v amdgpu.ids | tail -3 | tee $O/rvt.txt
 echo "== bench (default = rows), then the tile kernel, twice each"
 for i in 1 2; do
 timeout 900 python bench.py --steps 20 --warmup 3 2>&1 | grep -v amdgpu.ids | tee $O/bench_cfg2_$i.json | cut -c1-200

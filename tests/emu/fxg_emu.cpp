@@ -13,6 +13,28 @@
 #include "../../fastx_toolkit_amd/csrc/fxg_history.h"
 #include "../../fastx_toolkit_amd/csrc/fxg_stats.h"
 
+// fxg_kernel_rows: the lane holds its read's quality row in NW registers (bytes past the row: whatever follows in the staging buffer)
+template <int NW>
+static void emu_rows_decide_nw(const FxgKArgs &a, u32 read, u32 *keep, u32 *olen)
+{
+    u32 q[NW];
+    for (int k = 0; k < NW; ++k) {
+        u32 w = 0;
+        for (int i = 0; i < 4; ++i) {
+            const u64 at = (u64)read * a.stride + 4u * (u32)k + (u32)i;
+            w |= (u32)(at < a.total_bytes ? a.qual[at] : 0xA5u) << (8 * i);
+        }
+        q[k] = w;
+    }
+    fxg_rows_decide<NW>(a, q, read, keep, olen);
+}
+static void emu_rows_decide(int nw, const FxgKArgs &a, u32 read, u32 *keep, u32 *olen)
+{
+    if (nw == 10) emu_rows_decide_nw<10>(a, read, keep, olen);
+    else if (nw == 26) emu_rows_decide_nw<26>(a, read, keep, olen);
+    else emu_rows_decide_nw<38>(a, read, keep, olen);
+}
+
 template <int AMAX, bool REV, int MODE = 0>
 static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
 {
@@ -44,7 +66,8 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
                 if constexpr (AMAX != 0) fxg_phase_stage_bases(a.clip_src, a.clip_total, (u64)r0 * a.clip_stride, nreads * a.clip_stride, sb, tid, NT);
             }
             for (u32 tid = 0; tid < nreads; ++tid) {
-                fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid]);
+                if (AMAX == 0 && pl.rows_nw) emu_rows_decide(pl.rows_nw, a, r0 + tid, &keep[tid], &olen[tid]);   // what a lane of fxg_kernel_rows does
+                else fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid]);
                 anchor[tid] = tid * stride;
             }
         } else if (MODE == 3) {

@@ -100,6 +100,35 @@ def test_fuzz_vs_oracle(engine):
     assert kept > 10000
 
 
+def test_both_quality_kernels_on_the_same_batches(engine, monkeypatch):
+    """The quality stages run as fxg_kernel_rows (reads up to 152 bytes, compaction) or as fxg_kernel_tiles<0,0> (everything else,
+    FXG_ROWS=0): same batches through both, every output array, and the oracle for the first of them.  Lengths down to 1 and
+    minimum lengths of 1-2 put kept reads of fewer than 4 bytes into tiles (the predicated packing path of fxg_rows_pack);
+    partial last tiles; strides at the edges of the three register-row instances (40 / 41, 104 / 105, 152)."""
+    import torch
+    from fastx_toolkit_amd import make_params
+    kernels = set()
+    for seed, n, L, stride, var in [(1, 64, 150, 150, False), (2, 100, 150, 150, False), (3, 5000, 150, 150, False), (4, 3000, 36, 36, False),
+                                    (5, 2000, 100, 100, False), (6, 4000, 150, 152, True), (7, 1000, 13, 29, True), (8, 333, 7, 7, False),
+                                    (9, 70001, 150, 150, False), (10, 2500, 101, 104, True), (11, 700, 40, 40, True), (12, 700, 41, 41, True),
+                                    (13, 900, 105, 105, True), (14, 130, 1, 1, False), (15, 640, 3, 5, True)]:
+        b, q = engine.synth(seed, 0, n, L, False, stride)
+        lens = torch.from_numpy(np.random.default_rng(seed).integers(1, L + 1, n).astype(np.int16)).to(engine.device) if var else None
+        for k, pd in enumerate((dict(stages=6, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80), dict(stages=2, qt_threshold=25, qt_min_len=1),
+                                dict(stages=4, qf_min_quality=15, qf_min_percent=50), dict(stages=6, qt_threshold=30, qt_min_len=2, qf_min_quality=10, qf_min_percent=10))):
+            got = {}
+            for rows in ("1", "0"):
+                monkeypatch.setenv("FXG_ROWS", rows)
+                r = engine.run(b, q, make_params(**pd), lens=lens, fixed_len=None if var else L, compact=True, meta=True)
+                got[rows] = (engine.last_launch()["kernel"], r.to_host())
+            kernels.add(got["1"][0].split(" ")[0].split("<")[0]); kernels.add(got["0"][0].split(" ")[0].split("<")[0])
+            assert_same(got["0"][1], got["1"][1], "rows vs tiles %r %r" % ((seed, n, L, stride, var), pd))
+            if k == 0 and n <= 5000:
+                o = fo.run_pipeline(b.cpu().numpy(), q.cpu().numpy(), lens.cpu().numpy().view(np.uint16) if var else None, oracle_params(pd), fixed_len=None if var else L)
+                assert_same(o, got["1"][1], "rows vs oracle %r" % ((seed, n, L, stride, var),))
+    assert kernels == {"fxg_kernel_rows", "fxg_kernel_tiles"}, kernels
+
+
 def test_decision_only_fasta_and_tool_entry_points(engine):
     import ctypes as C
     import torch
