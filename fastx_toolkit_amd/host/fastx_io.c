@@ -19,7 +19,6 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
-#include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/types.h>
 #include <sys/wait.h>
@@ -344,18 +343,12 @@ static void *fxh_gz_worker(void *p)
     return NULL;
 }
 
-/* Plain output to a regular file.  write()/pwrite() to one file serialise on its inode lock (measured on tmpfs: 8 pwrite()
- * threads are no faster than one, ~4 GB/s), so large blocks go through a shared mapping instead: the file is extended with
- * ftruncate(), the new range is mmap()ed and several threads copy their slices into it -- page allocation and copy then run
- * in parallel.  Small blocks, pipes, terminals and O_APPEND descriptors keep the single write() stream. */
-struct fxh_cp_job { char *dst; const char *src; size_t n; };
-static void *fxh_copy_main(void *arg)
-{
-    struct fxh_cp_job *j = (struct fxh_cp_job *)arg;
-    memcpy(j->dst, j->src, j->n);
-    return NULL;
-}
-
+/* Plain output to a regular file goes out as positional writes from the writer's own offset (the descriptor's position is put
+ * right when the writer closes).  Measured on tmpfs (16 M reads, 2.5 GB out, profiles/r02/ab_e2e_mapped_output.txt): one pwrite()
+ * stream 0.37 s; several pwrite() threads are no faster (they serialise on the inode lock, and page allocation is the cost);
+ * mapping the output file instead -- one mapping over the expected output with helper threads faulting pages in ahead of the
+ * copies (MADV_POPULATE_WRITE) -- brings the writes themselves to 0.0-0.1 s of waiting but costs 0.3 s to take the 600 000 page
+ * mappings down again at exit, and mapping block by block is slower than pwrite() (0.6 s).  So: pwrite(). */
 static void fxh_pwrite_all(int fd, const char *buf, size_t n, off_t off)
 {
     size_t done = 0;
@@ -366,44 +359,9 @@ static void fxh_pwrite_all(int fd, const char *buf, size_t n, off_t off)
     }
 }
 
-static void fxh_write_parallel(struct fxh_writer *w, const char *buf, size_t n)
-{
-    int nt = w->io_threads;
-    if ((size_t)nt > n / ((size_t)2 << 20)) nt = (int)(n / ((size_t)2 << 20));
-    if (nt <= 1 || w->no_mmap) { fxh_pwrite_all(w->fd, buf, n, w->off); w->off += (off_t)n; return; }
-    const long pg = sysconf(_SC_PAGESIZE);
-    const off_t map_off = w->off & ~((off_t)pg - 1);
-    const size_t lead = (size_t)(w->off - map_off), map_len = lead + n;
-    char *m = MAP_FAILED;
-    if (ftruncate(w->fd, w->off + (off_t)n) == 0) m = (char *)mmap(NULL, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, w->fd, map_off);
-    if (m == MAP_FAILED) {                                   /* e.g. a file system without shared writable mappings: positional writes from here on */
-        w->no_mmap = 1;
-        fxh_pwrite_all(w->fd, buf, n, w->off); w->off += (off_t)n;
-        return;
-    }
-#ifdef MADV_HUGEPAGE
-    (void)madvise(m, map_len, MADV_HUGEPAGE);                  /* fewer, larger page faults where the file system allows it */
-#endif
-    pthread_t th[16];
-    struct fxh_cp_job job[16];
-    const size_t per = ((n + (size_t)nt - 1) / (size_t)nt + 4095) & ~(size_t)4095;
-    int used = 0;
-    for (int i = 0; i < nt; ++i) {
-        const size_t o = (size_t)i * per;
-        if (o >= n) break;
-        job[i].dst = m + lead + o; job[i].src = buf + o; job[i].n = n - o < per ? n - o : per;
-        used = i + 1;
-    }
-    for (int i = 1; i < used; ++i) if (pthread_create(&th[i], NULL, fxh_copy_main, &job[i]) != 0) err(1, "pthread_create");
-    fxh_copy_main(&job[0]);
-    for (int i = 1; i < used; ++i) pthread_join(th[i], NULL);
-    munmap(m, map_len);
-    w->off += (off_t)n;
-}
-
 void fxh_writer_emit(struct fxh_writer *w, const char *buf, size_t n)
 {
-    if (!w->gz) { if (w->positional) fxh_write_parallel(w, buf, n); else fxh_write_all(w->fd, buf, n); return; }
+    if (!w->gz) { if (w->positional) { fxh_pwrite_all(w->fd, buf, n, w->off); w->off += (off_t)n; } else fxh_write_all(w->fd, buf, n); return; }
     if (n == 0) return;
     struct fxh_gz_job job;
     job.in = buf; job.n = n; job.nchunks = (n + FXH_GZ_CHUNK - 1) / FXH_GZ_CHUNK;
@@ -483,12 +441,6 @@ static struct fxh_writer *fxh_writer_open(const char *filename, int gzip)
         struct stat sb;
         const off_t pos = lseek(w->fd, 0, SEEK_CUR);
         const int fl = fcntl(w->fd, F_GETFL);
-        const char *e = getenv("FXH_IO_THREADS");
-        long nt = e ? atol(e) : 8, ncpu = sysconf(_SC_NPROCESSORS_ONLN);
-        if (nt < 1) nt = 1;
-        if (nt > 16) nt = 16;
-        if (ncpu > 0 && nt > ncpu) nt = ncpu;
-        w->io_threads = (int)nt;
         w->positional = (!w->gz && pos >= 0 && fl >= 0 && !(fl & O_APPEND) && fstat(w->fd, &sb) == 0 && S_ISREG(sb.st_mode)) ? 1 : 0;
         w->off = pos;
     }

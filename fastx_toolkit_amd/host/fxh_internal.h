@@ -19,7 +19,7 @@ struct fxh_writer {
     size_t cap, len;
     int gz;                 /* -z: the output is a gzip stream, compressed here in parallel (one member per chunk) */
     unsigned long gz_members;
-    int positional, io_threads, no_mmap;  /* plain output to a regular file: positional (mapped, parallel) writes from `off` on */
+    int positional;         /* plain output to a regular file: positional writes from `off` on */
     off_t off;
 };
 

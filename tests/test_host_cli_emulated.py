@@ -237,7 +237,7 @@ def test_fused_trim_filter_equals_the_pipe(tools):
 
 
 def test_regular_files_use_parallel_io_same_bytes(tools, tmp_path):
-    """-i FILE / -o FILE: blocks are read with several pread() and written with several pwrite() in flight; same bytes as through pipes."""
+    """-i FILE / -o FILE: blocks are read with several pread() in flight and written with positional writes; same bytes as through pipes."""
     text = fo.synth_fastq(43, 0, 120000, 100, False)                    # ~28 MB
     argv = ["fastq_quality_trimmer", "-t", "20", "-l", "30"]
     want = _run([os.path.join(tools, argv[0])] + argv[1:], text)
