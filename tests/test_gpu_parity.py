@@ -111,7 +111,7 @@ def test_both_quality_kernels_on_the_same_batches(engine, monkeypatch):
     for seed, n, L, stride, var in [(1, 64, 150, 150, False), (2, 100, 150, 150, False), (3, 5000, 150, 150, False), (4, 3000, 36, 36, False),
                                     (5, 2000, 100, 100, False), (6, 4000, 150, 152, True), (7, 1000, 13, 29, True), (8, 333, 7, 7, False),
                                     (9, 70001, 150, 150, False), (10, 2500, 101, 104, True), (11, 700, 40, 40, True), (12, 700, 41, 41, True),
-                                    (13, 900, 105, 105, True), (14, 130, 1, 1, False), (15, 640, 3, 5, True)]:
+                                    (13, 900, 105, 105, True), (14, 130, 1, 1, False), (15, 640, 3, 5, True), (16, 1000, 100, 104, False), (17, 777, 150, 152, False)]:
         b, q = engine.synth(seed, 0, n, L, False, stride)
         lens = torch.from_numpy(np.random.default_rng(seed).integers(1, L + 1, n).astype(np.int16)).to(engine.device) if var else None
         for k, pd in enumerate((dict(stages=6, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80), dict(stages=2, qt_threshold=25, qt_min_len=1),
