@@ -348,7 +348,8 @@ static void *fxh_gz_worker(void *p)
  * stream 0.37 s; several pwrite() threads are no faster (they serialise on the inode lock, and page allocation is the cost);
  * mapping the output file instead -- one mapping over the expected output with helper threads faulting pages in ahead of the
  * copies (MADV_POPULATE_WRITE) -- brings the writes themselves to 0.0-0.1 s of waiting but costs 0.3 s to take the 600 000 page
- * mappings down again at exit, and mapping block by block is slower than pwrite() (0.6 s).  So: pwrite(). */
+ * mappings down again at exit, and mapping block by block is slower than pwrite() (0.6 s); allocating the pages ahead of the
+ * writes with fallocate() changes nothing (ab_e2e_prealloc.txt): the copy is the cost.  So: pwrite(). */
 static void fxh_pwrite_all(int fd, const char *buf, size_t n, off_t off)
 {
     size_t done = 0;

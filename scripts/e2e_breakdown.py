@@ -28,8 +28,6 @@ def run(label, argv, env=None):
             print(label, 'FAILED', p.stderr[-300:]); return
         if best is None or dt < best[0]: best = (dt, p.stderr.decode(errors='replace') + p.stdout.decode(errors='replace'))
     tl = ' | '.join(l for l in best[1].splitlines() if l.startswith('fxh timing'))
-    for l in best[1].splitlines():
-        if 'output mapping' in l: print('      ' + l)
     print('%-46s wall %.3f s = %5.1f Mreads/s   %s' % (label, best[0], R / best[0] / 1e6, tl[tl.find('run'):] if 'run' in tl else tl), flush=True)
 T = [B + 'fastq_quality_trimmer', '-t', '20', '-l', '30', '-i', '/dev/shm/in.fq']
 TF = [B + 'fastq_quality_trim_filter', '-t', '20', '-l', '30', '-q', '20', '-p', '80', '-i', '/dev/shm/in.fq']
@@ -44,8 +42,6 @@ for io in ('2', '4', '16'):
 run('trimmer lanes=2 -> tmpfs, 128 MB blocks', T + ['-o', '/dev/shm/out.fq'], {'FXH_LANES': '2', 'FXH_READ_BUFFER_MB': '128'})
 run('trimmer lanes=2 -> tmpfs, 32 MB blocks', T + ['-o', '/dev/shm/out.fq'], {'FXH_LANES': '2', 'FXH_READ_BUFFER_MB': '32'})
 run('fused trim+filter lanes=2 -> tmpfs', TF + ['-o', '/dev/shm/out.fq'], {'FXH_LANES': '2'})
-for mb in ('0', '256', '512', '2048', '8192'):
-    run('fused lanes=2 -> tmpfs, prefault window %s MB' % mb, TF + ['-o', '/dev/shm/out.fq'], {'FXH_LANES': '2', 'FXH_PREFAULT_MB': mb})
 run('fused trim+filter lanes=1 -> tmpfs', TF + ['-o', '/dev/shm/out.fq'], {'FXH_LANES': '1'})
 run('fused, two contexts as two devices', TF + ['-o', '/dev/shm/out.fq'], {'FXG_DEVICES': '0,0', 'FXH_LANES': '1'})
 run('host parse -> tmpfs', T + ['-o', '/dev/shm/out.fq'], {'FXH_HOST_PARSE': '1'})
