@@ -129,6 +129,31 @@ def test_both_quality_kernels_on_the_same_batches(engine, monkeypatch):
     assert kernels == {"fxg_kernel_rows", "fxg_kernel_tiles"}, kernels
 
 
+def test_quality_kernels_random_shapes(engine, monkeypatch):
+    """Seeded random batch shapes (stride 1..152, any fixed length below it or ragged lengths, any tile remainder), random thresholds:
+    fxg_kernel_rows and fxg_kernel_tiles<0,0> must produce the same arrays."""
+    import torch
+    from fastx_toolkit_amd import make_params
+    rng = np.random.default_rng(20260927)
+    kept = 0
+    for trial in range(48):
+        stride = int(rng.integers(1, 153))
+        L = int(rng.integers(1, stride + 1))
+        n = int(rng.integers(1, 9000))
+        var = bool(rng.integers(0, 2))
+        b, q = engine.synth(int(rng.integers(1, 1 << 20)), int(rng.integers(0, 1 << 30)), n, L, False, stride)
+        lens = torch.from_numpy(rng.integers(1, L + 1, n).astype(np.int16)).to(engine.device) if var else None
+        stages = int(rng.choice([2, 4, 6]))
+        pd = dict(stages=stages, qt_threshold=int(rng.integers(0, 45)), qt_min_len=int(rng.integers(0, L + 2)), qf_min_quality=int(rng.integers(0, 45)), qf_min_percent=int(rng.integers(0, 101)))
+        got = {}
+        for rows in ("1", "0"):
+            monkeypatch.setenv("FXG_ROWS", rows)
+            got[rows] = engine.run(b, q, make_params(**pd), lens=lens, fixed_len=None if var else L, compact=True, meta=True).to_host()
+        assert_same(got["0"], got["1"], "trial %d: n %d L %d stride %d ragged %s %r" % (trial, n, L, stride, var, pd))
+        kept += int(got["1"]["counters"][1])
+    assert kept > 10000
+
+
 def test_decision_only_fasta_and_tool_entry_points(engine):
     import ctypes as C
     import torch
