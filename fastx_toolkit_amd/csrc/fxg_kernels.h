@@ -243,15 +243,20 @@ FXG_HD void fxg_clip_rows_packed(const FxgKArgs &a, const uint8_t *rd, int len, 
         else fxg_clip_row_packed<AMAX, false, true, TN>(a, A, c, 0, S, Sm, W, best, bw, bq);
         q = 1;
     }
+    // The row's base comes out of LDS one row AHEAD of its use (rows >= 1 always exists in the staged tile: the bases of the next
+    // read or the tile's slack follow), so the load's latency is never waited for at the top of a row.
+    u32 cn = q < rows ? rd[q] : 0u;
 #pragma unroll 1
     for (; q < early_rows; ++q) {
-        const u32 c = rd[q];
+        const u32 c = cn;
+        cn = rd[q + 1];
         first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
         fxg_clip_row_packed<AMAX, true, false, TN>(a, A, c, q, S, Sm, W, best, bw, bq);
     }
 #pragma unroll 1
     for (; q < rows; ++q) {
-        const u32 c = rd[q];
+        const u32 c = cn;
+        cn = rd[q + 1];
         first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
         fxg_clip_row_packed<AMAX, false, false, TN>(a, A, c, q, S, Sm, W, best, bw, bq);
     }
