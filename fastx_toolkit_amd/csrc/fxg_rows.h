@@ -5,7 +5,7 @@
 // the tile kernel decides from the quality rows, then waits for the tile's place in the output (a prefix over all earlier tiles)
 // and gathers the kept prefixes from HBM -- it fetches the quality rows twice and the bases at cache-line granularity around every
 // kept read: 27.4 GB through the L2s per cfg2 launch against 22.3 GB of input + output.  Here every byte crosses the fabric once
-// (rocprofv3 PMC: 14.85 GB read + 7.27 GB written, profiles/r02_pmc_rows/):
+// (rocprofv3 PMC: 15.2 GB read + 7.7 GB written, profiles/pmc_traffic.json, r02_rows_pmc/):
 //   stage A, tile `cur`:  the quality rows come in by LDS-DMA (buffer_load ... lds, 1 KB per wave instruction) and are transposed
 //      through a 9.6 KB staging buffer: lane r holds read r (38 dwords for 150 bases, v_alignbyte_b32).  The lane builds its read's
 //      threshold bitmap in registers (v_dot4_u32_u8 gathers the compare flags), decides it, the wave scans (keep, length) with DPP
@@ -15,21 +15,21 @@
 //      stores the packed bytes as whole, aligned 16-byte units of the global array (fxg_rows_flush).  The base rows take the same
 //      road: LDS-DMA, transpose, pack, flush.
 // A workgroup IS one wave: no workgroup barrier anywhere, no gather tables, no second pass.  Twelve waves per CU (138 VGPRs).
-// Measured against fxg_kernel_tiles<0,0> on the same box the two are within noise of each other (4.03-4.15 ms for cfg2): both sit
-// at what the memory system gives this read : write mix -- a plain streaming kernel that reads 15 GB and writes 7.3 GB, nothing
+// Measured against fxg_kernel_tiles<0,0> on the same box it is 3-4 % faster (4.03 against 4.16-4.19 ms for cfg2), not the 18 % the
+// bytes suggest: both sit at what the memory system gives this read : write mix -- a plain streaming kernel that reads 15 GB and writes 7.3 GB, nothing
 // else, takes 4.25-4.5 ms (scripts/ubench/mix_rw.hip, profiles/r02/z_mix_rw.txt); read alone 2.34 ms, write alone 1.18 ms.
 #pragma once
 #include "fxg_kernels.h"
 
 #define FXG_ROWS_T 64u                  // reads per tile = lanes per wave
 #ifndef FXG_ROWS_LB
-#define FXG_ROWS_LB 3         // waves per SIMD: two tiles' quality rows live in registers (fxg_kernel_rows), 168 VGPRs
+#define FXG_ROWS_LB 3                   // waves per SIMD: two tiles' quality rows live in registers (fxg_kernel_rows), up to 168 VGPRs
 #endif
 #ifndef FXG_ROWS_SCAN_K
 #define FXG_ROWS_SCAN_K 8               // tiles per scanner batch / 64 (fxg_scanner_multi)
 #endif
 #ifndef FXG_ROWS_LD_AUX
-#define FXG_ROWS_LD_AUX 0             // cache policy bits of the row loads (2 = nt)
+#define FXG_ROWS_LD_AUX 0               // cache policy bits of the row loads (2 = nt: measured, no gain)
 #endif
 #ifndef FXG_ROWS_NSCAN
 #define FXG_ROWS_NSCAN 8                // scanner waves
