@@ -140,9 +140,12 @@ __device__ __forceinline__ void fxg_rows_fetch(const uint8_t *src, u64 tb, u32 t
 {
     constexpr int NC = (NW * 4 + 15) / 16;            // chunks per lane: 64 lanes x NC x 16 bytes cover 64 rows of up to 4 NW bytes
     const u32 nck = (tbytes + 1023u) >> 10;           // wave loads this tile needs (uniform)
-    // whole dwords (the range check is per dword): at most 3 bytes past the batch's last read, inside its 16-byte unit
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(src + tb), 0, (int)((tbytes + 3u) & ~3u), 0x00020000);
+    // whole dwords (the range check is per dword); only a batch's last tile can end inside a dword (64 rows are whole dwords): its
+    // last 1-3 bytes come in by byte loads, so nothing past the arrays is ever read
+    const u32 whole = tbytes & ~3u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(src + tb), 0, (int)whole, 0x00020000);
     fxg_rows_fetch_from<0, NC>(rs, sbuf, lane, nck, fxg_r16(tbytes));
+    if (whole != tbytes && lane < tbytes - whole) sbuf[whole + lane] = src[tb + whole + lane];
 }
 __device__ __forceinline__ void fxg_rows_landed()
 {
