@@ -338,6 +338,9 @@ def main():
                 "kernel": launch["kernel"], "kernel_ms_avg": round(kavg, 4), "kernel_ms_min": round(min(kms), 4),
                 "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_read": round(alg_bytes / R, 2),
                 "grid": launch["grid"], "block": launch["block"], "lds_bytes": launch["lds"], "tile_reads": launch["tile_reads"],
+                **({"note": "not measured in this run: a plain streaming kernel that reads 15 GB and writes 7.3 GB (this config's algorithmic bytes, nothing "
+                            "else) takes 4.25-4.56 ms on this part, read alone 2.34-2.50 ms, write alone 1.17-1.25 ms (scripts/ubench/mix_rw.hip, profiles/r02/z_mix_rw.txt)"}
+                   if args.config == "cfg2" and compact else {}),
             },
         }
         if cfg["bound"] == "valu":
