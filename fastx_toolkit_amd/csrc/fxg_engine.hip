@@ -355,9 +355,8 @@ extern "C" int fxg_run_pipeline(fxg_ctx *c, const fxg_batch *in, const fxg_param
     }
     u64 *ctr = (u64 *)out->counters;
 #define FXG_TILES_A(N) (fxg_kernel_tiles<N, 0>)
-    if (pl.rows_nw) {       // reads up to 152 bytes through the quality stages: one lane per read, rows in registers (fxg_rows.h)
+    if (pl.rows_nw) {       // rows of 80..152 bytes through the quality stages: one lane per read, rows in registers (fxg_rows.h)
         switch (pl.rows_nw) {
-        case 10: return fxg_launch_tiles(c, fxg_kernel_rows<10>, "fxg_kernel_rows<10> qtrim+qfilter", pl.ka, pl.lds, ctr, 64u);
         case 26: return fxg_launch_tiles(c, fxg_kernel_rows<26>, "fxg_kernel_rows<26> qtrim+qfilter", pl.ka, pl.lds, ctr, 64u);
         default: return fxg_launch_tiles(c, fxg_kernel_rows<38>, "fxg_kernel_rows<38> qtrim+qfilter", pl.ka, pl.lds, ctr, 64u);
         }

@@ -106,10 +106,12 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
         for (unsigned i = 0; i < sizeof pk / sizeof pk[0]; ++i) if (ka.alen <= pk[i]) { b = pk[i]; break; }
         pl->amax = -b;
     }
-    // quality trim / filter with compaction over reads of up to 152 bytes: one lane per read, 64 reads per tile (fxg_rows.h)
+    // quality trim / filter with compaction over rows of 80..152 bytes: one lane per read, 64 reads per tile (fxg_rows.h).  Shorter
+    // rows make its 64-read tiles too small (the tile kernel is 10-15 % ahead at 36-50 bases, ahead at 72, level at 76, 5-10 % behind from 88 on:
+    // profiles/r02/af_rows_vs_tiles_by_length.txt)
     pl->rows_nw = 0;
-    if (ga && !pl->clip && ka.compact && in->stride <= 152u && !(getenv("FXG_ROWS") && atoi(getenv("FXG_ROWS")) == 0))
-        pl->rows_nw = in->stride <= 40u ? 10 : in->stride <= 104u ? 26 : 38;
+    if (ga && !pl->clip && ka.compact && in->stride >= 80u && in->stride <= 152u && !(getenv("FXG_ROWS") && atoi(getenv("FXG_ROWS")) == 0))
+        pl->rows_nw = in->stride <= 104u ? 26 : 38;
     const u32 T = pl->rows_nw ? 64u : fxg_pick_tile(pl->clip ? ka.clip_stride : in->stride, pl->clip || gf);
     const u64 ntiles = (in->n + T - 1) / T;
     if (ntiles > 0x7FFFFFFFull || in->n > 0xFFFFFFFFull) FXG_PLAN_FAIL("batch too large (%llu reads): split it", (unsigned long long)in->n);

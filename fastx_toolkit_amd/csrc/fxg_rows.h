@@ -1,4 +1,4 @@
-// fxg_rows.h -- quality-trim / quality-filter with compaction for reads up to 152 bytes: one WAVE per tile of 64 reads, one LANE
+// fxg_rows.h -- quality-trim / quality-filter with compaction for rows of 80 to 152 bytes: one WAVE per tile of 64 reads, one LANE
 // per read, HBM traffic = input + output.
 //
 // Why a second kernel for the same stages (fxg_kernel_tiles<0,0> stays the general form: any read length, every other stage):

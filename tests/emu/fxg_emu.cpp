@@ -30,8 +30,7 @@ static void emu_rows_decide_nw(const FxgKArgs &a, u32 read, u32 *keep, u32 *olen
 }
 static void emu_rows_decide(int nw, const FxgKArgs &a, u32 read, u32 *keep, u32 *olen)
 {
-    if (nw == 10) emu_rows_decide_nw<10>(a, read, keep, olen);
-    else if (nw == 26) emu_rows_decide_nw<26>(a, read, keep, olen);
+    if (nw == 26) emu_rows_decide_nw<26>(a, read, keep, olen);
     else emu_rows_decide_nw<38>(a, read, keep, olen);
 }
 

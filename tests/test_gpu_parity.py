@@ -101,17 +101,18 @@ def test_fuzz_vs_oracle(engine):
 
 
 def test_both_quality_kernels_on_the_same_batches(engine, monkeypatch):
-    """The quality stages run as fxg_kernel_rows (reads up to 152 bytes, compaction) or as fxg_kernel_tiles<0,0> (everything else,
-    FXG_ROWS=0): same batches through both, every output array, and the oracle for the first of them.  Lengths down to 1 and
+    """The quality stages run as fxg_kernel_rows (rows of 80..152 bytes, compaction) or as fxg_kernel_tiles<0,0> (everything else,
+    FXG_ROWS=0): same batches through both, every output array, and the oracle for the first of them.  Ragged lengths down to 1 and
     minimum lengths of 1-2 put kept reads of fewer than 4 bytes into tiles (the predicated packing path of fxg_rows_pack);
-    partial last tiles; strides at the edges of the three register-row instances (40 / 41, 104 / 105, 152)."""
+    partial last tiles; strides at the edges of the two register-row instances (80, 104 / 105, 152) and outside them."""
     import torch
     from fastx_toolkit_amd import make_params
     kernels = set()
     for seed, n, L, stride, var in [(1, 64, 150, 150, False), (2, 100, 150, 150, False), (3, 5000, 150, 150, False), (4, 3000, 36, 36, False),
                                     (5, 2000, 100, 100, False), (6, 4000, 150, 152, True), (7, 1000, 13, 29, True), (8, 333, 7, 7, False),
                                     (9, 70001, 150, 150, False), (10, 2500, 101, 104, True), (11, 700, 40, 40, True), (12, 700, 41, 41, True),
-                                    (13, 900, 105, 105, True), (14, 130, 1, 1, False), (15, 640, 3, 5, True), (16, 1000, 100, 104, False), (17, 777, 150, 152, False)]:
+                                    (13, 900, 105, 105, True), (14, 130, 1, 1, False), (15, 640, 3, 5, True), (16, 1000, 100, 104, False), (17, 777, 150, 152, False),
+                                    (18, 1500, 80, 80, True), (19, 1500, 60, 81, True), (20, 999, 79, 79, False), (21, 3000, 9, 88, True)]:
         b, q = engine.synth(seed, 0, n, L, False, stride)
         lens = torch.from_numpy(np.random.default_rng(seed).integers(1, L + 1, n).astype(np.int16)).to(engine.device) if var else None
         for k, pd in enumerate((dict(stages=6, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80), dict(stages=2, qt_threshold=25, qt_min_len=1),
@@ -130,14 +131,14 @@ def test_both_quality_kernels_on_the_same_batches(engine, monkeypatch):
 
 
 def test_quality_kernels_random_shapes(engine, monkeypatch):
-    """Seeded random batch shapes (stride 1..152, any fixed length below it or ragged lengths, any tile remainder), random thresholds:
+    """Seeded random batch shapes (stride 60..152, any fixed length below it or ragged lengths, any tile remainder), random thresholds:
     fxg_kernel_rows and fxg_kernel_tiles<0,0> must produce the same arrays."""
     import torch
     from fastx_toolkit_amd import make_params
     rng = np.random.default_rng(20260927)
     kept = 0
     for trial in range(48):
-        stride = int(rng.integers(1, 153))
+        stride = int(rng.integers(60, 153))
         L = int(rng.integers(1, stride + 1))
         n = int(rng.integers(1, 9000))
         var = bool(rng.integers(0, 2))
