@@ -18,7 +18,7 @@ cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err
 if [ "${SKIP_PROF:-0}" != "1" ]; then
 cd /tmp
 rm -rf $R/gpurun_out/prof
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $R/gpurun_out/bench_prof.json 2> $R/gpurun_out/prof.err; echo "rocprof rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e > $R/gpurun_out/bench_prof.json 2> $R/gpurun_out/prof.err; echo "rocprof rc=$?"
 cd $R
 find gpurun_out/prof -name "*stats*" | head; 
 for f in $(find gpurun_out/prof -name "*kernel_stats.csv"); do head -12 $f; done
