@@ -262,6 +262,113 @@ FXG_HD void fxg_clip_rows_packed(const FxgKArgs &a, const uint8_t *rd, int len, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two passes for adapters up to 16 bases (every BASELINE config).  Only ONE cell's path summary is ever used -- the first maximum's --
+// and that path is short: it enters the matrix with a diagonal step from a border value <= 0 (in row 0 the gap candidates are -5
+// or -100000 against a diagonal >= -1; in column 0 the same), every diagonal step adds at most 1, every gap step -5, and the best
+// score is at least -1 (cell (q, 0) >= its own pair score), so it has at most (A + 1) / 5 gap steps and covers at most
+//   SPAN = A + (A + 1) / 5   rows   (15 for the 13-base adapter).
+// Pass 1 therefore carries SCORES only (5 VALU instructions per cell instead of 15): it finds the row of the first maximum
+// (first row whose maximum exceeds everything before it) and keeps checkpoints of the score row every C = SPAN / 2 rows -- three
+// live ones, P[j % 3] = the row before chunk j.  When the best moves in chunk j, the checkpoint two chunks back (2 C >= SPAN - 1 rows
+// before the chunk's first row) is remembered.  Pass 2 restarts the summary-carrying DP (fxg_clip_row_packed) from that checkpoint
+// and runs at most 3 C rows up to the best row; the scores it recomputes are the same fp32 operations in the same order, the
+// summaries of cells whose paths started before the checkpoint are garbage, and the best cell's path is not one of them.
+// Row 0 needs no variant of its own here: the virtual cells above it carry the summary a path entering diagonally at (0, t) starts
+// from ((t << 19) + one step, what FIRST computes on the spot), and gap moves out of the border never win (above).
+// ------------------------------------------------------------------------------------------------
+template <int AMAX> struct FxgClip2 {
+    static constexpr int SPAN = AMAX + (AMAX + 1) / 5;
+    static constexpr int C = SPAN / 2 > 0 ? SPAN / 2 : 1;      // ceil((SPAN - 1) / 2)
+    static constexpr int WIN = 3 * C;
+};
+
+// one row of pass 1: scores only; returns the row's maximum over the adapter's columns
+template <int AMAX, bool EARLY, bool TN>
+FXG_HD float fxg_clip_row_score(const FxgKArgs &a, int A, u32 c, int q, float (&S)[AMAX], float (&Sm)[AMAX])
+{
+    const bool qn = (c == (u32)'N');
+    const float pair_eq = qn ? 0.1f : 1.0f, pair_ne = qn ? 0.1f : -1.0f;                 // sequence_alignment.h:157-169
+    float ul[AMAX];
+#pragma unroll
+    for (int t = 0; t < AMAX; ++t) {                        // everything taken from the row above first (in-place update below)
+        const u32 tc = (u32)(uint8_t)a.adapter[t];
+        float pair = (c == tc) ? pair_eq : pair_ne;
+        if (TN) pair = (tc == (u32)'N') ? (qn ? 0.0f : 0.1f) : pair;
+        ul[t] = (t ? S[t - 1] : 0.0f) + pair;
+    }
+    float uSm = -5.0f, rowmax = -1000000.0f;
+    constexpr int AMIN = AMAX <= 4 ? 1 : (AMAX <= 8 ? 5 : AMAX);      // smallest adapter of the bucket: columns below it always count
+#pragma unroll
+    for (int t = 0; t < AMAX; ++t) {
+        float left = Sm[t];
+        if (EARLY && t > 3) left = (t - 3 > q) ? -100000.0f : left;                      // sequence_alignment.cpp:387-389
+        const float sc = fmaxf(fmaxf(ul[t], uSm), left);
+        const float scm = sc + -5.0f;
+        S[t] = sc; Sm[t] = scm; uSm = scm;
+        if (t < AMIN) rowmax = fmaxf(rowmax, sc);
+        else rowmax = (t < A) ? fmaxf(rowmax, sc) : rowmax;
+    }
+    return rowmax;
+}
+
+template <int AMAX, bool TN>
+FXG_HD void fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float &best, u32 &bw, u32 &bq, int &first_n)
+{
+    constexpr int C = FxgClip2<AMAX>::C;
+    float S[AMAX], Sm[AMAX], P0[AMAX], P1[AMAX], P2[AMAX], CB[AMAX];
+    const int A = a.alen;
+#pragma unroll
+    for (int t = 0; t < AMAX; ++t) { S[t] = (t <= 3) ? 0.0f : -5.0f * (float)(t - 3); Sm[t] = S[t] + -5.0f; P0[t] = P1[t] = P2[t] = CB[t] = S[t]; }
+    const int early_rows = (A - 4 < rows) ? (A - 4 > 0 ? A - 4 : 0) : rows;
+    if (rows <= 0) return;
+    // ---- pass 1 ----
+    float b1 = -1000000.0f;
+    int q = 0, r0 = 0, bq1 = 0;
+    u32 cn = rd[0];
+    // chunk j = rows [j C, j C + C): saves the row before it in Psave = P[j % 3]; the restart row for a best found in it is
+    // Pwin = P[(j + 1) % 3] = the row before chunk j - 2 (before chunk 0 for j < 2: the border, which all three start from)
+#define FXG_CLIP_CHUNK(Psave, Pwin)                                                                                          \
+    {                                                                                                                        \
+        _Pragma("unroll") for (int t = 0; t < AMAX; ++t) Psave[t] = S[t];                                                    \
+        const int q0 = q, qend = q + C < rows ? q + C : rows;                                                                \
+        bool upd = false;                                                                                                    \
+        _Pragma("unroll 1") for (; q < qend; ++q) {                                                                          \
+            const u32 c = cn;                                                                                                \
+            cn = rd[q + 1];                                                                                                  \
+            first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;                                            \
+            const float rm = q < early_rows ? fxg_clip_row_score<AMAX, true, TN>(a, A, c, q, S, Sm)                          \
+                                            : fxg_clip_row_score<AMAX, false, TN>(a, A, c, q, S, Sm);                        \
+            const bool g = rm > b1;                                                                                          \
+            b1 = g ? rm : b1; bq1 = g ? q : bq1; upd = upd || g;                                                             \
+        }                                                                                                                    \
+        if (upd) {                                                                                                           \
+            _Pragma("unroll") for (int t = 0; t < AMAX; ++t) CB[t] = Pwin[t];                                                \
+            r0 = q0 - 2 * C > 0 ? q0 - 2 * C : 0;                                                                            \
+        }                                                                                                                    \
+    }
+    while (q < rows) {
+        FXG_CLIP_CHUNK(P0, P1)
+        if (q >= rows) break;
+        FXG_CLIP_CHUNK(P1, P2)
+        if (q >= rows) break;
+        FXG_CLIP_CHUNK(P2, P0)
+    }
+#undef FXG_CLIP_CHUNK
+    // ---- pass 2: rows r0 .. bq1 with the path summaries, from the checkpoint ----
+    u32 W[AMAX];
+#pragma unroll
+    for (int t = 0; t < AMAX; ++t) { S[t] = CB[t]; Sm[t] = CB[t] + -5.0f; W[t] = ((u32)(t + 1) << 19) + FXG_PK_SZ1; }
+    q = r0;
+    int i = 0;
+#pragma unroll 1
+    for (; q <= bq1 && i < early_rows; ++q, ++i)            // window row i is read row r0 + i >= i: rows past i = A - 4 are past the early rule
+        fxg_clip_row_packed<AMAX, true, false, TN>(a, A, (u32)rd[q], q, S, Sm, W, best, bw, bq);
+#pragma unroll 1
+    for (; q <= bq1; ++q)
+        fxg_clip_row_packed<AMAX, false, false, TN>(a, A, (u32)rd[q], q, S, Sm, W, best, bw, bq);
+}
+
 template <int AMAX>
 FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len, int rows,
                                  u32 *out_len, u32 *keep, u32 *reason, u32 *clipped, u32 *adapter_only)
@@ -269,8 +376,12 @@ FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len, 
     float best = -1000000.0f;
     u32 bw = FXG_INVALID_TUPLE, bq = 0u;
     int first_n = len;
-    if (a.adapter_has_n) fxg_clip_rows_packed<AMAX, true>(a, rd, len, rows, best, bw, bq, first_n);    // uniform branch
-    else fxg_clip_rows_packed<AMAX, false>(a, rd, len, rows, best, bw, bq, first_n);
+    // adapters that contain 'N' take the general form (fxg_plan.h): the packed instances keep no per-column neutral selects
+#ifndef FXG_CLIP_ONE_PASS
+    if constexpr (AMAX <= 16) fxg_clip_two_pass<AMAX, false>(a, rd, len, rows, best, bw, bq, first_n);
+    else
+#endif
+    fxg_clip_rows_packed<AMAX, false>(a, rd, len, rows, best, bw, bq, first_n);
     const int matches = (int)(bw & 31u), diag = (int)((bw >> 14) & 31u);
     fxg_clip_finish(a, len, (int)(bw >> 24), (int)((bw >> 19) & 31u), diag - matches, (int)((bw >> 5) & 511u), matches,
                     (int)bq, first_n, out_len, keep, reason, clipped, adapter_only);

@@ -99,8 +99,9 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     if (pl->clip && ka.clip_stride > 65000u) FXG_PLAN_FAIL("clip: reads longer than 65000 are not supported");
     if ((st & FXG_STAGE_FTRIM) && p->ft_first < 1) FXG_PLAN_FAIL("-f must be >= 1");
     pl->amax = !pl->clip ? 0 : ka.alen <= 16 ? 16 : ka.alen <= 32 ? 32 : ka.alen <= 64 ? 64 : 100;
-    if (pl->clip && ka.alen <= 31 && ka.clip_stride <= 255u && !getenv("FXG_NO_PACKED_CLIP")) {
-        // packed path summary (one u32 per cell); buckets are fine-grained because every padded column costs a full cell
+    if (pl->clip && ka.alen <= 31 && ka.clip_stride <= 255u && !ka.adapter_has_n && !getenv("FXG_NO_PACKED_CLIP")) {
+        // packed path summary (one u32 per cell); buckets are fine-grained because every padded column costs a full cell.
+        // Adapters that contain 'N' (a neutral select per column) stay with the general form.
         static const int pk[] = {4, 8, 9, 10, 11, 12, 13, 14, 15, 16, 20, 24, 28, 32};
         int b = 32;
         for (unsigned i = 0; i < sizeof pk / sizeof pk[0]; ++i) if (ka.alen <= pk[i]) { b = pk[i]; break; }
