@@ -28,6 +28,18 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define FXG_TBLOCK 256          // threads per workgroup of the tile kernels
 #endif
 #define FXG_TWAVES (FXG_TBLOCK / 64)
+#ifndef FXG_CLIP_GATHER_K
+#define FXG_CLIP_GATHER_K 4     // chunks per lane in flight in the clip instances' gather (FXG_GATHER_K for the streaming instances)
+#endif
+#ifndef FXG_CLIP_STAGGER
+#define FXG_CLIP_STAGGER 0u     // default start stagger of the clip instances, units of s_sleep(127) = 3.4 us per wave slot (FXG_CLIP_STAGGER in the environment)
+#endif
+#ifndef FXG_CLIP_DEPTH
+#define FXG_CLIP_DEPTH 3u       // slots of the clip instances (FxgTileDepth in fxg_kernels.h)
+#endif
+#ifndef FXG_CLIP_TBLOCK
+#define FXG_CLIP_TBLOCK 256     // threads per workgroup of the two-pass clip instances (FxgTileBlock in fxg_kernels.h); 64 = one wave per workgroup, measured 6-25 % slower
+#endif
 #define FXG_MAX_TILE FXG_TBLOCK  // reads per tile (one thread decides one read)
 #define FXG_TICKET_GROUPS 8      // a single device-scope counter saturates near 88 tickets/us; shard it (one per XCD)
 #define FXG_TICKET_STRIDE 32     // u32 words between dispensers (128 B: one cache line each)
@@ -66,6 +78,8 @@ struct FxgKArgs {
     u32 *errflag;
     u32  compact;           // 1 = stream-compact kept reads into out_bases/out_qual
     u32  debug;             // FXG_DEBUG ablation bits (timing experiments only; results are wrong when set)
+    u32  depth;             // clip instances: slots = tiles a workgroup keeps between decision and write-out (2 or 3)
+    u32  stagger;           // clip instances: a workgroup that lands in wave slot k of its SIMDs starts k * stagger * 3.4 us late (fxg_kernel_tiles)
     // folded tool parameters
     u32  stages;
     u32  tq;                // quality trimmer: byte >= tq  <=>  q >= -t      (0..128)
@@ -470,18 +484,24 @@ __device__ __forceinline__ void fxg_wait_prefix_wave(const FxgKArgs &a, u32 tile
 }
 
 // ------------------------------------------------------------------------------------------------
-// workgroup exclusive scan of (keep, out_len) over FXG_TBLOCK threads.  scratch: u32[2*FXG_TWAVES]
+// workgroup exclusive scan of (keep, out_len) over TW waves.  scratch: u32[2*TW]
 // ------------------------------------------------------------------------------------------------
+template <int TW = FXG_TWAVES>
 __device__ __forceinline__ void fxg_block_scan2(u32 c, u32 b, u32 *scratch, u32 *ex_c, u32 *ex_b, u32 *tot_c, u32 *tot_b)
 {
     const u32 lane = fxg_lane(), wave = threadIdx.x >> 6;
     const u32 ic = fxg_wave_scan_dpp(c), ib = fxg_wave_scan_dpp(b);
-    if (lane == 63) { scratch[wave] = ic; scratch[FXG_TWAVES + wave] = ib; }
+    if constexpr (TW == 1) {                                 // the workgroup is one wave: totals by readlane, no LDS, no barrier
+        *ex_c = ic - c; *ex_b = ib - b;
+        *tot_c = (u32)__builtin_amdgcn_readlane((int)ic, 63); *tot_b = (u32)__builtin_amdgcn_readlane((int)ib, 63);
+        return;
+    }
+    if (lane == 63) { scratch[wave] = ic; scratch[TW + wave] = ib; }
     __syncthreads();
     u32 oc = 0, ob = 0, sc = 0, sb = 0;
 #pragma unroll
-    for (int w = 0; w < FXG_TWAVES; ++w) {
-        const u32 wc = scratch[w], wb = scratch[FXG_TWAVES + w];
+    for (int w = 0; w < TW; ++w) {
+        const u32 wc = scratch[w], wb = scratch[TW + w];
         if (w < (int)wave) { oc += wc; ob += wb; }
         sc += wc; sb += wb;
     }
@@ -575,7 +595,7 @@ FXG_HD void fxg_chunk_load(FxgChunk &c, const uint8_t *src_b, const uint8_t *src
     }
 }
 
-template <bool REV, bool MASK = false>
+template <bool REV, bool MASK = false, int GK = FXG_GATHER_K>
 FXG_HD u32 fxg_tile_gather(const FxgKArgs &a, const u32 *k_off, const u32 *k_src, const uint16_t *k_tab, u32 nk,
                            u64 tile_in_base, u32 tile_bytes, u64 B, u32 S, u32 tid, u32 nthreads)
 {
@@ -596,17 +616,17 @@ FXG_HD u32 fxg_tile_gather(const FxgKArgs &a, const u32 *k_off, const u32 *k_src
     const u32 Kmask = (128u - a.fq) * 0x01010101u, mask4 = (a.mask_char & 0xFFu) * 0x01010101u;
     u32 bad = 0;
 
-    // FXG_GATHER_K chunks per lane and trip: the source windows of all of them are requested before any is consumed
-    for (u32 c0 = tid; c0 < nfull; c0 += nthreads * FXG_GATHER_K) {
-        FxgChunk ch[FXG_GATHER_K];
+    // GK chunks per lane and trip: the source windows of all of them are requested before any is consumed
+    for (u32 c0 = tid; c0 < nfull; c0 += nthreads * GK) {
+        FxgChunk ch[GK];
 #pragma unroll
-        for (int u = 0; u < FXG_GATHER_K; ++u) {
+        for (int u = 0; u < GK; ++u) {
             const u32 ci = c0 + (u32)u * nthreads;
             ch[u].e = 0;
             if (ci < nfull) fxg_chunk_load<REV, MASK>(ch[u], src_b, src_q, has_q || MASK, k_off, k_src, k_tab, nk, S, o_lo + (ci << 4));
         }
 #pragma unroll
-        for (int u = 0; u < FXG_GATHER_K; ++u) {
+        for (int u = 0; u < GK; ++u) {
             if (ch[u].e == 0) continue;
             FxgChunk &c = ch[u];
             if (REV) { c.wb = fxg_reverse16(c.wb); c.wq = fxg_reverse16(c.wq); }

@@ -28,7 +28,7 @@ struct fxg_ctx {
     void *attr_kernel[8];   // kernels whose launch attributes were set, with the LDS size and the occupancy answer
     u32 attr_lds[8];
     int attr_per_cu[8];
-    int env_blocks_per_cu, env_ticket_groups;   // tuning knobs, read once
+    int env_blocks_per_cu, env_ticket_groups, env_clip_stagger;   // tuning knobs, read once
     u32 *errflag;           // [0] device error bits; tile dispensers start at word FXG_TICKET_STRIDE
     u64 *counters_scratch;  // used when the caller passes no counter block
     u64 *text_ws;           // newline census / scan levels / format items
@@ -84,6 +84,7 @@ extern "C" int fxg_ctx_create(int device_id, fxg_ctx **out)
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { free(c); return FXG_E_HIP; }
     c->stream = c->own_stream;
     { const char *e = getenv("FXG_BLOCKS_PER_CU"); c->env_blocks_per_cu = (e && atoi(e) > 0 && atoi(e) <= 16) ? atoi(e) : 0; }
+    { const char *e = getenv("FXG_CLIP_STAGGER"); c->env_clip_stagger = (e && atoi(e) >= 0 && atoi(e) <= 64) ? atoi(e) : -1; }
     { const char *e = getenv("FXG_TICKET_GROUPS"); c->env_ticket_groups = (e && atoi(e) > 0 && atoi(e) <= FXG_TICKET_GROUPS) ? atoi(e) : 0; }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreate(&c->kev0) != hipSuccess || hipEventCreate(&c->kev1) != hipSuccess ||
@@ -207,21 +208,21 @@ static int fxg_kernel_fit(fxg_ctx *c, K kernel, const char *kname, u32 lds, int 
 #define FXG_STATUS_WORDS(cap) (3 * (size_t)(cap) + 2 * ((size_t)(cap) / 256 + 2))
 
 template <typename K>
-static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &ka, u32 lds, u64 *counters, u32 block = FXG_TBLOCK)
+static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &ka, u32 lds, u64 *counters, u32 block = FXG_TBLOCK, bool rows_kernel = false)
 {
     FXG_HIP(c, hipSetDevice(c->device));
     int per_cu = 0;
     const int frc = fxg_kernel_fit(c, kernel, kname, lds, &per_cu, block);
     if (frc != FXG_OK) return frc;
     // Tiles are dispensed by ticket, so nothing depends on every workgroup being resident: fill the chip.
-    const int most = block == 64u ? 16 : 8;      // single-wave workgroups (fxg_rows.h): the LDS allows sixteen per CU
+    const int most = block == 64u ? 16 : 8;      // single-wave workgroups (fxg_rows.h, the two-pass clip instances): the LDS allows sixteen per CU
     int use = per_cu > most ? most : per_cu;
     if (c->env_blocks_per_cu > 0) use = c->env_blocks_per_cu;
     u64 workers = (u64)c->cus * (u64)use;
     if (workers > ka.ntiles) workers = ka.ntiles;
     if (workers < 1) workers = 1;
     // more workgroups: the scanner(s) (fxg_device.h); fxg_kernel_rows runs several once there is work for them
-    ka.nscan = !ka.compact ? 0u : (block == 64u && workers >= 64u * FXG_ROWS_NSCAN ? (u32)FXG_ROWS_NSCAN : 1u);
+    ka.nscan = !ka.compact ? 0u : (rows_kernel && workers >= 64u * FXG_ROWS_NSCAN ? (u32)FXG_ROWS_NSCAN : 1u);
     const u64 grid = workers + ka.nscan;
 
     if (ka.compact) {
@@ -245,6 +246,7 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
 #ifdef FXG_ABLATION
     { const char *dbg = getenv("FXG_DEBUG"); ka.debug = dbg ? (u32)atoi(dbg) : 0u; }
 #endif
+    ka.stagger = c->env_clip_stagger >= 0 ? (u32)c->env_clip_stagger : FXG_CLIP_STAGGER;
     ka.errflag = c->errflag;                     // control block (zeroed before every launch), layout at FXG_CTRL_WORDS
     ka.ticket = c->errflag + FXG_CTRL_WORDS;
     ka.extra = (u64 *)(c->errflag + 2);
@@ -357,23 +359,23 @@ extern "C" int fxg_run_pipeline(fxg_ctx *c, const fxg_batch *in, const fxg_param
 #define FXG_TILES_A(N) (fxg_kernel_tiles<N, 0>)
     if (pl.rows_nw) {       // rows of 80..152 bytes through the quality stages: one lane per read, rows in registers (fxg_rows.h)
         switch (pl.rows_nw) {
-        case 26: return fxg_launch_tiles(c, fxg_kernel_rows<26>, "fxg_kernel_rows<26> qtrim+qfilter", pl.ka, pl.lds, ctr, 64u);
-        default: return fxg_launch_tiles(c, fxg_kernel_rows<38>, "fxg_kernel_rows<38> qtrim+qfilter", pl.ka, pl.lds, ctr, 64u);
+        case 26: return fxg_launch_tiles(c, fxg_kernel_rows<26>, "fxg_kernel_rows<26> qtrim+qfilter", pl.ka, pl.lds, ctr, 64u, true);
+        default: return fxg_launch_tiles(c, fxg_kernel_rows<38>, "fxg_kernel_rows<38> qtrim+qfilter", pl.ka, pl.lds, ctr, 64u, true);
         }
     }
     if (pl.group_a) {
         switch (pl.amax) {
         case 0: return fxg_launch_tiles(c, FXG_TILES_A(0), "fxg_kernel_tiles<0,0> qtrim+qfilter", pl.ka, pl.lds, ctr);
-        case -4: return fxg_launch_tiles(c, FXG_TILES_A(-4), "fxg_kernel_tiles<-4,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
-        case -8: return fxg_launch_tiles(c, FXG_TILES_A(-8), "fxg_kernel_tiles<-8,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
-        case -9: return fxg_launch_tiles(c, FXG_TILES_A(-9), "fxg_kernel_tiles<-9,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
-        case -10: return fxg_launch_tiles(c, FXG_TILES_A(-10), "fxg_kernel_tiles<-10,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
-        case -11: return fxg_launch_tiles(c, FXG_TILES_A(-11), "fxg_kernel_tiles<-11,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
-        case -12: return fxg_launch_tiles(c, FXG_TILES_A(-12), "fxg_kernel_tiles<-12,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
-        case -13: return fxg_launch_tiles(c, FXG_TILES_A(-13), "fxg_kernel_tiles<-13,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
-        case -14: return fxg_launch_tiles(c, FXG_TILES_A(-14), "fxg_kernel_tiles<-14,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
-        case -15: return fxg_launch_tiles(c, FXG_TILES_A(-15), "fxg_kernel_tiles<-15,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
-        case -16: return fxg_launch_tiles(c, FXG_TILES_A(-16), "fxg_kernel_tiles<-16,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
+        case -4: return fxg_launch_tiles(c, FXG_TILES_A(-4), "fxg_kernel_tiles<-4,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
+        case -8: return fxg_launch_tiles(c, FXG_TILES_A(-8), "fxg_kernel_tiles<-8,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
+        case -9: return fxg_launch_tiles(c, FXG_TILES_A(-9), "fxg_kernel_tiles<-9,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
+        case -10: return fxg_launch_tiles(c, FXG_TILES_A(-10), "fxg_kernel_tiles<-10,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
+        case -11: return fxg_launch_tiles(c, FXG_TILES_A(-11), "fxg_kernel_tiles<-11,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
+        case -12: return fxg_launch_tiles(c, FXG_TILES_A(-12), "fxg_kernel_tiles<-12,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
+        case -13: return fxg_launch_tiles(c, FXG_TILES_A(-13), "fxg_kernel_tiles<-13,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
+        case -14: return fxg_launch_tiles(c, FXG_TILES_A(-14), "fxg_kernel_tiles<-14,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
+        case -15: return fxg_launch_tiles(c, FXG_TILES_A(-15), "fxg_kernel_tiles<-15,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
+        case -16: return fxg_launch_tiles(c, FXG_TILES_A(-16), "fxg_kernel_tiles<-16,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
         case -20: return fxg_launch_tiles(c, FXG_TILES_A(-20), "fxg_kernel_tiles<-20,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
         case -24: return fxg_launch_tiles(c, FXG_TILES_A(-24), "fxg_kernel_tiles<-24,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
         case -28: return fxg_launch_tiles(c, FXG_TILES_A(-28), "fxg_kernel_tiles<-28,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);

@@ -20,7 +20,7 @@
 
 // LDS carve-up shared by host (size) and device (pointers); every region is 16-byte aligned (G17).
 // k_off / k_src / k_idx / k_tab (the tile's kept reads, see fxg_tile_gather) are double buffered: stage B of tile i reads
-// slot s while stage A of tile i+1 fills slot s^1.
+// slot s while stage A of tile i+1 fills slot s^1 (the clip instances keep three slots: stage B runs two steps behind).
 #define FXG_NTALLY 16                            // tally slots: [0] reads seen, [1] kept, [2] kept bases, [3] adapter-only, [4 + reason] dropped for that reason
 struct FxgLds {
     u32 slot_bytes, so_ksrc, so_kidx, so_ktab;   // slot k lives at k * slot_bytes: k_off at +0, k_src at +so_ksrc, k_idx at +so_kidx, k_tab at +so_ktab
@@ -28,7 +28,9 @@ struct FxgLds {
     u32 has_tab;                                 // kernels that stage a tile of bases in LDS (clipper, census) spend no LDS on k_tab
 };
 __host__ __device__ inline u32 fxg_r16(u32 x) { return (x + 15u) & ~15u; }
-__host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, bool bitmaps, u32 stage_stride)   // stage_stride: row stride of the LDS copy of the tile's bases, 0 = none
+// nslots: tiles a workgroup keeps between decision and write-out (FxgTileDepth: 2, the clip instances 3)
+// bitmaps: 0 none, 2 both, 1 = ONE shared by trimmer and filter (same threshold: "below" is the complement of "at least"; off_bm_l == off_bm_g)
+__host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, u32 bitmaps, u32 stage_stride, u32 nslots = 2)   // stage_stride: row stride of the LDS copy of the tile's bases, 0 = none
 {
     FxgLds l;
     l.so_ksrc = fxg_r16((T + 1) * 4);
@@ -36,16 +38,20 @@ __host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, bool bitmaps
     l.so_ktab = l.so_kidx + fxg_r16(T * 2);
     l.has_tab = stage_stride ? 0u : 1u;
     l.slot_bytes = l.so_ktab + (l.has_tab ? fxg_r16(((T * stride + 15) / 16 + 1) * 2) : 0u);
-    u32 o = 2 * l.slot_bytes;
+    u32 o = nslots * l.slot_bytes;
     l.off_scratch = o; o += fxg_r16(48 * 4);
     l.off_tally = o;   o += FXG_NTALLY * 8;      // the workgroup's -v report tallies (u64), see fxg_tile_tally
     const u32 words = (T * stride + 31) / 32 + 2;
     l.off_bm_g = o;    o += bitmaps ? fxg_r16(words * 4) : 0;
-    l.off_bm_l = o;    o += bitmaps ? fxg_r16(words * 4) : 0;
+    l.off_bm_l = bitmaps == 1u ? l.off_bm_g : o;    o += bitmaps == 2u ? fxg_r16(words * 4) : 0;
     l.off_bases = o;   o += stage_stride ? fxg_r16(T * stage_stride + 16) : 0;
     l.total = o;
     return l;
 }
+
+// quality bitmaps a launch keeps in LDS (fxg_lds_layout): the clip instances share ONE between trimmer and filter when both use the
+// same threshold (the usual pipe) -- their LDS holds a tile of bases as well, and 5 KB decide how many workgroups fit on a CU
+FXG_HD u32 fxg_bitmap_count(const FxgKArgs &a, bool use_q, bool clip) { return !use_q ? 0u : (clip && a.tq == a.fq) ? 1u : 2u; }
 
 // ------------------------------------------------------------------------------------------------
 // fastx_clipper for one read: semi-global fp32 DP of read (query) x adapter (target) with the
@@ -60,9 +66,10 @@ FXG_HD void fxg_clip_finish(const FxgKArgs &a, int len, int qs, int ts, int mism
 {
     int i = -1;
     if (sz != 0 && !(a.clip_min_adapter_len > 0 && sz < a.clip_min_adapter_len)) {
+        // floor(100 m / sz) >= k  <=>  100 m >= k sz  (k an integer, sz > 0): no division
         if (bq == len - 1 && mism == 0) i = qs;
-        else if (sz > 5 && ts == 0 && (matches * 100 / sz) >= 75) i = qs;
-        else if (sz > 11 && (matches * 100 / sz) >= 80) i = qs;
+        else if (sz > 5 && ts == 0 && matches * 100 >= 75 * sz) i = qs;
+        else if (sz > 11 && matches * 100 >= 80 * sz) i = qs;
         else if (len >= 2 && bq >= len - 2 && sz <= 5 && matches >= 3) i = qs;
     }
     int cur = len;
@@ -158,7 +165,8 @@ FXG_HD void fxg_clip_read(const FxgKArgs &a, const uint8_t *rd, int len, int row
 // Sm holds every cell's score minus the gap penalty for the same reason (one subtraction serves `up` and `left`).
 // Cell rule (sequence_alignment.cpp:380-417): strict '>' from diag to up to left, i.e. the maximum with ties going to diag, then up:
 //   score = max3(ul, up, left); diag iff score == ul; else up iff score == up; else left.
-template <int AMAX, bool EARLY, bool FIRST, bool TN>
+// TRACK = false: the row cannot hold the first maximum (the second pass of fxg_clip_two_pass knows its row) -- no best-cell update.
+template <int AMAX, bool EARLY, bool FIRST, bool TN, bool TRACK = true>
 FXG_HD void fxg_clip_row_packed(const FxgKArgs &a, int A, u32 c, int q, float (&S)[AMAX], float (&Sm)[AMAX], u32 (&W)[AMAX], float &best, u32 &bw, u32 &bq)
 {
     const bool qn = (c == (u32)'N');
@@ -214,6 +222,7 @@ FXG_HD void fxg_clip_row_packed(const FxgKArgs &a, int A, u32 c, int q, float (&
         // bucket has AMIN bases, so only columns t >= AMIN need the test (none for the exact buckets 9..16) -- a mask that went
         // through a scalar AND costs a v_cndmask several times what a mask straight from a v_cmp does (scripts/ubench/valu_rate.hip).
         constexpr int AMIN = AMAX <= 4 ? 1 : (AMAX <= 8 ? 5 : (AMAX <= 16 ? AMAX : AMAX - 3));
+        if (!TRACK) continue;
         if (t < AMIN) {
             const bool gb = sc > best;
             bw = gb ? w : bw;
@@ -223,7 +232,7 @@ FXG_HD void fxg_clip_row_packed(const FxgKArgs &a, int A, u32 c, int q, float (&
             best = gb ? sc : best; bw = gb ? w : bw;
         }
     }
-    bq = (best > best_in) ? (u32)q : bq;                   // the best cell moved into this row (best only ever grows)
+    if (TRACK) bq = (best > best_in) ? (u32)q : bq;        // the best cell moved into this row (best only ever grows)
 }
 
 template <int AMAX, bool TN>
@@ -283,36 +292,39 @@ template <int AMAX> struct FxgClip2 {
     static constexpr int WIN = 3 * C;
 };
 
-// one row of pass 1: scores only; returns the row's maximum over the adapter's columns
-template <int AMAX, bool EARLY, bool TN>
+// one row of pass 1: scores only; returns the row's maximum over the adapter's columns.  One sweep (the cell above-left is saved
+// as the sweep passes it): with four waves per SIMD a wave issues every 6-10 cycles, which covers the dependent max3 -> add chain,
+// so nothing is gained by computing the diagonal candidates of the whole row first -- and that form copied the row every time.
+template <int AMAX, bool EARLY>
 FXG_HD float fxg_clip_row_score(const FxgKArgs &a, int A, u32 c, int q, float (&S)[AMAX], float (&Sm)[AMAX])
 {
     const bool qn = (c == (u32)'N');
-    const float pair_eq = qn ? 0.1f : 1.0f, pair_ne = qn ? 0.1f : -1.0f;                 // sequence_alignment.h:157-169
-    float ul[AMAX];
-#pragma unroll
-    for (int t = 0; t < AMAX; ++t) {                        // everything taken from the row above first (in-place update below)
-        const u32 tc = (u32)(uint8_t)a.adapter[t];
-        float pair = (c == tc) ? pair_eq : pair_ne;
-        if (TN) pair = (tc == (u32)'N') ? (qn ? 0.0f : 0.1f) : pair;
-        ul[t] = (t ? S[t - 1] : 0.0f) + pair;
-    }
-    float uSm = -5.0f, rowmax = -1000000.0f;
+    const float pair_eq = qn ? 0.1f : 1.0f, pair_ne = qn ? 0.1f : -1.0f;                 // sequence_alignment.h:157-169 (adapter without N)
+    float uSm = -5.0f, rowmax = -1000000.0f;                                             // S[q][-1] - 5
     constexpr int AMIN = AMAX <= 4 ? 1 : (AMAX <= 8 ? 5 : AMAX);      // smallest adapter of the bucket: columns below it always count
+    // The match masks of the whole row first: a lane mask needs two wait states between the v_cmp that writes it and the v_cndmask
+    // that reads it, and with the compare right in front of its select the compiler paid them in s_nops (11 per row).
+    bool eq[AMAX];
+#pragma unroll
+    for (int t = 0; t < AMAX; ++t) eq[t] = (c == (u32)(uint8_t)a.adapter[t]);
+    // the diagonal candidate of column t + 1 is taken from S[t] BEFORE the sweep overwrites S[t]: every array is updated in place
+    float ul = 0.0f + (eq[0] ? pair_eq : pair_ne);                                       // S[q-1][-1] = query_border = 0
 #pragma unroll
     for (int t = 0; t < AMAX; ++t) {
+        float ul_next = 0.0f;
+        if (t + 1 < AMAX) ul_next = S[t] + (eq[t + 1] ? pair_eq : pair_ne);
         float left = Sm[t];
         if (EARLY && t > 3) left = (t - 3 > q) ? -100000.0f : left;                      // sequence_alignment.cpp:387-389
-        const float sc = fmaxf(fmaxf(ul[t], uSm), left);
+        const float sc = fmaxf(fmaxf(ul, uSm), left);
         const float scm = sc + -5.0f;
-        S[t] = sc; Sm[t] = scm; uSm = scm;
+        S[t] = sc; Sm[t] = scm; uSm = scm; ul = ul_next;
         if (t < AMIN) rowmax = fmaxf(rowmax, sc);
         else rowmax = (t < A) ? fmaxf(rowmax, sc) : rowmax;
     }
     return rowmax;
 }
 
-template <int AMAX, bool TN>
+template <int AMAX>
 FXG_HD void fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float &best, u32 &bw, u32 &bq, int &first_n)
 {
     constexpr int C = FxgClip2<AMAX>::C;
@@ -328,7 +340,7 @@ FXG_HD void fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int
     u32 cn = rd[0];
     // chunk j = rows [j C, j C + C): saves the row before it in Psave = P[j % 3]; the restart row for a best found in it is
     // Pwin = P[(j + 1) % 3] = the row before chunk j - 2 (before chunk 0 for j < 2: the border, which all three start from)
-#define FXG_CLIP_CHUNK(Psave, Pwin)                                                                                          \
+#define FXG_CLIP_CHUNK(EARLY, Psave, Pwin)                                                                                   \
     {                                                                                                                        \
         _Pragma("unroll") for (int t = 0; t < AMAX; ++t) Psave[t] = S[t];                                                    \
         const int q0 = q, qend = q + C < rows ? q + C : rows;                                                                \
@@ -336,9 +348,7 @@ FXG_HD void fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int
         _Pragma("unroll 1") for (; q < qend; ++q) {                                                                          \
             const u32 c = cn;                                                                                                \
             cn = rd[q + 1];                                                                                                  \
-            first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;                                            \
-            const float rm = q < early_rows ? fxg_clip_row_score<AMAX, true, TN>(a, A, c, q, S, Sm)                          \
-                                            : fxg_clip_row_score<AMAX, false, TN>(a, A, c, q, S, Sm);                        \
+            const float rm = fxg_clip_row_score<AMAX, EARLY>(a, A, c, q, S, Sm);                                             \
             const bool g = rm > b1;                                                                                          \
             b1 = g ? rm : b1; bq1 = g ? q : bq1; upd = upd || g;                                                             \
         }                                                                                                                    \
@@ -347,26 +357,36 @@ FXG_HD void fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int
             r0 = q0 - 2 * C > 0 ? q0 - 2 * C : 0;                                                                            \
         }                                                                                                                    \
     }
+    // the early rule (rows q < A - 4, sequence_alignment.cpp:387-389) can only fire in the first two chunks: 2 C >= SPAN - 1 >= A - 4
+    static_assert(2 * C >= AMAX - 4, "early rows must end inside the first two chunks");
+    FXG_CLIP_CHUNK(true, P0, P1)
+    if (q < rows) FXG_CLIP_CHUNK(true, P1, P2)
     while (q < rows) {
-        FXG_CLIP_CHUNK(P0, P1)
+        FXG_CLIP_CHUNK(false, P2, P0)
         if (q >= rows) break;
-        FXG_CLIP_CHUNK(P1, P2)
+        FXG_CLIP_CHUNK(false, P0, P1)
         if (q >= rows) break;
-        FXG_CLIP_CHUNK(P2, P0)
+        FXG_CLIP_CHUNK(false, P1, P2)
     }
 #undef FXG_CLIP_CHUNK
-    // ---- pass 2: rows r0 .. bq1 with the path summaries, from the checkpoint ----
+    // ---- pass 2: rows r0 .. bq1 with the path summaries, from the checkpoint; only row bq1 can hold the first maximum ----
     u32 W[AMAX];
 #pragma unroll
     for (int t = 0; t < AMAX; ++t) { S[t] = CB[t]; Sm[t] = CB[t] + -5.0f; W[t] = ((u32)(t + 1) << 19) + FXG_PK_SZ1; }
     q = r0;
     int i = 0;
 #pragma unroll 1
-    for (; q <= bq1 && i < early_rows; ++q, ++i)            // window row i is read row r0 + i >= i: rows past i = A - 4 are past the early rule
-        fxg_clip_row_packed<AMAX, true, false, TN>(a, A, (u32)rd[q], q, S, Sm, W, best, bw, bq);
+    for (; q < bq1 && i < early_rows; ++q, ++i)             // window row i is read row r0 + i >= i: rows past i = A - 4 are past the early rule
+        fxg_clip_row_packed<AMAX, true, false, false, false>(a, A, (u32)rd[q], q, S, Sm, W, best, bw, bq);
 #pragma unroll 1
-    for (; q <= bq1; ++q)
-        fxg_clip_row_packed<AMAX, false, false, TN>(a, A, (u32)rd[q], q, S, Sm, W, best, bw, bq);
+    for (; q < bq1; ++q)
+        fxg_clip_row_packed<AMAX, false, false, false, false>(a, A, (u32)rd[q], q, S, Sm, W, best, bw, bq);
+    fxg_clip_row_packed<AMAX, true, false, false, true>(a, A, (u32)rd[bq1], bq1, S, Sm, W, best, bw, bq);
+    // the -n rule needs the first N of the read itself (fastx_clipper.cpp:306-311); nothing else does
+    if (!(a.clip_flags & FXG_CLIP_KEEP_N)) {
+#pragma unroll 1
+        for (int k = len - 1; k >= 0; --k) first_n = (rd[k] == (uint8_t)'N') ? k : first_n;
+    }
 }
 
 template <int AMAX>
@@ -378,7 +398,7 @@ FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len, 
     int first_n = len;
     // adapters that contain 'N' take the general form (fxg_plan.h): the packed instances keep no per-column neutral selects
 #ifndef FXG_CLIP_ONE_PASS
-    if constexpr (AMAX <= 16) fxg_clip_two_pass<AMAX, false>(a, rd, len, rows, best, bw, bq, first_n);
+    if constexpr (AMAX <= 16) fxg_clip_two_pass<AMAX>(a, rd, len, rows, best, bw, bq, first_n);
     else
 #endif
     fxg_clip_rows_packed<AMAX, false>(a, rd, len, rows, best, bw, bq, first_n);
@@ -439,6 +459,7 @@ FXG_HD void fxg_phase_bitmaps(const FxgKArgs &a, u64 tb, u32 tbytes, u32 *bm_g, 
     const bool same = a.tq == a.fq;      // trimmer and filter at the same threshold (the usual pipe): "below" is the complement of "at least"
     const u32 nchunks = (tbytes + 15u) >> 4;
     uint16_t *g16 = reinterpret_cast<uint16_t *>(bm_g), *l16 = reinterpret_cast<uint16_t *>(bm_l);
+    const bool one = bm_l == bm_g;       // one shared bitmap (fxg_bitmap_count): the filter counts its complement
     const uint8_t *src = a.qual + tb;
     if ((tbytes & 15u) == 0u && tb + tbytes <= a.total_bytes) {
         constexpr u32 U = FXG_BITMAP_U;
@@ -452,7 +473,7 @@ FXG_HD void fxg_phase_bitmaps(const FxgKArgs &a, u64 tb, u32 tbytes, u32 *bm_g, 
 #pragma unroll
             for (u32 u = 0; u < U; ++u) {
                 const u32 c = c0 + u * nthreads;
-                if (c < nchunks) { const u32 g = fxg_mask16(v[u], Kg); g16[c] = (uint16_t)g; l16[c] = (uint16_t)(~(same ? g : fxg_mask16(v[u], Kf))); }
+                if (c < nchunks) { const u32 g = fxg_mask16(v[u], Kg); g16[c] = (uint16_t)g; if (!one) l16[c] = (uint16_t)(~(same ? g : fxg_mask16(v[u], Kf))); }
             }
         }
         return;
@@ -461,7 +482,7 @@ FXG_HD void fxg_phase_bitmaps(const FxgKArgs &a, u64 tb, u32 tbytes, u32 *bm_g, 
         const u32 o = c << 4;
         const u32x4 v = fxg_window(a.qual, (long long)(tb + o), a.total_bytes, 0, (int)(tbytes - o < 16u ? tbytes - o : 16u));
         g16[c] = (uint16_t)fxg_mask16(v, Kg);
-        l16[c] = (uint16_t)(~fxg_mask16(v, Kf));
+        if (!one) l16[c] = (uint16_t)(~fxg_mask16(v, Kf));
     }
 }
 
@@ -495,14 +516,18 @@ FXG_HD u32 fxg_decide_a(const FxgKArgs &a, const u32 *bm_g, const u32 *bm_l, con
     u32 reason = FXG_R_KEPT, clipped = 0, keep = 1, curlen = rl, ao = 0;
     const int rows = a.wlen ? (int)a.wlen[r0 + tid] : (int)rl;      // clip history: the DP also runs over the stale tail (fxg_history.h)
     if constexpr (AMAX > 0) fxg_clip_read<AMAX>(a, sb + tid * a.clip_stride, (int)rl, rows, &curlen, &keep, &reason, &clipped, &ao);
-    if constexpr (AMAX < 0) fxg_clip_read_packed<-AMAX>(a, sb + tid * a.clip_stride, (int)rl, rows, &curlen, &keep, &reason, &clipped, &ao);
+    if constexpr (AMAX < 0) {
+        // fixed-length batch without clip history: the row count is a scalar, so every loop of the DP is a scalar loop
+        if (!a.len && !a.wlen) fxg_clip_read_packed<-AMAX>(a, sb + tid * a.clip_stride, (int)a.fixed_len, (int)a.fixed_len, &curlen, &keep, &reason, &clipped, &ao);
+        else fxg_clip_read_packed<-AMAX>(a, sb + tid * a.clip_stride, (int)rl, rows, &curlen, &keep, &reason, &clipped, &ao);
+    }
     if (keep && (a.stages & FXG_STAGE_QTRIM)) {             // fastq_quality_trimmer.c:94-101
         const u32 k = fxg_bits_last(bm_g, tid * stride, curlen);
         curlen = k;
         if (!(k > 0 && (int)k >= a.qt_min_len)) { keep = 0; reason = FXG_R_QTRIM; }
     }
     if (keep && (a.stages & FXG_STAGE_QFILTER)) {           // fastq_quality_filter.c:110-129,155 in closed form
-        const u32 low = fxg_bits_count(bm_l, tid * stride, curlen);
+        const u32 low = bm_l == bm_g ? curlen - fxg_bits_count(bm_g, tid * stride, curlen) : fxg_bits_count(bm_l, tid * stride, curlen);
         int n0 = (int)curlen * a.qf_keep_pct / 100;
         if (n0 < 0) n0 = 0;
         if (a.qf_drop_all || (int)low > n0) { keep = 0; reason = FXG_R_QFILTER; }
@@ -617,23 +642,39 @@ __device__ __forceinline__ void fxg_tile_tally(u32 w, bool valid, u64 *tally)
 #define FXG_CLIP_WAVES 4  // the same for the packed clip instances up to 16 adapter columns (S, S-5 and the path summary of every column live in registers)
 #endif
 #define FXG_NO_TILE 0xFFFFFFFFu
+// Threads per workgroup of an instance (FXG_CLIP_TBLOCK for the two-pass clip instances).  One wave per workgroup (64-read tiles, no
+// workgroup barrier anywhere) was built and measured for them: cfg3 14.2 against 13.9 ms, cfg5 60 against 50 ms (four times the tiles
+// to scan, publish and ticket, and 13 single-wave workgroups do not spread evenly over four SIMDs) -- profiles/r03/i_ablate.txt.
+// Steps between a tile's decision and its write-out (FxgKArgs.depth, chosen in fxg_plan.h).  The write-out needs the tile's place in the output, i.e. every EARLIER tile decided:
+// one step of slack (all the streaming instances need) is not enough where a step is a 50-microsecond DP whose speed depends on
+// what the other three waves of the SIMD are doing -- the clip instances waited for the prefix 17 % of their time
+// (profiles/r03/c_ablate_clip.txt); two steps behind, the slowest of the ~1000 tiles in flight has a whole extra DP to catch up.
+template <int AMAX, int MODE> struct FxgTileBlock { static constexpr int threads = (MODE == 0 && AMAX < 0 && AMAX >= -16) ? FXG_CLIP_TBLOCK : FXG_TBLOCK; };
 template <int AMAX, int MODE>
-__global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : ((AMAX < 0 && AMAX >= -16) ? FXG_CLIP_WAVES : 1))) void fxg_kernel_tiles(const FxgKArgs a)
+__global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? FXG_MIN_WAVES : ((AMAX < 0 && AMAX >= -16) ? FXG_CLIP_WAVES : 1))) void fxg_kernel_tiles(const FxgKArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool REV = (MODE == 2);
+    constexpr u32 TB = (u32)FxgTileBlock<AMAX, MODE>::threads, TW = TB / 64u;
     const u32 T = a.tile_reads, stride = a.stride, tid = threadIdx.x;
     const bool use_q = (MODE == 0 && (a.stages & (FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0) || MODE == 3;
-    const FxgLds L = fxg_lds_layout(T, stride, use_q, (MODE == 0 && AMAX != 0) ? a.clip_stride : (MODE == 4 ? stride : 0u));
+    const u32 NSLOT = (MODE == 0 && AMAX != 0) ? a.depth : 2u;        // tiles between decision and write-out (fxg_plan.h)
+    const FxgLds L = fxg_lds_layout(T, stride, fxg_bitmap_count(a, use_q, MODE == 0 && AMAX != 0), (MODE == 0 && AMAX != 0) ? a.clip_stride : (MODE == 4 ? stride : 0u), NSLOT);
     u32 m_reads = 0, m_nt = 0, art_bad = 0;      // MODE 3 report counters / MODE 4 alphabet check, folded once at the end
     u32 *bm_g = reinterpret_cast<u32 *>(smem + L.off_bm_g);
     u32 *bm_l = reinterpret_cast<u32 *>(smem + L.off_bm_l);
     uint8_t *sb = smem + L.off_bases;
-    u32 *scratch = reinterpret_cast<u32 *>(smem + L.off_scratch);   // [0,2W) scan, then 4 words tile totals per slot, 2 tickets, 2 pad
-    u32 *s_tot = scratch + 2 * FXG_TWAVES, *s_ticket = s_tot + 4;
+    u32 *scratch = reinterpret_cast<u32 *>(smem + L.off_scratch);   // [0,2W) scan, then 2 words of tile totals per slot (<= 3 slots), 2 tickets
+    u32 *s_tot = scratch + 2 * TW, *s_ticket = s_tot + 6;
     u64 *bc = reinterpret_cast<u64 *>(s_tot + 8);                   // [0,2) broadcast of the resolved bases
     u64 *tally = reinterpret_cast<u64 *>(smem + L.off_tally);       // this workgroup's share of the -v report counters
     if (tid < FXG_NTALLY) tally[tid] = 0ull;
+#ifdef FXG_ABLATION
+    u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = __builtin_amdgcn_s_memrealtime();   // 100 MHz clocks per phase (wave 0 of the workgroup), summed over its tiles
+#define FXG_TPHASE(i) do { const u64 now_ = __builtin_amdgcn_s_memrealtime(); ph[i] += now_ - pt; pt = now_; } while (0)
+#else
+#define FXG_TPHASE(i) do { } while (0)
+#endif
 
     // One workgroup turns the tiles' totals into prefixes (fxg_scanner); the others process tiles.
     if (a.compact) {
@@ -649,10 +690,19 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : ((AMAX < 0
     // progress never depends on residency, dispatch order or placement.
     const u32 G = a.ticket_groups, grp = blockIdx.x % G;
     u32 *my_ticket = a.ticket + grp * FXG_TICKET_STRIDE;
+    if constexpr (MODE == 0 && AMAX != 0) {
+        // The workgroups of a CU start together and take the same time per tile, so they would sit in the DP together (four waves
+        // per SIMD competing for the VALU) and then in the write-out together (VALU idle).  Waves that share a SIMD have different
+        // wave slots: starting slot k late by k * stagger spreads the phases, and nothing pulls them back together.
+        if (a.stagger && tid == 0) {
+            const u32 wslot = (u32)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15u;      // HW_REG_HW_ID, WAVE_ID
+            for (u32 i = 0; i < wslot * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
     if (tid == 0) s_ticket[0] = atomicAdd(my_ticket, 1u);
     __syncthreads();
     u32 cur = s_ticket[0] * G + grp;
-    u32 pend = FXG_NO_TILE;
+    u32 pend = FXG_NO_TILE, mid = FXG_NO_TILE;            // pend: written out in this step; mid (three slots): decided last step, written out next step
     u32 slot = 0, tk = 0;
     for (;;) {
         u64 peek = 0;                                    // first look at the prefix of `pend`, in flight during stage A
@@ -669,11 +719,12 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : ((AMAX < 0
             const u32 tbytes = nreads * stride;
             unsigned char *sl = smem + slot * L.slot_bytes;
             if constexpr (MODE == 0 || MODE == 3 || MODE == 4) {
-                if (use_q && !FXG_DBG(a, 8u)) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, FXG_TBLOCK);
-                if constexpr (MODE == 0 && AMAX != 0) fxg_phase_stage_bases(a.clip_src, a.clip_total, (u64)r0 * a.clip_stride, nreads * a.clip_stride, sb, tid, FXG_TBLOCK);
-                if constexpr (MODE == 4) fxg_phase_stage_bases(a.bases, a.total_bytes, tb, tbytes, sb, tid, FXG_TBLOCK);
+                if (use_q && !FXG_DBG(a, 8u)) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, TB);
+                if constexpr (MODE == 0 && AMAX != 0) fxg_phase_stage_bases(a.clip_src, a.clip_total, (u64)r0 * a.clip_stride, nreads * a.clip_stride, sb, tid, TB);
+                if constexpr (MODE == 4) fxg_phase_stage_bases(a.bases, a.total_bytes, tb, tbytes, sb, tid, TB);
                 __syncthreads();
             }
+            FXG_TPHASE(0);
             u32 keep = 0, olen = 0, anchor = tid * stride, word = 0;
             if (tid < nreads) {
                 if constexpr (MODE == 0) word = fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen);
@@ -683,9 +734,10 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : ((AMAX < 0
             }
             // the -v report counters (a12) are functions of res[]: tally the drop reasons this instance can produce, per wave, as the
             // words go by (popcount of a ballot; one LDS add per wave and reason that occurred) instead of a second pass over res[]
+            FXG_TPHASE(1);
             fxg_tile_tally<AMAX, MODE>(word, tid < nreads, tally);
             u32 exc, exb, totc, totb;
-            fxg_block_scan2(keep, keep ? olen : 0u, scratch, &exc, &exb, &totc, &totb);   // one __syncthreads inside
+            fxg_block_scan2<(int)TW>(keep, keep ? olen : 0u, scratch, &exc, &exb, &totc, &totb);   // one __syncthreads inside
             if (tid == 0) { tally[0] += nreads; tally[1] += totc; tally[2] += totb; }
             if (a.compact) {
                 if (tid == 0) fxg_publish_total(a, cur, totc, totb);     // as early as possible: the scanner and every later tile wait for it
@@ -698,11 +750,12 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : ((AMAX < 0
                 }
                 if (tid == 0) { k_off[totc] = totb; s_tot[2 * slot] = totc; s_tot[2 * slot + 1] = totb; }
             }
+            FXG_TPHASE(2);
         }
-        // ------------------------------ stage B: tile `pend` from slot `slot ^ 1` ------------------------------
-        // (one step behind stage A: the scanner has had a whole stage A to deliver the prefix, so the wait is off the critical path)
+        // ------------------------------ stage B: tile `pend`, decided NSLOT - 1 steps ago ------------------------------
+        // (behind stage A: the scanner has had at least a whole stage A to deliver the prefix, so the wait is off the critical path)
         if (pend != FXG_NO_TILE && a.compact) {
-            const u32 ps = slot ^ 1u;
+            const u32 ps = slot + 1u == NSLOT ? 0u : slot + 1u;
             const u32 r0 = pend * T;
             const u64 left = a.n - (u64)r0;
             const u32 nreads = left < (u64)T ? (u32)left : T;
@@ -713,22 +766,29 @@ __global__ __launch_bounds__(FXG_TBLOCK, (AMAX == 0 ? FXG_MIN_WAVES : ((AMAX < 0
             const uint16_t *k_tab = L.has_tab ? reinterpret_cast<const uint16_t *>(sl + L.so_ktab) : nullptr;
             if (tid < 64 && !FXG_DBG(a, 2u)) fxg_wait_prefix(a, pend, peek, bc);
             __syncthreads();
+            FXG_TPHASE(3);
             const u64 base_c = bc[0], base_b = bc[1];
             const u32 nk = s_tot[2 * ps], totb = s_tot[2 * ps + 1];
             if (tid < nk) fxg_write_kept_meta(a, base_c + tid, k_off[tid + 1] - k_off[tid], r0 + k_idx[tid], base_b + k_off[tid]);
             if (!FXG_DBG(a, 1u)) {
-                const u32 bad = fxg_tile_gather<REV, MODE == 3>(a, k_off, k_src, k_tab, nk, (u64)r0 * stride, nreads * stride, base_b, totb, tid, FXG_TBLOCK);
+                // the clip instances run four waves per SIMD: their gather keeps four chunks per lane in flight (FXG_GATHER_K)
+                constexpr int GK = (MODE == 0 && AMAX != 0) ? FXG_CLIP_GATHER_K : FXG_GATHER_K;
+                const u32 bad = fxg_tile_gather<REV, MODE == 3, GK>(a, k_off, k_src, k_tab, nk, (u64)r0 * stride, nreads * stride, base_b, totb, tid, TB);
                 if (REV && bad) atomicOr(a.errflag, FXG_DEV_ERR_BAD_BASE);
             }
+            FXG_TPHASE(4);
         }
-        if (cur >= a.ntiles) break;
-        __syncthreads();            // ticket written by thread 0 in stage A; also fences slot reuse two iterations apart
-        pend = cur;
-        tk ^= 1u;
-        cur = s_ticket[tk] * G + grp;
-        slot ^= 1u;
+        if (cur >= a.ntiles && (NSLOT == 2u || mid == FXG_NO_TILE)) break;
+        __syncthreads();            // ticket written by thread 0 in stage A; also fences slot reuse NSLOT iterations apart
+        const u32 done = cur < a.ntiles ? cur : FXG_NO_TILE;
+        if (NSLOT == 3u) { pend = mid; mid = done; } else pend = done;
+        if (cur < a.ntiles) { tk ^= 1u; cur = s_ticket[tk] * G + grp; }
+        slot = slot + 1u == NSLOT ? 0u : slot + 1u;
     }
     __syncthreads();
+#ifdef FXG_ABLATION
+    if (tid == 0) for (int i = 0; i < 8; ++i) atomicAdd(reinterpret_cast<u64 *>(a.errflag + 10) + i, ph[i]);
+#endif
     if (tid < FXG_NTALLY && tally[tid]) atomicAdd(&a.tally[tid], tally[tid]);     // one global add per workgroup and non-zero slot
     if constexpr (MODE == 3) {                       // masked reads / nucleotides: wave sums, one atomic pair per wave, once
         for (int d = 32; d >= 1; d >>= 1) { m_reads += __shfl_xor(m_reads, d, 64); m_nt += __shfl_xor(m_nt, d, 64); }

@@ -16,20 +16,21 @@ struct FxgPlan {
     int  amax;      // adapter bucket of the clip kernel instance (0 = no clip)
     u32  lds;       // dynamic LDS bytes per workgroup
     int  rows_nw;   // != 0: the quality stages run as fxg_kernel_rows<rows_nw> (fxg_rows.h): dwords of one read's row
+    u32  block;     // threads per workgroup of the instance (FxgTileBlock)
 };
 
 static inline int fxg_clampi(long long v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : (int)v); }
 
-static inline u32 fxg_pick_tile(u32 stride, bool clip)
+static inline u32 fxg_pick_tile(u32 stride, bool clip, u32 block = FXG_TBLOCK)
 {
     // Rows one workgroup covers per tile.  Streaming kernels: about 20 KB (128 reads of 150 bases) -- with the central scanner the
     // per-tile cost is small enough that the shorter pipeline step wins (cfg2: 4.13 ms at 128 reads, 4.19-4.31 at 256, 5.9 at 64;
     // profiles/r02/variants_*.txt).  Kernels that stage the tile's bases in LDS (clipper, census): up to 60 KB so that two or
     // more workgroups share a CU.
     const u64 budget = clip ? 60ull * 1024 : 20ull * 1024;
-    u32 T = FXG_MAX_TILE;
-    const char *env = getenv("FXG_TILE");   // tuning knob: 1..256, power of two
-    if (env && atoi(env) >= 1 && atoi(env) <= FXG_MAX_TILE && (atoi(env) & (atoi(env) - 1)) == 0) return (u32)atoi(env);
+    u32 T = block;                          // one thread decides one read
+    const char *env = getenv("FXG_TILE");   // tuning knob: 1..block, power of two
+    if (env && atoi(env) >= 1 && atoi(env) <= (int)block && (atoi(env) & (atoi(env) - 1)) == 0) return (u32)atoi(env);
     while (T > 1 && (u64)T * stride > budget) T >>= 1;
     return T;
 }
@@ -37,9 +38,9 @@ static inline u32 fxg_pick_tile(u32 stride, bool clip)
 static inline FxgLds fxg_plan_layout(const FxgPlan *pl)
 {
     const FxgKArgs &ka = pl->ka;
-    return pl->group_a ? fxg_lds_layout(ka.tile_reads, ka.stride, pl->use_q, pl->clip ? ka.clip_stride : 0u)
-         : pl->mask ? fxg_lds_layout(ka.tile_reads, ka.stride, true, 0u)
-         : pl->artifacts ? fxg_lds_layout(ka.tile_reads, ka.stride, false, ka.stride) : fxg_lds_layout(ka.tile_reads, ka.stride, false, 0u);
+    return pl->group_a ? fxg_lds_layout(ka.tile_reads, ka.stride, fxg_bitmap_count(ka, pl->use_q, pl->clip), pl->clip ? ka.clip_stride : 0u, pl->clip ? ka.depth : 2u)
+         : pl->mask ? fxg_lds_layout(ka.tile_reads, ka.stride, 2u, 0u)
+         : pl->artifacts ? fxg_lds_layout(ka.tile_reads, ka.stride, 0u, ka.stride) : fxg_lds_layout(ka.tile_reads, ka.stride, 0u, 0u);
 }
 static inline u32 fxg_plan_lds(const FxgPlan *pl) { return fxg_plan_layout(pl).total; }
 
@@ -113,10 +114,21 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     pl->rows_nw = 0;
     if (ga && !pl->clip && ka.compact && in->stride >= 80u && in->stride <= 152u && !(getenv("FXG_ROWS") && atoi(getenv("FXG_ROWS")) == 0))
         pl->rows_nw = in->stride <= 104u ? 26 : 38;
-    const u32 T = pl->rows_nw ? 64u : fxg_pick_tile(pl->clip ? ka.clip_stride : in->stride, pl->clip || gf);
+    pl->block = pl->rows_nw ? 64u : (ga && pl->amax < 0 && pl->amax >= -16) ? (u32)FXG_CLIP_TBLOCK : (u32)FXG_TBLOCK;     // FxgTileBlock
+    const u32 T = pl->rows_nw ? 64u : fxg_pick_tile(pl->clip ? ka.clip_stride : in->stride, pl->clip || gf, pl->block);
     const u64 ntiles = (in->n + T - 1) / T;
     if (ntiles > 0x7FFFFFFFull || in->n > 0xFFFFFFFFull) FXG_PLAN_FAIL("batch too large (%llu reads): split it", (unsigned long long)in->n);
     ka.tile_reads = T; ka.ntiles = (u32)ntiles;
+    // clip instances: the write-out runs two steps behind the decision (three slots) unless the extra slot costs a workgroup per CU
+    ka.depth = 2u;
+    if (pl->clip && FXG_CLIP_DEPTH == 3u) {
+        const u32 cu_lds = 160u * 1024u, regs_wg = pl->block == 64u ? 16u : 4u;      // workgroups per CU the registers allow (128 VGPRs)
+        const u32 lds2 = fxg_plan_lds(pl);
+        ka.depth = 3u;
+        const u32 lds3 = fxg_plan_lds(pl);
+        const u32 wg2 = cu_lds / lds2 < regs_wg ? cu_lds / lds2 : regs_wg, wg3 = cu_lds / lds3 < regs_wg ? cu_lds / lds3 : regs_wg;
+        if (wg3 < wg2) ka.depth = 2u;
+    }
     pl->lds = pl->rows_nw ? fxg_rows_lds(ka.stride) : fxg_plan_lds(pl);
     return FXG_OK;
 }

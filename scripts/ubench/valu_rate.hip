@@ -88,6 +88,19 @@ __global__ __launch_bounds__(1024) void k(unsigned long long *out, unsigned *sin
                                    : "=v"(d0), "=v"(d1), "=v"(d2), "=v"(d3) : "v"((threadIdx.x & 63u) * 16u + 4u) : "memory");   // 8-byte reads at 4-byte alignment
         if (OP == 30) asm volatile(X8("v_alignbyte_b32 %0, %1, %0, %8\n v_alignbyte_b32 %1, %2, %1, %8\n v_alignbyte_b32 %2, %3, %2, %8\n v_alignbyte_b32 %3, %4, %3, %8\n v_alignbyte_b32 %4, %5, %4, %8\n v_alignbyte_b32 %5, %6, %5, %8\n v_alignbyte_b32 %6, %7, %6, %8\n v_alignbyte_b32 %7, %0, %7, %8\n")
                                    : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(threadIdx.x & 3u));
+        // ---- dependent issue: how far apart must two instructions of ONE wave be when the second reads the first's result ----
+        if (OP == 31) asm volatile(X64("v_max3_f32 %0, %0, %1, %2\n") : "+v"(f0) : "v"(f1), "v"(f2));                                   // one chain
+        if (OP == 32) asm volatile(X8("v_max3_f32 %0, %0, %2, %3\n v_max3_f32 %1, %1, %2, %3\n v_max3_f32 %0, %0, %2, %3\n v_max3_f32 %1, %1, %2, %3\n v_max3_f32 %0, %0, %2, %3\n v_max3_f32 %1, %1, %2, %3\n v_max3_f32 %0, %0, %2, %3\n v_max3_f32 %1, %1, %2, %3\n")
+                                   : "+v"(f0), "+v"(f1) : "v"(f2), "v"(f3));                                                                // two chains
+        if (OP == 33) asm volatile(X8("v_max3_f32 %0, %0, %4, %5\n v_max3_f32 %1, %1, %4, %5\n v_max3_f32 %2, %2, %4, %5\n v_max3_f32 %3, %3, %4, %5\n v_max3_f32 %0, %0, %4, %5\n v_max3_f32 %1, %1, %4, %5\n v_max3_f32 %2, %2, %4, %5\n v_max3_f32 %3, %3, %4, %5\n")
+                                   : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(f4), "v"(f5));                                            // four chains
+        if (OP == 34) asm volatile(X64("v_add_f32 %0, %0, %1\n") : "+v"(f0) : "v"(f1));                                                    // one chain of adds
+        // the score row of the clip kernel's first pass, one cell after the other: cmp -> cndmask -> add -> max3 -> add, each feeding the next
+        if (OP == 35) asm volatile(X8("v_cmp_eq_u32 vcc, %4, %5\n v_cndmask_b32 %2, %6, %7, vcc\n v_add_f32 %2, %2, %1\n v_max3_f32 %1, %2, %0, %3\n v_add_f32 %0, %8, %1\n v_cmp_eq_u32 vcc, %4, %5\n v_cndmask_b32 %2, %6, %7, vcc\n v_add_f32 %2, %2, %1\n")
+                                   : "+v"(f0), "+v"(f1), "+v"(f2) : "v"(f3), "v"(u0), "v"(u1), "v"(f4), "v"(f5), "v"(f6) : "vcc");
+        // the same with two independent cells interleaved
+        if (OP == 36) asm volatile(X8("v_cmp_eq_u32 vcc, %7, %8\n v_cmp_eq_u32 s[20:21], %7, %9\n v_cndmask_b32 %2, %10, %11, vcc\n v_cndmask_b32 %5, %10, %11, s[20:21]\n v_add_f32 %2, %2, %1\n v_add_f32 %5, %5, %4\n v_max3_f32 %1, %2, %0, %6\n v_max3_f32 %4, %5, %3, %6\n")
+                                   : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5) : "v"(f6), "v"(u0), "v"(u1), "v"(u2), "v"(f7), "v"(f7) : "vcc", "s20", "s21");
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if ((threadIdx.x & 63u) == 0u) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
@@ -130,6 +143,8 @@ int main(int argc, char **argv)
     RUN(22, "v_cmp vcc ; s_and_b64 vcc ; v_cndmask vcc"); RUN(23, "v_cndmask_e64 with loop-invariant s[] masks");
     RUN(24, "v_cmp vcc ; 3 x v_cndmask vcc"); RUN(25, "v_cmp vcc ; 3 VALU ; v_cndmask vcc ; 2 VALU ; v_cndmask"); RUN(26, "v_cmp vcc ; v_addc vcc (pairs)");
     RUN(27, "ds_read_b32 (dword-aligned windows)"); RUN(28, "ds_read2_b32 (dword-aligned)"); RUN(29, "ds_read_b64 at 4-byte alignment"); RUN(30, "v_alignbyte_b32");
+    RUN(31, "v_max3_f32, ONE dependent chain"); RUN(32, "v_max3_f32, two chains"); RUN(33, "v_max3_f32, four chains"); RUN(34, "v_add_f32, ONE dependent chain");
+    RUN(35, "clip score cell (cmp,cndmask,add,max3,add dependent)"); RUN(36, "two clip score cells interleaved");
     RUN(15, "ds_add_u32 conflict-free"); RUN(16, "ds_add_u32 all lanes on one bank"); RUN(17, "ds_read_b128 aligned"); RUN(18, "ds_read_b128 unaligned (+5 B)");
     return 0;
 }
