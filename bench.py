@@ -33,9 +33,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
-# VALU issue peak for the clip kernel's instruction mix: 256 CUs x 4 SIMDs, one wave64 instruction per VALU_CYCLES cycles at 2.4 GHz
-# (scripts/ubench/valu_rate.hip measures the cycles per instruction class; profiles/r02_valu_rate.txt)
-VALU_CYCLES = 4.0
+# VALU peak: a SIMD issues one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md "Wave scheduling" and the per-instruction
+# table: v_fma_f32 wave64 = 2 cycles; 157.3 TFLOP/s fp32 vector = 78.6 T lane-ops/s x 2 flops), 256 CUs x 4 SIMDs x 64 lanes at 2.4 GHz.
+# The clip kernel's own instruction classes reach 1.6-2.6 cycles at four waves per SIMD (scripts/ubench/valu_rate.hip, profiles/r02_valu_rate_a.txt,
+# profiles/r03/g_valu_rate_dependent.txt), so a fraction of this peak near 0.8 is the practical ceiling for its mix.
+VALU_CYCLES = 2.0
 VALU_PEAK_GLANEOPS = 256 * 4 * 64 / VALU_CYCLES * 2.4
 ADAPTER = b"AGATCGGAAGAGC"
 QTF = dict(qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80)
@@ -56,8 +58,29 @@ CONFIGS = {
     "stats": dict(seed=2, reads=50_000_000, L=150, adapter=False, params=None,
                   metric="Mreads/s (150 bp) quality statistics", bound="hbm", what="fastx_quality_stats (per-cycle histogram reduction)"),
 }
-# static VALU instruction count per DP cell of fxg_kernel_tiles<-13,0>'s row loop (llvm-objdump of the shipped code object)
-CLIP_VALU_PER_CELL = 15.3
+# VALU wave-instructions the clip kernel issues per DP cell of the L x 13 matrix, everything included (both passes, staging, write-out):
+# SQ_INSTS_VALU x 64 / cells of profiles/r03_clip_pmc (scripts/pmc_sq.sh).  The first pass alone is 6.2 per cell (llvm-objdump of the row loop).
+CLIP_VALU_PER_CELL = {"cfg3": 10.6, "cfg5shard": 9.6}
+
+# What the timed launches of the default workloads must produce: (kept reads, kept bases, Result.checksum()).  The same tuples are
+# asserted by tests/test_gpu_parity.py::test_full_size_* on runs whose res[] and packed streams are compared with the oracle in a
+# prefix window, a suffix window and seeded interior windows -- so a bench line whose self_check matches is the oracle-verified output.
+EXPECTED = {
+    "cfg2": (33431448, 3558930905, 2378887646053514995),
+    "cfg3": (44712033, 3240876702, 531446952678075522),
+    "cfg4": (200000000, 28200000000, 8156573128088355123),
+    "cfg5shard": (71509386, 6067408648, 8691884730239237722),
+}
+
+
+def csrc_sha16():
+    """Hash of the kernel sources: counters replayed from profiles/ are only attached to a bench line built from the same code."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "fastx_toolkit_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def physical_cores():
@@ -73,65 +96,86 @@ def physical_cores():
         return os.cpu_count() or 1
 
 
-def _pipe_cmds(ref, inp, out):
-    return ([ref, "fastq_quality_trimmer", "-t", "20", "-l", "30", "-i", inp],
-            [ref, "fastq_quality_filter", "-q", "20", "-p", "80", "-o", out])
+def _pipe_cmds(config, ref, inp, out):
+    """The reference command line of a config as a real pipe of single-threaded processes (last one writes `out`)."""
+    ad = ADAPTER.decode()
+    stages = {
+        "cfg2": [["fastq_quality_trimmer", "-t", "20", "-l", "30"], ["fastq_quality_filter", "-q", "20", "-p", "80"]],
+        "cfg3": [["fastx_clipper", "-a", ad, "-l", "15", "-n"]],
+        "cfg4": [["fastx_reverse_complement"], ["fastx_trimmer", "-f", "5", "-l", "145"]],
+        "cfg5shard": [["fastx_clipper", "-a", ad, "-l", "15", "-n"], ["fastq_quality_trimmer", "-t", "20", "-l", "30"], ["fastq_quality_filter", "-q", "20", "-p", "80"]],
+    }[config]
+    cmds = [[ref] + st for st in stages]
+    cmds[0] += ["-i", inp]
+    cmds[-1] += ["-o", out]
+    return cmds
 
 
-def cpu_baseline(reads_per_pipe=250_000, max_pipes=64):
-    """Reference CPU path on this box's host cores, bounded sample of the cfg2 workload (rank 0, N=1 only).
+def cpu_baseline(config="cfg2", reads_per_pipe=250_000, one_pipe_reads=1_000_000, max_procs=128):
+    """Reference CPU path on this box's host cores, bounded sample of the config's workload (rank 0, N=1 only).
 
-    SURVEY 8d: the reference is single-threaded, so (i) one `trimmer | filter` shell pipe (2 processes) is timed alone and
-    (ii) the input is split at record boundaries into P/2 chunks and P/2 pipes run concurrently (P = physical cores);
+    SURVEY 8d: the reference is single-threaded, so (i) ONE pipe of the config's tools is timed alone on its first 1 M reads and
+    (ii) the input is split at record boundaries into chunks and as many pipes as the physical cores hold run concurrently;
     the aggregate rate is reported with the core counts next to it.
     """
     from concurrent.futures import ThreadPoolExecutor
     from oracle import fxoracle_py as fo
+    cfg = CONFIGS[config]
     ref = fo.ref_binary()
     try:
         fo.lib()
     except Exception:
         return None
     logical, phys = os.cpu_count() or 2, physical_cores()
-    pipes = max(1, min(max_pipes, phys // 2))
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
         if ref:
-            files = [os.path.join(td, "in%d.fq" % k) for k in range(pipes)]
+            per_pipe = len(_pipe_cmds(config, ref, "i", "o"))
+            pipes = max(1, min(max_procs, phys) // per_pipe)
+            nchunks = max(pipes, (one_pipe_reads + reads_per_pipe - 1) // reads_per_pipe)
+            files = [os.path.join(td, "in%d.fq" % k) for k in range(nchunks)]
 
             def gen(k):
                 with open(files[k], "wb") as f:
-                    f.write(fo.synth_fastq(2, k * reads_per_pipe, reads_per_pipe, 150, False))
+                    f.write(fo.synth_fastq(cfg["seed"], k * reads_per_pipe, reads_per_pipe, cfg["L"], cfg["adapter"]))
             with ThreadPoolExecutor(max_workers=min(logical, 32)) as ex:     # the generator is C (ctypes releases the GIL)
-                list(ex.map(gen, range(pipes)))
+                list(ex.map(gen, range(nchunks)))
+            one = os.path.join(td, "one.fq")                                 # the single pipe's input: the first one_pipe_reads reads
+            n_one = (one_pipe_reads + reads_per_pipe - 1) // reads_per_pipe
+            with open(one, "wb") as f:
+                for k in range(n_one):
+                    f.write(open(files[k], "rb").read())
 
-            def run(ks):
+            def run(inputs):
                 t0 = time.perf_counter()
                 procs = []
-                for k in ks:
-                    c1, c2 = _pipe_cmds(ref, files[k], os.path.join(td, "out%d.fq" % k))
-                    p1 = subprocess.Popen(c1, stdout=subprocess.PIPE)
-                    p2 = subprocess.Popen(c2, stdin=p1.stdout)
-                    p1.stdout.close()
-                    procs += [p1, p2]
+                for k, inp in enumerate(inputs):
+                    cmds = _pipe_cmds(config, ref, inp, os.path.join(td, "out%d.fq" % k))
+                    prev = None
+                    for i, c in enumerate(cmds):
+                        p = subprocess.Popen(c, stdin=prev.stdout if prev else None, stdout=subprocess.PIPE if i + 1 < len(cmds) else None)
+                        if prev:
+                            prev.stdout.close()
+                        procs.append(p)
+                        prev = p
                 ok = all(p.wait() == 0 for p in procs)
                 return ok, time.perf_counter() - t0
-            ok1, dt1 = run([0])
-            okp, dtp = run(range(pipes))
+            ok1, dt1 = run([one])
+            okp, dtp = run(files[:pipes])
             if ok1 and okp:
                 n = pipes * reads_per_pipe
-                return dict(value=round(n / dtp / 1e6, 4), unit="Mreads/s", cores=2 * pipes, kind="reference",
-                            one_pipe_value=round(reads_per_pipe / dt1 / 1e6, 4), one_pipe_cores=2,
+                return dict(value=round(n / dtp / 1e6, 4), unit="Mreads/s", cores=per_pipe * pipes, kind="reference",
+                            one_pipe_value=round(n_one * reads_per_pipe / dt1 / 1e6, 4), one_pipe_cores=per_pipe, one_pipe_reads=n_one * reads_per_pipe,
                             host_logical_cpus=logical, host_physical_cores=phys,
-                            sample="first %d reads of the same seed-2 150 bp set as FASTQ text on tmpfs, split into %d chunks; each chunk piped "
-                                   "through the reference libfastx reader/writer (compiled -O3 from /root/reference/src/libfastx) with the "
-                                   "trimmer|filter loop bodies of oracle/ref_driver.cpp; %d concurrent single-threaded processes = %d cores "
-                                   "(the box has %d physical cores / %d logical CPUs); one_pipe_value = one pipe (2 processes) alone"
-                                   % (n, pipes, 2 * pipes, 2 * pipes, phys, logical))
+                            sample="%s: `%s`; first %d reads of the same seed-%d %d bp set as FASTQ text on tmpfs, split into %d chunks; each chunk piped "
+                                   "through the reference libfastx reader/writer and aligner (compiled -O3 from /root/reference/src/libfastx) with the "
+                                   "tools' loop bodies of oracle/ref_driver.cpp; %d concurrent single-threaded processes = %d cores "
+                                   "(the box has %d physical cores / %d logical CPUs); one_pipe_value = one pipe (%d processes) alone on the first %d reads"
+                                   % (config, cfg["what"], n, cfg["seed"], cfg["L"], pipes, per_pipe * pipes, per_pipe * pipes, phys, logical, per_pipe, n_one * reads_per_pipe))
         # fall back to the plain-C port (SoA in memory, no text I/O), 1 thread
-        n = 4_000_000
-        b, q = fo.synth_batch(2, 0, n, 150)
+        n = 1_000_000 if cfg["bound"] == "valu" else 4_000_000
+        b, q = fo.synth_batch(cfg["seed"], 0, n, cfg["L"], cfg["adapter"])
         t0 = time.perf_counter()
-        fo.run_pipeline(b, q, None, fo.make_params(**CONFIGS["cfg2"]["params"]))
+        fo.run_pipeline(b, q, None, fo.make_params(**cfg["params"]))
         dt = time.perf_counter() - t0
         return dict(value=round(n / dt / 1e6, 4), unit="Mreads/s", cores=1, kind="port", host_logical_cpus=logical, host_physical_cores=phys,
                     sample="oracle/fxoracle.c on %d in-memory SoA reads (no FASTQ text parsing/formatting), 1 thread" % n)
@@ -299,16 +343,28 @@ def main():
     else:
         alg_bytes = R * (2 * L + 4) + 2 * kept_bytes if compact else R * (L + 4)
     achieved = alg_bytes / (kavg * 1e-3) / 1e9
+    # what the launches produced: counters and a device-side checksum of res[] + the packed stream, against the pinned tuple
+    self_check = None
+    if not is_stats and compact and rank == 0:
+        exp = EXPECTED.get(args.config) if R == cfg["reads"] else None
+        got = (kept, kept_bytes, res.checksum())
+        self_check = dict(kept=got[0], kept_bases=got[1], checksum=got[2], pinned=list(exp) if exp else None,
+                          matches_pinned=(exp is not None and got[:2] == tuple(exp[:2]) and (exp[2] is None or got[2] == exp[2])) if exp else None)
+        if exp is not None and not self_check["matches_pinned"]:
+            raise SystemExit("bench self-check failed: launches produced %r, pinned %r" % (got, exp))
+    # HBM traffic: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this config (scripts/pmc_traffic.py), attached only when they were
+    # collected on the SAME kernel sources (hash of fastx_toolkit_amd/csrc) and the same launch shape
     traffic, traffic_source = None, None
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if args.config == "cfg2" and os.path.exists(pmc):
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.config)
+    if os.path.exists(pmc):
         try:
             pj = json.load(open(pmc))
-            same_kernel = launch["kernel"].split(" ")[0].split("<")[0] in pj.get("kernel", "")      # the counters are of THIS kernel family
-            if pj.get("reads_per_launch") == R and compact and same_kernel:
+            if pj.get("reads_per_launch") == R and (compact or is_stats) and pj.get("csrc_sha16") == csrc_sha16() and pj.get("kernel_name", "").split("(")[0] in launch["kernel"].replace(" ", ""):
                 traffic = pj.get("hbm_bytes_per_launch")
-                traffic_source = "replayed from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of %s, kernel %s); not measured in this run" % (
-                    pj.get("command", "scripts/pmc_run.py"), pj.get("kernel_version", "as committed"))
+                traffic_source = "replayed from profiles/pmc_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of %s on csrc %s); not measured in this run" % (
+                    args.config, pj.get("command", "scripts/pmc_run.py"), pj.get("csrc_sha16"))
+            else:
+                traffic_source = "profiles/pmc_traffic_%s.json is of other kernel sources or another launch shape: not attached" % args.config
         except Exception:
             traffic = None
 
@@ -337,6 +393,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": launch["kernel"], "kernel_ms_avg": round(kavg, 4), "kernel_ms_min": round(min(kms), 4),
                 "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_read": round(alg_bytes / R, 2),
+                "traffic_over_algorithmic": round(traffic / alg_bytes, 4) if traffic else None,
                 "grid": launch["grid"], "block": launch["block"], "lds_bytes": launch["lds"], "tile_reads": launch["tile_reads"],
                 **({"note": "not measured in this run: a plain streaming kernel that reads 15 GB and writes 7.3 GB (this config's algorithmic bytes, nothing "
                             "else) takes 4.25-4.56 ms on this part, read alone 2.34-2.50 ms, write alone 1.17-1.25 ms (scripts/ubench/mix_rw.hip, profiles/r02/z_mix_rw.txt)"}
@@ -348,13 +405,18 @@ def main():
             cells = R * L * len(ADAPTER)
             gcups = cells / (kavg * 1e-3) / 1e9
             out["roofline"]["valu"] = {
-                "gcups": round(gcups, 1), "cells_per_launch": cells, "valu_instr_per_cell": CLIP_VALU_PER_CELL,
-                "achieved_glaneops": round(gcups * CLIP_VALU_PER_CELL, 1), "peak_glaneops": round(VALU_PEAK_GLANEOPS, 1),
-                "issue_frac": round(gcups * CLIP_VALU_PER_CELL / VALU_PEAK_GLANEOPS, 4),
-                "note": "bound is VALU issue (the `hbm` numbers above are low by construction); peak = 256 CUs x 4 SIMDs x 64 lanes / %.0f cycles x 2.4 GHz" % VALU_CYCLES,
+                "gcups": round(gcups, 1), "cells_per_launch": cells, "valu_instr_per_cell": CLIP_VALU_PER_CELL[args.config],
+                "achieved_glaneops": round(gcups * CLIP_VALU_PER_CELL[args.config], 1), "peak_glaneops": round(VALU_PEAK_GLANEOPS, 1),
+                "issue_frac": round(gcups * CLIP_VALU_PER_CELL[args.config] / VALU_PEAK_GLANEOPS, 4),
+                "note": "bound is VALU issue (the `hbm` numbers above are low by construction); peak = 256 CUs x 4 SIMDs x 64 lanes / %.0f cycles x 2.4 GHz "
+                        "(MI355X_MICROARCH.md: one wave64 VALU instruction per 2 cycles per SIMD); valu_instr_per_cell = SQ_INSTS_VALU x 64 / cells of the "
+                        "whole kernel (profiles/r03_clip_pmc), so achieved_glaneops is what the SIMDs really issued.  Cells are those of the full L x 13 "
+                        "matrix the reference fills; the kernel fills it once with scores only and re-runs <= 21 rows with path summaries." % VALU_CYCLES,
             }
-        if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
-            out["cpu_baseline"] = cpu_baseline()
+        if self_check is not None:
+            out["self_check"] = self_check
+        if world == 1 and not args.no_cpu_baseline and not is_stats:
+            out["cpu_baseline"] = cpu_baseline(args.config)
         if world == 1 and not args.no_e2e and args.config == "cfg2":
             try:
                 out["e2e"] = e2e_leg()

@@ -31,9 +31,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef FXG_CLIP_GATHER_K
 #define FXG_CLIP_GATHER_K 4     // chunks per lane in flight in the clip instances' gather (FXG_GATHER_K for the streaming instances)
 #endif
-#ifndef FXG_CLIP_STAGGER
-#define FXG_CLIP_STAGGER 0u     // default start stagger of the clip instances, units of s_sleep(127) = 3.4 us per wave slot (FXG_CLIP_STAGGER in the environment)
-#endif
 #ifndef FXG_CLIP_DEPTH
 #define FXG_CLIP_DEPTH 3u       // slots of the clip instances (FxgTileDepth in fxg_kernels.h)
 #endif
@@ -79,7 +76,6 @@ struct FxgKArgs {
     u32  compact;           // 1 = stream-compact kept reads into out_bases/out_qual
     u32  debug;             // FXG_DEBUG ablation bits (timing experiments only; results are wrong when set)
     u32  depth;             // clip instances: slots = tiles a workgroup keeps between decision and write-out (2 or 3)
-    u32  stagger;           // clip instances: a workgroup that lands in wave slot k of its SIMDs starts k * stagger * 3.4 us late (fxg_kernel_tiles)
     // folded tool parameters
     u32  stages;
     u32  tq;                // quality trimmer: byte >= tq  <=>  q >= -t      (0..128)
@@ -381,7 +377,8 @@ __device__ __forceinline__ void fxg_scanner_k(const FxgKArgs &a)
 // batch b is then its own running prefix at the end of batch b - S plus the totals of the S - 1 batches in between, which the other
 // waves publish as soon as THEIR batches are complete: no wave waits for another wave's prefix, so there is no serial chain from
 // batch to batch -- only "every earlier tile has published", which a prefix needs anyway.  Every scanner wave is running by
-// construction (roles are drawn at kernel start) and waits only for totals of drawn tiles: progress as for the single scanner.
+// construction (roles are drawn at kernel start).  Waiting for a WHOLE batch assumes enough resident workers to decide it (two tiles
+// each); when the batch stalls the wave falls back to publishing run by run (below), so progress does not depend on residency.
 template <int K>
 __device__ __forceinline__ void fxg_scanner_multi(const FxgKArgs &a, u32 j)
 {
@@ -407,7 +404,38 @@ __device__ __forceinline__ void fxg_scanner_multi(const FxgKArgs &a, u32 j)
             for (u32 k = 0; k < (u32)K; ++k) bad |= __ballot((u32)(v[k] >> FXG_TAG_SHIFT) != a.tag);
             if (!bad) break;
             __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 255u) == 0u && fxg_spin_expired(a, tstart)) return;
+            ++spins;
+            // The batch does not fill up.  A worker holds at most two decided tiles and draws its next ticket only after the earlier
+            // one is written out, so with few workers RESIDENT (a shared GPU, a CU mask, FXG_BLOCKS_PER_CU=1) the tiles that would
+            // complete this batch may never be drawn while everybody waits for its prefixes.  Every ~64 polls the wave therefore
+            // publishes the prefixes of the batch's leading published run (what fxg_scanner_k does every round): the workers waiting
+            // for those move on and draw the missing tiles.  The values are the final ones, published again when the batch is whole.
+            if ((spins & 63u) == 0u) {
+                const u32 first = b >= S ? b - S + 1u : 0u, cnt = b - first;
+                u64 wc = tagw, wb = tagw;
+                if (lane < cnt) { wc = fxg_granule_load(a.bbase + 2 * (u64)(first + lane)); wb = fxg_granule_load(a.bbase + 2 * (u64)(first + lane) + 1); }
+                if (__ballot((u32)(wc >> FXG_TAG_SHIFT) != a.tag || (u32)(wb >> FXG_TAG_SHIFT) != a.tag) == 0ull) {      // every earlier batch is whole
+                    const u32 sc = fxg_wave_scan_dpp(lane < cnt ? (u32)FXG_TAG_VALUE(wc) : 0u), sb = fxg_wave_scan_dpp(lane < cnt ? (u32)FXG_TAG_VALUE(wb) : 0u);
+                    u64 run_c = end_c + (u32)__builtin_amdgcn_readlane((int)sc, 63), run_b = end_b + (u32)__builtin_amdgcn_readlane((int)sb, 63);
+                    bool open = true;
+#pragma unroll
+                    for (u32 k = 0; k < (u32)K; ++k) {
+                        if (!open) continue;                    // wave-uniform
+                        const u64 idx = (u64)t0 + k * 64u + lane;
+                        const u64 bal = __ballot((u32)(v[k] >> FXG_TAG_SHIFT) == a.tag);
+                        const u32 m = bal == ~0ull ? 64u : (u32)__builtin_ctzll(~bal);
+                        const u32 c = lane < m ? (u32)(v[k] >> 32) & 0xFFFFu : 0u, bb = lane < m ? (u32)v[k] : 0u;
+                        const u32 ic = fxg_wave_scan_dpp(c), ib = fxg_wave_scan_dpp(bb);
+                        if (lane < m && idx < a.ntiles) {
+                            fxg_granule_store_raw(a.pfx + 2 * idx, tagw | (run_c + (ic - c)));
+                            fxg_granule_store_raw(a.pfx + 2 * idx + 1, tagw | (run_b + (ib - bb)));
+                        }
+                        run_c += (u32)__builtin_amdgcn_readlane((int)ic, 63); run_b += (u32)__builtin_amdgcn_readlane((int)ib, 63);
+                        open = (m == 64u);
+                    }
+                }
+            }
+            if ((spins & 255u) == 0u && fxg_spin_expired(a, tstart)) return;
         }
         u32 exc[K], exb[K], rc = 0, rb = 0;                     // exclusive prefixes inside the batch; 64 K tiles of < 2^20 bytes each
 #pragma unroll
@@ -460,7 +488,10 @@ __device__ __forceinline__ void fxg_wait_prefix(const FxgKArgs &a, u32 tile, u64
         if (lane < 2u) v = fxg_granule_load(a.pfx + 2 * (u64)tile + lane);
         if ((++spins & 255u) == 0u && fxg_spin_expired(a, t0)) break;
     }
-    if (lane < 2u) bc[lane] = FXG_TAG_VALUE(v);
+    // expired: the granule belongs to an EARLIER launch (the arrays are not cleared between launches) -- its value must not be used
+    // as an offset.  ~0 tells the caller to write nothing for this tile; the host sees FXG_DEV_ERR_SCAN_TIMEOUT.
+    const bool ok = __ballot((u32)(v >> FXG_TAG_SHIFT) != a.tag) == 0ull;
+    if (lane < 2u) bc[lane] = ok ? FXG_TAG_VALUE(v) : ~0ull;
 }
 
 // the same for a workgroup that IS one wave (fxg_rows.h): the prefix comes back in registers
@@ -478,7 +509,8 @@ __device__ __forceinline__ void fxg_wait_prefix_wave(const FxgKArgs &a, u32 tile
         if (lane < 2u) v = fxg_granule_load(a.pfx + 2 * (u64)tile + lane);
         if ((++spins & 255u) == 0u && fxg_spin_expired(a, t0)) break;
     }
-    v = FXG_TAG_VALUE(v);                                   // scalars from here on
+    const bool ok = __ballot((u32)(v >> FXG_TAG_SHIFT) != a.tag) == 0ull;      // expired: a stale granule of an earlier launch, see fxg_wait_prefix
+    v = ok ? FXG_TAG_VALUE(v) : ~0ull;                      // scalars from here on
     bc[0] = ((u64)(u32)__builtin_amdgcn_readlane((int)(v >> 32), 0) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)v, 0);
     bc[1] = ((u64)(u32)__builtin_amdgcn_readlane((int)(v >> 32), 1) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)v, 1);
 }

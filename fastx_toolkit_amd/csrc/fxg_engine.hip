@@ -28,7 +28,11 @@ struct fxg_ctx {
     void *attr_kernel[8];   // kernels whose launch attributes were set, with the LDS size and the occupancy answer
     u32 attr_lds[8];
     int attr_per_cu[8];
-    int env_blocks_per_cu, env_ticket_groups, env_clip_stagger;   // tuning knobs, read once
+    int attr_next;          // next slot to evict
+    void *lds_kernel[32];   // largest MaxDynamicSharedMemorySize set per kernel (the attribute is only ever raised)
+    u32 lds_max[32];
+    int env_blocks_per_cu, env_ticket_groups;   // tuning knobs, read once
+    int env_workers, env_nscan;                 // test knobs: cap on the worker workgroups of a launch / forced number of scanner waves (fxg_kernel_rows)
     u32 *errflag;           // [0] device error bits; tile dispensers start at word FXG_TICKET_STRIDE
     u64 *counters_scratch;  // used when the caller passes no counter block
     u64 *text_ws;           // newline census / scan levels / format items
@@ -84,7 +88,8 @@ extern "C" int fxg_ctx_create(int device_id, fxg_ctx **out)
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { free(c); return FXG_E_HIP; }
     c->stream = c->own_stream;
     { const char *e = getenv("FXG_BLOCKS_PER_CU"); c->env_blocks_per_cu = (e && atoi(e) > 0 && atoi(e) <= 16) ? atoi(e) : 0; }
-    { const char *e = getenv("FXG_CLIP_STAGGER"); c->env_clip_stagger = (e && atoi(e) >= 0 && atoi(e) <= 64) ? atoi(e) : -1; }
+    { const char *e = getenv("FXG_WORKERS"); c->env_workers = (e && atoi(e) > 0) ? atoi(e) : 0; }
+    { const char *e = getenv("FXG_NSCAN"); c->env_nscan = (e && atoi(e) > 0 && atoi(e) <= 64) ? atoi(e) : 0; }
     { const char *e = getenv("FXG_TICKET_GROUPS"); c->env_ticket_groups = (e && atoi(e) > 0 && atoi(e) <= FXG_TICKET_GROUPS) ? atoi(e) : 0; }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreate(&c->kev0) != hipSuccess || hipEventCreate(&c->kev1) != hipSuccess ||
@@ -195,11 +200,19 @@ static int fxg_kernel_fit(fxg_ctx *c, K kernel, const char *kname, u32 lds, int 
 {
     for (int i = 0; i < 8; ++i)
         if (c->attr_kernel[i] == (void *)kernel && c->attr_lds[i] == lds) { *per_cu = c->attr_per_cu[i]; return FXG_OK; }
-    FXG_HIP(c, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // the attribute is a property of the kernel, not of the cache entry: one kernel alternating between LDS sizes must never be
+    // launched with more than was last set, so it is only ever raised
+    int k = -1;
+    for (int i = 0; i < 32; ++i) { if (c->lds_kernel[i] == (void *)kernel) { k = i; break; } if (!c->lds_kernel[i] && k < 0) k = i; }
+    if (k < 0 || c->lds_kernel[k] != (void *)kernel || c->lds_max[k] < lds) {
+        FXG_HIP(c, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (k >= 0) { c->lds_kernel[k] = (void *)kernel; c->lds_max[k] = lds; }
+    }
     FXG_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kernel, (int)block, lds));
     if (*per_cu < 1) return fxg_fail(c, FXG_E_INVALID, "%s does not fit on a CU (lds=%u)", kname, lds);
-    int slot = 0;
+    int slot = -1;
     for (int i = 0; i < 8; ++i) if (!c->attr_kernel[i]) { slot = i; break; }
+    if (slot < 0) { slot = c->attr_next; c->attr_next = (c->attr_next + 1) % 8; }
     c->attr_kernel[slot] = (void *)kernel; c->attr_lds[slot] = lds; c->attr_per_cu[slot] = *per_cu;
     return FXG_OK;
 }
@@ -219,10 +232,12 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
     int use = per_cu > most ? most : per_cu;
     if (c->env_blocks_per_cu > 0) use = c->env_blocks_per_cu;
     u64 workers = (u64)c->cus * (u64)use;
+    if (c->env_workers > 0 && workers > (u64)c->env_workers) workers = (u64)c->env_workers;
     if (workers > ka.ntiles) workers = ka.ntiles;
     if (workers < 1) workers = 1;
     // more workgroups: the scanner(s) (fxg_device.h); fxg_kernel_rows runs several once there is work for them
     ka.nscan = !ka.compact ? 0u : (rows_kernel && workers >= 64u * FXG_ROWS_NSCAN ? (u32)FXG_ROWS_NSCAN : 1u);
+    if (ka.compact && rows_kernel && c->env_nscan > 0) ka.nscan = (u32)c->env_nscan;
     const u64 grid = workers + ka.nscan;
 
     if (ka.compact) {
@@ -246,7 +261,6 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
 #ifdef FXG_ABLATION
     { const char *dbg = getenv("FXG_DEBUG"); ka.debug = dbg ? (u32)atoi(dbg) : 0u; }
 #endif
-    ka.stagger = c->env_clip_stagger >= 0 ? (u32)c->env_clip_stagger : FXG_CLIP_STAGGER;
     ka.errflag = c->errflag;                     // control block (zeroed before every launch), layout at FXG_CTRL_WORDS
     ka.ticket = c->errflag + FXG_CTRL_WORDS;
     ka.extra = (u64 *)(c->errflag + 2);

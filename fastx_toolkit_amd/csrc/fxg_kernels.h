@@ -690,15 +690,6 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
     // progress never depends on residency, dispatch order or placement.
     const u32 G = a.ticket_groups, grp = blockIdx.x % G;
     u32 *my_ticket = a.ticket + grp * FXG_TICKET_STRIDE;
-    if constexpr (MODE == 0 && AMAX != 0) {
-        // The workgroups of a CU start together and take the same time per tile, so they would sit in the DP together (four waves
-        // per SIMD competing for the VALU) and then in the write-out together (VALU idle).  Waves that share a SIMD have different
-        // wave slots: starting slot k late by k * stagger spreads the phases, and nothing pulls them back together.
-        if (a.stagger && tid == 0) {
-            const u32 wslot = (u32)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15u;      // HW_REG_HW_ID, WAVE_ID
-            for (u32 i = 0; i < wslot * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-        }
-    }
     if (tid == 0) s_ticket[0] = atomicAdd(my_ticket, 1u);
     __syncthreads();
     u32 cur = s_ticket[0] * G + grp;
@@ -769,8 +760,9 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
             FXG_TPHASE(3);
             const u64 base_c = bc[0], base_b = bc[1];
             const u32 nk = s_tot[2 * ps], totb = s_tot[2 * ps + 1];
-            if (tid < nk) fxg_write_kept_meta(a, base_c + tid, k_off[tid + 1] - k_off[tid], r0 + k_idx[tid], base_b + k_off[tid]);
-            if (!FXG_DBG(a, 1u)) {
+            const bool placed = base_c != ~0ull;        // false: the wait for the prefix expired (error flag set) -- nothing of this tile is written
+            if (placed && tid < nk) fxg_write_kept_meta(a, base_c + tid, k_off[tid + 1] - k_off[tid], r0 + k_idx[tid], base_b + k_off[tid]);
+            if (placed && !FXG_DBG(a, 1u)) {
                 // the clip instances run four waves per SIMD: their gather keeps four chunks per lane in flight (FXG_GATHER_K)
                 constexpr int GK = (MODE == 0 && AMAX != 0) ? FXG_CLIP_GATHER_K : FXG_GATHER_K;
                 const u32 bad = fxg_tile_gather<REV, MODE == 3, GK>(a, k_off, k_src, k_tab, nk, (u64)r0 * stride, nreads * stride, base_b, totb, tid, TB);

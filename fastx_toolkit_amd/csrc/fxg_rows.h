@@ -264,7 +264,8 @@ __global__ __launch_bounds__(64, FXG_ROWS_LB) void fxg_kernel_rows(const FxgKArg
     u32 role = 0;
     if (lane == 0) role = atomicAdd(a.role, 1u);
     role = (u32)__builtin_amdgcn_readfirstlane((int)role);
-    if (role < a.nscan) { fxg_scanner_multi<FXG_ROWS_SCAN_K>(a, role); return; }
+    // one scanner: the run-by-run form, whose progress does not depend on how many workers are resident (fxg_device.h)
+    if (role < a.nscan) { if (a.nscan == 1u) fxg_scanner_k<FXG_ROWS_SCAN_K>(a); else fxg_scanner_multi<FXG_ROWS_SCAN_K>(a, role); return; }
     const u32 G = a.ticket_groups, grp = blockIdx.x % G;
     u32 *my_ticket = a.ticket + grp * FXG_TICKET_STRIDE;
     u32 tk = 0;
@@ -330,13 +331,14 @@ __global__ __launch_bounds__(64, FXG_ROWS_LB) void fxg_kernel_rows(const FxgKArg
             const u32 nreads = left < (u64)FXG_ROWS_T ? (u32)left : FXG_ROWS_T;
             const u64 tb = (u64)r0 * stride;
             const u32 tbytes = nreads * stride;
-            const u32 keep = p_info >> 31, olen = (p_info >> 16) & 0x7FFFu, exb = p_info & 0xFFFFu;
+            const bool placed = bc[0] != ~0ull;         // false: the wait for the prefix expired (error flag set) -- nothing of this tile is written
+            const u32 keep = placed ? p_info >> 31 : 0u, olen = (p_info >> 16) & 0x7FFFu, exb = p_info & 0xFFFFu;
             // the kept prefixes of the quality rows, packed in read order, into the staging buffer; whole 16-byte units from there
             const bool fast = __ballot(keep && olen < 4u) == 0ull;
             if (keep && !FXG_DBG(a, 64u)) fxg_rows_pack<NW>(smem, exb, qp, olen, fast);
             FXG_WAVE_SYNC();
             FXG_PHASE(6);
-            if (!FXG_DBG(a, 1u)) fxg_rows_flush(a.out_qual, bc[1], p_totb, smem, lane);
+            if (placed && !FXG_DBG(a, 1u)) fxg_rows_flush(a.out_qual, bc[1], p_totb, smem, lane);
             if (keep) fxg_write_kept_meta(a, bc[0] + p_exc, olen, r0 + lane, bc[1] + exb);
             FXG_WAVE_SYNC();                                                  // the buffer is free again
             FXG_PHASE(3);
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(64, FXG_ROWS_LB) void fxg_kernel_rows(const FxgKArg
                 if (keep && !FXG_DBG(a, 64u)) fxg_rows_pack<NW>(smem, exb, b, olen, fast);
                 FXG_WAVE_SYNC();
                 FXG_PHASE(7);
-                if (!FXG_DBG(a, 1u)) fxg_rows_flush(a.out_bases, bc[1], p_totb, smem, lane);
+                if (placed && !FXG_DBG(a, 1u)) fxg_rows_flush(a.out_bases, bc[1], p_totb, smem, lane);
                 FXG_WAVE_SYNC();
             }
             FXG_PHASE(5);

@@ -174,11 +174,13 @@ __device__ __forceinline__ int fxg_parse_numeric(const uint8_t *text, u32 s, u32
         const u32 d0 = p;
         u64 mag = 0;
         bool sat = false;
+        const u64 limit = neg ? 0x8000000000000000ull : 0x7FFFFFFFFFFFFFFFull;      // strtol saturates exactly past LONG_MAX / below LONG_MIN
         for (; p < e && text[p] >= '0' && text[p] <= '9'; ++p) {
-            if (mag > (0x7FFFFFFFFFFFFFFFull - 9ull) / 10ull) sat = true; else mag = mag * 10ull + (u64)(text[p] - '0');
+            const u64 d = (u64)(text[p] - '0');
+            if (sat || mag > (limit - d) / 10ull) sat = true; else mag = mag * 10ull + d;
         }
         if (p == d0) return -1;
-        const long long lv = sat ? (neg ? (-0x7FFFFFFFFFFFFFFFll - 1ll) : 0x7FFFFFFFFFFFFFFFll) : (neg ? -(long long)mag : (long long)mag);
+        const long long lv = sat ? (neg ? (-0x7FFFFFFFFFFFFFFFll - 1ll) : 0x7FFFFFFFFFFFFFFFll) : (long long)(neg ? 0ull - mag : mag);
         const int v = (int)lv;
         if (v > 93 || v < -15) return -1;
         if (out && (u32)cnt < cap) out[cnt] = (uint8_t)(v + 33);

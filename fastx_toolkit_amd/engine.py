@@ -152,6 +152,25 @@ class FxgError(RuntimeError):
     pass
 
 
+def stream_checksum(torch, res, out_bases, out_qual, nbytes, chunk=1 << 27):
+    """sum(byte[i] * (1 + i % 251)) over the packed bases, the packed qualities and the bytes of res[], folded into one 63-bit number.
+    The weights make it sensitive to a shifted or permuted stream; int64 wrap-around is deterministic."""
+    M = (1 << 63) - 1
+
+    def one(t, n):
+        acc = 0
+        for lo in range(0, n, chunk):
+            hi = min(n, lo + chunk)
+            w = (torch.arange(lo, hi, device=t.device, dtype=torch.int64) % 251) + 1
+            acc = (acc + int((t[lo:hi].to(torch.int64) * w).sum().item())) & M
+        return acc
+    cs = one(res.view(torch.uint8), res.numel() * res.element_size())
+    for t in (out_bases, out_qual):
+        if t is not None:
+            cs = (cs * 1000003 + one(t, nbytes)) & M
+    return cs
+
+
 class Result:
     """Device-resident outputs of one pipeline run (torch tensors) plus lazily fetched host counters."""
 
@@ -175,6 +194,11 @@ class Result:
     @property
     def kept_bytes(self):
         return int(self.counters[C_KEPT_BASES])
+
+    def checksum(self):
+        """Position-weighted 63-bit checksum of the packed output stream (bases, then qualities) and of res[], computed on the device:
+        what bench.py prints for its timed launches and tests/test_gpu_parity.py pins against an oracle-verified run."""
+        return stream_checksum(self.engine.torch, self.res, self.out_bases, self.out_qual, self.kept_bytes)
 
     def to_host(self):
         """numpy copies trimmed to the kept counts (same keys as the oracle's run_pipeline)."""

@@ -245,14 +245,16 @@ int fxh_decode_quality(FASTX *fx, struct fxh_rawrec *rec, int *out_i32, unsigned
             const size_t d0 = j;
             unsigned long long mag = 0;
             int sat = 0;
+            const unsigned long long limit = neg ? 0x8000000000000000ull : 0x7FFFFFFFFFFFFFFFull;   /* strtol saturates exactly past LONG_MAX / below LONG_MIN */
             for (; j < n && s[j] >= '0' && s[j] <= '9'; ++j) {
-                if (mag > (0x7FFFFFFFFFFFFFFFull - 9) / 10) sat = 1; else mag = mag * 10 + (unsigned long long)(s[j] - '0');
+                const unsigned long long d = (unsigned long long)(s[j] - '0');
+                if (sat || mag > (limit - d) / 10) sat = 1; else mag = mag * 10 + d;
             }
             if (j == d0) {                                     /* endptr == quality_tok */
                 fxh_fail(fx, rec, "Error: invalid quality score data on line %lld (quality_tok = \"%.*s\"", fx->input_line_number, (int)(n - pos), s + pos);
                 return -1;
             }
-            const long lv = sat ? (neg ? (-0x7FFFFFFFFFFFFFFFL - 1) : 0x7FFFFFFFFFFFFFFFL) : (neg ? -(long)mag : (long)mag);
+            const long lv = sat ? (neg ? (-0x7FFFFFFFFFFFFFFFL - 1) : 0x7FFFFFFFFFFFFFFFL) : (long)(neg ? 0ull - mag : mag);
             const int v = (int)lv;                             /* the reference stores strtol's long in an int */
             if (v > 93 || v < -15) { fxh_fail(fx, rec, "invalid quality score value (%d) in line %lld.", v, fx->input_line_number); return -1; }
             if (idx < rec->seq_len) {

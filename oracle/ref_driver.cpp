@@ -35,7 +35,7 @@ static FASTX fx;
 static int qt_threshold = 0, qt_min_len = 0;
 static int qt_args(int, int c, char *arg)
 {
-    if (c == 'l') qt_min_len = (int)strtoul(arg, NULL, 10);
+    if (c == 'l') { qt_min_len = (int)strtoul(arg, NULL, 10); if (qt_min_len < 0) errx(1, "Invalid minimum length value (-l %s)", arg); }   /* :60-62 */
     else if (c == 't') qt_threshold = (int)strtol(arg, NULL, 10);
     else errx(1, "Unknown argument (%c)", c);
     return 1;

@@ -113,3 +113,36 @@ def fuzz_cases(seed, trials, clip_trials):
         yield ("clip7_%d" % trial, b, q, None, stride,
                dict(stages=7, adapter=ad, clip_min_len=5, clip_flags=flags & 7, qt_threshold=15, qt_min_len=4,
                     qf_min_quality=12, qf_min_percent=60))
+
+
+# Command lines the reference rejects (exit 1 + a message), with an input that is otherwise fine: shared by the CPU tier (emulation
+# stub) and the GPU tier, both of which compare exit code, stdout and message with the real libfastx driver (oracle/_ref/fxref).
+_REC = b"@r\nA\n+\nI\n"
+FLAG_ERROR_CASES = [
+    (["fastq_quality_trimmer"], _REC),                                   # -t missing (fastq_quality_trimmer.c:82-83)
+    (["fastq_quality_trimmer", "-t", "0"], _REC),
+    (["fastq_quality_trimmer", "-t", "20", "-l", "-1"], _REC),           # :60-62 -- strtoul("-1") lands negative in an int
+    (["fastq_quality_trimmer", "-t", "20", "-l", "-300"], _REC),
+    (["fastq_quality_filter", "-p", "0"], b""),
+    (["fastq_quality_filter", "-p", "101", "-q", "5"], _REC),
+    (["fastq_quality_filter", "-p", "-5", "-q", "5"], _REC),
+    (["fastx_trimmer", "-f", "2", "-t", "3"], _REC),
+    (["fastx_trimmer", "-f", "0"], _REC),
+    (["fastx_trimmer", "-f", "-2"], _REC),
+    (["fastx_trimmer", "-l", "25000"], _REC),
+    (["fastx_trimmer", "-l", "0"], _REC),
+    (["fastx_trimmer", "-t", "0"], _REC),
+    (["fastx_trimmer", "-t", "3", "-m", "0"], _REC),
+    (["fastx_trimmer", "-t", "25000"], _REC),
+    (["fastx_clipper", "-M", "0"], _REC),
+    (["fastx_clipper", "-M", "-4"], _REC),
+    (["fastx_clipper", "-d", "-3"], _REC),                                # fastx_clipper.cpp:121-123
+    (["fastq_masker", "-r", "xy"], _REC),
+    (["fastq_masker", "-q", "-50"], _REC),                                # fastq_masker.c:62-63
+    (["fastq_masker", "-r", ""], _REC),
+    (["fastq_quality_trimmer", "-t", "20"], b""),                        # empty input (R1)
+    (["fastq_quality_trimmer", "-t", "20"], b">fa\nAC\n"),              # FASTQ only
+    (["fastq_quality_trimmer", "-t", "20", "-Q", "64"], b"@r\nA\n+\n!\n"),
+    (["fastq_quality_trimmer", "-t", "20", "-x"], _REC),                 # unknown option: getopt's message, then the usage hint
+    (["fastx_artifacts_filter", "-q", "3"], _REC),
+]

@@ -209,12 +209,7 @@ def test_lanes_devices_and_the_fused_tool(tools, tmp_path):
 def test_flag_errors_and_usage_on_the_gpu_build(tools):
     """F1-F6 against the real libfxg.so (the CPU tier runs the same checks against the emulation stub): exit codes, usage text, and the
     reference's messages where fxref is on the box."""
-    cases = [(["fastq_quality_trimmer"], b"@r\nA\n+\nI\n"), (["fastq_quality_trimmer", "-t", "0"], b"@r\nA\n+\nI\n"),
-             (["fastq_quality_filter", "-p", "0"], b""), (["fastq_quality_filter", "-p", "101", "-q", "5"], b"@r\nA\n+\nI\n"),
-             (["fastx_trimmer", "-f", "2", "-t", "3"], b"@r\nA\n+\nI\n"), (["fastx_trimmer", "-f", "0"], b"@r\nA\n+\nI\n"),
-             (["fastx_trimmer", "-l", "25000"], b"@r\nA\n+\nI\n"), (["fastx_clipper", "-M", "0"], b"@r\nA\n+\nI\n"),
-             (["fastq_masker", "-r", "xy"], b"@r\nA\n+\nI\n"), (["fastq_quality_trimmer", "-t", "20"], b""),
-             (["fastq_quality_trimmer", "-t", "20"], b">fa\nAC\n"), (["fastq_quality_trimmer", "-t", "20", "-Q", "64"], b"@r\nA\n+\n!\n")]
+    from helpers import FLAG_ERROR_CASES as cases
     for argv, data in cases:
         rc, out, err = _run([os.path.join(tools, argv[0])] + argv[1:], data)
         assert rc == 1, argv

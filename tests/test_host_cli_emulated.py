@@ -110,6 +110,12 @@ def test_fuzz_every_tool_vs_reference(tools):
 
 
 def test_flag_errors_and_usage(tools):
+    from helpers import FLAG_ERROR_CASES
+    for argv, data in FLAG_ERROR_CASES:                       # exit code, stdout and message of the real libfastx driver
+        rc, out, err = _run([os.path.join(tools, argv[0])] + argv[1:], data)
+        rrc, rout, rerr = _run([REF] + argv, data)
+        assert rc == 1 and (rc, out) == (rrc, rout), argv
+        assert _msg(err) == _msg(rerr), (argv, err, rerr)
     assert _run([os.path.join(tools, "fastq_quality_trimmer")], b"@r\nA\n+\nI\n")[0] == 1          # missing -t
     assert _run([os.path.join(tools, "fastq_quality_filter"), "-p", "0"], b"")[0] == 1
     assert _run([os.path.join(tools, "fastx_trimmer"), "-f", "2", "-t", "3"], b"@r\nA\n+\nI\n")[0] == 1
