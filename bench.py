@@ -181,66 +181,109 @@ def cpu_baseline(config="cfg2", reads_per_pipe=250_000, one_pipe_reads=1_000_000
                     sample="oracle/fxoracle.c on %d in-memory SoA reads (no FASTQ text parsing/formatting), 1 thread" % n)
 
 
-def e2e_leg(reads=16_000_000):
+def _gen_fastq(path, reads, seed=2, L=150, chunk=250_000):
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import fxoracle_py as fo
+    with open(path, "wb") as f:
+        with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 2, 48)) as ex:     # the generator is C (ctypes releases the GIL)
+            for part in ex.map(lambda k: fo.synth_fastq(seed, k * chunk, chunk, L, False), range(reads // chunk)):
+                f.write(part)
+
+
+def _same_bytes(parts, single, chunk=1 << 28):
+    """cat(parts) == single, compared in parallel slices (numpy releases the GIL)."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    sizes = [os.path.getsize(f) for f in parts]
+    if sum(sizes) != os.path.getsize(single):
+        return False
+    jobs, off = [], 0
+    for f, n in zip(parts, sizes):
+        for o in range(0, n, chunk):
+            jobs.append((f, o, min(chunk, n - o), off + o))
+        off += n
+
+    def cmp(j):
+        f, o, n, so = j
+        return np.array_equal(np.fromfile(f, dtype=np.uint8, count=n, offset=o), np.fromfile(single, dtype=np.uint8, count=n, offset=so))
+    with ThreadPoolExecutor(max_workers=16) as ex:
+        return all(ex.map(cmp, jobs))
+
+
+def e2e_leg(reads=16_000_000, big_reads=64_000_000, parts=4, lanes=2):
     """End to end on one GPU: FASTQ text on tmpfs -> the C tools (host/bin) -> FASTQ text; the same seed-2 reads the CPU baseline uses.
 
     `pipe`   = fastq_quality_trimmer -t 20 -l 30 | fastq_quality_filter -q 20 -p 80 (two processes, both on the GPU, as a user would type it)
     `fused`  = fastq_quality_trim_filter -t 20 -l 30 -q 20 -p 80 (one process, one pass; byte-identical output)
-    `fused_to_devnull` = the same with -o /dev/null: what the tool does when the output file system is not the limit (writing the
-               2.5 GB result to tmpfs runs at ~7 GB/s on this box whatever the number of writer threads)
+    `fused_to_devnull` = the same with -o /dev/null: what the tool does when the output file system is not the limit
+    `sharded` = the same command with FXH_PARTS=k (host/fxh_batch.c): k byte ranges of the input cut at record boundaries, k runs side by
+               side in the process (own reader threads, lanes and writer thread each), k output parts; md5 of their concatenation
+    `sharded_big` = the sharded run on a sample four times the size (process start and the first HIP context are ~0.2 s of every run),
+               checked byte for byte against the one-stream output of the same input
     Wall time of the command, file to file, best of two runs (the previous output is removed outside the timed region);
     Mreads/s and Gbases/s of INPUT."""
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle import fxoracle_py as fo
     import hashlib
     bindir = os.path.join(ROOT, "fastx_toolkit_amd", "host", "bin")
     trimmer, filt, fused = (os.path.join(bindir, t) for t in ("fastq_quality_trimmer", "fastq_quality_filter", "fastq_quality_trim_filter"))
     if not (os.path.exists(trimmer) and os.path.exists(filt)):
         return None
-    chunk = 250_000
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
         inp = os.path.join(td, "in.fq")
-        with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 2, 32)) as ex:
-            parts = list(ex.map(lambda k: fo.synth_fastq(2, k * chunk, chunk, 150, False), range(reads // chunk)))
-        with open(inp, "wb") as f:
-            for p in parts:
-                f.write(p)
-        del parts
+        _gen_fastq(inp, reads)
         out = {"reads": reads, "input_bytes": os.path.getsize(inp)}
 
-        def md5(path):
+        def md5(paths):
             h = hashlib.md5()
-            with open(path, "rb") as f:
-                for blk in iter(lambda: f.read(1 << 24), b""):
-                    h.update(blk)
+            for path in paths:
+                with open(path, "rb") as f:
+                    for blk in iter(lambda: f.read(1 << 24), b""):
+                        h.update(blk)
             return h.hexdigest()
 
-        def timed(name, fn, outfile):
+        def timed(dst, name, fn, outfiles, nreads, want_md5=True):
             best = None
             for _ in range(2):                             # the first run pays the library load and context creation from cold caches
-                if outfile and os.path.exists(outfile):
-                    os.unlink(outfile)
+                for f in outfiles or []:
+                    if os.path.exists(f):
+                        os.unlink(f)
                 t0 = time.perf_counter()
                 ok = fn()
                 dt = time.perf_counter() - t0
                 if not ok:
                     return
                 best = dt if best is None else min(best, dt)
-            out[name] = dict(wall_s=round(best, 3), mreads_s=round(reads / best / 1e6, 2), gbases_s=round(reads * 150 / best / 1e9, 3))
-            if outfile:
-                out[name]["output_bytes"] = os.path.getsize(outfile)
-                out[name]["output_md5"] = md5(outfile)
+            dst[name] = dict(wall_s=round(best, 3), mreads_s=round(nreads / best / 1e6, 2), gbases_s=round(nreads * 150 / best / 1e9, 3))
+            if outfiles:
+                dst[name]["output_bytes"] = sum(os.path.getsize(f) for f in outfiles)
+                if want_md5:
+                    dst[name]["output_md5"] = md5(outfiles)
 
         def pipe():
             p1 = subprocess.Popen([trimmer, "-t", "20", "-l", "30", "-i", inp], stdout=subprocess.PIPE)
             p2 = subprocess.Popen([filt, "-q", "20", "-p", "80", "-o", os.path.join(td, "pipe.fq")], stdin=p1.stdout)
             p1.stdout.close()
             return p1.wait() == 0 and p2.wait() == 0
-        timed("pipe", pipe, os.path.join(td, "pipe.fq"))
+        timed(out, "pipe", pipe, [os.path.join(td, "pipe.fq")], reads)
         if os.path.exists(fused):
             fa = [fused, "-t", "20", "-l", "30", "-q", "20", "-p", "80", "-i", inp]
-            timed("fused", lambda: subprocess.call(fa + ["-o", os.path.join(td, "fused.fq")]) == 0, os.path.join(td, "fused.fq"))
-            timed("fused_to_devnull", lambda: subprocess.call(fa + ["-o", "/dev/null"]) == 0, None)
+            penv = dict(os.environ, FXH_PARTS=str(parts), FXH_LANES=str(lanes))
+            pnames = [os.path.join(td, "part.%d.fq" % r) for r in range(parts)]
+            timed(out, "fused", lambda: subprocess.call(fa + ["-o", os.path.join(td, "fused.fq")]) == 0, [os.path.join(td, "fused.fq")], reads)
+            timed(out, "fused_to_devnull", lambda: subprocess.call(fa + ["-o", "/dev/null"]) == 0, None, reads)
+            timed(out, "sharded", lambda: subprocess.call(fa + ["-o", os.path.join(td, "part.%r.fq")], env=penv) == 0, pnames, reads)
+            if "sharded" in out:
+                out["sharded"].update(parts=parts, lanes_per_part=lanes, md5_of_concatenation_equals_fused=out["sharded"].get("output_md5") == out.get("fused", {}).get("output_md5"))
+            if big_reads and "sharded" in out:
+                for f in os.listdir(td):
+                    os.unlink(os.path.join(td, f))
+                _gen_fastq(inp, big_reads)
+                big = {"reads": big_reads, "input_bytes": os.path.getsize(inp), "parts": parts, "lanes_per_part": lanes}
+                single = os.path.join(td, "single.fq")
+                timed(big, "one_stream", lambda: subprocess.call(fa + ["-o", single]) == 0, [single], big_reads, want_md5=False)
+                timed(big, "sharded", lambda: subprocess.call(fa + ["-o", os.path.join(td, "part.%r.fq")], env=penv) == 0, pnames, big_reads, want_md5=False)
+                if "sharded" in big and "one_stream" in big:
+                    big["concatenation_identical_to_one_stream"] = _same_bytes(pnames, single)
+                out["sharded_big"] = big
         if "pipe" in out and "fused" in out:
             out["fused_equals_pipe"] = out["pipe"]["output_md5"] == out["fused"]["output_md5"]
         return out

@@ -31,6 +31,7 @@ struct FxgTextState {                 // device-resident scalars of one block of
 // ---------------------------------------------------------------------------------------------------------
 #define FXG_SCAN_PER_BLOCK 1024u      // 256 threads x 4 items
 
+#ifndef FXG_HOST_EMULATION
 __device__ __forceinline__ u64 fxg_wave_incl_scan64(u64 v)
 {
     const u32 lane = fxg_lane();
@@ -72,8 +73,11 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_scan_add(u64 *data, u64 
     for (int i = 0; i < 4; ++i) if (base + i < n) data[base + i] += add;
 }
 
+#endif  // FXG_HOST_EMULATION
+
 // ---------------------------------------------------------------------------------------------------------
-// newline census and scatter
+// newline census and scatter.  Per-thread bodies are __host__ __device__ (tests/emu runs them serially on the CPU tier); the
+// kernels around them add only the wave-level reductions.
 // ---------------------------------------------------------------------------------------------------------
 // bit i of the result = byte i of v equals ch
 FXG_HD u32 fxg_eq_mask16(u32x4 v, u32 ch)
@@ -91,7 +95,7 @@ FXG_HD u32 fxg_eq_mask16(u32x4 v, u32 ch)
 }
 
 // 16 bytes of text at offset off (zero beyond text_len); the buffer itself is readable 16 bytes past text_len
-__device__ __forceinline__ u32x4 fxg_text16(const uint8_t *text, u64 off, u64 text_len)
+FXG_HD u32x4 fxg_text16(const uint8_t *text, u64 off, u64 text_len)
 {
     u32x4 v = fxg_ld16(text + off);
     if (off + 16 > text_len) {
@@ -101,17 +105,33 @@ __device__ __forceinline__ u32x4 fxg_text16(const uint8_t *text, u64 off, u64 te
     return v;
 }
 
+// one lane's 16 bytes of a segment: newline mask (and carriage-return mask) of text[off, off + 16)
+FXG_HD u32 fxg_text_nl_mask(const uint8_t *text, u64 off, u64 text_len, u32 *cr)
+{
+    if (off >= text_len) { if (cr) *cr = 0u; return 0u; }
+    const u32x4 v = fxg_text16(text, off, text_len);
+    if (cr) *cr = fxg_eq_mask16(v, '\r');
+    return fxg_eq_mask16(v, '\n');
+}
+// the newlines of one lane's mask are lines j, j + 1, ...: line_end[j] = their position, line_start[j + 1] = the byte after
+FXG_HD void fxg_text_nl_store(u32 m, u64 off, u64 j, u32 *line_start, u32 *line_end, u64 cap_lines)
+{
+    while (m) {
+        const u32 b = (u32)__builtin_ctz(m);
+        m &= m - 1u;
+        if (j + 1 < cap_lines) { line_start[j + 1] = (u32)(off + b + 1); line_end[j] = (u32)(off + b); }
+        ++j;
+    }
+}
+
+#ifndef FXG_HOST_EMULATION
 // pass 1: newlines per 4 KB segment (+ carriage-return detection)
 __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_nl_count(const uint8_t *text, u64 text_len, u64 *seg_count, FxgTextState *st)
 {
     __shared__ u32 wsum[FXG_WAVES];
     const u64 off = (u64)blockIdx.x * FXG_TEXT_SEG + (u64)threadIdx.x * 16;
-    u32 c = 0, cr = 0;
-    if (off < text_len) {
-        const u32x4 v = fxg_text16(text, off, text_len);
-        c = (u32)__builtin_popcount(fxg_eq_mask16(v, '\n'));
-        cr = fxg_eq_mask16(v, '\r');
-    }
+    u32 cr = 0;
+    u32 c = (u32)__builtin_popcount(fxg_text_nl_mask(text, off, text_len, &cr));
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
     if (fxg_lane() == 0) wsum[threadIdx.x >> 6] = c;
     if (__ballot(cr != 0u) != 0ull && fxg_lane() == 0) atomicOr(&st->has_cr, 1u);
@@ -124,8 +144,7 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_nl_scatter(const uint8_t
 {
     __shared__ u32 wsum[FXG_WAVES];
     const u64 off = (u64)blockIdx.x * FXG_TEXT_SEG + (u64)threadIdx.x * 16;
-    u32 m = 0;
-    if (off < text_len) m = fxg_eq_mask16(fxg_text16(text, off, text_len), '\n');
+    const u32 m = fxg_text_nl_mask(text, off, text_len, nullptr);
     const u32 mine = (u32)__builtin_popcount(m);
     u32 incl = mine;
     const u32 lane = fxg_lane(), wave = threadIdx.x >> 6;
@@ -136,21 +155,16 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_nl_scatter(const uint8_t
     u32 woff = 0;
 #pragma unroll
     for (int w = 0; w < FXG_WAVES; ++w) if (w < (int)wave) woff += wsum[w];
-    u64 j = seg_off[blockIdx.x] + woff + incl - mine;
     if (blockIdx.x == 0 && threadIdx.x == 0) line_start[0] = 0u;
-    while (m) {
-        const u32 b = (u32)__builtin_ctz(m);
-        m &= m - 1u;
-        if (j + 1 < cap_lines) { line_start[j + 1] = (u32)(off + b + 1); line_end[j] = (u32)(off + b); }
-        ++j;
-    }
+    fxg_text_nl_store(m, off, seg_off[blockIdx.x] + woff + incl - mine, line_start, line_end, cap_lines);
 }
+#endif  // FXG_HOST_EMULATION
 
 // ---------------------------------------------------------------------------------------------------------
 // per-record checks on the line index; chomp; quality-line encoding; writes len[], flags[] and the batch extrema
 // ---------------------------------------------------------------------------------------------------------
 // first '\r' in text[s, e), or e
-__device__ __forceinline__ u32 fxg_first_cr(const uint8_t *text, u32 s, u32 e)
+FXG_HD u32 fxg_first_cr(const uint8_t *text, u32 s, u32 e)
 {
     for (u32 p = s; p < e; p += 16u) {
         u32 m = fxg_eq_mask16(fxg_ld16(text + p), '\r');
@@ -163,7 +177,7 @@ __device__ __forceinline__ u32 fxg_first_cr(const uint8_t *text, u32 s, u32 e)
 // Numeric quality line text[s, e) with the reference's token rules (fastx.c:137-167): strtol() on the rest of the line until the
 // rest is empty -- leading isspace() bytes, one optional sign, digits; the long lands in an int.  Returns the number of values, or
 // -1 if a token is not a number or a value lies outside -15..93.  out (optional) receives value + 33 for the first cap values.
-__device__ __forceinline__ int fxg_parse_numeric(const uint8_t *text, u32 s, u32 e, uint8_t *out, u32 cap)
+FXG_HD int fxg_parse_numeric(const uint8_t *text, u32 s, u32 e, uint8_t *out, u32 cap)
 {
     u32 p = s;
     int cnt = 0;
@@ -189,35 +203,48 @@ __device__ __forceinline__ int fxg_parse_numeric(const uint8_t *text, u32 s, u32
     return cnt;
 }
 
-// LPR: lines per record (4 FASTQ, 2 FASTA)
+// LPR: lines per record (4 FASTQ, 2 FASTA).  One record: chomp its lines, check them, classify its quality line; writes le[] (when the
+// block has CR bytes), len[r], flags[r]; returns the FXG_TEXT_IRR_* bits, the sequence length and whether the quality line is numeric.
+template <int LPR>
+FXG_HD u32 fxg_text_record(const uint8_t *text, const u32 *ls, u32 *le, u64 r, u32 has_cr, uint16_t *len, uint8_t *flags, u32 *seq_len, u32 *numeric)
+{
+    const u64 b = (u64)LPR * r;
+    u32 irr = 0;
+    u32 s[LPR], e[LPR];
+#pragma unroll
+    for (int k = 0; k < LPR; ++k) { s[k] = ls[b + k]; e[k] = le[b + k]; }
+    if (has_cr) {                                            // chomp: a line ends at its first CR (chomp.c:36-41)
+#pragma unroll
+        for (int k = 0; k < LPR; ++k) { e[k] = fxg_first_cr(text, s[k], e[k]); le[b + k] = e[k]; }
+    }
+    const u32 sl = e[1] - s[1];
+    if (s[0] == e[0] || text[s[0]] != (LPR == 4 ? '@' : '>')) irr |= FXG_TEXT_IRR_PREFIX;      // (an empty first line has no prefix either)
+    if (sl == 0u || sl >= 24998u || e[0] - s[0] >= 24999u) irr |= FXG_TEXT_IRR_SEQLEN;
+    u32 fl = 0;
+    if (LPR == 4) {
+        const u32 ql = e[3] - s[3];
+        if (e[2] - s[2] >= 24999u) irr |= FXG_TEXT_IRR_SEQLEN;
+        if (ql != sl && !irr) {                                // R6: not one character per base -> numbers
+            if (fxg_parse_numeric(text, s[3], e[3], nullptr, 0u) == (int)sl) fl = FXG_REC_NUMERIC;
+            else irr |= FXG_TEXT_IRR_QUALLEN;
+        }
+    }
+    flags[r] = (uint8_t)fl;
+    len[r] = (uint16_t)(sl > 65535u ? 65535u : sl);
+    *seq_len = sl; *numeric = fl;
+    return irr;
+}
+
+#ifndef FXG_HOST_EMULATION
 template <int LPR>
 __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_records(const uint8_t *text, const u32 *ls, u32 *le, u64 n, uint16_t *len, uint8_t *flags, FxgTextState *st)
 {
     const u64 r = (u64)blockIdx.x * FXG_BLOCK + threadIdx.x;
     u32 irr = 0, sl = 0;
     if (r < n) {
-        const u64 b = (u64)LPR * r;
-        u32 s[LPR], e[LPR];
-#pragma unroll
-        for (int k = 0; k < LPR; ++k) { s[k] = ls[b + k]; e[k] = le[b + k]; }
-        if (st->has_cr) {                                        // chomp: a line ends at its first CR (chomp.c:36-41)
-#pragma unroll
-            for (int k = 0; k < LPR; ++k) { e[k] = fxg_first_cr(text, s[k], e[k]); le[b + k] = e[k]; }
-        }
-        sl = e[1] - s[1];
-        if (s[0] == e[0] || text[s[0]] != (LPR == 4 ? '@' : '>')) irr |= FXG_TEXT_IRR_PREFIX;      // (an empty first line has no prefix either)
-        if (sl == 0u || sl >= 24998u || e[0] - s[0] >= 24999u) irr |= FXG_TEXT_IRR_SEQLEN;
         u32 fl = 0;
-        if (LPR == 4) {
-            const u32 ql = e[3] - s[3];
-            if (e[2] - s[2] >= 24999u) irr |= FXG_TEXT_IRR_SEQLEN;
-            if (ql != sl && !irr) {                                // R6: not one character per base -> numbers
-                if (fxg_parse_numeric(text, s[3], e[3], nullptr, 0u) == (int)sl) { fl = FXG_REC_NUMERIC; atomicAdd(&st->n_numeric, 1u); }
-                else irr |= FXG_TEXT_IRR_QUALLEN;
-            }
-        }
-        flags[r] = (uint8_t)fl;
-        len[r] = (uint16_t)(sl > 65535u ? 65535u : sl);
+        irr = fxg_text_record<LPR>(text, ls, le, r, st->has_cr, len, flags, &sl, &fl);
+        if (fl) atomicAdd(&st->n_numeric, 1u);
         if (irr) { atomicOr(&st->irregular, irr); atomicMin(&st->first_bad, (u32)r); }
     }
     // batch extrema: wave reduction, then one pair of atomics per workgroup (a single address takes ~11 ns per atomic)
@@ -233,6 +260,7 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_records(const uint8
         if (mn != 0xFFFFFFFFu) atomicMin(&st->min_len, mn);
     }
 }
+#endif  // FXG_HOST_EMULATION
 
 // ---------------------------------------------------------------------------------------------------------
 // text -> SoA rows.  One lane owns one 16-byte aligned chunk of the row array and assembles it from the
@@ -240,18 +268,16 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_records(const uint8
 // Qualities are normalised to Phred+33 codes (byte - (Q - 33)) and range-checked; bases are alphabet-checked.
 // Records with numeric quality lines are left zero here and filled by fxg_kernel_text_numeric.
 // ---------------------------------------------------------------------------------------------------------
+// one 16-byte chunk c of the row array; returns nonzero if a byte of it is not a valid base / quality character
 template <bool QUAL, int LPR>
-__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_pack(const uint8_t *text, u64 text_len, const u32 *ls, const u32 *le, const uint8_t *flags, u64 n, u32 stride,
-                                                                  int qoffset, uint8_t *rows, FxgTextState *st)
+FXG_HD u32 fxg_text_pack_chunk(const uint8_t *text, u64 text_len, const u32 *ls, const u32 *le, const uint8_t *flags, u64 n, u32 stride, int qoffset, uint8_t *rows, u64 c)
 {
-    const u64 total = n * (u64)stride;
-    const u64 nchunks = (total + 15) >> 4;
     const int qlo = qoffset - 15 < 0 ? 0 : qoffset - 15, qhi = qoffset + 93 > 127 ? 127 : qoffset + 93;   // valid raw characters
     const u32 Klo = (u32)(128 - qlo) * 0x01010101u, Khi = (u32)(128 - (qhi + 1)) * 0x01010101u;
     const int dq = qoffset - 33;                                     // raw character -> Phred+33 code
     const u32 adj4 = (u32)(dq >= 0 ? dq : -dq) * 0x01010101u;
     u32 bad = 0;
-    for (u64 c = (u64)blockIdx.x * FXG_BLOCK + threadIdx.x; c < nchunks; c += (u64)gridDim.x * FXG_BLOCK) {
+    {
         const u64 b0 = c << 4;
         u64 r = b0 / stride;
         u32 pos = (u32)(b0 - r * stride);            // position inside row r of chunk byte 0
@@ -308,6 +334,25 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_pack(const uint8_t 
         }
         *reinterpret_cast<u32x4 *>(rows + b0) = acc;       // rows[] is padded to a multiple of 16 bytes by the caller
     }
+    return bad;
+}
+
+// quality row of record r when its quality line is numeric (fxg_text_pack_chunk<true> left it zero)
+FXG_HD void fxg_text_numeric_row(const uint8_t *text, const u32 *ls, const u32 *le, const uint8_t *flags, u32 stride, uint8_t *rows, u64 r)
+{
+    if (!(flags[r] & FXG_REC_NUMERIC)) return;
+    (void)fxg_parse_numeric(text, ls[4 * r + 3], le[4 * r + 3], rows + r * (u64)stride, stride);
+}
+
+#ifndef FXG_HOST_EMULATION
+template <bool QUAL, int LPR>
+__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_pack(const uint8_t *text, u64 text_len, const u32 *ls, const u32 *le, const uint8_t *flags, u64 n, u32 stride,
+                                                                  int qoffset, uint8_t *rows, FxgTextState *st)
+{
+    const u64 nchunks = (n * (u64)stride + 15) >> 4;
+    u32 bad = 0;
+    for (u64 c = (u64)blockIdx.x * FXG_BLOCK + threadIdx.x; c < nchunks; c += (u64)gridDim.x * FXG_BLOCK)
+        bad |= fxg_text_pack_chunk<QUAL, LPR>(text, text_len, ls, le, flags, n, stride, qoffset, rows, c);
     if (bad) atomicOr(&st->irregular, QUAL ? FXG_TEXT_IRR_QUAL : FXG_TEXT_IRR_BASE);
 }
 
@@ -315,12 +360,12 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_pack(const uint8_t 
 __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_numeric(const uint8_t *text, const u32 *ls, const u32 *le, const uint8_t *flags, u64 n, u32 stride, uint8_t *rows)
 {
     const u64 r = (u64)blockIdx.x * FXG_BLOCK + threadIdx.x;
-    if (r >= n || !(flags[r] & FXG_REC_NUMERIC)) return;
-    (void)fxg_parse_numeric(text, ls[4 * r + 3], le[4 * r + 3], rows + r * (u64)stride, stride);
+    if (r < n) fxg_text_numeric_row(text, ls, le, flags, stride, rows, r);
 }
+#endif  // FXG_HOST_EMULATION
 
 // read count of a FASTA record: the number after the first '-' of its identifier, 1 if there is none (fastx.c:475-495)
-__device__ __forceinline__ u32 fxg_reads_count(const uint8_t *text, u32 s, u32 e)
+FXG_HD u32 fxg_reads_count(const uint8_t *text, u32 s, u32 e)
 {
     u32 p = s;
     while (p < e && text[p] != '-') ++p;
@@ -336,21 +381,25 @@ __device__ __forceinline__ u32 fxg_reads_count(const uint8_t *text, u32 s, u32 e
 }
 
 // -v report tallies weighted by read count (FASTA input): [0] input reads, [1] output reads, then the clipper's five reasons
+FXG_HD void fxg_text_weights_record(const uint8_t *text, const u32 *ls, const u32 *le, const u32 *res, u64 r, u64 (&v)[7])
+{
+    const u64 w = fxg_reads_count(text, ls[2 * r] + 1u, le[2 * r]);
+    const u32 x = res[r], why = (x >> 17) & 0xFu;
+    v[0] = w;
+    if ((x >> 16) & 1u) v[1] = w;
+    if (why == FXG_R_CLIP_TOO_SHORT) v[2] = w;
+    if ((x >> FXG_RES_ADAPTER_ONLY_BIT) & 1u) v[3] = w;
+    if (why == FXG_R_CLIP_NO_ADAPTER) v[4] = w;
+    if (why == FXG_R_CLIP_ADAPTER_FOUND) v[5] = w;
+    if (why == FXG_R_CLIP_N) v[6] = w;
+}
+
+#ifndef FXG_HOST_EMULATION
 __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_weights(const uint8_t *text, const u32 *ls, const u32 *le, const u32 *res, u64 n, FxgTextState *st)
 {
     const u64 r = (u64)blockIdx.x * FXG_BLOCK + threadIdx.x;
     u64 v[7] = {0, 0, 0, 0, 0, 0, 0};
-    if (r < n) {
-        const u64 w = fxg_reads_count(text, ls[2 * r] + 1u, le[2 * r]);
-        const u32 x = res[r], why = (x >> 17) & 0xFu;
-        v[0] = w;
-        if ((x >> 16) & 1u) v[1] = w;
-        if (why == FXG_R_CLIP_TOO_SHORT) v[2] = w;
-        if ((x >> FXG_RES_ADAPTER_ONLY_BIT) & 1u) v[3] = w;
-        if (why == FXG_R_CLIP_NO_ADAPTER) v[4] = w;
-        if (why == FXG_R_CLIP_ADAPTER_FOUND) v[5] = w;
-        if (why == FXG_R_CLIP_N) v[6] = w;
-    }
+    if (r < n) fxg_text_weights_record(text, ls, le, res, r, v);
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
         u64 x = v[i];
@@ -358,6 +407,7 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_weights(const uint8
         if (fxg_lane() == 0 && x) atomicAdd(&st->weighted[i], x);
     }
 }
+#endif  // FXG_HOST_EMULATION
 
 // ---------------------------------------------------------------------------------------------------------
 // formatting: sizes -> (scan on the host side of this header) -> copy
@@ -377,14 +427,12 @@ struct FxgFormatArgs {
     uint8_t *out;
 };
 
-__device__ __forceinline__ u32 fxg_num_width(int v) { return (v < 0 ? 1u : 0u) + ((v <= -10 || v >= 10) ? 2u : 1u); }     // -15..93
+FXG_HD u32 fxg_num_width(int v) { return (v < 0 ? 1u : 0u) + ((v <= -10 || v >= 10) ? 2u : 1u); }     // -15..93
 
 // item r = output bytes of record r in the low 40 bits, keep flag above (the scan then yields offset and rank)
 template <int LPR>
-__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_sizes(const FxgFormatArgs a, u64 *item)
+FXG_HD u64 fxg_text_size_record(const FxgFormatArgs &a, u64 r)
 {
-    const u64 r = (u64)blockIdx.x * FXG_BLOCK + threadIdx.x;
-    if (r >= a.n) return;
     const u32 w = a.res[r];
     u64 v = 0;
     if ((w >> 16) & 1u) {
@@ -407,11 +455,11 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_sizes(const FxgForm
         }
         v = bytes | (1ull << 40);
     }
-    item[r] = v;
+    return v;
 }
 
 // n bytes from src to dst, both arbitrarily aligned, by `lanes` cooperating lanes (lane id `l`); add is applied per byte
-__device__ __forceinline__ void fxg_copy_bytes(uint8_t *dst, const uint8_t *src, u32 n, u32 l, u32 lanes, int add)
+FXG_HD void fxg_copy_bytes(uint8_t *dst, const uint8_t *src, u32 n, u32 l, u32 lanes, int add)
 {
     const u32 full = n >> 4;
     const u32 a4 = (u32)(add >= 0 ? add : -add) * 0x01010101u;
@@ -428,11 +476,8 @@ __device__ __forceinline__ void fxg_copy_bytes(uint8_t *dst, const uint8_t *src,
 // Forward outputs are slices of the input lines; reverse-complemented / masked outputs come from the engine's packed arrays at
 // pk_off[rank] and hold Phred+33 codes.  Numeric quality lines are printed from the codes by one lane.
 template <int LPR>
-__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_format(const FxgFormatArgs a)
+FXG_HD void fxg_text_format_record(const FxgFormatArgs &a, u64 r, u32 l)
 {
-    const u32 l = threadIdx.x & 15u;
-    const u64 r = ((u64)blockIdx.x * FXG_BLOCK + threadIdx.x) >> 4;
-    if (r >= a.n) return;
     const u32 w = a.res[r];
     if (!((w >> 16) & 1u)) return;
     const u64 sc = a.item_scan[r];
@@ -472,3 +517,19 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_format(const FxgFor
         qd[k] = '\n';
     }
 }
+
+#ifndef FXG_HOST_EMULATION
+template <int LPR>
+__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_sizes(const FxgFormatArgs a, u64 *item)
+{
+    const u64 r = (u64)blockIdx.x * FXG_BLOCK + threadIdx.x;
+    if (r < a.n) item[r] = fxg_text_size_record<LPR>(a, r);
+}
+
+template <int LPR>
+__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_text_format(const FxgFormatArgs a)
+{
+    const u64 r = ((u64)blockIdx.x * FXG_BLOCK + threadIdx.x) >> 4;
+    if (r < a.n) fxg_text_format_record<LPR>(a, r, threadIdx.x & 15u);
+}
+#endif  // FXG_HOST_EMULATION

@@ -43,6 +43,14 @@ struct fxh_reader *fxh_reader_open(const char *filename, size_t capacity)
     return r;
 }
 
+struct fxh_reader *fxh_reader_open_range(const char *filename, size_t capacity, off_t start, off_t limit)
+{
+    struct fxh_reader *r = fxh_reader_open(filename, capacity);
+    if (lseek(r->fd, start, SEEK_SET) != start) err(1, "failed to seek in input file '%s'", filename);
+    r->limit = limit;
+    return r;
+}
+
 /* enlarge the block (batch mode wants tens of MB per engine call); existing unread bytes are kept */
 void fxh_reader_reserve(struct fxh_reader *r, size_t capacity)
 {
@@ -62,7 +70,13 @@ void fxh_reader_fill(struct fxh_reader *r)
         r->beg = 0;
     }
     while (!r->eof && r->end < r->cap) {
-        ssize_t k = read(r->fd, r->buf + r->end, r->cap - r->end);
+        size_t want = r->cap - r->end;
+        if (r->limit > 0) {                                    /* a part of a sharded run: the input ends at `limit` */
+            const off_t pos = lseek(r->fd, 0, SEEK_CUR);
+            if (pos < 0 || pos >= r->limit) { r->eof = 1; break; }
+            if ((off_t)want > r->limit - pos) want = (size_t)(r->limit - pos);
+        }
+        ssize_t k = read(r->fd, r->buf + r->end, want);
         if (k < 0) { if (errno == EINTR) continue; err(1, "read failed"); }
         if (k == 0) { r->eof = 1; break; }
         r->end += (size_t)k;
@@ -431,6 +445,9 @@ static int fxh_open_output(const char *filename)
     return fd;
 }
 
+static struct fxh_writer *fxh_writer_open(const char *filename, int gzip);
+struct fxh_writer *fxh_writer_open_file(const char *filename, int gzip) { return fxh_writer_open(filename, gzip); }
+
 static struct fxh_writer *fxh_writer_open(const char *filename, int gzip)
 {
     struct fxh_writer *w = (struct fxh_writer *)calloc(1, sizeof *w);
@@ -496,7 +513,14 @@ void fastx_init_writer(FASTX *fx, const char *filename, OUTPUT_FILE_TYPE output_
     if (fx->reader == NULL) errx(1, "Internal error: pFASTX not initialized (%s:%d)", __FILE__, __LINE__);
     fx->compress_output = compress_output;
     strncpy(fx->output_file_name, filename, sizeof fx->output_file_name - 1);
-    fx->writer = fxh_writer_open(filename, compress_output);
+    {   /* FXH_PARTS=k: "-o out.%r.fq" names the k output parts; this writer is part 0 (fxh_batch.c opens the others) */
+        char first[PATH_MAX];
+        const char *pe = getenv("FXH_PARTS"), *pr = strstr(filename, "%r");
+        if (pe && atoi(pe) >= 1 && pr && strlen(filename) < sizeof first - 8) {
+            snprintf(first, sizeof first, "%.*s0%s", (int)(pr - filename), filename, pr + 2);
+            fx->writer = fxh_writer_open(first, compress_output);
+        } else fx->writer = fxh_writer_open(filename, compress_output);
+    }
     switch (output_type) {
     case OUTPUT_FASTA:
         fx->write_fastq = 0; fx->output_sequence_id_prefix = '>';

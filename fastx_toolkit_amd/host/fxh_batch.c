@@ -3,6 +3,7 @@
 #include "fxh_batch.h"
 
 #include <err.h>
+#include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -368,7 +369,7 @@ typedef struct {
     size_t newlines;                   /* '\n' bytes among the `filled` bytes */
     int state;                         /* 0 idle, 1 requested, 2 done, 3 quit */
     int regular, io_threads;           /* regular file: parallel pread() from `offset` on */
-    off_t offset;
+    off_t offset, limit;               /* limit > 0: the input ends at this file offset (a part of a sharded run) */
 } fxh_prefetch;
 
 /* Regular files are read with several pread() in flight (page-cache copies scale with threads; one read() stream is ~3 GB/s);
@@ -423,25 +424,33 @@ static void *fxh_prefetch_main(void *arg)
         size_t got = 0, newlines = (size_t)-1; int eof = 0;
         const size_t gap = pf->gap;
         if (pf->regular) {
-            const size_t want = cap - gap;
-            int nt = pf->io_threads;
-            if ((size_t)nt > want / ((size_t)4 << 20)) nt = (int)(want / ((size_t)4 << 20));
-            if (nt < 1) nt = 1;
-            pthread_t th[16];
-            fxh_pread_job job[16];
-            const size_t per = (want + (size_t)nt - 1) / (size_t)nt;
-            for (int i = 0; i < nt; ++i) {
-                const size_t o = (size_t)i * per;
-                job[i].fd = pf->fd; job[i].dst = buf + gap + o; job[i].off = pf->offset + (off_t)o;
-                job[i].n = o >= want ? 0 : (want - o < per ? want - o : per);
+            size_t want = cap - gap;
+            if (pf->limit > 0) {                                       /* a part of a sharded run: the input ends at `limit` */
+                if (pf->offset >= pf->limit) want = 0;
+                else if ((off_t)want > pf->limit - pf->offset) want = (size_t)(pf->limit - pf->offset);
             }
-            for (int i = 1; i < nt; ++i) if (pthread_create(&th[i], NULL, fxh_pread_main, &job[i]) != 0) err(1, "pthread_create");
-            fxh_pread_main(&job[0]);
-            for (int i = 1; i < nt; ++i) pthread_join(th[i], NULL);
-            size_t nl = 0;
-            for (int i = 0; i < nt; ++i) { got += job[i].got; nl += job[i].newlines; if (job[i].got < job[i].n) { eof = 1; break; } }   /* a short slice is the end of the file */
-            pf->offset += (off_t)got;
-            newlines = nl;
+            if (want == 0) { eof = 1; newlines = 0; }
+            else {
+                int nt = pf->io_threads;
+                if ((size_t)nt > want / ((size_t)4 << 20)) nt = (int)(want / ((size_t)4 << 20));
+                if (nt < 1) nt = 1;
+                pthread_t th[16];
+                fxh_pread_job job[16];
+                const size_t per = (want + (size_t)nt - 1) / (size_t)nt;
+                for (int i = 0; i < nt; ++i) {
+                    const size_t o = (size_t)i * per;
+                    job[i].fd = pf->fd; job[i].dst = buf + gap + o; job[i].off = pf->offset + (off_t)o;
+                    job[i].n = o >= want ? 0 : (want - o < per ? want - o : per);
+                }
+                for (int i = 1; i < nt; ++i) if (pthread_create(&th[i], NULL, fxh_pread_main, &job[i]) != 0) err(1, "pthread_create");
+                fxh_pread_main(&job[0]);
+                for (int i = 1; i < nt; ++i) pthread_join(th[i], NULL);
+                size_t nl = 0;
+                for (int i = 0; i < nt; ++i) { got += job[i].got; nl += job[i].newlines; if (job[i].got < job[i].n) { eof = 1; break; } }   /* a short slice is the end of the file */
+                pf->offset += (off_t)got;
+                if (pf->limit > 0 && pf->offset >= pf->limit) eof = 1;
+                newlines = nl;
+            }
         } else {
             while (gap + got < cap) {
                 ssize_t k = read(pf->fd, buf + gap + got, cap - gap - got);
@@ -487,6 +496,7 @@ static void fxh_next_block(fxh_prefetch *pf, struct fxh_reader *rd, char **spare
             pf->fd = rd->fd; pf->state = 0; pf->started = 1;
             pf->gap = rd->cap / 4 < FXH_GAP_MAX ? rd->cap / 4 : FXH_GAP_MAX;
             fxh_prefetch_probe(pf, rd->fd);
+            pf->limit = rd->limit;
             if (pthread_create(&pf->th, NULL, fxh_prefetch_main, pf) != 0) err(1, "pthread_create");
             *spare = (char *)malloc(rd->cap + 1);
             if (!*spare) err(1, "out of memory");
@@ -521,6 +531,7 @@ static void fxh_next_block_ring(fxh_prefetch *pf, struct fxh_reader *rd, char *t
             pf->fd = rd->fd; pf->state = 0; pf->started = 1;
             pf->gap = rd->cap / 4 < FXH_GAP_MAX ? rd->cap / 4 : FXH_GAP_MAX;
             fxh_prefetch_probe(pf, rd->fd);
+            pf->limit = rd->limit;
             if (pthread_create(&pf->th, NULL, fxh_prefetch_main, pf) != 0) err(1, "pthread_create");
             fxh_prefetch_request(pf, target, rd->cap);
         }
@@ -647,6 +658,9 @@ static void fxh_awriter_submit_ext(fxh_awriter *aw, struct fxh_writer *w, const 
 #ifndef FXH_MAX_LANES
 #define FXH_MAX_LANES 32
 #endif
+static volatile int g_parts_abort;         /* sharded run: some part met input it does not handle (fxh_run_parts) */
+static pthread_mutex_t g_first_ctx_mu = PTHREAD_MUTEX_INITIALIZER;   /* the HIP runtime's first-use initialisation: one thread at a time */
+static int g_first_ctx_done;
 struct fxh_pinned { pthread_mutex_t mu; const void *ptr[FXH_MAX_LANES + 4]; int n; };
 
 #define FXH_MAX_LANES 32
@@ -760,7 +774,10 @@ static void *fxh_lane_main(void *arg)
         pthread_mutex_unlock(&ln->first->mu);
     }
     double t0 = fxh_now();
-    int rc = fxg_ctx_create(ln->device, &ln->st.ctx);
+    int rc;
+    pthread_mutex_lock(&g_first_ctx_mu);    /* the parts of a sharded run each have a lane 0: the process-wide first context still comes alone */
+    if (!g_first_ctx_done) { rc = fxg_ctx_create(ln->device, &ln->st.ctx); g_first_ctx_done = 1; pthread_mutex_unlock(&g_first_ctx_mu); }
+    else { pthread_mutex_unlock(&g_first_ctx_mu); rc = fxg_ctx_create(ln->device, &ln->st.ctx); }
     if (rc != 0) errx(1, "no usable MI355X/HIP device %d (fxg_ctx_create = %d); this build has no CPU path", ln->device, rc);
     FXG_CHECK(&ln->st, fxg_malloc_device(ln->st.ctx, FXG_NCOUNTERS * sizeof(uint64_t), (void **)&ln->st.d_counters));
     /* one fastx_clipper process = one aligner whose query buffer survives from read to read (sequence_alignment.cpp:135-136,
@@ -867,6 +884,9 @@ typedef struct fxh_run {
     int overlap;
     char errmsg[768];
     int have_err, at_eof;
+    int part, nparts;                      /* sharded run (FXH_PARTS): this run is part `part` of `nparts`; irregular input aborts it (fxh_run_parts) */
+    int aborted;
+    struct fxh_pinned pinned;              /* input buffers the lanes have page-locked */
     unsigned long n_fallback;
     double t_index, t_pack, t_gpu, t_fmt, t_init;
     double t_wait_lane, t_wait_writer, t_drain;      /* lanes loop: main thread blocked on a lane / on the writer / final drain */
@@ -1110,8 +1130,8 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
     FASTX *fx = R->fx;
     struct fxh_reader *rd = fx->reader;
     struct fxh_writer *wr = fx->writer;
-    static struct fxh_pinned pinned;
-    pthread_mutex_init(&pinned.mu, NULL);
+    struct fxh_pinned *pinned = &R->pinned;
+    pthread_mutex_init(&pinned->mu, NULL);
     fxh_lane *lanes = (fxh_lane *)calloc((size_t)nlanes, sizeof(fxh_lane));
     const int NB = nlanes + 2;             /* input buffers: nlanes blocks in flight + the one being cut + the one being read */
     char **inbuf = (char **)calloc((size_t)NB, sizeof(char *));
@@ -1122,7 +1142,7 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
         ln->id = i; ln->device = lane_dev[i]; ln->p = R->p; ln->revcomp = R->job.revcomp; ln->fwd_start = R->job.fwd_start;
         ln->qoffset = fx->fastq_ascii_quality_offset;
         ln->reverse = (R->p->stages & FXG_STAGE_REVCOMP) != 0; ln->lpr = R->job.lpr; ln->has_q = R->job.has_q; ln->out_fasta = !fx->write_fastq;
-        ln->pinned = &pinned; ln->first = &lanes[0];
+        ln->pinned = pinned; ln->first = &lanes[0];
         if ((R->p->stages & FXG_STAGE_CLIP) && nlanes == 1) { ln->clip_history = 1; R->st_shared = 1; }
         pthread_mutex_init(&ln->mu, NULL); pthread_cond_init(&ln->cv, NULL);
         if (pthread_create(&ln->th, NULL, fxh_lane_main, ln) != 0) err(1, "pthread_create");
@@ -1133,7 +1153,7 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
     int input_done = 0, have_carry = 0;
     unsigned long long carry_lines = 0;
 
-    while (!R->have_err) {
+    while (!R->have_err && !R->aborted && !(R->nparts > 1 && g_parts_abort)) {
         /* ---- collect finished blocks in input order until a lane and an input buffer are free ---- */
         while (next_emit < nblocks && (nblocks - next_emit >= (size_t)nlanes || input_done)) {
             fxh_block *b = &blk[next_emit % (size_t)NB];
@@ -1151,6 +1171,10 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
                     if (!R->overlap) fxh_awriter_wait(&R->aw);
                     fxh_add_counters(R->tot, ln->ctr, b->records, ln->lpr == 2 ? ln->weighted : NULL);
                 }
+            }
+            if (!handled && R->nparts > 1) {   /* a part of a sharded run only takes what the device path takes: the whole run starts over unsharded */
+                R->aborted = 1; g_parts_abort = 1;
+                break;
             }
             if (!handled) {                /* this block goes through the host parser, at its place in the output order */
                 R->n_fallback++;
@@ -1180,6 +1204,7 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
             next_emit++;
             if (R->have_err) break;
         }
+        if (R->aborted) break;
         if (R->have_err || input_done) { if (next_emit >= nblocks) break; else continue; }
 
         /* ---- next block of text: [unread tail of the previous block | prefetched data] ---- */
@@ -1265,17 +1290,18 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
     free(inbuf); free(blk); free(lanes);
 }
 
-static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_stats_run *stats, uint64_t **hist_out, uint32_t *cols_out)
+static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_stats_run *stats, uint64_t **hist_out, uint32_t *cols_out, int part, int nparts)
 {
     fxh_run R;
     memset(&R, 0, sizeof R);
     memset(tot, 0, sizeof *tot);
-    R.fx = fx; R.p = p; R.tot = tot; R.stats = stats;
+    R.fx = fx; R.p = p; R.tot = tot; R.stats = stats; R.part = part; R.nparts = nparts;
     const int timing = getenv("FXH_TIMING") != NULL;
     const double t_run0 = fxh_now();
     double t_read = 0, t_lane_init = 0, t0;
     int dev[FXH_MAX_LANES];
-    const int ndev = fxh_device_list(dev, FXH_MAX_LANES);
+    int ndev = fxh_device_list(dev, FXH_MAX_LANES);
+    if (nparts > 1 && ndev > 1) { dev[0] = dev[part % ndev]; ndev = 1; }      /* a part of a sharded run stays on one GPU */
     R.st_device = dev[0];
     struct fxh_reader *rd = fx->reader;
     if (!getenv("FXH_READ_BUFFER_MB")) fxh_reader_reserve(rd, (size_t)64 << 20);   /* one engine call per 64 MB of text */
@@ -1338,6 +1364,12 @@ static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_sta
     }
     fxh_awriter_stop(&R.aw);
     fxh_prefetch_stop(&pf);
+    if (nparts > 1 && (R.aborted || R.have_err || g_parts_abort)) {      /* fxh_run_parts starts the whole job over, unsharded */
+        g_parts_abort = 1;
+        for (int i = 0; i < job->nworkers; ++i) { free(job->w[i].rec); free(job->w[i].shadow); }
+        free(job->w);
+        return 2;
+    }
     if (R.have_err) {
         if (!stats) fxh_writer_flush(fx->writer);   /* every record before the bad one has been written, like the reference */
         errx(1, "%s", R.errmsg);
@@ -1353,8 +1385,8 @@ static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_sta
         }
     }
     if (timing)
-        fprintf(stderr, "fxh timing (%d threads, %s parse, %d lanes on %d GPU(s), %lu host-parsed blocks): run %.3f = init %.3f read %.3f index %.3f pack %.3f format+write %.3f wait-lane %.3f wait-writer %.3f drain %.3f; gpu(h2d+kernel+d2h, summed over lanes) %.3f s\n",
-                job->nworkers, gpu_text ? "device" : "host", nlanes, nlanes ? ndev : 1, R.n_fallback, fxh_now() - t_run0, R.t_init + t_lane_init, t_read, R.t_index, R.t_pack, R.t_fmt,
+        fprintf(stderr, "fxh timing part %d/%d (%d threads, %s parse, %d lanes on %d GPU(s), %lu host-parsed blocks): run %.3f = init %.3f read %.3f index %.3f pack %.3f format+write %.3f wait-lane %.3f wait-writer %.3f drain %.3f; gpu(h2d+kernel+d2h, summed over lanes) %.3f s\n",
+                part, nparts, job->nworkers, gpu_text ? "device" : "host", nlanes, nlanes ? ndev : 1, R.n_fallback, fxh_now() - t_run0, R.t_init + t_lane_init, t_read, R.t_index, R.t_pack, R.t_fmt,
                 R.t_wait_lane, R.t_wait_writer, R.t_drain, R.t_gpu);
     if (R.st.ctx) fxg_ctx_destroy(R.st.ctx);
     for (int i = 0; i < job->nworkers; ++i) { free(job->w[i].rec); free(job->w[i].shadow); }
@@ -1362,12 +1394,164 @@ static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_sta
     return 0;
 }
 
-int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *tot) { return fxh_run_impl(fx, p, tot, NULL, NULL, NULL); }
+/* ---------------------------------------------------------------------------------------------- */
+/* Sharded run (FXH_PARTS=k): the text-level analogue of fxg_shard_range / fxg_epilogue / fxg_concat_pwrite.  The input file is   */
+/* cut into k contiguous byte ranges at record boundaries; k runs (each the lanes loop above: own reader threads, own lanes, own    */
+/* writer thread) work through them at the same time, part r on GPU r mod #GPUs, and write k output parts whose concatenation in    */
+/* part order is the output of the unsharded run: one writer stream is what caps a single run (a tmpfs or page-cache write is one   */
+/* thread under the inode lock), k parts are k streams.  `-o NAME` names part 0 NAME and part r NAME.r; `-o out.%r.fq` substitutes. */
+/* An index NAME.parts lists (part, file, input bytes, records in, records out, output bytes).                                       */
+/*   A record is four (two) lines counted from the start of the input, so a cut is only KNOWN to be a record boundary when the line */
+/* count before it is: the cut points are found by pattern (an '@' line, a '+' line two below it, equal lengths, the same again)    */
+/* and then PROVEN -- part r ends exactly at part r+1's cut, so if its lines are a whole number of records and part r started at a  */
+/* boundary, so does part r+1 (induction from offset 0).  A part that meets anything the device path does not take (a ragged end =   */
+/* a wrong cut, a malformed record, CR-less oddities the host parser owns) stops all parts; the process then re-executes its own     */
+/* command line unsharded, so messages, exit codes and partial output are the reference's in every case.                            */
+/* ---------------------------------------------------------------------------------------------- */
+static off_t fxh_find_cut(int fd, off_t from, off_t size, int lpr)
+{
+    const size_t W = (size_t)4 << 20;
+    char *w = (char *)malloc(W);
+    if (!w) err(1, "out of memory");
+    ssize_t got = pread(fd, w, W, from);
+    off_t found = -1;
+    if (got > 0) {
+        size_t n = (size_t)got, ls[12];
+        const char *nl = (const char *)memchr(w, '\n', n);
+        size_t pos = nl ? (size_t)(nl - w) + 1 : n;                         /* first line start after `from` */
+        while (pos < n && found < 0) {
+            int k = 0;                                                       /* starts of this line and the next 2 lpr */
+            size_t q = pos;
+            while (k < 2 * lpr + 1 && q < n) { ls[k++] = q; const char *e = (const char *)memchr(w + q, '\n', n - q); if (!e) { q = n; break; } q = (size_t)(e - w) + 1; }
+            if (k < 2 * lpr + 1) break;                                     /* not enough text in the window */
+            int ok;
+            if (lpr == 2) ok = w[ls[0]] == '>' && w[ls[2]] == '>';
+            else ok = w[ls[0]] == '@' && w[ls[2]] == '+' && (ls[2] - ls[1]) == (ls[4] - ls[3]) &&
+                      w[ls[4]] == '@' && w[ls[6]] == '+' && (ls[6] - ls[5]) == (ls[8] - ls[7]);
+            if (ok) found = from + (off_t)ls[0];
+            else pos = ls[1];
+        }
+    }
+    free(w);
+    return (found > 0 && found < size) ? found : -1;
+}
+
+typedef struct { FASTX *fx; const fxg_params *p; fxh_totals tot; int part, nparts, rc; pthread_t th; off_t start, limit; char name[PATH_MAX + 16]; } fxh_part;
+static void *fxh_part_main(void *arg)
+{
+    fxh_part *pt = (fxh_part *)arg;
+    pt->rc = fxh_run_impl(pt->fx, pt->p, &pt->tot, NULL, NULL, NULL, pt->part, pt->nparts);
+    return NULL;
+}
+
+static void fxh_part_name(const FASTX *fx, int r, char *dst, size_t cap)
+{
+    const char *name = fx->output_file_name, *pr = strstr(name, "%r");
+    if (pr) snprintf(dst, cap, "%.*s%d%s", (int)(pr - name), name, r, pr + 2);
+    else if (r == 0) snprintf(dst, cap, "%s", name);
+    else snprintf(dst, cap, "%s.%d", name, r);
+}
+
+/* 0 = done; -1 = not eligible (run unsharded); does not return when the sharded attempt has to be abandoned (re-exec) */
+static int fxh_run_parts(FASTX *fx, const fxg_params *p, fxh_totals *tot, int k)
+{
+    struct fxh_reader *rd = fx->reader;
+    struct stat sb;
+    if (k > FXH_MAX_LANES) k = FXH_MAX_LANES;
+    if (rd->fd == STDIN_FILENO || fstat(rd->fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return -1;
+    if (strcmp(fx->output_file_name, "-") == 0 || fx->compress_output || g_rename_ids || getenv("FXH_HOST_PARSE")) return -1;
+    if ((p->stages & FXG_STAGE_CLIP) && getenv("FXH_CLIP_PARALLEL") == NULL) return -1;      /* one aligner, one history (N3) */
+    const off_t size = sb.st_size, here = lseek(rd->fd, 0, SEEK_CUR);
+    const int lpr = fx->read_fastq ? 4 : 2;
+    off_t cut[FXH_MAX_LANES + 1];
+    cut[0] = 0; cut[k] = size;
+    for (int r = 1; r < k; ++r) {
+        cut[r] = fxh_find_cut(rd->fd, (off_t)((unsigned long long)size * (unsigned)r / (unsigned)k), size, lpr);
+        if (cut[r] < 0 || cut[r] <= cut[r - 1] || (r == 1 && cut[r] < here)) return -1;       /* small or odd input: one run */
+    }
+    fxh_part *pt = (fxh_part *)calloc((size_t)k, sizeof(fxh_part));
+    if (!pt) err(1, "out of memory");
+    const char *cap_env = getenv("FXH_READ_BUFFER_MB");
+    for (int r = 0; r < k; ++r) {
+        pt[r].p = p; pt[r].part = r; pt[r].nparts = k; pt[r].start = cut[r]; pt[r].limit = cut[r + 1];
+        fxh_part_name(fx, r, pt[r].name, sizeof pt[r].name);
+        if (r == 0) { pt[r].fx = fx; rd->limit = cut[1]; continue; }
+        FASTX *f = (FASTX *)malloc(sizeof(FASTX));
+        if (!f) err(1, "out of memory");
+        memcpy(f, fx, sizeof(FASTX));
+        f->reader = fxh_reader_open_range(fx->input_file_name, cap_env && atoi(cap_env) > 0 ? (size_t)atoi(cap_env) << 20 : 0, cut[r], cut[r + 1]);
+        f->writer = fxh_writer_open_file(pt[r].name, 0);
+        f->input_line_number = 0; f->num_input_sequences = f->num_input_reads = f->num_output_sequences = f->num_output_reads = 0;
+        pt[r].fx = f;
+    }
+    g_parts_abort = 0;
+    for (int r = 1; r < k; ++r) if (pthread_create(&pt[r].th, NULL, fxh_part_main, &pt[r]) != 0) err(1, "pthread_create");
+    fxh_part_main(&pt[0]);
+    for (int r = 1; r < k; ++r) pthread_join(pt[r].th, NULL);
+    int bad = g_parts_abort;
+    for (int r = 0; r < k; ++r) if (pt[r].rc != 0) bad = 1;
+    if (bad) {
+        /* Irregular input somewhere (or a cut that was no record boundary): the reference's behaviour -- message, exit code, what
+         * has been written before the bad record -- is defined for ONE stream.  Empty the parts and run the command line again
+         * unsharded; part 0 then receives everything (FXH_PARTS=1 keeps a "%r" name pointing at part 0). */
+        for (int r = 1; r < k; ++r) { fxh_writer_close(pt[r].fx->writer); if (truncate(pt[r].name, 0) != 0) warn("%s", pt[r].name); }
+        fflush(NULL);
+        setenv("FXH_PARTS", "1", 1);
+        setenv("FXH_PARTS_RESTARTED", "1", 1);
+        if (fxh_saved_argv) execv("/proc/self/exe", fxh_saved_argv);
+        errx(1, "sharded run abandoned (irregular input) and the unsharded restart failed; run again without FXH_PARTS");
+    }
+    memset(tot, 0, sizeof *tot);
+    FILE *ix = NULL;
+    {
+        char ixname[PATH_MAX + 8];
+        const char *name = fx->output_file_name, *pr = strstr(name, "%r");
+        if (pr) snprintf(ixname, sizeof ixname, "%.*sparts%s", (int)(pr - name), name, pr + 2); else snprintf(ixname, sizeof ixname, "%s.parts", name);
+        ix = fopen(ixname, "w");
+        if (ix) fprintf(ix, "#part\tfile\tinput_bytes\tinput_records\toutput_records\toutput_bytes\n");
+    }
+    for (int r = 0; r < k; ++r) {
+        const fxh_totals *t = &pt[r].tot;
+        tot->input_sequences += t->input_sequences; tot->input_reads += t->input_reads; tot->output_sequences += t->output_sequences; tot->output_reads += t->output_reads;
+        tot->clip_input += t->clip_input; tot->clip_too_short += t->clip_too_short; tot->clip_adapter_only += t->clip_adapter_only;
+        tot->clip_no_adapter += t->clip_no_adapter; tot->clip_adapter_found += t->clip_adapter_found; tot->clip_n += t->clip_n;
+        tot->masked_reads += t->masked_reads; tot->masked_nucleotides += t->masked_nucleotides; tot->qtrim_dropped += t->qtrim_dropped;
+        if (r > 0) fxh_writer_flush(pt[r].fx->writer);
+        const off_t out_bytes = r == 0 ? fx->writer->off + (off_t)fx->writer->len : pt[r].fx->writer->off;
+        if (ix) fprintf(ix, "%d\t%s\t%lld\t%zu\t%zu\t%lld\n", r, pt[r].name, (long long)(pt[r].limit - pt[r].start), t->input_sequences, t->output_sequences, (long long)out_bytes);
+        if (r > 0) { fxh_writer_close(pt[r].fx->writer); free(pt[r].fx); }
+    }
+    if (ix) fclose(ix);
+    fx->num_input_sequences = tot->input_sequences; fx->num_input_reads = tot->input_reads;
+    fx->num_output_sequences = tot->output_sequences; fx->num_output_reads = tot->output_reads;
+    free(pt);
+    return 0;
+}
+
+int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *tot)
+{
+    const char *pe = getenv("FXH_PARTS");
+    int k = pe ? atoi(pe) : 0;
+    if (k > FXH_MAX_LANES) k = FXH_MAX_LANES;
+    if (k > 1 && fxh_run_parts(fx, p, tot, k) == 0) return 0;
+    const int rc = fxh_run_impl(fx, p, tot, NULL, NULL, NULL, 0, 1);
+    if (k > 1 && strcmp(fx->output_file_name, "-") != 0 && !getenv("FXH_PARTS_RESTARTED")) {
+        /* asked for k parts but run as one stream (a pipe, a small file, -z, the serial clipper): part 0 holds everything, the others
+         * exist and are empty, so that `cat` over the k names is the output either way */
+        for (int r = 1; r < k; ++r) {
+            char name[PATH_MAX + 16];
+            fxh_part_name(fx, r, name, sizeof name);
+            FILE *f = fopen(name, "w");
+            if (f) fclose(f);
+        }
+    }
+    return rc;
+}
 
 int fxh_run_quality_stats(FASTX *fx, uint64_t **hist, uint32_t *cols, fxh_totals *tot)
 {
     fxg_params p;
     fxh_stats_run sr = {NULL, 0};
     fxh_default_params(&p, fx->fastq_ascii_quality_offset);
-    return fxh_run_impl(fx, &p, tot, &sr, hist, cols);
+    return fxh_run_impl(fx, &p, tot, &sr, hist, cols, 0, 1);
 }

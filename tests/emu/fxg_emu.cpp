@@ -12,6 +12,7 @@
 #include "../../fastx_toolkit_amd/csrc/fxg_plan.h"
 #include "../../fastx_toolkit_amd/csrc/fxg_history.h"
 #include "../../fastx_toolkit_amd/csrc/fxg_stats.h"
+#include "../../fastx_toolkit_amd/csrc/fxg_text.h"
 
 // fxg_kernel_rows: the lane holds its read's quality row in NW registers (bytes past the row: whatever follows in the staging buffer)
 template <int NW>
@@ -252,6 +253,113 @@ extern "C" int fxg_emu_run_quality_stats(const fxg_batch *in, uint64_t *hist, ui
             for (u32 t = 0; t < FXG_QS_TBLOCK; ++t) fxg_stats_flush(lds.data(), part, t, FXG_QS_TBLOCK);
         }
         for (u32 e = 0; e < FXG_QS_PART_WORDS; ++e) fxg_stats_fold(a, e);
+    }
+    return FXG_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// FASTA/FASTQ text on the "device": the per-thread bodies of fxg_text.h, one lane after the other; the wave-level reductions and
+// the scans between the kernels (fxg_engine.hip) are serial sums here.  Same contracts as fxg_fastq_index / _pack / _format / fxg_fasta_weights.
+// ------------------------------------------------------------------------------------------------
+extern "C" int fxg_emu_fastq_index(FxgTextState *st, const uint8_t *text, uint64_t text_len, int at_eof, int lpr, uint32_t *d_line, uint64_t cap_lines,
+                                   uint16_t *d_len, uint8_t *d_flags, fxg_text_info *info)
+{
+    if (!text || !d_line || !d_len || !d_flags || !info || (lpr != 4 && lpr != 2)) return FXG_E_INVALID;
+    memset(info, 0, sizeof *info);
+    info->first_bad = 0xFFFFFFFFu;
+    if (text_len == 0) return FXG_OK;
+    if (text_len > 0xFFFFFFF0ull) return FXG_E_INVALID;
+    u32 *ls = d_line, *le = d_line + cap_lines;
+    memset(st, 0, sizeof *st);
+    st->min_len = 0xFFFFFFFFu; st->first_bad = 0xFFFFFFFFu;
+    const u64 nseg = (text_len + FXG_TEXT_SEG - 1) / FXG_TEXT_SEG;
+    u64 j = 0;
+    ls[0] = 0u;
+    for (u64 seg = 0; seg < nseg; ++seg)
+        for (u32 t = 0; t < FXG_BLOCK; ++t) {
+            const u64 off = seg * FXG_TEXT_SEG + (u64)t * 16;
+            u32 cr = 0;
+            const u32 m = fxg_text_nl_mask(text, off, text_len, &cr);
+            if (cr) st->has_cr = 1u;
+            fxg_text_nl_store(m, off, j, ls, le, cap_lines);
+            j += (u64)__builtin_popcount(m);
+        }
+    const u64 lines = j;
+    info->lines = lines;
+    u64 n = lines / (u64)lpr;
+    if ((u64)lpr * n + 1 > cap_lines) n = (cap_lines - 1) / (u64)lpr;
+    info->records = n;
+    if (n == 0) { if (at_eof && lines % (u64)lpr != 0) info->irregular |= FXG_TEXT_IRR_TAIL; return FXG_OK; }
+    for (u64 r = 0; r < n; ++r) {
+        u32 sl = 0, fl = 0;
+        const u32 irr = lpr == 4 ? fxg_text_record<4>(text, ls, le, r, st->has_cr, d_len, d_flags, &sl, &fl) : fxg_text_record<2>(text, ls, le, r, st->has_cr, d_len, d_flags, &sl, &fl);
+        if (fl) st->n_numeric++;
+        if (irr) { st->irregular |= irr; if ((u32)r < st->first_bad) st->first_bad = (u32)r; }
+        else { if (sl > st->max_len) st->max_len = sl; if (sl < st->min_len) st->min_len = sl; }
+    }
+    info->consumed = ls[(u64)lpr * n];
+    info->max_len = st->max_len; info->min_len = st->min_len; info->irregular = st->irregular; info->first_bad = st->first_bad;
+    info->numeric_records = st->n_numeric; info->has_cr = st->has_cr;
+    if (at_eof && (lines % (u64)lpr != 0 || info->consumed != text_len)) info->irregular |= FXG_TEXT_IRR_TAIL;
+    return FXG_OK;
+}
+
+extern "C" int fxg_emu_fastq_pack(const uint8_t *text, uint64_t text_len, int lpr, const uint32_t *d_line, uint64_t cap_lines, const uint8_t *flags, uint64_t n,
+                                  uint32_t stride, int qoffset, uint8_t *bases, uint8_t *qual, uint32_t *irregular)
+{
+    if (!text || !d_line || !flags || !bases || !irregular || stride == 0 || (lpr != 4 && lpr != 2)) return FXG_E_INVALID;
+    *irregular = 0;
+    if (n == 0) return FXG_OK;
+    if (lpr == 2 && qual) return FXG_E_INVALID;
+    const u32 *ls = d_line, *le = d_line + cap_lines;
+    const u64 nchunks = (n * (u64)stride + 15) >> 4;
+    u32 badb = 0, badq = 0;
+    for (u64 c = 0; c < nchunks; ++c) {
+        badb |= lpr == 4 ? fxg_text_pack_chunk<false, 4>(text, text_len, ls, le, flags, n, stride, qoffset, bases, c) : fxg_text_pack_chunk<false, 2>(text, text_len, ls, le, flags, n, stride, qoffset, bases, c);
+        if (qual) badq |= fxg_text_pack_chunk<true, 4>(text, text_len, ls, le, flags, n, stride, qoffset, qual, c);
+    }
+    if (qual) for (u64 r = 0; r < n; ++r) fxg_text_numeric_row(text, ls, le, flags, stride, qual, r);
+    if (badb) *irregular |= FXG_TEXT_IRR_BASE;
+    if (badq) *irregular |= FXG_TEXT_IRR_QUAL;
+    return FXG_OK;
+}
+
+extern "C" int fxg_emu_fastq_format(const uint8_t *text, int lpr, const uint32_t *d_line, uint64_t cap_lines, const uint8_t *flags, uint64_t n, const uint32_t *res,
+                                    uint32_t fwd_start, int reverse, const uint8_t *pk_bases, const uint8_t *pk_qual, const uint64_t *pk_off, const uint8_t *rows_qual,
+                                    uint32_t stride, int qoffset, int out_fasta, uint8_t *out, uint64_t *out_bytes)
+{
+    if (!text || !d_line || !flags || !res || !out || !out_bytes || (lpr != 4 && lpr != 2)) return FXG_E_INVALID;
+    *out_bytes = 0;
+    if (n == 0) return FXG_OK;
+    const bool fastq_out = lpr == 4 && !out_fasta;
+    if (pk_bases && (!pk_off || (fastq_out && !pk_qual))) return FXG_E_INVALID;
+    if (fastq_out && !rows_qual) return FXG_E_INVALID;
+    std::vector<u64> item(n);
+    FxgFormatArgs a;
+    a.text = text; a.ls = d_line; a.le = d_line + cap_lines; a.res = res; a.flags = flags; a.item_scan = item.data(); a.n = n;
+    a.fwd_start = fwd_start; a.rev = reverse ? 1u : 0u; a.pk_bases = pk_bases; a.pk_qual = pk_qual; a.pk_off = (const u64 *)pk_off;
+    a.rows_qual = rows_qual; a.stride = stride; a.qoffset = qoffset; a.out_fasta = out_fasta ? 1u : 0u; a.out = out;
+    u64 run = 0;
+    for (u64 r = 0; r < n; ++r) {                               // sizes, then the exclusive scan (offset in the low 40 bits, rank above)
+        const u64 v = lpr == 4 ? fxg_text_size_record<4>(a, r) : fxg_text_size_record<2>(a, r);
+        item[r] = run;
+        run += v;
+    }
+    for (u64 r = 0; r < n; ++r)
+        for (u32 l = 0; l < 16; ++l) { if (lpr == 4) fxg_text_format_record<4>(a, r, l); else fxg_text_format_record<2>(a, r, l); }
+    *out_bytes = run & ((1ull << 40) - 1ull);
+    return FXG_OK;
+}
+
+extern "C" int fxg_emu_fasta_weights(const uint8_t *text, const uint32_t *d_line, uint64_t cap_lines, uint64_t n, const uint32_t *res, uint64_t weighted[8])
+{
+    if (!text || !d_line || !res || !weighted) return FXG_E_INVALID;
+    memset(weighted, 0, 8 * sizeof(uint64_t));
+    for (u64 r = 0; r < n; ++r) {
+        u64 v[7] = {0, 0, 0, 0, 0, 0, 0};
+        fxg_text_weights_record(text, d_line, d_line + cap_lines, res, r, v);
+        for (int i = 0; i < 7; ++i) weighted[i] += v[i];
     }
     return FXG_OK;
 }

@@ -1,7 +1,7 @@
 // fxg_stub.cpp -- TEST-ONLY stand-in for libfxg.so so that the host C layer (fastx_toolkit_amd/host) can be exercised
 // on machines without a GPU.  It exports the same C-ABI, keeps "device" memory in host RAM and runs the kernels'
-// per-thread code through the serial emulator (fxg_emu.cpp).  The device text path reports every block as irregular,
-// so the tools use their host parser.  Never installed next to the product: tests put tests/emu/stub first on
+// per-thread code through the serial emulator (fxg_emu.cpp), the device text path (fxg_text.h) included, so the tools' lanes loop,
+// block cutting and sharded runs execute as on a GPU box.  Never installed next to the product: tests put tests/emu/stub first on
 // LD_LIBRARY_PATH.  The product library has no CPU path and this file is not part of it.
 #include <cstdio>
 #include <cstdlib>
@@ -15,11 +15,25 @@ extern "C" fxg_emu_hist *fxg_emu_hist_new(void);
 extern "C" int fxg_emu_run_quality_stats(const fxg_batch *in, uint64_t *hist, uint32_t hist_cols);
 extern "C" void fxg_emu_hist_free(fxg_emu_hist *h);
 
-struct fxg_ctx { char err[512]; uint64_t scratch[FXG_NCOUNTERS]; fxg_emu_hist *hist; };
+extern "C" int fxg_emu_fastq_index(void *st, const uint8_t *text, uint64_t text_len, int at_eof, int lpr, uint32_t *d_line, uint64_t cap_lines, uint16_t *d_len, uint8_t *d_flags, fxg_text_info *info);
+extern "C" int fxg_emu_fastq_pack(const uint8_t *text, uint64_t text_len, int lpr, const uint32_t *d_line, uint64_t cap_lines, const uint8_t *flags, uint64_t n, uint32_t stride, int qoffset, uint8_t *bases, uint8_t *qual, uint32_t *irregular);
+extern "C" int fxg_emu_fastq_format(const uint8_t *text, int lpr, const uint32_t *d_line, uint64_t cap_lines, const uint8_t *flags, uint64_t n, const uint32_t *res, uint32_t fwd_start, int reverse, const uint8_t *pk_bases, const uint8_t *pk_qual, const uint64_t *pk_off, const uint8_t *rows_qual, uint32_t stride, int qoffset, int out_fasta, uint8_t *out, uint64_t *out_bytes);
+extern "C" int fxg_emu_fasta_weights(const uint8_t *text, const uint32_t *d_line, uint64_t cap_lines, uint64_t n, const uint32_t *res, uint64_t weighted[8]);
+
+struct fxg_ctx { char err[512]; uint64_t scratch[FXG_NCOUNTERS]; fxg_emu_hist *hist; uint64_t text_state[16]; int device; };
 
 extern "C" {
 int fxg_abi_version(void) { return FXG_ABI_VERSION; }
-int fxg_ctx_create(int, fxg_ctx **out) { *out = (fxg_ctx *)calloc(1, sizeof(fxg_ctx)); return *out ? 0 : FXG_E_NOMEM; }
+// FXG_EMU_DEVICES (default 1) fake devices, so that FXG_DEVICES=0,1 exercises the per-device bookkeeping of the lanes
+static int emu_device_count(void) { const char *e = getenv("FXG_EMU_DEVICES"); return e && atoi(e) > 0 ? atoi(e) : 1; }
+int fxg_ctx_create(int dev, fxg_ctx **out)
+{
+    *out = nullptr;
+    if (dev < 0 || dev >= emu_device_count()) return FXG_E_HIP;
+    *out = (fxg_ctx *)calloc(1, sizeof(fxg_ctx));
+    if (*out) { (*out)->device = dev; if (const char *log = getenv("FXG_EMU_LOG")) { FILE *f = fopen(log, "a"); if (f) { fprintf(f, "ctx device %d\n", dev); fclose(f); } } }
+    return *out ? 0 : FXG_E_NOMEM;
+}
 void fxg_ctx_destroy(fxg_ctx *c) { if (c) fxg_emu_hist_free(c->hist); free(c); }
 int fxg_set_clip_history(fxg_ctx *c, int on) { fxg_emu_hist_free(c->hist); c->hist = on ? fxg_emu_hist_new() : nullptr; return 0; }
 const char *fxg_last_error(const fxg_ctx *c) { return c ? c->err : "null"; }
@@ -53,11 +67,18 @@ int fxg_read_counters(fxg_ctx *c, const uint64_t *d, uint64_t host[FXG_NCOUNTERS
     return 0;
 }
 int fxg_synth_generate(fxg_ctx *, uint64_t, uint64_t, uint64_t, uint32_t, int, uint8_t *, uint8_t *, uint32_t) { return FXG_E_INVALID; }
-int fxg_fastq_index(fxg_ctx *, const uint8_t *, uint64_t, int, int, uint32_t *, uint64_t, uint16_t *, uint8_t *, fxg_text_info *info) { memset(info, 0, sizeof *info); info->irregular = FXG_TEXT_IRR_TAIL; return 0; }
-int fxg_fastq_pack(fxg_ctx *, const uint8_t *, uint64_t, int, const uint32_t *, uint64_t, const uint8_t *, uint64_t, uint32_t, int, uint8_t *, uint8_t *, uint32_t *irr) { *irr = 1; return 0; }
-int fxg_fastq_format(fxg_ctx *, const uint8_t *, int, const uint32_t *, uint64_t, const uint8_t *, uint64_t, const uint32_t *, uint32_t, int, const uint8_t *, const uint8_t *, const uint64_t *, const uint8_t *, uint32_t, int, int, uint8_t *, uint64_t *n) { *n = 0; return FXG_E_INVALID; }
-int fxg_fasta_weights(fxg_ctx *, const uint8_t *, const uint32_t *, uint64_t, uint64_t, const uint32_t *, uint64_t *w) { memset(w, 0, 8 * sizeof(uint64_t)); return FXG_E_INVALID; }
-int fxg_device_count(void) { return 1; }
+int fxg_fastq_index(fxg_ctx *c, const uint8_t *t, uint64_t len, int eof, int lpr, uint32_t *line, uint64_t cap, uint16_t *l16, uint8_t *fl, fxg_text_info *info)
+{
+    if (getenv("FXG_EMU_NO_TEXT")) { memset(info, 0, sizeof *info); info->irregular = FXG_TEXT_IRR_TAIL; return 0; }     // every block to the host parser
+    return fxg_emu_fastq_index(c->text_state, t, len, eof, lpr, line, cap, l16, fl, info);
+}
+int fxg_fastq_pack(fxg_ctx *, const uint8_t *t, uint64_t len, int lpr, const uint32_t *line, uint64_t cap, const uint8_t *fl, uint64_t n, uint32_t stride, int qo, uint8_t *b, uint8_t *q, uint32_t *irr)
+{ return fxg_emu_fastq_pack(t, len, lpr, line, cap, fl, n, stride, qo, b, q, irr); }
+int fxg_fastq_format(fxg_ctx *, const uint8_t *t, int lpr, const uint32_t *line, uint64_t cap, const uint8_t *fl, uint64_t n, const uint32_t *res, uint32_t fs, int rev, const uint8_t *pb, const uint8_t *pq,
+                     const uint64_t *po, const uint8_t *rq, uint32_t stride, int qo, int fa, uint8_t *out, uint64_t *nb)
+{ return fxg_emu_fastq_format(t, lpr, line, cap, fl, n, res, fs, rev, pb, pq, po, rq, stride, qo, fa, out, nb); }
+int fxg_fasta_weights(fxg_ctx *, const uint8_t *t, const uint32_t *line, uint64_t cap, uint64_t n, const uint32_t *res, uint64_t *w) { return fxg_emu_fasta_weights(t, line, cap, n, res, w); }
+int fxg_device_count(void) { return emu_device_count(); }
 int fxg_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi) { *lo = n * rank / world; *hi = n * (rank + 1) / world; return 0; }
 int fxg_epilogue(const uint64_t *, uint32_t, uint32_t, uint64_t *, uint64_t *, uint64_t *) { return FXG_E_INVALID; }
 int fxg_concat_pwrite(int, const void *, uint64_t, uint64_t) { return FXG_E_INVALID; }

@@ -26,7 +26,7 @@ def build():
     defs = os.environ.get("FXG_EMU_DEFS", "").split()           # e.g. "-DFXG_V_TABLE": check a kernel variant on the CPU tier
     so = os.path.join(_EMU, "libfxgemu%s.so" % "".join(d.replace("-D", "_") for d in defs))
     csrc = os.path.join(_HERE, "..", "fastx_toolkit_amd", "csrc")
-    deps = [src] + [os.path.join(csrc, f) for f in ("fxg_device.h", "fxg_kernels.h", "fxg_plan.h")]
+    deps = [src] + [os.path.join(csrc, f) for f in ("fxg_device.h", "fxg_kernels.h", "fxg_plan.h", "fxg_text.h", "fxg_rows.h", "fxg_history.h", "fxg_stats.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["hipcc", "--cuda-host-only", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                                "-Wno-pass-failed", "-DFXG_HOST_EMULATION"] + defs + [src, "-o", so])

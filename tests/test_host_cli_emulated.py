@@ -27,7 +27,7 @@ def tools():
     os.makedirs(STUB_DIR, exist_ok=True)
     so = os.path.join(STUB_DIR, "libfxg.so")
     srcs = [os.path.join(ROOT, "tests", "emu", f) for f in ("fxg_stub.cpp", "fxg_emu.cpp")]
-    deps = srcs + [os.path.join(ROOT, "fastx_toolkit_amd", "csrc", f) for f in ("fxg_device.h", "fxg_kernels.h", "fxg_plan.h", "fxg_history.h", "fxg_stats.h")] + [os.path.join(ROOT, "include", "fxg.h")]
+    deps = srcs + [os.path.join(ROOT, "fastx_toolkit_amd", "csrc", f) for f in ("fxg_device.h", "fxg_kernels.h", "fxg_plan.h", "fxg_history.h", "fxg_stats.h", "fxg_text.h", "fxg_rows.h")] + [os.path.join(ROOT, "include", "fxg.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["hipcc", "--cuda-host-only", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-pass-failed",
                                "-DFXG_HOST_EMULATION"] + srcs + ["-o", so])
@@ -190,22 +190,103 @@ def test_reader_rules_through_the_batch_path(tools):
                 argvs += [["fastq_quality_trimmer", "-t", "18", "-l", "8", "-v"], ["fastq_quality_filter", "-q", "15", "-p", "60", "-v"],
                           ["fastq_masker", "-q", "12"], ["fastq_to_fasta", "-r"], ["fastx_quality_stats"]]
             for argv in argvs:
-                rc, out, err = _run([os.path.join(tools, argv[0])] + argv[1:], data, threads=str([3, 1, 8][trial % 3]), buf_mb="1" if trial % 2 else None)
-                rrc, rout, rerr = _run([REF] + argv, data)
-                assert (rc, out) == (rrc, rout), (trial, kind, argv, err[-200:], rerr[-200:])
-                assert _msg(err) == _msg(rerr), (trial, kind, argv)
+                # the device text path (fxg_text.h's per-thread bodies through the emulator), and the host parser on the same input
+                for no_text in (False, True):
+                    rc, out, err = _run([os.path.join(tools, argv[0])] + argv[1:], data, threads=str([3, 1, 8][trial % 3]), buf_mb="1" if trial % 2 else None,
+                                        extra_env={"FXH_TIMING": "1", **({"FXG_EMU_NO_TEXT": "1"} if no_text else {})})
+                    rrc, rout, rerr = _run([REF] + argv, data)
+                    assert (rc, out) == (rrc, rout), (trial, kind, argv, no_text, err[-200:], rerr[-200:])
+                    err = b"".join(l for l in err.splitlines(True) if not l.startswith(b"fxh timing"))
+                    assert _msg(err) == _msg(rerr), (trial, kind, argv, no_text)
+
+
+def test_device_text_path_takes_crlf_numeric_and_fasta_without_the_host_parser(tools):
+    """CPU-tier twin of the GPU test: CRLF, missing final newline, numeric quality lines, FASTA with collapsed ids are indexed, packed
+    and formatted by the device code (here: its per-thread bodies, run serially) -- no block may fall back to the host parser."""
+    rng = np.random.default_rng(79)
+    for kind, data in _odd_inputs(rng).items():
+        fasta = kind.startswith("fasta")
+        argvs = [["fastx_trimmer", "-f", "3", "-l", "20"], ["fastx_reverse_complement"], ["fastx_artifacts_filter", "-v"]]
+        if not fasta:
+            argvs += [["fastq_quality_trimmer", "-t", "18", "-l", "8", "-v"], ["fastq_masker", "-q", "12"], ["fastq_to_fasta"]]
+        for argv in argvs:
+            rc, out, err = _run([os.path.join(tools, argv[0])] + argv[1:], data, buf_mb="1", extra_env={"FXH_TIMING": "1"})
+            assert rc == 0 and b"device parse" in err and b" 0 host-parsed blocks" in err, (kind, argv, err[-300:])
+            if REF:
+                assert out == _run([REF] + argv, data)[1], (kind, argv)
+
+
+def test_sharded_run_parts_concatenate_to_the_single_stream_output(tools, tmp_path):
+    """FXH_PARTS=k: k byte ranges of the input cut at record boundaries, k runs side by side (own reader threads, lanes and writer), k
+    output parts.  cat(parts) must be the unsharded output, the -v report the same, the index consistent; with two fake devices the
+    parts go to different GPUs.  Irregular input anywhere makes the process start over unsharded: messages, exit code and partial
+    output are those of the single stream."""
+    text = fo.synth_fastq(47, 0, 90000, 100, False)                     # ~20 MB
+    inp = tmp_path / "in.fq"
+    inp.write_bytes(text)
+    argv = ["fastq_quality_trim_filter", "-t", "20", "-l", "30", "-q", "20", "-p", "80", "-v"]
+    single = tmp_path / "single.fq"
+    want = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", str(single)], b"", buf_mb="1")
+    assert want[0] == 0 and single.stat().st_size > 5_000_000
+    for k, name in ((2, "p.%r.fq"), (3, "q.fq"), (5, "r.%r")):
+        pat = str(tmp_path / name)
+        log = tmp_path / ("ctx%d.log" % k)
+        got = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", pat], b"", buf_mb="1",
+                   extra_env={"FXH_PARTS": str(k), "FXH_TIMING": "1", "FXG_EMU_DEVICES": "2", "FXG_DEVICES": "0,1", "FXG_EMU_LOG": str(log)})
+        assert got[0] == 0 and got[1] == want[1], (k, got[2][-300:])               # the report (stdout with -o) is the single run's
+        assert got[2].count(b"fxh timing part") == k and b" 0 host-parsed blocks" in got[2]
+        parts = [pat.replace("%r", str(r)) if "%r" in pat else (pat if r == 0 else "%s.%d" % (pat, r)) for r in range(k)]
+        assert b"".join(open(f, "rb").read() for f in parts) == single.read_bytes(), k
+        ix = open(pat.replace("%r", "parts") if "%r" in pat else pat + ".parts").read().splitlines()[1:]
+        assert len(ix) == k and sum(int(l.split("\t")[2]) for l in ix) == len(text) and sum(int(l.split("\t")[3]) for l in ix) == 90000
+        assert [int(l.split("\t")[5]) for l in ix] == [os.path.getsize(f) for f in parts]
+        devs = [int(l.split()[-1]) for l in open(log).read().splitlines()]
+        assert set(devs) == {0, 1}, devs                                           # part r runs on GPU r mod 2
+    # irregular input: a damaged record inside the third of four parts, a ragged end, a FASTA/FASTQ mix-up -> the single-stream behaviour
+    k0 = text.index(b"\n@", int(len(text) * 0.6)) + 1
+    for bad in (text[:k0] + b"#" + text[k0 + 1:], text[:-200], text[:k0] + b"@x\nACGT\n+\nII\n" + text[k0:]):
+        inp.write_bytes(bad)
+        ref_out = tmp_path / "bad_single.fq"
+        w = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", str(ref_out)], b"", buf_mb="1")
+        pat = str(tmp_path / "bad.%r.fq")
+        g = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", pat], b"", buf_mb="1", extra_env={"FXH_PARTS": "4"})
+        assert w[0] == 1 and (g[0], g[1]) == (w[0], w[1]) and _msg(g[2]) == _msg(w[2]), (g[2][-300:], w[2][-300:])
+        assert b"".join(open(pat.replace("%r", str(r)), "rb").read() for r in range(4)) == ref_out.read_bytes()
+    # quality lines that start with '@' right where a cut is looked for: the pattern may pick a wrong line, the line count finds out
+    recs = [b"@r%d\nACGTACGTACGTACGTACGT\n+\n@IIIIIIIIIIIIIIIIIII\n" % i for i in range(200000)]
+    tricky = b"".join(recs)
+    inp.write_bytes(tricky)
+    w = _run([os.path.join(tools, "fastq_quality_trimmer"), "-t", "20", "-l", "5", "-i", str(inp), "-o", str(tmp_path / "t_single.fq")], b"", buf_mb="1")
+    g = _run([os.path.join(tools, "fastq_quality_trimmer"), "-t", "20", "-l", "5", "-i", str(inp), "-o", str(tmp_path / "t.%r.fq")], b"", buf_mb="1", extra_env={"FXH_PARTS": "3", "FXH_TIMING": "1"})
+    assert w[0] == 0 and g[0] == 0 and g[2].count(b"fxh timing part") == 3
+    assert b"".join(open(str(tmp_path / ("t.%d.fq" % r)), "rb").read() for r in range(3)) == (tmp_path / "t_single.fq").read_bytes()
+    # an input too small to shard (and a pipe): one stream, the other parts exist and are empty
+    small = fo.synth_fastq(48, 0, 500, 100, False)
+    inp.write_bytes(small)
+    g = _run([os.path.join(tools, "fastq_quality_trimmer"), "-t", "20", "-l", "5", "-i", str(inp), "-o", str(tmp_path / "s.%r.fq")], b"", extra_env={"FXH_PARTS": "3"})
+    assert g[0] == 0 and os.path.getsize(str(tmp_path / "s.0.fq")) > 0 and os.path.getsize(str(tmp_path / "s.1.fq")) == 0 and os.path.getsize(str(tmp_path / "s.2.fq")) == 0
+    g = _run([os.path.join(tools, "fastq_quality_trimmer"), "-t", "20", "-l", "5", "-o", str(tmp_path / "pipe.fq")], small, extra_env={"FXH_PARTS": "2"})
+    assert g[0] == 0 and (tmp_path / "pipe.fq").read_bytes() == (tmp_path / "s.0.fq").read_bytes() and os.path.getsize(str(tmp_path / "pipe.fq.1")) == 0
+    # FASTA in, sharded
+    fa = b"".join(b">%d-%d\n%s\n" % (i, 1 + i % 7, b"ACGTTGCANN"[: 4 + i % 7] * 3) for i in range(200000))
+    inp.write_bytes(fa)
+    w = _run([os.path.join(tools, "fastx_reverse_complement"), "-v", "-i", str(inp), "-o", str(tmp_path / "fa_single.fa")], b"", buf_mb="1")
+    g = _run([os.path.join(tools, "fastx_reverse_complement"), "-v", "-i", str(inp), "-o", str(tmp_path / "fa.%r.fa")], b"", buf_mb="1", extra_env={"FXH_PARTS": "4"})
+    assert w[0] == 0 and (g[0], g[1]) == (w[0], w[1])
+    assert b"".join(open(str(tmp_path / ("fa.%d.fa" % r)), "rb").read() for r in range(4)) == (tmp_path / "fa_single.fa").read_bytes()
 
 
 def test_lanes_many_blocks_any_lane_count_same_bytes(tools):
     """The lanes loop of the tools (blocks cut at record boundaries on the host, dealt round-robin to lanes over FXG_DEVICES, collected
-    in input order): output, report and error behaviour must not depend on the number of lanes, devices or on the block size.  (With the
-    stub every block comes back "irregular", so this drives the ordering, the buffer ring and the host-parser hand-back; the GPU tier
-    runs the same matrix against the real engine.)"""
+    in input order): output, report and error behaviour must not depend on the number of lanes, devices or on the block size -- through
+    the emulated device text path, through the host parser (FXH_HOST_PARSE) and with every block handed back to it (FXG_EMU_NO_TEXT);
+    the GPU tier runs the same matrix against the real engine."""
     text = fo.synth_fastq(41, 0, 30000, 100, False)                     # ~7 MB: seven blocks of 1 MB
     argv = ["fastq_quality_trimmer", "-t", "20", "-l", "30", "-v"]
     base = _run([os.path.join(tools, argv[0])] + argv[1:], text)
     assert base[0] == 0
-    for env in ({"FXH_LANES": "1"}, {"FXH_LANES": "3"}, {"FXG_DEVICES": "0,0,0", "FXH_LANES": "2"}, {"FXH_NO_OVERLAP": "1"}, {"FXH_HOST_PARSE": "1"}):
+    for env in ({"FXH_LANES": "1"}, {"FXH_LANES": "3"}, {"FXG_DEVICES": "0,0,0", "FXH_LANES": "2"}, {"FXH_NO_OVERLAP": "1"}, {"FXH_HOST_PARSE": "1"},
+                {"FXG_EMU_NO_TEXT": "1", "FXH_LANES": "3"}, {"FXG_EMU_DEVICES": "3", "FXG_DEVICES": "0,2,1", "FXH_LANES": "2"}):
         for buf in ("1", "2", None):
             assert _run([os.path.join(tools, argv[0])] + argv[1:], text, buf_mb=buf, extra_env=env) == base, (env, buf)
     # a damaged record in the fifth megabyte: everything before it is written, then the reference's message and exit 1
