@@ -369,6 +369,7 @@ typedef struct {
     size_t newlines;                   /* '\n' bytes among the `filled` bytes */
     int state;                         /* 0 idle, 1 requested, 2 done, 3 quit */
     int regular, io_threads;           /* regular file: parallel pread() from `offset` on */
+    size_t io_slice;                   /* smallest piece worth a thread of its own */
     off_t offset, limit;               /* limit > 0: the input ends at this file offset (a part of a sharded run) */
 } fxh_prefetch;
 
@@ -402,10 +403,12 @@ static void *fxh_pread_main(void *arg)
     return NULL;
 }
 
+static int g_parts_mode;               /* a sharded run is under way (fxh_run_parts): smaller blocks and fewer helper threads per part */
+
 static int fxh_io_threads(void)
 {
     const char *e = getenv("FXH_IO_THREADS");
-    long n = e ? atol(e) : 8, ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    long n = e ? atol(e) : (g_parts_mode ? 4 : 8), ncpu = sysconf(_SC_NPROCESSORS_ONLN);
     if (n < 1) n = 1;
     if (n > 16) n = 16;
     if (ncpu > 0 && n > ncpu) n = ncpu;
@@ -432,7 +435,7 @@ static void *fxh_prefetch_main(void *arg)
             if (want == 0) { eof = 1; newlines = 0; }
             else {
                 int nt = pf->io_threads;
-                if ((size_t)nt > want / ((size_t)4 << 20)) nt = (int)(want / ((size_t)4 << 20));
+                if ((size_t)nt > want / pf->io_slice) nt = (int)(want / pf->io_slice);
                 if (nt < 1) nt = 1;
                 pthread_t th[16];
                 fxh_pread_job job[16];
@@ -476,6 +479,7 @@ static void fxh_prefetch_probe(fxh_prefetch *pf, int fd)
     pf->regular = (pos >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) ? 1 : 0;
     pf->offset = pos;
     pf->io_threads = fxh_io_threads();
+    { const char *e = getenv("FXH_IO_SLICE_MB"); const long v = e ? atol(e) : 0; pf->io_slice = (size_t)(v >= 1 && v <= 1024 ? v : (g_parts_mode ? 2 : 4)) << 20; }
 }
 
 static void fxh_prefetch_request(fxh_prefetch *pf, char *buf, size_t cap)
@@ -1304,7 +1308,9 @@ static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_sta
     if (nparts > 1 && ndev > 1) { dev[0] = dev[part % ndev]; ndev = 1; }      /* a part of a sharded run stays on one GPU */
     R.st_device = dev[0];
     struct fxh_reader *rd = fx->reader;
-    if (!getenv("FXH_READ_BUFFER_MB")) fxh_reader_reserve(rd, (size_t)64 << 20);   /* one engine call per 64 MB of text */
+    /* one engine call per 64 MB of text; the parts of a sharded run take 8 MB blocks (four parts x two lanes keep the link busy with
+     * less to allocate, page-lock and touch first: 52 -> 62 Mreads/s on the 64 M read sample, profiles/r03/p_e2e_parts_block_size.txt) */
+    if (!getenv("FXH_READ_BUFFER_MB")) fxh_reader_reserve(rd, (size_t)(nparts > 1 ? 8 : 64) << 20);
     fxh_job *job = &R.job;
     job->fx = fx; job->st = &R.st; job->p = p;
     job->revcomp = (p->stages & (FXG_STAGE_REVCOMP | FXG_STAGE_MASK)) != 0;   /* stages whose output is not a slice of the input text */
@@ -1313,7 +1319,7 @@ static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_sta
     job->fwd_start = (p->stages & FXG_STAGE_FTRIM) && p->ft_first > 1 ? (uint32_t)p->ft_first - 1u : 0u;
     {
         const char *te = getenv("FXH_THREADS");
-        long nt = te ? atol(te) : 16, ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+        long nt = te ? atol(te) : (nparts > 1 ? 4 : 16), ncpu = sysconf(_SC_NPROCESSORS_ONLN);
         if (nt < 1) nt = 1;
         if (nt > 64) nt = 64;
         if (ncpu > 0 && nt > ncpu) nt = ncpu;
@@ -1485,6 +1491,7 @@ static int fxh_run_parts(FASTX *fx, const fxg_params *p, fxh_totals *tot, int k)
         pt[r].fx = f;
     }
     g_parts_abort = 0;
+    g_parts_mode = 1;
     for (int r = 1; r < k; ++r) if (pthread_create(&pt[r].th, NULL, fxh_part_main, &pt[r]) != 0) err(1, "pthread_create");
     fxh_part_main(&pt[0]);
     for (int r = 1; r < k; ++r) pthread_join(pt[r].th, NULL);

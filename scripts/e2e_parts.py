@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 from oracle import fxoracle_py as fo  # noqa: E402
 
 reads = int(os.environ.get("READS", "16000000"))
-matrix = [tuple(int(x) for x in m.split(":")) for m in os.environ.get("MATRIX", "1:2,2:2,4:2,4:1,8:1").split(",")]
+matrix = [tuple(m.split(":")) for m in os.environ.get("MATRIX", "1:2,2:2,4:2,4:1,8:1").split(",")]     # parts:lanes[:ENV=VAL[:ENV=VAL]]
 tool = os.path.join(ROOT, "fastx_toolkit_amd", "host", "bin", "fastq_quality_trim_filter")
 chunk = 250_000
 with tempfile.TemporaryDirectory(dir="/dev/shm") as td:
@@ -26,8 +26,11 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as td:
                 f.write(part)
     print("input: %d reads, %.2f GB, generated in %.1f s" % (reads, os.path.getsize(inp) / 1e9, time.perf_counter() - t0), flush=True)
     ref_md5 = None
-    for parts, lanes in matrix:
+    for item in matrix:
+        parts, lanes = int(item[0]), int(item[1])
         env = dict(os.environ, FXH_LANES=str(lanes), FXH_TIMING="1")
+        for kv in item[2:]:
+            env[kv.split("=")[0]] = kv.split("=")[1]
         if parts > 1:
             env["FXH_PARTS"] = str(parts)
         pat = os.path.join(td, "out.%r.fq") if parts > 1 else os.path.join(td, "out.fq")
@@ -50,8 +53,8 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as td:
                     h.update(blk); nbytes += len(blk)
         if ref_md5 is None:
             ref_md5 = h.hexdigest()
-        print("parts %d lanes/part %d: wall %.3f s  %.1f Mreads/s  %.2f Gbases/s  out %.2f GB  md5 %s %s" % (
-            parts, lanes, best, reads / best / 1e6, reads * 150 / best / 1e9, nbytes / 1e9, h.hexdigest(), "== single" if h.hexdigest() == ref_md5 else "DIFFERS"), flush=True)
+        print("parts %d lanes/part %d %s: wall %.3f s  %.1f Mreads/s  %.2f Gbases/s  out %.2f GB  md5 %s %s" % (
+            parts, lanes, " ".join(item[2:]), best, reads / best / 1e6, reads * 150 / best / 1e9, nbytes / 1e9, h.hexdigest(), "== single" if h.hexdigest() == ref_md5 else "DIFFERS"), flush=True)
         for l in errtxt.decode(errors="replace").splitlines():
             if l.startswith("fxh timing"):
                 print("    " + l[:330], flush=True)
