@@ -662,7 +662,9 @@ static void fxh_awriter_submit_ext(fxh_awriter *aw, struct fxh_writer *w, const 
 #ifndef FXH_MAX_LANES
 #define FXH_MAX_LANES 32
 #endif
-static volatile int g_parts_abort;         /* sharded run: some part met input it does not handle (fxh_run_parts) */
+static int g_parts_abort;                  /* sharded run: some part met input it does not handle (fxh_run_parts); relaxed atomics, it is only a "stop soon" */
+#define FXH_ABORT_SET() __atomic_store_n(&g_parts_abort, 1, __ATOMIC_RELAXED)
+#define FXH_ABORTED()   __atomic_load_n(&g_parts_abort, __ATOMIC_RELAXED)
 static pthread_mutex_t g_first_ctx_mu = PTHREAD_MUTEX_INITIALIZER;   /* the HIP runtime's first-use initialisation: one thread at a time */
 static int g_first_ctx_done;
 struct fxh_pinned { pthread_mutex_t mu; const void *ptr[FXH_MAX_LANES + 4]; int n; };
@@ -1157,7 +1159,7 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
     int input_done = 0, have_carry = 0;
     unsigned long long carry_lines = 0;
 
-    while (!R->have_err && !R->aborted && !(R->nparts > 1 && g_parts_abort)) {
+    while (!R->have_err && !R->aborted && !(R->nparts > 1 && FXH_ABORTED())) {
         /* ---- collect finished blocks in input order until a lane and an input buffer are free ---- */
         while (next_emit < nblocks && (nblocks - next_emit >= (size_t)nlanes || input_done)) {
             fxh_block *b = &blk[next_emit % (size_t)NB];
@@ -1177,7 +1179,7 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
                 }
             }
             if (!handled && R->nparts > 1) {   /* a part of a sharded run only takes what the device path takes: the whole run starts over unsharded */
-                R->aborted = 1; g_parts_abort = 1;
+                R->aborted = 1; FXH_ABORT_SET();
                 break;
             }
             if (!handled) {                /* this block goes through the host parser, at its place in the output order */
@@ -1370,8 +1372,8 @@ static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_sta
     }
     fxh_awriter_stop(&R.aw);
     fxh_prefetch_stop(&pf);
-    if (nparts > 1 && (R.aborted || R.have_err || g_parts_abort)) {      /* fxh_run_parts starts the whole job over, unsharded */
-        g_parts_abort = 1;
+    if (nparts > 1 && (R.aborted || R.have_err || FXH_ABORTED())) {      /* fxh_run_parts starts the whole job over, unsharded */
+        FXH_ABORT_SET();
         for (int i = 0; i < job->nworkers; ++i) { free(job->w[i].rec); free(job->w[i].shadow); }
         free(job->w);
         return 2;
@@ -1490,12 +1492,12 @@ static int fxh_run_parts(FASTX *fx, const fxg_params *p, fxh_totals *tot, int k)
         f->input_line_number = 0; f->num_input_sequences = f->num_input_reads = f->num_output_sequences = f->num_output_reads = 0;
         pt[r].fx = f;
     }
-    g_parts_abort = 0;
+    __atomic_store_n(&g_parts_abort, 0, __ATOMIC_RELAXED);
     g_parts_mode = 1;
     for (int r = 1; r < k; ++r) if (pthread_create(&pt[r].th, NULL, fxh_part_main, &pt[r]) != 0) err(1, "pthread_create");
     fxh_part_main(&pt[0]);
     for (int r = 1; r < k; ++r) pthread_join(pt[r].th, NULL);
-    int bad = g_parts_abort;
+    int bad = FXH_ABORTED();
     for (int r = 0; r < k; ++r) if (pt[r].rc != 0) bad = 1;
     if (bad) {
         /* Irregular input somewhere (or a cut that was no record boundary): the reference's behaviour -- message, exit code, what
