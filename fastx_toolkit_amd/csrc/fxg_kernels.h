@@ -12,7 +12,8 @@
 //                         published totals into prefixes in tile order; it has had a whole stage A to do so
 //                      5. order-preserving gather of the kept prefixes into the packed output, one 16 B
 //                         aligned output chunk per lane                    [HBM read <= 2L, write 2*new_len / kept read]
-// The -v report counters are not kept in this kernel: a second tiny pass reduces res[] (4 B/read).
+// The -v report counters are tallied here as the result words go by (fxg_tile_tally: a ballot per drop reason, one LDS add per wave);
+// fxg_kernel_finish_counters lays them out.  The clip instances write out two steps behind (three slots) where LDS allows.
 #pragma once
 #include "fxg_device.h"
 

@@ -23,7 +23,7 @@
 
 #define FXG_ROWS_T 64u                  // reads per tile = lanes per wave
 #ifndef FXG_ROWS_LB
-#define FXG_ROWS_LB 3                   // waves per SIMD: two tiles' quality rows live in registers (fxg_kernel_rows), up to 168 VGPRs
+#define FXG_ROWS_LB 3                   // waves per SIMD (__launch_bounds__): two tiles' quality rows live in registers; the kernel uses 138 VGPRs of the 168 this allows
 #endif
 #ifndef FXG_ROWS_SCAN_K
 #define FXG_ROWS_SCAN_K 8               // tiles per scanner batch / 64 (fxg_scanner_multi)

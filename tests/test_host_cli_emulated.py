@@ -116,6 +116,8 @@ def test_flag_errors_and_usage(tools):
         rrc, rout, rerr = _run([REF] + argv, data)
         assert rc == 1 and (rc, out) == (rrc, rout), argv
         assert _msg(err) == _msg(rerr), (argv, err, rerr)
+    rc, out, err = _run([os.path.join(tools, "fastx_clipper"), "-a", "ACGT", "-D"], b"@r\nA\n+\nI\n")   # a documented divergence: no silent no-op
+    assert rc == 1 and out == b"" and b"[-D]" in err
     assert _run([os.path.join(tools, "fastq_quality_trimmer")], b"@r\nA\n+\nI\n")[0] == 1          # missing -t
     assert _run([os.path.join(tools, "fastq_quality_filter"), "-p", "0"], b"")[0] == 1
     assert _run([os.path.join(tools, "fastx_trimmer"), "-f", "2", "-t", "3"], b"@r\nA\n+\nI\n")[0] == 1
