@@ -289,6 +289,70 @@ def e2e_leg(reads=16_000_000, big_reads=64_000_000, parts=4, lanes=2):
         return out
 
 
+def e2e_ranks(config, rank, local, world, reads_per_rank, dist, device):
+    """--e2e: the config's command line end to end, one process per GPU as in the kernel-level run: every rank generates ITS shard of
+    the synthetic set as FASTQ text on tmpfs, runs the tools of the config on its GPU (FXG_DEVICE = local rank; pipes where the
+    reference uses pipes), file to file; barrier on both sides, the slowest rank's wall time counts.  Weak scaling, like the kernel line."""
+    import torch
+    cfg = CONFIGS[config]
+    bindir = os.path.join(ROOT, "fastx_toolkit_amd", "host", "bin")
+    ad = ADAPTER.decode()
+    tf = ["fastq_quality_trim_filter", "-t", "20", "-l", "30", "-q", "20", "-p", "80"]
+    chain = {"cfg2": [tf], "cfg3": [["fastx_clipper", "-a", ad, "-l", "15", "-n"]],
+             "cfg4": [["fastx_reverse_complement"], ["fastx_trimmer", "-f", "5", "-l", "145"]],
+             "cfg5shard": [["fastx_clipper", "-a", ad, "-l", "15", "-n"], tf]}[config]
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import fxoracle_py as fo
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+        inp, outp = os.path.join(td, "in.fq"), os.path.join(td, "out.fq")
+        chunk = 250_000
+        first = rank * reads_per_rank
+        with open(inp, "wb") as f:
+            with ThreadPoolExecutor(max_workers=max(2, min(32, (os.cpu_count() or 2) // max(1, world)))) as ex:
+                for part in ex.map(lambda k: fo.synth_fastq(cfg["seed"], first + k * chunk, chunk, cfg["L"], cfg["adapter"]), range(reads_per_rank // chunk)):
+                    f.write(part)
+        env = dict(os.environ, FXG_DEVICE=str(local), FXH_CLIP_PARALLEL="1")     # fixed-length shard: the clipper needs no history (SURVEY N3)
+        env.pop("FXG_DEVICES", None)
+
+        def once():
+            if os.path.exists(outp):
+                os.unlink(outp)
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            procs, prev = [], None
+            for i, st in enumerate(chain):
+                cmd = [os.path.join(bindir, st[0])] + st[1:] + (["-i", inp] if i == 0 else []) + (["-o", outp] if i + 1 == len(chain) else [])
+                p = subprocess.Popen(cmd, env=env, stdin=prev.stdout if prev else None, stdout=subprocess.PIPE if i + 1 < len(chain) else None)
+                if prev:
+                    prev.stdout.close()
+                procs.append(p)
+                prev = p
+            ok = all(p.wait() == 0 for p in procs)
+            dt = time.perf_counter() - t0
+            t = torch.tensor([dt, 0.0 if ok else 1.0], dtype=torch.float64, device=device if (world > 1 and dist.get_backend() == "nccl") else "cpu")
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t[0]), float(t[1]) == 0.0
+        best = None
+        for _ in range(2):
+            dt, ok = once()
+            if not ok:
+                return {"error": "a tool of the chain failed"}
+            best = dt if best is None else min(best, dt)
+        recs = 0
+        with open(outp, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 24), b""):
+                recs += blk.count(b"\n")
+        t = torch.tensor([recs // 4, os.path.getsize(outp)], dtype=torch.int64, device=device if (world > 1 and dist.get_backend() == "nccl") else "cpu")
+        if world > 1:
+            dist.all_reduce(t)
+        total = reads_per_rank * world
+        return dict(command=" | ".join(" ".join(st) for st in chain), reads_per_rank=reads_per_rank, ranks=world, wall_s=round(best, 3),
+                    mreads_s=round(total / best / 1e6, 2), gbases_s=round(total * cfg["L"] / best / 1e9, 3), kept_reads=int(t[0]), output_bytes=int(t[1]),
+                    note="one tool chain per GPU on its own shard of the input (FASTQ text on tmpfs in and out), barrier to barrier, slowest rank; best of two")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -298,6 +362,8 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the configuration's size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--e2e", action="store_true", help="also time the config's command line end to end, one tool chain per GPU (weak scaling; any --gpus)")
+    ap.add_argument("--e2e-reads", type=int, default=8_000_000, help="reads per rank of the --e2e leg")
     ap.add_argument("--decision-only", action="store_true", help="no compaction: 154 B/read variant (not the headline)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -411,6 +477,12 @@ def main():
         except Exception:
             traffic = None
 
+    e2e_r = None
+    if args.e2e and not is_stats:
+        try:
+            e2e_r = e2e_ranks(args.config, rank, local, world, args.e2e_reads, dist, eng.device)
+        except Exception as e:
+            e2e_r = {"error": repr(e)[:200]}
     if rank == 0:
         total_reads = R * world * args.steps
         out = {
@@ -458,6 +530,8 @@ def main():
             }
         if self_check is not None:
             out["self_check"] = self_check
+        if e2e_r is not None:
+            out["e2e_ranks"] = e2e_r
         if world == 1 and not args.no_cpu_baseline and not is_stats:
             out["cpu_baseline"] = cpu_baseline(args.config)
         if world == 1 and not args.no_e2e and args.config == "cfg2":

@@ -1,6 +1,8 @@
 // fxg_engine.hip -- host side of the C-ABI declared in include/fxg.h (gfx950 only).
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <fcntl.h>
 #include <cerrno>
 #include <cstdarg>
 #include <cstdio>
@@ -750,6 +752,90 @@ extern "C" int fxg_concat_pwrite(int fd, const void *host_buf, uint64_t bytes, u
         p += k; offset += (uint64_t)k; bytes -= (uint64_t)k;
     }
     return FXG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RCCL transport of the counter blocks (one process per GPU, C hosts).  librccl.so is opened at run time.
+// ------------------------------------------------------------------------------------------------
+typedef struct { char internal[128]; } fxg_nccl_id;          // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
+struct fxg_comm {
+    void *lib, *comm;
+    uint32_t rank, world;
+    u64 *d_gather;                                            // world * FXG_NCOUNTERS
+    int (*get_id)(fxg_nccl_id *);
+    int (*init_rank)(void **, int, fxg_nccl_id, int);
+    int (*all_gather)(const void *, void *, size_t, int, void *, hipStream_t);
+    int (*destroy)(void *);
+    const char *(*err_string)(int);
+};
+
+extern "C" void fxg_comm_destroy(fxg_comm *m)
+{
+    if (!m) return;
+    if (m->comm && m->destroy) (void)m->destroy(m->comm);
+    (void)hipFree(m->d_gather);
+    if (m->lib) dlclose(m->lib);
+    free(m);
+}
+
+extern "C" int fxg_comm_create(fxg_ctx *c, const char *file, uint32_t rank, uint32_t world, int timeout_s, fxg_comm **out)
+{
+    if (!c || !file || !out || world == 0 || rank >= world) return FXG_E_INVALID;
+    *out = nullptr;
+    fxg_comm *m = (fxg_comm *)calloc(1, sizeof(fxg_comm));
+    if (!m) return FXG_E_NOMEM;
+    m->rank = rank; m->world = world;
+    m->lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!m->lib) m->lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!m->lib) { free(m); return fxg_fail(c, FXG_E_HIP, "RCCL is not installed (dlopen librccl.so: %s)", dlerror()); }
+    m->get_id = (int (*)(fxg_nccl_id *))dlsym(m->lib, "ncclGetUniqueId");
+    m->init_rank = (int (*)(void **, int, fxg_nccl_id, int))dlsym(m->lib, "ncclCommInitRank");
+    m->all_gather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(m->lib, "ncclAllGather");
+    m->destroy = (int (*)(void *))dlsym(m->lib, "ncclCommDestroy");
+    m->err_string = (const char *(*)(int))dlsym(m->lib, "ncclGetErrorString");
+    if (!m->get_id || !m->init_rank || !m->all_gather || !m->destroy) { fxg_comm_destroy(m); return fxg_fail(c, FXG_E_HIP, "librccl.so lacks the NCCL entry points"); }
+    fxg_nccl_id id;
+    memset(&id, 0, sizeof id);
+    if (rank == 0) {                                          // publish the id atomically: write a temporary, rename it into place
+        const int rc = m->get_id(&id);
+        if (rc != 0) { fxg_comm_destroy(m); return fxg_fail(c, FXG_E_HIP, "ncclGetUniqueId: %s", m->err_string ? m->err_string(rc) : "error"); }
+        char tmp[4096];
+        snprintf(tmp, sizeof tmp, "%s.tmp.%d", file, (int)getpid());
+        const int fd = open(tmp, O_CREAT | O_WRONLY | O_TRUNC, 0600);
+        if (fd < 0 || write(fd, &id, sizeof id) != (ssize_t)sizeof id || close(fd) != 0 || rename(tmp, file) != 0) { fxg_comm_destroy(m); return fxg_fail(c, FXG_E_INVALID, "cannot write the rendezvous file %s: %s", file, strerror(errno)); }
+    } else {
+        bool got = false;
+        for (int tries = 0; tries < (timeout_s > 0 ? timeout_s : 60) * 20 && !got; ++tries) {
+            const int fd = open(file, O_RDONLY);
+            if (fd >= 0) { got = read(fd, &id, sizeof id) == (ssize_t)sizeof id; close(fd); }
+            if (!got) usleep(50000);
+        }
+        if (!got) { fxg_comm_destroy(m); return fxg_fail(c, FXG_E_INVALID, "rank %u: no RCCL id in %s after %d s", rank, file, timeout_s > 0 ? timeout_s : 60); }
+    }
+    if (hipSetDevice(c->device) != hipSuccess || hipMalloc((void **)&m->d_gather, (size_t)world * FXG_NCOUNTERS * sizeof(u64)) != hipSuccess) { fxg_comm_destroy(m); return fxg_fail(c, FXG_E_HIP, "hipMalloc of the gather buffer failed"); }
+    const int rc = m->init_rank(&m->comm, (int)world, id, (int)rank);
+    if (rc != 0) { m->comm = nullptr; fxg_comm_destroy(m); return fxg_fail(c, FXG_E_HIP, "ncclCommInitRank(rank %u of %u): %s", rank, world, m->err_string ? m->err_string(rc) : "error"); }
+    *out = m;
+    return FXG_OK;
+}
+
+extern "C" int fxg_epilogue_rccl(fxg_ctx *c, fxg_comm *m, const uint64_t *d_counters, uint64_t totals[FXG_NCOUNTERS], uint64_t *read_off,
+                                 uint64_t *byte_off, uint64_t *gathered)
+{
+    if (!c || !m || !m->comm) return FXG_E_INVALID;
+    FXG_HIP(c, hipSetDevice(c->device));
+    const u64 *src = d_counters ? (const u64 *)d_counters : c->counters_scratch;
+    const int rc = m->all_gather(src, m->d_gather, FXG_NCOUNTERS, 5 /* ncclUint64 */, m->comm, c->stream);     // behind the pass on the same stream
+    if (rc != 0) return fxg_fail(c, FXG_E_HIP, "ncclAllGather: %s", m->err_string ? m->err_string(rc) : "error");
+    u64 *host = (u64 *)malloc((size_t)m->world * FXG_NCOUNTERS * sizeof(u64));
+    if (!host) return FXG_E_NOMEM;
+    hipError_t e = hipMemcpyAsync(host, m->d_gather, (size_t)m->world * FXG_NCOUNTERS * sizeof(u64), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { free(host); return fxg_fail(c, FXG_E_HIP, "copying the gathered counters failed: %s", hipGetErrorString(e)); }
+    const int erc = fxg_epilogue((const uint64_t *)host, m->world, m->rank, totals, read_off, byte_off);
+    if (gathered) memcpy(gathered, host, (size_t)m->world * FXG_NCOUNTERS * sizeof(u64));
+    free(host);
+    return erc;
 }
 
 extern "C" int fxg_set_profiling(fxg_ctx *c, int enabled)

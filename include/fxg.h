@@ -298,6 +298,21 @@ int  fxg_epilogue(const uint64_t *gathered, uint32_t world, uint32_t rank, uint6
  * (pwrite until done; shards may write concurrently, in any order). */
 int  fxg_concat_pwrite(int fd, const void *host_buf, uint64_t bytes, uint64_t offset);
 
+/* The exchange itself for a C host, one process per GPU: the counter blocks travel by ONE RCCL all-gather (192 bytes per rank, over
+ * xGMI inside a node) -- SURVEY 8e's ncclAllReduce + ncclAllGather folded into one collective, since the gathered blocks give both the
+ * totals and the offsets.  librccl.so is opened at run time (dlopen), so a single-GPU installation needs no RCCL.
+ *   fxg_comm_create : ranks meet through `rendezvous_file` (a path all of them can reach): rank 0 writes the RCCL unique id there,
+ *                     the others wait up to timeout_s seconds for it; every rank then joins the communicator of `world` ranks on its
+ *                     context's device.  The file may be removed once every rank has returned.
+ *   fxg_epilogue_rccl : d_counters = this rank's counter block on the device (fxg_out.counters of the pass just enqueued; NULL = the
+ *                     context's own).  Enqueues the all-gather on the context's stream behind the pass, waits for it, and applies
+ *                     fxg_epilogue.  gathered (optional, world * FXG_NCOUNTERS values) receives the blocks in rank order. */
+typedef struct fxg_comm fxg_comm;
+int  fxg_comm_create(fxg_ctx *ctx, const char *rendezvous_file, uint32_t rank, uint32_t world, int timeout_s, fxg_comm **comm);
+void fxg_comm_destroy(fxg_comm *comm);
+int  fxg_epilogue_rccl(fxg_ctx *ctx, fxg_comm *comm, const uint64_t *d_counters, uint64_t totals[FXG_NCOUNTERS],
+                       uint64_t *read_off, uint64_t *byte_off, uint64_t *gathered);
+
 /* Kernel-level timing: when enabled, every fxg_run_pipeline brackets its dominant kernel (not the
  * memset / counter-reduce helpers) with HIP events on the launch stream; fxg_last_kernel_ms waits for
  * that launch and returns its duration. */

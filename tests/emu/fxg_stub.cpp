@@ -82,6 +82,9 @@ int fxg_device_count(void) { return emu_device_count(); }
 int fxg_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi) { *lo = n * rank / world; *hi = n * (rank + 1) / world; return 0; }
 int fxg_epilogue(const uint64_t *, uint32_t, uint32_t, uint64_t *, uint64_t *, uint64_t *) { return FXG_E_INVALID; }
 int fxg_concat_pwrite(int, const void *, uint64_t, uint64_t) { return FXG_E_INVALID; }
+int fxg_comm_create(fxg_ctx *, const char *, uint32_t, uint32_t, int, fxg_comm **out) { *out = nullptr; return FXG_E_HIP; }
+void fxg_comm_destroy(fxg_comm *) {}
+int fxg_epilogue_rccl(fxg_ctx *, fxg_comm *, const uint64_t *, uint64_t *, uint64_t *, uint64_t *, uint64_t *) { return FXG_E_INVALID; }
 int fxg_host_register(fxg_ctx *, void *, size_t) { return 0; }
 int fxg_host_unregister(fxg_ctx *, void *) { return 0; }
 int fxg_set_profiling(fxg_ctx *, int) { return 0; }

@@ -320,13 +320,35 @@ def test_bench_two_ranks_on_one_gpu_via_gloo():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, FXG_BENCH_SHARED_GPU="1", FXG_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--reads", "2000000"]
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--reads", "2000000", "--e2e", "--e2e-reads", "500000"]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
     assert d["config"]["reads_per_gpu"] == 2000000
+    er = d["e2e_ranks"]                                          # one tool chain per rank on its own shard, barrier to barrier
+    assert er["ranks"] == 2 and er["reads_per_rank"] == 500000 and 0 < er["kept_reads"] < 1000000 and er["mreads_s"] > 0, er
+
+
+def test_rccl_epilogue_through_the_c_abi(engine, tmp_path):
+    """fxg_comm_create / fxg_epilogue_rccl: the counter blocks gathered by RCCL inside libfxg.so (dlopen), no Python transport.
+    This box has one GPU, so the communicator has one rank: the gathered block is the pass's own, the offsets are zero."""
+    import ctypes as C
+    import torch
+    b, q = engine.synth(2, 0, 100000, 150, False)
+    r = engine.run(b, q, _engine_params(dict(stages=6, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80)), fixed_len=150)
+    comm = C.c_void_p()
+    engine._after_torch()
+    rc = engine.lib.fxg_comm_create(engine.ctx, str(tmp_path / "rccl.id").encode(), 0, 1, 30, C.byref(comm))
+    assert rc == 0, engine.lib.fxg_last_error(engine.ctx)
+    totals = (C.c_uint64 * 24)()
+    gathered = (C.c_uint64 * 24)()
+    ro, bo = C.c_uint64(7), C.c_uint64(7)
+    rc = engine.lib.fxg_epilogue_rccl(engine.ctx, comm, r.d_counters.data_ptr(), totals, C.byref(ro), C.byref(bo), gathered)
+    assert rc == 0, engine.lib.fxg_last_error(engine.ctx)
+    assert list(totals)[:13] == [int(x) for x in r.counters[:13]] and list(gathered) == list(totals) and ro.value == 0 and bo.value == 0
+    engine.lib.fxg_comm_destroy(comm)
 
 
 def test_quality_stats_vs_oracle_and_full_size(engine):
