@@ -374,6 +374,10 @@ extern "C" int fxg_run_pipeline(fxg_ctx *c, const fxg_batch *in, const fxg_param
     u64 *ctr = (u64 *)out->counters;
 #define FXG_TILES_A(N) (fxg_kernel_tiles<N, 0>)
     if (pl.rows_nw) {       // rows of 80..152 bytes through the quality stages: one lane per read, rows in registers (fxg_rows.h)
+        if (pl.rows_h == 2) {     // rows of 153..304 bytes: two lanes per read
+            if (pl.rows_nw == 26) return fxg_launch_tiles(c, fxg_kernel_rows<26, 2>, "fxg_kernel_rows<26,2> qtrim+qfilter", pl.ka, pl.lds, ctr, 64u, true);
+            return fxg_launch_tiles(c, fxg_kernel_rows<38, 2>, "fxg_kernel_rows<38,2> qtrim+qfilter", pl.ka, pl.lds, ctr, 64u, true);
+        }
         switch (pl.rows_nw) {
         case 26: return fxg_launch_tiles(c, fxg_kernel_rows<26>, "fxg_kernel_rows<26> qtrim+qfilter", pl.ka, pl.lds, ctr, 64u, true);
         default: return fxg_launch_tiles(c, fxg_kernel_rows<38>, "fxg_kernel_rows<38> qtrim+qfilter", pl.ka, pl.lds, ctr, 64u, true);

@@ -15,7 +15,8 @@ struct FxgPlan {
     bool mask, artifacts;
     int  amax;      // adapter bucket of the clip kernel instance (0 = no clip)
     u32  lds;       // dynamic LDS bytes per workgroup
-    int  rows_nw;   // != 0: the quality stages run as fxg_kernel_rows<rows_nw> (fxg_rows.h): dwords of one read's row
+    int  rows_nw;   // != 0: the quality stages run as fxg_kernel_rows<rows_nw, rows_h> (fxg_rows.h): dwords of one lane's piece of a row
+    int  rows_h;    // lanes per read of that instance (1: rows up to 152 bytes, 2: up to 304)
     u32  block;     // threads per workgroup of the instance (FxgTileBlock)
 };
 
@@ -111,11 +112,21 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     // quality trim / filter with compaction over rows of 80..152 bytes: one lane per read, 64 reads per tile (fxg_rows.h).  Shorter
     // rows make its 64-read tiles too small (the tile kernel is 10-15 % ahead at 36-50 bases, ahead at 72, level at 76, 5-10 % behind from 88 on:
     // profiles/r02/af_rows_vs_tiles_by_length.txt)
-    pl->rows_nw = 0;
-    if (ga && !pl->clip && ka.compact && in->stride >= 80u && in->stride <= 152u && !(getenv("FXG_ROWS") && atoi(getenv("FXG_ROWS")) == 0))
-        pl->rows_nw = in->stride <= 104u ? 26 : 38;
+    // Rows of 153..304 bytes: the same kernel with TWO lanes per read, 32 reads per tile.  Measured (profiles/r03/s_rows_vs_tiles_long.txt):
+    // 2 % ahead of the tile kernel at 200 bases, 4 % / 2 % BEHIND at 250 / 300 (a 250-byte row fills 82 % of its two register pieces, and
+    // the tile kernel's per-tile costs shrink with the row length) -- so it is the default up to 208 bytes only; FXG_ROWS=2 selects it
+    // wherever it exists (tests, measurements), FXG_ROWS=0 never.
+    pl->rows_nw = 0; pl->rows_h = 1;
+    {
+        const int want = getenv("FXG_ROWS") ? atoi(getenv("FXG_ROWS")) : 1;
+        const u32 top = want >= 2 ? 304u : 208u;
+        if (ga && !pl->clip && ka.compact && in->stride >= 80u && in->stride <= top && want != 0) {
+            pl->rows_h = in->stride <= 152u ? 1 : 2;
+            pl->rows_nw = in->stride <= 104u * (u32)pl->rows_h ? 26 : 38;
+        }
+    }
     pl->block = pl->rows_nw ? 64u : (ga && pl->amax < 0 && pl->amax >= -16) ? (u32)FXG_CLIP_TBLOCK : (u32)FXG_TBLOCK;     // FxgTileBlock
-    const u32 T = pl->rows_nw ? 64u : fxg_pick_tile(pl->clip ? ka.clip_stride : in->stride, pl->clip || gf, pl->block);
+    const u32 T = pl->rows_nw ? 64u / (u32)pl->rows_h : fxg_pick_tile(pl->clip ? ka.clip_stride : in->stride, pl->clip || gf, pl->block);
     const u64 ntiles = (in->n + T - 1) / T;
     if (ntiles > 0x7FFFFFFFull || in->n > 0xFFFFFFFFull) FXG_PLAN_FAIL("batch too large (%llu reads): split it", (unsigned long long)in->n);
     ka.tile_reads = T; ka.ntiles = (u32)ntiles;
@@ -129,6 +140,6 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
         const u32 wg2 = cu_lds / lds2 < regs_wg ? cu_lds / lds2 : regs_wg, wg3 = cu_lds / lds3 < regs_wg ? cu_lds / lds3 : regs_wg;
         if (wg3 < wg2) ka.depth = 2u;
     }
-    pl->lds = pl->rows_nw ? fxg_rows_lds(ka.stride) : fxg_plan_lds(pl);
+    pl->lds = pl->rows_nw ? fxg_rows_lds(ka.stride, (u32)pl->rows_h) : fxg_plan_lds(pl);
     return FXG_OK;
 }

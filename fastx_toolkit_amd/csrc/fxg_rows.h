@@ -36,7 +36,7 @@
 #endif
 
 // staging buffer: the tile's rows + slack (every lane reads and packs a full register row, up to 156 bytes, whatever the stride)
-__host__ __device__ inline u32 fxg_rows_lds(u32 stride) { return fxg_r16(FXG_ROWS_T * stride) + 176u; }
+__host__ __device__ inline u32 fxg_rows_lds(u32 stride, u32 lanes_per_read = 1u) { return fxg_r16(FXG_ROWS_T / lanes_per_read * stride) + 176u; }
 
 // The lane's row -> its own threshold bitmap, bit i = (byte i >= thr), K = (128 - thr) * 0x01010101 (fxg_ge_flags).  Two dwords at a
 // time: the flags are bytes of 0x80 and a dot product with the byte weights (1,2,4,8) / (16,32,64,128) gathers eight of them
@@ -84,34 +84,61 @@ FXG_HD u32 fxg_rows_count(const u32 (&M)[NM], u32 len, bool invert)
     return c;
 }
 
-// fxg_decide_a<0> for a lane that holds its read's quality row in registers: quality trim, then quality filter.
+// fxg_decide_a<0> for lanes that hold quality rows in registers, in pieces so that ONE lane (rows up to 152 bytes) or TWO lanes (rows
+// up to 304 bytes: lane 2r holds bytes [0, 4 NW) of read r, lane 2r + 1 the rest) can decide a read:
+//   fxg_rows_piece_last : this piece's threshold bitmap G and 1 + its highest set bit below `plen` (quality trimmer, fastq_quality_trimmer.c:94-101)
+//   fxg_rows_piece_low  : bases below the filter threshold among the piece's first `plen` (fastq_quality_filter.c:110-129 in closed form)
+//   fxg_rows_verdict    : the read's result word from its length, trim point and low count
+template <int NW>
+FXG_HD u32 fxg_rows_piece_last(const FxgKArgs &a, const u32 (&q)[NW], u32 plen, u32 (&G)[(NW * 4 + 31) / 32])
+{
+    constexpr int NM = (NW * 4 + 31) / 32;
+    const bool trim = (a.stages & FXG_STAGE_QTRIM) != 0u, same = a.tq == a.fq;
+    if (trim || same) fxg_rows_bits<NW>(q, (128u - a.tq) * 0x01010101u, G);
+    return trim ? fxg_rows_last<NM>(G, plen) : 0u;
+}
+template <int NW>
+FXG_HD u32 fxg_rows_piece_low(const FxgKArgs &a, const u32 (&q)[NW], const u32 (&G)[(NW * 4 + 31) / 32], u32 plen)
+{
+    constexpr int NM = (NW * 4 + 31) / 32;
+    if (!(a.stages & FXG_STAGE_QFILTER)) return 0u;
+    if (a.tq == a.fq) return fxg_rows_count<NM>(G, plen, true);      // trimmer and filter at the same threshold share one bitmap
+    u32 F[NM];
+    fxg_rows_bits<NW>(q, (128u - a.fq) * 0x01010101u, F);
+    return fxg_rows_count<NM>(F, plen, true);
+}
+FXG_HD u32 fxg_rows_verdict(const FxgKArgs &a, u32 rl, u32 k, u32 low, u32 *keep_out, u32 *len_out)
+{
+    u32 reason = FXG_R_KEPT, keep = 1, curlen = rl;
+    if (a.stages & FXG_STAGE_QTRIM) {                         // fastq_quality_trimmer.c:94-101
+        curlen = k;
+        if (!(k > 0 && (int)k >= a.qt_min_len)) { keep = 0; reason = FXG_R_QTRIM; }
+    }
+    if (a.stages & FXG_STAGE_QFILTER) {                       // fastq_quality_filter.c:110-129,155 in closed form
+        int n0 = (int)curlen * a.qf_keep_pct / 100;
+        if (n0 < 0) n0 = 0;
+        if (keep && (a.qf_drop_all || (int)low > n0)) { keep = 0; reason = FXG_R_QFILTER; }
+    }
+    *keep_out = keep; *len_out = curlen;
+    return (curlen & 0xFFFFu) | (keep << 16) | (reason << 17);
+}
+
+// one lane, one read
 template <int NW>
 FXG_HD u32 fxg_rows_decide(const FxgKArgs &a, const u32 (&q)[NW], u32 read, u32 *keep_out, u32 *len_out)
 {
     constexpr int NM = (NW * 4 + 31) / 32;
     const u32 rl = a.len ? (u32)a.len[read] : a.fixed_len;
-    u32 reason = FXG_R_KEPT, keep = 1, curlen = rl;
     u32 G[NM];
-    const bool trim = (a.stages & FXG_STAGE_QTRIM) != 0u, filt = (a.stages & FXG_STAGE_QFILTER) != 0u, same = a.tq == a.fq;
-    if (trim || same) fxg_rows_bits<NW>(q, (128u - a.tq) * 0x01010101u, G);
-    if (trim) {                                               // fastq_quality_trimmer.c:94-101
-        const u32 k = fxg_rows_last<NM>(G, curlen);
-        curlen = k;
-        if (!(k > 0 && (int)k >= a.qt_min_len)) { keep = 0; reason = FXG_R_QTRIM; }
-    }
-    if (filt) {                                               // fastq_quality_filter.c:110-129,155 in closed form
-        u32 low;
-        if (trim || same) { if (same) low = fxg_rows_count<NM>(G, curlen, true); else { u32 F[NM]; fxg_rows_bits<NW>(q, (128u - a.fq) * 0x01010101u, F); low = fxg_rows_count<NM>(F, curlen, true); } }
-        else { u32 F[NM]; fxg_rows_bits<NW>(q, (128u - a.fq) * 0x01010101u, F); low = fxg_rows_count<NM>(F, curlen, true); }
-        int n0 = (int)curlen * a.qf_keep_pct / 100;
-        if (n0 < 0) n0 = 0;
-        if (keep && (a.qf_drop_all || (int)low > n0)) { keep = 0; reason = FXG_R_QFILTER; }
-    }
-    const u32 w = (curlen & 0xFFFFu) | (keep << 16) | (reason << 17);
+    const u32 k = fxg_rows_piece_last<NW>(a, q, rl, G);
+    const u32 curlen = (a.stages & FXG_STAGE_QTRIM) ? k : rl;
+    const u32 low = fxg_rows_piece_low<NW>(a, q, G, curlen);
+    const u32 w = fxg_rows_verdict(a, rl, k, low, keep_out, len_out);
     a.res[read] = w;
-    *keep_out = keep; *len_out = curlen;
     return w;
 }
+// the piece lengths of a read of `len` bytes split at HB = 4 NW
+FXG_HD u32 fxg_rows_piece_len(u32 len, u32 HB, u32 h) { return h == 0u ? (len < HB ? len : HB) : (len > HB ? len - HB : 0u); }
 
 #ifndef FXG_HOST_EMULATION
 // A workgroup is ONE wave: its LDS accesses execute in order, so "every lane's reads / writes before this point are done" needs no
@@ -153,11 +180,12 @@ __device__ __forceinline__ void fxg_rows_landed()
     FXG_WAVE_SYNC();
 }
 
-// staging buffer -> row[] of the lane's own read: dwords from the 4-byte aligned address below its first byte, shifted down by the odd bytes
+// staging buffer -> row[] of the lane's own piece, NW dwords from byte `base` on: dwords from the 4-byte aligned address below its first
+// byte, shifted down by the odd bytes
 template <int NW>
-__device__ __forceinline__ void fxg_rows_read(const unsigned char *sbuf, u32 lane, u32 stride, u32 (&row)[NW])
+__device__ __forceinline__ void fxg_rows_read(const unsigned char *sbuf, u32 base, u32 (&row)[NW])
 {
-    const u32 base = lane * stride, sh = base & 3u;
+    const u32 sh = base & 3u;
     typedef const u32 __attribute__((address_space(3))) lds_u32;                // dword reads: the address is only 4-byte aligned
     lds_u32 *w = (lds_u32 *)(sbuf + (base & ~3u));
     // batches of eight dwords: all 39 reads in flight at once would need 39 more registers next to the rows already held
@@ -253,9 +281,13 @@ __device__ __forceinline__ void fxg_rows_flush(uint8_t *out, u64 base, u32 totb,
 #define FXG_PHASE(i) do { } while (0)
 #endif
 
-template <int NW>
+// H = lanes per read: 1 for rows up to 4 NW bytes; 2 for rows up to 8 NW bytes -- lane 2r holds the first 4 NW bytes of read r, lane 2r + 1
+// the rest, a tile is 32 reads.  The two lanes exchange their pieces' trim point and low-quality count (one DPP swap each) and then
+// behave like two reads that happen to be adjacent in the output: every later step (scan, pack, flush) works on pieces.
+template <int NW, int H = 1>
 __global__ __launch_bounds__(64, FXG_ROWS_LB) void fxg_kernel_rows(const FxgKArgs a)
 {
+    constexpr u32 TR = FXG_ROWS_T / (u32)H, HB = 4u * (u32)NW;          // reads per tile; bytes per piece
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     fxg_lds_u8 *lsm = (fxg_lds_u8 *)smem;
     u32 lane = threadIdx.x;
@@ -287,32 +319,53 @@ __global__ __launch_bounds__(64, FXG_ROWS_LB) void fxg_kernel_rows(const FxgKArg
         u32 c_info = 0, c_exc = 0, c_totb = 0;
         // ------------------------------ stage A: tile `cur` ------------------------------
         if (havec) {
-            const u32 r0 = cur * FXG_ROWS_T;
+            const u32 r0 = cur * TR;
             const u64 left = a.n - (u64)r0;
-            const u32 nreads = left < (u64)FXG_ROWS_T ? (u32)left : FXG_ROWS_T;
+            const u32 nreads = left < (u64)TR ? (u32)left : TR;
             const u64 tb = (u64)r0 * stride;
             const u32 tbytes = nreads * stride;
-            // quality rows: HBM -> staging buffer -> this lane's row in registers; the lane decides its read from them
+            const u32 rd = lane / (u32)H, hf = lane % (u32)H;               // this lane's read inside the tile and which piece of it
+            // quality rows: HBM -> staging buffer -> this lane's piece in registers; the lane(s) decide the read from them
             fxg_rows_fetch<NW>(a.qual, tb, tbytes, lsm, lane);
             fxg_rows_landed();
             FXG_PHASE(0);
-            fxg_rows_read<NW>(smem, lane, stride, q);
+            fxg_rows_read<NW>(smem, rd * stride + hf * HB, q);
             FXG_WAVE_SYNC();                                                  // every lane has its row: the buffer is free for stage B
             u32 keep = 0, olen = 0, word = 0;
-            if (lane < nreads) word = fxg_rows_decide<NW>(a, q, r0 + lane, &keep, &olen);
+            if constexpr (H == 1) {
+                if (lane < nreads) word = fxg_rows_decide<NW>(a, q, r0 + lane, &keep, &olen);
+            } else {
+                constexpr int NM = (NW * 4 + 31) / 32;
+                const bool live = rd < nreads;
+                const u32 rl = live ? (a.len ? (u32)a.len[r0 + rd] : a.fixed_len) : 0u;
+                u32 G[NM];
+                const u32 kp = fxg_rows_piece_last<NW>(a, q, fxg_rows_piece_len(rl, HB, hf), G);
+                const u32 ko = (u32)__builtin_amdgcn_mov_dpp((int)kp, 0xB1, 0xf, 0xf, true);          // quad_perm [1,0,3,2]: the partner lane's value
+                const u32 k_lo = hf ? ko : kp, k_hi = hf ? kp : ko;
+                const u32 k = k_hi ? HB + k_hi : k_lo;                       // 1 + the highest position at or above the threshold
+                const u32 cl = (a.stages & FXG_STAGE_QTRIM) ? k : rl;
+                const u32 lp = fxg_rows_piece_low<NW>(a, q, G, fxg_rows_piece_len(cl, HB, hf));
+                const u32 lo_ = (u32)__builtin_amdgcn_mov_dpp((int)lp, 0xB1, 0xf, 0xf, true);
+                u32 rlen = 0;
+                word = fxg_rows_verdict(a, rl, k, lp + lo_, &keep, &rlen);
+                if (!live) { keep = 0; word = 0; }
+                if (live && hf == 0u) a.res[r0 + rd] = word;
+                olen = keep ? fxg_rows_piece_len(rlen, HB, hf) : 0u;         // this piece's share of the kept prefix
+                if (hf) word = 0;                                            // tallies and the kept count: once per read
+            }
             {
-                const u32 why = lane < nreads ? (word >> 17) & 0xFu : 0u;
+                const u32 why = (H == 1 ? lane < nreads : rd < nreads) ? (word >> 17) & 0xFu : 0u;
                 t_qtrim += (u64)__builtin_popcountll(__ballot(why == FXG_R_QTRIM));
                 t_qfilter += (u64)__builtin_popcountll(__ballot(why == FXG_R_QFILTER));
             }
-            // wave scan of (kept, kept bytes) in ONE word: at most 64 reads and 64 * 152 bytes per tile
-            const u32 mine = keep ? (1u << 16) | olen : 0u;
+            // wave scan of (kept reads, kept bytes) in ONE word: at most 64 reads and 64 * 152 bytes per tile; a read counts once
+            const u32 mine = keep ? ((hf == 0u ? 1u << 16 : 0u) | olen) : 0u;
             const u32 inc = fxg_wave_scan_dpp(mine);
             const u32 tot = (u32)__builtin_amdgcn_readlane((int)inc, 63);
             const u32 totc = tot >> 16;
             c_totb = tot & 0xFFFFu;
             c_exc = (inc - mine) >> 16;
-            c_info = (keep << 31) | (olen << 16) | ((inc - mine) & 0xFFFFu);
+            c_info = ((keep && (H == 1 || olen)) ? 1u << 31 : 0u) | (olen << 16) | ((inc - mine) & 0xFFFFu);      // "keep" of a piece: it has bytes to write
             if (lane == 0) fxg_publish_total(a, cur, totc, c_totb);
             t_in += nreads; t_kept += totc; t_bases += c_totb;
             FXG_PHASE(1);
@@ -320,17 +373,18 @@ __global__ __launch_bounds__(64, FXG_ROWS_LB) void fxg_kernel_rows(const FxgKArg
         // ------------------------------ stage B: tile `pend` ------------------------------
         u64 bc[2] = {0, 0};
         if (havep) {
-            if (!FXG_DBG(a, 2u)) fxg_wait_prefix_wave(a, pend, bc); else { bc[0] = (u64)pend * FXG_ROWS_T; bc[1] = bc[0] * stride; }
+            if (!FXG_DBG(a, 2u)) fxg_wait_prefix_wave(a, pend, bc); else { bc[0] = (u64)pend * TR; bc[1] = bc[0] * stride; }
             FXG_PHASE(2);
         }
         u32 nxt = 0;
         if (havec && lane == 0) nxt = atomicAdd(my_ticket, 1u);               // next ticket: in flight during the write-out (never held across a wait)
         if (havep) {
-            const u32 r0 = pend * FXG_ROWS_T;
+            const u32 r0 = pend * TR;
             const u64 left = a.n - (u64)r0;
-            const u32 nreads = left < (u64)FXG_ROWS_T ? (u32)left : FXG_ROWS_T;
+            const u32 nreads = left < (u64)TR ? (u32)left : TR;
             const u64 tb = (u64)r0 * stride;
             const u32 tbytes = nreads * stride;
+            const u32 rd = lane / (u32)H, hf = lane % (u32)H;
             const bool placed = bc[0] != ~0ull;         // false: the wait for the prefix expired (error flag set) -- nothing of this tile is written
             const u32 keep = placed ? p_info >> 31 : 0u, olen = (p_info >> 16) & 0x7FFFu, exb = p_info & 0xFFFFu;
             // the kept prefixes of the quality rows, packed in read order, into the staging buffer; whole 16-byte units from there
@@ -339,7 +393,11 @@ __global__ __launch_bounds__(64, FXG_ROWS_LB) void fxg_kernel_rows(const FxgKArg
             FXG_WAVE_SYNC();
             FXG_PHASE(6);
             if (placed && !FXG_DBG(a, 1u)) fxg_rows_flush(a.out_qual, bc[1], p_totb, smem, lane);
-            if (keep) fxg_write_kept_meta(a, bc[0] + p_exc, olen, r0 + lane, bc[1] + exb);
+            if constexpr (H == 1) { if (keep) fxg_write_kept_meta(a, bc[0] + p_exc, olen, r0 + lane, bc[1] + exb); }
+            else {                                                            // the first piece speaks for the read (it is never empty when the read is kept)
+                const u32 oo = (u32)__builtin_amdgcn_mov_dpp((int)olen, 0xB1, 0xf, 0xf, true);
+                if (keep && hf == 0u) fxg_write_kept_meta(a, bc[0] + p_exc, olen + oo, r0 + rd, bc[1] + exb);
+            }
             FXG_WAVE_SYNC();                                                  // the buffer is free again
             FXG_PHASE(3);
             // the base rows take the same road: HBM -> staging buffer -> registers -> packed -> out
@@ -348,7 +406,7 @@ __global__ __launch_bounds__(64, FXG_ROWS_LB) void fxg_kernel_rows(const FxgKArg
                 fxg_rows_fetch<NW>(a.bases, tb, tbytes, lsm, lane);
                 fxg_rows_landed();
                 FXG_PHASE(4);
-                fxg_rows_read<NW>(smem, lane, stride, b);
+                fxg_rows_read<NW>(smem, rd * stride + hf * HB, b);
                 FXG_WAVE_SYNC();
                 if (keep && !FXG_DBG(a, 64u)) fxg_rows_pack<NW>(smem, exb, b, olen, fast);
                 FXG_WAVE_SYNC();

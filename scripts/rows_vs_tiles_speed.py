@@ -12,11 +12,11 @@ from fastx_toolkit_amd import Engine, make_params  # noqa: E402
 eng = Engine(0)
 eng.set_profiling(True)
 P = make_params(stages=6, qt_threshold=20, qt_min_len=10, qf_min_quality=20, qf_min_percent=80)
-for L in [int(x) for x in (sys.argv[1:] or ["36", "50", "76", "100", "125", "150"])]:
+for L in [int(x) for x in (sys.argv[1:] or ["36", "50", "76", "100", "125", "150", "200", "250", "300"])]:
     n = min(7_500_000_000 // L, 200_000_000)
     b, q = eng.synth(2, 0, n, L, False, L)
     outs = eng.alloc_outputs(n, L, compact=True, meta=False)
-    for rows in ("1", "0"):
+    for rows in ("2", "0"):                  # 2: the register-row kernel wherever it exists (to 304 bytes), 0: the tile kernel
         os.environ["FXG_ROWS"] = rows
         ms = []
         for _ in range(5):

@@ -14,25 +14,41 @@
 #include "../../fastx_toolkit_amd/csrc/fxg_stats.h"
 #include "../../fastx_toolkit_amd/csrc/fxg_text.h"
 
-// fxg_kernel_rows: the lane holds its read's quality row in NW registers (bytes past the row: whatever follows in the staging buffer)
+// fxg_kernel_rows: a lane holds NW registers of its read's quality row from byte `from` on (bytes past the batch: whatever follows in
+// the staging buffer); with two lanes per read the pieces' results are combined as the kernel's DPP swaps do
 template <int NW>
-static void emu_rows_decide_nw(const FxgKArgs &a, u32 read, u32 *keep, u32 *olen)
+static void emu_rows_piece(const FxgKArgs &a, u32 read, u32 from, u32 (&q)[NW])
 {
-    u32 q[NW];
     for (int k = 0; k < NW; ++k) {
         u32 w = 0;
         for (int i = 0; i < 4; ++i) {
-            const u64 at = (u64)read * a.stride + 4u * (u32)k + (u32)i;
+            const u64 at = (u64)read * a.stride + from + 4u * (u32)k + (u32)i;
             w |= (u32)(at < a.total_bytes ? a.qual[at] : 0xA5u) << (8 * i);
         }
         q[k] = w;
     }
-    fxg_rows_decide<NW>(a, q, read, keep, olen);
 }
-static void emu_rows_decide(int nw, const FxgKArgs &a, u32 read, u32 *keep, u32 *olen)
+template <int NW>
+static void emu_rows_decide_nw(const FxgKArgs &a, int h, u32 read, u32 *keep, u32 *olen)
 {
-    if (nw == 26) emu_rows_decide_nw<26>(a, read, keep, olen);
-    else emu_rows_decide_nw<38>(a, read, keep, olen);
+    constexpr int NM = (NW * 4 + 31) / 32;
+    constexpr u32 HB = 4u * NW;
+    u32 q0[NW], q1[NW];
+    emu_rows_piece<NW>(a, read, 0, q0);
+    if (h == 1) { fxg_rows_decide<NW>(a, q0, read, keep, olen); return; }
+    emu_rows_piece<NW>(a, read, HB, q1);
+    const u32 rl = a.len ? (u32)a.len[read] : a.fixed_len;
+    u32 G0[NM], G1[NM];
+    const u32 k_lo = fxg_rows_piece_last<NW>(a, q0, fxg_rows_piece_len(rl, HB, 0), G0), k_hi = fxg_rows_piece_last<NW>(a, q1, fxg_rows_piece_len(rl, HB, 1), G1);
+    const u32 k = k_hi ? HB + k_hi : k_lo;
+    const u32 cl = (a.stages & FXG_STAGE_QTRIM) ? k : rl;
+    const u32 low = fxg_rows_piece_low<NW>(a, q0, G0, fxg_rows_piece_len(cl, HB, 0)) + fxg_rows_piece_low<NW>(a, q1, G1, fxg_rows_piece_len(cl, HB, 1));
+    a.res[read] = fxg_rows_verdict(a, rl, k, low, keep, olen);
+}
+static void emu_rows_decide(int nw, int h, const FxgKArgs &a, u32 read, u32 *keep, u32 *olen)
+{
+    if (nw == 26) emu_rows_decide_nw<26>(a, h, read, keep, olen);
+    else emu_rows_decide_nw<38>(a, h, read, keep, olen);
 }
 
 template <int AMAX, bool REV, int MODE = 0>
@@ -66,7 +82,7 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
                 if constexpr (AMAX != 0) fxg_phase_stage_bases(a.clip_src, a.clip_total, (u64)r0 * a.clip_stride, nreads * a.clip_stride, sb, tid, NT);
             }
             for (u32 tid = 0; tid < nreads; ++tid) {
-                if (AMAX == 0 && pl.rows_nw) emu_rows_decide(pl.rows_nw, a, r0 + tid, &keep[tid], &olen[tid]);   // what a lane of fxg_kernel_rows does
+                if (AMAX == 0 && pl.rows_nw) emu_rows_decide(pl.rows_nw, pl.rows_h, a, r0 + tid, &keep[tid], &olen[tid]);   // what a lane of fxg_kernel_rows does
                 else fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid]);
                 anchor[tid] = tid * stride;
             }

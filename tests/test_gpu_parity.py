@@ -112,20 +112,23 @@ def test_both_quality_kernels_on_the_same_batches(engine, monkeypatch):
                                     (5, 2000, 100, 100, False), (6, 4000, 150, 152, True), (7, 1000, 13, 29, True), (8, 333, 7, 7, False),
                                     (9, 70001, 150, 150, False), (10, 2500, 101, 104, True), (11, 700, 40, 40, True), (12, 700, 41, 41, True),
                                     (13, 900, 105, 105, True), (14, 130, 1, 1, False), (15, 640, 3, 5, True), (16, 1000, 100, 104, False), (17, 777, 150, 152, False),
-                                    (18, 1500, 80, 80, True), (19, 1500, 60, 81, True), (20, 999, 79, 79, False), (21, 3000, 9, 88, True)]:
+                                    (18, 1500, 80, 80, True), (19, 1500, 60, 81, True), (20, 999, 79, 79, False), (21, 3000, 9, 88, True),
+                                    # two lanes per read: 250 / 300 base reads, the edges of its two instances (153, 208 / 209, 304), pieces of 1-3 bytes, second pieces that are empty
+                                    (22, 3000, 250, 250, False), (23, 3000, 300, 300, False), (24, 2000, 300, 304, True), (25, 1000, 153, 153, True), (26, 1500, 208, 208, False),
+                                    (27, 1500, 209, 209, True), (28, 700, 155, 160, True), (29, 50001, 250, 250, False), (30, 900, 104, 250, True), (31, 33, 300, 300, False)]:
         b, q = engine.synth(seed, 0, n, L, False, stride)
         lens = torch.from_numpy(np.random.default_rng(seed).integers(1, L + 1, n).astype(np.int16)).to(engine.device) if var else None
         for k, pd in enumerate((dict(stages=6, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80), dict(stages=2, qt_threshold=25, qt_min_len=1),
                                 dict(stages=4, qf_min_quality=15, qf_min_percent=50), dict(stages=6, qt_threshold=30, qt_min_len=2, qf_min_quality=10, qf_min_percent=10))):
             got = {}
             for rows in ("1", "0"):
-                monkeypatch.setenv("FXG_ROWS", rows)
+                monkeypatch.setenv("FXG_ROWS", "2" if rows == "1" else "0")      # 2: the register-row kernel wherever it exists (to 304 bytes)
                 r = engine.run(b, q, make_params(**pd), lens=lens, fixed_len=None if var else L, compact=True, meta=True)
                 got[rows] = (engine.last_launch()["kernel"], r.to_host())
             kernels.add(got["1"][0].split(" ")[0].split("<")[0]); kernels.add(got["0"][0].split(" ")[0].split("<")[0])
             assert_same(got["0"][1], got["1"][1], "rows vs tiles %r %r" % ((seed, n, L, stride, var), pd))
             for rows in ("1", "0"):                 # the call shape bench.py times: no per-kept-read arrays (three NULL pointers in the launch arguments)
-                monkeypatch.setenv("FXG_ROWS", rows)
+                monkeypatch.setenv("FXG_ROWS", "2" if rows == "1" else "0")
                 r = engine.run(b, q, make_params(**pd), lens=lens, fixed_len=None if var else L, compact=True, meta=False)
                 assert r.out_len is None and r.kept_index is None and r.out_off is None
                 h = r.to_host()
@@ -139,14 +142,15 @@ def test_both_quality_kernels_on_the_same_batches(engine, monkeypatch):
 
 
 def test_quality_kernels_random_shapes(engine, monkeypatch):
-    """Seeded random batch shapes (stride 60..152, any fixed length below it or ragged lengths, any tile remainder), random thresholds:
-    fxg_kernel_rows and fxg_kernel_tiles<0,0> must produce the same arrays."""
+    """Seeded random batch shapes (stride 60..310: one lane per read up to 152, two lanes per read up to 304, the tile kernel beyond; any
+    fixed length below the stride or ragged lengths, any tile remainder), random thresholds: fxg_kernel_rows and fxg_kernel_tiles<0,0>
+    must produce the same arrays, and the oracle's on the smaller batches."""
     import torch
     from fastx_toolkit_amd import make_params
     rng = np.random.default_rng(20260927)
     kept = 0
-    for trial in range(48):
-        stride = int(rng.integers(60, 153))
+    for trial in range(96):
+        stride = int(rng.integers(60, 153)) if trial % 2 == 0 else int(rng.integers(153, 311))
         L = int(rng.integers(1, stride + 1))
         n = int(rng.integers(1, 9000))
         var = bool(rng.integers(0, 2))
@@ -156,9 +160,12 @@ def test_quality_kernels_random_shapes(engine, monkeypatch):
         pd = dict(stages=stages, qt_threshold=int(rng.integers(0, 45)), qt_min_len=int(rng.integers(0, L + 2)), qf_min_quality=int(rng.integers(0, 45)), qf_min_percent=int(rng.integers(0, 101)))
         got = {}
         for rows in ("1", "0"):
-            monkeypatch.setenv("FXG_ROWS", rows)
+            monkeypatch.setenv("FXG_ROWS", "2" if rows == "1" else "0")
             got[rows] = engine.run(b, q, make_params(**pd), lens=lens, fixed_len=None if var else L, compact=True, meta=True).to_host()
         assert_same(got["0"], got["1"], "trial %d: n %d L %d stride %d ragged %s %r" % (trial, n, L, stride, var, pd))
+        if n <= 2500:
+            o = fo.run_pipeline(b.cpu().numpy(), q.cpu().numpy(), lens.cpu().numpy().view(np.uint16) if var else None, oracle_params(pd), fixed_len=None if var else L)
+            assert_same(o, got["1"], "trial %d vs oracle" % trial)
         kept += int(got["1"]["counters"][1])
     assert kept > 10000
 
