@@ -300,7 +300,7 @@ def e2e_ranks(config, rank, local, world, reads_per_rank, dist, device):
     tf = ["fastq_quality_trim_filter", "-t", "20", "-l", "30", "-q", "20", "-p", "80"]
     chain = {"cfg2": [tf], "cfg3": [["fastx_clipper", "-a", ad, "-l", "15", "-n"]],
              "cfg4": [["fastx_reverse_complement"], ["fastx_trimmer", "-f", "5", "-l", "145"]],
-             "cfg5shard": [["fastx_clipper", "-a", ad, "-l", "15", "-n"], tf]}[config]
+             "cfg5shard": [["fastx_clip_trim_filter", "-a", ad, "-l", "15", "-n", "-t", "20", "-m", "30", "-q", "20", "-p", "80"]]}[config]
     from concurrent.futures import ThreadPoolExecutor
     from oracle import fxoracle_py as fo
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
@@ -313,10 +313,16 @@ def e2e_ranks(config, rank, local, world, reads_per_rank, dist, device):
                     f.write(part)
         env = dict(os.environ, FXG_DEVICE=str(local), FXH_CLIP_PARALLEL="1")     # fixed-length shard: the clipper needs no history
         env.pop("FXG_DEVICES", None)
+        if len(chain) == 1:                      # one tool, file to file: its sharded run (four input ranges, four writer streams) on this GPU
+            env.update(FXH_PARTS="4", FXH_LANES="2")
+            outp = os.path.join(td, "out.%r.fq")
+
+        outs = [outp.replace("%r", str(r)) for r in range(4)] if "%r" in outp else [outp]
 
         def once():
-            if os.path.exists(outp):
-                os.unlink(outp)
+            for f in outs:
+                if os.path.exists(f):
+                    os.unlink(f)
             if world > 1:
                 dist.barrier()
             t0 = time.perf_counter()
@@ -341,16 +347,17 @@ def e2e_ranks(config, rank, local, world, reads_per_rank, dist, device):
                 return {"error": "a tool of the chain failed"}
             best = dt if best is None else min(best, dt)
         recs = 0
-        with open(outp, "rb") as f:
-            for blk in iter(lambda: f.read(1 << 24), b""):
-                recs += blk.count(b"\n")
-        t = torch.tensor([recs // 4, os.path.getsize(outp)], dtype=torch.int64, device=device if (world > 1 and dist.get_backend() == "nccl") else "cpu")
+        for fn in outs:
+            with open(fn, "rb") as f:
+                for blk in iter(lambda: f.read(1 << 24), b""):
+                    recs += blk.count(b"\n")
+        t = torch.tensor([recs // 4, sum(os.path.getsize(fn) for fn in outs)], dtype=torch.int64, device=device if (world > 1 and dist.get_backend() == "nccl") else "cpu")
         if world > 1:
             dist.all_reduce(t)
         total = reads_per_rank * world
         return dict(command=" | ".join(" ".join(st) for st in chain), reads_per_rank=reads_per_rank, ranks=world, wall_s=round(best, 3),
                     mreads_s=round(total / best / 1e6, 2), gbases_s=round(total * cfg["L"] / best / 1e9, 3), kept_reads=int(t[0]), output_bytes=int(t[1]),
-                    note="one tool chain per GPU on its own shard of the input (FASTQ text on tmpfs in and out), barrier to barrier, slowest rank; best of two")
+                    note="one tool chain per GPU on its own shard of the input (FASTQ text on tmpfs in and out; a single tool runs sharded, FXH_PARTS=4), barrier to barrier, slowest rank; best of two")
 
 
 def main():

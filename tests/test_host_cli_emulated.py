@@ -325,6 +325,31 @@ def test_fused_trim_filter_equals_the_pipe(tools):
     assert _run([os.path.join(tools, "fastq_quality_trim_filter"), "-q", "20"], text)[0] == 1            # -t is mandatory, as for the trimmer
 
 
+def test_fused_clip_trim_filter_equals_the_three_tool_pipe(tools):
+    """fastx_clip_trim_filter (BASELINE config 5 in one pass) writes the bytes of fastx_clipper | fastq_quality_trimmer | fastq_quality_filter
+    and prints the three reports in turn -- against the real libfastx driver, fixed-length and ragged input, several flag sets."""
+    rng = np.random.default_rng(31)
+    ad = "AGATCGGAAGAGC"
+    from helpers import random_batch
+    texts = [fo.synth_fastq(5, 0, 3000, 150, True)]
+    b, q, lens = random_batch(rng, 800, 90, 20, 90, False, adapter=ad.encode())
+    texts.append(b"".join(b"@v%d\n%s\n+\n%s\n" % (i, bytes(b[i, :lens[i]]), bytes(q[i, :lens[i]])) for i in range(800)))
+    for text in texts:
+        for cflags, extra in (([], []), (["-n"], []), (["-c"], ["-m", "12"]), (["-C", "-n", "-M", "6"], ["-m", "5"])):
+            c = _run([os.path.join(tools, "fastx_clipper"), "-a", ad, "-l", "15", "-v"] + cflags, text)
+            t = _run([os.path.join(tools, "fastq_quality_trimmer"), "-t", "20", "-v"] + (["-l", extra[1]] if extra else []), c[1])
+            f = _run([os.path.join(tools, "fastq_quality_filter"), "-q", "20", "-p", "80", "-v"], t[1])
+            one = _run([os.path.join(tools, "fastx_clip_trim_filter"), "-a", ad, "-l", "15", "-t", "20", "-q", "20", "-p", "80", "-v"] + cflags + extra, text)
+            assert one[0] == 0 and one[1] == f[1], (cflags, extra, one[2][-300:])
+            assert one[2] == c[2] + t[2] + f[2], (cflags, extra, one[2], c[2] + t[2] + f[2])
+            if REF:
+                rc_ = _run([REF, "fastx_clipper", "-a", ad, "-l", "15", "-v"] + cflags, text)
+                rt = _run([REF, "fastq_quality_trimmer", "-t", "20", "-v"] + (["-l", extra[1]] if extra else []), rc_[1])
+                rf = _run([REF, "fastq_quality_filter", "-q", "20", "-p", "80", "-v"], rt[1])
+                assert one[1] == rf[1] and one[2] == rc_[2] + rt[2] + rf[2], (cflags, extra)
+    assert _run([os.path.join(tools, "fastx_clip_trim_filter"), "-q", "20"], texts[0])[0] == 1            # -t is mandatory, as for the trimmer
+
+
 def test_regular_files_use_parallel_io_same_bytes(tools, tmp_path):
     """-i FILE / -o FILE: blocks are read with several pread() in flight and written with positional writes; same bytes as through pipes."""
     text = fo.synth_fastq(43, 0, 120000, 100, False)                    # ~28 MB
