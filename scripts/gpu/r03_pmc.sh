@@ -14,6 +14,6 @@ for c in $CFGS; do
     rm -rf $O/$ctr
     CFG=$c timeout 300 rocprofv3 --pmc $ctr -d $O/$ctr -o pmc --output-format csv -- python $R/scripts/pmc_run.py > $O/$ctr.log 2>&1
     echo "$c $ctr rc=$? $(grep '^cfg' $O/$ctr.log | cut -c1-160)"
-    f=$(find $O/$ctr -name "*counter_collection.csv" | head -1); [ -n "$f" ] && mv $f $O/$ctr/pmc_counter_collection.csv
+    f=$(find $O/$ctr -name "*counter_collection.csv" | head -1); [ -n "$f" ] && [ "$f" != "$O/$ctr/pmc_counter_collection.csv" ] && mv $f $O/$ctr/pmc_counter_collection.csv
   done
 done

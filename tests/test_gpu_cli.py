@@ -206,6 +206,44 @@ def test_lanes_devices_and_the_fused_tool(tools, tmp_path):
     assert clean(one[2]) == clean(t[2]) + clean(f[2])
 
 
+def test_sharded_run_and_the_three_stage_tool_on_the_gpu_build(tools, tmp_path):
+    """FXH_PARTS on the real engine: parts concatenate to the one-stream output (also for a damaged input: unsharded restart, the
+    reference's message and partial output), and fastx_clip_trim_filter (config 5 in one pass) == the three-tool pipe of the real libfastx."""
+    text = fo.synth_fastq(5, 0, 150000, 150, True)                       # ~48 MB
+    inp = tmp_path / "in.fq"
+    inp.write_bytes(text)
+    ad = "AGATCGGAAGAGC"
+    for argv, penv in ((["fastq_quality_trim_filter", "-t", "20", "-l", "30", "-q", "20", "-p", "80", "-v"], {}),
+                       (["fastx_clip_trim_filter", "-a", ad, "-l", "15", "-n", "-t", "20", "-m", "30", "-q", "20", "-p", "80", "-v"], {"FXH_CLIP_PARALLEL": "1"}),
+                       (["fastx_reverse_complement", "-v"], {})):
+        single = tmp_path / "single.fq"
+        want = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", str(single)], b"", dict(os.environ, **penv))
+        assert want[0] == 0
+        for k in (2, 4):
+            pat = str(tmp_path / ("p%d.%%r.fq" % k))
+            got = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", pat], b"", dict(os.environ, FXH_PARTS=str(k), FXH_READ_BUFFER_MB="4", FXH_TIMING="1", **penv))
+            assert got[0] == 0 and got[1] == want[1], (argv[0], k, got[2][-300:])
+            if not PARSE_ENV:
+                assert got[2].count(b"fxh timing part") == k, got[2][-400:]
+            assert b"".join(open(pat.replace("%r", str(r)), "rb").read() for r in range(k)) == single.read_bytes(), (argv[0], k)
+    k0 = text.index(b"\n@", int(len(text) * 0.8)) + 1
+    inp.write_bytes(text[:k0] + b"#" + text[k0 + 1:])
+    argv = ["fastq_quality_trimmer", "-t", "20", "-l", "30"]
+    w = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", str(tmp_path / "bad1.fq")], b"")
+    g = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", str(tmp_path / "bad.%r.fq")], b"", dict(os.environ, FXH_PARTS="4", FXH_READ_BUFFER_MB="4"))
+    assert w[0] == 1 and (g[0], g[1]) == (w[0], w[1]) and _msg(g[2]) == _msg(w[2])
+    assert b"".join(open(str(tmp_path / ("bad.%d.fq" % r)), "rb").read() for r in range(4)) == (tmp_path / "bad1.fq").read_bytes()
+    if REF:                                                               # config 5 as the reference runs it: three processes in a pipe
+        small = text[:3_000_000]
+        small = small[:small.rindex(b"\n@") + 1]
+        rc_ = _run([REF, "fastx_clipper", "-a", ad, "-l", "15", "-n", "-v"], small)
+        rt = _run([REF, "fastq_quality_trimmer", "-t", "20", "-l", "30", "-v"], rc_[1])
+        rf = _run([REF, "fastq_quality_filter", "-q", "20", "-p", "80", "-v"], rt[1])
+        one = _run([os.path.join(tools, "fastx_clip_trim_filter"), "-a", ad, "-l", "15", "-n", "-t", "20", "-m", "30", "-q", "20", "-p", "80", "-v"], small)
+        clean = lambda e: b"\n".join(l for l in e.split(b"\n") if b"amdgpu.ids" not in l)
+        assert one[0] == 0 and one[1] == rf[1] and clean(one[2]) == rc_[2] + rt[2] + rf[2]
+
+
 def test_flag_errors_and_usage_on_the_gpu_build(tools):
     """F1-F6 against the real libfxg.so (the CPU tier runs the same checks against the emulation stub): exit codes, usage text, and the
     reference's messages where fxref is on the box."""
@@ -219,6 +257,8 @@ def test_flag_errors_and_usage_on_the_gpu_build(tools):
             assert _msg(err) == _msg(rerr), argv
     rc, out, _ = _run([os.path.join(tools, "fastx_clipper"), "-h"], b"")
     assert rc == 1 and out.startswith(b"usage: fastx_clipper")                                     # -h exits 1 (F5)
+    rc, out, err = _run([os.path.join(tools, "fastx_clipper"), "-a", "ACGT", "-D"], b"@r\nA\n+\nI\n")
+    assert rc == 1 and out == b"" and b"[-D]" in err                                              # documented divergence: no silent no-op
     rc, out, err = _run([os.path.join(tools, "fastq_quality_filter"), "-q", "94", "-v"], b"@r\nACGT\n+\nIIII\n")   # F2: -p omitted, -q > 93 drops everything
     assert rc == 0 and out == b""
     rc, out, err = _run([os.path.join(tools, "fastq_quality_filter"), "-q", "40"], b"@r\nACGT\n+\n!!!!\n")         # F2: -p omitted, everything passes
