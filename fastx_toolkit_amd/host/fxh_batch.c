@@ -1130,19 +1130,14 @@ typedef struct fxh_block {
     int lane;                              /* -1: not given to a lane (ragged end of input, oversized record): host parser */
 } fxh_block;
 
-/* The lanes loop (device text path).  Returns when the input is exhausted or an error is pending in R. */
-static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *lane_dev, double *t_read, double *t_lane_init)
+/* ---- the lanes loop (device text path) in four pieces: start the lanes, emit a finished block, cut the next block, stop ---- */
+static fxh_lane *fxh_lanes_start(fxh_run *R, int nlanes, const int *lane_dev)
 {
     FASTX *fx = R->fx;
-    struct fxh_reader *rd = fx->reader;
-    struct fxh_writer *wr = fx->writer;
     struct fxh_pinned *pinned = &R->pinned;
     pthread_mutex_init(&pinned->mu, NULL);
     fxh_lane *lanes = (fxh_lane *)calloc((size_t)nlanes, sizeof(fxh_lane));
-    const int NB = nlanes + 2;             /* input buffers: nlanes blocks in flight + the one being cut + the one being read */
-    char **inbuf = (char **)calloc((size_t)NB, sizeof(char *));
-    fxh_block *blk = (fxh_block *)calloc((size_t)NB, sizeof(fxh_block));
-    if (!lanes || !inbuf || !blk) err(1, "out of memory");
+    if (!lanes) err(1, "out of memory");
     for (int i = 0; i < nlanes; ++i) {
         fxh_lane *ln = &lanes[i];
         ln->id = i; ln->device = lane_dev[i]; ln->p = R->p; ln->revcomp = R->job.revcomp; ln->fwd_start = R->job.fwd_start;
@@ -1153,6 +1148,130 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
         pthread_mutex_init(&ln->mu, NULL); pthread_cond_init(&ln->cv, NULL);
         if (pthread_create(&ln->th, NULL, fxh_lane_main, ln) != 0) err(1, "pthread_create");
     }
+    return lanes;
+}
+
+/* Block `b` is next in the output order: wait for its lane and hand the formatted text to the writer, or -- a block the device
+ * flagged, or one that never went to a lane -- run it through the host parser at its turn.  Returns 0 when the run must stop
+ * (a part of a sharded run met such a block: R->aborted). */
+static int fxh_lanes_emit(fxh_run *R, fxh_lane *lanes, fxh_block *b)
+{
+    FASTX *fx = R->fx;
+    struct fxh_reader *rd = fx->reader;
+    int handled = 0;
+    if (b->lane >= 0) {
+        fxh_lane *ln = &lanes[b->lane];
+        double tw = fxh_now();
+        fxh_lane_wait(ln);
+        R->t_wait_lane += fxh_now() - tw;
+        if (ln->handled) {
+            handled = 1;
+            tw = fxh_now();
+            fxh_awriter_submit_ext(&R->aw, fx->writer, ln->out[ln->slot], ln->out_len);
+            R->t_wait_writer += fxh_now() - tw;
+            if (!R->overlap) fxh_awriter_wait(&R->aw);
+            fxh_add_counters(R->tot, ln->ctr, b->records, ln->lpr == 2 ? ln->weighted : NULL);
+        }
+    }
+    if (!handled && R->nparts > 1) {   /* a part of a sharded run only takes what the device path takes: the whole run starts over unsharded */
+        R->aborted = 1; FXH_ABORT_SET();
+        return 0;
+    }
+    if (!handled) {                    /* this block goes through the host parser, at its place in the output order */
+        R->n_fallback++;
+        if (R->st_shared && !R->st.ctx) {          /* serial clipper run: the host parser works through lane 0's context */
+            fxh_lane *l0 = &lanes[0];
+            pthread_mutex_lock(&l0->mu);
+            while (!l0->ready) pthread_cond_wait(&l0->cv, &l0->mu);
+            pthread_mutex_unlock(&l0->mu);
+            R->st.ctx = l0->st.ctx; R->st.d_counters = l0->st.d_counters;
+        }
+        struct fxh_reader save = *rd;
+        const unsigned long long save_line = fx->input_line_number;
+        rd->buf = b->buf; rd->beg = b->beg; rd->end = b->end; rd->eof = b->eof;
+        fx->input_line_number = b->line0;
+        while (rd->beg < rd->end && !R->have_err) {
+            const size_t before = rd->beg;
+            fxh_host_block(R);
+            if (rd->beg == before) break;
+        }
+        if (!R->have_err && rd->beg < rd->end) errx(1, "internal error: host parser left %zu bytes of a block", rd->end - rd->beg);
+        *rd = save;
+        fx->input_line_number = save_line;
+        R->at_eof = 0;
+    }
+    fx->num_input_sequences = R->tot->input_sequences; fx->num_input_reads = R->tot->input_reads;
+    fx->num_output_sequences = R->tot->output_sequences; fx->num_output_reads = R->tot->output_reads;
+    return 1;
+}
+
+/* Cut the unread text of the reader's buffer at a record boundary: records are groups of lpr lines counted from the start of the
+ * input, so the cut only needs the number of complete lines.  fresh_nl = newlines the reader threads counted in the freshly read
+ * part ((size_t)-1: unknown), carry_lines = complete lines of the unread tail in front of it (when *have_carry).  Out: `end` (the
+ * text's end incl. a '\n' appended at end of input), `lines` up to there, `cut` (end of the last whole record). */
+static void fxh_cut_records(fxh_run *R, size_t fresh_nl, int have_carry, unsigned long long carry_lines, size_t *end_out, unsigned long long *lines_out, size_t *cut_out)
+{
+    struct fxh_reader *rd = R->fx->reader;
+    size_t end = rd->end;
+    if (rd->eof && rd->buf[end - 1] != '\n') { rd->buf[end] = '\n'; end += 1; }       /* the buffer has one spare byte */
+    fxh_job *job = &R->job;
+    const int T = job->nworkers;
+    for (int i = 0; i < T; ++i) {
+        job->w[i].a0 = rd->beg + (size_t)((unsigned long long)(end - rd->beg) * (unsigned)i / (unsigned)T);
+        job->w[i].a1 = rd->beg + (size_t)((unsigned long long)(end - rd->beg) * (unsigned)(i + 1) / (unsigned)T);
+    }
+    unsigned long long lines = 0;
+    if (fresh_nl != (size_t)-1 && have_carry) lines = carry_lines + fresh_nl + (end > rd->end ? 1u : 0u);   /* tail of the last block + fresh data (+ the appended '\n') */
+    else {
+        fxh_parallel(job, fxh_phase_census);
+        for (int i = 0; i < T; ++i) lines += job->w[i].nl_count;
+    }
+    const unsigned lpr = (unsigned)job->lpr;
+    size_t cut = end;
+    if (!rd->eof || lines % lpr != 0) {  /* drop the incomplete last line and the lines of the incomplete record in front of it */
+        unsigned drop = (unsigned)(lines % lpr);
+        const char *q = (const char *)memrchr(rd->buf + rd->beg, '\n', end - rd->beg);
+        cut = q ? (size_t)(q - rd->buf) + 1 : rd->beg;
+        while (drop-- && cut > rd->beg) {
+            q = (const char *)memrchr(rd->buf + rd->beg, '\n', cut - 1 - rd->beg);
+            cut = q ? (size_t)(q - rd->buf) + 1 : rd->beg;
+        }
+    }
+    *end_out = end; *lines_out = lines; *cut_out = cut;
+}
+
+static void fxh_lanes_stop(fxh_run *R, fxh_lane *lanes, int nlanes, double *t_lane_init)
+{
+    /* (when an error is pending, blocks after the bad record are abandoned, like everything after an errx() in the reference) */
+    for (int i = 0; i < nlanes; ++i) {
+        fxh_lane *ln = &lanes[i];
+        pthread_mutex_lock(&ln->mu);
+        while (ln->state == 1) pthread_cond_wait(&ln->cv, &ln->mu);
+        ln->state = 3;
+        pthread_cond_broadcast(&ln->cv);
+        pthread_mutex_unlock(&ln->mu);
+        pthread_join(ln->th, NULL);
+        *t_lane_init += ln->t_init;
+        R->t_gpu += ln->t_busy;
+    }
+    { const double tw = fxh_now(); fxh_awriter_wait(&R->aw); R->t_drain += fxh_now() - tw; }   /* the last lane buffer must be on its way out before the contexts go */
+    /* The process is about to exit: device buffers, streams and page-locked memory go with it, there is nothing to gain from
+     * tearing each context down first (FXH_TEARDOWN=1 does it anyway, for leak checkers). */
+    if (R->st_shared) { if (R->st.ctx) fxg_sync(R->st.ctx); R->st.ctx = NULL; }
+    if (getenv("FXH_TEARDOWN")) for (int i = 0; i < nlanes; ++i) fxg_ctx_destroy(lanes[i].st.ctx);
+    free(lanes);
+}
+
+/* The lanes loop.  Returns when the input is exhausted or an error is pending in R. */
+static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *lane_dev, double *t_read, double *t_lane_init)
+{
+    FASTX *fx = R->fx;
+    struct fxh_reader *rd = fx->reader;
+    fxh_lane *lanes = fxh_lanes_start(R, nlanes, lane_dev);
+    const int NB = nlanes + 2;             /* input buffers: nlanes blocks in flight + the one being cut + the one being read */
+    char **inbuf = (char **)calloc((size_t)NB, sizeof(char *));
+    fxh_block *blk = (fxh_block *)calloc((size_t)NB, sizeof(fxh_block));
+    if (!inbuf || !blk) err(1, "out of memory");
     inbuf[0] = rd->buf;
     size_t nblocks = 0, next_emit = 0;
     size_t lane_uses[FXH_MAX_LANES] = {0};
@@ -1162,51 +1281,7 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
     while (!R->have_err && !R->aborted && !(R->nparts > 1 && FXH_ABORTED())) {
         /* ---- collect finished blocks in input order until a lane and an input buffer are free ---- */
         while (next_emit < nblocks && (nblocks - next_emit >= (size_t)nlanes || input_done)) {
-            fxh_block *b = &blk[next_emit % (size_t)NB];
-            int handled = 0;
-            if (b->lane >= 0) {
-                fxh_lane *ln = &lanes[b->lane];
-                double tw = fxh_now();
-                fxh_lane_wait(ln);
-                R->t_wait_lane += fxh_now() - tw;
-                if (ln->handled) {
-                    handled = 1;
-                    tw = fxh_now();
-                    fxh_awriter_submit_ext(&R->aw, wr, ln->out[ln->slot], ln->out_len);
-                    R->t_wait_writer += fxh_now() - tw;
-                    if (!R->overlap) fxh_awriter_wait(&R->aw);
-                    fxh_add_counters(R->tot, ln->ctr, b->records, ln->lpr == 2 ? ln->weighted : NULL);
-                }
-            }
-            if (!handled && R->nparts > 1) {   /* a part of a sharded run only takes what the device path takes: the whole run starts over unsharded */
-                R->aborted = 1; FXH_ABORT_SET();
-                break;
-            }
-            if (!handled) {                /* this block goes through the host parser, at its place in the output order */
-                R->n_fallback++;
-                if (R->st_shared && !R->st.ctx) {          /* serial clipper run: the host parser works through lane 0's context */
-                    fxh_lane *l0 = &lanes[0];
-                    pthread_mutex_lock(&l0->mu);
-                    while (!l0->ready) pthread_cond_wait(&l0->cv, &l0->mu);
-                    pthread_mutex_unlock(&l0->mu);
-                    R->st.ctx = l0->st.ctx; R->st.d_counters = l0->st.d_counters;
-                }
-                struct fxh_reader save = *rd;
-                const unsigned long long save_line = fx->input_line_number;
-                rd->buf = b->buf; rd->beg = b->beg; rd->end = b->end; rd->eof = b->eof;
-                fx->input_line_number = b->line0;
-                while (rd->beg < rd->end && !R->have_err) {
-                    const size_t before = rd->beg;
-                    fxh_host_block(R);
-                    if (rd->beg == before) break;
-                }
-                if (!R->have_err && rd->beg < rd->end) errx(1, "internal error: host parser left %zu bytes of a block", rd->end - rd->beg);
-                *rd = save;
-                fx->input_line_number = save_line;
-                R->at_eof = 0;
-            }
-            fx->num_input_sequences = R->tot->input_sequences; fx->num_input_reads = R->tot->input_reads;
-            fx->num_output_sequences = R->tot->output_sequences; fx->num_output_reads = R->tot->output_reads;
+            if (!fxh_lanes_emit(R, lanes, &blk[next_emit % (size_t)NB])) break;
             next_emit++;
             if (R->have_err) break;
         }
@@ -1217,43 +1292,20 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
         double t0 = fxh_now();
         size_t fresh_nl = (size_t)-1;      /* newlines in the freshly read part, when the reader threads counted them */
         {
-            char *target = NULL;           /* where the read-ahead for the block after this one goes */
-            const size_t nxt = (nblocks + 1) % (size_t)NB;
+            const size_t nxt = (nblocks + 1) % (size_t)NB;        /* where the read-ahead for the block after this one goes */
             if (!inbuf[nxt]) { inbuf[nxt] = (char *)malloc(rd->cap + 1); if (!inbuf[nxt]) err(1, "out of memory"); }
-            target = inbuf[nxt];
-            fxh_next_block_ring(pf, rd, target, &fresh_nl);
+            fxh_next_block_ring(pf, rd, inbuf[nxt], &fresh_nl);
         }
         *t_read += fxh_now() - t0;
         if (rd->beg == rd->end && rd->eof) { input_done = 1; continue; }
 
-        /* ---- cut it at a record boundary: records are groups of four lines counted from the start of the input ---- */
+        /* ---- cut it at a record boundary and give it to the next lane ---- */
         t0 = fxh_now();
-        size_t end = rd->end;
-        if (rd->eof && rd->buf[end - 1] != '\n') { rd->buf[end] = '\n'; end += 1; }       /* the buffer has one spare byte */
-        fxh_job *job = &R->job;
-        const int T = job->nworkers;
-        for (int i = 0; i < T; ++i) {
-            job->w[i].a0 = rd->beg + (size_t)((unsigned long long)(end - rd->beg) * (unsigned)i / (unsigned)T);
-            job->w[i].a1 = rd->beg + (size_t)((unsigned long long)(end - rd->beg) * (unsigned)(i + 1) / (unsigned)T);
-        }
-        unsigned long long lines = 0;
-        if (fresh_nl != (size_t)-1 && have_carry) lines = carry_lines + fresh_nl + (end > rd->end ? 1u : 0u);   /* tail of the last block + fresh data (+ the appended '\n') */
-        else {
-            fxh_parallel(job, fxh_phase_census);
-            for (int i = 0; i < T; ++i) lines += job->w[i].nl_count;
-        }
-        const unsigned lpr = (unsigned)job->lpr;
+        size_t end, cut;
+        unsigned long long lines;
+        fxh_cut_records(R, fresh_nl, have_carry, carry_lines, &end, &lines, &cut);
+        const unsigned lpr = (unsigned)R->job.lpr;
         const uint64_t records = lines / lpr;
-        size_t cut = end;
-        if (!rd->eof || lines % lpr != 0) {  /* drop the incomplete last line and the lines of the incomplete record in front of it */
-            unsigned drop = (unsigned)(lines % lpr);
-            const char *q = (const char *)memrchr(rd->buf + rd->beg, '\n', end - rd->beg);
-            cut = q ? (size_t)(q - rd->buf) + 1 : rd->beg;
-            while (drop-- && cut > rd->beg) {
-                q = (const char *)memrchr(rd->buf + rd->beg, '\n', cut - 1 - rd->beg);
-                cut = q ? (size_t)(q - rd->buf) + 1 : rd->beg;
-            }
-        }
         R->t_index += fxh_now() - t0;
         fxh_block *b = &blk[nblocks % (size_t)NB];
         b->buf = rd->buf; b->beg = rd->beg; b->line0 = fx->input_line_number; b->records = records; b->lane = -1;
@@ -1275,25 +1327,9 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
         }
         nblocks++;
     }
-    /* an error is pending: blocks after the bad record are abandoned, like everything after an errx() in the reference */
-    for (int i = 0; i < nlanes; ++i) {
-        fxh_lane *ln = &lanes[i];
-        pthread_mutex_lock(&ln->mu);
-        while (ln->state == 1) pthread_cond_wait(&ln->cv, &ln->mu);
-        ln->state = 3;
-        pthread_cond_broadcast(&ln->cv);
-        pthread_mutex_unlock(&ln->mu);
-        pthread_join(ln->th, NULL);
-        *t_lane_init += ln->t_init;
-        R->t_gpu += ln->t_busy;
-    }
-    { const double tw = fxh_now(); fxh_awriter_wait(&R->aw); R->t_drain += fxh_now() - tw; }   /* the last lane buffer must be on its way out before the contexts go */
-    /* The process is about to exit: device buffers, streams and page-locked memory go with it, there is nothing to gain from
-     * tearing each context down first (FXH_TEARDOWN=1 does it anyway, for leak checkers). */
-    if (R->st_shared) { if (R->st.ctx) fxg_sync(R->st.ctx); R->st.ctx = NULL; }
-    if (getenv("FXH_TEARDOWN")) for (int i = 0; i < nlanes; ++i) fxg_ctx_destroy(lanes[i].st.ctx);
+    fxh_lanes_stop(R, lanes, nlanes, t_lane_init);
     for (int k = 1; k < NB; ++k) if (inbuf[k] && inbuf[k] != rd->buf) free(inbuf[k]);
-    free(inbuf); free(blk); free(lanes);
+    free(inbuf); free(blk);
 }
 
 static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_stats_run *stats, uint64_t **hist_out, uint32_t *cols_out, int part, int nparts)
