@@ -911,19 +911,18 @@ static void fxh_run_ctx(fxh_run *R)
     R->t_init += fxh_now() - t0;
 }
 
-/* Host-parser path for the unread part [rd->beg, rd->end) of the current block: index + validate in parallel, pack the SoA rows,
- * run the engine, format the kept records.  Consumes whole records (rd->beg moves on), sets have_err / at_eof. */
-static void fxh_host_block(fxh_run *R)
+/* what the four steps of the host-parser path hand to one another */
+typedef struct { size_t beg, end, n, maxlen, minlen; int stop; uint64_t ctr[FXG_NCOUNTERS]; } fxh_hb;
+
+/* 1. split [beg, end) into worker ranges at record boundaries, index and validate the records in parallel, merge in input order
+ * (the first error / end condition wins) and, where one long read would blow the rows up, cut the batch at a record boundary.
+ * Returns 0 when there is nothing to process (R->have_err / R->at_eof say why). */
+static int fxh_host_index(fxh_run *R, fxh_hb *hb)
 {
     FASTX *fx = R->fx;
     fxh_job *job = &R->job;
-    fxh_state *st = &R->st;
-    fxh_totals *tot = R->tot;
-    const fxg_params *p = R->p;
     struct fxh_reader *rd = fx->reader;
-    double t0 = fxh_now();
-    fxh_run_ctx(R);
-    const size_t beg = rd->beg, end = rd->end;
+    const size_t beg = hb->beg, end = hb->end;
     const int T = job->nworkers;
     for (int i = 0; i < T; ++i) {
         job->w[i].a0 = beg + (size_t)((unsigned long long)(end - beg) * (unsigned)i / (unsigned)T);
@@ -984,7 +983,7 @@ static void fxh_host_block(fxh_run *R)
     for (int i = stop + 1; i < T; ++i) { job->w[i].use = 0; job->w[i].rec0 = n; }
     if (n == 0) {
         if (!R->have_err && !R->at_eof) errx(1, "input record does not fit in the %zu MB read buffer", rd->cap >> 20);
-        return;
+        return 0;
     }
     /* One long read among short ones must not blow the rows up (rows are n * longest): cut the batch at a record boundary when
      * the SoA would exceed ~16x the text of the block; the rest of the block is the next call's business. */
@@ -1016,11 +1015,18 @@ static void fxh_host_block(fxh_run *R)
             }
         }
     }
-    R->t_index += fxh_now() - t0; t0 = fxh_now();
+    hb->n = n; hb->maxlen = maxlen; hb->minlen = minlen; hb->stop = stop;
+    return 1;
+}
 
-    /* ---- 2. pack the SoA rows (qualities normalised to Phred+33 codes) ---- */
-    job->stride = (uint32_t)maxlen;
-    fxh_grow(st, n, n * (size_t)job->stride, job->revcomp);
+/* 2. pack the SoA rows (qualities normalised to Phred+33 codes); a bad base or quality ends the batch in front of its record */
+static void fxh_host_pack(fxh_run *R, fxh_hb *hb)
+{
+    fxh_job *job = &R->job;
+    const int T = job->nworkers, stop = hb->stop;
+    size_t n = hb->n;
+    job->stride = (uint32_t)hb->maxlen;
+    fxh_grow(&R->st, n, n * (size_t)job->stride, job->revcomp);
     fxh_parallel(job, fxh_phase_pack);
     for (int i = 0; i <= stop; ++i) {
         fxh_worker *w = &job->w[i];
@@ -1033,9 +1039,20 @@ static void fxh_host_block(fxh_run *R)
             break;
         }
     }
-    R->t_pack += fxh_now() - t0; t0 = fxh_now();
-    if (n == 0) return;
-    /* ---- 3. engine ---- */
+    hb->n = n;
+}
+
+/* 3. upload, one engine call, download res[] (and the packed arrays of reverse-complemented / masked output).  Returns 0 when the
+ * batch fed fastx_quality_stats (nothing to write). */
+static int fxh_host_engine(fxh_run *R, fxh_hb *hb)
+{
+    FASTX *fx = R->fx;
+    fxh_job *job = &R->job;
+    fxh_state *st = &R->st;
+    fxh_totals *tot = R->tot;
+    const fxg_params *p = R->p;
+    const size_t n = hb->n, maxlen = hb->maxlen, minlen = hb->minlen;
+    uint64_t *ctr = hb->ctr;
     const uint32_t stride = job->stride;
     const size_t bytes = n * (size_t)stride;
     const int fixed = (minlen == maxlen);
@@ -1049,15 +1066,13 @@ static void fxh_host_block(fxh_run *R)
         FXG_CHECK(st, fxg_sync(st->ctx));
         tot->input_sequences += n; tot->input_reads += n;
         fx->num_input_sequences = tot->input_sequences; fx->num_input_reads = tot->input_reads;
-        R->t_gpu += fxh_now() - t0;
-        return;
+        return 0;
     }
     fxg_out out = {st->d_res, job->revcomp ? st->d_out_bases : NULL, (job->revcomp && job->has_q) ? st->d_out_qual : NULL, NULL, NULL, NULL, st->d_counters};
     fxg_params pp = *p;
     pp.qoffset = 33;                        /* rows hold Phred+33 codes whatever -Q was */
     FXG_CHECK(st, fxg_run_pipeline(st->ctx, &in, &pp, &out));
     FXG_CHECK(st, fxg_memcpy_d2h(st->ctx, st->h_res, st->d_res, n * sizeof(uint32_t)));
-    uint64_t ctr[FXG_NCOUNTERS];
     {
         int rc = fxg_read_counters(st->ctx, st->d_counters, ctr);   /* synchronises */
         if (rc == FXG_E_DEVICE && (ctr[FXG_C_ERRORS] & FXG_DEV_ERR_BAD_BASE)) errx(1, "%s", fxg_last_error(st->ctx));
@@ -1069,9 +1084,16 @@ static void fxh_host_block(fxh_run *R)
         if (job->has_q) FXG_CHECK(st, fxg_memcpy_d2h(st->ctx, st->h_out_qual, st->d_out_qual, ctr[FXG_C_KEPT_BASES]));
         FXG_CHECK(st, fxg_sync(st->ctx));
     }
-    R->t_gpu += fxh_now() - t0; t0 = fxh_now();
+    return 1;
+}
 
-    /* ---- 4. format the kept records in input order (each worker its own slice), tally the report counters ---- */
+/* 4. format the kept records in input order (each worker its own slice), tally the report counters, hand the text to the writer */
+static void fxh_host_format(fxh_run *R)
+{
+    FASTX *fx = R->fx;
+    fxh_job *job = &R->job;
+    fxh_totals *tot = R->tot;
+    const int T = job->nworkers;
     fxh_parallel(job, fxh_phase_count);
     {
         size_t base = tot->output_sequences + 1;
@@ -1097,6 +1119,29 @@ static void fxh_host_block(fxh_run *R)
     if (R->overlap) fxh_awriter_submit(&R->aw, wr, &R->wr_spare, &R->wr_spare_cap); else fxh_writer_flush(wr);
     fx->num_input_sequences = tot->input_sequences; fx->num_input_reads = tot->input_reads;
     fx->num_output_sequences = tot->output_sequences; fx->num_output_reads = tot->output_reads;
+}
+
+
+/* Host-parser path for the unread part [rd->beg, rd->end) of the current block: index + validate in parallel, pack the SoA rows,
+ * run the engine, format the kept records.  Consumes whole records (rd->beg moves on), sets have_err / at_eof. */
+static void fxh_host_block(fxh_run *R)
+{
+    struct fxh_reader *rd = R->fx->reader;
+    fxh_hb hb;
+    memset(&hb, 0, sizeof hb);
+    double t0 = fxh_now();
+    fxh_run_ctx(R);
+    hb.beg = rd->beg; hb.end = rd->end;
+    const int have = fxh_host_index(R, &hb);
+    R->t_index += fxh_now() - t0; t0 = fxh_now();
+    if (!have) return;
+    fxh_host_pack(R, &hb);
+    R->t_pack += fxh_now() - t0; t0 = fxh_now();
+    if (hb.n == 0) return;
+    const int to_write = fxh_host_engine(R, &hb);
+    R->t_gpu += fxh_now() - t0; t0 = fxh_now();
+    if (!to_write) return;
+    fxh_host_format(R);
     R->t_fmt += fxh_now() - t0;
 }
 
