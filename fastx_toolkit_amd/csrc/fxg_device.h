@@ -34,6 +34,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef FXG_CLIP_DEPTH
 #define FXG_CLIP_DEPTH 3u       // slots of the clip instances (FxgTileDepth in fxg_kernels.h)
 #endif
+#define FXG_CK_SLOTS 7u         // checkpoints a read can leave (fxg_plan.h picks the interval so that they suffice)
 #ifndef FXG_CLIP_TBLOCK
 #define FXG_CLIP_TBLOCK 256     // threads per workgroup of the two-pass clip instances (FxgTileBlock in fxg_kernels.h); 64 = one wave per workgroup, measured 6-25 % slower
 #endif
@@ -99,6 +100,8 @@ struct FxgKArgs {
     u64  clip_total;        // n * clip_stride
     u32  clip_stride;
     const uint16_t *wlen;   // DP rows per read (null: the read's own length)
+    float *clip_ck;         // two-pass clipper for 17..99 adapter columns (fxg_clip_two_pass_k): score-row checkpoints, FXG_CK_SLOTS x bucket x threads floats per workgroup (null: one pass)
+    u32  clip_ck_rows;      // a checkpoint every this many rows
     char adapter[100];
 };
 

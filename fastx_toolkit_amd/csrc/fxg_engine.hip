@@ -48,6 +48,8 @@ struct fxg_ctx {
     u32 *hist_w;            // [2]
     uint8_t *hist_ws;       // M, BT, ext, wlen
     size_t hist_ws_cap;
+    float *clip_ck;         // fxg_clip_two_pass_k: checkpoint scratch, FxgPlan.ck_per_wg floats per workgroup
+    size_t clip_ck_cap;     // in floats
     u32 *stats_ws;          // fxg_run_quality_stats: one u32 partial histogram per workgroup
     size_t stats_ws_cap;
     char err[512];
@@ -111,7 +113,7 @@ extern "C" void fxg_ctx_destroy(fxg_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->status); (void)hipFree(c->errflag); (void)hipFree(c->counters_scratch);
     (void)hipFree(c->text_ws); (void)hipFree(c->text_state);
-    (void)hipFree(c->hist_buf[0]); (void)hipFree(c->hist_buf[1]); (void)hipFree(c->hist_w); (void)hipFree(c->hist_ws); (void)hipFree(c->stats_ws);
+    (void)hipFree(c->hist_buf[0]); (void)hipFree(c->hist_buf[1]); (void)hipFree(c->hist_w); (void)hipFree(c->hist_ws); (void)hipFree(c->stats_ws); (void)hipFree(c->clip_ck);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipEventDestroy(c->kev0); (void)hipEventDestroy(c->kev1);
     (void)hipStreamDestroy(c->own_stream);
@@ -223,7 +225,7 @@ static int fxg_kernel_fit(fxg_ctx *c, K kernel, const char *kname, u32 lds, int 
 #define FXG_STATUS_WORDS(cap) (3 * (size_t)(cap) + 2 * ((size_t)(cap) / 256 + 2))
 
 template <typename K>
-static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &ka, u32 lds, u64 *counters, u32 block = FXG_TBLOCK, bool rows_kernel = false)
+static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &ka, u32 lds, u64 *counters, u32 block = FXG_TBLOCK, bool rows_kernel = false, u64 ck_per_wg = 0)
 {
     FXG_HIP(c, hipSetDevice(c->device));
     int per_cu = 0;
@@ -259,6 +261,17 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
         ka.pfx = c->status + c->status_cap;
         ka.bbase = c->status + 3 * c->status_cap;
         ka.tag = c->epoch;
+    }
+    ka.clip_ck = nullptr;
+    if (ck_per_wg) {                             // checkpoint rows of the two-pass clipper (fxg_clip_two_pass_k): written and read by the same thread
+        const size_t need = (size_t)grid * (size_t)ck_per_wg;
+        if (c->clip_ck_cap < need) {
+            (void)hipFree(c->clip_ck);
+            c->clip_ck = nullptr; c->clip_ck_cap = 0;
+            FXG_HIP(c, hipMalloc((void **)&c->clip_ck, need * sizeof(float)));
+            c->clip_ck_cap = need;
+        }
+        ka.clip_ck = c->clip_ck;
     }
 #ifdef FXG_ABLATION
     { const char *dbg = getenv("FXG_DEBUG"); ka.debug = dbg ? (u32)atoi(dbg) : 0u; }
@@ -396,10 +409,15 @@ extern "C" int fxg_run_pipeline(fxg_ctx *c, const fxg_batch *in, const fxg_param
         case -14: return fxg_launch_tiles(c, FXG_TILES_A(-14), "fxg_kernel_tiles<-14,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
         case -15: return fxg_launch_tiles(c, FXG_TILES_A(-15), "fxg_kernel_tiles<-15,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
         case -16: return fxg_launch_tiles(c, FXG_TILES_A(-16), "fxg_kernel_tiles<-16,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
-        case -20: return fxg_launch_tiles(c, FXG_TILES_A(-20), "fxg_kernel_tiles<-20,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
-        case -24: return fxg_launch_tiles(c, FXG_TILES_A(-24), "fxg_kernel_tiles<-24,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
-        case -28: return fxg_launch_tiles(c, FXG_TILES_A(-28), "fxg_kernel_tiles<-28,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
-        case -32: return fxg_launch_tiles(c, FXG_TILES_A(-32), "fxg_kernel_tiles<-32,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
+        case -20: return fxg_launch_tiles(c, FXG_TILES_A(-20), "fxg_kernel_tiles<-20,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -24: return fxg_launch_tiles(c, FXG_TILES_A(-24), "fxg_kernel_tiles<-24,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -28: return fxg_launch_tiles(c, FXG_TILES_A(-28), "fxg_kernel_tiles<-28,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -32: return fxg_launch_tiles(c, FXG_TILES_A(-32), "fxg_kernel_tiles<-32,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -40: return fxg_launch_tiles(c, FXG_TILES_A(-40), "fxg_kernel_tiles<-40,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -48: return fxg_launch_tiles(c, FXG_TILES_A(-48), "fxg_kernel_tiles<-48,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -64: return fxg_launch_tiles(c, FXG_TILES_A(-64), "fxg_kernel_tiles<-64,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -216: return fxg_launch_tiles(c, FXG_TILES_A(-216), "fxg_kernel_tiles<-216,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -100: return fxg_launch_tiles(c, FXG_TILES_A(-100), "fxg_kernel_tiles<-100,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case 16: return fxg_launch_tiles(c, FXG_TILES_A(16), "fxg_kernel_tiles<16,0> clip[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
         case 32: return fxg_launch_tiles(c, FXG_TILES_A(32), "fxg_kernel_tiles<32,0> clip[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
         case 64: return fxg_launch_tiles(c, FXG_TILES_A(64), "fxg_kernel_tiles<64,0> clip[+qtrim+qfilter]", pl.ka, pl.lds, ctr);

@@ -390,19 +390,260 @@ FXG_HD void fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Adapters of 17..100 bases (MAX_ADAPTER_LEN, fastx_clipper.cpp:35), reads <= 255: one pass, the summary still ONE u32 per cell.
+// A path can only enter the matrix in row 0 or in column 0, so its start is one number, not two:
+//   k = start:9 | path_len:9 | diagonal:7 | matches:7        start = query_start (target_start 0), or 256 + target_start (query_start 0)
+// (path_len <= L + A <= 355, diagonal and matches <= A <= 100).  The row is swept in place: the diagonal candidate of column t + 1 --
+// score and summary -- is taken from column t before the sweep overwrites it, so a row needs no copy of itself and the live state
+// is S (+ S - 5 where registers allow) and K: 2-3 registers per adapter column, which is what decides how many waves a SIMD holds
+// (the earlier form kept three more arrays per row and fell to one wave per SIMD from 20 columns on: 2 200-2 700 GCUPS at 17..28
+// bases, 1 040 at 32 and 200 from 33 on -- profiles/r03/u_clip_by_adapter_len_before.txt).
+// The virtual cells above row 0 carry the summary a path entering diagonally at (0, t) starts from, as in fxg_clip_two_pass.
+// ------------------------------------------------------------------------------------------------
+#ifdef FXG_HOST_EMULATION
+#define FXG_KEEP_V(x) ((void)0)
+#else
+#define FXG_KEEP_V(x) asm volatile("" : "+v"(x))
+#endif
+#define FXG_K_MAT1 1u
+#define FXG_K_DIA1 (1u << 7)
+#define FXG_K_SZ1  (1u << 14)
+#define FXG_K_START(v) ((u32)(v) << 23)
+// smallest adapter of the bucket AMAX (fxg_plan.h): columns below it always count towards the best cell
+__host__ __device__ constexpr int fxg_clip_k_amin(int amax) { return amax <= 16 ? 1 : amax <= 20 ? 17 : amax <= 32 ? amax - 3 : amax <= 48 ? amax - 7 : amax <= 64 ? 49 : 65; }
+template <int AMAX> struct FxgClipK { static constexpr bool SM = AMAX <= 28; static constexpr int NSM = SM ? AMAX : 1; };
+
+template <int AMAX, bool EARLY, bool TRACK>
+FXG_HD void fxg_clip_row_k(const FxgKArgs &a, int A, u32 c, int q, u32 vstart, float (&S)[AMAX], float (&Sm)[FxgClipK<AMAX>::NSM], u32 (&W)[AMAX],
+                           float &best, u32 &bw, u32 &bq)
+{
+    constexpr bool SM = FxgClipK<AMAX>::SM;
+    constexpr int AMIN = fxg_clip_k_amin(AMAX);
+    const bool qn = (c == (u32)'N');
+    const float pair_eq = qn ? 0.1f : 1.0f, pair_ne = qn ? 0.1f : -1.0f;                 // sequence_alignment.h:157-169 (adapter without N)
+    const u32 dxr = qn ? 0u : FXG_K_DIA1;
+    const float best_in = best;
+    float uSm = -5.0f;                                                                   // S[q][-1] - 5
+    u32 uW = 0u;
+    const bool eq0 = (c == (u32)(uint8_t)a.adapter[0]);
+    float ul = 0.0f + (eq0 ? pair_eq : pair_ne);                                         // S[q-1][-1] = query_border = 0
+    u32 wd = dxr + (u32)eq0;                                                             // no predecessor left of column 0: the step alone
+#pragma unroll
+    for (int b0 = 0; b0 < AMAX; b0 += 16) {
+        // the match masks of the next 16 diagonals first (a lane mask needs two wait states between its v_cmp and the v_cndmask that reads it)
+        bool eq[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) eq[k] = (b0 + k + 1 < AMAX) ? (c == (u32)(uint8_t)a.adapter[b0 + k + 1]) : false;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int t = b0 + k;
+            if (t >= AMAX) break;
+            float ul_next = 0.0f;
+            u32 wd_next = 0u;
+            if (t + 1 < AMAX) {
+                ul_next = S[t] + (eq[k] ? pair_eq : pair_ne);
+                u32 wdx = W[t] + dxr;
+                FXG_KEEP_V(wdx);                                                         // keeps "+ match" the carry-in of one v_addc_co_u32 (else: select 0/1, or, add)
+                wd_next = wdx + (u32)eq[k];
+            }
+            float left = SM ? Sm[SM ? t : 0] : S[t] + -5.0f;
+            if (EARLY && t > 3) left = (t - 3 > q) ? -100000.0f : left;                  // sequence_alignment.cpp:387-389, rows q < A - 4 only
+            const float sc = fmaxf(fmaxf(ul, uSm), left);
+            const bool isd = (sc == ul), isu = (sc == uSm);                              // diag > up > left on ties (:380-417)
+            u32 w;
+            if (t == 0) {                                                                // diag and up come from outside the matrix: the path starts here
+                const u32 fresh = FXG_K_START(vstart) + FXG_K_SZ1 + (isd ? wd : 0u);
+                w = (isd || isu) ? fresh : W[0];
+            } else {
+                w = isu ? uW : W[t];
+                w = isd ? wd : w;
+            }
+            const u32 wp = w + FXG_K_SZ1;                                                // stored already extended by one gap step, see fxg_clip_row_packed
+            const float scm = sc + -5.0f;
+            S[t] = sc; W[t] = wp;
+            if (SM) Sm[SM ? t : 0] = scm;
+            uSm = scm; uW = wp; ul = ul_next; wd = wd_next;
+            if (!TRACK) continue;
+            if (t < AMIN) {
+                const bool gb = sc > best;
+                bw = gb ? w : bw;
+                best = fmaxf(best, sc);
+            } else {
+                const bool gb = (sc > best) && (t < A);
+                best = gb ? sc : best; bw = gb ? w : bw;
+            }
+        }
+    }
+    if (TRACK) bq = (best > best_in) ? (u32)q : bq;
+}
+
 template <int AMAX>
+FXG_HD void fxg_clip_rows_k(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float &best, u32 &bw, u32 &bq, int &first_n)
+{
+    float S[AMAX], Sm[FxgClipK<AMAX>::NSM];
+    u32 W[AMAX];
+    const int A = a.alen;
+#pragma unroll
+    for (int t = 0; t < AMAX; ++t) {
+        S[t] = (t <= 3) ? 0.0f : -5.0f * (float)(t - 3);                                 // target_border (:355-361)
+        if (FxgClipK<AMAX>::SM) Sm[FxgClipK<AMAX>::SM ? t : 0] = S[t] + -5.0f;
+        W[t] = FXG_K_START(256 + t + 1) + FXG_K_SZ1;                                     // what a path entering diagonally at (0, t + 1) starts from
+    }
+    const int early_rows = (A - 4 < rows) ? (A - 4 > 0 ? A - 4 : 0) : rows;
+    if (rows <= 0) return;
+    int q = 0;
+    u32 cn = rd[0];
+#pragma unroll 1
+    for (; q < early_rows; ++q) {
+        const u32 c = cn;
+        cn = rd[q + 1];
+        first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
+        fxg_clip_row_k<AMAX, true, true>(a, A, c, q, (u32)q, S, Sm, W, best, bw, bq);
+    }
+#pragma unroll 1
+    for (; q < rows; ++q) {
+        const u32 c = cn;
+        cn = rd[q + 1];
+        first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
+        fxg_clip_row_k<AMAX, false, true>(a, A, c, q, (u32)q, S, Sm, W, best, bw, bq);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same two passes as fxg_clip_two_pass for 17..99 adapter columns, where the checkpoints no longer fit in registers: pass 1
+// (scores only, 6-7 VALU instructions per cell) leaves its score row in global scratch every a.clip_ck_rows rows -- slot j - 1 holds
+// the row before row j * clip_ck_rows, [slot][column][thread] so that a wave's store is one line per column -- and finds the row bq1
+// of the first maximum.  The best path covers at most SPAN = A + (A + 1) / 5 rows (see fxg_clip_two_pass), i.e. starts in row
+// r0 = bq1 - SPAN + 1 or later: the scores are re-run from the last checkpoint at or before r0 up to r0, then rows r0..bq1 carry the
+// summaries (fxg_clip_row_k), and only row bq1 looks for the best cell.  A path that starts in pass 2 starts in column 0 (or in row 0
+// when r0 = 0), so its `start` is the row RELATIVE to r0: reads of any length fit the 9 bits.
+// ------------------------------------------------------------------------------------------------
+template <int AMAX, bool EARLY>
+FXG_HD float fxg_clip_row_score_k(const FxgKArgs &a, int A, u32 c, int q, float (&S)[AMAX], float (&Sm)[AMAX])
+{
+    constexpr bool SM = AMAX <= 48;                 // the score rows keep S - 5 as well where that still leaves room: nothing else is live while they run
+    constexpr int AMIN = fxg_clip_k_amin(AMAX);
+    const bool qn = (c == (u32)'N');
+    const float pair_eq = qn ? 0.1f : 1.0f, pair_ne = qn ? 0.1f : -1.0f;
+    float uSm = -5.0f, rowmax = -1000000.0f;
+    float ul = 0.0f + ((c == (u32)(uint8_t)a.adapter[0]) ? pair_eq : pair_ne);
+#pragma unroll
+    for (int b0 = 0; b0 < AMAX; b0 += 16) {
+        bool eq[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) eq[k] = (b0 + k + 1 < AMAX) ? (c == (u32)(uint8_t)a.adapter[b0 + k + 1]) : false;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int t = b0 + k;
+            if (t >= AMAX) break;
+            float ul_next = 0.0f;
+            if (t + 1 < AMAX) ul_next = S[t] + (eq[k] ? pair_eq : pair_ne);
+            float left = SM ? Sm[SM ? t : 0] : S[t] + -5.0f;
+            if (EARLY && t > 3) left = (t - 3 > q) ? -100000.0f : left;
+            const float sc = fmaxf(fmaxf(ul, uSm), left);
+            const float scm = sc + -5.0f;
+            S[t] = sc;
+            if (SM) Sm[SM ? t : 0] = scm;
+            uSm = scm; ul = ul_next;
+            if (t < AMIN) rowmax = fmaxf(rowmax, sc);
+            else rowmax = (t < A) ? fmaxf(rowmax, sc) : rowmax;
+        }
+    }
+    return rowmax;
+}
+
+// returns r0 (the row the `start` field of bw counts from)
+template <int AMAX>
+FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float *ck, u32 cks, float &best, u32 &bw, u32 &bq, int &first_n)
+{
+    float S[AMAX], Sm[AMAX];
+    const int A = a.alen, K = (int)a.clip_ck_rows;
+    const int early_rows = (A - 4 < rows) ? (A - 4 > 0 ? A - 4 : 0) : rows;
+    if (rows <= 0) return 0;
+#pragma unroll
+    for (int t = 0; t < AMAX; ++t) { S[t] = (t <= 3) ? 0.0f : -5.0f * (float)(t - 3); Sm[t] = S[t] + -5.0f; }
+    // ---- pass 1 ----
+    float b1 = -1000000.0f;
+    int bq1 = 0, next_ck = K, q = 0;
+    float *slot = ck;
+    u32 cn = rd[0];
+#define FXG_CK_ROW(EARLY)                                                                                                    \
+    {                                                                                                                        \
+        if (q == next_ck) {                                                                                                  \
+            _Pragma("unroll") for (int t = 0; t < AMAX; ++t) slot[(size_t)t * cks] = S[t];                                   \
+            slot += (size_t)AMAX * cks; next_ck += K;                                                                        \
+        }                                                                                                                    \
+        const u32 c = cn;                                                                                                    \
+        cn = rd[q + 1];                                                                                                      \
+        const float rm = fxg_clip_row_score_k<AMAX, EARLY>(a, A, c, q, S, Sm);                                               \
+        const bool g = rm > b1;                                                                                              \
+        b1 = g ? rm : b1; bq1 = g ? q : bq1;                                                                                 \
+    }
+#pragma unroll 1
+    for (; q < early_rows; ++q) FXG_CK_ROW(true)
+#pragma unroll 1
+    for (; q < rows; ++q) FXG_CK_ROW(false)
+#undef FXG_CK_ROW
+    // ---- pass 2 ----
+    const int span = A + (A + 1) / 5;
+    const int r0 = bq1 - span + 1 > 0 ? bq1 - span + 1 : 0;
+    const int j0 = r0 / K;
+    q = j0 * K;
+    {
+        const float *from = ck + (size_t)(j0 > 0 ? j0 - 1 : 0) * AMAX * cks;
+#pragma unroll
+        for (int t = 0; t < AMAX; ++t) {
+            const float border = (t <= 3) ? 0.0f : -5.0f * (float)(t - 3);
+            S[t] = j0 > 0 ? from[(size_t)t * cks] : border;
+            Sm[t] = S[t] + -5.0f;
+        }
+    }
+    // Every lane has its own rows here, so the loops keep ONE body each: the early form (which tests the row number itself) wherever a
+    // row below A - 4 can occur -- the < clip_ck_rows rows of the score re-run and the first A - 4 rows of the summary window.
+#pragma unroll 1
+    for (; q < r0; ++q) (void)fxg_clip_row_score_k<AMAX, true>(a, A, (u32)rd[q], q, S, Sm);
+    u32 W[AMAX];
+#pragma unroll
+    for (int t = 0; t < AMAX; ++t) W[t] = FXG_K_START(256 + t + 1) + FXG_K_SZ1;         // the cells above row 0 (r0 > 0: never on the best path)
+    float (&Sk)[FxgClipK<AMAX>::NSM] = reinterpret_cast<float (&)[FxgClipK<AMAX>::NSM]>(Sm);    // the summary rows keep S - 5 only where registers allow
+    int i = 0;
+#pragma unroll 1
+    for (; q < bq1 && i < early_rows; ++q, ++i) fxg_clip_row_k<AMAX, true, false>(a, A, (u32)rd[q], q, (u32)(q - r0), S, Sk, W, best, bw, bq);
+#pragma unroll 1
+    for (; q < bq1; ++q) fxg_clip_row_k<AMAX, false, false>(a, A, (u32)rd[q], q, (u32)(q - r0), S, Sk, W, best, bw, bq);
+    fxg_clip_row_k<AMAX, true, true>(a, A, (u32)rd[bq1], bq1, (u32)(bq1 - r0), S, Sk, W, best, bw, bq);
+    if (!(a.clip_flags & FXG_CLIP_KEEP_N)) {                                             // the -n rule needs the first N of the read itself
+#pragma unroll 1
+        for (int k = len - 1; k >= 0; --k) first_n = (rd[k] == (uint8_t)'N') ? k : first_n;
+    }
+    return r0;
+}
+
+// KFORM: the one-word summary of fxg_clip_row_k (17..99 columns; also 16 columns for reads beyond 255 bases, which the register
+// form of fxg_clip_two_pass cannot describe: its start field is absolute)
+template <int AMAX, bool KFORM>
 FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len, int rows,
-                                 u32 *out_len, u32 *keep, u32 *reason, u32 *clipped, u32 *adapter_only)
+                                 u32 *out_len, u32 *keep, u32 *reason, u32 *clipped, u32 *adapter_only, float *ck = nullptr, u32 cks = 0u)
 {
     float best = -1000000.0f;
     u32 bw = FXG_INVALID_TUPLE, bq = 0u;
     int first_n = len;
     // adapters that contain 'N' take the general form (fxg_plan.h): the packed instances keep no per-column neutral selects
 #ifndef FXG_CLIP_ONE_PASS
-    if constexpr (AMAX <= 16) fxg_clip_two_pass<AMAX>(a, rd, len, rows, best, bw, bq, first_n);
+    if constexpr (!KFORM) fxg_clip_two_pass<AMAX>(a, rd, len, rows, best, bw, bq, first_n);
     else
 #endif
-    fxg_clip_rows_packed<AMAX, false>(a, rd, len, rows, best, bw, bq, first_n);
+    if constexpr (!KFORM) fxg_clip_rows_packed<AMAX, false>(a, rd, len, rows, best, bw, bq, first_n);
+    if constexpr (KFORM) {
+        int r0 = 0;
+        if (ck) r0 = fxg_clip_two_pass_k<AMAX>(a, rd, len, rows, ck, cks, best, bw, bq, first_n);
+        else fxg_clip_rows_k<AMAX>(a, rd, len, rows, best, bw, bq, first_n);
+        const int v = (int)(bw >> 23), matches = (int)(bw & 127u), diag = (int)((bw >> 7) & 127u);
+        fxg_clip_finish(a, len, v < 256 ? r0 + v : 0, v < 256 ? 0 : v - 256, diag - matches, (int)((bw >> 14) & 511u), matches,
+                        (int)bq, first_n, out_len, keep, reason, clipped, adapter_only);
+        return;
+    }
     const int matches = (int)(bw & 31u), diag = (int)((bw >> 14) & 31u);
     fxg_clip_finish(a, len, (int)(bw >> 24), (int)((bw >> 19) & 31u), diag - matches, (int)((bw >> 5) & 511u), matches,
                     (int)bq, first_n, out_len, keep, reason, clipped, adapter_only);
@@ -507,10 +748,12 @@ FXG_HD void fxg_phase_stage_bases(const uint8_t *src, u64 total, u64 tb, u32 tby
 }
 
 // phase 2, group A: thread tid decides read r0 + tid
-// AMAX > 0: general clipper; AMAX < 0: packed clipper with bucket -AMAX (reads <= 255, adapter <= 31)
+// AMAX > 0: general clipper; AMAX < 0: packed clipper with bucket -AMAX columns (-216: 16 columns in the form of the 17..99 buckets)
+__host__ __device__ constexpr int fxg_clip_cols(int amax) { return amax <= -200 ? -amax - 200 : -amax; }
+__host__ __device__ constexpr bool fxg_clip_kform(int amax) { return amax < -16; }
 template <int AMAX>
 FXG_HD u32 fxg_decide_a(const FxgKArgs &a, const u32 *bm_g, const u32 *bm_l, const uint8_t *sb, u32 r0, u32 tid,
-                        u32 *keep_out, u32 *len_out)
+                        u32 *keep_out, u32 *len_out, float *ck = nullptr, u32 cks = 0u)      // ck: this thread's checkpoint scratch (fxg_clip_two_pass_k), cks its stride
 {
     const u32 stride = a.stride;
     const u32 rl = a.len ? (u32)a.len[r0 + tid] : a.fixed_len;
@@ -519,8 +762,10 @@ FXG_HD u32 fxg_decide_a(const FxgKArgs &a, const u32 *bm_g, const u32 *bm_l, con
     if constexpr (AMAX > 0) fxg_clip_read<AMAX>(a, sb + tid * a.clip_stride, (int)rl, rows, &curlen, &keep, &reason, &clipped, &ao);
     if constexpr (AMAX < 0) {
         // fixed-length batch without clip history: the row count is a scalar, so every loop of the DP is a scalar loop
-        if (!a.len && !a.wlen) fxg_clip_read_packed<-AMAX>(a, sb + tid * a.clip_stride, (int)a.fixed_len, (int)a.fixed_len, &curlen, &keep, &reason, &clipped, &ao);
-        else fxg_clip_read_packed<-AMAX>(a, sb + tid * a.clip_stride, (int)rl, rows, &curlen, &keep, &reason, &clipped, &ao);
+        constexpr int COLS = fxg_clip_cols(AMAX);
+        constexpr bool KF = fxg_clip_kform(AMAX);
+        if (!a.len && !a.wlen) fxg_clip_read_packed<COLS, KF>(a, sb + tid * a.clip_stride, (int)a.fixed_len, (int)a.fixed_len, &curlen, &keep, &reason, &clipped, &ao, ck, cks);
+        else fxg_clip_read_packed<COLS, KF>(a, sb + tid * a.clip_stride, (int)rl, rows, &curlen, &keep, &reason, &clipped, &ao, ck, cks);
     }
     if (keep && (a.stages & FXG_STAGE_QTRIM)) {             // fastq_quality_trimmer.c:94-101
         const u32 k = fxg_bits_last(bm_g, tid * stride, curlen);
@@ -650,9 +895,13 @@ __device__ __forceinline__ void fxg_tile_tally(u32 w, bool valid, u64 *tally)
 // one step of slack (all the streaming instances need) is not enough where a step is a 50-microsecond DP whose speed depends on
 // what the other three waves of the SIMD are doing -- the clip instances waited for the prefix 17 % of their time
 // (profiles/r03/c_ablate_clip.txt); two steps behind, the slowest of the ~1000 tiles in flight has a whole extra DP to catch up.
+// waves per SIMD the clip instances are compiled for: the packed forms keep 2-3 registers per adapter column (two-pass: 6 of <= 16)
+// (64 columns at three waves = 168 registers spilled and came out WRONG on the GPU in the two-pass form -- 19 of 223 reads of one
+// adversarial case, the emulator and every other bucket agreeing with the oracle; at two waves nothing spills and it is right)
+__host__ __device__ constexpr int fxg_clip_waves(int amax) { return amax > 0 ? 1 : (amax >= -32 || amax <= -200) ? FXG_CLIP_WAVES : amax >= -48 ? 3 : 2; }
 template <int AMAX, int MODE> struct FxgTileBlock { static constexpr int threads = (MODE == 0 && AMAX < 0 && AMAX >= -16) ? FXG_CLIP_TBLOCK : FXG_TBLOCK; };
 template <int AMAX, int MODE>
-__global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? FXG_MIN_WAVES : ((AMAX < 0 && AMAX >= -16) ? FXG_CLIP_WAVES : 1))) void fxg_kernel_tiles(const FxgKArgs a)
+__global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? FXG_MIN_WAVES : fxg_clip_waves(AMAX))) void fxg_kernel_tiles(const FxgKArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool REV = (MODE == 2);
@@ -719,7 +968,10 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
             FXG_TPHASE(0);
             u32 keep = 0, olen = 0, anchor = tid * stride, word = 0;
             if (tid < nreads) {
-                if constexpr (MODE == 0) word = fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen);
+                if constexpr (MODE == 0 && AMAX < -16) {
+                    float *ck = a.clip_ck ? a.clip_ck + (size_t)blockIdx.x * ((size_t)FXG_CK_SLOTS * (u32)fxg_clip_cols(AMAX) * TB) + tid : nullptr;
+                    word = fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen, ck, TB);
+                } else if constexpr (MODE == 0) word = fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen);
                 else if constexpr (MODE == 3) { u32 nl; word = fxg_decide_mask(a, bm_l, r0, tid, &keep, &olen, &nl); m_nt += nl; m_reads += (nl != 0u); }
                 else if constexpr (MODE == 4) word = fxg_decide_census(a, sb + tid * stride, r0, tid, &keep, &olen, &art_bad);
                 else word = fxg_decide_b<REV>(a, r0, tid, &keep, &olen, &anchor);

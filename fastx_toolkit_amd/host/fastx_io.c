@@ -107,10 +107,12 @@ int fxh_reader_line(struct fxh_reader *r, const char **p, size_t *raw, int may_r
     }
 }
 
-size_t fxh_chomp_len(const char *s, size_t n)   /* chomp.c:36-41: cut at the first CR or LF */
+/* chomp.c:36-41: cut at the first CR or LF.  The reference's lines are C strings (fgets into a buffer, then strlen / %s), so a NUL byte
+ * ends a line's content the same way: what follows it up to the newline is read and never looked at. */
+size_t fxh_chomp_len(const char *s, size_t n)
 {
     size_t k = 0;
-    while (k < n && s[k] != '\r' && s[k] != '\n') k++;
+    while (k < n && s[k] != '\r' && s[k] != '\n' && s[k] != '\0') k++;
     return k;
 }
 
@@ -178,7 +180,9 @@ int fxh_next_raw(FASTX *fx, struct fxh_rawrec *rec, int may_refill)
         return -2;
     }
     if (!fx->read_fastq && rec->prefix != '>') {
-        size_t k = fxh_chomp_len(p, raw), i = 0;
+        /* fastx.c:327,337: only the name (from the second byte on) is chomped before the "is this a line of bases" test, so a line
+         * that STARTS with CR or LF -- a blank line -- fails it, while an empty C string (leading NUL) passes */
+        size_t k = p[0] ? 1 + fxh_chomp_len(p + 1, raw - 1) : 0, i = 0;
         while (i < k && fx->allowed_nucleotides[(unsigned char)p[i]]) i++;
         if (i == k)
             fxh_fail(fx, rec, "Invalid input: This looks like a multi-line FASTA file.\nLine %lld contains a nucleotides string instead of a '>' prefix.\n"

@@ -83,7 +83,10 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
             }
             for (u32 tid = 0; tid < nreads; ++tid) {
                 if (AMAX == 0 && pl.rows_nw) emu_rows_decide(pl.rows_nw, pl.rows_h, a, r0 + tid, &keep[tid], &olen[tid]);   // what a lane of fxg_kernel_rows does
-                else fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid]);
+                else if (AMAX < -16 && pl.ck_per_wg) {        // the two-pass form with its checkpoint scratch (here: one thread's, stride 1)
+                    std::vector<float> ck((size_t)FXG_CK_SLOTS * (size_t)(AMAX < 0 ? fxg_clip_cols(AMAX) : 1), 1.0e30f);   // the device's scratch is not cleared either
+                    fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid], ck.data(), 1u);
+                } else fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid]);
                 anchor[tid] = tid * stride;
             }
         } else if (MODE == 3) {
@@ -206,6 +209,11 @@ extern "C" int fxg_emu_run_pipeline_hist(const fxg_batch *in, const fxg_params *
         case -24: return emu_run<-24, false>(pl, ctr, err, cap);
         case -28: return emu_run<-28, false>(pl, ctr, err, cap);
         case -32: return emu_run<-32, false>(pl, ctr, err, cap);
+        case -40: return emu_run<-40, false>(pl, ctr, err, cap);
+        case -48: return emu_run<-48, false>(pl, ctr, err, cap);
+        case -64: return emu_run<-64, false>(pl, ctr, err, cap);
+        case -100: return emu_run<-100, false>(pl, ctr, err, cap);
+        case -216: return emu_run<-216, false>(pl, ctr, err, cap);
         case 16: return emu_run<16, false>(pl, ctr, err, cap);
         case 32: return emu_run<32, false>(pl, ctr, err, cap);
         case 64: return emu_run<64, false>(pl, ctr, err, cap);

@@ -146,3 +146,63 @@ FLAG_ERROR_CASES = [
     (["fastq_quality_trimmer", "-t", "20", "-x"], _REC),                 # unknown option: getopt's message, then the usage hint
     (["fastx_artifacts_filter", "-q", "3"], _REC),
 ]
+
+
+def adversarial_clip_cases(long_adapters):
+    """Yields (name, bases, qual, params_dict): inputs built to stress the clip kernels' bound on the best path's length -- every adapter
+    length 1..16 (all packed buckets of the two-pass form) or, with long_adapters, 17..99 (every bucket of the one-pass in-place form);
+    low-complexity reads and adapters (long runs of ties), N-rich reads and adapters, adapters repeated along the read, reads shorter
+    than the adapter, best cells in the first / last rows, an insertion / deletion right before a planted adapter."""
+    rng = np.random.default_rng(11)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for trial in range(96):
+        alen = 1 + trial % 16
+        if long_adapters:
+            alen = [17, 20, 21, 24, 25, 28, 29, 31, 32, 33, 34, 40, 41, 48, 49, 58, 64, 65, 80, 99][trial % 20]
+        kind = trial % 6
+        if kind == 0:
+            ad = bytes(rng.choice(acgt, size=alen))
+        elif kind == 1:
+            ad = bytes([int(rng.choice(acgt))]) * alen                          # homopolymer adapter
+        elif kind == 2:
+            ad = (b"AC" * alen)[:alen]
+        elif kind == 3:
+            ad = bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=alen))
+        elif kind == 4:
+            ad = (b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACATCACGATCTCGTATGCCGTCTTCTGCTTGAAAAAAAAAAGGGGGGGGGGCCCCCCCCCCTTTTTTTTTT")[:alen]
+        else:
+            ad = bytes(rng.choice(acgt[:2], size=alen))
+        if ad.count(b"N") == alen:
+            ad = b"A" + ad[1:]
+        stride = int(rng.choice([3, 8, 17, 30, 64, 100, 150, 255, 300, 421]))    # beyond 255: only the forms with a relative path start
+        n = int(rng.integers(50, 400))
+        style = trial % 5
+        if style == 0:
+            b = rng.choice(acgt, size=(n, stride))
+        elif style == 1:
+            b = rng.choice(acgt[:2], size=(n, stride))                          # two-letter reads: ties everywhere
+        elif style == 2:
+            b = np.full((n, stride), ad[0], dtype=np.uint8)                     # homopolymer reads
+            b[rng.random((n, stride)) < 0.05] = ord("C")
+        elif style == 3:
+            b = rng.choice(acgt, size=(n, stride))
+            b[rng.random((n, stride)) < 0.25] = ord("N")
+        else:
+            reps = np.frombuffer((ad * (stride // len(ad) + 2))[:stride], dtype=np.uint8)
+            b = np.tile(reps, (n, 1))
+            b[rng.random((n, stride)) < 0.1] = rng.choice(acgt)
+        b = np.ascontiguousarray(b)
+        adv = np.frombuffer(ad, dtype=np.uint8)
+        for i in range(0, n, 3):                                                 # plant (damaged) adapters, also at the very start / end
+            pos = int(rng.choice([0, 1, max(0, stride - alen), max(0, stride - 2), int(rng.integers(0, stride))]))
+            k = min(alen, stride - pos)
+            a2 = adv.copy()
+            if rng.random() < 0.5:
+                a2[int(rng.integers(0, alen))] = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8))
+            b[i, pos:pos + k] = a2[:k]
+            if rng.random() < 0.3 and pos > 1:                                   # an insertion / deletion right before it
+                b[i, pos - 1] = b[i, pos]
+        q = rng.integers(33, 75, size=(n, stride), dtype=np.uint8)
+        for flags in (0, 4, int(rng.integers(0, 16))):
+            pd = dict(stages=1, adapter=ad, clip_min_len=int(rng.integers(0, 12)), clip_min_adapter_len=int(rng.choice([0, 0, 2, 5])), clip_flags=flags)
+            yield "clip2.t%d.a%s.s%d.f%d" % (trial, ad.decode(), stride, flags), b, q, pd

@@ -5,9 +5,10 @@ per-read decision incl. the forward-carried clipper DP, 16-byte chunk gather, re
 only the wave-level scan / look-back is replaced by a serial prefix.  Bit-exact or it fails.
 """
 import numpy as np
+import pytest
 
 import emu_py as emu
-from helpers import assert_same, fuzz_cases, oracle_params
+from helpers import adversarial_clip_cases, assert_same, fuzz_cases, oracle_params
 from oracle import fxoracle_py as fo
 
 
@@ -128,65 +129,17 @@ def test_emulated_long_reads():
         qs.close()
 
 
-def test_emulated_clip_two_pass_adversarial():
-    """The two-pass clipper (score pass + restart from a checkpoint, fxg_clip_two_pass) against the oracle's full matrix + traceback on
-    inputs built to stress its bound on the best path's length: every adapter length 1..16 (all packed buckets of the two-pass form),
-    low-complexity reads and adapters (long runs of ties), N-rich reads and adapters, adapters repeated along the read, reads shorter
-    than the adapter, best cells in the first / last rows."""
-    rng = np.random.default_rng(11)
-    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+@pytest.mark.parametrize("form", ["short", "long", "long-one-pass"])
+def test_emulated_clip_two_pass_adversarial(form, monkeypatch):
+    """The two-pass clipper (score pass + restart from a checkpoint, fxg_clip_two_pass) and, for adapters of 17..99 bases, its
+    counterpart with the checkpoints in scratch (fxg_clip_two_pass_k; reads beyond 255 bases included) and the one-pass in-place form
+    (fxg_clip_rows_k: short reads, or everywhere with FXG_CLIP_K_ONE_PASS) against the oracle's full matrix + traceback on
+    helpers.adversarial_clip_cases."""
     checked = 0
-    for trial in range(96):
-        alen = 1 + trial % 16
-        kind = trial % 6
-        if kind == 0:
-            ad = bytes(rng.choice(acgt, size=alen))
-        elif kind == 1:
-            ad = bytes([int(rng.choice(acgt))]) * alen                          # homopolymer adapter
-        elif kind == 2:
-            ad = (b"AC" * alen)[:alen]
-        elif kind == 3:
-            ad = bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=alen))
-        elif kind == 4:
-            ad = (b"AGATCGGAAGAGCACAC")[:alen]
-        else:
-            ad = bytes(rng.choice(acgt[:2], size=alen))
-        if ad.count(b"N") == alen:
-            ad = b"A" + ad[1:]
-        stride = int(rng.choice([3, 8, 17, 30, 64, 100, 150, 255]))
-        n = int(rng.integers(50, 400))
-        style = trial % 5
-        if style == 0:
-            b = rng.choice(acgt, size=(n, stride))
-        elif style == 1:
-            b = rng.choice(acgt[:2], size=(n, stride))                          # two-letter reads: ties everywhere
-        elif style == 2:
-            b = np.full((n, stride), ad[0], dtype=np.uint8)                     # homopolymer reads
-            b[rng.random((n, stride)) < 0.05] = ord("C")
-        elif style == 3:
-            b = rng.choice(acgt, size=(n, stride))
-            b[rng.random((n, stride)) < 0.25] = ord("N")
-        else:
-            reps = np.frombuffer((ad * (stride // len(ad) + 2))[:stride], dtype=np.uint8)
-            b = np.tile(reps, (n, 1))
-            b[rng.random((n, stride)) < 0.1] = rng.choice(acgt)
-        b = np.ascontiguousarray(b)
-        adv = np.frombuffer(ad, dtype=np.uint8)
-        for i in range(0, n, 3):                                                 # plant (damaged) adapters, also at the very start / end
-            pos = int(rng.choice([0, 1, max(0, stride - alen), max(0, stride - 2), int(rng.integers(0, stride))]))
-            k = min(alen, stride - pos)
-            a2 = adv.copy()
-            if rng.random() < 0.5:
-                a2[int(rng.integers(0, alen))] = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8))
-            b[i, pos:pos + k] = a2[:k]
-            if rng.random() < 0.3 and pos > 1:                                   # an insertion / deletion right before it
-                b[i, pos - 1] = b[i, pos]
-        q = rng.integers(33, 75, size=(n, stride), dtype=np.uint8)
-        for flags in (0, 4, int(rng.integers(0, 16))):
-            pd = dict(stages=1, adapter=ad, clip_min_len=int(rng.integers(0, 12)), clip_min_adapter_len=int(rng.choice([0, 0, 2, 5])), clip_flags=flags)
-            p = oracle_params(pd)
-            o = fo.run_pipeline(b, q, None, p)
-            e = emu.run_pipeline(b, q, None, p)
-            assert_same(o, e, "clip2.t%d.a%s.s%d.f%d" % (trial, ad.decode(), stride, flags))
-            checked += n
+    if form == "long-one-pass":
+        monkeypatch.setenv("FXG_CLIP_K_ONE_PASS", "1")
+    for name, b, q, pd in adversarial_clip_cases(form != "short"):
+        p = oracle_params(pd)
+        assert_same(fo.run_pipeline(b, q, None, p), emu.run_pipeline(b, q, None, p), name)
+        checked += b.shape[0]
     assert checked > 40000

@@ -7,7 +7,7 @@ size-independent properties (prefix/suffix windows vs the oracle, offset algebra
 import numpy as np
 import pytest
 
-from helpers import assert_same, fuzz_cases, md5, oracle_params
+from helpers import adversarial_clip_cases, assert_same, fuzz_cases, md5, oracle_params
 from oracle import fxoracle_py as fo
 
 pytestmark = pytest.mark.gpu
@@ -98,6 +98,21 @@ def test_fuzz_vs_oracle(engine):
         assert_same(o, e, name)
         kept += int(o["counters"][1])
     assert kept > 10000
+
+
+@pytest.mark.parametrize("long_adapters", [False, True])
+def test_clip_adversarial_every_adapter_bucket(engine, long_adapters):
+    """Every clip instance on the inputs built against its assumptions (helpers.adversarial_clip_cases): adapters of 1..16 bases run
+    the two-pass form in registers (reads beyond 255 bases: instance -216), 17..99 the two-pass form with checkpoints in scratch or,
+    for short reads, its one-pass form, adapters with N the general form -- all against the oracle's full matrix + traceback.  The kernel that ran is checked, so a bucket that silently fell back to the general form would fail here."""
+    seen = set()
+    for name, b, q, pd in adversarial_clip_cases(long_adapters):
+        assert_same(fo.run_pipeline(b, q, None, oracle_params(pd)), _run(engine, b, q, None, pd, fixed_len=b.shape[1]), name)
+        k = engine.last_launch()["kernel"]
+        assert ("clip(packed)" in k) == (b"N" not in pd["adapter"]), (name, k)
+        seen.add(k.split(" ")[0])
+    want = {"fxg_kernel_tiles<-%d,0>" % a for a in ((20, 24, 28, 32, 40, 48, 64, 100) if long_adapters else (4, 8, 9, 10, 11, 12, 13, 14, 15, 16, 216))}
+    assert want <= seen, sorted(want - seen)
 
 
 def test_both_quality_kernels_on_the_same_batches(engine, monkeypatch):
