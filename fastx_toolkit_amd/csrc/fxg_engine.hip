@@ -413,6 +413,7 @@ extern "C" int fxg_run_pipeline(fxg_ctx *c, const fxg_batch *in, const fxg_param
         case -24: return fxg_launch_tiles(c, FXG_TILES_A(-24), "fxg_kernel_tiles<-24,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case -28: return fxg_launch_tiles(c, FXG_TILES_A(-28), "fxg_kernel_tiles<-28,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case -32: return fxg_launch_tiles(c, FXG_TILES_A(-32), "fxg_kernel_tiles<-32,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -36: return fxg_launch_tiles(c, FXG_TILES_A(-36), "fxg_kernel_tiles<-36,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case -40: return fxg_launch_tiles(c, FXG_TILES_A(-40), "fxg_kernel_tiles<-40,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case -48: return fxg_launch_tiles(c, FXG_TILES_A(-48), "fxg_kernel_tiles<-48,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case -64: return fxg_launch_tiles(c, FXG_TILES_A(-64), "fxg_kernel_tiles<-64,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);

@@ -411,7 +411,7 @@ FXG_HD void fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int
 #define FXG_K_SZ1  (1u << 14)
 #define FXG_K_START(v) ((u32)(v) << 23)
 // smallest adapter of the bucket AMAX (fxg_plan.h): columns below it always count towards the best cell
-__host__ __device__ constexpr int fxg_clip_k_amin(int amax) { return amax <= 16 ? 1 : amax <= 20 ? 17 : amax <= 32 ? amax - 3 : amax <= 48 ? amax - 7 : amax <= 64 ? 49 : 65; }
+__host__ __device__ constexpr int fxg_clip_k_amin(int amax) { return amax <= 16 ? 1 : amax <= 20 ? 17 : amax <= 40 ? amax - 3 : amax <= 48 ? 41 : amax <= 64 ? 49 : 65; }
 template <int AMAX> struct FxgClipK { static constexpr bool SM = AMAX <= 28; static constexpr int NSM = SM ? AMAX : 1; };
 
 template <int AMAX, bool EARLY, bool TRACK>

@@ -113,7 +113,7 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
         // packed path summary (one u32 per cell); buckets are fine-grained because every padded column costs a full cell.
         // Up to 16 columns: two passes in registers (fxg_clip_two_pass); 17..99: fxg_clip_rows_k / fxg_clip_two_pass_k.
         // Adapters that contain 'N' (a neutral select per column) stay with the general form.
-        static const int pk[] = {4, 8, 9, 10, 11, 12, 13, 14, 15, 16, 20, 24, 28, 32, 40, 48, 64, 100};
+        static const int pk[] = {4, 8, 9, 10, 11, 12, 13, 14, 15, 16, 20, 24, 28, 32, 36, 40, 48, 64, 100};      // 36: the 33/34-base TruSeq adapters
         int b = 100;
         for (unsigned i = 0; i < sizeof pk / sizeof pk[0]; ++i) if (ka.alen <= pk[i]) { b = pk[i]; break; }
         if (b < 16 && ka.clip_stride > 255u) b = 16;             // reads beyond 255 bases: only the form with the relative start can describe them

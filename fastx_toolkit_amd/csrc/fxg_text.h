@@ -105,12 +105,16 @@ FXG_HD u32x4 fxg_text16(const uint8_t *text, u64 off, u64 text_len)
     return v;
 }
 
-// one lane's 16 bytes of a segment: newline mask (and carriage-return mask) of text[off, off + 16)
+// one lane's 16 bytes of a segment: newline mask of text[off, off + 16); *cr (optional): carriage-return mask in the low half, NUL
+// bytes of the text in the high half (the reference's lines are C strings: a NUL ends a line's content, which only the host reader does)
 FXG_HD u32 fxg_text_nl_mask(const uint8_t *text, u64 off, u64 text_len, u32 *cr)
 {
     if (off >= text_len) { if (cr) *cr = 0u; return 0u; }
     const u32x4 v = fxg_text16(text, off, text_len);
-    if (cr) *cr = fxg_eq_mask16(v, '\r');
+    if (cr) {
+        const u32 valid = text_len - off >= 16u ? 0xFFFFu : ((1u << (u32)(text_len - off)) - 1u);      // fxg_text16 zero-fills past the end
+        *cr = fxg_eq_mask16(v, '\r') | ((fxg_eq_mask16(v, 0) & valid) << 16);
+    }
     return fxg_eq_mask16(v, '\n');
 }
 // the newlines of one lane's mask are lines j, j + 1, ...: line_end[j] = their position, line_start[j + 1] = the byte after
@@ -134,7 +138,8 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_nl_count(const uint8_t *
     u32 c = (u32)__builtin_popcount(fxg_text_nl_mask(text, off, text_len, &cr));
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
     if (fxg_lane() == 0) wsum[threadIdx.x >> 6] = c;
-    if (__ballot(cr != 0u) != 0ull && fxg_lane() == 0) atomicOr(&st->has_cr, 1u);
+    if (__ballot((cr & 0xFFFFu) != 0u) != 0ull && fxg_lane() == 0) atomicOr(&st->has_cr, 1u);
+    if (__ballot((cr >> 16) != 0u) != 0ull && fxg_lane() == 0) atomicOr(&st->irregular, FXG_TEXT_IRR_NUL);
     __syncthreads();
     if (threadIdx.x == 0) seg_count[blockIdx.x] = (u64)wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }

@@ -26,7 +26,7 @@ enum { ALL = 0, NUC_INDEX_SIZE = 6 };
 static const char *nucleotide_index_name[NUC_INDEX_SIZE] = {"ALL", "A", "C", "G", "T", "N"};
 
 /* fastx_quality_stats.c:115-134.  The reference declares these after including fastx.h, which leaves #pragma pack(1) on
- * (fastx.h:37), and keeps them in one static array; get_nth_value (:237-243) walks past the end of bases_values_count when a
+ * (fastx.h:61), and keeps them in one static array; get_nth_value (:237-243) walks past the end of bases_values_count when a
  * class has bases but no qualities (FASTA input) and lands on the next record's min = 100.  Same layout here, so the same
  * walk reads the same numbers (and, like there, a quality of 93 indexes one past the array: SURVEY N2). */
 #pragma pack(push, 1)
@@ -104,12 +104,16 @@ static int get_nth_value(size_t cycle, int nucleotide, int n)   /* :218-247 */
         fprintf(stderr, "Internal error at get_nth_value (cycle=%d, nucleotide=%d, n=%d), count_values[%d]=%d\n", (int)cycle, nucleotide, n, (int)cycle, d->count);
         exit(1);
     }
+    /* the walk may leave this class' array (FASTA input: bases but no qualities) and run through its neighbours -- as in the reference,
+     * whose numbers it then reproduces -- but not past the end of `cycles`: there the reference reads whatever globals follow, this stops */
+    const int last = (int)(((const char *)cycles + sizeof cycles - (const char *)d->bases_values_count) / (ptrdiff_t)sizeof(int)) - 1;
     int pos = 0;
     while (n > 0) {
         if (d->bases_values_count[pos] > n) break;
         n -= d->bases_values_count[pos];
+        if (pos >= last) break;
         pos++;
-        while (d->bases_values_count[pos] == 0 && (const char *)&d->bases_values_count[pos + 1] < (const char *)cycles + sizeof cycles) pos++;
+        while (d->bases_values_count[pos] == 0 && pos < last) pos++;
     }
     return pos + MIN_QUALITY_VALUE;
 }

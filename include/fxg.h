@@ -235,6 +235,7 @@ typedef struct fxg_text_info {
 #define FXG_TEXT_IRR_BASE      0x10u
 #define FXG_TEXT_IRR_QUAL      0x20u
 #define FXG_TEXT_IRR_TAIL      0x40u
+#define FXG_TEXT_IRR_NUL       0x80u   /* a NUL byte: the reference's lines are C strings, the host reader cuts them there */
 #define FXG_REC_NUMERIC_QUAL   0x01u   /* d_flags[record]: numeric quality line */
 
 /* d_text: device, readable up to text_len + 16 bytes, every line '\n'-terminated (the caller appends one at end of input).

@@ -367,13 +367,19 @@ static int run_align(int argc, char **argv)
 
 /* ---- fastx_quality_stats.c:115-463 (struct nucleotide_data, read_file, get_nth_value, both print functions) ---- */
 struct qs_nuc { int min, max, count; unsigned long long sum; int values[QUALITY_VALUES_RANGE]; };
-static std::vector<qs_nuc> qs_cycles;       /* [column * 6 + nucleotide]; the reference has a static [MAX_SEQ_LINE_LENGTH][6] */
+/* [column * 6 + nucleotide], static and initialised to its end like the reference's (:136, :158-163): get_nth_value walks past a
+ * class that has bases but no qualities (FASTA input) into its neighbours, so what lies there is part of the behaviour.  fastx.h
+ * leaves #pragma pack(1) on (:61), here as there. */
+static qs_nuc qs_store[(size_t)MAX_SEQ_LINE_LENGTH * 6];
+static size_t qs_used = 0;                  /* cycles with data */
 static int qs_new_format = 0;
 static qs_nuc &qs_at(size_t col, int nuc)
 {
-    const size_t need = (col + 1) * 6;
-    while (qs_cycles.size() < need) { qs_nuc z; memset(&z, 0, sizeof z); z.min = 100; z.max = -100; qs_cycles.push_back(z); }   /* init_values :158-163 */
-    return qs_cycles[col * 6 + (size_t)nuc];
+    static bool init = false;
+    if (!init) { for (size_t i = 0; i < (size_t)MAX_SEQ_LINE_LENGTH * 6; ++i) { qs_store[i].min = 100; qs_store[i].max = -100; } init = true; }   /* init_values */
+    if (col >= (size_t)MAX_SEQ_LINE_LENGTH) errx(1, "Internal error: sequence too long. Hard-coded max. length is %d", MAX_SEQ_LINE_LENGTH);
+    if (col + 1 > qs_used) qs_used = col + 1;
+    return qs_store[col * 6 + (size_t)nuc];
 }
 static int qs_nuc_index(int c)              /* :142-155 */
 {
@@ -429,7 +435,7 @@ static int run_quality_stats(int argc, char **argv)
             }
         }
     }
-    const size_t ncols = qs_cycles.size() / 6;
+    const size_t ncols = qs_used;
     if (qs_new_format) {                                                            /* print_statistics :296-334 */
         static const char *nn[6] = {"ALL", "A", "C", "G", "T", "N"};
         static const char *hd[11] = {"count", "min", "max", "sum", "mean", "Q1", "med", "Q3", "IQR", "lW", "rW"};

@@ -209,6 +209,7 @@ extern "C" int fxg_emu_run_pipeline_hist(const fxg_batch *in, const fxg_params *
         case -24: return emu_run<-24, false>(pl, ctr, err, cap);
         case -28: return emu_run<-28, false>(pl, ctr, err, cap);
         case -32: return emu_run<-32, false>(pl, ctr, err, cap);
+        case -36: return emu_run<-36, false>(pl, ctr, err, cap);
         case -40: return emu_run<-40, false>(pl, ctr, err, cap);
         case -48: return emu_run<-48, false>(pl, ctr, err, cap);
         case -64: return emu_run<-64, false>(pl, ctr, err, cap);
@@ -305,7 +306,8 @@ extern "C" int fxg_emu_fastq_index(FxgTextState *st, const uint8_t *text, uint64
             const u64 off = seg * FXG_TEXT_SEG + (u64)t * 16;
             u32 cr = 0;
             const u32 m = fxg_text_nl_mask(text, off, text_len, &cr);
-            if (cr) st->has_cr = 1u;
+            if (cr & 0xFFFFu) st->has_cr = 1u;
+            if (cr >> 16) st->irregular |= FXG_TEXT_IRR_NUL;
             fxg_text_nl_store(m, off, j, ls, le, cap_lines);
             j += (u64)__builtin_popcount(m);
         }

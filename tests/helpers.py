@@ -158,7 +158,7 @@ def adversarial_clip_cases(long_adapters):
     for trial in range(96):
         alen = 1 + trial % 16
         if long_adapters:
-            alen = [17, 20, 21, 24, 25, 28, 29, 31, 32, 33, 34, 40, 41, 48, 49, 58, 64, 65, 80, 99][trial % 20]
+            alen = [17, 20, 21, 24, 25, 28, 29, 31, 32, 33, 34, 36, 37, 40, 41, 48, 49, 64, 65, 99][trial % 20]
         kind = trial % 6
         if kind == 0:
             ad = bytes(rng.choice(acgt, size=alen))

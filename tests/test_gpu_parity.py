@@ -111,7 +111,7 @@ def test_clip_adversarial_every_adapter_bucket(engine, long_adapters):
         k = engine.last_launch()["kernel"]
         assert ("clip(packed)" in k) == (b"N" not in pd["adapter"]), (name, k)
         seen.add(k.split(" ")[0])
-    want = {"fxg_kernel_tiles<-%d,0>" % a for a in ((20, 24, 28, 32, 40, 48, 64, 100) if long_adapters else (4, 8, 9, 10, 11, 12, 13, 14, 15, 16, 216))}
+    want = {"fxg_kernel_tiles<-%d,0>" % a for a in ((20, 24, 28, 32, 36, 40, 48, 64, 100) if long_adapters else (4, 8, 9, 10, 11, 12, 13, 14, 15, 16, 216))}
     assert want <= seen, sorted(want - seen)
 
 

@@ -383,3 +383,67 @@ def test_one_long_read_among_short_ones_does_not_blow_up_the_rows(tools):
             assert (rc, out) == (rrc, rout)
         else:
             assert out.count(b"\n") == (4 * 150002 if argv[0] != "fastq_quality_trimmer" else out.count(b"\n"))
+
+
+def _corner_corpus():
+    """Hand-written malformed / corner-case inputs (the reader rules R1-R9 at their edges): what the reference does with each is
+    whatever its fgets + chomp + strlen code does, and the tools must do the same -- exit code, stdout, message."""
+    rec = b"@r1\nACGTACGTAC\n+\nIIIIIIIIII\n"
+    rec2 = b"@r2 desc\nTTGCANNACG\n+r2 desc\n#5?IIII#5I\n"
+    C = {
+     "empty": b"", "only_newline": b"\n", "just_at": b"@", "header_only": b"@r1\n", "two_lines": b"@r1\nACGT\n", "three_lines": b"@r1\nACGT\n+\n",
+     "no_final_newline": rec[:-1], "truncated_quality": b"@r1\nACGTACGT\n+\nIII\n", "long_quality": b"@r1\nACGT\n+\nIIIIIIII\n",
+     "bad_base": b"@r1\nACGXT\n+\nIIIII\n", "lowercase": b"@r1\nacgt\n+\nIIII\n", "empty_sequence": b"@r1\n\n+\n\n", "no_plus": b"@r1\nACGT\n-\nIIII\n",
+     "crlf": rec.replace(b"\n", b"\r\n") * 3, "cr_only": rec.replace(b"\n", b"\r"), "mixed_numeric": rec + b"@r2\nACGT\n+\n40 40 30 2\n" + rec,
+     "numeric_overflow": b"@r1\nAC\n+\n99999999999999999999 3\n", "numeric_negative": b"@r1\nACG\n+\n-5 -15 -16\n", "numeric_junk": b"@r1\nACG\n+\n3 x 4\n",
+     "quality_too_high": b"@r1\nACGT\n+\nII\x7fI\n", "quality_too_low": b"@r1\nACGT\n+\nII\x10I\n", "high_bit": b"@r1\nACGT\n+\nII\xffI\n",
+     "fasta": b">1-5\nACGTN\n>2\nTTGCA\n", "fasta_in_fastq": rec + b">x\nACGT\n", 
+     "blank_between": rec + b"\n" + rec, "garbage": bytes(range(256)) * 4, "many_small": b"@\nA\n\nI\n" * 50,
+     "second_record_bad": rec * 50 + b"@bad\nACGT\n+\nII\n" + rec * 50,
+     # new ones
+     "leading_blank": b"\n" + rec, "trailing_blanks": rec + b"\n\n", "space_in_seq": b"@r1\nACG T\n+\nIIIII\n", "tab_in_seq": b"@r1\nACG\tT\n+\nIIIII\n",
+     "trailing_space_seq": b"@r1\nACGT \n+\nIIII\n", "trailing_space_qual": b"@r1\nACGT\n+\nIIII \n", "numeric_trailing_space": b"@r1\nACGT\n+\n40 40 40 40 \n",
+     "numeric_leading_space": b"@r1\nACGT\n+\n 40 40 40 40\n", "numeric_double_space": b"@r1\nACGT\n+\n40  40 40 40\n", "numeric_tabs": b"@r1\nACGT\n+\n40\t40\t40\t40\n",
+     "numeric_plus_sign": b"@r1\nACGT\n+\n+40 +4 40 40\n", "numeric_too_few": b"@r1\nACGT\n+\n40 40 40\n", "numeric_too_many": b"@r1\nACGT\n+\n40 40 40 40 40\n",
+     "numeric_single_base": b"@r1\nA\n+\n40\n", "ascii_single_digit": b"@r1\nA\n+\n5\n", "ascii_digits_same_len": b"@r1\nACG\n+\n555\n", "ascii_with_space": b"@r1\nACG\n+\nI I\n",
+     "numeric_big_in_range": b"@r1\nAC\n+\n93 -40\n", "numeric_out_of_range_hi": b"@r1\nAC\n+\n94 3\n", "numeric_out_of_range_lo": b"@r1\nAC\n+\n-41 3\n",
+     "plus_with_other_name": b"@r1\nACGT\n+zzz\nIIII\n", "at_in_quality": b"@r1\nACGT\n+\n@@@@\n" + rec, "gt_first_in_fastq_tool": b">r1\nACGT\n" + rec,
+     "fasta_multiline": b">r1\nACGT\nACGT\n>r2\nAC\n", "fasta_empty_seq": b">r1\n\n>r2\nACGT\n", "fasta_no_final_nl": b">r1\nACGT", "fasta_lower": b">r1\nacgt\n", 
+     "fasta_blank_lines": b">r1\nACGT\n\n>r2\nACGT\n", "fasta_only_header": b">r1\n", "fasta_N_only": b">r1\nNNNN\n", "fasta_collapsed": b">12-345\nACGTACGT\n>13-1\nACGT\n",
+     "fasta_bad_collapsed": b">12-abc\nACGT\n>-5\nAC\n>3-\nAC\n", "nul_byte_in_seq": b"@r1\nAC\x00GT\n+\nIIIII\n", "nul_in_id": b"@r\x001\nACGT\n+\nIIII\n",
+     "seq_only_N": b"@r1\nNNNNNN\n+\nIIIIII\n", "one_base": b"@r1\nA\n+\nI\n", "qual_all_low": b"@r1\nACGTACGT\n+\n!!!!!!!!\n", "qual_max": b"@r1\nACGT\n+\n}}}}\n",
+     "crlf_numeric": b"@r1\r\nACGT\r\n+\r\n40 40 30 2\r\n", "crlf_no_final": rec.replace(b"\n", b"\r\n")[:-2], "cr_at_end_only": rec[:-1] + b"\r\n",
+     "lf_cr": rec.replace(b"\n", b"\n\r"), "dos_eof": rec + b"\x1a", "bom": b"\xef\xbb\xbf" + rec, "id_empty": b"@\nACGT\n+\nIIII\n", "id_spaces": b"@  a  b \nACGT\n+\nIIII\n",
+     "two_ok_then_trunc": rec + rec2 + b"@r3\nACGT\n+\n", "two_ok_then_header": rec + rec2 + b"@r3", "ok_then_garbage": rec + b"hello\n", "u_base": b"@r1\nACGU\n+\nIIII\n",
+     "iupac": b"@r1\nACGTRYKM\n+\nIIIIIIII\n", "dot_base": b"@r1\nAC.T\n+\nIIII\n", "dash_base": b"@r1\nAC-T\n+\nIIII\n", "star_qual": rec2*3,
+     "long_read_2000": b"@r1\n" + b"ACGT"*500 + b"\n+\n" + b"I"*2000 + b"\n", "mixed_lengths": rec + b"@s\nAC\n+\nII\n" + b"@t\n" + b"G"*300 + b"\n+\n" + b"5"*300 + b"\n" + rec2,
+     "numeric_then_ascii": b"@r2\nACGT\n+\n40 40 30 2\n" + rec, "numeric_minus_alone": b"@r1\nAC\n+\n- 3\n", "numeric_decimal": b"@r1\nAC\n+\n3.5 3\n", "numeric_hex": b"@r1\nAC\n+\n0x10 3\n",
+     "numeric_leading_zero": b"@r1\nAC\n+\n007 010\n", "seq_with_cr_mid": b"@r1\nAC\rGT\n+\nIIIII\n",
+    }
+    return C
+
+
+def test_corner_case_inputs_vs_reference(tools):
+    """Every corner-case input through the tools -- device text path (emulated) and host parser -- against the real libfastx."""
+    if not REF:
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    argvs = [["fastq_quality_trimmer", "-t", "20", "-l", "2", "-v"], ["fastq_quality_filter", "-q", "20", "-p", "50", "-v"], ["fastx_trimmer", "-f", "2", "-l", "9"],
+             ["fastx_reverse_complement"], ["fastx_clipper", "-a", "GTAC", "-l", "2", "-v"], ["fastq_masker", "-q", "30"], ["fastq_to_fasta", "-n"],
+             ["fastx_artifacts_filter", "-v"], ["fastx_quality_stats"], ["fastx_quality_stats", "-N"], ["fastx_trimmer", "-t", "2", "-m", "3"],
+             ["fastx_clipper", "-a", "CGTA", "-l", "1", "-n", "-C"]]
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(job):
+        name, data, argv = job
+        r = _run([REF] + argv, data)
+        for mode in ({}, {"FXH_HOST_PARSE": "1"}):
+            g = _run([os.path.join(tools, argv[0])] + argv[1:], data, threads="2", extra_env=mode)
+            assert (g[0], g[1]) == (r[0], r[1]) and _msg(g[2]) == _msg(r[2]), (name, argv, mode, g[0], g[1][:80], g[2][:200], r[0], r[1][:80], r[2][:200])
+        return 2
+
+    # (collapsed FASTA with hundreds of reads per record into fastx_quality_stats -N: the reference's percentile walk leaves its
+    #  25 000-cycle array and reads unrelated globals -- no defined answer to compare with; the tool stops at the array's end)
+    jobs = [(name, data, argv) for name, data in _corner_corpus().items() for argv in argvs if not (name == "fasta_collapsed" and argv[-1] == "-N")]
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as ex:
+        checked = sum(ex.map(one, jobs))
+    assert checked > 1500
