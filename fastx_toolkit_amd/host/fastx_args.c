@@ -21,13 +21,11 @@ int compress_output_flag(void) { return g_args.gzip; }
 int get_fastq_ascii_quality_offset(void) { return g_args.qoffset; }
 FILE *get_report_file(void) { return g_args.report ? g_args.report : stderr; }
 
-char **fxh_saved_argv;     /* fxh_batch.c: a sharded run re-executes this command line unsharded when the input turns out irregular */
 
 int fastx_parse_cmdline(int argc, char *argv[], const char *program_options, parse_argument_func program_parse_arg)
 {
     char spec[128];
     int c;
-    fxh_saved_argv = argv;
     snprintf(spec, sizeof spec, "Q:zhvi:o:%s", program_options);
     g_args.report = stderr;
     while ((c = getopt(argc, argv, spec)) != -1) {

@@ -10,6 +10,8 @@
 #include <time.h>
 #include <sys/stat.h>
 #include <sys/types.h>
+#include <sys/wait.h>
+#include <signal.h>
 #include <unistd.h>
 
 #include "fxh_internal.h"
@@ -1541,7 +1543,8 @@ static void fxh_part_name(const FASTX *fx, int r, char *dst, size_t cap)
     else snprintf(dst, cap, "%s.%d", name, r);
 }
 
-/* 0 = done; -1 = not eligible (run unsharded); does not return when the sharded attempt has to be abandoned (re-exec) */
+#define FXH_EXIT_ABANDON 99
+/* 0 = done (in the child of the fork below: the caller goes on to print its reports); -1 = run unsharded (not eligible, or the sharded attempt was abandoned) */
 static int fxh_run_parts(FASTX *fx, const fxg_params *p, fxh_totals *tot, int k)
 {
     struct fxh_reader *rd = fx->reader;
@@ -1557,6 +1560,26 @@ static int fxh_run_parts(FASTX *fx, const fxg_params *p, fxh_totals *tot, int k)
     for (int r = 1; r < k; ++r) {
         cut[r] = fxh_find_cut(rd->fd, (off_t)((unsigned long long)size * (unsigned)r / (unsigned)k), size, lpr);
         if (cut[r] < 0 || cut[r] <= cut[r - 1] || (r == 1 && cut[r] < here)) return -1;       /* small or odd input: one run */
+    }
+    /* The sharded attempt runs in a CHILD process.  Irregular input anywhere (or a cut that was no record boundary) abandons it: the
+     * reference's behaviour -- message, exit code, what has been written before the bad record -- is defined for ONE stream, so the
+     * child empties the parts and exits with FXH_EXIT_ABANDON, and this process -- which has not touched the GPU yet -- runs the same
+     * input unsharded (part 0 then receives everything).  Nothing is ever exec'd or killed with device work in flight: the child ends
+     * like any tool run, after its threads have been joined and its contexts destroyed. */
+    fflush(NULL);
+    const pid_t child = fork();
+    if (child < 0) return -1;
+    if (child > 0) {
+        int st = 0;
+        while (waitpid(child, &st, 0) < 0) { if (errno != EINTR) err(1, "waitpid"); }
+        if (WIFEXITED(st) && WEXITSTATUS(st) == FXH_EXIT_ABANDON) {
+            if (lseek(rd->fd, here, SEEK_SET) < 0) err(1, "%s", fx->input_file_name);      /* the child read through the shared descriptor */
+            struct fxh_writer *w = fx->writer;
+            if (w && w->fd >= 0) { if (ftruncate(w->fd, 0) != 0 || lseek(w->fd, 0, SEEK_SET) < 0) warn("%s", fx->output_file_name); }
+            return -1;
+        }
+        if (WIFSIGNALED(st)) { signal(WTERMSIG(st), SIG_DFL); raise(WTERMSIG(st)); _exit(128 + WTERMSIG(st)); }
+        _exit(WIFEXITED(st) ? WEXITSTATUS(st) : 1);                                      /* the child printed the reports and closed the parts */
     }
     fxh_part *pt = (fxh_part *)calloc((size_t)k, sizeof(fxh_part));
     if (!pt) err(1, "out of memory");
@@ -1581,15 +1604,9 @@ static int fxh_run_parts(FASTX *fx, const fxg_params *p, fxh_totals *tot, int k)
     int bad = FXH_ABORTED();
     for (int r = 0; r < k; ++r) if (pt[r].rc != 0) bad = 1;
     if (bad) {
-        /* Irregular input somewhere (or a cut that was no record boundary): the reference's behaviour -- message, exit code, what
-         * has been written before the bad record -- is defined for ONE stream.  Empty the parts and run the command line again
-         * unsharded; part 0 then receives everything (FXH_PARTS=1 keeps a "%r" name pointing at part 0). */
         for (int r = 1; r < k; ++r) { fxh_writer_close(pt[r].fx->writer); if (truncate(pt[r].name, 0) != 0) warn("%s", pt[r].name); }
         fflush(NULL);
-        setenv("FXH_PARTS", "1", 1);
-        setenv("FXH_PARTS_RESTARTED", "1", 1);
-        if (fxh_saved_argv) execv("/proc/self/exe", fxh_saved_argv);
-        errx(1, "sharded run abandoned (irregular input) and the unsharded restart failed; run again without FXH_PARTS");
+        exit(FXH_EXIT_ABANDON);                  /* the parent runs the input again as one stream (see the fork above) */
     }
     memset(tot, 0, sizeof *tot);
     FILE *ix = NULL;
@@ -1625,7 +1642,7 @@ int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *tot)
     if (k > FXH_MAX_LANES) k = FXH_MAX_LANES;
     if (k > 1 && fxh_run_parts(fx, p, tot, k) == 0) return 0;
     const int rc = fxh_run_impl(fx, p, tot, NULL, NULL, NULL, 0, 1);
-    if (k > 1 && strcmp(fx->output_file_name, "-") != 0 && !getenv("FXH_PARTS_RESTARTED")) {
+    if (k > 1 && strcmp(fx->output_file_name, "-") != 0) {
         /* asked for k parts but run as one stream (a pipe, a small file, -z, the serial clipper): part 0 holds everything, the others
          * exist and are empty, so that `cat` over the k names is the output either way */
         for (int r = 1; r < k; ++r) {
