@@ -1496,8 +1496,9 @@ static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_sta
 /* count before it is: the cut points are found by pattern (an '@' line, a '+' line two below it, equal lengths, the same again)    */
 /* and then PROVEN -- part r ends exactly at part r+1's cut, so if its lines are a whole number of records and part r started at a  */
 /* boundary, so does part r+1 (induction from offset 0).  A part that meets anything the device path does not take (a ragged end =   */
-/* a wrong cut, a malformed record, CR-less oddities the host parser owns) stops all parts; the process then re-executes its own     */
-/* command line unsharded, so messages, exit codes and partial output are the reference's in every case.                            */
+/* a wrong cut, a malformed record, CR-less oddities the host parser owns) stops all parts; the attempt ran in a child process, which */
+/* empties the parts and exits, and the parent runs the input as one stream: messages, exit codes and partial output are the         */
+/* reference's in every case.                                                                                                         */
 /* ---------------------------------------------------------------------------------------------- */
 static off_t fxh_find_cut(int fd, off_t from, off_t size, int lpr)
 {
