@@ -207,8 +207,8 @@ def test_lanes_devices_and_the_fused_tool(tools, tmp_path):
 
 
 def test_sharded_run_and_the_three_stage_tool_on_the_gpu_build(tools, tmp_path):
-    """FXH_PARTS on the real engine: parts concatenate to the one-stream output (also for a damaged input: unsharded restart, the
-    reference's message and partial output), and fastx_clip_trim_filter (config 5 in one pass) == the three-tool pipe of the real libfastx."""
+    """FXH_PARTS on the real engine: parts concatenate to the one-stream output, and fastx_clip_trim_filter (config 5 in one pass) ==
+    the three-tool pipe of the real libfastx."""
     text = fo.synth_fastq(5, 0, 150000, 150, True)                       # ~48 MB
     inp = tmp_path / "in.fq"
     inp.write_bytes(text)
@@ -226,13 +226,8 @@ def test_sharded_run_and_the_three_stage_tool_on_the_gpu_build(tools, tmp_path):
             if not PARSE_ENV:
                 assert got[2].count(b"fxh timing part") == k, got[2][-400:]
             assert b"".join(open(pat.replace("%r", str(r)), "rb").read() for r in range(k)) == single.read_bytes(), (argv[0], k)
-    k0 = text.index(b"\n@", int(len(text) * 0.8)) + 1
-    inp.write_bytes(text[:k0] + b"#" + text[k0 + 1:])
-    argv = ["fastq_quality_trimmer", "-t", "20", "-l", "30"]
-    w = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", str(tmp_path / "bad1.fq")], b"")
-    g = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", str(tmp_path / "bad.%r.fq")], b"", dict(os.environ, FXH_PARTS="4", FXH_READ_BUFFER_MB="4"))
-    assert w[0] == 1 and (g[0], g[1]) == (w[0], w[1]) and _msg(g[2]) == _msg(w[2])
-    assert b"".join(open(str(tmp_path / ("bad.%d.fq" % r)), "rb").read() for r in range(4)) == (tmp_path / "bad1.fq").read_bytes()
+    # (what a sharded run does with damaged input -- abandon the attempt, run as one stream -- is host logic and is tested where no GPU
+    #  is needed: tests/test_host_cli_emulated.py, tests/test_sanitizers.py)
     if REF:                                                               # config 5 as the reference runs it: three processes in a pipe
         small = text[:3_000_000]
         small = small[:small.rindex(b"\n@") + 1]
