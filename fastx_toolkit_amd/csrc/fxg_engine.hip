@@ -417,6 +417,12 @@ extern "C" int fxg_run_pipeline(fxg_ctx *c, const fxg_batch *in, const fxg_param
         case -40: return fxg_launch_tiles(c, FXG_TILES_A(-40), "fxg_kernel_tiles<-40,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case -48: return fxg_launch_tiles(c, FXG_TILES_A(-48), "fxg_kernel_tiles<-48,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case -64: return fxg_launch_tiles(c, FXG_TILES_A(-64), "fxg_kernel_tiles<-64,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -316: return fxg_launch_tiles(c, FXG_TILES_A(-316), "fxg_kernel_tiles<-316,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -324: return fxg_launch_tiles(c, FXG_TILES_A(-324), "fxg_kernel_tiles<-324,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -336: return fxg_launch_tiles(c, FXG_TILES_A(-336), "fxg_kernel_tiles<-336,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -348: return fxg_launch_tiles(c, FXG_TILES_A(-348), "fxg_kernel_tiles<-348,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -364: return fxg_launch_tiles(c, FXG_TILES_A(-364), "fxg_kernel_tiles<-364,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -400: return fxg_launch_tiles(c, FXG_TILES_A(-400), "fxg_kernel_tiles<-400,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case -216: return fxg_launch_tiles(c, FXG_TILES_A(-216), "fxg_kernel_tiles<-216,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case -100: return fxg_launch_tiles(c, FXG_TILES_A(-100), "fxg_kernel_tiles<-100,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case 16: return fxg_launch_tiles(c, FXG_TILES_A(16), "fxg_kernel_tiles<16,0> clip[+qtrim+qfilter]", pl.ka, pl.lds, ctr);

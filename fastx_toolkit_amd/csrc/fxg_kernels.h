@@ -411,24 +411,33 @@ FXG_HD void fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int
 #define FXG_K_SZ1  (1u << 14)
 #define FXG_K_START(v) ((u32)(v) << 23)
 // smallest adapter of the bucket AMAX (fxg_plan.h): columns below it always count towards the best cell
-__host__ __device__ constexpr int fxg_clip_k_amin(int amax) { return amax <= 16 ? 1 : amax <= 20 ? 17 : amax <= 40 ? amax - 3 : amax <= 48 ? 41 : amax <= 64 ? 49 : 65; }
+__host__ __device__ constexpr int fxg_clip_k_amin(int amax, bool tn = false)
+{
+    return tn ? (amax <= 16 ? 1 : amax <= 24 ? 17 : amax <= 36 ? 25 : amax <= 48 ? 37 : amax <= 64 ? 49 : 65)        // buckets 16 24 36 48 64 100 (adapters with N)
+              : (amax <= 16 ? 1 : amax <= 20 ? 17 : amax <= 40 ? amax - 3 : amax <= 48 ? 41 : amax <= 64 ? 49 : 65);
+}
 template <int AMAX> struct FxgClipK { static constexpr bool SM = AMAX <= 28; static constexpr int NSM = SM ? AMAX : 1; };
 
-template <int AMAX, bool EARLY, bool TRACK>
+// TN: the adapter may contain 'N' (sequence_alignment.h:157-169: a neutral pair scores 0.1, N against N 0.0, and counts neither as match
+// nor as mismatch).  Which columns are N is the same for every lane, so it costs scalar selects of the masks and two more VALU
+// instructions per cell (the pair value and the diagonal's step each take one more select); the instances without it are unchanged.
+template <int AMAX, bool EARLY, bool TRACK, bool TN = false>
 FXG_HD void fxg_clip_row_k(const FxgKArgs &a, int A, u32 c, int q, u32 vstart, float (&S)[AMAX], float (&Sm)[FxgClipK<AMAX>::NSM], u32 (&W)[AMAX],
                            float &best, u32 &bw, u32 &bq)
 {
     constexpr bool SM = FxgClipK<AMAX>::SM;
-    constexpr int AMIN = fxg_clip_k_amin(AMAX);
+    constexpr int AMIN = fxg_clip_k_amin(AMAX, TN);
     const bool qn = (c == (u32)'N');
-    const float pair_eq = qn ? 0.1f : 1.0f, pair_ne = qn ? 0.1f : -1.0f;                 // sequence_alignment.h:157-169 (adapter without N)
+    const float pair_eq = qn ? 0.1f : 1.0f, pair_ne = qn ? 0.1f : -1.0f;                 // sequence_alignment.h:157-169 for an adapter base that is not N
+    const float pair_tn = qn ? 0.0f : 0.1f;                                              // ... and for one that is
     const u32 dxr = qn ? 0u : FXG_K_DIA1;
     const float best_in = best;
     float uSm = -5.0f;                                                                   // S[q][-1] - 5
     u32 uW = 0u;
     const bool eq0 = (c == (u32)(uint8_t)a.adapter[0]);
-    float ul = 0.0f + (eq0 ? pair_eq : pair_ne);                                         // S[q-1][-1] = query_border = 0
-    u32 wd = dxr + (u32)eq0;                                                             // no predecessor left of column 0: the step alone
+    const bool tn0 = TN && ((u32)(uint8_t)a.adapter[0] == (u32)'N');
+    float ul = 0.0f + (tn0 ? pair_tn : (eq0 ? pair_eq : pair_ne));                       // S[q-1][-1] = query_border = 0
+    u32 wd = tn0 ? 0u : dxr + (u32)eq0;                                                  // no predecessor left of column 0: the step alone
 #pragma unroll
     for (int b0 = 0; b0 < AMAX; b0 += 16) {
         // the match masks of the next 16 diagonals first (a lane mask needs two wait states between its v_cmp and the v_cndmask that reads it)
@@ -442,10 +451,12 @@ FXG_HD void fxg_clip_row_k(const FxgKArgs &a, int A, u32 c, int q, u32 vstart, f
             float ul_next = 0.0f;
             u32 wd_next = 0u;
             if (t + 1 < AMAX) {
-                ul_next = S[t] + (eq[k] ? pair_eq : pair_ne);
-                u32 wdx = W[t] + dxr;
+                const bool tn1 = TN && ((u32)(uint8_t)a.adapter[t + 1] == (u32)'N');      // uniform: a scalar condition
+                const float pv = eq[k] ? pair_eq : pair_ne;
+                ul_next = S[t] + (tn1 ? pair_tn : pv);
+                u32 wdx = W[t] + (tn1 ? 0u : dxr);
                 FXG_KEEP_V(wdx);                                                         // keeps "+ match" the carry-in of one v_addc_co_u32 (else: select 0/1, or, add)
-                wd_next = wdx + (u32)eq[k];
+                wd_next = wdx + (u32)(eq[k] && !tn1);
             }
             float left = SM ? Sm[SM ? t : 0] : S[t] + -5.0f;
             if (EARLY && t > 3) left = (t - 3 > q) ? -100000.0f : left;                  // sequence_alignment.cpp:387-389, rows q < A - 4 only
@@ -478,7 +489,7 @@ FXG_HD void fxg_clip_row_k(const FxgKArgs &a, int A, u32 c, int q, u32 vstart, f
     if (TRACK) bq = (best > best_in) ? (u32)q : bq;
 }
 
-template <int AMAX>
+template <int AMAX, bool TN>
 FXG_HD void fxg_clip_rows_k(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float &best, u32 &bw, u32 &bq, int &first_n)
 {
     float S[AMAX], Sm[FxgClipK<AMAX>::NSM];
@@ -499,14 +510,14 @@ FXG_HD void fxg_clip_rows_k(const FxgKArgs &a, const uint8_t *rd, int len, int r
         const u32 c = cn;
         cn = rd[q + 1];
         first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
-        fxg_clip_row_k<AMAX, true, true>(a, A, c, q, (u32)q, S, Sm, W, best, bw, bq);
+        fxg_clip_row_k<AMAX, true, true, TN>(a, A, c, q, (u32)q, S, Sm, W, best, bw, bq);
     }
 #pragma unroll 1
     for (; q < rows; ++q) {
         const u32 c = cn;
         cn = rd[q + 1];
         first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
-        fxg_clip_row_k<AMAX, false, true>(a, A, c, q, (u32)q, S, Sm, W, best, bw, bq);
+        fxg_clip_row_k<AMAX, false, true, TN>(a, A, c, q, (u32)q, S, Sm, W, best, bw, bq);
     }
 }
 
@@ -519,15 +530,17 @@ FXG_HD void fxg_clip_rows_k(const FxgKArgs &a, const uint8_t *rd, int len, int r
 // summaries (fxg_clip_row_k), and only row bq1 looks for the best cell.  A path that starts in pass 2 starts in column 0 (or in row 0
 // when r0 = 0), so its `start` is the row RELATIVE to r0: reads of any length fit the 9 bits.
 // ------------------------------------------------------------------------------------------------
-template <int AMAX, bool EARLY>
+template <int AMAX, bool EARLY, bool TN>
 FXG_HD float fxg_clip_row_score_k(const FxgKArgs &a, int A, u32 c, int q, float (&S)[AMAX], float (&Sm)[AMAX])
 {
     constexpr bool SM = AMAX <= 48;                 // the score rows keep S - 5 as well where that still leaves room: nothing else is live while they run
-    constexpr int AMIN = fxg_clip_k_amin(AMAX);
+    constexpr int AMIN = fxg_clip_k_amin(AMAX, TN);
     const bool qn = (c == (u32)'N');
     const float pair_eq = qn ? 0.1f : 1.0f, pair_ne = qn ? 0.1f : -1.0f;
+    const float pair_tn = qn ? 0.0f : 0.1f;
     float uSm = -5.0f, rowmax = -1000000.0f;
-    float ul = 0.0f + ((c == (u32)(uint8_t)a.adapter[0]) ? pair_eq : pair_ne);
+    const bool tn0 = TN && ((u32)(uint8_t)a.adapter[0] == (u32)'N');
+    float ul = 0.0f + (tn0 ? pair_tn : ((c == (u32)(uint8_t)a.adapter[0]) ? pair_eq : pair_ne));
 #pragma unroll
     for (int b0 = 0; b0 < AMAX; b0 += 16) {
         bool eq[16];
@@ -538,7 +551,11 @@ FXG_HD float fxg_clip_row_score_k(const FxgKArgs &a, int A, u32 c, int q, float 
             const int t = b0 + k;
             if (t >= AMAX) break;
             float ul_next = 0.0f;
-            if (t + 1 < AMAX) ul_next = S[t] + (eq[k] ? pair_eq : pair_ne);
+            if (t + 1 < AMAX) {
+                const bool tn1 = TN && ((u32)(uint8_t)a.adapter[t + 1] == (u32)'N');
+                const float pv = eq[k] ? pair_eq : pair_ne;
+                ul_next = S[t] + (tn1 ? pair_tn : pv);
+            }
             float left = SM ? Sm[SM ? t : 0] : S[t] + -5.0f;
             if (EARLY && t > 3) left = (t - 3 > q) ? -100000.0f : left;
             const float sc = fmaxf(fmaxf(ul, uSm), left);
@@ -554,7 +571,7 @@ FXG_HD float fxg_clip_row_score_k(const FxgKArgs &a, int A, u32 c, int q, float 
 }
 
 // returns r0 (the row the `start` field of bw counts from)
-template <int AMAX>
+template <int AMAX, bool TN>
 FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float *ck, u32 cks, float &best, u32 &bw, u32 &bq, int &first_n)
 {
     float S[AMAX], Sm[AMAX];
@@ -576,7 +593,7 @@ FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, in
         }                                                                                                                    \
         const u32 c = cn;                                                                                                    \
         cn = rd[q + 1];                                                                                                      \
-        const float rm = fxg_clip_row_score_k<AMAX, EARLY>(a, A, c, q, S, Sm);                                               \
+        const float rm = fxg_clip_row_score_k<AMAX, EARLY, TN>(a, A, c, q, S, Sm);                                               \
         const bool g = rm > b1;                                                                                              \
         b1 = g ? rm : b1; bq1 = g ? q : bq1;                                                                                 \
     }
@@ -602,17 +619,17 @@ FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, in
     // Every lane has its own rows here, so the loops keep ONE body each: the early form (which tests the row number itself) wherever a
     // row below A - 4 can occur -- the < clip_ck_rows rows of the score re-run and the first A - 4 rows of the summary window.
 #pragma unroll 1
-    for (; q < r0; ++q) (void)fxg_clip_row_score_k<AMAX, true>(a, A, (u32)rd[q], q, S, Sm);
+    for (; q < r0; ++q) (void)fxg_clip_row_score_k<AMAX, true, TN>(a, A, (u32)rd[q], q, S, Sm);
     u32 W[AMAX];
 #pragma unroll
     for (int t = 0; t < AMAX; ++t) W[t] = FXG_K_START(256 + t + 1) + FXG_K_SZ1;         // the cells above row 0 (r0 > 0: never on the best path)
     float (&Sk)[FxgClipK<AMAX>::NSM] = reinterpret_cast<float (&)[FxgClipK<AMAX>::NSM]>(Sm);    // the summary rows keep S - 5 only where registers allow
     int i = 0;
 #pragma unroll 1
-    for (; q < bq1 && i < early_rows; ++q, ++i) fxg_clip_row_k<AMAX, true, false>(a, A, (u32)rd[q], q, (u32)(q - r0), S, Sk, W, best, bw, bq);
+    for (; q < bq1 && i < early_rows; ++q, ++i) fxg_clip_row_k<AMAX, true, false, TN>(a, A, (u32)rd[q], q, (u32)(q - r0), S, Sk, W, best, bw, bq);
 #pragma unroll 1
-    for (; q < bq1; ++q) fxg_clip_row_k<AMAX, false, false>(a, A, (u32)rd[q], q, (u32)(q - r0), S, Sk, W, best, bw, bq);
-    fxg_clip_row_k<AMAX, true, true>(a, A, (u32)rd[bq1], bq1, (u32)(bq1 - r0), S, Sk, W, best, bw, bq);
+    for (; q < bq1; ++q) fxg_clip_row_k<AMAX, false, false, TN>(a, A, (u32)rd[q], q, (u32)(q - r0), S, Sk, W, best, bw, bq);
+    fxg_clip_row_k<AMAX, true, true, TN>(a, A, (u32)rd[bq1], bq1, (u32)(bq1 - r0), S, Sk, W, best, bw, bq);
     if (!(a.clip_flags & FXG_CLIP_KEEP_N)) {                                             // the -n rule needs the first N of the read itself
 #pragma unroll 1
         for (int k = len - 1; k >= 0; --k) first_n = (rd[k] == (uint8_t)'N') ? k : first_n;
@@ -622,7 +639,7 @@ FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, in
 
 // KFORM: the one-word summary of fxg_clip_row_k (17..99 columns; also 16 columns for reads beyond 255 bases, which the register
 // form of fxg_clip_two_pass cannot describe: its start field is absolute)
-template <int AMAX, bool KFORM>
+template <int AMAX, bool KFORM, bool TN = false>
 FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len, int rows,
                                  u32 *out_len, u32 *keep, u32 *reason, u32 *clipped, u32 *adapter_only, float *ck = nullptr, u32 cks = 0u)
 {
@@ -637,8 +654,8 @@ FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len, 
     if constexpr (!KFORM) fxg_clip_rows_packed<AMAX, false>(a, rd, len, rows, best, bw, bq, first_n);
     if constexpr (KFORM) {
         int r0 = 0;
-        if (ck) r0 = fxg_clip_two_pass_k<AMAX>(a, rd, len, rows, ck, cks, best, bw, bq, first_n);
-        else fxg_clip_rows_k<AMAX>(a, rd, len, rows, best, bw, bq, first_n);
+        if (ck) r0 = fxg_clip_two_pass_k<AMAX, TN>(a, rd, len, rows, ck, cks, best, bw, bq, first_n);
+        else fxg_clip_rows_k<AMAX, TN>(a, rd, len, rows, best, bw, bq, first_n);
         const int v = (int)(bw >> 23), matches = (int)(bw & 127u), diag = (int)((bw >> 7) & 127u);
         fxg_clip_finish(a, len, v < 256 ? r0 + v : 0, v < 256 ? 0 : v - 256, diag - matches, (int)((bw >> 14) & 511u), matches,
                         (int)bq, first_n, out_len, keep, reason, clipped, adapter_only);
@@ -749,8 +766,10 @@ FXG_HD void fxg_phase_stage_bases(const uint8_t *src, u64 total, u64 tb, u32 tby
 
 // phase 2, group A: thread tid decides read r0 + tid
 // AMAX > 0: general clipper; AMAX < 0: packed clipper with bucket -AMAX columns (-216: 16 columns in the form of the 17..99 buckets)
-__host__ __device__ constexpr int fxg_clip_cols(int amax) { return amax <= -200 ? -amax - 200 : -amax; }
+//   -(300 + columns): the same form for adapters that contain 'N' (buckets 16 24 36 48 64 100)
+__host__ __device__ constexpr int fxg_clip_cols(int amax) { return amax <= -300 ? -amax - 300 : amax <= -200 ? -amax - 200 : -amax; }
 __host__ __device__ constexpr bool fxg_clip_kform(int amax) { return amax < -16; }
+__host__ __device__ constexpr bool fxg_clip_tn(int amax) { return amax <= -300; }
 template <int AMAX>
 FXG_HD u32 fxg_decide_a(const FxgKArgs &a, const u32 *bm_g, const u32 *bm_l, const uint8_t *sb, u32 r0, u32 tid,
                         u32 *keep_out, u32 *len_out, float *ck = nullptr, u32 cks = 0u)      // ck: this thread's checkpoint scratch (fxg_clip_two_pass_k), cks its stride
@@ -763,9 +782,9 @@ FXG_HD u32 fxg_decide_a(const FxgKArgs &a, const u32 *bm_g, const u32 *bm_l, con
     if constexpr (AMAX < 0) {
         // fixed-length batch without clip history: the row count is a scalar, so every loop of the DP is a scalar loop
         constexpr int COLS = fxg_clip_cols(AMAX);
-        constexpr bool KF = fxg_clip_kform(AMAX);
-        if (!a.len && !a.wlen) fxg_clip_read_packed<COLS, KF>(a, sb + tid * a.clip_stride, (int)a.fixed_len, (int)a.fixed_len, &curlen, &keep, &reason, &clipped, &ao, ck, cks);
-        else fxg_clip_read_packed<COLS, KF>(a, sb + tid * a.clip_stride, (int)rl, rows, &curlen, &keep, &reason, &clipped, &ao, ck, cks);
+        constexpr bool KF = fxg_clip_kform(AMAX), TN = fxg_clip_tn(AMAX);
+        if (!a.len && !a.wlen) fxg_clip_read_packed<COLS, KF, TN>(a, sb + tid * a.clip_stride, (int)a.fixed_len, (int)a.fixed_len, &curlen, &keep, &reason, &clipped, &ao, ck, cks);
+        else fxg_clip_read_packed<COLS, KF, TN>(a, sb + tid * a.clip_stride, (int)rl, rows, &curlen, &keep, &reason, &clipped, &ao, ck, cks);
     }
     if (keep && (a.stages & FXG_STAGE_QTRIM)) {             // fastq_quality_trimmer.c:94-101
         const u32 k = fxg_bits_last(bm_g, tid * stride, curlen);
@@ -898,7 +917,7 @@ __device__ __forceinline__ void fxg_tile_tally(u32 w, bool valid, u64 *tally)
 // waves per SIMD the clip instances are compiled for: the packed forms keep 2-3 registers per adapter column (two-pass: 6 of <= 16)
 // (64 columns at three waves = 168 registers spilled and came out WRONG on the GPU in the two-pass form -- 19 of 223 reads of one
 // adversarial case, the emulator and every other bucket agreeing with the oracle; at two waves nothing spills and it is right)
-__host__ __device__ constexpr int fxg_clip_waves(int amax) { return amax > 0 ? 1 : (amax >= -32 || amax <= -200) ? FXG_CLIP_WAVES : amax >= -48 ? 3 : 2; }
+__host__ __device__ constexpr int fxg_clip_waves(int amax) { return amax > 0 ? 1 : fxg_clip_cols(amax) <= 32 ? FXG_CLIP_WAVES : fxg_clip_cols(amax) <= 48 ? 3 : 2; }
 template <int AMAX, int MODE> struct FxgTileBlock { static constexpr int threads = (MODE == 0 && AMAX < 0 && AMAX >= -16) ? FXG_CLIP_TBLOCK : FXG_TBLOCK; };
 template <int AMAX, int MODE>
 __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? FXG_MIN_WAVES : fxg_clip_waves(AMAX))) void fxg_kernel_tiles(const FxgKArgs a)

@@ -215,6 +215,12 @@ extern "C" int fxg_emu_run_pipeline_hist(const fxg_batch *in, const fxg_params *
         case -64: return emu_run<-64, false>(pl, ctr, err, cap);
         case -100: return emu_run<-100, false>(pl, ctr, err, cap);
         case -216: return emu_run<-216, false>(pl, ctr, err, cap);
+        case -316: return emu_run<-316, false>(pl, ctr, err, cap);
+        case -324: return emu_run<-324, false>(pl, ctr, err, cap);
+        case -336: return emu_run<-336, false>(pl, ctr, err, cap);
+        case -348: return emu_run<-348, false>(pl, ctr, err, cap);
+        case -364: return emu_run<-364, false>(pl, ctr, err, cap);
+        case -400: return emu_run<-400, false>(pl, ctr, err, cap);
         case 16: return emu_run<16, false>(pl, ctr, err, cap);
         case 32: return emu_run<32, false>(pl, ctr, err, cap);
         case 64: return emu_run<64, false>(pl, ctr, err, cap);

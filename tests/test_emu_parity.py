@@ -129,16 +129,19 @@ def test_emulated_long_reads():
         qs.close()
 
 
-@pytest.mark.parametrize("form", ["short", "long", "long-one-pass"])
+@pytest.mark.parametrize("form", ["short", "long", "long-one-pass", "short-general", "long-general"])
 def test_emulated_clip_two_pass_adversarial(form, monkeypatch):
     """The two-pass clipper (score pass + restart from a checkpoint, fxg_clip_two_pass) and, for adapters of 17..99 bases, its
     counterpart with the checkpoints in scratch (fxg_clip_two_pass_k; reads beyond 255 bases included) and the one-pass in-place form
     (fxg_clip_rows_k: short reads, or everywhere with FXG_CLIP_K_ONE_PASS) against the oracle's full matrix + traceback on
-    helpers.adversarial_clip_cases."""
+    helpers.adversarial_clip_cases.  Adapters that contain N run the same forms with the neutral-column selects; FXG_NO_PACKED_CLIP
+    sends everything through the general two-word form."""
     checked = 0
     if form == "long-one-pass":
         monkeypatch.setenv("FXG_CLIP_K_ONE_PASS", "1")
-    for name, b, q, pd in adversarial_clip_cases(form != "short"):
+    if form.endswith("general"):                       # the two-word form every adapter took before the packed ones: still the fallback
+        monkeypatch.setenv("FXG_NO_PACKED_CLIP", "1")
+    for name, b, q, pd in adversarial_clip_cases(form.startswith("long")):
         p = oracle_params(pd)
         assert_same(fo.run_pipeline(b, q, None, p), emu.run_pipeline(b, q, None, p), name)
         checked += b.shape[0]
