@@ -423,7 +423,9 @@ extern "C" int fxg_run_pipeline(fxg_ctx *c, const fxg_batch *in, const fxg_param
         case -348: return fxg_launch_tiles(c, FXG_TILES_A(-348), "fxg_kernel_tiles<-348,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case -364: return fxg_launch_tiles(c, FXG_TILES_A(-364), "fxg_kernel_tiles<-364,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case -400: return fxg_launch_tiles(c, FXG_TILES_A(-400), "fxg_kernel_tiles<-400,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+#ifdef FXG_CLIP_ONE_PASS     // (ablation build only: reads beyond 255 bases with a short adapter; the regular build's register form takes them)
         case -216: return fxg_launch_tiles(c, FXG_TILES_A(-216), "fxg_kernel_tiles<-216,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+#endif
         case -100: return fxg_launch_tiles(c, FXG_TILES_A(-100), "fxg_kernel_tiles<-100,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case 16: return fxg_launch_tiles(c, FXG_TILES_A(16), "fxg_kernel_tiles<16,0> clip[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
         case 32: return fxg_launch_tiles(c, FXG_TILES_A(32), "fxg_kernel_tiles<32,0> clip[+qtrim+qfilter]", pl.ka, pl.lds, ctr);

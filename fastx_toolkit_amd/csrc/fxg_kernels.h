@@ -167,8 +167,10 @@ FXG_HD void fxg_clip_read(const FxgKArgs &a, const uint8_t *rd, int len, int row
 // Cell rule (sequence_alignment.cpp:380-417): strict '>' from diag to up to left, i.e. the maximum with ties going to diag, then up:
 //   score = max3(ul, up, left); diag iff score == ul; else up iff score == up; else left.
 // TRACK = false: the row cannot hold the first maximum (the second pass of fxg_clip_two_pass knows its row) -- no best-cell update.
+// vstart: what a path that enters the matrix in this row records as its query_start (8 bits): the row itself in the one-pass form, the
+// row relative to the second pass' first row in fxg_clip_two_pass -- which is what lets that form take reads of any length.
 template <int AMAX, bool EARLY, bool FIRST, bool TN, bool TRACK = true>
-FXG_HD void fxg_clip_row_packed(const FxgKArgs &a, int A, u32 c, int q, float (&S)[AMAX], float (&Sm)[AMAX], u32 (&W)[AMAX], float &best, u32 &bw, u32 &bq)
+FXG_HD void fxg_clip_row_packed(const FxgKArgs &a, int A, u32 c, int q, u32 vstart, float (&S)[AMAX], float (&Sm)[AMAX], u32 (&W)[AMAX], float &best, u32 &bw, u32 &bq)
 {
     const bool qn = (c == (u32)'N');
     const float pair_eq = qn ? 0.1f : 1.0f, pair_ne = qn ? 0.1f : -1.0f;                 // sequence_alignment.h:157-169 for a target base that is not N
@@ -210,7 +212,7 @@ FXG_HD void fxg_clip_row_packed(const FxgKArgs &a, int A, u32 c, int q, float (&
         if (FIRST || t == 0) {                                                               // a predecessor may lie outside the matrix
             const u32 src = isd ? dWv[t] : (isu ? uW : W[t]);
             const u32 step = isd ? wd[t] - dWv[t] : 0u;
-            w = (src == 0u) ? ((((u32)q << 24) | ((u32)t << 19)) + FXG_PK_SZ1 + step) : (src + step);   // the path enters the matrix here
+            w = (src == 0u) ? (((vstart << 24) | ((u32)t << 19)) + FXG_PK_SZ1 + step) : (src + step);   // the path enters the matrix here
         } else {
             w = isu ? uW : W[t];
             w = isd ? wd[t] : w;
@@ -249,8 +251,8 @@ FXG_HD void fxg_clip_rows_packed(const FxgKArgs &a, const uint8_t *rd, int len, 
     if (rows > 0) {                                                           // row 0: every cell may start a path
         const u32 c = rd[0];
         first_n = (c == (u32)'N' && 0 < len) ? 0 : first_n;
-        if (early_rows > 0) fxg_clip_row_packed<AMAX, true, true, TN>(a, A, c, 0, S, Sm, W, best, bw, bq);
-        else fxg_clip_row_packed<AMAX, false, true, TN>(a, A, c, 0, S, Sm, W, best, bw, bq);
+        if (early_rows > 0) fxg_clip_row_packed<AMAX, true, true, TN>(a, A, c, 0, 0u, S, Sm, W, best, bw, bq);
+        else fxg_clip_row_packed<AMAX, false, true, TN>(a, A, c, 0, 0u, S, Sm, W, best, bw, bq);
         q = 1;
     }
     // The row's base comes out of LDS one row AHEAD of its use (rows >= 1 always exists in the staged tile: the bases of the next
@@ -261,14 +263,14 @@ FXG_HD void fxg_clip_rows_packed(const FxgKArgs &a, const uint8_t *rd, int len, 
         const u32 c = cn;
         cn = rd[q + 1];
         first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
-        fxg_clip_row_packed<AMAX, true, false, TN>(a, A, c, q, S, Sm, W, best, bw, bq);
+        fxg_clip_row_packed<AMAX, true, false, TN>(a, A, c, q, (u32)q, S, Sm, W, best, bw, bq);
     }
 #pragma unroll 1
     for (; q < rows; ++q) {
         const u32 c = cn;
         cn = rd[q + 1];
         first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
-        fxg_clip_row_packed<AMAX, false, false, TN>(a, A, c, q, S, Sm, W, best, bw, bq);
+        fxg_clip_row_packed<AMAX, false, false, TN>(a, A, c, q, (u32)q, S, Sm, W, best, bw, bq);
     }
 }
 
@@ -325,8 +327,9 @@ FXG_HD float fxg_clip_row_score(const FxgKArgs &a, int A, u32 c, int q, float (&
     return rowmax;
 }
 
+// returns the row the query_start field of bw counts from
 template <int AMAX>
-FXG_HD void fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float &best, u32 &bw, u32 &bq, int &first_n)
+FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float &best, u32 &bw, u32 &bq, int &first_n)
 {
     constexpr int C = FxgClip2<AMAX>::C;
     float S[AMAX], Sm[AMAX], P0[AMAX], P1[AMAX], P2[AMAX], CB[AMAX];
@@ -334,7 +337,7 @@ FXG_HD void fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int
 #pragma unroll
     for (int t = 0; t < AMAX; ++t) { S[t] = (t <= 3) ? 0.0f : -5.0f * (float)(t - 3); Sm[t] = S[t] + -5.0f; P0[t] = P1[t] = P2[t] = CB[t] = S[t]; }
     const int early_rows = (A - 4 < rows) ? (A - 4 > 0 ? A - 4 : 0) : rows;
-    if (rows <= 0) return;
+    if (rows <= 0) return 0;
     // ---- pass 1 ----
     float b1 = -1000000.0f;
     int q = 0, r0 = 0, bq1 = 0;
@@ -378,16 +381,17 @@ FXG_HD void fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int
     int i = 0;
 #pragma unroll 1
     for (; q < bq1 && i < early_rows; ++q, ++i)             // window row i is read row r0 + i >= i: rows past i = A - 4 are past the early rule
-        fxg_clip_row_packed<AMAX, true, false, false, false>(a, A, (u32)rd[q], q, S, Sm, W, best, bw, bq);
+        fxg_clip_row_packed<AMAX, true, false, false, false>(a, A, (u32)rd[q], q, (u32)(q - r0), S, Sm, W, best, bw, bq);
 #pragma unroll 1
     for (; q < bq1; ++q)
-        fxg_clip_row_packed<AMAX, false, false, false, false>(a, A, (u32)rd[q], q, S, Sm, W, best, bw, bq);
-    fxg_clip_row_packed<AMAX, true, false, false, true>(a, A, (u32)rd[bq1], bq1, S, Sm, W, best, bw, bq);
+        fxg_clip_row_packed<AMAX, false, false, false, false>(a, A, (u32)rd[q], q, (u32)(q - r0), S, Sm, W, best, bw, bq);
+    fxg_clip_row_packed<AMAX, true, false, false, true>(a, A, (u32)rd[bq1], bq1, (u32)(bq1 - r0), S, Sm, W, best, bw, bq);
     // the -n rule needs the first N of the read itself (fastx_clipper.cpp:306-311); nothing else does
     if (!(a.clip_flags & FXG_CLIP_KEEP_N)) {
 #pragma unroll 1
         for (int k = len - 1; k >= 0; --k) first_n = (rd[k] == (uint8_t)'N') ? k : first_n;
     }
+    return r0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -645,10 +649,9 @@ FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len, 
 {
     float best = -1000000.0f;
     u32 bw = FXG_INVALID_TUPLE, bq = 0u;
-    int first_n = len;
-    // adapters that contain 'N' take the general form (fxg_plan.h): the packed instances keep no per-column neutral selects
+    int first_n = len, qbase = 0;
 #ifndef FXG_CLIP_ONE_PASS
-    if constexpr (!KFORM) fxg_clip_two_pass<AMAX>(a, rd, len, rows, best, bw, bq, first_n);
+    if constexpr (!KFORM) qbase = fxg_clip_two_pass<AMAX>(a, rd, len, rows, best, bw, bq, first_n);
     else
 #endif
     if constexpr (!KFORM) fxg_clip_rows_packed<AMAX, false>(a, rd, len, rows, best, bw, bq, first_n);
@@ -662,7 +665,7 @@ FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len, 
         return;
     }
     const int matches = (int)(bw & 31u), diag = (int)((bw >> 14) & 31u);
-    fxg_clip_finish(a, len, (int)(bw >> 24), (int)((bw >> 19) & 31u), diag - matches, (int)((bw >> 5) & 511u), matches,
+    fxg_clip_finish(a, len, qbase + (int)(bw >> 24), (int)((bw >> 19) & 31u), diag - matches, (int)((bw >> 5) & 511u), matches,
                     (int)bq, first_n, out_len, keep, reason, clipped, adapter_only);
 }
 

@@ -103,17 +103,23 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     if ((st & FXG_STAGE_FTRIM) && p->ft_first < 1) FXG_PLAN_FAIL("-f must be >= 1");
     pl->amax = !pl->clip ? 0 : ka.alen <= 16 ? 16 : ka.alen <= 32 ? 32 : ka.alen <= 64 ? 64 : 100;
     // Packed path summary (one u32 per cell); buckets are fine-grained because every padded column costs a full cell.
-    //   up to 16 columns, reads up to 255 bases, no 'N' in the adapter: two passes in registers (fxg_clip_two_pass);
-    //   everything else: the form with ONE start field (fxg_clip_row_k) -- 17..99 columns, reads beyond 255 bases (its start is relative
-    //   to the second pass' first row), adapters that contain 'N' (instances -(300 + columns), two more instructions per cell).
+    //   up to 16 columns, no 'N' in the adapter: two passes in registers (fxg_clip_two_pass), reads of any length (the start of a path
+    //   is recorded relative to the second pass' first row);
+    //   everything else: the form with ONE start field (fxg_clip_row_k) -- 17..99 columns, adapters that contain 'N' (instances
+    //   -(300 + columns), two more instructions per cell).
     // That form runs two passes with its checkpoints in global scratch once the read is long enough to pay for the second one (one pass
     // ~15 VALU instructions per cell; two: ~6.5 + the <= SPAN + clip_ck_rows rows of the second pass), and always beyond 255 bases.
-    const bool kform = pl->clip && (ka.alen > 16 || ka.clip_stride > 255u || ka.adapter_has_n);
+#ifdef FXG_CLIP_ONE_PASS
+    const bool reg_any_len = false;              // (ablation build: the register form in one pass records absolute rows, 8 bits)
+#else
+    const bool reg_any_len = true;
+#endif
+    const bool kform = pl->clip && (ka.alen > 16 || ka.adapter_has_n || (ka.clip_stride > 255u && !reg_any_len));
     const bool two_pass_k = kform && (ka.clip_stride >= 20u + 2u * (u32)ka.alen || ka.clip_stride > 255u) && !getenv("FXG_CLIP_K_ONE_PASS");
     pl->ck_per_wg = 0;
     ka.clip_ck = nullptr;
     ka.clip_ck_rows = (ka.clip_stride + 7u) / 8u < 4u ? 4u : (ka.clip_stride + 7u) / 8u;      // (rows - 1) / clip_ck_rows <= FXG_CK_SLOTS
-    if (pl->clip && (ka.clip_stride <= 255u || two_pass_k) && !getenv("FXG_NO_PACKED_CLIP")) {
+    if (pl->clip && (ka.clip_stride <= 255u || two_pass_k || (!kform && reg_any_len)) && !getenv("FXG_NO_PACKED_CLIP")) {
         static const int pk[] = {4, 8, 9, 10, 11, 12, 13, 14, 15, 16, 20, 24, 28, 32, 36, 40, 48, 64, 100};      // 36: the 33/34-base TruSeq adapters
         static const int pn[] = {16, 24, 36, 48, 64, 100};
         int b = 100;

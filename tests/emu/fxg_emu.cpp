@@ -214,7 +214,9 @@ extern "C" int fxg_emu_run_pipeline_hist(const fxg_batch *in, const fxg_params *
         case -48: return emu_run<-48, false>(pl, ctr, err, cap);
         case -64: return emu_run<-64, false>(pl, ctr, err, cap);
         case -100: return emu_run<-100, false>(pl, ctr, err, cap);
+#ifdef FXG_CLIP_ONE_PASS
         case -216: return emu_run<-216, false>(pl, ctr, err, cap);
+#endif
         case -316: return emu_run<-316, false>(pl, ctr, err, cap);
         case -324: return emu_run<-324, false>(pl, ctr, err, cap);
         case -336: return emu_run<-336, false>(pl, ctr, err, cap);
