@@ -1567,6 +1567,7 @@ static int fxh_run_parts(FASTX *fx, const fxg_params *p, fxh_totals *tot, int k)
      * child empties the parts and exits with FXH_EXIT_ABANDON, and this process -- which has not touched the GPU yet -- runs the same
      * input unsharded (part 0 then receives everything).  Nothing is ever exec'd or killed with device work in flight: the child ends
      * like any tool run, after its threads have been joined and its contexts destroyed. */
+    if (g_first_ctx_done) return -1;             /* this process has used the GPU already (a host that calls in twice): no fork over a live HIP runtime */
     fflush(NULL);
     const pid_t child = fork();
     if (child < 0) return -1;
