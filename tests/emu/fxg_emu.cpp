@@ -178,6 +178,10 @@ static void emu_hist_prepass(fxg_emu_hist *hs, const fxg_batch *in, u32 T, u32 e
     if (lmax > hs->wcap) hs->wcap = lmax;
 }
 
+// what fxg_make_plan chose for the last pipeline call: the clip instance (FxgPlan.amax) and whether it runs its two-pass form with checkpoints in scratch
+static int g_last_amax, g_last_two_pass;
+extern "C" void fxg_emu_last_plan(int *amax, int *two_pass) { *amax = g_last_amax; *two_pass = g_last_two_pass; }
+
 extern "C" int fxg_emu_run_pipeline_hist(const fxg_batch *in, const fxg_params *p, const fxg_out *out, char *err, size_t cap, fxg_emu_hist *hs)
 {
     FxgPlan pl;
@@ -185,6 +189,7 @@ extern "C" int fxg_emu_run_pipeline_hist(const fxg_batch *in, const fxg_params *
     const u32 estride = hist && hs->wcap > in->stride ? hs->wcap : in->stride;
     const int rc = fxg_make_plan(in, p, out, &pl, err, cap, hist ? estride : 0u);
     if (rc != FXG_OK) return rc;
+    g_last_amax = pl.amax; g_last_two_pass = pl.ck_per_wg != 0;
     if (in->n == 0) return FXG_OK;
     if (hist) {
         int use = 0;

@@ -105,3 +105,10 @@ def run_quality_stats(bases, qual, lens, fixed_len=None, hist=None, cols=None):
     if rc != 0:
         raise ValueError("emu quality_stats rc=%d" % rc)
     return hist
+
+
+def last_plan():
+    """(clip instance, runs its scratch-checkpoint two-pass form) of the last run_pipeline call -- what fxg_make_plan chose."""
+    a, t = C.c_int(), C.c_int()
+    lib().fxg_emu_last_plan(C.byref(a), C.byref(t))
+    return a.value, bool(t.value)

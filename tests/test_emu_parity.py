@@ -146,3 +146,33 @@ def test_emulated_clip_two_pass_adversarial(form, monkeypatch):
         assert_same(fo.run_pipeline(b, q, None, p), emu.run_pipeline(b, q, None, p), name)
         checked += b.shape[0]
     assert checked > 40000
+
+
+def test_clip_instance_selection(monkeypatch):
+    """fxg_make_plan (host logic shared with the engine): which clip instance a request gets.  A request that silently fell back to the
+    general form (positive codes) would still be right, only 5-50 times slower -- so the choice itself is pinned here."""
+    rng = np.random.default_rng(3)
+    full = b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACATCACGATCTCGTATGCCGTCTTCTGCTTGAAAAAAAAAAGGGGGGGGGGCCCCCCCCCCTTTTTTTTT"
+    with_n = b"AGATCGGAAGNGCACACGTCTGAACTCCAGTCACNNNNNNATCTCGTATGCCGTCTTCTGCTTGAAAAAAAAAAGGGGGGGGGGCCCCCCCCCCTTTTTTTTT"
+    cases = [  # adapter, stride, instance, two passes with checkpoints in scratch
+        (full[:4], 100, -4, False), (full[:7], 100, -8, False), (full[:13], 100, -13, False), (full[:16], 255, -16, False),
+        (full[:13], 300, -13, False), (full[:13], 1000, -13, False),                      # the register form takes reads of any length
+        (full[:17], 100, -20, True), (full[:17], 50, -20, False), (full[:24], 100, -24, True), (full[:32], 100, -32, True),
+        (full[:33], 100, -36, True), (full[:34], 150, -36, True), (full[:34], 60, -36, False), (full[:40], 100, -40, True),
+        (full[:48], 150, -48, True), (full[:64], 150, -64, True), (full[:64], 100, -64, False), (full[:99], 255, -100, True),
+        (full[:34], 300, -36, True), (full[:99], 421, -100, True),
+        (with_n[:13], 100, -316, True), (with_n[:13], 30, -316, False), (with_n[:24], 100, -324, True), (with_n[:34], 100, -336, True),
+        (with_n[:48], 150, -348, True), (with_n[:64], 150, -364, True), (with_n[:99], 300, -400, True), (with_n[:13], 300, -316, True),
+    ]
+    for ad, stride, amax, two in cases:
+        b = np.ascontiguousarray(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(3, stride)))
+        q = np.full((3, stride), 70, dtype=np.uint8)
+        emu.run_pipeline(b, q, None, oracle_params(dict(stages=1, adapter=ad, clip_min_len=5, clip_flags=4)))
+        assert emu.last_plan() == (amax, two), (ad, stride, emu.last_plan(), (amax, two))
+    monkeypatch.setenv("FXG_CLIP_K_ONE_PASS", "1")
+    emu.run_pipeline(b, q, None, oracle_params(dict(stages=1, adapter=full[:34], clip_min_len=5, clip_flags=4)))
+    assert emu.last_plan()[0] > 0                       # 300-base reads, 34 columns, one pass: only the general form describes them
+    monkeypatch.delenv("FXG_CLIP_K_ONE_PASS")
+    monkeypatch.setenv("FXG_NO_PACKED_CLIP", "1")
+    emu.run_pipeline(b, q, None, oracle_params(dict(stages=1, adapter=full[:13], clip_min_len=5, clip_flags=4)))
+    assert emu.last_plan() == (16, False)
