@@ -148,7 +148,7 @@ FXG_HD void fxg_clip_read(const FxgKArgs &a, const uint8_t *rd, int len, int row
                     (int)bq, first_n, out_len, keep, reason, clipped, adapter_only);
 }
 
-// Packed form for reads <= 255 and adapters <= 31 (every BASELINE config): the whole path summary is ONE u32
+// Packed form for adapters up to 16 columns (every BASELINE config; the field widths would take 31): the whole path summary is ONE u32
 //   w = query_start:8 | target_start:5 | diagonal:5 | path_len:9 | matches:5      (path_len <= L + A <= 286)
 // `diagonal` counts the non-neutral diagonal steps (matches + mismatches): it grows by a constant of the row (0 when the read
 // base is 'N'), and `matches` sits in the lowest bits so that "+1 where read base == adapter base" is the carry-in of that
@@ -395,7 +395,7 @@ FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Adapters of 17..100 bases (MAX_ADAPTER_LEN, fastx_clipper.cpp:35), reads <= 255: one pass, the summary still ONE u32 per cell.
+// Adapters of 17..99 bases (MAX_ADAPTER_LEN, fastx_clipper.cpp:35): the summary still ONE u32 per cell; this is the one-pass driver (reads <= 255).
 // A path can only enter the matrix in row 0 or in column 0, so its start is one number, not two:
 //   k = start:9 | path_len:9 | diagonal:7 | matches:7        start = query_start (target_start 0), or 256 + target_start (query_start 0)
 // (path_len <= L + A <= 355, diagonal and matches <= A <= 100).  The row is swept in place: the diagonal candidate of column t + 1 --
@@ -768,7 +768,7 @@ FXG_HD void fxg_phase_stage_bases(const uint8_t *src, u64 total, u64 tb, u32 tby
 }
 
 // phase 2, group A: thread tid decides read r0 + tid
-// AMAX > 0: general clipper; AMAX < 0: packed clipper with bucket -AMAX columns (-216: 16 columns in the form of the 17..99 buckets)
+// AMAX > 0: general clipper (fallback, FXG_NO_PACKED_CLIP); AMAX < 0: packed clipper with bucket -AMAX columns (-216: 16 columns in the form of the 17..99 buckets, ablation build only)
 //   -(300 + columns): the same form for adapters that contain 'N' (buckets 16 24 36 48 64 100)
 __host__ __device__ constexpr int fxg_clip_cols(int amax) { return amax <= -300 ? -amax - 300 : amax <= -200 ? -amax - 200 : -amax; }
 __host__ __device__ constexpr bool fxg_clip_kform(int amax) { return amax < -16; }
