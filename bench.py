@@ -370,7 +370,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--e2e", action="store_true", help="also time the config's command line end to end, one tool chain per GPU (weak scaling; any --gpus)")
-    ap.add_argument("--e2e-reads", type=int, default=8_000_000, help="reads per rank of the --e2e leg")
+    ap.add_argument("--e2e-reads", type=int, default=32_000_000, help="reads per rank of the --e2e leg")
     ap.add_argument("--decision-only", action="store_true", help="no compaction: 154 B/read variant (not the headline)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
