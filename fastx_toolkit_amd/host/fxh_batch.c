@@ -11,6 +11,7 @@
 #include <sys/stat.h>
 #include <sys/types.h>
 #include <sys/wait.h>
+#include <sys/prctl.h>
 #include <signal.h>
 #include <unistd.h>
 
@@ -1583,6 +1584,7 @@ static int fxh_run_parts(FASTX *fx, const fxg_params *p, fxh_totals *tot, int k)
         if (WIFSIGNALED(st)) { signal(WTERMSIG(st), SIG_DFL); raise(WTERMSIG(st)); _exit(128 + WTERMSIG(st)); }
         _exit(WIFEXITED(st) ? WEXITSTATUS(st) : 1);                                      /* the child printed the reports and closed the parts */
     }
+    (void)prctl(PR_SET_PDEATHSIG, SIGTERM);      /* the child: a tool process that was killed takes its sharded attempt along */
     fxh_part *pt = (fxh_part *)calloc((size_t)k, sizeof(fxh_part));
     if (!pt) err(1, "out of memory");
     const char *cap_env = getenv("FXH_READ_BUFFER_MB");
