@@ -697,6 +697,7 @@ typedef struct fxh_lane {
     uint64_t ctr[FXG_NCOUNTERS];
     uint64_t weighted[8];                  /* FASTA: tallies weighted by the records' read counts (fxg_fasta_weights) */
     double t_busy, t_init;
+    double t_call[8];                        /* FXH_TIMING: seconds inside h2d, index, pack, pipeline, counters, format, d2h+sync, blocks */
 } fxh_lane;
 
 static void fxh_lane_run(fxh_lane *ln)
@@ -729,9 +730,13 @@ static void fxh_lane_run(fxh_lane *ln)
         if (!known && pn->n < (int)(sizeof pn->ptr / sizeof pn->ptr[0])) { pn->ptr[pn->n++] = ln->text_base; pthread_mutex_unlock(&pn->mu); (void)fxg_host_register(st->ctx, ln->text_base, ln->text_cap); }
         else pthread_mutex_unlock(&pn->mu);
     }
+    double tc = fxh_now(), tn;
+#define FXH_TCALL(k) do { tn = fxh_now(); ln->t_call[k] += tn - tc; tc = tn; } while (0)
     FXG_CHECK(st, fxg_memcpy_h2d(st->ctx, st->d_text, ln->text, len));
+    FXH_TCALL(0);
     fxg_text_info info;
     FXG_CHECK(st, fxg_fastq_index(st->ctx, st->d_text, len, 1, lpr, st->d_ls, st->d_ls_cap, st->d_len16, st->d_flags, &info));
+    FXH_TCALL(1);
     if (info.irregular || info.records == 0 || info.records != ln->records || info.consumed != len) return;
     const uint64_t n = info.records;
     const uint32_t stride = info.max_len;
@@ -740,6 +745,7 @@ static void fxh_lane_run(fxh_lane *ln)
     uint32_t irr = 0;
     FXG_CHECK(st, fxg_fastq_pack(st->ctx, st->d_text, len, lpr, st->d_ls, st->d_ls_cap, st->d_flags, n, stride, ln->qoffset, st->d_bases,
                                  ln->has_q ? st->d_qual : NULL, &irr));
+    FXH_TCALL(2);
     if (irr) return;
     if (revcomp && st->d_off_cap < n) {
         if (st->d_out_off) fxg_free_device(st->ctx, st->d_out_off);
@@ -752,16 +758,19 @@ static void fxh_lane_run(fxh_lane *ln)
     fxg_params pp = *ln->p;
     pp.qoffset = 33;
     FXG_CHECK(st, fxg_run_pipeline(st->ctx, &in, &pp, &out));
+    FXH_TCALL(3);
     {
         int rc = fxg_read_counters(st->ctx, st->d_counters, ln->ctr);
         if (rc == FXG_E_DEVICE && (ln->ctr[FXG_C_ERRORS] & FXG_DEV_ERR_BAD_BASE)) return;   /* the host parser prints the reference's message at its turn */
         if (rc != 0) errx(1, "GPU engine error %d: %s", rc, fxg_last_error(st->ctx));
     }
+    FXH_TCALL(4);
     if (lpr == 2) FXG_CHECK(st, fxg_fasta_weights(st->ctx, st->d_text, st->d_ls, st->d_ls_cap, n, st->d_res, ln->weighted));
     uint64_t out_bytes = 0;
     FXG_CHECK(st, fxg_fastq_format(st->ctx, st->d_text, lpr, st->d_ls, st->d_ls_cap, st->d_flags, n, st->d_res, ln->fwd_start, ln->reverse,
                                    revcomp ? st->d_out_bases : NULL, (revcomp && ln->has_q) ? st->d_out_qual : NULL, revcomp ? st->d_out_off : NULL,
                                    ln->has_q ? st->d_qual : NULL, stride, ln->qoffset, ln->out_fasta, st->d_out_text, &out_bytes));
+    FXH_TCALL(5);
     const int s = ln->slot;
     if (ln->out_cap[s] < out_bytes + 16) {
         if (ln->out[s]) fxg_free_host(st->ctx, ln->out[s]);
@@ -770,6 +779,9 @@ static void fxh_lane_run(fxh_lane *ln)
     }
     FXG_CHECK(st, fxg_memcpy_d2h(st->ctx, ln->out[s], st->d_out_text, out_bytes));
     FXG_CHECK(st, fxg_sync(st->ctx));
+    FXH_TCALL(6);
+    ln->t_call[7] += 1.0;
+#undef FXH_TCALL
     ln->out_len = (size_t)out_bytes;
     ln->handled = 1;
 }
@@ -1301,6 +1313,10 @@ static void fxh_lanes_stop(fxh_run *R, fxh_lane *lanes, int nlanes, double *t_la
         pthread_join(ln->th, NULL);
         *t_lane_init += ln->t_init;
         R->t_gpu += ln->t_busy;
+        if (getenv("FXH_TIMING") && ln->t_call[7] > 0)
+            fprintf(stderr, "fxh timing lane %d: %.0f blocks, ms per block: h2d %.3f index %.3f pack %.3f pipeline %.3f counters %.3f format %.3f d2h+sync %.3f\n", i, ln->t_call[7],
+                    1e3 * ln->t_call[0] / ln->t_call[7], 1e3 * ln->t_call[1] / ln->t_call[7], 1e3 * ln->t_call[2] / ln->t_call[7], 1e3 * ln->t_call[3] / ln->t_call[7],
+                    1e3 * ln->t_call[4] / ln->t_call[7], 1e3 * ln->t_call[5] / ln->t_call[7], 1e3 * ln->t_call[6] / ln->t_call[7]);
     }
     { const double tw = fxh_now(); fxh_awriter_wait(&R->aw); R->t_drain += fxh_now() - tw; }   /* the last lane buffer must be on its way out before the contexts go */
     /* The process is about to exit: device buffers, streams and page-locked memory go with it, there is nothing to gain from
