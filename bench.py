@@ -289,6 +289,42 @@ def e2e_leg(reads=16_000_000, big_reads=64_000_000, parts=4, lanes=2):
         return out
 
 
+def _gpu_node_cpus(index):
+    """(NUMA node, its CPUs) of GPU `index`, or (None, None): the boxes are two-socket machines with four GPUs per node, and a tool
+    process whose page-locked buffers sit on the other socket uploads across the socket link (profiles/r03/z_e2e_numa.txt: -8 %)."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(index)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return None, None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        return (node, cpus) if cpus else (None, None)
+    except Exception:
+        return None, None
+
+
+class _on_gpu_node:
+    """The launcher's part of NUMA placement: this process (and the tool processes and tmpfs pages it creates) on the CPUs of the GPU's node."""
+    def __init__(self, index):
+        self.node, self.cpus = _gpu_node_cpus(index)
+    def __enter__(self):
+        self.saved = os.sched_getaffinity(0)
+        if self.cpus and not os.environ.get("FXG_BENCH_NO_NUMA"):
+            os.sched_setaffinity(0, self.cpus)
+        else:
+            self.node = None
+        return self
+    def __exit__(self, *exc):
+        os.sched_setaffinity(0, self.saved)
+        return False
+
+
 def e2e_ranks(config, rank, local, world, reads_per_rank, dist, device):
     """--e2e: the config's command line end to end, one process per GPU as in the kernel-level run: every rank generates ITS shard of
     the synthetic set as FASTQ text on tmpfs, runs the tools of the config on its GPU (FXG_DEVICE = local rank; pipes where the
@@ -487,7 +523,10 @@ def main():
     e2e_r = None
     if args.e2e and not is_stats:
         try:
-            e2e_r = e2e_ranks(args.config, rank, local, world, args.e2e_reads, dist, eng.device)
+            with _on_gpu_node(local) as place:
+                e2e_r = e2e_ranks(args.config, rank, local, world, args.e2e_reads, dist, eng.device)
+            if isinstance(e2e_r, dict):
+                e2e_r["numa_node"] = place.node                 # the tool chain ran on its GPU's NUMA node (None: not pinned)
         except Exception as e:
             e2e_r = {"error": repr(e)[:200]}
     if rank == 0:
@@ -543,7 +582,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.config)
         if world == 1 and not args.no_e2e and args.config == "cfg2":
             try:
-                out["e2e"] = e2e_leg()
+                with _on_gpu_node(local) as place:
+                    out["e2e"] = e2e_leg()
+                out["e2e"]["numa_node"] = place.node
             except Exception as e:                         # the end-to-end leg must never take the headline line down
                 out["e2e"] = {"error": repr(e)[:200]}
         print(json.dumps(out), flush=True)

@@ -742,6 +742,20 @@ extern "C" int fxg_host_unregister(fxg_ctx *c, void *ptr)
 // ------------------------------------------------------------------------------------------------
 // several GPUs: shard ranges, the epilogue arithmetic and the concatenation (host only)
 // ------------------------------------------------------------------------------------------------
+extern "C" int fxg_device_numa_node(int device)
+{
+    char id[64] = {0}, path[128];
+    if (hipDeviceGetPCIBusId(id, (int)sizeof id - 1, device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char *q = id; *q; ++q) if (*q >= 'A' && *q <= 'F') *q = (char)(*q - 'A' + 'a');       // sysfs names are lower case
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", id);
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+
 extern "C" int fxg_device_count(void)
 {
     int n = 0;

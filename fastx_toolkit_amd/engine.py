@@ -25,7 +25,7 @@ EXPORTS = [
     "fxg_run_qtrim_qfilter", "fxg_run_clip", "fxg_run_revcomp_trim", "fxg_read_counters", "fxg_synth_generate",
     "fxg_last_launch_info", "fxg_set_profiling", "fxg_last_kernel_ms", "fxg_set_clip_history", "fxg_run_quality_stats",
     "fxg_fastq_index", "fxg_fastq_pack", "fxg_fastq_format", "fxg_fasta_weights", "fxg_host_register", "fxg_host_unregister",
-    "fxg_shard_range", "fxg_epilogue", "fxg_concat_pwrite", "fxg_device_count", "fxg_comm_create", "fxg_comm_destroy", "fxg_epilogue_rccl",
+    "fxg_shard_range", "fxg_epilogue", "fxg_concat_pwrite", "fxg_device_count", "fxg_device_numa_node", "fxg_comm_create", "fxg_comm_destroy", "fxg_epilogue_rccl",
 ]
 
 

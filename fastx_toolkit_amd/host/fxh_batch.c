@@ -12,6 +12,7 @@
 #include <sys/types.h>
 #include <sys/wait.h>
 #include <sys/prctl.h>
+#include <sched.h>
 #include <signal.h>
 #include <unistd.h>
 
@@ -840,6 +841,40 @@ static void fxh_lane_wait(fxh_lane *ln)
     pthread_mutex_unlock(&ln->mu);
 }
 
+/* A run that uses ONE GPU moves to the CPUs of that GPU's NUMA node before it creates its helper threads and touches its buffers
+ * (they are page-locked where first touched): uploads from the other socket cross the socket link -- 61.9 against 68.7 Mreads/s on the
+ * sharded run of 64 M reads (profiles/r03/z_e2e_numa.txt, bench.py e2e).  The calling thread only; threads it creates inherit it.
+ * FXH_NO_NUMA=1 leaves the placement to the caller (taskset / numactl / a job scheduler that already did it). */
+static void fxh_bind_near_device(int device)
+{
+    if (getenv("FXH_NO_NUMA")) return;
+    pthread_mutex_lock(&g_first_ctx_mu);         /* the query is a first use of the HIP runtime: one thread at a time, like the first context */
+    const int node = fxg_device_numa_node(device);
+    pthread_mutex_unlock(&g_first_ctx_mu);
+    if (node < 0) return;
+    char path[96], line[4096];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return;
+    const int got = fgets(line, sizeof line, f) != NULL;
+    fclose(f);
+    if (!got) return;
+    cpu_set_t now, want;
+    if (sched_getaffinity(0, sizeof now, &now) != 0) return;
+    CPU_ZERO(&want);
+    int any = 0;
+    for (const char *q = line; *q && *q != '\n';) {                  /* "0-63,128-191" */
+        char *end;
+        long a = strtol(q, &end, 10), b = a;
+        if (end == q) break;
+        if (*end == '-') { q = end + 1; b = strtol(q, &end, 10); if (end == q) break; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) if (c >= 0 && CPU_ISSET((int)c, &now)) { CPU_SET((int)c, &want); any = 1; }
+        q = (*end == ',') ? end + 1 : end;
+        if (*end != ',') break;
+    }
+    if (any) (void)sched_setaffinity(0, sizeof want, &want);          /* (never widens what the caller allowed) */
+}
+
 /* FXG_DEVICES = "0,1,3" | "all" | unset (then FXG_DEVICE, default 0) */
 static int fxh_device_list(int *dev, int cap)
 {
@@ -1409,6 +1444,7 @@ static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_sta
     int ndev = fxh_device_list(dev, FXH_MAX_LANES);
     if (nparts > 1 && ndev > 1) { dev[0] = dev[part % ndev]; ndev = 1; }      /* a part of a sharded run stays on one GPU */
     R.st_device = dev[0];
+    if (ndev == 1) fxh_bind_near_device(dev[0]);
     struct fxh_reader *rd = fx->reader;
     /* one engine call per 64 MB of text; the parts of a sharded run take 8 MB blocks (four parts x two lanes keep the link busy with
      * less to allocate, page-lock and touch first: 52 -> 62 Mreads/s on the 64 M read sample, profiles/r03/p_e2e_parts_block_size.txt) */

@@ -79,6 +79,7 @@ int fxg_fastq_format(fxg_ctx *, const uint8_t *t, int lpr, const uint32_t *line,
 { return fxg_emu_fastq_format(t, lpr, line, cap, fl, n, res, fs, rev, pb, pq, po, rq, stride, qo, fa, out, nb); }
 int fxg_fasta_weights(fxg_ctx *, const uint8_t *t, const uint32_t *line, uint64_t cap, uint64_t n, const uint32_t *res, uint64_t *w) { return fxg_emu_fasta_weights(t, line, cap, n, res, w); }
 int fxg_device_count(void) { return emu_device_count(); }
+int fxg_device_numa_node(int device) { (void)device; const char *e = getenv("FXG_EMU_NUMA_NODE"); return e ? atoi(e) : -1; }   /* no GPU, no node; the env lets a test walk the binding code */
 int fxg_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi) { *lo = n * rank / world; *hi = n * (rank + 1) / world; return 0; }
 int fxg_epilogue(const uint64_t *, uint32_t, uint32_t, uint64_t *, uint64_t *, uint64_t *) { return FXG_E_INVALID; }
 int fxg_concat_pwrite(int, const void *, uint64_t, uint64_t) { return FXG_E_INVALID; }

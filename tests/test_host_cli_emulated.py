@@ -278,6 +278,18 @@ def test_sharded_run_parts_concatenate_to_the_single_stream_output(tools, tmp_pa
     assert b"".join(open(str(tmp_path / ("fa.%d.fa" % r)), "rb").read() for r in range(4)) == (tmp_path / "fa_single.fa").read_bytes()
 
 
+def test_numa_binding_walks_and_changes_nothing(tools):
+    """A run on one GPU binds itself to the CPUs of that GPU's NUMA node (fxh_bind_near_device); the stub has no GPU, FXG_EMU_NUMA_NODE
+    names a node so that the code runs: same bytes, also sharded, also when the node does not exist or FXH_NO_NUMA is set."""
+    text = fo.synth_fastq(9, 0, 4000, 100, True)
+    argv = [os.path.join(tools, "fastq_quality_trim_filter"), "-t", "20", "-l", "30", "-q", "20", "-p", "80", "-v"]
+    want = _run(argv, text)
+    for env in ({"FXG_EMU_NUMA_NODE": "0"}, {"FXG_EMU_NUMA_NODE": "0", "FXH_LANES": "2", "FXH_READ_BUFFER_MB": "1"}, {"FXG_EMU_NUMA_NODE": "977"},
+                {"FXG_EMU_NUMA_NODE": "0", "FXH_NO_NUMA": "1"}):
+        got = _run(argv, text, extra_env=env)
+        assert got == want, env
+
+
 def test_lanes_many_blocks_any_lane_count_same_bytes(tools):
     """The lanes loop of the tools (blocks cut at record boundaries on the host, dealt round-robin to lanes over FXG_DEVICES, collected
     in input order): output, report and error behaviour must not depend on the number of lanes, devices or on the block size -- through
