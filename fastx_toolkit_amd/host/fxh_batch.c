@@ -845,22 +845,23 @@ static void fxh_lane_wait(fxh_lane *ln)
  * (they are page-locked where first touched): uploads from the other socket cross the socket link -- 61.9 against 68.7 Mreads/s on the
  * sharded run of 64 M reads (profiles/r03/z_e2e_numa.txt, bench.py e2e).  The calling thread only; threads it creates inherit it.
  * FXH_NO_NUMA=1 leaves the placement to the caller (taskset / numactl / a job scheduler that already did it). */
-static void fxh_bind_near_device(int device)
+/* returns 1 and the previous CPU set in *before when the calling thread was moved (the caller puts it back when the run is over) */
+static int fxh_bind_near_device(int device, cpu_set_t *before)
 {
-    if (getenv("FXH_NO_NUMA")) return;
+    if (getenv("FXH_NO_NUMA")) return 0;
     pthread_mutex_lock(&g_first_ctx_mu);         /* the query is a first use of the HIP runtime: one thread at a time, like the first context */
     const int node = fxg_device_numa_node(device);
     pthread_mutex_unlock(&g_first_ctx_mu);
-    if (node < 0) return;
+    if (node < 0) return 0;
     char path[96], line[4096];
     snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
     FILE *f = fopen(path, "r");
-    if (!f) return;
+    if (!f) return 0;
     const int got = fgets(line, sizeof line, f) != NULL;
     fclose(f);
-    if (!got) return;
+    if (!got) return 0;
     cpu_set_t now, want;
-    if (sched_getaffinity(0, sizeof now, &now) != 0) return;
+    if (sched_getaffinity(0, sizeof now, &now) != 0) return 0;
     CPU_ZERO(&want);
     int any = 0;
     for (const char *q = line; *q && *q != '\n';) {                  /* "0-63,128-191" */
@@ -872,7 +873,9 @@ static void fxh_bind_near_device(int device)
         q = (*end == ',') ? end + 1 : end;
         if (*end != ',') break;
     }
-    if (any) (void)sched_setaffinity(0, sizeof want, &want);          /* (never widens what the caller allowed) */
+    if (!any || sched_setaffinity(0, sizeof want, &want) != 0) return 0;      /* (never widens what the caller allowed) */
+    *before = now;
+    return 1;
 }
 
 /* FXG_DEVICES = "0,1,3" | "all" | unset (then FXG_DEVICE, default 0) */
@@ -1444,7 +1447,8 @@ static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_sta
     int ndev = fxh_device_list(dev, FXH_MAX_LANES);
     if (nparts > 1 && ndev > 1) { dev[0] = dev[part % ndev]; ndev = 1; }      /* a part of a sharded run stays on one GPU */
     R.st_device = dev[0];
-    if (ndev == 1) fxh_bind_near_device(dev[0]);
+    cpu_set_t cpus_before;
+    const int moved = ndev == 1 ? fxh_bind_near_device(dev[0], &cpus_before) : 0;
     struct fxh_reader *rd = fx->reader;
     /* one engine call per 64 MB of text; the parts of a sharded run take 8 MB blocks (four parts x two lanes keep the link busy with
      * less to allocate, page-lock and touch first: 52 -> 62 Mreads/s on the 64 M read sample, profiles/r03/p_e2e_parts_block_size.txt) */
@@ -1512,6 +1516,7 @@ static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_sta
         FXH_ABORT_SET();
         for (int i = 0; i < job->nworkers; ++i) { free(job->w[i].rec); free(job->w[i].shadow); }
         free(job->w);
+        if (moved) (void)sched_setaffinity(0, sizeof cpus_before, &cpus_before);
         return 2;
     }
     if (R.have_err) {
@@ -1535,6 +1540,7 @@ static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_sta
     if (R.st.ctx) fxg_ctx_destroy(R.st.ctx);
     for (int i = 0; i < job->nworkers; ++i) { free(job->w[i].rec); free(job->w[i].shadow); }
     free(job->w);
+    if (moved) (void)sched_setaffinity(0, sizeof cpus_before, &cpus_before);      /* a host that calls in again finds its own CPU set */
     return 0;
 }
 
