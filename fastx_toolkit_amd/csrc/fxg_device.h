@@ -102,6 +102,9 @@ struct FxgKArgs {
     const uint16_t *wlen;   // DP rows per read (null: the read's own length)
     float *clip_ck;         // two-pass clipper for 17..99 adapter columns (fxg_clip_two_pass_k): score-row checkpoints, FXG_CK_SLOTS x bucket x threads floats per workgroup (null: one pass)
     u32  clip_ck_rows;      // a checkpoint every this many rows
+#ifdef FXG_CLIP_DEBUG
+    u32 *clip_dbg;          // debug builds only (scripts/debug/clip64_bisect.py): 16 words per read of fxg_clip_two_pass_k's intermediate state
+#endif
     char adapter[100];
 };
 

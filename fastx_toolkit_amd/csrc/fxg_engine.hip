@@ -276,6 +276,15 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
 #ifdef FXG_ABLATION
     { const char *dbg = getenv("FXG_DEBUG"); ka.debug = dbg ? (u32)atoi(dbg) : 0u; }
 #endif
+#ifdef FXG_CLIP_DEBUG   // debug builds only (scripts/debug/clip64_bisect.py): FXG_CLIP_DBG_WORDS words per read from fxg_clip_two_pass_k, appended to $FXG_CLIP_DEBUG_OUT
+    u32 *clip_dbg = nullptr;
+    ka.clip_dbg = nullptr;
+    if (ck_per_wg && getenv("FXG_CLIP_DEBUG_OUT")) {
+        FXG_HIP(c, hipMalloc((void **)&clip_dbg, (size_t)ka.n * FXG_CLIP_DBG_WORDS * 4));
+        FXG_HIP(c, hipMemsetAsync(clip_dbg, 0xEE, (size_t)ka.n * FXG_CLIP_DBG_WORDS * 4, c->stream));
+        ka.clip_dbg = clip_dbg;
+    }
+#endif
     ka.errflag = c->errflag;                     // control block (zeroed before every launch), layout at FXG_CTRL_WORDS
     ka.ticket = c->errflag + FXG_CTRL_WORDS;
     ka.extra = (u64 *)(c->errflag + 2);
@@ -296,6 +305,17 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
     FXG_HIP(c, hipGetLastError());
     snprintf(c->last_kernel, sizeof c->last_kernel, "%s", kname);
     c->last_grid = (u32)grid; c->last_block = block; c->last_lds = lds; c->last_tile = ka.tile_reads;
+#ifdef FXG_CLIP_DEBUG
+    if (clip_dbg) {
+        u32 *h = (u32 *)malloc((size_t)ka.n * FXG_CLIP_DBG_WORDS * 4);
+        FXG_HIP(c, hipStreamSynchronize(c->stream));
+        FXG_HIP(c, hipMemcpy(h, clip_dbg, (size_t)ka.n * FXG_CLIP_DBG_WORDS * 4, hipMemcpyDeviceToHost));
+        FILE *f = fopen(getenv("FXG_CLIP_DEBUG_OUT"), "ab");
+        if (f) { fwrite(h, FXG_CLIP_DBG_WORDS * 4, (size_t)ka.n, f); fclose(f); }
+        free(h);
+        (void)hipFree(clip_dbg);
+    }
+#endif
     return FXG_OK;
 }
 
@@ -762,126 +782,21 @@ extern "C" int fxg_device_count(void)
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 
-extern "C" int fxg_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi)
+// the multi-GPU host code (shard ranges, epilogue, concatenation, RCCL transport) is fxg_comm.h: it reaches device memory through
+// these hooks only, so that the CPU tier compiles the very same code over host memory (tests/emu/fxg_stub.cpp)
+#define FXG_COMM_FAIL(c, code, ...) fxg_fail(c, code, __VA_ARGS__)
+#define FXG_COMM_SET_DEVICE(c) (hipSetDevice((c)->device) == hipSuccess)
+#define FXG_COMM_MALLOC(pp, bytes) (hipMalloc((void **)(pp), (bytes)) == hipSuccess)
+#define FXG_COMM_FREE(p) ((void)hipFree(p))
+#define FXG_COMM_STREAM(c) ((void *)(c)->stream)
+#define FXG_COMM_SCRATCH(c) ((const uint64_t *)(c)->counters_scratch)
+static const char *fxg_comm_d2h_sync(fxg_ctx *c, void *dst, const void *src, size_t bytes)
 {
-    if (!lo || !hi || world == 0 || rank >= world) return FXG_E_INVALID;
-    *lo = (uint64_t)(((unsigned __int128)n * rank) / world);
-    *hi = (uint64_t)(((unsigned __int128)n * (rank + 1u)) / world);
-    return FXG_OK;
-}
-
-extern "C" int fxg_epilogue(const uint64_t *gathered, uint32_t world, uint32_t rank, uint64_t totals[FXG_NCOUNTERS],
-                            uint64_t *read_off, uint64_t *byte_off)
-{
-    if (!gathered || world == 0 || rank >= world) return FXG_E_INVALID;
-    uint64_t ro = 0, bo = 0;
-    if (totals) memset(totals, 0, FXG_NCOUNTERS * sizeof(uint64_t));
-    for (uint32_t g = 0; g < world; ++g) {
-        const uint64_t *c = gathered + (size_t)g * FXG_NCOUNTERS;
-        if (g < rank) { ro += c[FXG_C_KEPT]; bo += c[FXG_C_KEPT_BASES]; }
-        if (totals)
-            for (int i = 0; i < FXG_NCOUNTERS; ++i) { if (i == FXG_C_ERRORS) totals[i] |= c[i]; else totals[i] += c[i]; }
-    }
-    if (read_off) *read_off = ro;
-    if (byte_off) *byte_off = bo;
-    return FXG_OK;
-}
-
-extern "C" int fxg_concat_pwrite(int fd, const void *host_buf, uint64_t bytes, uint64_t offset)
-{
-    if (fd < 0 || (!host_buf && bytes)) return FXG_E_INVALID;
-    const char *p = (const char *)host_buf;
-    while (bytes) {
-        const ssize_t k = pwrite(fd, p, bytes > ((uint64_t)1 << 30) ? ((size_t)1 << 30) : (size_t)bytes, (off_t)offset);
-        if (k < 0) { if (errno == EINTR) continue; return FXG_E_INVALID; }
-        p += k; offset += (uint64_t)k; bytes -= (uint64_t)k;
-    }
-    return FXG_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// RCCL transport of the counter blocks (one process per GPU, C hosts).  librccl.so is opened at run time.
-// ------------------------------------------------------------------------------------------------
-typedef struct { char internal[128]; } fxg_nccl_id;          // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
-struct fxg_comm {
-    void *lib, *comm;
-    uint32_t rank, world;
-    u64 *d_gather;                                            // world * FXG_NCOUNTERS
-    int (*get_id)(fxg_nccl_id *);
-    int (*init_rank)(void **, int, fxg_nccl_id, int);
-    int (*all_gather)(const void *, void *, size_t, int, void *, hipStream_t);
-    int (*destroy)(void *);
-    const char *(*err_string)(int);
-};
-
-extern "C" void fxg_comm_destroy(fxg_comm *m)
-{
-    if (!m) return;
-    if (m->comm && m->destroy) (void)m->destroy(m->comm);
-    (void)hipFree(m->d_gather);
-    if (m->lib) dlclose(m->lib);
-    free(m);
-}
-
-extern "C" int fxg_comm_create(fxg_ctx *c, const char *file, uint32_t rank, uint32_t world, int timeout_s, fxg_comm **out)
-{
-    if (!c || !file || !out || world == 0 || rank >= world) return FXG_E_INVALID;
-    *out = nullptr;
-    fxg_comm *m = (fxg_comm *)calloc(1, sizeof(fxg_comm));
-    if (!m) return FXG_E_NOMEM;
-    m->rank = rank; m->world = world;
-    m->lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!m->lib) m->lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-    if (!m->lib) { free(m); return fxg_fail(c, FXG_E_HIP, "RCCL is not installed (dlopen librccl.so: %s)", dlerror()); }
-    m->get_id = (int (*)(fxg_nccl_id *))dlsym(m->lib, "ncclGetUniqueId");
-    m->init_rank = (int (*)(void **, int, fxg_nccl_id, int))dlsym(m->lib, "ncclCommInitRank");
-    m->all_gather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(m->lib, "ncclAllGather");
-    m->destroy = (int (*)(void *))dlsym(m->lib, "ncclCommDestroy");
-    m->err_string = (const char *(*)(int))dlsym(m->lib, "ncclGetErrorString");
-    if (!m->get_id || !m->init_rank || !m->all_gather || !m->destroy) { fxg_comm_destroy(m); return fxg_fail(c, FXG_E_HIP, "librccl.so lacks the NCCL entry points"); }
-    fxg_nccl_id id;
-    memset(&id, 0, sizeof id);
-    if (rank == 0) {                                          // publish the id atomically: write a temporary, rename it into place
-        const int rc = m->get_id(&id);
-        if (rc != 0) { fxg_comm_destroy(m); return fxg_fail(c, FXG_E_HIP, "ncclGetUniqueId: %s", m->err_string ? m->err_string(rc) : "error"); }
-        char tmp[4096];
-        snprintf(tmp, sizeof tmp, "%s.tmp.%d", file, (int)getpid());
-        const int fd = open(tmp, O_CREAT | O_WRONLY | O_TRUNC, 0600);
-        if (fd < 0 || write(fd, &id, sizeof id) != (ssize_t)sizeof id || close(fd) != 0 || rename(tmp, file) != 0) { fxg_comm_destroy(m); return fxg_fail(c, FXG_E_INVALID, "cannot write the rendezvous file %s: %s", file, strerror(errno)); }
-    } else {
-        bool got = false;
-        for (int tries = 0; tries < (timeout_s > 0 ? timeout_s : 60) * 20 && !got; ++tries) {
-            const int fd = open(file, O_RDONLY);
-            if (fd >= 0) { got = read(fd, &id, sizeof id) == (ssize_t)sizeof id; close(fd); }
-            if (!got) usleep(50000);
-        }
-        if (!got) { fxg_comm_destroy(m); return fxg_fail(c, FXG_E_INVALID, "rank %u: no RCCL id in %s after %d s", rank, file, timeout_s > 0 ? timeout_s : 60); }
-    }
-    if (hipSetDevice(c->device) != hipSuccess || hipMalloc((void **)&m->d_gather, (size_t)world * FXG_NCOUNTERS * sizeof(u64)) != hipSuccess) { fxg_comm_destroy(m); return fxg_fail(c, FXG_E_HIP, "hipMalloc of the gather buffer failed"); }
-    const int rc = m->init_rank(&m->comm, (int)world, id, (int)rank);
-    if (rc != 0) { m->comm = nullptr; fxg_comm_destroy(m); return fxg_fail(c, FXG_E_HIP, "ncclCommInitRank(rank %u of %u): %s", rank, world, m->err_string ? m->err_string(rc) : "error"); }
-    *out = m;
-    return FXG_OK;
-}
-
-extern "C" int fxg_epilogue_rccl(fxg_ctx *c, fxg_comm *m, const uint64_t *d_counters, uint64_t totals[FXG_NCOUNTERS], uint64_t *read_off,
-                                 uint64_t *byte_off, uint64_t *gathered)
-{
-    if (!c || !m || !m->comm) return FXG_E_INVALID;
-    FXG_HIP(c, hipSetDevice(c->device));
-    const u64 *src = d_counters ? (const u64 *)d_counters : c->counters_scratch;
-    const int rc = m->all_gather(src, m->d_gather, FXG_NCOUNTERS, 5 /* ncclUint64 */, m->comm, c->stream);     // behind the pass on the same stream
-    if (rc != 0) return fxg_fail(c, FXG_E_HIP, "ncclAllGather: %s", m->err_string ? m->err_string(rc) : "error");
-    u64 *host = (u64 *)malloc((size_t)m->world * FXG_NCOUNTERS * sizeof(u64));
-    if (!host) return FXG_E_NOMEM;
-    hipError_t e = hipMemcpyAsync(host, m->d_gather, (size_t)m->world * FXG_NCOUNTERS * sizeof(u64), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) { free(host); return fxg_fail(c, FXG_E_HIP, "copying the gathered counters failed: %s", hipGetErrorString(e)); }
-    const int erc = fxg_epilogue((const uint64_t *)host, m->world, m->rank, totals, read_off, byte_off);
-    if (gathered) memcpy(gathered, host, (size_t)m->world * FXG_NCOUNTERS * sizeof(u64));
-    free(host);
-    return erc;
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }
+#include "fxg_comm.h"
 
 extern "C" int fxg_set_profiling(fxg_ctx *c, int enabled)
 {

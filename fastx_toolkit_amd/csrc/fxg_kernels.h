@@ -405,7 +405,7 @@ FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int 
 // bases, 1 040 at 32 and 200 from 33 on -- profiles/r03/u_clip_by_adapter_len_before.txt).
 // The virtual cells above row 0 carry the summary a path entering diagonally at (0, t) starts from, as in fxg_clip_two_pass.
 // ------------------------------------------------------------------------------------------------
-#ifdef FXG_HOST_EMULATION
+#if defined(FXG_HOST_EMULATION) || defined(FXG_NO_KEEP_V)
 #define FXG_KEEP_V(x) ((void)0)
 #else
 #define FXG_KEEP_V(x) asm volatile("" : "+v"(x))
@@ -574,10 +574,21 @@ FXG_HD float fxg_clip_row_score_k(const FxgKArgs &a, int A, u32 c, int q, float 
     return rowmax;
 }
 
+#ifdef FXG_CLIP_DEBUG
+#define FXG_CLIP_DBG_WORDS 512u   // per read: [0,16) scalars and hashes, [16,272) level 3: (hash S, hash W) after each summary row, [272,464): S at r0, S and W before the last row
+#define FXG_CLIP_DBG(i, v) do { if (dbg) dbg[i] = (u32)(v); } while (0)
+FXG_HD u32 fxg_fbits(float f) { union { float f; u32 u; } x; x.f = f; return x.u; }
+template <int N> FXG_HD u32 fxg_dbg_hash(const float (&S)[N]) { u32 h = 0; for (int t = 0; t < N; ++t) h = h * 31u + fxg_fbits(S[t]); return h; }
+template <int N> FXG_HD u32 fxg_dbg_hash(const u32 (&W)[N]) { u32 h = 0; for (int t = 0; t < N; ++t) h = h * 31u + W[t]; return h; }
+#else
+FXG_HD u32 fxg_fbits(float) { return 0u; }
+#define FXG_CLIP_DBG(i, v) do { } while (0)
+#endif
 // returns r0 (the row the `start` field of bw counts from)
 template <int AMAX, bool TN>
-FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float *ck, u32 cks, float &best, u32 &bw, u32 &bq, int &first_n)
+FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float *ck, u32 cks, float &best, u32 &bw, u32 &bq, int &first_n, u32 *dbg = nullptr)
 {
+    (void)dbg;
     float S[AMAX], Sm[AMAX];
     const int A = a.alen, K = (int)a.clip_ck_rows;
     const int early_rows = (A - 4 < rows) ? (A - 4 > 0 ? A - 4 : 0) : rows;
@@ -611,6 +622,7 @@ FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, in
     const int r0 = bq1 - span + 1 > 0 ? bq1 - span + 1 : 0;
     const int j0 = r0 / K;
     q = j0 * K;
+    FXG_CLIP_DBG(0, bq1); FXG_CLIP_DBG(1, fxg_fbits(b1)); FXG_CLIP_DBG(2, r0); FXG_CLIP_DBG(3, j0);
     {
         const float *from = ck + (size_t)(j0 > 0 ? j0 - 1 : 0) * AMAX * cks;
 #pragma unroll
@@ -622,18 +634,50 @@ FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, in
     }
     // Every lane has its own rows here, so the loops keep ONE body each: the early form (which tests the row number itself) wherever a
     // row below A - 4 can occur -- the < clip_ck_rows rows of the score re-run and the first A - 4 rows of the summary window.
+#if defined(FXG_CLIP_DEBUG) && FXG_CLIP_DEBUG >= 2
+    FXG_CLIP_DBG(4, fxg_dbg_hash(S));
+#endif
 #pragma unroll 1
     for (; q < r0; ++q) (void)fxg_clip_row_score_k<AMAX, true, TN>(a, A, (u32)rd[q], q, S, Sm);
+#if defined(FXG_CLIP_DEBUG) && FXG_CLIP_DEBUG >= 2
+    FXG_CLIP_DBG(5, fxg_dbg_hash(S));
+#endif
     u32 W[AMAX];
 #pragma unroll
     for (int t = 0; t < AMAX; ++t) W[t] = FXG_K_START(256 + t + 1) + FXG_K_SZ1;         // the cells above row 0 (r0 > 0: never on the best path)
     float (&Sk)[FxgClipK<AMAX>::NSM] = reinterpret_cast<float (&)[FxgClipK<AMAX>::NSM]>(Sm);    // the summary rows keep S - 5 only where registers allow
     int i = 0;
+#ifdef FXG_CLIP_DEBUG
+    constexpr int DT0 = AMAX > 64 ? AMAX - 64 : 0;          // the LAST 64 columns of the wide buckets
+    (void)DT0;
+#endif
+#if defined(FXG_CLIP_DEBUG) && FXG_CLIP_DEBUG >= 3
+    if (dbg) for (int t = DT0; t < AMAX; ++t) dbg[272 + t - DT0] = fxg_fbits(S[t]);
+#define FXG_CLIP_DBG_ROW() do { const int wr_ = q - r0; if (dbg && wr_ < 128) { dbg[16 + 2 * wr_] = fxg_dbg_hash(S); dbg[17 + 2 * wr_] = fxg_dbg_hash(W); } } while (0)
+#else
+#define FXG_CLIP_DBG_ROW() do { } while (0)
+#endif
 #pragma unroll 1
-    for (; q < bq1 && i < early_rows; ++q, ++i) fxg_clip_row_k<AMAX, true, false, TN>(a, A, (u32)rd[q], q, (u32)(q - r0), S, Sk, W, best, bw, bq);
+    for (; q < bq1 && i < early_rows; ++q, ++i) { fxg_clip_row_k<AMAX, true, false, TN>(a, A, (u32)rd[q], q, (u32)(q - r0), S, Sk, W, best, bw, bq); FXG_CLIP_DBG_ROW(); }
 #pragma unroll 1
-    for (; q < bq1; ++q) fxg_clip_row_k<AMAX, false, false, TN>(a, A, (u32)rd[q], q, (u32)(q - r0), S, Sk, W, best, bw, bq);
+    for (; q < bq1; ++q) { fxg_clip_row_k<AMAX, false, false, TN>(a, A, (u32)rd[q], q, (u32)(q - r0), S, Sk, W, best, bw, bq); FXG_CLIP_DBG_ROW(); }
+#if defined(FXG_CLIP_DEBUG) && FXG_CLIP_DEBUG >= 3
+    if (dbg) for (int t = DT0; t < AMAX; ++t) { dbg[336 + t - DT0] = fxg_fbits(S[t]); dbg[400 + t - DT0] = W[t]; }
+#endif
+#ifdef FXG_CLIP_DEBUG_W      // lighter probes (the level-3 build no longer failed): only W / only a window of W before the last row
+    if (dbg) for (int t = (FXG_CLIP_DEBUG_W); t < AMAX && t < 64; ++t) dbg[400 + t] = W[t];
+#endif
+#ifdef FXG_CLIP_DEBUG_S
+    if (dbg) for (int t = (FXG_CLIP_DEBUG_S); t < AMAX && t < 64; ++t) dbg[336 + t] = fxg_fbits(S[t]);
+#endif
+#if defined(FXG_CLIP_DEBUG) && FXG_CLIP_DEBUG >= 2
+    FXG_CLIP_DBG(10, fxg_dbg_hash(S)); FXG_CLIP_DBG(11, fxg_dbg_hash(W));
+#endif
     fxg_clip_row_k<AMAX, true, true, TN>(a, A, (u32)rd[bq1], bq1, (u32)(bq1 - r0), S, Sk, W, best, bw, bq);
+    FXG_CLIP_DBG(6, fxg_fbits(best)); FXG_CLIP_DBG(7, bw); FXG_CLIP_DBG(8, bq);
+#if defined(FXG_CLIP_DEBUG) && FXG_CLIP_DEBUG >= 2
+    FXG_CLIP_DBG(12, fxg_dbg_hash(S)); FXG_CLIP_DBG(13, fxg_dbg_hash(W));
+#endif
     if (!(a.clip_flags & FXG_CLIP_KEEP_N)) {                                             // the -n rule needs the first N of the read itself
 #pragma unroll 1
         for (int k = len - 1; k >= 0; --k) first_n = (rd[k] == (uint8_t)'N') ? k : first_n;
@@ -645,8 +689,9 @@ FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, in
 // form of fxg_clip_two_pass cannot describe: its start field is absolute)
 template <int AMAX, bool KFORM, bool TN = false>
 FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len, int rows,
-                                 u32 *out_len, u32 *keep, u32 *reason, u32 *clipped, u32 *adapter_only, float *ck = nullptr, u32 cks = 0u)
+                                 u32 *out_len, u32 *keep, u32 *reason, u32 *clipped, u32 *adapter_only, float *ck = nullptr, u32 cks = 0u, u32 *dbg = nullptr)
 {
+    (void)dbg;
     float best = -1000000.0f;
     u32 bw = FXG_INVALID_TUPLE, bq = 0u;
     int first_n = len, qbase = 0;
@@ -657,7 +702,7 @@ FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len, 
     if constexpr (!KFORM) fxg_clip_rows_packed<AMAX, false>(a, rd, len, rows, best, bw, bq, first_n);
     if constexpr (KFORM) {
         int r0 = 0;
-        if (ck) r0 = fxg_clip_two_pass_k<AMAX, TN>(a, rd, len, rows, ck, cks, best, bw, bq, first_n);
+        if (ck) r0 = fxg_clip_two_pass_k<AMAX, TN>(a, rd, len, rows, ck, cks, best, bw, bq, first_n, dbg);
         else fxg_clip_rows_k<AMAX, TN>(a, rd, len, rows, best, bw, bq, first_n);
         const int v = (int)(bw >> 23), matches = (int)(bw & 127u), diag = (int)((bw >> 7) & 127u);
         fxg_clip_finish(a, len, v < 256 ? r0 + v : 0, v < 256 ? 0 : v - 256, diag - matches, (int)((bw >> 14) & 511u), matches,
@@ -786,8 +831,13 @@ FXG_HD u32 fxg_decide_a(const FxgKArgs &a, const u32 *bm_g, const u32 *bm_l, con
         // fixed-length batch without clip history: the row count is a scalar, so every loop of the DP is a scalar loop
         constexpr int COLS = fxg_clip_cols(AMAX);
         constexpr bool KF = fxg_clip_kform(AMAX), TN = fxg_clip_tn(AMAX);
-        if (!a.len && !a.wlen) fxg_clip_read_packed<COLS, KF, TN>(a, sb + tid * a.clip_stride, (int)a.fixed_len, (int)a.fixed_len, &curlen, &keep, &reason, &clipped, &ao, ck, cks);
-        else fxg_clip_read_packed<COLS, KF, TN>(a, sb + tid * a.clip_stride, (int)rl, rows, &curlen, &keep, &reason, &clipped, &ao, ck, cks);
+#ifdef FXG_CLIP_DEBUG
+        u32 *dbg = a.clip_dbg ? a.clip_dbg + (size_t)(r0 + tid) * FXG_CLIP_DBG_WORDS : nullptr;
+#else
+        u32 *dbg = nullptr;
+#endif
+        if (!a.len && !a.wlen) fxg_clip_read_packed<COLS, KF, TN>(a, sb + tid * a.clip_stride, (int)a.fixed_len, (int)a.fixed_len, &curlen, &keep, &reason, &clipped, &ao, ck, cks, dbg);
+        else fxg_clip_read_packed<COLS, KF, TN>(a, sb + tid * a.clip_stride, (int)rl, rows, &curlen, &keep, &reason, &clipped, &ao, ck, cks, dbg);
     }
     if (keep && (a.stages & FXG_STAGE_QTRIM)) {             // fastq_quality_trimmer.c:94-101
         const u32 k = fxg_bits_last(bm_g, tid * stride, curlen);
@@ -920,7 +970,14 @@ __device__ __forceinline__ void fxg_tile_tally(u32 w, bool valid, u64 *tally)
 // waves per SIMD the clip instances are compiled for: the packed forms keep 2-3 registers per adapter column (two-pass: 6 of <= 16)
 // (64 columns at three waves = 168 registers spilled and came out WRONG on the GPU in the two-pass form -- 19 of 223 reads of one
 // adversarial case, the emulator and every other bucket agreeing with the oracle; at two waves nothing spills and it is right)
-__host__ __device__ constexpr int fxg_clip_waves(int amax) { return amax > 0 ? 1 : fxg_clip_cols(amax) <= 32 ? FXG_CLIP_WAVES : fxg_clip_cols(amax) <= 48 ? 3 : 2; }
+#ifndef FXG_CLIP_WAVES_WIDE
+#define FXG_CLIP_WAVES_WIDE 2   // 49..99 columns (ablation builds: 3)
+#endif
+#ifdef FXG_CLIP_WAVES_ALL    // the instance x launch-bounds parity matrix (tests/test_gpu_clip_matrix.py): every packed clip instance at this many waves per SIMD
+__host__ __device__ constexpr int fxg_clip_waves(int amax) { return amax > 0 ? 1 : FXG_CLIP_WAVES_ALL; }
+#else
+__host__ __device__ constexpr int fxg_clip_waves(int amax) { return amax > 0 ? 1 : fxg_clip_cols(amax) <= 32 ? FXG_CLIP_WAVES : fxg_clip_cols(amax) <= 48 ? 3 : FXG_CLIP_WAVES_WIDE; }
+#endif
 template <int AMAX, int MODE> struct FxgTileBlock { static constexpr int threads = (MODE == 0 && AMAX < 0 && AMAX >= -16) ? FXG_CLIP_TBLOCK : FXG_TBLOCK; };
 template <int AMAX, int MODE>
 __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? FXG_MIN_WAVES : fxg_clip_waves(AMAX))) void fxg_kernel_tiles(const FxgKArgs a)

@@ -84,7 +84,7 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
             for (u32 tid = 0; tid < nreads; ++tid) {
                 if (AMAX == 0 && pl.rows_nw) emu_rows_decide(pl.rows_nw, pl.rows_h, a, r0 + tid, &keep[tid], &olen[tid]);   // what a lane of fxg_kernel_rows does
                 else if (AMAX < -16 && pl.ck_per_wg) {        // the two-pass form with its checkpoint scratch (here: one thread's, stride 1)
-                    std::vector<float> ck((size_t)FXG_CK_SLOTS * (size_t)(AMAX < 0 ? fxg_clip_cols(AMAX) : 1), 1.0e30f);   // the device's scratch is not cleared either
+                    std::vector<float> ck((size_t)FXG_CK_SLOTS * (size_t)(AMAX < 0 ? fxg_clip_cols(AMAX) : 1), (getenv("FXG_EMU_CK_FILL") ? (float)atof(getenv("FXG_EMU_CK_FILL")) : 1.0e30f));   // the device's scratch is not cleared either
                     fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid], ck.data(), 1u);
                 } else fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid]);
                 anchor[tid] = tid * stride;
@@ -182,6 +182,10 @@ static void emu_hist_prepass(fxg_emu_hist *hs, const fxg_batch *in, u32 T, u32 e
 static int g_last_amax, g_last_two_pass;
 extern "C" void fxg_emu_last_plan(int *amax, int *two_pass) { *amax = g_last_amax; *two_pass = g_last_two_pass; }
 
+#ifdef FXG_CLIP_DEBUG
+static std::vector<u32> g_clip_dbg;
+extern "C" size_t fxg_emu_clip_debug(u32 *out, size_t cap_words) { const size_t k = g_clip_dbg.size() < cap_words ? g_clip_dbg.size() : cap_words; memcpy(out, g_clip_dbg.data(), k * 4); return k; }
+#endif
 extern "C" int fxg_emu_run_pipeline_hist(const fxg_batch *in, const fxg_params *p, const fxg_out *out, char *err, size_t cap, fxg_emu_hist *hs)
 {
     FxgPlan pl;
@@ -191,6 +195,10 @@ extern "C" int fxg_emu_run_pipeline_hist(const fxg_batch *in, const fxg_params *
     if (rc != FXG_OK) return rc;
     g_last_amax = pl.amax; g_last_two_pass = pl.ck_per_wg != 0;
     if (in->n == 0) return FXG_OK;
+#ifdef FXG_CLIP_DEBUG      // debug builds (scripts/debug/clip64_bisect.py): the per-read dump of fxg_clip_two_pass_k, read back through fxg_emu_clip_debug
+    g_clip_dbg.assign((size_t)in->n * FXG_CLIP_DBG_WORDS, 0xEEEEEEEEu);
+    pl.ka.clip_dbg = g_clip_dbg.data();
+#endif
     if (hist) {
         int use = 0;
         emu_hist_prepass(hs, in, pl.ka.tile_reads, estride, &pl.ka, &use);

@@ -80,15 +80,28 @@ int fxg_fastq_format(fxg_ctx *, const uint8_t *t, int lpr, const uint32_t *line,
 int fxg_fasta_weights(fxg_ctx *, const uint8_t *t, const uint32_t *line, uint64_t cap, uint64_t n, const uint32_t *res, uint64_t *w) { return fxg_emu_fasta_weights(t, line, cap, n, res, w); }
 int fxg_device_count(void) { return emu_device_count(); }
 int fxg_device_numa_node(int device) { (void)device; const char *e = getenv("FXG_EMU_NUMA_NODE"); return e ? atoi(e) : -1; }   /* no GPU, no node; the env lets a test walk the binding code */
-int fxg_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi) { *lo = n * rank / world; *hi = n * (rank + 1) / world; return 0; }
-int fxg_epilogue(const uint64_t *, uint32_t, uint32_t, uint64_t *, uint64_t *, uint64_t *) { return FXG_E_INVALID; }
-int fxg_concat_pwrite(int, const void *, uint64_t, uint64_t) { return FXG_E_INVALID; }
-int fxg_comm_create(fxg_ctx *, const char *, uint32_t, uint32_t, int, fxg_comm **out) { *out = nullptr; return FXG_E_HIP; }
-void fxg_comm_destroy(fxg_comm *) {}
-int fxg_epilogue_rccl(fxg_ctx *, fxg_comm *, const uint64_t *, uint64_t *, uint64_t *, uint64_t *, uint64_t *) { return FXG_E_INVALID; }
 int fxg_host_register(fxg_ctx *, void *, size_t) { return 0; }
 int fxg_host_unregister(fxg_ctx *, void *) { return 0; }
 int fxg_set_profiling(fxg_ctx *, int) { return 0; }
 int fxg_last_kernel_ms(fxg_ctx *, float *ms) { *ms = 0; return 0; }
 int fxg_last_launch_info(const fxg_ctx *, char *name, size_t cap, uint32_t *g, uint32_t *b, uint32_t *l, uint32_t *t) { if (name && cap) name[0] = 0; if (g) *g = 0; if (b) *b = 0; if (l) *l = 0; if (t) *t = 0; return 0; }
 }
+
+// The multi-GPU host code is the product's own (csrc/fxg_comm.h) over this stub's host-memory "device": shard ranges, epilogue,
+// concatenation and the RCCL transport -- which dlopens librccl.so.1, i.e. tests/emu/fakerccl's shared-memory stand-in when the
+// test puts it first on LD_LIBRARY_PATH -- run here with world > 1 (tests/test_comm_cpu.py).
+#include <cstdarg>
+static int stub_fail(fxg_ctx *c, int code, const char *fmt, ...)
+{
+    if (c) { va_list ap; va_start(ap, fmt); vsnprintf(c->err, sizeof c->err, fmt, ap); va_end(ap); }
+    return code;
+}
+#define FXG_COMM_FAIL(c, code, ...) stub_fail(c, code, __VA_ARGS__)
+#define FXG_COMM_SET_DEVICE(c) ((c)->device >= 0)
+#define FXG_COMM_MALLOC(pp, bytes) ((*(void **)(pp) = getenv("FXG_EMU_COMM_NOMEM") ? nullptr : amalloc(bytes)) != nullptr)
+#define FXG_COMM_FREE(p) free(p)
+#define FXG_COMM_STREAM(c) ((void *)nullptr)
+#define FXG_COMM_SCRATCH(c) ((const uint64_t *)(c)->scratch)
+static const char *fxg_comm_d2h_sync(fxg_ctx *, void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); return nullptr; }
+#include "../../fastx_toolkit_amd/csrc/fxg_comm.h"
+

@@ -33,6 +33,33 @@ def build():
     return so
 
 
+def build_stub():
+    """tests/emu/stub/libfxg.so: the test-only look-alike of the engine library (fxg_stub.cpp over the emulator, plus the product's own
+    multi-GPU host code, csrc/fxg_comm.h).  Returns the directory to put first on LD_LIBRARY_PATH."""
+    build()
+    d = os.path.join(_EMU, "stub")
+    os.makedirs(d, exist_ok=True)
+    so = os.path.join(d, "libfxg.so")
+    srcs = [os.path.join(_EMU, f) for f in ("fxg_stub.cpp", "fxg_emu.cpp")]
+    root = os.path.join(_HERE, "..")
+    deps = srcs + [os.path.join(root, "fastx_toolkit_amd", "csrc", f) for f in ("fxg_device.h", "fxg_kernels.h", "fxg_plan.h", "fxg_history.h", "fxg_stats.h", "fxg_text.h", "fxg_rows.h", "fxg_comm.h")] + \
+        [os.path.join(root, "include", "fxg.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(x) for x in deps):
+        subprocess.check_call(["hipcc", "--cuda-host-only", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-pass-failed",
+                               "-DFXG_HOST_EMULATION"] + srcs + ["-o", so, "-ldl"])
+    return d
+
+
+def build_fake_rccl():
+    """tests/emu/fakerccl/librccl.so.1: the five NCCL entry points the transport binds, over a shared-memory file (fake_rccl.c)."""
+    d = os.path.join(_EMU, "fakerccl")
+    os.makedirs(d, exist_ok=True)
+    so, src = os.path.join(d, "librccl.so.1"), os.path.join(_EMU, "fake_rccl.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O1", "-std=gnu11", "-Wall", "-Wextra", "-fPIC", "-shared", src, "-o", so])
+    return d
+
+
 def lib():
     global _LIB
     if _LIB is None:

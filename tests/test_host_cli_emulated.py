@@ -23,14 +23,7 @@ REF = fo.ref_binary()
 @pytest.fixture(scope="module")
 def tools():
     import emu_py
-    emu_py.build()
-    os.makedirs(STUB_DIR, exist_ok=True)
-    so = os.path.join(STUB_DIR, "libfxg.so")
-    srcs = [os.path.join(ROOT, "tests", "emu", f) for f in ("fxg_stub.cpp", "fxg_emu.cpp")]
-    deps = srcs + [os.path.join(ROOT, "fastx_toolkit_amd", "csrc", f) for f in ("fxg_device.h", "fxg_kernels.h", "fxg_plan.h", "fxg_history.h", "fxg_stats.h", "fxg_text.h", "fxg_rows.h")] + [os.path.join(ROOT, "include", "fxg.h")]
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["hipcc", "--cuda-host-only", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-pass-failed",
-                               "-DFXG_HOST_EMULATION"] + srcs + ["-o", so])
+    assert os.path.samefile(emu_py.build_stub(), STUB_DIR)
     from fastx_toolkit_amd import build as b
     b.build_engine()          # the tools link against the real library's soname; the stub replaces it at run time only
     subprocess.check_call(["make", "-s", "-C", HOST])

@@ -56,15 +56,9 @@ def _msg(err):
 
 def _plain_build():
     import emu_py
-    emu_py.build()
     from fastx_toolkit_amd import build as b
     b.build_engine()
-    so = os.path.join(STUB_DIR, "libfxg.so")
-    srcs = [os.path.join(ROOT, "tests", "emu", f) for f in ("fxg_stub.cpp", "fxg_emu.cpp")]
-    deps = srcs + [os.path.join(ROOT, "fastx_toolkit_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "fastx_toolkit_amd", "csrc"))] + [os.path.join(ROOT, "include", "fxg.h")]
-    os.makedirs(STUB_DIR, exist_ok=True)
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["hipcc", "--cuda-host-only", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-pass-failed", "-DFXG_HOST_EMULATION"] + srcs + ["-o", so])
+    emu_py.build_stub()
     subprocess.check_call(["make", "-s", "-C", HOST])
     return os.path.join(HOST, "bin")
 
