@@ -2,6 +2,7 @@
 import os
 import shutil
 import subprocess
+import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
@@ -26,10 +27,35 @@ def hipcc():
     return exe
 
 
+def check_exec_zero(so):
+    """Refuse a library whose kernels contain the miscompile of DESIGN.md section 3: ROCm 7.2's register allocator can put the spill
+    stores / copies of a lane-divergent loop's live-out values into the loop's exit block AHEAD of the EXEC restore, where they run
+    for no lane -- silently wrong integers that move with every change of the allocation (scripts/check_exec_zero.py reads the ISA)."""
+    tool = os.path.join(ROOT, "scripts", "check_exec_zero.py")
+    p = subprocess.run([sys.executable, tool, so], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if p.returncode != 0:
+        raise RuntimeError("%s REJECTED: vector/memory code runs with EXEC = 0 at the exit of a lane-divergent loop (compiler bug, DESIGN.md section 3).\n"
+                           "Change the register budget of the named instance (fxg_clip_waves / __launch_bounds__) or its source and rebuild.\n%s" % (so, p.stdout[-3000:]))
+
+
+def compile_engine(out, extra_flags=(), check=True):
+    """hipcc of csrc/fxg_engine.hip into `out`, through a temporary name: a library that fails the ISA check never appears under `out`."""
+    tmp = out + ".new"
+    subprocess.check_call([hipcc()] + HIPCC_FLAGS + list(extra_flags) + [os.path.join(CSRC, "fxg_engine.hip"), "-o", tmp])
+    if check:
+        try:
+            check_exec_zero(tmp)
+        except Exception:
+            os.replace(tmp, out + ".rejected")
+            raise
+    os.replace(tmp, out)
+    return out
+
+
 def build_engine(force=False):
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "fxg.h")]
     if force or _newer(LIBFXG, deps):
-        subprocess.check_call([hipcc()] + HIPCC_FLAGS + [os.path.join(CSRC, "fxg_engine.hip"), "-o", LIBFXG])
+        compile_engine(LIBFXG)
     return LIBFXG
 
 

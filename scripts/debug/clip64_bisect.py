@@ -24,6 +24,15 @@ from fastx_toolkit_amd import build as _b  # noqa: E402
 
 W3 = ["-DFXG_CLIP_WAVES_WIDE=3"]
 D2, D3 = ["-DFXG_CLIP_DEBUG=2"], ["-DFXG_CLIP_DEBUG=3"]
+W4 = ["-DFXG_CLIP_WAVES_ALL=4"]
+VARIANTS_W4 = {                                # CASES=wide-348: the 48-column N instance at four waves per SIMD (wrong on ragged input with clip history, call r04_c)
+    "w4": (W4, "-O3"),
+    "w4_dbg1": (W4 + ["-DFXG_CLIP_DEBUG=1"], "-O3"),
+    "w4_dbg2": (W4 + ["-DFXG_CLIP_DEBUG=2"], "-O3"),
+    "w4_dbg3": (W4 + ["-DFXG_CLIP_DEBUG=3"], "-O3"),
+    "w3all": (["-DFXG_CLIP_WAVES_ALL=3"], "-O3"),
+    "w3all_dbg3": (["-DFXG_CLIP_WAVES_ALL=3", "-DFXG_CLIP_DEBUG=3"], "-O3"),
+}
 VARIANTS = {                                  # name: (extra flags, optimisation level)
     "w2_dbg2": (D2, "-O3"),                                           # wrong on the GPU in calls r04_a, r04_b (the shipped allocation + hash dumps)
     "w2_dbg2_W0": (D2 + ["-DFXG_CLIP_DEBUG_W=0"], "-O3"),             # + all of W before the last row
@@ -54,11 +63,37 @@ def build(names):
         print(n, "rc", p.wait(), flush=True)
 
 
+WIDE_ADS = {"-48": b"ACGTTGCAAGGCTTAACCGGATATCGCGTATAGCTAGCTAGGATCCA"[:44], "-64": b"GTCGTAGACCGATCGGGGACCCCTTGTTTCACGCGTCGTATAGCTGCTATGTCATTAGC"[:57],
+            "-100": (b"ACGTTGCA" * 12)[:91], "-348": b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCG"[:46],
+            "-364": b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCGTATGCCGTCTTC"[:58],
+            "-400": b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCGTATGCCGTCTTCTGCTTGAAAAAAAAAAGGGGGG"[:80]}
+
+
+def wide_cases(only=None):
+    """The seeded fuzz of tests/test_gpu_clip_matrix.py that names the wide instances: (name, bases, qual, lens, params, history)."""
+    import numpy as np
+    from helpers import random_batch
+    rng = np.random.default_rng(404)
+    for tag, ad in WIDE_ADS.items():
+        for stride in (150, 151, 250, 300):
+            for fixed in (True, False):
+                nreads = int(rng.integers(200, 700))
+                b, q, lens = random_batch(rng, nreads, stride, max(1, stride // 3), stride, fixed, adapter=ad)
+                pd = dict(stages=1, adapter=ad, clip_min_len=int(rng.integers(0, 20)), clip_flags=int(rng.integers(0, 16)), clip_min_adapter_len=int(rng.choice([0, 0, 5])))
+                if only is None or tag in only:
+                    yield "wide%s.s%d.%s" % (tag, stride, "fixed" if fixed else "ragged+history"), b, q, lens, pd, not fixed
+
+
 def cases():
+    """(name, bases, qual, lens, params, clip history on) -- CASES=wide-348,... selects the wide fuzz of those instances instead of the adversarial corpus"""
+    sel = os.environ.get("CASES", "")
+    if sel.startswith("wide"):
+        yield from wide_cases(sel[4:].split(",") if len(sel) > 4 else None)
+        return
     from helpers import adversarial_clip_cases
     for name, b, q, pd in adversarial_clip_cases(True):
         if len(pd["adapter"]) >= 49:
-            yield name, b, q, pd
+            yield name, b, q, None, pd, False
 
 
 OUT = os.path.join(ROOT, "gpurun_out", os.environ.get("BISECT_OUT", "r04_bisect"))
@@ -73,10 +108,14 @@ def one(name):
         os.environ["FXG_CLIP_DEBUG_OUT"] = dump
     eng = Engine(0)
     out = {}
-    for k, (cname, b, q, pd) in enumerate(cases()):
+    import torch
+    for k, (cname, b, q, lens, pd, hist) in enumerate(cases()):
         if os.path.exists(dump):
             os.remove(dump)
-        r = eng.run(eng.upload(b).view(b.shape), eng.upload(q).view(q.shape), make_params(**pd), fixed_len=b.shape[1], compact=True).to_host()
+        dl = torch.from_numpy(np.ascontiguousarray(lens).view(np.int16)).to(eng.device) if lens is not None else None
+        eng.set_clip_history(hist)
+        r = eng.run(eng.upload(b).view(b.shape), eng.upload(q).view(q.shape), make_params(**pd), lens=dl, fixed_len=None if lens is not None else b.shape[1], compact=True).to_host()
+        eng.set_clip_history(False)
         out["res%d" % k] = r["res"]
         if os.path.exists(dump):
             out["dump%d" % k] = np.fromfile(dump, dtype=np.uint32).reshape(-1, DBG_WORDS)[-b.shape[0]:]
@@ -96,8 +135,11 @@ def emu():
     L.fxg_emu_clip_debug.restype = C.c_size_t
     L.fxg_emu_clip_debug.argtypes = [C.c_void_p, C.c_size_t]
     out = {}
-    for k, (cname, b, q, pd) in enumerate(cases()):
-        out["res%d" % k] = emu_py.run_pipeline(b, q, None, fo.make_params(**pd))["res"]
+    for k, (cname, b, q, lens, pd, hist) in enumerate(cases()):
+        h = emu_py.hist_new() if hist else None
+        out["res%d" % k] = emu_py.run_pipeline(b, q, lens, fo.make_params(**pd), hist=h)["res"]
+        if h:
+            emu_py.hist_free(h)
         d = np.zeros(b.shape[0] * DBG_WORDS, dtype=np.uint32)
         L.fxg_emu_clip_debug(d.ctypes.data, d.size)
         out["dump%d" % k] = d.reshape(-1, DBG_WORDS)
@@ -109,7 +151,7 @@ def run(names):
     import numpy as np
     from helpers import oracle_params
     from oracle import fxoracle_py as fo
-    want = [(cname, fo.run_pipeline(b, q, None, oracle_params(pd))["res"], b, pd) for cname, b, q, pd in cases()]
+    want = [(cname, fo.run_pipeline(b, q, lens, oracle_params(pd))["res"], b, pd) for cname, b, q, lens, pd, hist in cases()]
     for n in names:
         if not os.path.exists(lib(n)):
             print(n, "not built")
@@ -120,7 +162,7 @@ def run(names):
             continue
         g = np.load(os.path.join(OUT, "%s.npz" % n))
         bad = [(cname, int((g["res%d" % k] != ores).sum()), len(pd["adapter"]), b.shape) for k, (cname, ores, b, pd) in enumerate(want) if (g["res%d" % k] != ores).any()]
-        print("%-18s %s cases that differ from the oracle: %d of %d  %s" % (n, g["kernel"], len(bad), len(want), [(c[:9], k, a, sh) for c, k, a, sh in bad]), flush=True)
+        print("%-18s %s cases that differ from the oracle: %d of %d  %s" % (n, g["kernel"], len(bad), len(want), [(c[:26], k, a, sh) for c, k, a, sh in bad]), flush=True)
 
 
 def analyze(names):
@@ -136,12 +178,12 @@ def analyze(names):
         if not os.path.exists(f):
             continue
         g = np.load(f)
-        for k, (cname, b, q, pd) in enumerate(cases()):
-            ores = fo.run_pipeline(b, q, None, oracle_params(pd))["res"]
+        for k, (cname, b, q, lens, pd, hist) in enumerate(cases()):
+            ores = fo.run_pipeline(b, q, lens, oracle_params(pd))["res"]
             wrong = np.nonzero(g["res%d" % k] != ores)[0]
             if "dump%d" % k not in g:
                 if len(wrong):
-                    print("%-18s %s A=%d L=%d n=%d: %d reads wrong (no dump): %s" % (n, cname[:10], len(pd["adapter"]), b.shape[1], b.shape[0], len(wrong), wrong[:12]))
+                    print("%-18s %s A=%d L=%d n=%d: %d reads wrong (no dump): %s" % (n, cname[:26], len(pd["adapter"]), b.shape[1], b.shape[0], len(wrong), wrong[:12]))
                 continue
             dv, tv = g["dump%d" % k], t["dump%d" % k]
             firsts = {}
@@ -152,11 +194,12 @@ def analyze(names):
                         break
             if firsts or len(wrong):
                 print("%-18s %s A=%d L=%d n=%d: %d reads wrong; first differing stage -> reads: %s" % (
-                    n, cname[:10], len(pd["adapter"]), b.shape[1], b.shape[0], len(wrong), {l: (len(v), v[:6]) for l, v in firsts.items()}))
+                    n, cname[:26], len(pd["adapter"]), b.shape[1], b.shape[0], len(wrong), {l: (len(v), v[:6]) for l, v in firsts.items()}))
 
 
 if __name__ == "__main__":
-    names = sys.argv[2:] or list(VARIANTS)
+    VARIANTS.update(VARIANTS_W4)
+    names = sys.argv[2:] or [n for n in VARIANTS if n not in VARIANTS_W4]
     if sys.argv[1] == "build":
         build(names)
     elif sys.argv[1] == "one":

@@ -355,6 +355,52 @@ def test_bench_two_ranks_on_one_gpu_via_gloo():
     assert er["ranks"] == 2 and er["reads_per_rank"] == 500000 and 0 < er["kept_reads"] < 1000000 and er["mreads_s"] > 0, er
 
 
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg5"])
+def test_engine_shards_reassemble_to_the_whole_run(engine, cfg):
+    """Multi-GPU readiness without the node: the REAL engine on reads [0, N) against the REAL engine on the shards
+    fxg_shard_range cuts -- even and odd splits, 2 / 3 / 8 ranks -- put together the way a job does it: res[] in rank order, every
+    rank's packed bytes at the byte offset fxg_epilogue derives from the gathered counter blocks, kept_index + the shard's first read,
+    out_off + the byte offset, the counters summed by fxg_epilogue.  Everything must equal the one-shard run byte for byte (reads are
+    independent: the reference is one process over one stream, fastq_quality_trimmer.c:76-124)."""
+    import ctypes as C
+    from fastx_toolkit_amd import distributed as fxd
+    N = 4_000_003                                               # odd, not a multiple of any tile size
+    ad = b"AGATCGGAAGAGC"
+    spec = dict(cfg2=(2, 150, False, dict(stages=6, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80)),
+                cfg3=(3, 100, True, dict(stages=1, adapter=ad, clip_min_len=15, clip_flags=4)),
+                cfg5=(5, 150, True, dict(stages=7, adapter=ad, clip_min_len=15, clip_flags=4, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80)))[cfg]
+    seed, L, with_ad, pd = spec
+    b, q = engine.synth(seed, 0, N, L, with_ad)
+    whole = engine.run(b, q, _engine_params(pd), fixed_len=L).to_host()
+    for world in (2, 3, 8):
+        parts, blocks = [], np.zeros((world, 24), dtype=np.uint64)
+        for g in range(world):
+            lo, hi = fxd.shard_range(N, g, world)
+            # a rank holds only its shard: a fresh batch (own allocation, own alignment), generated as the job would (first read = lo)
+            sb, sq = engine.synth(seed, lo, hi - lo, L, with_ad)
+            assert bool((sb == b[lo:hi]).all())
+            r = engine.run(sb, sq, _engine_params(pd), fixed_len=L).to_host()
+            parts.append((lo, hi, r))
+            blocks[g] = r["counters"]
+        res = np.concatenate([r["res"] for _, _, r in parts])
+        assert np.array_equal(res, whole["res"]), (cfg, world)
+        ob, oq = np.zeros_like(whole["out_bases"]), np.zeros_like(whole["out_qual"])
+        kept, olen, ooff = np.zeros_like(whole["kept_index"]), np.zeros_like(whole["out_len"]), np.zeros_like(whole["out_off"])
+        for g, (lo, hi, r) in enumerate(parts):
+            totals = (C.c_uint64 * 24)()
+            ro, bo = C.c_uint64(), C.c_uint64()
+            assert engine.lib.fxg_epilogue(blocks.ctypes.data, world, g, totals, C.byref(ro), C.byref(bo)) == 0
+            assert list(totals)[:13] == [int(x) for x in whole["counters"][:13]], (cfg, world, g)
+            nb, nk = len(r["out_bases"]), len(r["kept_index"])
+            ob[bo.value:bo.value + nb] = r["out_bases"]; oq[bo.value:bo.value + nb] = r["out_qual"]
+            kept[ro.value:ro.value + nk] = r["kept_index"] + np.uint32(lo)
+            olen[ro.value:ro.value + nk] = r["out_len"]
+            ooff[ro.value:ro.value + nk] = r["out_off"] + np.uint64(bo.value)
+        for name, got in (("out_bases", ob), ("out_qual", oq), ("kept_index", kept), ("out_len", olen), ("out_off", ooff)):
+            assert np.array_equal(got, whole[name]), (cfg, world, name)
+    del b, q
+
+
 def test_rccl_epilogue_through_the_c_abi(engine, tmp_path):
     """fxg_comm_create / fxg_epilogue_rccl: the counter blocks gathered by RCCL inside libfxg.so (dlopen), no Python transport.
     This box has one GPU, so the communicator has one rank: the gathered block is the pass's own, the offsets are zero."""
