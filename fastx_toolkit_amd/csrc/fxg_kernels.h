@@ -967,9 +967,11 @@ __device__ __forceinline__ void fxg_tile_tally(u32 w, bool valid, u64 *tally)
 // one step of slack (all the streaming instances need) is not enough where a step is a 50-microsecond DP whose speed depends on
 // what the other three waves of the SIMD are doing -- the clip instances waited for the prefix 17 % of their time
 // (profiles/r03/c_ablate_clip.txt); two steps behind, the slowest of the ~1000 tiles in flight has a whole extra DP to catch up.
-// waves per SIMD the clip instances are compiled for: the packed forms keep 2-3 registers per adapter column (two-pass: 6 of <= 16)
-// (64 columns at three waves = 168 registers spilled and came out WRONG on the GPU in the two-pass form -- 19 of 223 reads of one
-// adversarial case, the emulator and every other bucket agreeing with the oracle; at two waves nothing spills and it is right)
+// waves per SIMD the clip instances are compiled for: the packed forms keep 2-3 registers per adapter column (two-pass: 6 of <= 16).
+// 64 columns at three waves came out WRONG on the GPU in round 3 (19 of 223 reads): ROCm 7.2's register allocator had put the spill
+// stores of the summary loop's live-out values into the loop's exit block ahead of the EXEC restore, where they run for no lane
+// (DESIGN.md section 3).  The budget here is a performance choice; what keeps that miscompile out of the product is the ISA check every
+// built library goes through (scripts/check_exec_zero.py, build.py) and the launch-bounds matrix (tests/test_gpu_clip_matrix.py).
 #ifndef FXG_CLIP_WAVES_WIDE
 #define FXG_CLIP_WAVES_WIDE 2   // 49..99 columns (ablation builds: 3)
 #endif

@@ -26,7 +26,16 @@ def lib(w):
 
 def stale(w):
     deps = [os.path.join(b.CSRC, f) for f in os.listdir(b.CSRC)] + [os.path.join(ROOT, "include", "fxg.h")]
-    return b._newer(lib(w), deps) or not os.path.exists(lib(w)[:-3] + ".json")
+    return b._newer(lib(w), deps)
+
+
+def verdict(w):
+    """The ISA check's answer for one library (always computed afresh: the checker may have learnt since the library was built)."""
+    chk = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_exec_zero.py"), lib(w)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    rejected = sorted({"<%s,%s>" % (a.replace("n", "-"), m) for a, m in re.findall(r"fxg_kernel_tilesILi(n?\d+)ELi(\d+)EEv", chk.stdout)})
+    v = dict(waves=w, accepted=chk.returncode == 0, rejected_instances=rejected, report=chk.stdout[-4000:])
+    json.dump(v, open(lib(w)[:-3] + ".json", "w"), indent=1)
+    return v
 
 
 def build_all(waves=WAVES):
@@ -35,10 +44,7 @@ def build_all(waves=WAVES):
     for w, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed for the %d-wave matrix library" % w)
-        chk = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_exec_zero.py"), lib(w)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        rejected = sorted({"<%s,%s>" % (a.replace("n", "-"), m) for a, m in re.findall(r"fxg_kernel_tilesILi(n?\d+)ELi(\d+)EEv", chk.stdout)})
-        json.dump(dict(waves=w, accepted=chk.returncode == 0, rejected_instances=rejected, report=chk.stdout[-4000:]), open(lib(w)[:-3] + ".json", "w"), indent=1)
-    return {w: json.load(open(lib(w)[:-3] + ".json")) for w in waves}
+    return {w: verdict(w) for w in waves}
 
 
 if __name__ == "__main__":

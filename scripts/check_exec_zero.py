@@ -17,10 +17,14 @@ the instruction that restores the lanes.  Vector and memory instructions with EX
 whatever the slot held before the loop.  Nothing in the source is wrong and nothing at run time reports it; which values are hit
 changes with every change of the register allocation.
 
-This script disassembles every kernel of the library and reports each vector / memory instruction that is certain to run with
-EXEC = 0: the straight-line code between a backward `s_cbranch_execnz` (a lane-divergent loop's back edge: falling through means
-no lane is left) and the next write of EXEC.  v_readlane / v_readfirstlane / v_writelane ignore EXEC and are not reported, nor is the
-bracket `s_or_saveexec_b64 sN, -1 ... s_mov_b64 exec, sN` (whole-wave spill of an SGPR-spill register, which sets the mask itself).
+This script disassembles every kernel of the library, builds its control flow graph and follows what is known about EXEC: it is zero
+on the fall-through edge of `s_cbranch_execnz` (a lane-divergent loop's back edge: falling through means no lane is left) and on the
+taken edge of `s_cbranch_execz`, until something writes it.  Reported are
+  (a) every vector / memory instruction in a block that is ONLY ever entered with EXEC = 0, ahead of the block's EXEC restore (the
+      listing above), and
+  (b) scratch stores ahead of the EXEC restore of a block that CAN be entered with EXEC = 0 (the same misplacement in a join block).
+v_readlane / v_readfirstlane / v_writelane ignore EXEC and are not reported, nor is the bracket `s_or_saveexec_b64 sN, -1 ... s_mov_b64
+exec, sN` (whole-wave spill of an SGPR-spill register, which sets the mask itself).
 
     python scripts/check_exec_zero.py fastx_toolkit_amd/libfxg.so [more.so ...]     # exit code 1 if anything is found
 
@@ -53,81 +57,104 @@ def code_object(so, tmp):
 
 
 def check_kernel(name, ins, full_lines, joins=False):
-    """Returns [(loop branch address, [instruction texts])] for every exit of a lane-divergent loop with vector/memory code ahead of the EXEC restore."""
-    base = ins[0][0] if ins else 0
+    """Every vector / memory instruction of one kernel that is CERTAIN to run with EXEC = 0, by a forward data flow over the kernel's
+    control flow graph.  EXEC is known to be zero on the fall-through edge of `s_cbranch_execnz` and on the taken edge of `s_cbranch_execz`;
+    a block starts with EXEC = 0 when every edge into it carries that; any write of EXEC ends the knowledge (the bracket
+    `s_or_saveexec_b64 sN, -1 ... s_mov_b64 exec, sN` of a whole-wave spill sets the mask itself and then restores what it found).
+    Returns [(address of the first such instruction of a block, [instruction texts])]."""
+    if not ins:
+        return []
+    base = ins[0][0]
     addr_index = {a: i for i, (a, _, _, _) in enumerate(ins)}
-    targets = set()
     tgt_of = {}
     for i, (a, mn, ops, _) in enumerate(ins):
         if mn.startswith("s_cbranch") or mn == "s_branch":
             m = re.search(r"\+0x([0-9a-f]+)>", full_lines[i])
-            if m:
-                t = base + int(m.group(1), 16)
-                targets.add(t)
-                tgt_of[i] = t
-            elif re.search(r"<[^>+]+>", full_lines[i]):       # branch to the symbol itself
-                targets.add(base)
-                tgt_of[i] = base
+            t = base + int(m.group(1), 16) if m else (base if re.search(r"<[^>+]+>\s*$", full_lines[i]) else None)
+            if t in addr_index:
+                tgt_of[i] = addr_index[t]
+    leaders = {0} | set(tgt_of.values()) | {i + 1 for i in tgt_of if i + 1 < len(ins)}
+    leaders = sorted(leaders)
+    block_of = {}
+    for b, l in enumerate(leaders):
+        for k in range(l, leaders[b + 1] if b + 1 < len(leaders) else len(ins)):
+            block_of[k] = b
+    nb = len(leaders)
+    ends = [(leaders[b + 1] if b + 1 < nb else len(ins)) - 1 for b in range(nb)]
+
+    def writes_exec(mn, ops):
+        return mn.startswith("s_") and (re.match(r"^(exec|exec_lo|exec_hi)\b", ops) is not None or "saveexec" in mn)
+
+    def walk(b, zero, report=None):
+        """state at the end of block b when it is entered with EXEC = 0 (zero) or unknown; collects the instructions that run under 0"""
+        wwm = None                                            # (register, state before the bracket)
+        for k in range(leaders[b], ends[b] + 1):
+            a, mn, ops, txt = ins[k]
+            if mn.startswith("s_or_saveexec") and ops.replace(" ", "").endswith(",-1"):
+                wwm = (ops.split(",")[0].strip(), zero)
+                zero = False
+                continue
+            if wwm and mn == "s_mov_b64" and ops.replace(" ", "") == "exec,%s" % wwm[0]:
+                zero, wwm = wwm[1], None
+                continue
+            if writes_exec(mn, ops):
+                zero, wwm = False, None
+                continue
+            if zero and report is not None and ((mn.startswith("v_") and mn not in IGNORES_EXEC) or mn.startswith(MEM_PREFIX)):
+                report.append((a, txt))
+        return zero
+
+    # edges: (from block, to block, state override) -- override True: EXEC = 0 on this edge whatever the block ends with, False: not zero
+    preds = [[] for _ in range(nb)]
+    for b in range(nb):
+        k = ends[b]
+        a, mn, ops, _ = ins[k]
+        nxt = block_of.get(k + 1)
+        if mn == "s_branch":
+            if k in tgt_of:
+                preds[block_of[tgt_of[k]]].append((b, None))
+        elif mn.startswith("s_cbranch"):
+            if k in tgt_of:
+                preds[block_of[tgt_of[k]]].append((b, True if mn == "s_cbranch_execz" else False if mn == "s_cbranch_execnz" else None))
+            if nxt is not None:
+                preds[nxt].append((b, True if mn == "s_cbranch_execnz" else False if mn == "s_cbranch_execz" else None))
+        elif mn not in ("s_endpgm", "s_setpc_b64") and nxt is not None:
+            preds[nxt].append((b, None))
+    entry = [True] * nb                                       # optimistic start; the kernel's first block is entered with live lanes
+    entry[0] = False
+    changed = True
+    while changed:
+        changed = False
+        out = [walk(b, entry[b]) for b in range(nb)]
+        for b in range(1, nb):
+            if not entry[b]:
+                continue
+            ok = bool(preds[b]) and all((ov if ov is not None else out[p]) for p, ov in preds[b])
+            if not ok:
+                entry[b] = False
+                changed = True
     found = []
-    for i, (a, mn, ops, _) in enumerate(ins):
-        if mn != "s_cbranch_execnz" or i not in tgt_of or tgt_of[i] > a:
+    for b in range(nb):
+        if entry[b]:
+            rep = []
+            walk(b, True, rep)
+            if rep:
+                found.append((rep[0][0], [t for _, t in rep]))
+    # Second form: a block that CAN be entered with EXEC = 0 (the taken edge of a skip branch, or a loop exit, is among its edges) but also
+    # with some lanes live, and that has scratch STORES ahead of its EXEC restore.  On the zero path the store is lost, on the others it
+    # covers only the lanes of that path; the lanes the restore brings back reload what the slot held before -- from an earlier launch
+    # if nothing else wrote it.  (Found as a 48-column instance at four waves per SIMD that was wrong on the FIRST launch after another
+    # kernel had used the scratch and right on every repetition: the stale slot then held the same launch's own values.)  hipcc's regular
+    # output has no such block: four builds of the 62 kernels show exactly that one.
+    out = [walk(b, entry[b]) for b in range(nb)]
+    for b in range(1, nb):
+        if entry[b] or not any((ov if ov is not None else out[p]) for p, ov in preds[b]):
             continue
-        dead, wwm = [], None
-        for j in range(i + 1, len(ins)):
-            aj, mj, oj, tj = ins[j]
-            if aj in targets:
-                break                                         # another path joins here: its lanes may be live
-            if mj.startswith("s_or_saveexec") and oj.endswith("-1"):
-                wwm = oj.split(",")[0].strip()
-                continue
-            if wwm and mj == "s_mov_b64" and oj.replace(" ", "") == "exec,%s" % wwm:
-                wwm = None
-                continue
-            if wwm:
-                continue                                      # inside a whole-wave bracket: EXEC = -1
-            if (re.match(r"^(exec|exec_lo|exec_hi)\b", oj) and mj.startswith("s_")) or mj.startswith(("s_or_saveexec", "s_and_saveexec", "s_xor_saveexec", "s_andn2_saveexec")):
-                break                                         # EXEC is written: the lanes are back
-            if mj.startswith("s_cbranch") or mj in ("s_branch", "s_endpgm", "s_setpc_b64"):
-                break
-            if (mj.startswith("v_") and mj not in IGNORES_EXEC) or mj.startswith(MEM_PREFIX):
-                dead.append(tj)
-        if dead:
-            found.append((a, dead))
-    # --joins (investigation only, never part of the gate): `s_cbranch_execz L` is only ever taken with EXEC = 0; vector or memory code
-    # between L and the next EXEC restore runs for no lane on the taken path and for the fall-through lanes only on the other.  That is
-    # what structured control flow means for a loop latch or a then-block's tail, so most reports are fine; a SPILL STORE there is
-    # worth a look (is the value live for the other lanes as well?).
-    if not joins:
-        return found
-    seen = set()
-    for i, (a, mn, ops, _) in enumerate(ins):
-        if mn != "s_cbranch_execz" or i not in tgt_of or tgt_of[i] in seen or tgt_of[i] not in addr_index:
-            continue
-        seen.add(tgt_of[i])
-        dead, wwm = [], None
-        for j in range(addr_index[tgt_of[i]], len(ins)):
-            aj, mj, oj, tj = ins[j]
-            if j > addr_index[tgt_of[i]] and aj in targets:
-                break
-            if mj.startswith("s_or_saveexec") and oj.endswith("-1"):
-                wwm = oj.split(",")[0].strip()
-                continue
-            if wwm and mj == "s_mov_b64" and oj.replace(" ", "") == "exec,%s" % wwm:
-                wwm = None
-                continue
-            if wwm:
-                continue
-            if re.match(r"^(exec|exec_lo|exec_hi)\b", oj) and mj.startswith("s_"):
-                break
-            if mj.startswith("s_cbranch") or mj in ("s_branch", "s_endpgm", "s_setpc_b64"):
-                dead = []                                     # no restore before the next branch: not a join block of this form
-                break
-            if (mj.startswith("v_") and mj not in IGNORES_EXEC) or mj.startswith(MEM_PREFIX):
-                dead.append(tj)
-        else:
-            dead = []
-        if dead:
-            found.append((-tgt_of[i], dead))
+        rep = []
+        walk(b, True, rep)
+        rep = [(a, t) for a, t in rep if t.startswith("scratch_store")]
+        if rep:
+            found.append((-rep[0][0], [t for _, t in rep]))
     return found
 
 
@@ -158,13 +185,12 @@ def check(so, joins=False):
 
 def main(paths):
     bad = 0
-    joins = "--joins" in paths
-    for so in [p for p in paths if p != "--joins"]:
-        report, nk = check(so, joins)
+    for so in paths:
+        report, nk = check(so)
         for name, addr, dead in report:
-            bad += addr > 0
+            bad += 1
             mem = [d for d in dead if d.startswith(MEM_PREFIX)]
-            where = "exit of the lane-divergent loop at 0x%X" % addr if addr > 0 else "target 0x%X of a skip branch (s_cbranch_execz)" % -addr
+            where = "block at 0x%X is only ever entered with EXEC = 0" % addr if addr > 0 else "block at 0x%X can be entered with EXEC = 0 and spills ahead of its EXEC restore" % -addr
             print("%s: %s: %s: %d vector/memory instructions ahead of the EXEC restore (%d of them memory), e.g.\n      %s" % (
                 os.path.basename(so), name, where, len(dead), len(mem), "\n      ".join(dead[:4])))
         print("%s: %d kernels, %d places with vector/memory code ahead of the EXEC restore" % (os.path.basename(so), nk, len(report)))
