@@ -104,6 +104,7 @@ def _pipe_cmds(config, ref, inp, out):
         "cfg3": [["fastx_clipper", "-a", ad, "-l", "15", "-n"]],
         "cfg4": [["fastx_reverse_complement"], ["fastx_trimmer", "-f", "5", "-l", "145"]],
         "cfg5shard": [["fastx_clipper", "-a", ad, "-l", "15", "-n"], ["fastq_quality_trimmer", "-t", "20", "-l", "30"], ["fastq_quality_filter", "-q", "20", "-p", "80"]],
+        "stats": [["fastx_quality_stats"]],
     }[config]
     cmds = [[ref] + st for st in stages]
     cmds[0] += ["-i", inp]
@@ -171,6 +172,8 @@ def cpu_baseline(config="cfg2", reads_per_pipe=250_000, one_pipe_reads=1_000_000
                                    "tools' loop bodies of oracle/ref_driver.cpp; %d concurrent single-threaded processes = %d cores "
                                    "(the box has %d physical cores / %d logical CPUs); one_pipe_value = one pipe (%d processes) alone on the first %d reads"
                                    % (config, cfg["what"], n, cfg["seed"], cfg["L"], pipes, per_pipe * pipes, per_pipe * pipes, phys, logical, per_pipe, n_one * reads_per_pipe))
+        if cfg["params"] is None:
+            return None                                   # (the plain-C port has no stand-alone statistics entry point worth timing)
         # fall back to the plain-C port (SoA in memory, no text I/O), 1 thread
         n = 1_000_000 if cfg["bound"] == "valu" else 4_000_000
         b, q = fo.synth_batch(cfg["seed"], 0, n, cfg["L"], cfg["adapter"])
@@ -283,10 +286,49 @@ def e2e_leg(reads=16_000_000, big_reads=64_000_000, parts=4, lanes=2):
                 timed(big, "sharded", lambda: subprocess.call(fa + ["-o", os.path.join(td, "part.%r.fq")], env=penv) == 0, pnames, big_reads, want_md5=False)
                 if "sharded" in big and "one_stream" in big:
                     big["concatenation_identical_to_one_stream"] = _same_bytes(pnames, single)
+                # one GPU's share of the 8-GPU box: 16 of the node's 64 cores (32 of its 128 CPUs) for the whole tool -- readers, lanes, writers
+                share = _cpu_share(16)
+                if share:
+                    timed(big, "sharded_host_share_16c", lambda: subprocess.call(fa + ["-o", os.path.join(td, "part.%r.fq")], env=penv,
+                                                                                  preexec_fn=lambda: os.sched_setaffinity(0, share)) == 0, pnames, big_reads, want_md5=False)
+                    if "sharded_host_share_16c" in big:
+                        big["sharded_host_share_16c"].update(cpus=len(share), cores=16, note="the same sharded command restricted to 16 physical cores (with their SMT siblings) of the "
+                                                             "GPU's NUMA node: what each GPU's tool chain has on an 8-GPU box with 2 x 64 cores")
                 out["sharded_big"] = big
         if "pipe" in out and "fused" in out:
             out["fused_equals_pipe"] = out["pipe"]["output_md5"] == out["fused"]["output_md5"]
+        if "fused" in out:
+            # what a user gets WITHOUT knowing any knob: the plain command line, one process, no environment variables.  Since round 4 a
+            # regular-file input of >= 1 GB with `-o NAME` is sharded by the tool itself (fxh_auto_parts), so this is the tuned path's number
+            # minus the choice of the part names; `fused` above is the same command on the 16 M-read sample.
+            out["default_invocation"] = dict(command="fastq_quality_trim_filter -t 20 -l 30 -q 20 -p 80 -i in.fq -o out.fq", env="none",
+                                             sample_16m=out["fused"], sample_64m=out.get("sharded_big", {}).get("one_stream"))
         return out
+
+
+def _cpu_share(cores):
+    """`cores` physical cores (all their SMT siblings) out of the CPUs this process may use, lowest numbered first; None if there are not more than that."""
+    try:
+        allowed = os.sched_getaffinity(0)
+        groups, seen = [], set()
+        for c in sorted(allowed):
+            if c in seen:
+                continue
+            sib = set()
+            for part in open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip().split(","):
+                a, _, b = part.partition("-")
+                sib.update(range(int(a), int(b or a) + 1))
+            sib &= allowed
+            seen |= sib
+            groups.append(sib)
+        if len(groups) <= cores:
+            return None
+        out = set()
+        for g in groups[:cores]:
+            out |= g
+        return out
+    except Exception:
+        return None
 
 
 def _gpu_node_cpus(index):
@@ -339,7 +381,16 @@ def e2e_ranks(config, rank, local, world, reads_per_rank, dist, device):
              "cfg5shard": [["fastx_clip_trim_filter", "-a", ad, "-l", "15", "-n", "-t", "20", "-m", "30", "-q", "20", "-p", "80"]]}[config]
     from concurrent.futures import ThreadPoolExecutor
     from oracle import fxoracle_py as fo
-    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+    import hashlib
+    import shutil
+    # one directory for the job (every rank's files side by side, so that rank 0 can hash the outputs in rank order at the end)
+    shared = [tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)] if rank == 0 else [None]
+    if world > 1:
+        dist.broadcast_object_list(shared, src=0)
+    jobdir = shared[0]
+    td = os.path.join(jobdir, "rank%d" % rank)
+    os.makedirs(td, exist_ok=True)
+    try:
         inp, outp = os.path.join(td, "in.fq"), os.path.join(td, "out.fq")
         chunk = 250_000
         first = rank * reads_per_rank
@@ -391,9 +442,33 @@ def e2e_ranks(config, rank, local, world, reads_per_rank, dist, device):
         if world > 1:
             dist.all_reduce(t)
         total = reads_per_rank * world
+        # the job's output = the ranks' outputs in rank order (each rank's parts in part order): its md5 must not depend on the number of ranks
+        names = [outs]
+        if world > 1:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, outs)
+            names = gathered
+        md5 = None
+        if rank == 0:
+            h = hashlib.md5()
+            for per_rank in names:
+                for fn in per_rank:
+                    with open(fn, "rb") as f:
+                        for blk in iter(lambda: f.read(1 << 24), b""):
+                            h.update(blk)
+            md5 = h.hexdigest()
+        if world > 1:
+            dist.barrier()
         return dict(command=" | ".join(" ".join(st) for st in chain), reads_per_rank=reads_per_rank, ranks=world, wall_s=round(best, 3),
                     mreads_s=round(total / best / 1e6, 2), gbases_s=round(total * cfg["L"] / best / 1e9, 3), kept_reads=int(t[0]), output_bytes=int(t[1]),
-                    note="one tool chain per GPU on its own shard of the input (FASTQ text on tmpfs in and out; a single tool runs sharded, FXH_PARTS=4), barrier to barrier, slowest rank; best of two")
+                    output_md5=md5,
+                    note="one tool chain per GPU on its own shard of the input (FASTQ text on tmpfs in and out; a single tool runs sharded, FXH_PARTS=4), barrier to barrier, slowest rank; best of two; "
+                         "output_md5 = md5 of the ranks' outputs concatenated in rank order (equal for every number of ranks over the same reads)")
+    finally:
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            shutil.rmtree(jobdir, ignore_errors=True)
 
 
 def main():
@@ -454,6 +529,9 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    # HIP events around the dominant kernel of every TIMED launch (two event records per step on the launch stream, read after the final
+    # synchronisation: a ring of the last 64 launches in the context) -- kernel_ms_avg below is of these very launches
+    eng.set_profiling(True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -465,6 +543,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    kms = eng.profiled_kernel_ms(min(args.steps, 64))
+    eng.set_profiling(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=eng.device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -480,14 +560,7 @@ def main():
             totals, read_off, byte_off, _ = fxd.offsets_from_gathered(gathered[0], rank)
             assert int(totals[0]) == R * world
 
-    # kernel-level time of the dominant kernel: HIP events on the launch stream, one launch at a time
-    eng.set_profiling(True)
-    kms = []
-    for _ in range(max(5, min(args.steps, 20))):
-        step()
-        kms.append(eng.last_kernel_ms())
-    eng.set_profiling(False)
-    kavg = sum(kms) / len(kms)
+    kavg = sum(kms) / len(kms)          # the timed loop's own launches (the last min(steps, 64) of them)
     launch = eng.last_launch()
     # algorithmic bytes per launch: read 2L per read, write 4 B result per read + 2*new_len per kept read
     if is_stats:
@@ -549,36 +622,44 @@ def main():
                 "reads_per_gpu": R, "read_len": L, "seed": cfg["seed"], "kept_reads_per_gpu": kept, "kept_bases_per_gpu": kept_bytes,
                 "gbases_per_s_in": round(total_reads * L / dt / 1e9, 2), "parallelism": "reads sharded x%d, no data-path collective" % world,
             },
-            "roofline": {
-                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": launch["kernel"], "kernel_ms_avg": round(kavg, 4), "kernel_ms_min": round(min(kms), 4),
-                "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_read": round(alg_bytes / R, 2),
-                "traffic_over_algorithmic": round(traffic / alg_bytes, 4) if traffic else None,
-                "grid": launch["grid"], "block": launch["block"], "lds_bytes": launch["lds"], "tile_reads": launch["tile_reads"],
+        }
+        hbm = {
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "traffic_source": traffic_source,
+            "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_read": round(alg_bytes / R, 2),
+            "traffic_over_algorithmic": round(traffic / alg_bytes, 4) if traffic else None,
+        }
+        shape = {"kernel": launch["kernel"], "kernel_ms_avg": round(kavg, 4), "kernel_ms_min": round(min(kms), 4), "kernel_ms_launches": len(kms),
+                 "kernel_ms_source": "HIP events around the dominant kernel of the timed loop's own launches (fxg_profiled_kernel_ms)",
+                 "grid": launch["grid"], "block": launch["block"], "lds_bytes": launch["lds"], "tile_reads": launch["tile_reads"]}
+        if cfg["bound"] == "valu":
+            # the aligner is a per-thread fp32 dynamic program: L x 13 cells per read, bounded by VALU issue, not by HBM -- the roofline object
+            # describes THAT resource; the HBM figures (low by construction) sit in the sub-object
+            cells = R * L * len(ADAPTER)
+            gcups = cells / (kavg * 1e-3) / 1e9
+            glane = gcups * CLIP_VALU_PER_CELL[args.config]
+            out["roofline"] = {
+                "bound": "valu", "achieved": round(glane, 1), "peak": round(VALU_PEAK_GLANEOPS, 1), "unit": "G lane-ops/s",
+                "frac": round(glane / VALU_PEAK_GLANEOPS, 4), "traffic": traffic,
+                "gcups": round(gcups, 1), "cells_per_launch": cells, "valu_instr_per_cell": CLIP_VALU_PER_CELL[args.config],
+                **shape, "hbm": hbm,
+                "note": "bound is VALU issue; peak = 256 CUs x 4 SIMDs x 64 lanes / %.0f cycles x 2.4 GHz (MI355X_MICROARCH.md: one wave64 VALU instruction "
+                        "per 2 cycles per SIMD); achieved = cells/s x valu_instr_per_cell, the wave-instructions the kernel issues per cell of the full "
+                        "L x 13 matrix the reference fills (SQ_INSTS_VALU x 64 / cells, whole kernel: both passes, staging, write-out; profiles/r03_clip_pmc, "
+                        "re-measured in profiles/r04 when the kernel changes), so it is what the SIMDs really issued" % VALU_CYCLES,
+            }
+        else:
+            out["roofline"] = {
+                "bound": "hbm", **hbm, **shape,
                 **({"note": "not measured in this run: a plain streaming kernel that reads 15 GB and writes 7.3 GB (this config's algorithmic bytes, nothing "
                             "else) takes 4.25-4.56 ms on this part, read alone 2.34-2.50 ms, write alone 1.17-1.25 ms (scripts/ubench/mix_rw.hip, profiles/r02/z_mix_rw.txt)"}
                    if args.config == "cfg2" and compact else {}),
-            },
-        }
-        if cfg["bound"] == "valu":
-            # the aligner is a per-thread fp32 dynamic program: L x 13 cells per read, bounded by VALU issue, not by HBM
-            cells = R * L * len(ADAPTER)
-            gcups = cells / (kavg * 1e-3) / 1e9
-            out["roofline"]["valu"] = {
-                "gcups": round(gcups, 1), "cells_per_launch": cells, "valu_instr_per_cell": CLIP_VALU_PER_CELL[args.config],
-                "achieved_glaneops": round(gcups * CLIP_VALU_PER_CELL[args.config], 1), "peak_glaneops": round(VALU_PEAK_GLANEOPS, 1),
-                "issue_frac": round(gcups * CLIP_VALU_PER_CELL[args.config] / VALU_PEAK_GLANEOPS, 4),
-                "note": "bound is VALU issue (the `hbm` numbers above are low by construction); peak = 256 CUs x 4 SIMDs x 64 lanes / %.0f cycles x 2.4 GHz "
-                        "(MI355X_MICROARCH.md: one wave64 VALU instruction per 2 cycles per SIMD); valu_instr_per_cell = SQ_INSTS_VALU x 64 / cells of the "
-                        "whole kernel (profiles/r03_clip_pmc), so achieved_glaneops is what the SIMDs really issued.  Cells are those of the full L x 13 "
-                        "matrix the reference fills; the kernel fills it once with scores only and re-runs <= 21 rows with path summaries." % VALU_CYCLES,
             }
         if self_check is not None:
             out["self_check"] = self_check
         if e2e_r is not None:
             out["e2e_ranks"] = e2e_r
-        if world == 1 and not args.no_cpu_baseline and not is_stats:
+        if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config)
         if world == 1 and not args.no_e2e and args.config == "cfg2":
             try:

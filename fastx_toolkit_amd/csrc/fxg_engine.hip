@@ -22,8 +22,10 @@ struct fxg_ctx {
     hipStream_t own_stream;
     hipStream_t stream;
     hipEvent_t ev0, ev1;
-    hipEvent_t kev0, kev1;  // around the dominant kernel when profiling
-    int profiling, kev_valid;
+#define FXG_KEV_RING 64
+    hipEvent_t kev0[FXG_KEV_RING], kev1[FXG_KEV_RING];  // around the dominant kernel of the last FXG_KEV_RING launches when profiling
+    int profiling;
+    u64 kev_count;          // profiled launches since fxg_set_profiling(1)
     u64 *status;            // FXG_STATUS_WORDS(status_cap) granules: tile totals [cap], prefixes [2 * cap], batch bases
     size_t status_cap;      // in tiles
     u32 epoch;              // tag of the granules of the current launch (1..255); 0 = never valid
@@ -96,7 +98,6 @@ extern "C" int fxg_ctx_create(int device_id, fxg_ctx **out)
     { const char *e = getenv("FXG_NSCAN"); c->env_nscan = (e && atoi(e) > 0 && atoi(e) <= 64) ? atoi(e) : 0; }
     { const char *e = getenv("FXG_TICKET_GROUPS"); c->env_ticket_groups = (e && atoi(e) > 0 && atoi(e) <= FXG_TICKET_GROUPS) ? atoi(e) : 0; }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipEventCreate(&c->kev0) != hipSuccess || hipEventCreate(&c->kev1) != hipSuccess ||
         hipMalloc((void **)&c->errflag, (FXG_CTRL_WORDS + FXG_TICKET_GROUPS * FXG_TICKET_STRIDE) * sizeof(u32)) != hipSuccess ||
         hipMalloc((void **)&c->counters_scratch, FXG_NCOUNTERS * sizeof(u64)) != hipSuccess) {
         free(c);
@@ -115,7 +116,7 @@ extern "C" void fxg_ctx_destroy(fxg_ctx *c)
     (void)hipFree(c->text_ws); (void)hipFree(c->text_state);
     (void)hipFree(c->hist_buf[0]); (void)hipFree(c->hist_buf[1]); (void)hipFree(c->hist_w); (void)hipFree(c->hist_ws); (void)hipFree(c->stats_ws); (void)hipFree(c->clip_ck);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
-    (void)hipEventDestroy(c->kev0); (void)hipEventDestroy(c->kev1);
+    for (int i = 0; i < FXG_KEV_RING; ++i) { if (c->kev0[i]) (void)hipEventDestroy(c->kev0[i]); if (c->kev1[i]) (void)hipEventDestroy(c->kev1[i]); }
     (void)hipStreamDestroy(c->own_stream);
     free(c);
 }
@@ -295,10 +296,10 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
     { u32 g = c->env_ticket_groups > 0 ? (u32)c->env_ticket_groups : FXG_TICKET_GROUPS; ka.ticket_groups = grid >= (u64)(ka.nscan + 1u) * g ? g : 1u; }
     FXG_HIP(c, hipMemsetAsync(c->errflag, 0, (FXG_CTRL_WORDS + FXG_TICKET_GROUPS * FXG_TICKET_STRIDE) * sizeof(u32), c->stream));
 
-    if (c->profiling) FXG_HIP(c, hipEventRecord(c->kev0, c->stream));
+    if (c->profiling) FXG_HIP(c, hipEventRecord(c->kev0[c->kev_count % FXG_KEV_RING], c->stream));
     hipLaunchKernelGGL(kernel, dim3((u32)grid), dim3(block), lds, c->stream, ka);
     FXG_HIP(c, hipGetLastError());
-    if (c->profiling) { FXG_HIP(c, hipEventRecord(c->kev1, c->stream)); c->kev_valid = 1; }
+    if (c->profiling) { FXG_HIP(c, hipEventRecord(c->kev1[c->kev_count % FXG_KEV_RING], c->stream)); c->kev_count++; }
     // -v report counters: the tile kernel tallied them; one tiny kernel lays them out
     hipLaunchKernelGGL(fxg_kernel_finish_counters, dim3(1), dim3(64), 0, c->stream, (const u64 *)ka.tally, ka.stages, (const u32 *)c->errflag,
                        (const u64 *)(c->errflag + 2), counters ? counters : c->counters_scratch);
@@ -490,10 +491,10 @@ extern "C" int fxg_run_quality_stats(fxg_ctx *c, const fxg_batch *in, uint64_t *
     for (u32 s0 = 0; s0 < nstrips; s0 += FXG_QS_WAVES) {       // one pass per block of 160 columns (one pass for reads up to 160)
         a.strip0 = s0;
         const bool timed = c->profiling && s0 == 0;
-        if (timed) FXG_HIP(c, hipEventRecord(c->kev0, c->stream));
+        if (timed) FXG_HIP(c, hipEventRecord(c->kev0[c->kev_count % FXG_KEV_RING], c->stream));
         hipLaunchKernelGGL(fxg_kernel_quality_stats, dim3(a.nwg), dim3(FXG_QS_TBLOCK), lds, c->stream, a);
         FXG_HIP(c, hipGetLastError());
-        if (timed) { FXG_HIP(c, hipEventRecord(c->kev1, c->stream)); c->kev_valid = 1; }
+        if (timed) { FXG_HIP(c, hipEventRecord(c->kev1[c->kev_count % FXG_KEV_RING], c->stream)); c->kev_count++; }
         hipLaunchKernelGGL(fxg_kernel_quality_stats_fold, dim3((FXG_QS_PART_WORDS + FXG_BLOCK - 1) / FXG_BLOCK), dim3(FXG_BLOCK), 0, c->stream, a);
         FXG_HIP(c, hipGetLastError());
     }
@@ -801,8 +802,12 @@ static const char *fxg_comm_d2h_sync(fxg_ctx *c, void *dst, const void *src, siz
 extern "C" int fxg_set_profiling(fxg_ctx *c, int enabled)
 {
     if (!c) return FXG_E_INVALID;
+    if (enabled && !c->kev0[0]) {                            // the event ring is made on first use
+        FXG_HIP(c, hipSetDevice(c->device));
+        for (int i = 0; i < FXG_KEV_RING; ++i) { FXG_HIP(c, hipEventCreate(&c->kev0[i])); FXG_HIP(c, hipEventCreate(&c->kev1[i])); }
+    }
     c->profiling = enabled ? 1 : 0;
-    c->kev_valid = 0;
+    c->kev_count = 0;
     return FXG_OK;
 }
 
@@ -820,9 +825,25 @@ extern "C" int fxg_debug_phase_clocks(fxg_ctx *c, uint64_t out[11])
 extern "C" int fxg_last_kernel_ms(fxg_ctx *c, float *ms)
 {
     if (!c || !ms) return FXG_E_INVALID;
-    if (!c->kev_valid) return fxg_fail(c, FXG_E_INVALID, "no profiled launch recorded");
-    FXG_HIP(c, hipEventSynchronize(c->kev1));
-    FXG_HIP(c, hipEventElapsedTime(ms, c->kev0, c->kev1));
+    if (!c->kev_count) return fxg_fail(c, FXG_E_INVALID, "no profiled launch recorded");
+    const int k = (int)((c->kev_count - 1) % FXG_KEV_RING);
+    FXG_HIP(c, hipEventSynchronize(c->kev1[k]));
+    FXG_HIP(c, hipEventElapsedTime(ms, c->kev0[k], c->kev1[k]));
+    return FXG_OK;
+}
+
+extern "C" int fxg_profiled_kernel_ms(fxg_ctx *c, float *ms, uint32_t cap, uint32_t *n)
+{
+    if (!c || !ms || !n) return FXG_E_INVALID;
+    const u64 have = c->kev_count < FXG_KEV_RING ? c->kev_count : FXG_KEV_RING;
+    const u32 k = (u32)(have < cap ? have : cap);
+    *n = 0;
+    for (u32 i = 0; i < k; ++i) {                            // oldest first
+        const int slot = (int)((c->kev_count - k + i) % FXG_KEV_RING);
+        FXG_HIP(c, hipEventSynchronize(c->kev1[slot]));
+        FXG_HIP(c, hipEventElapsedTime(&ms[i], c->kev0[slot], c->kev1[slot]));
+    }
+    *n = k;
     return FXG_OK;
 }
 

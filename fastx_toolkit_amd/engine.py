@@ -23,7 +23,7 @@ EXPORTS = [
     "fxg_device_info", "fxg_malloc_device", "fxg_free_device", "fxg_malloc_host", "fxg_free_host", "fxg_memcpy_h2d",
     "fxg_memcpy_d2h", "fxg_memset_device", "fxg_timer_start", "fxg_timer_stop", "fxg_run_pipeline",
     "fxg_run_qtrim_qfilter", "fxg_run_clip", "fxg_run_revcomp_trim", "fxg_read_counters", "fxg_synth_generate",
-    "fxg_last_launch_info", "fxg_set_profiling", "fxg_last_kernel_ms", "fxg_set_clip_history", "fxg_run_quality_stats",
+    "fxg_last_launch_info", "fxg_set_profiling", "fxg_last_kernel_ms", "fxg_profiled_kernel_ms", "fxg_set_clip_history", "fxg_run_quality_stats",
     "fxg_fastq_index", "fxg_fastq_pack", "fxg_fastq_format", "fxg_fasta_weights", "fxg_host_register", "fxg_host_unregister",
     "fxg_shard_range", "fxg_epilogue", "fxg_concat_pwrite", "fxg_device_count", "fxg_device_numa_node", "fxg_comm_create", "fxg_comm_destroy", "fxg_epilogue_rccl",
 ]
@@ -131,6 +131,7 @@ def load_library(path=None):
     L.fxg_set_clip_history.argtypes = [vp, i32]
     L.fxg_run_quality_stats.argtypes = [vp, C.POINTER(FxgBatch), vp, C.c_uint32]
     L.fxg_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.fxg_profiled_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), u32, C.POINTER(u32)]
     if path is None:
         _LIB = L
     return L
@@ -311,6 +312,12 @@ class Engine:
         ms = C.c_float()
         self._check(self.lib.fxg_last_kernel_ms(self.ctx, C.byref(ms)))
         return ms.value
+
+    def profiled_kernel_ms(self, cap=64):
+        """Durations (ms) of the last profiled launches, oldest first (waits for them): the timed loop's own launches."""
+        ms, n = (C.c_float * cap)(), C.c_uint32()
+        self._check(self.lib.fxg_profiled_kernel_ms(self.ctx, ms, cap, C.byref(n)))
+        return [float(ms[i]) for i in range(n.value)]
 
     def timer_start(self):
         self._check(self.lib.fxg_timer_start(self.ctx))

@@ -451,15 +451,20 @@ static int fxh_open_output(const char *filename)
 
 static struct fxh_writer *fxh_writer_open(const char *filename, int gzip);
 struct fxh_writer *fxh_writer_open_file(const char *filename, int gzip) { return fxh_writer_open(filename, gzip); }
+static struct fxh_writer *fxh_writer_from_fd(int fd, int gzip);
+/* a writer over a descriptor the caller has opened (the parts of a sharded run are opened before anything can fail halfway) */
+struct fxh_writer *fxh_writer_open_fd(int fd) { return fxh_writer_from_fd(fd, 0); }
 
-static struct fxh_writer *fxh_writer_open(const char *filename, int gzip)
+static struct fxh_writer *fxh_writer_open(const char *filename, int gzip) { return fxh_writer_from_fd(fxh_open_output(filename), gzip); }
+
+static struct fxh_writer *fxh_writer_from_fd(int fd, int gzip)
 {
     struct fxh_writer *w = (struct fxh_writer *)calloc(1, sizeof *w);
     if (!w) err(1, "out of memory");
     w->cap = 8u << 20;
     w->buf = (char *)malloc(w->cap);
     if (!w->buf) err(1, "out of memory");
-    w->fd = fxh_open_output(filename);
+    w->fd = fd;
     w->gz = gzip ? 1 : 0;
     {
         struct stat sb;
@@ -517,10 +522,11 @@ void fastx_init_writer(FASTX *fx, const char *filename, OUTPUT_FILE_TYPE output_
     if (fx->reader == NULL) errx(1, "Internal error: pFASTX not initialized (%s:%d)", __FILE__, __LINE__);
     fx->compress_output = compress_output;
     strncpy(fx->output_file_name, filename, sizeof fx->output_file_name - 1);
-    {   /* FXH_PARTS=k: "-o out.%r.fq" names the k output parts; this writer is part 0 (fxh_batch.c opens the others) */
+    {   /* "-o out.%r.fq" names the output parts of a sharded run (FXH_PARTS=k, or chosen by the tool: fxh_run_tool); this writer is
+         * part 0 (fxh_batch.c opens the others) */
         char first[PATH_MAX];
         const char *pe = getenv("FXH_PARTS"), *pr = strstr(filename, "%r");
-        if (pe && atoi(pe) >= 1 && pr && strlen(filename) < sizeof first - 8) {
+        if ((!pe || atoi(pe) >= 1) && pr && strlen(filename) < sizeof first - 8) {
             snprintf(first, sizeof first, "%.*s0%s", (int)(pr - filename), filename, pr + 2);
             fx->writer = fxh_writer_open(first, compress_output);
         } else fx->writer = fxh_writer_open(filename, compress_output);

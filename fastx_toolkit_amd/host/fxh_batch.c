@@ -3,6 +3,7 @@
 #include "fxh_batch.h"
 
 #include <err.h>
+#include <fcntl.h>
 #include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -671,6 +672,7 @@ static int g_parts_abort;                  /* sharded run: some part met input i
 #define FXH_ABORTED()   __atomic_load_n(&g_parts_abort, __ATOMIC_RELAXED)
 static pthread_mutex_t g_first_ctx_mu = PTHREAD_MUTEX_INITIALIZER;   /* the HIP runtime's first-use initialisation: one thread at a time */
 static int g_first_ctx_done;
+static int g_hip_touched;                   /* this process has initialised the HIP runtime (a context, or the device query of fxh_bind_near_device): never fork() after that */
 struct fxh_pinned { pthread_mutex_t mu; const void *ptr[FXH_MAX_LANES + 4]; int n; };
 
 #define FXH_MAX_LANES 32
@@ -692,6 +694,8 @@ typedef struct fxh_lane {
     const char *text; size_t len;          /* job: whole records, every line '\n'-terminated */
     uint64_t records;
     int clip_history;                      /* this lane is the one aligner of a fastx_clipper run */
+    int clip_guard;                        /* clipper run in its parallel phase (fxh_run.clip_auto): a block whose reads are not all of one length is handed back untouched */
+    uint32_t fixed_len;                    /* result: the one length of the block's reads, 0 = they differ (or the block was not indexed) */
     int slot;                              /* which of out[] receives the text (the other may still be with the writer) */
     int handled;                           /* result: 0 = irregular block, parse it on the host */
     char *out[2]; size_t out_cap[2]; size_t out_len;
@@ -706,7 +710,7 @@ static void fxh_lane_run(fxh_lane *ln)
     fxh_state *st = &ln->st;
     const size_t len = ln->len;
     const int revcomp = ln->revcomp;
-    ln->handled = 0; ln->out_len = 0;
+    ln->handled = 0; ln->out_len = 0; ln->fixed_len = 0;
     if (st->d_text_cap < len + 32) {
         if (st->d_text) { fxg_free_device(st->ctx, st->d_text); fxg_free_device(st->ctx, st->d_out_text); }
         st->d_text_cap = len + len / 8 + 4096;
@@ -741,6 +745,8 @@ static void fxh_lane_run(fxh_lane *ln)
     if (info.irregular || info.records == 0 || info.records != ln->records || info.consumed != len) return;
     const uint64_t n = info.records;
     const uint32_t stride = info.max_len;
+    ln->fixed_len = info.min_len == info.max_len ? info.max_len : 0u;
+    if (ln->clip_guard && !ln->fixed_len) return;           /* ragged block of a clipper run: the one-aligner mode takes over at this block (fxh_clip_go_serial) */
     if ((uint64_t)n * stride > (uint64_t)8 * len + (1u << 20)) return;   /* ragged beyond reason: the host path handles it */
     fxh_grow_device(st, n, (size_t)n * stride + 16, revcomp);
     uint32_t irr = 0;
@@ -798,6 +804,7 @@ static void *fxh_lane_main(void *arg)
     double t0 = fxh_now();
     int rc;
     pthread_mutex_lock(&g_first_ctx_mu);    /* the parts of a sharded run each have a lane 0: the process-wide first context still comes alone */
+    g_hip_touched = 1;
     if (!g_first_ctx_done) { rc = fxg_ctx_create(ln->device, &ln->st.ctx); g_first_ctx_done = 1; pthread_mutex_unlock(&g_first_ctx_mu); }
     else { pthread_mutex_unlock(&g_first_ctx_mu); rc = fxg_ctx_create(ln->device, &ln->st.ctx); }
     if (rc != 0) errx(1, "no usable MI355X/HIP device %d (fxg_ctx_create = %d); this build has no CPU path", ln->device, rc);
@@ -851,6 +858,7 @@ static int fxh_bind_near_device(int device, cpu_set_t *before)
     if (getenv("FXH_NO_NUMA")) return 0;
     pthread_mutex_lock(&g_first_ctx_mu);         /* the query is a first use of the HIP runtime: one thread at a time, like the first context */
     const int node = fxg_device_numa_node(device);
+    g_hip_touched = 1;                           /* (no fork() over an initialised runtime from here on, fxh_run_parts) */
     pthread_mutex_unlock(&g_first_ctx_mu);
     if (node < 0) return 0;
     char path[96], line[4096];
@@ -937,6 +945,15 @@ typedef struct fxh_run {
     fxh_stats_run *stats;
     fxh_state st;                          /* the host-parser path's own context and buffers (created on first use) */
     int st_device, st_shared;              /* st_shared: the context belongs to lane 0 (serial clipper run) */
+    /* fastx_clipper without being told anything: the reference's aligner carries its query buffer from read to read, but the
+     * stale tail only exists once a read SHORTER than the longest so far turns up (sequence_alignment.cpp:135-136).  While every block so
+     * far consists of reads of ONE length (clip_len, the first block's), blocks are independent: lanes and parts run in parallel without
+     * history (clip_auto).  The first block that is different -- ragged, another length, or anything the device path hands back -- switches
+     * the run to the reference's mode at that block: one lane, history on, seeded with the last record before it (clip_seed), which is
+     * exactly the aligner's state after reads of one length (fxh_clip_go_serial). */
+    int clip_auto;
+    uint32_t clip_len;
+    char *clip_seed; size_t clip_seed_len, clip_seed_cap;
     fxh_job job;
     fxh_awriter aw;
     char *wr_spare; size_t wr_spare_cap;
@@ -955,6 +972,9 @@ static void fxh_run_ctx(fxh_run *R)
 {
     if (R->st.ctx) return;
     const double t0 = fxh_now();
+    pthread_mutex_lock(&g_first_ctx_mu);
+    g_hip_touched = 1;
+    pthread_mutex_unlock(&g_first_ctx_mu);
     int rc = fxg_ctx_create(R->st_device, &R->st.ctx);
     if (rc != 0) errx(1, "no usable MI355X/HIP device (fxg_ctx_create = %d); this build has no CPU path", rc);
     FXG_CHECK(&R->st, fxg_malloc_device(R->st.ctx, FXG_NCOUNTERS * sizeof(uint64_t), (void **)&R->st.d_counters));
@@ -1226,6 +1246,7 @@ typedef struct fxh_block {
     unsigned long long line0;              /* lines read before it */
     uint64_t records;
     int lane;                              /* -1: not given to a lane (ragged end of input, oversized record): host parser */
+    int posted;                            /* its lane has the job (0 only between fxh_clip_go_serial and the block's turn) */
 } fxh_block;
 
 /* ---- the lanes loop (device text path) in four pieces: start the lanes, emit a finished block, cut the next block, stop ---- */
@@ -1242,7 +1263,8 @@ static fxh_lane *fxh_lanes_start(fxh_run *R, int nlanes, const int *lane_dev)
         ln->qoffset = fx->fastq_ascii_quality_offset;
         ln->reverse = (R->p->stages & FXG_STAGE_REVCOMP) != 0; ln->lpr = R->job.lpr; ln->has_q = R->job.has_q; ln->out_fasta = !fx->write_fastq;
         ln->pinned = pinned; ln->first = &lanes[0];
-        if ((R->p->stages & FXG_STAGE_CLIP) && nlanes == 1) { ln->clip_history = 1; R->st_shared = 1; }
+        if ((R->p->stages & FXG_STAGE_CLIP) && !R->clip_auto) { ln->clip_history = 1; R->st_shared = 1; }      /* (one lane: fxh_run_impl saw to that) */
+        ln->clip_guard = R->clip_auto;
         pthread_mutex_init(&ln->mu, NULL); pthread_cond_init(&ln->cv, NULL);
         if (pthread_create(&ln->th, NULL, fxh_lane_main, ln) != 0) err(1, "pthread_create");
     }
@@ -1251,7 +1273,8 @@ static fxh_lane *fxh_lanes_start(fxh_run *R, int nlanes, const int *lane_dev)
 
 /* Block `b` is next in the output order: wait for its lane and hand the formatted text to the writer, or -- a block the device
  * flagged, or one that never went to a lane -- run it through the host parser at its turn.  Returns 0 when the run must stop
- * (a part of a sharded run met such a block: R->aborted). */
+ * (a part of a sharded run met such a block: R->aborted), 2 when a clipper run in its parallel phase meets its first block that is
+ * not "reads of the one length seen so far" (nothing of the block has been written; see fxh_clip_go_serial). */
 static int fxh_lanes_emit(fxh_run *R, fxh_lane *lanes, fxh_block *b)
 {
     FASTX *fx = R->fx;
@@ -1262,8 +1285,20 @@ static int fxh_lanes_emit(fxh_run *R, fxh_lane *lanes, fxh_block *b)
         double tw = fxh_now();
         fxh_lane_wait(ln);
         R->t_wait_lane += fxh_now() - tw;
+        if (R->clip_auto && !(ln->handled && ln->fixed_len && (R->clip_len == 0u || ln->fixed_len == R->clip_len))) {
+            if (R->nparts > 1) { R->aborted = 1; FXH_ABORT_SET(); return 0; }      /* a part cannot know what came before it: the whole run starts over as one stream */
+            return 2;                      /* the caller switches to the one-aligner mode and brings this block back */
+        }
         if (ln->handled) {
             handled = 1;
+            if (R->clip_auto) {            /* remember the block's last record: what the aligner would hold if the next block is the first different one */
+                R->clip_len = ln->fixed_len;
+                const char *t = b->buf + b->beg, *e = b->buf + b->end, *q = e;
+                for (int k = 0; k < ln->lpr && q > t; ++k) { const char *r = (const char *)memrchr(t, '\n', (size_t)(q - 1 - t)); q = r ? r + 1 : t; }
+                const size_t need = (size_t)(e - q);
+                if (R->clip_seed_cap < need) { free(R->clip_seed); R->clip_seed_cap = need + 256; R->clip_seed = (char *)malloc(R->clip_seed_cap); if (!R->clip_seed) err(1, "out of memory"); }
+                memcpy(R->clip_seed, q, need); R->clip_seed_len = need;
+            }
             tw = fxh_now();
             fxh_awriter_submit_ext(&R->aw, fx->writer, ln->out[ln->slot], ln->out_len);
             R->t_wait_writer += fxh_now() - tw;
@@ -1271,6 +1306,7 @@ static int fxh_lanes_emit(fxh_run *R, fxh_lane *lanes, fxh_block *b)
             fxh_add_counters(R->tot, ln->ctr, b->records, ln->lpr == 2 ? ln->weighted : NULL);
         }
     }
+    if (!handled && R->clip_auto && R->nparts <= 1) return 2;      /* (a block that never went to a lane: the host parser needs the one aligner too) */
     if (!handled && R->nparts > 1) {   /* a part of a sharded run only takes what the device path takes: the whole run starts over unsharded */
         R->aborted = 1; FXH_ABORT_SET();
         return 0;
@@ -1360,8 +1396,36 @@ static void fxh_lanes_stop(fxh_run *R, fxh_lane *lanes, int nlanes, double *t_la
     /* The process is about to exit: device buffers, streams and page-locked memory go with it, there is nothing to gain from
      * tearing each context down first (FXH_TEARDOWN=1 does it anyway, for leak checkers). */
     if (R->st_shared) { if (R->st.ctx) fxg_sync(R->st.ctx); R->st.ctx = NULL; }
-    if (getenv("FXH_TEARDOWN")) for (int i = 0; i < nlanes; ++i) fxg_ctx_destroy(lanes[i].st.ctx);
+    if (getenv("FXH_TEARDOWN") || (R->nparts > 1 && (R->aborted || R->have_err || FXH_ABORTED())))     /* an abandoned sharded attempt ends with the device idle and no context left */
+        for (int i = 0; i < nlanes; ++i) fxg_ctx_destroy(lanes[i].st.ctx);
     free(lanes);
+}
+
+/* A clipper run leaves its parallel phase at block blk[first]: every lane comes to rest (what the lanes made of this and the later
+ * blocks is dropped -- none of it has been written), lane 0 becomes the reference's one aligner (history on, as in a serial run) and
+ * is brought to the state that aligner has after reads of one length -- its buffer holds the LAST of them -- by running the last record
+ * before the block through it; then the blocks already cut go through it again, in order.  From here on the run is the serial run. */
+static void fxh_clip_go_serial(fxh_run *R, fxh_lane *lanes, int nlanes, fxh_block *blk, int NB, size_t first, size_t nblocks, size_t *lane_uses)
+{
+    for (int i = 0; i < nlanes; ++i) { fxh_lane_wait(&lanes[i]); lanes[i].clip_guard = 0; }
+    fxh_awriter_wait(&R->aw);               /* no output buffer of a lane is with the writer while lane 0 runs the seed */
+    fxh_lane *l0 = &lanes[0];
+    pthread_mutex_lock(&l0->mu);
+    while (!l0->ready) pthread_cond_wait(&l0->cv, &l0->mu);
+    pthread_mutex_unlock(&l0->mu);
+    FXG_CHECK(&l0->st, fxg_set_clip_history(l0->st.ctx, 1));
+    l0->clip_history = 1;
+    R->clip_auto = 0; R->st_shared = 1;
+    if (R->clip_seed_len) {                 /* (no record before the block: the aligner is fresh, as at the start of a serial run) */
+        fxh_lane_post(l0, NULL, 0, R->clip_seed, R->clip_seed_len, 1, (int)(lane_uses[0]++ & 1u));
+        fxh_lane_wait(l0);
+        if (!l0->handled) errx(1, "internal error: the record before the first ragged block did not pass the device path a second time");
+    }
+    for (size_t j = first; j < nblocks; ++j) {          /* the blocks already cut: lane 0 takes them one by one as they are emitted */
+        fxh_block *b = &blk[j % (size_t)NB];
+        if (b->lane >= 0) { b->lane = 0; b->posted = 0; }
+    }
+    if (getenv("FXH_TIMING")) fprintf(stderr, "fxh clipper: reads of one length (%u) up to block %zu; one aligner with history from there on\n", R->clip_len, first);
 }
 
 /* The lanes loop.  Returns when the input is exhausted or an error is pending in R. */
@@ -1379,11 +1443,19 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
     size_t lane_uses[FXH_MAX_LANES] = {0};
     int input_done = 0, have_carry = 0;
     unsigned long long carry_lines = 0;
+    int nl = nlanes;                        /* lanes that take blocks: all of them, or lane 0 alone once a clipper run has gone serial */
 
     while (!R->have_err && !R->aborted && !(R->nparts > 1 && FXH_ABORTED())) {
         /* ---- collect finished blocks in input order until a lane and an input buffer are free ---- */
-        while (next_emit < nblocks && (nblocks - next_emit >= (size_t)nlanes || input_done)) {
-            if (!fxh_lanes_emit(R, lanes, &blk[next_emit % (size_t)NB])) break;
+        while (next_emit < nblocks && (nblocks - next_emit >= (size_t)nl || input_done)) {
+            fxh_block *eb = &blk[next_emit % (size_t)NB];
+            if (eb->lane >= 0 && !eb->posted) {          /* a block fxh_clip_go_serial took back: lane 0 runs it now, with history */
+                fxh_lane_post(&lanes[0], eb->buf, rd->cap + 1, eb->buf + eb->beg, eb->end - eb->beg, eb->records, (int)(lane_uses[0]++ & 1u));
+                eb->posted = 1;
+            }
+            const int erc = fxh_lanes_emit(R, lanes, eb);
+            if (erc == 2) { fxh_clip_go_serial(R, lanes, nlanes, blk, NB, next_emit, nblocks, lane_uses); nl = 1; continue; }
+            if (!erc) break;
             next_emit++;
             if (R->have_err) break;
         }
@@ -1410,7 +1482,7 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
         const uint64_t records = lines / lpr;
         R->t_index += fxh_now() - t0;
         fxh_block *b = &blk[nblocks % (size_t)NB];
-        b->buf = rd->buf; b->beg = rd->beg; b->line0 = fx->input_line_number; b->records = records; b->lane = -1;
+        b->buf = rd->buf; b->beg = rd->beg; b->line0 = fx->input_line_number; b->records = records; b->lane = -1; b->posted = 0;
         if (rd->eof && (lines % lpr != 0 || records == 0)) {
             /* ragged end of input: the host parser owns the message; hand it everything that is left */
             b->end = end; b->eof = 1;
@@ -1419,8 +1491,8 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
             errx(1, "input record does not fit in the %zu MB read buffer", rd->cap >> 20);
         } else {
             b->end = cut; b->eof = (rd->eof && cut == end);
-            const int li = (int)(nblocks % (size_t)nlanes);
-            b->lane = li;
+            const int li = (int)(nblocks % (size_t)nl);
+            b->lane = li; b->posted = 1;
             fxh_lane_post(&lanes[li], rd->buf, rd->cap + 1, rd->buf + rd->beg, cut - rd->beg, records, (int)(lane_uses[li]++ & 1u));
             rd->beg = cut < rd->end ? cut : rd->end;
             carry_lines = lines - (unsigned long long)lpr * records - (end > rd->end ? 1u : 0u); have_carry = 1;   /* complete lines left in the unread tail */
@@ -1434,6 +1506,7 @@ static void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *l
     free(inbuf); free(blk);
 }
 
+static uint32_t g_part_clip_len[FXH_MAX_LANES];      /* clipper parts: the one read length each part saw (0: not a clipper run / no reads) */
 static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_stats_run *stats, uint64_t **hist_out, uint32_t *cols_out, int part, int nparts)
 {
     fxh_run R;
@@ -1486,9 +1559,12 @@ static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_sta
     int nlanes = 0;
     int lane_dev[FXH_MAX_LANES];
     if (gpu_text) {
-        /* The clipper's aligner carries state from read to read: its blocks must pass through ONE context in order,
-         * unless the caller knows the input has one fixed length (FXH_CLIP_PARALLEL=1). */
-        const int serial = (p->stages & FXG_STAGE_CLIP) && getenv("FXH_CLIP_PARALLEL") == NULL;
+        /* The clipper's aligner carries state from read to read.  By default the run is parallel for as long as that state
+         * cannot matter and goes serial at the first block where it can (clip_auto); FXH_CLIP_PARALLEL=1 is the caller's word that the
+         * input has one fixed length (no checks), FXH_CLIP_SERIAL=1 asks for the one aligner from the start. */
+        const int clip = (p->stages & FXG_STAGE_CLIP) != 0;
+        const int serial = clip && getenv("FXH_CLIP_SERIAL") != NULL && getenv("FXH_CLIP_PARALLEL") == NULL;      /* FXH_CLIP_SERIAL=1: the one aligner from the first read on */
+        R.clip_auto = clip && !serial && getenv("FXH_CLIP_PARALLEL") == NULL;      /* the default: parallel while it is exact, see fxh_run.clip_auto */
         const char *le = getenv("FXH_LANES");
         int per = le ? atoi(le) : 2;
         if (per < 1) per = 1;
@@ -1512,6 +1588,8 @@ static int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_sta
     }
     fxh_awriter_stop(&R.aw);
     fxh_prefetch_stop(&pf);
+    free(R.clip_seed);
+    if (nparts > 1) g_part_clip_len[part] = R.clip_auto ? R.clip_len : 0u;
     if (nparts > 1 && (R.aborted || R.have_err || FXH_ABORTED())) {      /* fxh_run_parts starts the whole job over, unsharded */
         FXH_ABORT_SET();
         for (int i = 0; i < job->nworkers; ++i) { free(job->w[i].rec); free(job->w[i].shadow); }
@@ -1612,7 +1690,7 @@ static int fxh_run_parts(FASTX *fx, const fxg_params *p, fxh_totals *tot, int k)
     if (k > FXH_MAX_LANES) k = FXH_MAX_LANES;
     if (rd->fd == STDIN_FILENO || fstat(rd->fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return -1;
     if (strcmp(fx->output_file_name, "-") == 0 || fx->compress_output || g_rename_ids || getenv("FXH_HOST_PARSE")) return -1;
-    if ((p->stages & FXG_STAGE_CLIP) && getenv("FXH_CLIP_PARALLEL") == NULL) return -1;      /* one aligner, one history (N3) */
+    if ((p->stages & FXG_STAGE_CLIP) && getenv("FXH_CLIP_SERIAL") != NULL && getenv("FXH_CLIP_PARALLEL") == NULL) return -1;      /* one aligner asked for */
     const off_t size = sb.st_size, here = lseek(rd->fd, 0, SEEK_CUR);
     const int lpr = fx->read_fastq ? 4 : 2;
     off_t cut[FXH_MAX_LANES + 1];
@@ -1626,12 +1704,31 @@ static int fxh_run_parts(FASTX *fx, const fxg_params *p, fxh_totals *tot, int k)
      * child empties the parts and exits with FXH_EXIT_ABANDON, and this process -- which has not touched the GPU yet -- runs the same
      * input unsharded (part 0 then receives everything).  Nothing is ever exec'd or killed with device work in flight: the child ends
      * like any tool run, after its threads have been joined and its contexts destroyed. */
-    if (g_first_ctx_done) return -1;             /* this process has used the GPU already (a host that calls in twice): no fork over a live HIP runtime */
+    if (g_hip_touched) return -1;                /* this process has used the HIP runtime already (a host that calls in twice): no fork over a live runtime */
+    /* Every part is opened HERE, before anything has run: an output that cannot take parts -- /dev/null, a FIFO, a directory where the
+     * sibling names cannot be created -- means one stream (part 0 alone, as named by the caller), never a failure halfway. */
+    int part_fd[FXH_MAX_LANES];
+    {
+        struct stat ob;
+        struct fxh_writer *w0 = fx->writer;
+        if (!w0 || w0->fd < 0 || fstat(w0->fd, &ob) != 0 || !S_ISREG(ob.st_mode)) return -1;
+        for (int r = 1; r < k; ++r) {
+            char name[PATH_MAX + 16];
+            fxh_part_name(fx, r, name, sizeof name);
+            part_fd[r] = open(name, O_CREAT | O_WRONLY | O_TRUNC, 0666);
+            if (part_fd[r] < 0 || fstat(part_fd[r], &ob) != 0 || !S_ISREG(ob.st_mode)) {
+                warn("%s: cannot be an output part, running as one stream", name);
+                for (int q = 1; q <= r; ++q) if (part_fd[q] >= 0) close(part_fd[q]);
+                return -1;
+            }
+        }
+    }
     fflush(NULL);
     const pid_t child = fork();
-    if (child < 0) return -1;
+    if (child < 0) { for (int r = 1; r < k; ++r) close(part_fd[r]); return -1; }
     if (child > 0) {
         int st = 0;
+        for (int r = 1; r < k; ++r) close(part_fd[r]);                                  /* the child writes them */
         while (waitpid(child, &st, 0) < 0) { if (errno != EINTR) err(1, "waitpid"); }
         if (WIFEXITED(st) && WEXITSTATUS(st) == FXH_EXIT_ABANDON) {
             if (lseek(rd->fd, here, SEEK_SET) < 0) err(1, "%s", fx->input_file_name);      /* the child read through the shared descriptor */
@@ -1654,7 +1751,7 @@ static int fxh_run_parts(FASTX *fx, const fxg_params *p, fxh_totals *tot, int k)
         if (!f) err(1, "out of memory");
         memcpy(f, fx, sizeof(FASTX));
         f->reader = fxh_reader_open_range(fx->input_file_name, cap_env && atoi(cap_env) > 0 ? (size_t)atoi(cap_env) << 20 : 0, cut[r], cut[r + 1]);
-        f->writer = fxh_writer_open_file(pt[r].name, 0);
+        f->writer = fxh_writer_open_fd(part_fd[r]);
         f->input_line_number = 0; f->num_input_sequences = f->num_input_reads = f->num_output_sequences = f->num_output_reads = 0;
         pt[r].fx = f;
     }
@@ -1665,10 +1762,21 @@ static int fxh_run_parts(FASTX *fx, const fxg_params *p, fxh_totals *tot, int k)
     for (int r = 1; r < k; ++r) pthread_join(pt[r].th, NULL);
     int bad = FXH_ABORTED();
     for (int r = 0; r < k; ++r) if (pt[r].rc != 0) bad = 1;
+    {   /* clipper: every part found reads of one length -- it has to be the SAME length in all of them (a shorter read after a longer one
+         * sees the longer one's tail); otherwise the parent runs the input as one stream, which goes serial where it must */
+        uint32_t len0 = 0;
+        for (int r = 0; r < k && !bad; ++r) { if (!g_part_clip_len[r]) continue; if (!len0) len0 = g_part_clip_len[r]; else if (g_part_clip_len[r] != len0) bad = 1; }
+    }
     if (bad) {
-        for (int r = 1; r < k; ++r) { fxh_writer_close(pt[r].fx->writer); if (truncate(pt[r].name, 0) != 0) warn("%s", pt[r].name); }
+        /* Abandoned.  Every thread of every part has been joined and its contexts are gone (fxh_lanes_stop destroys them for a part
+         * that stops), the device is idle.  The parts are emptied through their own descriptors, part 0 -- whose descriptor the parent
+         * shares -- is emptied here as well, and the process leaves with _exit: no exit handler of this half-finished attempt (the
+         * writers' flush-at-exit, the runtime's) gets to run.  The parent then runs the input as one stream (see the fork above). */
+        for (int r = 1; r < k; ++r) { struct fxh_writer *w = pt[r].fx->writer; w->len = 0; if (ftruncate(w->fd, 0) != 0) warn("%s", pt[r].name); close(w->fd); w->fd = -1; }
+        { struct fxh_writer *w = fx->writer; w->len = 0; if (ftruncate(w->fd, 0) != 0 || lseek(w->fd, 0, SEEK_SET) < 0) warn("%s", pt[0].name); }
+        if (getenv("FXH_TIMING")) fprintf(stderr, "fxh parts: abandoned, contexts destroyed, parts emptied\n");
         fflush(NULL);
-        exit(FXH_EXIT_ABANDON);                  /* the parent runs the input again as one stream (see the fork above) */
+        _exit(FXH_EXIT_ABANDON);
     }
     memset(tot, 0, sizeof *tot);
     FILE *ix = NULL;
@@ -1697,10 +1805,23 @@ static int fxh_run_parts(FASTX *fx, const fxg_params *p, fxh_totals *tot, int k)
     return 0;
 }
 
+/* `-o out.%r.fq` without FXH_PARTS: the caller has said where parts may go, the tool picks their number -- four (what one GPU's link and
+ * four writer streams take, profiles/r03/l..q_e2e_parts*.txt) for a regular input file of at least 1 GB (FXH_AUTO_PARTS_MIN_MB), where
+ * the ~0.1 s of three more contexts is paid back; one otherwise (part 0 then holds everything). */
+static int fxh_auto_parts(const FASTX *fx)
+{
+    struct stat sb;
+    if (!strstr(fx->output_file_name, "%r") || strcmp(fx->output_file_name, "-") == 0) return 0;
+    const char *me = getenv("FXH_AUTO_PARTS_MIN_MB");
+    const long long min_bytes = (me ? atoll(me) : 1024ll) << 20;
+    if (fx->reader->fd == STDIN_FILENO || fstat(fx->reader->fd, &sb) != 0 || !S_ISREG(sb.st_mode) || (long long)sb.st_size < min_bytes) return 1;
+    return 4;
+}
+
 int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *tot)
 {
     const char *pe = getenv("FXH_PARTS");
-    int k = pe ? atoi(pe) : 0;
+    int k = pe ? atoi(pe) : fxh_auto_parts(fx);
     if (k > FXH_MAX_LANES) k = FXH_MAX_LANES;
     if (k > 1 && fxh_run_parts(fx, p, tot, k) == 0) return 0;
     const int rc = fxh_run_impl(fx, p, tot, NULL, NULL, NULL, 0, 1);

@@ -38,6 +38,7 @@ struct fxh_rawrec {
 struct fxh_reader *fxh_reader_open(const char *filename, size_t capacity);
 struct fxh_reader *fxh_reader_open_range(const char *filename, size_t capacity, off_t start, off_t limit);   /* regular file, bytes [start, limit) */
 struct fxh_writer *fxh_writer_open_file(const char *filename, int gzip);
+struct fxh_writer *fxh_writer_open_fd(int fd);
 void   fxh_reader_reserve(struct fxh_reader *r, size_t capacity);
 void   fxh_reader_fill(struct fxh_reader *r);
 int    fxh_reader_peek(struct fxh_reader *r);

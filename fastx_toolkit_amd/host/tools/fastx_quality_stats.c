@@ -1,8 +1,20 @@
-/* fastx_quality_stats -- same command line and output (old and -N format) as the reference tool
- * (src/fastx_quality_stats/fastx_quality_stats.c).  For FASTQ input the per-column histograms are built on the GPU
- * (fxg_run_quality_stats) and everything the reference derives from its counting-sort arrays -- count, min, max, sum,
- * quartiles, whiskers (:218-414) -- is derived here from that histogram with the reference's own arithmetic.  FASTA input
- * (counts only, weighted by collapsed-read multiplicity) stays on the record API. */
+/* fastx_quality_stats -- command line and both report formats of the reference tool (src/fastx_quality_stats/fastx_quality_stats.c:296-414).
+ *
+ * FASTQ input is reduced on the GPU to hist[column][A,C,G,T,N][quality byte] (fxg_run_quality_stats); the report is a function of
+ * that histogram.  FASTA input has bases but no qualities: counts per column and class, weighted by the collapsed-read multiplicity,
+ * come from the record API.
+ *
+ * The numbers are kept the way the reference's arithmetic sees them: one flat image of `int`s, REC ints per (column, class) record --
+ *     [0] smallest quality (100 while empty)   [1] largest (-100 while empty)   [2] bases   [3..4] sum of qualities (64 bit)
+ *     [5 .. 5 + QUALITY_VALUES_RANGE)  bases per quality value, bin = quality - MIN_QUALITY_VALUE
+ * records in (column, class) order, class 0 = all bases.  Two behaviours of the reference fall out of this layout and nothing else
+ * (its structs are byte-packed because fastx.h:61 leaves `#pragma pack(1)` on, so a record is exactly these REC ints):
+ *   * quality 93 has bin QUALITY_VALUES_RANGE, one past a record's bins: it is counted in field [0] of the NEXT record;
+ *   * the k-th smallest quality of a record is found by walking its bins upwards (fastx_quality_stats.c:237-243).  With FASTA input
+ *     a record has bases and no qualities, so the walk leaves the record and runs through the fields of the records behind it.
+ * cell() below is that image, including the untouched records behind the last column of the input (the reference's array has
+ * MAX_SEQ_LINE_LENGTH columns); the walk stops at the end of the image, where the reference would read whatever the linker put next.
+ */
 #include <err.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -22,189 +34,190 @@ const char *usage =
     "Old format: column count min max sum mean Q1 med Q3 IQR lW rW A_Count C_Count G_Count T_Count N_Count Max_count\n"
     "New format: cycle max_count, then count min max sum mean Q1 med Q3 IQR lW rW for each of ALL A C G T N\n\n";
 
-enum { ALL = 0, NUC_INDEX_SIZE = 6 };
-static const char *nucleotide_index_name[NUC_INDEX_SIZE] = {"ALL", "A", "C", "G", "T", "N"};
+enum { CLASSES = 6, REC = 5 + QUALITY_VALUES_RANGE, F_LOW = 0, F_HIGH = 1, F_BASES = 2, F_SUM = 3, F_BIN0 = 5 };
+static const char *const class_name[CLASSES] = {"ALL", "A", "C", "G", "T", "N"};
+static const char *const column_name[11] = {"count", "min", "max", "sum", "mean", "Q1", "med", "Q3", "IQR", "lW", "rW"};
 
-/* fastx_quality_stats.c:115-134.  The reference declares these after including fastx.h, which leaves #pragma pack(1) on
- * (fastx.h:61), and keeps them in one static array; get_nth_value (:237-243) walks past the end of bases_values_count when a
- * class has bases but no qualities (FASTA input) and lands on the next record's min = 100.  Same layout here, so the same
- * walk reads the same numbers (and, like there, a quality of 93 indexes one past the array: SURVEY N2). */
-#pragma pack(push, 1)
-struct nucleotide_data {
-    int min, max, count;
-    unsigned long long sum;
-    int bases_values_count[QUALITY_VALUES_RANGE];
-};
-#pragma pack(pop)
-#define MAX_SEQUENCE_LENGTH MAX_SEQ_LINE_LENGTH
-static struct nucleotide_data cycles[MAX_SEQUENCE_LENGTH][NUC_INDEX_SIZE];
-static size_t ncycles = MAX_SEQUENCE_LENGTH;
-static FILE *outfile;
-static int new_output_format = 0;
-static FASTX fastx;
+static int *image;                  /* REC ints per record, records_held of them */
+static size_t columns_held;         /* columns of the input (records_held = columns_held * CLASSES) */
+static const size_t image_records = (size_t)MAX_SEQ_LINE_LENGTH * CLASSES;
 
-static void init_values(void)            /* :138-163 */
+static void hold_columns(size_t n)
 {
-    for (size_t i = 0; i < MAX_SEQUENCE_LENGTH; ++i)
-        for (int j = 0; j < NUC_INDEX_SIZE; ++j) { cycles[i][j].min = 100; cycles[i][j].max = -100; }
-}
-static void grow_cycles(size_t n)
-{
-    if (n > MAX_SEQUENCE_LENGTH) errx(1, "Internal error: sequence too long. Hard-coded max. length is %d", MAX_SEQ_LINE_LENGTH);
+    if (n > MAX_SEQ_LINE_LENGTH) errx(1, "Internal error: sequence too long. Hard-coded max. length is %d", MAX_SEQ_LINE_LENGTH);
+    if (n <= columns_held) return;
+    image = realloc(image, n * CLASSES * REC * sizeof(int));
+    if (!image) err(1, "out of memory");
+    for (size_t r = columns_held * CLASSES; r < n * CLASSES; ++r) {
+        memset(image + r * REC, 0, REC * sizeof(int));
+        image[r * REC + F_LOW] = 100;
+        image[r * REC + F_HIGH] = -100;
+    }
+    columns_held = n;
 }
 
-static int nuc_to_index(int c)            /* :142-155 */
+/* int number i of the image; records nobody touched read as they were initialised */
+static int cell(size_t i)
 {
-    switch (c) {
-    case 'A': case 'a': return 1; case 'C': case 'c': return 2; case 'G': case 'g': return 3;
-    case 'T': case 't': return 4; case 'N': case 'n': return 5; default: return 0;
+    if (i < columns_held * CLASSES * REC) return image[i];
+    const size_t field = i % REC;
+    return field == F_LOW ? 100 : field == F_HIGH ? -100 : 0;
+}
+static size_t record(size_t column, int cls) { return (column * CLASSES + (size_t)cls) * REC; }
+static long long quality_sum(size_t rec) { unsigned long long s; memcpy(&s, image + rec + F_SUM, sizeof s); return (long long)s; }
+
+/* `bases` bases of quality q in one (column, class): the record itself and the all-bases record of the column */
+static void tally(size_t column, int cls, int q, long long bases)
+{
+    const size_t recs[2] = {record(column, 0), record(column, cls)};
+    for (int k = 0; k < 2; ++k) {
+        int *r = image + recs[k];
+        unsigned long long s;
+        if (q < r[F_LOW]) r[F_LOW] = q;
+        if (q > r[F_HIGH]) r[F_HIGH] = q;
+        r[F_BASES] += (int)bases;
+        memcpy(&s, r + F_SUM, sizeof s);
+        s += (unsigned long long)((long long)q * bases);
+        memcpy(r + F_SUM, &s, sizeof s);
+        const size_t bin = recs[k] + F_BIN0 + (size_t)(q - MIN_QUALITY_VALUE);      /* q = 93: field [0] of the next record (N2) */
+        if (bin < columns_held * CLASSES * REC) image[bin] += (int)bases;
     }
 }
 
-/* device histogram [col][A,C,G,T,N][quality + 33] -> the reference's per-cycle records (what read_file :166-216 leaves) */
-static void cycles_from_histogram(const uint64_t *hist, uint32_t cols)
+/* the device's hist[column][A,C,G,T,N][quality + 33] into the image */
+static void take_histogram(const uint64_t *hist, uint32_t cols)
 {
-    grow_cycles(cols);
+    hold_columns(cols < MAX_SEQ_LINE_LENGTH ? cols + 1u : cols);      /* one untouched column behind the input: where a quality of 93 in the last column is counted */
     for (uint32_t c = 0; c < cols; ++c)
-        for (int k = 1; k < NUC_INDEX_SIZE; ++k) {
-            const uint64_t *h = hist + ((size_t)c * FXG_QS_CLASSES + (size_t)(k - 1)) * FXG_QS_BINS;
-            for (int b = 0; b < FXG_QS_BINS; ++b) {
-                if (!h[b]) continue;
-                const int v = b - 33;
-                struct nucleotide_data *d[2] = {&cycles[c][ALL], &cycles[c][k]};
-                for (int t = 0; t < 2; ++t) {
-                    if (v < d[t]->min) d[t]->min = v;
-                    if (v > d[t]->max) d[t]->max = v;
-                    d[t]->count += (int)h[b];
-                    d[t]->sum += (unsigned long long)((long long)v * (long long)h[b]);
-                    d[t]->bases_values_count[v - MIN_QUALITY_VALUE] += (int)h[b];
-                }
-            }
+        for (int cls = 1; cls < CLASSES; ++cls) {
+            const uint64_t *h = hist + ((size_t)c * FXG_QS_CLASSES + (size_t)(cls - 1)) * FXG_QS_BINS;
+            for (int byte = 0; byte < FXG_QS_BINS; ++byte)
+                if (h[byte]) tally(c, cls, byte - 33, (long long)h[byte]);
         }
 }
 
-static void read_fasta_on_host(void)     /* read_file :166-216 without qualities */
+/* FASTA: bases only (fastx_quality_stats.c:183-190), a record of `>id-count` standing for `count` reads */
+static void take_fasta(FASTX *fx)
 {
-    while (fastx_read_next_record(&fastx)) {
-        const size_t L = strlen(fastx.nucleotides);
-        grow_cycles(L);
-        const int reads_count = get_reads_count(&fastx);
+    static const char letters[] = "ACGTN";
+    while (fastx_read_next_record(fx)) {
+        const size_t L = strlen(fx->nucleotides);
+        const int weight = get_reads_count(fx);
+        hold_columns(L);
         for (size_t i = 0; i < L; ++i) {
-            cycles[i][ALL].count += reads_count;
-            cycles[i][nuc_to_index(fastx.nucleotides[i])].count += reads_count;
+            const char up = (char)(fx->nucleotides[i] & ~0x20);
+            const char *hit = up ? strchr(letters, up) : NULL;
+            image[record(i, 0) + F_BASES] += weight;
+            image[record(i, hit ? (int)(hit - letters) + 1 : 0) + F_BASES] += weight;
         }
     }
 }
 
-static int get_nth_value(size_t cycle, int nucleotide, int n)   /* :218-247 */
+/* quality of the base of rank n (0-based, ascending) of one record: the reference's walk over the image */
+static int ranked_quality(size_t column, int cls, int n)
 {
-    const struct nucleotide_data *d = &cycles[cycle][nucleotide];
-    if (n == 0) return d->min;
-    if (n < 0 || n >= d->count) {
-        fprintf(stderr, "Internal error at get_nth_value (cycle=%d, nucleotide=%d, n=%d), count_values[%d]=%d\n", (int)cycle, nucleotide, n, (int)cycle, d->count);
+    const size_t rec = record(column, cls);
+    const int bases = cell(rec + F_BASES);
+    if (n == 0) return cell(rec + F_LOW);
+    if (n < 0 || n >= bases) {
+        fprintf(stderr, "Internal error at get_nth_value (cycle=%d, nucleotide=%d, n=%d), count_values[%d]=%d\n", (int)column, cls, n, (int)column, bases);
         exit(1);
     }
-    /* the walk may leave this class' array (FASTA input: bases but no qualities) and run through its neighbours -- as in the reference,
-     * whose numbers it then reproduces -- but not past the end of `cycles`: there the reference reads whatever globals follow, this stops */
-    const int last = (int)(((const char *)cycles + sizeof cycles - (const char *)d->bases_values_count) / (ptrdiff_t)sizeof(int)) - 1;
-    int pos = 0;
+    const size_t first = rec + F_BIN0, last = image_records * REC - 1;
+    size_t at = first;
     while (n > 0) {
-        if (d->bases_values_count[pos] > n) break;
-        n -= d->bases_values_count[pos];
-        if (pos >= last) break;
-        pos++;
-        while (d->bases_values_count[pos] == 0 && pos < last) pos++;
+        const int here = cell(at);
+        if (here > n) break;
+        n -= here;
+        if (at >= last) break;
+        do ++at; while (cell(at) == 0 && at < last);
     }
-    return pos + MIN_QUALITY_VALUE;
+    return (int)(at - first) + MIN_QUALITY_VALUE;
 }
 
-static void box(size_t cycle, int nuc, int *Q1, int *Q3, int *IQR, int *lw, int *rw)   /* :276-291 */
+/* the eleven numbers the reports print for one record, in column_name[] order (mean apart: it is the one floating-point field) */
+struct summary { long long v[11]; double mean; };
+static struct summary summarise(size_t column, int cls)
 {
-    const struct nucleotide_data *d = &cycles[cycle][nuc];
-    *Q1 = get_nth_value(cycle, nuc, d->count / 4);
-    *Q3 = get_nth_value(cycle, nuc, d->count * 3 / 4);
-    *IQR = *Q3 - *Q1;
-    *lw = (*Q1 - *IQR * 3 / 2) < d->min ? d->min : (*Q1 - *IQR * 3 / 2);
-    *rw = (*Q3 + *IQR * 3 / 2) > d->max ? d->max : (*Q3 + *IQR * 3 / 2);
+    struct summary s;
+    const size_t rec = record(column, cls);
+    const int bases = cell(rec + F_BASES), low = cell(rec + F_LOW), high = cell(rec + F_HIGH);
+    const int q1 = ranked_quality(column, cls, bases / 4), med = ranked_quality(column, cls, bases / 2), q3 = ranked_quality(column, cls, bases * 3 / 4);
+    const int iqr = q3 - q1, reach = iqr * 3 / 2;
+    s.v[0] = bases; s.v[1] = low; s.v[2] = high; s.v[3] = quality_sum(rec); s.v[4] = 0;
+    s.v[5] = q1; s.v[6] = med; s.v[7] = q3; s.v[8] = iqr;
+    s.v[9] = q1 - reach < low ? low : q1 - reach;
+    s.v[10] = q3 + reach > high ? high : q3 + reach;
+    s.mean = (double)(unsigned long long)s.v[3] / (double)bases;      /* the reference's sum is unsigned: a negative total prints as 2^64 - |sum| here */
+    return s;
 }
-
-static void print_nucleotide_statistics(size_t cycle, int nuc)   /* :271-294 */
+static void print_summary(FILE *out, const struct summary *s)
 {
-    const struct nucleotide_data *d = &cycles[cycle][nuc];
-    int Q1, Q3, IQR, lw, rw;
-    box(cycle, nuc, &Q1, &Q3, &IQR, &lw, &rw);
-    fprintf(outfile, "\t%d\t%d\t%d\t%lld\t", d->count, d->min, d->max, (long long)d->sum);
-    fprintf(outfile, "%3.2f\t%d\t%d\t%d\t", ((double)d->sum) / ((double)d->count), Q1, get_nth_value(cycle, nuc, d->count / 2), Q3);
-    fprintf(outfile, "%d\t%d\t%d", IQR, lw, rw);
-}
-
-static void print_statistics(void)       /* :296-334 */
-{
-    static const char *headers[] = {"count", "min", "max", "sum", "mean", "Q1", "med", "Q3", "IQR", "lW", "rW"};
-    fprintf(outfile, "cycle\tmax_count");
-    for (int nuc = 0; nuc < NUC_INDEX_SIZE; ++nuc)
-        for (int h = 0; h < 11; ++h) fprintf(outfile, "\t%s_%s", nucleotide_index_name[nuc], headers[h]);
-    fprintf(outfile, "\n");
-    const int max_count = ncycles ? cycles[0][ALL].count : 0;
-    for (size_t cycle = 0; cycle < ncycles; ++cycle) {
-        if (cycles[cycle][ALL].count == 0) break;
-        fprintf(outfile, "%d\t%d", (int)cycle + 1, max_count);
-        for (int nuc = 0; nuc < NUC_INDEX_SIZE; ++nuc) print_nucleotide_statistics(cycle, nuc);
-        fprintf(outfile, "\n");
+    for (int f = 0; f < 11; ++f) {
+        if (f) fputc('\t', out);
+        if (f == 4) fprintf(out, "%3.2f", s->mean);
+        else fprintf(out, "%lld", s->v[f]);
     }
 }
 
-static void print_old_statistics(void)   /* :340-414 */
+/* one line per column up to the first column without bases.  Old format: the all-bases summary, the five class counts and the
+ * first column's count; -N: the first column's count, then the summary of every class */
+static void report(FILE *out, int per_class)
 {
-    fprintf(outfile, "column\t");
-    fprintf(outfile, "count\tmin\tmax\tsum\t");
-    fprintf(outfile, "mean\tQ1\tmed\tQ3\t");
-    fprintf(outfile, "IQR\tlW\trW\t");
-    fprintf(outfile, "A_Count\tC_Count\tG_Count\tT_Count\tN_Count\t");
-    fprintf(outfile, "Max_count\n");
-    for (size_t i = 0; i < ncycles; ++i) {
-        const struct nucleotide_data *d = &cycles[i][ALL];
-        if (d->count == 0) break;
-        int Q1, Q3, IQR, lw, rw;
-        box(i, ALL, &Q1, &Q3, &IQR, &lw, &rw);
-        fprintf(outfile, "%d\t", (int)i + 1);
-        fprintf(outfile, "%d\t%d\t%d\t%lld\t", d->count, d->min, d->max, (long long)d->sum);
-        fprintf(outfile, "%3.2f\t%d\t%d\t%d\t", ((double)d->sum) / ((double)d->count), Q1, get_nth_value(i, ALL, d->count / 2), Q3);
-        fprintf(outfile, "%d\t%d\t%d\t", IQR, lw, rw);
-        fprintf(outfile, "%d\t%d\t%d\t%d\t%d\t", cycles[i][1].count, cycles[i][2].count, cycles[i][3].count, cycles[i][4].count, cycles[i][5].count);
-        fprintf(outfile, "%d\n", cycles[0][ALL].count);
+    if (per_class) {
+        fputs("cycle\tmax_count", out);
+        for (int cls = 0; cls < CLASSES; ++cls)
+            for (int f = 0; f < 11; ++f) fprintf(out, "\t%s_%s", class_name[cls], column_name[f]);
+    } else {
+        fputs("column", out);
+        for (int f = 0; f < 11; ++f) fprintf(out, "\t%s", column_name[f]);
+        for (int cls = 1; cls < CLASSES; ++cls) fprintf(out, "\t%s_Count", class_name[cls]);
+        fputs("\tMax_count", out);
+    }
+    fputc('\n', out);
+    const int first_column_bases = cell(record(0, 0) + F_BASES);
+    for (size_t column = 0; column < MAX_SEQ_LINE_LENGTH && cell(record(column, 0) + F_BASES) != 0; ++column) {
+        fprintf(out, "%d", (int)column + 1);
+        if (per_class) fprintf(out, "\t%d", first_column_bases);
+        for (int cls = 0; cls < (per_class ? CLASSES : 1); ++cls) {
+            const struct summary s = summarise(column, cls);
+            fputc('\t', out);
+            print_summary(out, &s);
+        }
+        if (!per_class) {
+            for (int cls = 1; cls < CLASSES; ++cls) fprintf(out, "\t%d", cell(record(column, cls) + F_BASES));
+            fprintf(out, "\t%d", first_column_bases);
+        }
+        fputc('\n', out);
     }
 }
 
-static int parse_program_args(int optind_, int optc, char *optarg_)   /* :417-428 */
+static int want_per_class;
+static int option(int index, int letter, char *value)
 {
-    (void)optind_; (void)optarg_;
-    switch (optc) {
-    case 'N': new_output_format = 1; break;
-    default: errx(1, "fastx_quality_stats.c:%d: Unknown argument (%c)", __LINE__, optc);
-    }
+    (void)index; (void)value;
+    if (letter != 'N') errx(1, "fastx_quality_stats.c:%d: Unknown argument (%c)", __LINE__, letter);
+    want_per_class = 1;
     return 1;
 }
 
 int main(int argc, char *argv[])
 {
-    fastx_parse_cmdline(argc, argv, "N", parse_program_args);                       /* :432-447 */
-    init_values();
-    fastx_init_reader(&fastx, get_input_filename(), FASTA_OR_FASTQ, ALLOW_N, REQUIRE_UPPERCASE, get_fastq_ascii_quality_offset());
-    if (strcmp(get_output_filename(), "-") == 0) outfile = stdout;
-    else {
-        outfile = fopen(get_output_filename(), "w+");
-        if (outfile == NULL) err(1, "Failed to create output file (%s)", get_output_filename());
-    }
-    if (fastx.read_fastq) {
+    static FASTX fx;
+    fastx_parse_cmdline(argc, argv, "N", option);
+    fastx_init_reader(&fx, get_input_filename(), FASTA_OR_FASTQ, ALLOW_N, REQUIRE_UPPERCASE, get_fastq_ascii_quality_offset());
+    FILE *out = stdout;
+    if (strcmp(get_output_filename(), "-") != 0 && !(out = fopen(get_output_filename(), "w+")))
+        err(1, "Failed to create output file (%s)", get_output_filename());
+    if (fx.read_fastq) {
         uint64_t *hist = NULL;
         uint32_t cols = 0;
-        fxh_totals tot;
-        fxh_run_quality_stats(&fastx, &hist, &cols, &tot);
-        cycles_from_histogram(hist, cols);
+        fxh_totals totals;
+        fxh_run_quality_stats(&fx, &hist, &cols, &totals);
+        take_histogram(hist, cols);
         free(hist);
-    } else read_fasta_on_host();
-    if (new_output_format) print_statistics(); else print_old_statistics();
-    fflush(outfile);
+    } else take_fasta(&fx);
+    report(out, want_per_class);
+    fflush(out);
     return 0;
 }

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FXG_ABI_VERSION 3
+#define FXG_ABI_VERSION 4
 
 /* ---- error codes ---- */
 #define FXG_OK            0
@@ -323,6 +323,9 @@ int  fxg_epilogue_rccl(fxg_ctx *ctx, fxg_comm *comm, const uint64_t *d_counters,
  * that launch and returns its duration. */
 int  fxg_set_profiling(fxg_ctx *ctx, int enabled);
 int  fxg_last_kernel_ms(fxg_ctx *ctx, float *elapsed_ms);
+/* The durations of the last profiled launches (a ring of 64), oldest first, without disturbing launches that are still being
+ * enqueued back to back: a timed loop records its own launches and reads them all after its final synchronisation (bench.py). */
+int  fxg_profiled_kernel_ms(fxg_ctx *ctx, float *elapsed_ms, uint32_t cap, uint32_t *n);
 
 /* Name and launch geometry of the dominant kernel of the last fxg_run_pipeline (for profiling). */
 int  fxg_last_launch_info(const fxg_ctx *ctx, char *kernel_name, size_t cap, uint32_t *grid, uint32_t *block,

@@ -214,7 +214,7 @@ def test_sharded_run_and_the_three_stage_tool_on_the_gpu_build(tools, tmp_path):
     inp.write_bytes(text)
     ad = "AGATCGGAAGAGC"
     for argv, penv in ((["fastq_quality_trim_filter", "-t", "20", "-l", "30", "-q", "20", "-p", "80", "-v"], {}),
-                       (["fastx_clip_trim_filter", "-a", ad, "-l", "15", "-n", "-t", "20", "-m", "30", "-q", "20", "-p", "80", "-v"], {"FXH_CLIP_PARALLEL": "1"}),
+                       (["fastx_clip_trim_filter", "-a", ad, "-l", "15", "-n", "-t", "20", "-m", "30", "-q", "20", "-p", "80", "-v"], {}),       # fixed-length input: parallel by itself (round 4)
                        (["fastx_reverse_complement", "-v"], {})):
         single = tmp_path / "single.fq"
         want = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", str(single)], b"", dict(os.environ, **penv))
@@ -226,8 +226,7 @@ def test_sharded_run_and_the_three_stage_tool_on_the_gpu_build(tools, tmp_path):
             if not PARSE_ENV:
                 assert got[2].count(b"fxh timing part") == k, got[2][-400:]
             assert b"".join(open(pat.replace("%r", str(r)), "rb").read() for r in range(k)) == single.read_bytes(), (argv[0], k)
-    # (what a sharded run does with damaged input -- abandon the attempt, run as one stream -- is host logic and is tested where no GPU
-    #  is needed: tests/test_host_cli_emulated.py, tests/test_sanitizers.py)
+    # (what a sharded run does with damaged input -- abandon the attempt, run as one stream: the last test of this file, on the real runtime)
     if REF:                                                               # config 5 as the reference runs it: three processes in a pipe
         small = text[:3_000_000]
         small = small[:small.rindex(b"\n@") + 1]
@@ -274,3 +273,76 @@ def test_output_longer_than_input_and_ragged_blocks(tools):
     assert rc == 0 and out.count(b"\n") == 4 * 100001
     if REF:
         assert out == _run([REF, "fastx_reverse_complement"], data)[1]
+
+
+@pytest.mark.skipif(REF is None, reason="oracle/_ref/fxref not built")
+def test_clipper_default_command_line_on_ragged_input(tools, tmp_path):
+    """fastx_clipper with no environment variable on the real engine: parallel lanes while the reads have one length, the reference's one
+    aligner (seeded with the last record before) from the first block that differs -- byte-identical to the real libfastx clipper when
+    the ragged reads start at 0 %, 50 %, 99 % of the input or never."""
+    rng = np.random.default_rng(78)
+    ad = "AGATCGGAAGAGC"
+    lines = fo.synth_fastq(62, 0, 60000, 150, True).split(b"\n")
+    recs = [b"\n".join(lines[4 * i:4 * i + 4]) + b"\n" for i in range(60000)]
+
+    def ragged(rec):
+        L = int(rng.integers(20, 150))
+        l = rec.split(b"\n")
+        return b"\n".join([l[0], l[1][:L], l[2], l[3][:L]]) + b"\n"
+    for name, start in (("never", None), ("at_0", 0.0), ("at_50", 0.5), ("at_99", 0.99)):
+        k = len(recs) if start is None else int(len(recs) * start)
+        data = b"".join(recs[:k]) + b"".join(ragged(r) if rng.random() < 0.5 else r for r in recs[k:])
+        ref = _run([REF, "fastx_clipper", "-a", ad, "-l", "15", "-v"], data)
+        for env in ({"FXH_READ_BUFFER_MB": "2"}, {"FXH_READ_BUFFER_MB": "2", "FXH_LANES": "3"}):
+            got = _run([os.path.join(tools, "fastx_clipper"), "-a", ad, "-l", "15", "-v"], data, dict(os.environ, FXH_TIMING="1", **env))
+            assert (got[0], got[1]) == (0, ref[1]), (name, env, got[2][-400:])
+            if not PARSE_ENV:
+                assert (b"one aligner with history from there on" in got[2]) == (name != "never"), (name, got[2][-400:])
+
+
+@pytest.mark.skipif(REF is None, reason="oracle/_ref/fxref not built")
+def test_sharded_run_abandoned_on_the_real_runtime(tools, tmp_path):
+    """LAST in this file on purpose.  FXH_PARTS=4 over input the device path does not take: the sharded attempt (a forked child with four
+    parts, each with its own contexts, streams and page-locked buffers on the real HIP runtime) is abandoned -- every thread joined, every
+    context destroyed, the parts emptied, _exit(99) -- and the parent, which has not touched the GPU, runs the input as one stream:
+    exit code, message, -v report and partial output are the reference's.  (The first version of this, in round 3, re-exec'd the
+    process with device work in flight and took two GPU boxes down; it has only ever run against the emulation stub since.)"""
+    if PARSE_ENV:
+        pytest.skip("the sharded run is the device-parse path")
+    text = fo.synth_fastq(47, 0, 1_200_000, 100, False)                  # ~280 MB, 1.2 M reads
+    k0 = text.index(b"\n@", int(len(text) * 0.4)) + 1                    # inside part 1 of 0..3 ("part 2 of 4")
+    cases = {"damaged_record": text[:k0] + b"#" + text[k0 + 1:], "ragged_end": text[:-150],
+             "ragged_clipper_input": None}
+    argv = ["fastq_quality_trim_filter", "-t", "20", "-l", "30", "-q", "20", "-p", "80", "-v"]
+    inp = tmp_path / "in.fq"
+    for name in ("damaged_record", "ragged_end"):
+        inp.write_bytes(cases[name])
+        ref1 = _run([REF, "fastq_quality_trimmer", "-t", "20", "-l", "30"], cases[name])
+        ref2 = _run([REF, "fastq_quality_filter", "-q", "20", "-p", "80"], ref1[1])          # what the reference leaves behind before it fails
+        pat = str(tmp_path / (name + ".%r.fq"))
+        p = subprocess.run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", pat], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, FXH_PARTS="4", FXH_TIMING="1"), timeout=120)
+        assert p.returncode == 1 == ref1[0], p.stderr[-600:]
+        assert b"fxh parts: abandoned, contexts destroyed, parts emptied" in p.stderr
+        assert _msg(p.stderr.split(b"fxh parts: abandoned, contexts destroyed, parts emptied\n")[-1]) == _msg(ref1[2]), (p.stderr[-400:], ref1[2])
+        out = b"".join(open(pat.replace("%r", str(r)), "rb").read() for r in range(4))
+        assert out == ref2[1], (name, len(out), len(ref2[1]))               # everything before the bad record, nothing after it
+        assert all(os.path.getsize(pat.replace("%r", str(r))) == 0 for r in (1, 2, 3))
+    # a clipper run whose reads stop being of one length inside part 2: the attempt is abandoned, the one-stream run goes serial where it must
+    head = text[:60_000_000]
+    lines = head[:head.rindex(b"\n@")].split(b"\n")                      # whole records (the generator's quality lines never start with '@')
+    assert len(lines) % 4 == 0
+    cut = len(lines) // 8 * 4
+    for i in range(cut, len(lines), 8):
+        lines[i + 1] = lines[i + 1][:61]; lines[i + 3] = lines[i + 3][:61]
+    data = b"\n".join(lines) + b"\n"
+    inp.write_bytes(data)
+    ad = "AGATCGGAAGAGC"
+    ref = _run([REF, "fastx_clipper", "-a", ad, "-l", "15", "-v"], data)
+    pat = str(tmp_path / "clip.%r.fq")
+    p = subprocess.run([os.path.join(tools, "fastx_clipper"), "-a", ad, "-l", "15", "-v", "-i", str(inp), "-o", pat], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, FXH_PARTS="4", FXH_TIMING="1"), timeout=120)
+    assert p.returncode == 0 and b"fxh parts: abandoned" in p.stderr and b"one aligner with history from there on" in p.stderr, p.stderr[-600:]
+    assert p.stdout == ref[2]                                             # the -v report (on stdout when -o names a file) is the reference's
+    assert b"".join(open(pat.replace("%r", str(r)), "rb").read() for r in range(4)) == ref[1]
+

@@ -353,6 +353,15 @@ def test_bench_two_ranks_on_one_gpu_via_gloo():
     assert d["config"]["reads_per_gpu"] == 2000000
     er = d["e2e_ranks"]                                          # one tool chain per rank on its own shard, barrier to barrier
     assert er["ranks"] == 2 and er["reads_per_rank"] == 500000 and 0 < er["kept_reads"] < 1000000 and er["mreads_s"] > 0, er
+    # the same million reads through ONE rank: the job's kept reads and the md5 of its output (the ranks' outputs in rank order) must not
+    # depend on how many ranks shared the work
+    cmd1 = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--reads", "2000000", "--e2e", "--e2e-reads", "1000000",
+            "--no-cpu-baseline", "--no-e2e"]
+    p1 = subprocess.run(cmd1, env=dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    e1 = json.loads([l for l in p1.stdout.decode().splitlines() if l.startswith("{")][-1])["e2e_ranks"]
+    assert e1["ranks"] == 1 and e1["reads_per_rank"] == 1000000
+    assert (er["kept_reads"], er["output_bytes"], er["output_md5"]) == (e1["kept_reads"], e1["output_bytes"], e1["output_md5"]) and er["output_md5"], (er, e1)
 
 
 @pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg5"])
