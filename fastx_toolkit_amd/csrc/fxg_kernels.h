@@ -1033,7 +1033,11 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
         if (cur < a.ntiles) {
             // The next ticket is in flight while this tile is decided.  (Holding a ticket is only harmless because nothing in
             // this step waits for a tile later than `pend`: a one-slot variant that gathered `cur` itself serialised the chip.)
-            if (tid == 0) s_ticket[tk ^ 1u] = atomicAdd(my_ticket, 1u);
+            // Clip instances draw it only AFTER this tile's decision (below): a ticket held through a 50-microsecond DP means its tile is decided a
+            // whole step later than the tickets other workgroups drew right after it, and every later tile's place in the output waits for
+            // it (cfg3 14.4 -> 13.8 ms, cfg5 -1.5 %, profiles/r04/l_ticket_timing.txt; the streaming instances lose 1 % that way and keep the early draw)
+            constexpr bool TICKET_AFTER_DECISION = (MODE == 0 && AMAX != 0);
+            if (!TICKET_AFTER_DECISION && tid == 0) s_ticket[tk ^ 1u] = atomicAdd(my_ticket, 1u);
             const u32 r0 = cur * T;
             const u64 left = a.n - (u64)r0;
             const u32 nreads = left < (u64)T ? (u32)left : T;
@@ -1060,6 +1064,7 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
             // the -v report counters (a12) are functions of res[]: tally the drop reasons this instance can produce, per wave, as the
             // words go by (popcount of a ballot; one LDS add per wave and reason that occurred) instead of a second pass over res[]
             FXG_TPHASE(1);
+            if (TICKET_AFTER_DECISION && tid == 0) s_ticket[tk ^ 1u] = atomicAdd(my_ticket, 1u);
             fxg_tile_tally<AMAX, MODE>(word, tid < nreads, tally);
             u32 exc, exb, totc, totb;
             fxg_block_scan2<(int)TW>(keep, keep ? olen : 0u, scratch, &exc, &exb, &totc, &totb);   // one __syncthreads inside

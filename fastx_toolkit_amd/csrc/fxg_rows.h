@@ -365,7 +365,9 @@ __global__ __launch_bounds__(64, FXG_ROWS_LB) void fxg_kernel_rows(const FxgKArg
             const u32 totc = tot >> 16;
             c_totb = tot & 0xFFFFu;
             c_exc = (inc - mine) >> 16;
-            c_info = ((keep && (H == 1 || olen)) ? 1u << 31 : 0u) | (olen << 16) | ((inc - mine) & 0xFFFFu);      // "keep" of a piece: it has bytes to write
+            // "keep" of a piece: it has bytes to write -- and the FIRST piece of a kept read always carries it, bytes or not: it writes the read's
+            // metadata (a read of length 0 is kept by the filter alone; an empty piece packs nothing and sends the tile down the predicated path)
+            c_info = ((keep && (H == 1 || hf == 0u || olen)) ? 1u << 31 : 0u) | (olen << 16) | ((inc - mine) & 0xFFFFu);
             if (lane == 0) fxg_publish_total(a, cur, totc, c_totb);
             t_in += nreads; t_kept += totc; t_bases += c_totb;
             FXG_PHASE(1);

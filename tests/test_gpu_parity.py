@@ -7,7 +7,7 @@ size-independent properties (prefix/suffix windows vs the oracle, offset algebra
 import numpy as np
 import pytest
 
-from helpers import adversarial_clip_cases, assert_same, fuzz_cases, md5, oracle_params
+from helpers import adversarial_clip_cases, assert_same, fuzz_cases, md5, oracle_params, random_batch
 from oracle import fxoracle_py as fo
 
 pytestmark = pytest.mark.gpu
@@ -185,6 +185,30 @@ def test_quality_kernels_random_shapes(engine, monkeypatch):
             assert_same(o, got["1"], "trial %d vs oracle" % trial)
         kept += int(got["1"]["counters"][1])
     assert kept > 10000
+
+
+def test_rows_kernel_keeps_empty_reads_with_their_metadata(engine, monkeypatch):
+    """fxg_kernel_rows with two lanes per read (rows of 153..304 bytes): a kept read of length 0 (only the C / Python API can send one: the
+    reference's reader refuses an empty sequence, so the oracle has no opinion) must get its kept_index / out_len / out_off entries like
+    in the one-lane form and in fxg_kernel_tiles -- its first piece has no bytes to write but speaks for the read (advisor finding, round 3)."""
+    rng = np.random.default_rng(19)
+    for stride in (153, 200, 304, 150):
+        b, q, lens = random_batch(rng, 700, stride, 1, stride, False)
+        lens[rng.random(700) < 0.2] = 0
+        lens[:3] = 0; lens[-1] = 0
+        for pd in (dict(stages=4, qf_min_quality=20, qf_min_percent=50), dict(stages=6, qt_threshold=15, qt_min_len=0, qf_min_quality=10, qf_min_percent=0)):
+            monkeypatch.setenv("FXG_ROWS", "2")
+            e = _run(engine, b, q, lens, pd)
+            assert "fxg_kernel_rows" in engine.last_launch()["kernel"], engine.last_launch()
+            monkeypatch.setenv("FXG_ROWS", "0")
+            t = _run(engine, b, q, lens, pd)
+            assert "fxg_kernel_tiles" in engine.last_launch()["kernel"]
+            kept = int(e["counters"][1])
+            assert kept == int(t["counters"][1]) and int(((e["res"] >> 16) & 1)[lens == 0].sum()) > 0          # empty reads are among the kept ones
+            for k in ("res", "out_bases", "out_qual", "out_len", "kept_index", "out_off"):
+                assert np.array_equal(e[k], t[k]), (stride, pd["stages"], k)
+            assert np.array_equal(e["kept_index"], np.nonzero((e["res"] >> 16) & 1)[0].astype(np.uint32))
+    monkeypatch.delenv("FXG_ROWS")
 
 
 def test_decision_only_fasta_and_tool_entry_points(engine):
