@@ -32,7 +32,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define FXG_CLIP_GATHER_K 4     // chunks per lane in flight in the clip instances' gather (FXG_GATHER_K for the streaming instances)
 #endif
 #ifndef FXG_CLIP_DEPTH
-#define FXG_CLIP_DEPTH 3u       // slots of the clip instances (FxgTileDepth in fxg_kernels.h)
+#define FXG_CLIP_DEPTH 4u       // slots of the clip instances at most (fxg_plan.h takes the deepest pipeline that does not cost a workgroup per CU: cfg3 four, cfg5 three)
 #endif
 #define FXG_CK_SLOTS 7u         // checkpoints a read can leave (fxg_plan.h picks the interval so that they suffice)
 #ifndef FXG_CLIP_TBLOCK

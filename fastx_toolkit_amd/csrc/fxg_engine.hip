@@ -783,6 +783,16 @@ extern "C" int fxg_device_count(void)
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 
+extern "C" int fxg_concat_peer(fxg_ctx *dst, void *d_dst, uint64_t byte_off, fxg_ctx *src, const void *d_src, uint64_t bytes)
+{
+    if (!dst || !src || (!d_dst && bytes) || (!d_src && bytes)) return FXG_E_INVALID;
+    if (!bytes) return FXG_OK;
+    FXG_HIP(src, hipSetDevice(src->device));
+    if (dst->device == src->device) FXG_HIP(src, hipMemcpyAsync((char *)d_dst + byte_off, d_src, bytes, hipMemcpyDeviceToDevice, src->stream));
+    else FXG_HIP(src, hipMemcpyPeerAsync((char *)d_dst + byte_off, dst->device, d_src, src->device, bytes, src->stream));
+    return FXG_OK;
+}
+
 // the multi-GPU host code (shard ranges, epilogue, concatenation, RCCL transport) is fxg_comm.h: it reaches device memory through
 // these hooks only, so that the CPU tier compiles the very same code over host memory (tests/emu/fxg_stub.cpp)
 #define FXG_COMM_FAIL(c, code, ...) fxg_fail(c, code, __VA_ARGS__)

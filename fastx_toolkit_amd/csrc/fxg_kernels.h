@@ -995,9 +995,9 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
     u32 *bm_g = reinterpret_cast<u32 *>(smem + L.off_bm_g);
     u32 *bm_l = reinterpret_cast<u32 *>(smem + L.off_bm_l);
     uint8_t *sb = smem + L.off_bases;
-    u32 *scratch = reinterpret_cast<u32 *>(smem + L.off_scratch);   // [0,2W) scan, then 2 words of tile totals per slot (<= 3 slots), 2 tickets
-    u32 *s_tot = scratch + 2 * TW, *s_ticket = s_tot + 6;
-    u64 *bc = reinterpret_cast<u64 *>(s_tot + 8);                   // [0,2) broadcast of the resolved bases
+    u32 *scratch = reinterpret_cast<u32 *>(smem + L.off_scratch);   // [0,2W) scan, then 2 words of tile totals per slot (<= 4 slots), 2 tickets, the broadcast pair
+    u32 *s_tot = scratch + 2 * TW, *s_ticket = s_tot + 8;          // two words of tile totals per slot (<= 4 slots), two tickets
+    u64 *bc = reinterpret_cast<u64 *>(s_tot + 10);                   // [0,2) broadcast of the resolved bases
     u64 *tally = reinterpret_cast<u64 *>(smem + L.off_tally);       // this workgroup's share of the -v report counters
     if (tid < FXG_NTALLY) tally[tid] = 0ull;
 #ifdef FXG_ABLATION
@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
     if (tid == 0) s_ticket[0] = atomicAdd(my_ticket, 1u);
     __syncthreads();
     u32 cur = s_ticket[0] * G + grp;
-    u32 pend = FXG_NO_TILE, mid = FXG_NO_TILE;            // pend: written out in this step; mid (three slots): decided last step, written out next step
+    u32 pend = FXG_NO_TILE, mid = FXG_NO_TILE, mid2 = FXG_NO_TILE;      // pend: written out in this step; mid / mid2 (three / four slots): decided one / two steps ago, written out later
     u32 slot = 0, tk = 0;
     for (;;) {
         u64 peek = 0;                                    // first look at the prefix of `pend`, in flight during stage A
@@ -1109,10 +1109,10 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
             }
             FXG_TPHASE(4);
         }
-        if (cur >= a.ntiles && (NSLOT == 2u || mid == FXG_NO_TILE)) break;
+        if (cur >= a.ntiles && (NSLOT == 2u || (mid == FXG_NO_TILE && mid2 == FXG_NO_TILE))) break;
         __syncthreads();            // ticket written by thread 0 in stage A; also fences slot reuse NSLOT iterations apart
         const u32 done = cur < a.ntiles ? cur : FXG_NO_TILE;
-        if (NSLOT == 3u) { pend = mid; mid = done; } else pend = done;
+        if (NSLOT == 4u) { pend = mid; mid = mid2; mid2 = done; } else if (NSLOT == 3u) { pend = mid; mid = done; } else pend = done;
         if (cur < a.ntiles) { tk ^= 1u; cur = s_ticket[tk] * G + grp; }
         slot = slot + 1u == NSLOT ? 0u : slot + 1u;
     }

@@ -152,13 +152,20 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     ka.tile_reads = T; ka.ntiles = (u32)ntiles;
     // clip instances: the write-out runs two steps behind the decision (three slots) unless the extra slot costs a workgroup per CU
     ka.depth = 2u;
-    if (pl->clip && FXG_CLIP_DEPTH == 3u) {
-        const u32 cu_lds = 160u * 1024u, regs_wg = pl->block == 64u ? 16u : 4u;      // workgroups per CU the registers allow (128 VGPRs)
+    if (pl->clip && FXG_CLIP_DEPTH >= 3u) {
+        // (156 KB: three workgroups of 53.9 KB -- 161.6 KB, nominally inside the CU's 160 KB = 163 840 bytes -- ran as TWO per CU: cfg5 9.7 against 7.7 ms, profiles/r04/m_clip_depth.txt)
+        const u32 cu_lds = 156u * 1024u, regs_wg = pl->block == 64u ? 16u : 4u;      // workgroups per CU the registers allow (128 VGPRs)
         const u32 lds2 = fxg_plan_lds(pl);
-        ka.depth = 3u;
-        const u32 lds3 = fxg_plan_lds(pl);
-        const u32 wg2 = cu_lds / lds2 < regs_wg ? cu_lds / lds2 : regs_wg, wg3 = cu_lds / lds3 < regs_wg ? cu_lds / lds3 : regs_wg;
-        if (wg3 < wg2) ka.depth = 2u;
+        const u32 wg2 = cu_lds / lds2 < regs_wg ? cu_lds / lds2 : regs_wg;
+        u32 want = FXG_CLIP_DEPTH;
+        { const char *e = getenv("FXG_CLIP_DEPTH_RT"); if (e && atoi(e) >= 2 && atoi(e) <= 4) want = (u32)atoi(e); }      // tuning knob
+        for (u32 d = want; d >= 3u; --d) {           // the deepest pipeline that does not cost a workgroup per CU
+            ka.depth = d;
+            const u32 ldsd = fxg_plan_lds(pl);
+            if ((cu_lds / ldsd < regs_wg ? cu_lds / ldsd : regs_wg) >= wg2) break;
+            ka.depth = 2u;
+        }
+        if (want == 2u) ka.depth = 2u;
     }
     pl->lds = pl->rows_nw ? fxg_rows_lds(ka.stride, (u32)pl->rows_h) : fxg_plan_lds(pl);
     return FXG_OK;

@@ -25,7 +25,7 @@ EXPORTS = [
     "fxg_run_qtrim_qfilter", "fxg_run_clip", "fxg_run_revcomp_trim", "fxg_read_counters", "fxg_synth_generate",
     "fxg_last_launch_info", "fxg_set_profiling", "fxg_last_kernel_ms", "fxg_profiled_kernel_ms", "fxg_set_clip_history", "fxg_run_quality_stats",
     "fxg_fastq_index", "fxg_fastq_pack", "fxg_fastq_format", "fxg_fasta_weights", "fxg_host_register", "fxg_host_unregister",
-    "fxg_shard_range", "fxg_epilogue", "fxg_concat_pwrite", "fxg_device_count", "fxg_device_numa_node", "fxg_comm_create", "fxg_comm_destroy", "fxg_epilogue_rccl",
+    "fxg_shard_range", "fxg_epilogue", "fxg_concat_pwrite", "fxg_concat_peer", "fxg_device_count", "fxg_device_numa_node", "fxg_comm_create", "fxg_comm_destroy", "fxg_epilogue_rccl",
 ]
 
 
@@ -124,6 +124,7 @@ def load_library(path=None):
     L.fxg_shard_range.argtypes = [u64, u32, u32, C.POINTER(u64), C.POINTER(u64)]
     L.fxg_epilogue.argtypes = [vp, u32, u32, vp, C.POINTER(u64), C.POINTER(u64)]
     L.fxg_concat_pwrite.argtypes = [i32, vp, u64, u64]
+    L.fxg_concat_peer.argtypes = [vp, vp, u64, vp, vp, u64]
     L.fxg_comm_create.argtypes = [vp, C.c_char_p, u32, u32, i32, C.POINTER(vp)]
     L.fxg_comm_destroy.argtypes = [vp]; L.fxg_comm_destroy.restype = None
     L.fxg_epilogue_rccl.argtypes = [vp, vp, vp, vp, C.POINTER(u64), C.POINTER(u64), vp]

@@ -1425,7 +1425,7 @@ static void fxh_clip_go_serial(fxh_run *R, fxh_lane *lanes, int nlanes, fxh_bloc
         fxh_block *b = &blk[j % (size_t)NB];
         if (b->lane >= 0) { b->lane = 0; b->posted = 0; }
     }
-    if (getenv("FXH_TIMING")) fprintf(stderr, "fxh clipper: reads of one length (%u) up to block %zu; one aligner with history from there on\n", R->clip_len, first);
+    if (getenv("FXH_TIMING")) fprintf(stderr, "fxh timing clipper: reads of one length (%u) up to block %zu; one aligner with history from there on\n", R->clip_len, first);
 }
 
 /* The lanes loop.  Returns when the input is exhausted or an error is pending in R. */
@@ -1774,7 +1774,7 @@ static int fxh_run_parts(FASTX *fx, const fxg_params *p, fxh_totals *tot, int k)
          * writers' flush-at-exit, the runtime's) gets to run.  The parent then runs the input as one stream (see the fork above). */
         for (int r = 1; r < k; ++r) { struct fxh_writer *w = pt[r].fx->writer; w->len = 0; if (ftruncate(w->fd, 0) != 0) warn("%s", pt[r].name); close(w->fd); w->fd = -1; }
         { struct fxh_writer *w = fx->writer; w->len = 0; if (ftruncate(w->fd, 0) != 0 || lseek(w->fd, 0, SEEK_SET) < 0) warn("%s", pt[0].name); }
-        if (getenv("FXH_TIMING")) fprintf(stderr, "fxh parts: abandoned, contexts destroyed, parts emptied\n");
+        if (getenv("FXH_TIMING")) fprintf(stderr, "fxh timing parts: abandoned, contexts destroyed, parts emptied\n");
         fflush(NULL);
         _exit(FXH_EXIT_ABANDON);
     }

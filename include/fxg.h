@@ -302,6 +302,11 @@ int  fxg_epilogue(const uint64_t *gathered, uint32_t world, uint32_t rank, uint6
 /* The concatenation: write this shard's `bytes` bytes of packed output (host memory) at `offset` of the open file `fd`
  * (pwrite until done; shards may write concurrently, in any order). */
 int  fxg_concat_pwrite(int fd, const void *host_buf, uint64_t bytes, uint64_t offset);
+/* The concatenation kept on the devices (one process driving several GPUs): copy this shard's `bytes` bytes of packed
+ * output from `d_src` (memory of context `src`) to `d_dst + byte_off` (memory of context `dst`, the job's assembled output) -- over xGMI
+ * when the contexts sit on different GPUs (hipMemcpyPeerAsync on `src`'s stream, behind the pass that produced the slice).  The caller
+ * waits for every source context (fxg_sync) before it reads the assembled output. */
+int  fxg_concat_peer(fxg_ctx *dst, void *d_dst, uint64_t byte_off, fxg_ctx *src, const void *d_src, uint64_t bytes);
 
 /* The exchange itself for a C host, one process per GPU: the counter blocks travel by ONE RCCL all-gather (192 bytes per rank, over
  * xGMI inside a node) -- SURVEY 8e's ncclAllReduce + ncclAllGather folded into one collective, since the gathered blocks give both the

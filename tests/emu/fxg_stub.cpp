@@ -80,6 +80,7 @@ int fxg_fastq_format(fxg_ctx *, const uint8_t *t, int lpr, const uint32_t *line,
 int fxg_fasta_weights(fxg_ctx *, const uint8_t *t, const uint32_t *line, uint64_t cap, uint64_t n, const uint32_t *res, uint64_t *w) { return fxg_emu_fasta_weights(t, line, cap, n, res, w); }
 int fxg_device_count(void) { return emu_device_count(); }
 int fxg_device_numa_node(int device) { (void)device; const char *e = getenv("FXG_EMU_NUMA_NODE"); return e ? atoi(e) : -1; }   /* no GPU, no node; the env lets a test walk the binding code */
+int fxg_concat_peer(fxg_ctx *dst, void *d, uint64_t off, fxg_ctx *src, const void *s, uint64_t n) { if (!dst || !src) return FXG_E_INVALID; if (n) memcpy((char *)d + off, s, n); return 0; }
 int fxg_host_register(fxg_ctx *, void *, size_t) { return 0; }
 int fxg_host_unregister(fxg_ctx *, void *) { return 0; }
 int fxg_set_profiling(fxg_ctx *, int) { return 0; }

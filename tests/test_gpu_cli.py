@@ -323,8 +323,8 @@ def test_sharded_run_abandoned_on_the_real_runtime(tools, tmp_path):
         p = subprocess.run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", pat], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                            env=dict(os.environ, FXH_PARTS="4", FXH_TIMING="1"), timeout=120)
         assert p.returncode == 1 == ref1[0], p.stderr[-600:]
-        assert b"fxh parts: abandoned, contexts destroyed, parts emptied" in p.stderr
-        assert _msg(p.stderr.split(b"fxh parts: abandoned, contexts destroyed, parts emptied\n")[-1]) == _msg(ref1[2]), (p.stderr[-400:], ref1[2])
+        assert b"fxh timing parts: abandoned, contexts destroyed, parts emptied" in p.stderr
+        assert _msg(p.stderr.split(b"fxh timing parts: abandoned, contexts destroyed, parts emptied\n")[-1]) == _msg(ref1[2]), (p.stderr[-400:], ref1[2])
         out = b"".join(open(pat.replace("%r", str(r)), "rb").read() for r in range(4))
         assert out == ref2[1], (name, len(out), len(ref2[1]))               # everything before the bad record, nothing after it
         assert all(os.path.getsize(pat.replace("%r", str(r))) == 0 for r in (1, 2, 3))
@@ -342,7 +342,7 @@ def test_sharded_run_abandoned_on_the_real_runtime(tools, tmp_path):
     pat = str(tmp_path / "clip.%r.fq")
     p = subprocess.run([os.path.join(tools, "fastx_clipper"), "-a", ad, "-l", "15", "-v", "-i", str(inp), "-o", pat], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        env=dict(os.environ, FXH_PARTS="4", FXH_TIMING="1"), timeout=120)
-    assert p.returncode == 0 and b"fxh parts: abandoned" in p.stderr and b"one aligner with history from there on" in p.stderr, p.stderr[-600:]
+    assert p.returncode == 0 and b"fxh timing parts: abandoned" in p.stderr and b"one aligner with history from there on" in p.stderr, p.stderr[-600:]
     assert p.stdout == ref[2]                                             # the -v report (on stdout when -o names a file) is the reference's
     assert b"".join(open(pat.replace("%r", str(r)), "rb").read() for r in range(4)) == ref[1]
 

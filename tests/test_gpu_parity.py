@@ -204,7 +204,7 @@ def test_rows_kernel_keeps_empty_reads_with_their_metadata(engine, monkeypatch):
             t = _run(engine, b, q, lens, pd)
             assert "fxg_kernel_tiles" in engine.last_launch()["kernel"]
             kept = int(e["counters"][1])
-            assert kept == int(t["counters"][1]) and int(((e["res"] >> 16) & 1)[lens == 0].sum()) > 0          # empty reads are among the kept ones
+            assert kept == int(t["counters"][1]) and (pd["stages"] != 4 or int(((e["res"] >> 16) & 1)[lens == 0].sum()) > 0)   # filter alone: empty reads are among the kept ones (the trimmer drops them)
             for k in ("res", "out_bases", "out_qual", "out_len", "kept_index", "out_off"):
                 assert np.array_equal(e[k], t[k]), (stride, pd["stages"], k)
             assert np.array_equal(e["kept_index"], np.nonzero((e["res"] >> 16) & 1)[0].astype(np.uint32))
@@ -431,7 +431,32 @@ def test_engine_shards_reassemble_to_the_whole_run(engine, cfg):
             ooff[ro.value:ro.value + nk] = r["out_off"] + np.uint64(bo.value)
         for name, got in (("out_bases", ob), ("out_qual", oq), ("kept_index", kept), ("out_len", olen), ("out_off", ooff)):
             assert np.array_equal(got, whole[name]), (cfg, world, name)
-    del b, q
+    # the concatenation kept on the device (fxg_concat_peer): two contexts (on this box: one GPU), each runs its shard on its own stream and
+    # copies its packed slices into the job's output at the offsets of fxg_epilogue; the assembled arrays are the one-shard run's
+    import torch
+    from fastx_toolkit_amd import Engine
+    other = Engine(0)
+    total = len(whole["out_bases"])
+    d_bases, d_qual = torch.zeros(total + 16, dtype=torch.uint8, device=engine.device), torch.zeros(total + 16, dtype=torch.uint8, device=engine.device)
+    engs, runs, blocks = (engine, other), [], np.zeros((2, 24), dtype=np.uint64)
+    for g in range(2):
+        lo, hi = fxd.shard_range(N, g, 2)
+        sb, sq = engs[g].synth(seed, lo, hi - lo, L, with_ad)
+        r = engs[g].run(sb, sq, _engine_params(pd), fixed_len=L)
+        blocks[g] = r.counters
+        runs.append((r, sb, sq))
+    for g in range(2):
+        bo = C.c_uint64()
+        assert engine.lib.fxg_epilogue(blocks.ctypes.data, 2, g, None, None, C.byref(bo)) == 0
+        r = runs[g][0]
+        engs[g]._after_torch()
+        for src, dst in ((r.out_bases, d_bases), (r.out_qual, d_qual)):
+            assert engine.lib.fxg_concat_peer(engine.ctx, dst.data_ptr(), bo.value, engs[g].ctx, src.data_ptr(), int(blocks[g][2])) == 0
+        engs[g].sync()
+    torch.cuda.synchronize()
+    assert np.array_equal(d_bases[:total].cpu().numpy(), whole["out_bases"]) and np.array_equal(d_qual[:total].cpu().numpy(), whole["out_qual"]), cfg
+    other.close()
+    del b, q, runs
 
 
 def test_rccl_epilogue_through_the_c_abi(engine, tmp_path):
