@@ -55,6 +55,28 @@ __host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, u32 bitmaps,
 FXG_HD u32 fxg_bitmap_count(const FxgKArgs &a, bool use_q, bool clip) { return !use_q ? 0u : (clip && a.tq == a.fq) ? 1u : 2u; }
 
 // ------------------------------------------------------------------------------------------------
+// No lane-divergent loops in the DP.  A loop whose trip count differs between the lanes of a wave is left when EXEC = 0, and ROCm 7.2's
+// register allocator may put the spill stores / copies of the loop's live-out values into the exit block AHEAD of the instruction that
+// brings the lanes back -- where they do nothing (how clip instances came out wrong on the GPU only, for some
+// register budgets and not for others).  The DP's loops are the register-hungry ones, so they all run a WAVE-UNIFORM number of trips
+// (the maximum over the wave's active lanes, fxg_wave_max) with the row predicated per lane: the loop branch is scalar, EXEC never
+// becomes zero at a loop exit, and a lane idles exactly as long as it did in the divergent form.  The ISA check of the build
+// (scripts/check_exec_zero.py) stays as the net under this.
+// ------------------------------------------------------------------------------------------------
+#ifdef FXG_HOST_EMULATION
+FXG_HD int fxg_wave_max(int n) { return n; }
+#else
+// maximum of n >= 0 over the active lanes, as a scalar (ds_bpermute reads 0 from a lane that is not active)
+__device__ __forceinline__ int fxg_wave_max(int n)
+{
+    int v = n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+    return __builtin_amdgcn_readfirstlane(v);
+}
+#endif
+
+// ------------------------------------------------------------------------------------------------
 // fastx_clipper for one read: semi-global fp32 DP of read (query) x adapter (target) with the
 // alignment path summary carried forward instead of a traceback matrix.
 // Reference: sequence_alignment.cpp:340-428 (borders, cell rule, first-max), :496-604 (traceback
@@ -91,7 +113,7 @@ FXG_HD void fxg_clip_finish(const FxgKArgs &a, int len, int qs, int ts, int mism
 // Every select is written as a ternary on values (no control flow) so that the cell is ~30 straight VALU ops.
 template <int AMAX>
 FXG_HD void fxg_clip_read(const FxgKArgs &a, const uint8_t *rd, int len, int rows,
-                          u32 *out_len, u32 *keep, u32 *reason, u32 *clipped, u32 *adapter_only)
+                          u32 *out_len, u32 *keep, u32 *reason, u32 *clipped, u32 *adapter_only, const bool UR = false)      // UR: `rows` is the same in every lane
 {
     float S[AMAX];
     u32 W0[AMAX], W1[AMAX];
@@ -104,8 +126,10 @@ FXG_HD void fxg_clip_read(const FxgKArgs &a, const uint8_t *rd, int len, int row
     float best = -1000000.0f;
     u32 bw0 = FXG_INVALID_TUPLE, bw1 = 0u, bq = 0u;
     int first_n = len;
+    const int rows_u = UR ? rows : fxg_wave_max(rows);
 #pragma unroll 1
-    for (int q = 0; q < rows; ++q) {                       // rows == len unless the stale tail of earlier reads is emulated
+    for (int q = 0; q < rows_u; ++q) {                     // rows == len unless the stale tail of earlier reads is emulated
+        if (q >= rows) continue;                           // (a lane whose read is shorter idles; the loop itself is wave-uniform)
         const u32 c = rd[q];
         const bool qn = (c == (u32)'N');
         first_n = (qn && first_n == len && q < len) ? q : first_n;
@@ -239,7 +263,7 @@ FXG_HD void fxg_clip_row_packed(const FxgKArgs &a, int A, u32 c, int q, u32 vsta
 }
 
 template <int AMAX, bool TN>
-FXG_HD void fxg_clip_rows_packed(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float &best, u32 &bw, u32 &bq, int &first_n)
+FXG_HD void fxg_clip_rows_packed(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float &best, u32 &bw, u32 &bq, int &first_n, const bool UR = false)
 {
     float S[AMAX], Sm[AMAX];
     u32 W[AMAX];
@@ -257,18 +281,19 @@ FXG_HD void fxg_clip_rows_packed(const FxgKArgs &a, const uint8_t *rd, int len, 
     }
     // The row's base comes out of LDS one row AHEAD of its use (rows >= 1 always exists in the staged tile: the bases of the next
     // read or the tile's slack follow), so the load's latency is never waited for at the top of a row.
-    u32 cn = q < rows ? rd[q] : 0u;
+    // wave-uniform loops (fxg_wave_max above): the early form tests the row number itself, so it serves every lane while ANY lane is early
+    const int early_u = UR ? early_rows : fxg_wave_max(early_rows), rows_u = UR ? rows : fxg_wave_max(rows);
 #pragma unroll 1
-    for (; q < early_rows; ++q) {
-        const u32 c = cn;
-        cn = rd[q + 1];
+    for (; q < early_u; ++q) {
+        if (q >= rows) continue;
+        const u32 c = rd[q];
         first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
         fxg_clip_row_packed<AMAX, true, false, TN>(a, A, c, q, (u32)q, S, Sm, W, best, bw, bq);
     }
 #pragma unroll 1
-    for (; q < rows; ++q) {
-        const u32 c = cn;
-        cn = rd[q + 1];
+    for (; q < rows_u; ++q) {
+        if (q >= rows) continue;
+        const u32 c = rd[q];
         first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
         fxg_clip_row_packed<AMAX, false, false, TN>(a, A, c, q, (u32)q, S, Sm, W, best, bw, bq);
     }
@@ -329,7 +354,7 @@ FXG_HD float fxg_clip_row_score(const FxgKArgs &a, int A, u32 c, int q, float (&
 
 // returns the row the query_start field of bw counts from
 template <int AMAX>
-FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float &best, u32 &bw, u32 &bq, int &first_n)
+FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float &best, u32 &bw, u32 &bq, int &first_n, const bool UR = false)
 {
     constexpr int C = FxgClip2<AMAX>::C;
     float S[AMAX], Sm[AMAX], P0[AMAX], P1[AMAX], P2[AMAX], CB[AMAX];
@@ -337,7 +362,10 @@ FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int 
 #pragma unroll
     for (int t = 0; t < AMAX; ++t) { S[t] = (t <= 3) ? 0.0f : -5.0f * (float)(t - 3); Sm[t] = S[t] + -5.0f; P0[t] = P1[t] = P2[t] = CB[t] = S[t]; }
     const int early_rows = (A - 4 < rows) ? (A - 4 > 0 ? A - 4 : 0) : rows;
-    if (rows <= 0) return 0;
+    // every loop below runs a wave-uniform number of trips (fxg_wave_max): q and the chunk bounds are scalars, a lane past its own
+    // last row skips the row, and a lane without rows at all (rows == 0) walks through with everything predicated off
+    const int rows_u = UR ? rows : fxg_wave_max(rows > 0 ? rows : 0);
+    if (rows_u <= 0) return 0;
     // ---- pass 1 ----
     float b1 = -1000000.0f;
     int q = 0, r0 = 0, bq1 = 0;
@@ -347,11 +375,12 @@ FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int 
 #define FXG_CLIP_CHUNK(EARLY, Psave, Pwin)                                                                                   \
     {                                                                                                                        \
         _Pragma("unroll") for (int t = 0; t < AMAX; ++t) Psave[t] = S[t];                                                    \
-        const int q0 = q, qend = q + C < rows ? q + C : rows;                                                                \
+        const int q0 = q, qend = q + C < rows_u ? q + C : rows_u;                                                            \
         bool upd = false;                                                                                                    \
         _Pragma("unroll 1") for (; q < qend; ++q) {                                                                          \
             const u32 c = cn;                                                                                                \
             cn = rd[q + 1];                                                                                                  \
+            if (!UR && q >= rows) continue;                                                                                  \
             const float rm = fxg_clip_row_score<AMAX, EARLY>(a, A, c, q, S, Sm);                                             \
             const bool g = rm > b1;                                                                                          \
             b1 = g ? rm : b1; bq1 = g ? q : bq1; upd = upd || g;                                                             \
@@ -364,32 +393,43 @@ FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int 
     // the early rule (rows q < A - 4, sequence_alignment.cpp:387-389) can only fire in the first two chunks: 2 C >= SPAN - 1 >= A - 4
     static_assert(2 * C >= AMAX - 4, "early rows must end inside the first two chunks");
     FXG_CLIP_CHUNK(true, P0, P1)
-    if (q < rows) FXG_CLIP_CHUNK(true, P1, P2)
-    while (q < rows) {
+    if (q < rows_u) FXG_CLIP_CHUNK(true, P1, P2)
+    while (q < rows_u) {
         FXG_CLIP_CHUNK(false, P2, P0)
-        if (q >= rows) break;
+        if (q >= rows_u) break;
         FXG_CLIP_CHUNK(false, P0, P1)
-        if (q >= rows) break;
+        if (q >= rows_u) break;
         FXG_CLIP_CHUNK(false, P1, P2)
     }
 #undef FXG_CLIP_CHUNK
+    if (rows <= 0) return 0;                                // (only now: the loops above are the wave's, not the lane's)
     // ---- pass 2: rows r0 .. bq1 with the path summaries, from the checkpoint; only row bq1 can hold the first maximum ----
     u32 W[AMAX];
 #pragma unroll
     for (int t = 0; t < AMAX; ++t) { S[t] = CB[t]; Sm[t] = CB[t] + -5.0f; W[t] = ((u32)(t + 1) << 19) + FXG_PK_SZ1; }
     q = r0;
-    int i = 0;
+    // window row i is read row r0 + i >= i: rows past i = A - 4 are past the early rule.  n1 rows in the early form, n2 in the other;
+    // both loops run the wave's maximum, a lane beyond its own count skips the row
+    const int win = bq1 - r0, n1 = win < early_rows ? win : early_rows, n2 = win - n1;
+    const int n1u = fxg_wave_max(n1), n2u = fxg_wave_max(n2);
 #pragma unroll 1
-    for (; q < bq1 && i < early_rows; ++q, ++i)             // window row i is read row r0 + i >= i: rows past i = A - 4 are past the early rule
+    for (int i = 0; i < n1u; ++i) {
+        if (i >= n1) continue;
         fxg_clip_row_packed<AMAX, true, false, false, false>(a, A, (u32)rd[q], q, (u32)(q - r0), S, Sm, W, best, bw, bq);
+        ++q;
+    }
 #pragma unroll 1
-    for (; q < bq1; ++q)
+    for (int i = 0; i < n2u; ++i) {
+        if (i >= n2) continue;
         fxg_clip_row_packed<AMAX, false, false, false, false>(a, A, (u32)rd[q], q, (u32)(q - r0), S, Sm, W, best, bw, bq);
+        ++q;
+    }
     fxg_clip_row_packed<AMAX, true, false, false, true>(a, A, (u32)rd[bq1], bq1, (u32)(bq1 - r0), S, Sm, W, best, bw, bq);
     // the -n rule needs the first N of the read itself (fastx_clipper.cpp:306-311); nothing else does
     if (!(a.clip_flags & FXG_CLIP_KEEP_N)) {
+        const int len_u = UR ? len : fxg_wave_max(len);
 #pragma unroll 1
-        for (int k = len - 1; k >= 0; --k) first_n = (rd[k] == (uint8_t)'N') ? k : first_n;
+        for (int k = len_u - 1; k >= 0; --k) first_n = (k < len && rd[k] == (uint8_t)'N') ? k : first_n;
     }
     return r0;
 }
@@ -494,7 +534,7 @@ FXG_HD void fxg_clip_row_k(const FxgKArgs &a, int A, u32 c, int q, u32 vstart, f
 }
 
 template <int AMAX, bool TN>
-FXG_HD void fxg_clip_rows_k(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float &best, u32 &bw, u32 &bq, int &first_n)
+FXG_HD void fxg_clip_rows_k(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float &best, u32 &bw, u32 &bq, int &first_n, const bool UR = false)
 {
     float S[AMAX], Sm[FxgClipK<AMAX>::NSM];
     u32 W[AMAX];
@@ -506,20 +546,24 @@ FXG_HD void fxg_clip_rows_k(const FxgKArgs &a, const uint8_t *rd, int len, int r
         W[t] = FXG_K_START(256 + t + 1) + FXG_K_SZ1;                                     // what a path entering diagonally at (0, t + 1) starts from
     }
     const int early_rows = (A - 4 < rows) ? (A - 4 > 0 ? A - 4 : 0) : rows;
-    if (rows <= 0) return;
+    // wave-uniform loops (fxg_wave_max): the early form tests the row number itself and serves every lane while ANY lane is early
+    const int early_u = UR ? early_rows : fxg_wave_max(early_rows), rows_u = UR ? rows : fxg_wave_max(rows > 0 ? rows : 0);
+    if (rows_u <= 0) return;
     int q = 0;
     u32 cn = rd[0];
 #pragma unroll 1
-    for (; q < early_rows; ++q) {
+    for (; q < early_u; ++q) {
         const u32 c = cn;
         cn = rd[q + 1];
+        if (!UR && q >= rows) continue;
         first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
         fxg_clip_row_k<AMAX, true, true, TN>(a, A, c, q, (u32)q, S, Sm, W, best, bw, bq);
     }
 #pragma unroll 1
-    for (; q < rows; ++q) {
+    for (; q < rows_u; ++q) {
         const u32 c = cn;
         cn = rd[q + 1];
+        if (!UR && q >= rows) continue;
         first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
         fxg_clip_row_k<AMAX, false, true, TN>(a, A, c, q, (u32)q, S, Sm, W, best, bw, bq);
     }
@@ -586,13 +630,17 @@ FXG_HD u32 fxg_fbits(float) { return 0u; }
 #endif
 // returns r0 (the row the `start` field of bw counts from)
 template <int AMAX, bool TN>
-FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float *ck, u32 cks, float &best, u32 &bw, u32 &bq, int &first_n, u32 *dbg = nullptr)
+FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float *ck, u32 cks, float &best, u32 &bw, u32 &bq, int &first_n, u32 *dbg = nullptr, const bool UR = false)
 {
     (void)dbg;
     float S[AMAX], Sm[AMAX];
     const int A = a.alen, K = (int)a.clip_ck_rows;
     const int early_rows = (A - 4 < rows) ? (A - 4 > 0 ? A - 4 : 0) : rows;
-    if (rows <= 0) return 0;
+    // every loop runs a wave-uniform number of trips (fxg_wave_max): in pass 1 the row number q and the checkpoint schedule are scalars, a
+    // lane past its own last row skips the row (and the checkpoint, which it will never read); the early form tests the row number
+    // itself and serves every lane while ANY lane is early
+    const int early_u = UR ? early_rows : fxg_wave_max(early_rows), rows_u = UR ? rows : fxg_wave_max(rows > 0 ? rows : 0);
+    if (rows_u <= 0) return 0;
 #pragma unroll
     for (int t = 0; t < AMAX; ++t) { S[t] = (t <= 3) ? 0.0f : -5.0f * (float)(t - 3); Sm[t] = S[t] + -5.0f; }
     // ---- pass 1 ----
@@ -602,21 +650,25 @@ FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, in
     u32 cn = rd[0];
 #define FXG_CK_ROW(EARLY)                                                                                                    \
     {                                                                                                                        \
+        const bool mine = UR || q < rows;                                                                                    \
         if (q == next_ck) {                                                                                                  \
-            _Pragma("unroll") for (int t = 0; t < AMAX; ++t) slot[(size_t)t * cks] = S[t];                                   \
+            if (mine) { _Pragma("unroll") for (int t = 0; t < AMAX; ++t) slot[(size_t)t * cks] = S[t]; }                     \
             slot += (size_t)AMAX * cks; next_ck += K;                                                                        \
         }                                                                                                                    \
         const u32 c = cn;                                                                                                    \
         cn = rd[q + 1];                                                                                                      \
-        const float rm = fxg_clip_row_score_k<AMAX, EARLY, TN>(a, A, c, q, S, Sm);                                               \
-        const bool g = rm > b1;                                                                                              \
-        b1 = g ? rm : b1; bq1 = g ? q : bq1;                                                                                 \
+        if (mine) {                                                                                                          \
+            const float rm = fxg_clip_row_score_k<AMAX, EARLY, TN>(a, A, c, q, S, Sm);                                       \
+            const bool g = rm > b1;                                                                                          \
+            b1 = g ? rm : b1; bq1 = g ? q : bq1;                                                                             \
+        }                                                                                                                    \
     }
 #pragma unroll 1
-    for (; q < early_rows; ++q) FXG_CK_ROW(true)
+    for (; q < early_u; ++q) FXG_CK_ROW(true)
 #pragma unroll 1
-    for (; q < rows; ++q) FXG_CK_ROW(false)
+    for (; q < rows_u; ++q) FXG_CK_ROW(false)
 #undef FXG_CK_ROW
+    if (rows <= 0) return 0;                                // (only now: the loops above are the wave's, not the lane's)
     // ---- pass 2 ----
     const int span = A + (A + 1) / 5;
     const int r0 = bq1 - span + 1 > 0 ? bq1 - span + 1 : 0;
@@ -637,8 +689,15 @@ FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, in
 #if defined(FXG_CLIP_DEBUG) && FXG_CLIP_DEBUG >= 2
     FXG_CLIP_DBG(4, fxg_dbg_hash(S));
 #endif
+    {
+        const int n0 = r0 - q, n0u = fxg_wave_max(n0);      // < clip_ck_rows rows of scores up to the first summary row
 #pragma unroll 1
-    for (; q < r0; ++q) (void)fxg_clip_row_score_k<AMAX, true, TN>(a, A, (u32)rd[q], q, S, Sm);
+        for (int i = 0; i < n0u; ++i) {
+            if (i >= n0) continue;
+            (void)fxg_clip_row_score_k<AMAX, true, TN>(a, A, (u32)rd[q], q, S, Sm);
+            ++q;
+        }
+    }
 #if defined(FXG_CLIP_DEBUG) && FXG_CLIP_DEBUG >= 2
     FXG_CLIP_DBG(5, fxg_dbg_hash(S));
 #endif
@@ -646,7 +705,6 @@ FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, in
 #pragma unroll
     for (int t = 0; t < AMAX; ++t) W[t] = FXG_K_START(256 + t + 1) + FXG_K_SZ1;         // the cells above row 0 (r0 > 0: never on the best path)
     float (&Sk)[FxgClipK<AMAX>::NSM] = reinterpret_cast<float (&)[FxgClipK<AMAX>::NSM]>(Sm);    // the summary rows keep S - 5 only where registers allow
-    int i = 0;
 #ifdef FXG_CLIP_DEBUG
     constexpr int DT0 = AMAX > 64 ? AMAX - 64 : 0;          // the LAST 64 columns of the wide buckets
     (void)DT0;
@@ -657,10 +715,20 @@ FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, in
 #else
 #define FXG_CLIP_DBG_ROW() do { } while (0)
 #endif
+    const int win = bq1 - r0, n1 = win < early_rows ? win : early_rows, n2 = win - n1;      // summary rows in the early form / in the other
+    const int n1u = fxg_wave_max(n1), n2u = fxg_wave_max(n2);
 #pragma unroll 1
-    for (; q < bq1 && i < early_rows; ++q, ++i) { fxg_clip_row_k<AMAX, true, false, TN>(a, A, (u32)rd[q], q, (u32)(q - r0), S, Sk, W, best, bw, bq); FXG_CLIP_DBG_ROW(); }
+    for (int i = 0; i < n1u; ++i) {
+        if (i >= n1) continue;
+        fxg_clip_row_k<AMAX, true, false, TN>(a, A, (u32)rd[q], q, (u32)(q - r0), S, Sk, W, best, bw, bq); FXG_CLIP_DBG_ROW();
+        ++q;
+    }
 #pragma unroll 1
-    for (; q < bq1; ++q) { fxg_clip_row_k<AMAX, false, false, TN>(a, A, (u32)rd[q], q, (u32)(q - r0), S, Sk, W, best, bw, bq); FXG_CLIP_DBG_ROW(); }
+    for (int i = 0; i < n2u; ++i) {
+        if (i >= n2) continue;
+        fxg_clip_row_k<AMAX, false, false, TN>(a, A, (u32)rd[q], q, (u32)(q - r0), S, Sk, W, best, bw, bq); FXG_CLIP_DBG_ROW();
+        ++q;
+    }
 #if defined(FXG_CLIP_DEBUG) && FXG_CLIP_DEBUG >= 3
     if (dbg) for (int t = DT0; t < AMAX; ++t) { dbg[336 + t - DT0] = fxg_fbits(S[t]); dbg[400 + t - DT0] = W[t]; }
 #endif
@@ -679,8 +747,9 @@ FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, in
     FXG_CLIP_DBG(12, fxg_dbg_hash(S)); FXG_CLIP_DBG(13, fxg_dbg_hash(W));
 #endif
     if (!(a.clip_flags & FXG_CLIP_KEEP_N)) {                                             // the -n rule needs the first N of the read itself
+        const int len_u = UR ? len : fxg_wave_max(len);
 #pragma unroll 1
-        for (int k = len - 1; k >= 0; --k) first_n = (rd[k] == (uint8_t)'N') ? k : first_n;
+        for (int k = len_u - 1; k >= 0; --k) first_n = (k < len && rd[k] == (uint8_t)'N') ? k : first_n;
     }
     return r0;
 }
@@ -689,21 +758,21 @@ FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, in
 // form of fxg_clip_two_pass cannot describe: its start field is absolute)
 template <int AMAX, bool KFORM, bool TN = false>
 FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len, int rows,
-                                 u32 *out_len, u32 *keep, u32 *reason, u32 *clipped, u32 *adapter_only, float *ck = nullptr, u32 cks = 0u, u32 *dbg = nullptr)
+                                 u32 *out_len, u32 *keep, u32 *reason, u32 *clipped, u32 *adapter_only, float *ck = nullptr, u32 cks = 0u, u32 *dbg = nullptr, const bool UR = false)
 {
     (void)dbg;
     float best = -1000000.0f;
     u32 bw = FXG_INVALID_TUPLE, bq = 0u;
     int first_n = len, qbase = 0;
 #ifndef FXG_CLIP_ONE_PASS
-    if constexpr (!KFORM) qbase = fxg_clip_two_pass<AMAX>(a, rd, len, rows, best, bw, bq, first_n);
+    if constexpr (!KFORM) qbase = fxg_clip_two_pass<AMAX>(a, rd, len, rows, best, bw, bq, first_n, UR);
     else
 #endif
-    if constexpr (!KFORM) fxg_clip_rows_packed<AMAX, false>(a, rd, len, rows, best, bw, bq, first_n);
+    if constexpr (!KFORM) fxg_clip_rows_packed<AMAX, false>(a, rd, len, rows, best, bw, bq, first_n, UR);
     if constexpr (KFORM) {
         int r0 = 0;
-        if (ck) r0 = fxg_clip_two_pass_k<AMAX, TN>(a, rd, len, rows, ck, cks, best, bw, bq, first_n, dbg);
-        else fxg_clip_rows_k<AMAX, TN>(a, rd, len, rows, best, bw, bq, first_n);
+        if (ck) r0 = fxg_clip_two_pass_k<AMAX, TN>(a, rd, len, rows, ck, cks, best, bw, bq, first_n, dbg, UR);
+        else fxg_clip_rows_k<AMAX, TN>(a, rd, len, rows, best, bw, bq, first_n, UR);
         const int v = (int)(bw >> 23), matches = (int)(bw & 127u), diag = (int)((bw >> 7) & 127u);
         fxg_clip_finish(a, len, v < 256 ? r0 + v : 0, v < 256 ? 0 : v - 256, diag - matches, (int)((bw >> 14) & 511u), matches,
                         (int)bq, first_n, out_len, keep, reason, clipped, adapter_only);
@@ -826,7 +895,7 @@ FXG_HD u32 fxg_decide_a(const FxgKArgs &a, const u32 *bm_g, const u32 *bm_l, con
     const u32 rl = a.len ? (u32)a.len[r0 + tid] : a.fixed_len;
     u32 reason = FXG_R_KEPT, clipped = 0, keep = 1, curlen = rl, ao = 0;
     const int rows = a.wlen ? (int)a.wlen[r0 + tid] : (int)rl;      // clip history: the DP also runs over the stale tail (fxg_history.h)
-    if constexpr (AMAX > 0) fxg_clip_read<AMAX>(a, sb + tid * a.clip_stride, (int)rl, rows, &curlen, &keep, &reason, &clipped, &ao);
+    if constexpr (AMAX > 0) fxg_clip_read<AMAX>(a, sb + tid * a.clip_stride, (int)rl, rows, &curlen, &keep, &reason, &clipped, &ao, !a.len && !a.wlen);
     if constexpr (AMAX < 0) {
         // fixed-length batch without clip history: the row count is a scalar, so every loop of the DP is a scalar loop
         constexpr int COLS = fxg_clip_cols(AMAX);
@@ -836,7 +905,7 @@ FXG_HD u32 fxg_decide_a(const FxgKArgs &a, const u32 *bm_g, const u32 *bm_l, con
 #else
         u32 *dbg = nullptr;
 #endif
-        if (!a.len && !a.wlen) fxg_clip_read_packed<COLS, KF, TN>(a, sb + tid * a.clip_stride, (int)a.fixed_len, (int)a.fixed_len, &curlen, &keep, &reason, &clipped, &ao, ck, cks, dbg);
+        if (!a.len && !a.wlen) fxg_clip_read_packed<COLS, KF, TN>(a, sb + tid * a.clip_stride, (int)a.fixed_len, (int)a.fixed_len, &curlen, &keep, &reason, &clipped, &ao, ck, cks, dbg, true);
         else fxg_clip_read_packed<COLS, KF, TN>(a, sb + tid * a.clip_stride, (int)rl, rows, &curlen, &keep, &reason, &clipped, &ao, ck, cks, dbg);
     }
     if (keep && (a.stages & FXG_STAGE_QTRIM)) {             // fastq_quality_trimmer.c:94-101
