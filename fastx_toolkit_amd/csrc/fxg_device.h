@@ -102,8 +102,6 @@ struct FxgKArgs {
     const uint16_t *wlen;   // DP rows per read (null: the read's own length)
     float *clip_ck;         // two-pass clipper for 17..99 adapter columns (fxg_clip_two_pass_k): score-row checkpoints, FXG_CK_SLOTS x bucket x threads floats per workgroup (null: one pass)
     u32  clip_ck_rows;      // a checkpoint every this many rows
-    u32  writer_every;      // clip instances, roles (fxg_clip_writer): every writer_every-th workgroup to start only writes tiles out, the others only decide; 0 = every workgroup does both
-    u32 *wr_ticket;         // the writers' tile dispenser (zeroed with the control block)
 #ifdef FXG_CLIP_DEBUG
     u32 *clip_dbg;          // debug builds only (scripts/debug/clip64_bisect.py): 16 words per read of fxg_clip_two_pass_k's intermediate state
 #endif

@@ -225,13 +225,9 @@ static int fxg_kernel_fit(fxg_ctx *c, K kernel, const char *kname, u32 lds, int 
 // u64 words of the inter-workgroup state for `cap` tiles: totals, two prefixes per tile, two per scanner batch (batches of >= 256 tiles)
 #define FXG_STATUS_WORDS(cap) (3 * (size_t)(cap) + 2 * ((size_t)(cap) / 256 + 2))
 
-#ifndef FXG_CLIP_WRITER_EVERY
-#define FXG_CLIP_WRITER_EVERY 0      // roles of the clip instances (fxg_clip_writer): 0 = off (experiment: FXG_CLIP_WRITER_EVERY=4 in the environment)
-#endif
 template <typename K>
 static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &ka, u32 lds, u64 *counters, u32 block = FXG_TBLOCK, bool rows_kernel = false, u64 ck_per_wg = 0)
 {
-    const bool clip_roles = (ka.stages & FXG_STAGE_CLIP) != 0;
     FXG_HIP(c, hipSetDevice(c->device));
     int per_cu = 0;
     const int frc = fxg_kernel_fit(c, kernel, kname, lds, &per_cu, block);
@@ -294,13 +290,6 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
     ka.ticket = c->errflag + FXG_CTRL_WORDS;
     ka.extra = (u64 *)(c->errflag + 2);
     ka.role = c->errflag + 8;
-    ka.wr_ticket = c->errflag + 9;
-    ka.writer_every = 0u;
-    if (clip_roles && ka.compact && !rows_kernel && grid >= 64u && ka.ntiles >= 4ull * grid) {       // roles pay with many tiles per workgroup; small launches keep the one-role form
-        const char *e = getenv("FXG_CLIP_WRITER_EVERY");
-        ka.writer_every = e ? (u32)atoi(e) : (u32)FXG_CLIP_WRITER_EVERY;
-        if (ka.writer_every == 1u || ka.writer_every > 16u) ka.writer_every = 0u;
-    }
     ka.tally = (u64 *)(c->errflag + 32);
     // Dispenser g serves the workgroups with blockIdx % groups == g, so every group needs a worker even if the scanner role
     // falls to its members: eight groups only when each has more workgroups than there are scanners.

@@ -920,11 +920,6 @@ FXG_HD u32 fxg_decide_a(const FxgKArgs &a, const u32 *bm_g, const u32 *bm_l, con
         if (a.qf_drop_all || (int)low > n0) { keep = 0; reason = FXG_R_QFILTER; }
     }
     const u32 w = (curlen & 0xFFFFu) | (keep << 16) | (reason << 17) | (clipped << 21) | (ao << FXG_RES_ADAPTER_ONLY_BIT);
-#if !defined(FXG_HOST_EMULATION)
-    // with separate writer workgroups (a.writer_every) the word is read by ANOTHER workgroup, possibly on another XCD: written through (sc1)
-    if (AMAX != 0 && a.writer_every) __hip_atomic_store(a.res + r0 + tid, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else
-#endif
     a.res[r0 + tid] = w;
     *keep_out = keep; *len_out = curlen;
     return w;
@@ -1054,75 +1049,6 @@ __host__ __device__ constexpr int fxg_clip_waves(int amax) { return amax > 0 ? 1
 #else
 __host__ __device__ constexpr int fxg_clip_waves(int amax) { return amax > 0 ? 1 : fxg_clip_cols(amax) <= 32 ? FXG_CLIP_WAVES : fxg_clip_cols(amax) <= 48 ? 3 : FXG_CLIP_WAVES_WIDE; }
 #endif
-// ------------------------------------------------------------------------------------------------
-// Roles (clip instances, a.writer_every = E > 0).  The write-out of a tile needs its place in the output, i.e. every earlier tile
-// decided, and is a chain of memory round trips; a workgroup that does both spends a third of its life outside the DP, parked.
-// With roles the workgroups that decide never wait -- stage bases, DP, scan, publish the totals, next tile -- and every E-th workgroup
-// to start does nothing but write tiles out, in tile order: wait for the tile's totals (the tile is decided), read its result words,
-// rebuild the kept-read tables, fetch the prefix, gather.  Roles are drawn by arrival (like the scanner's), so among the workgroups
-// that are running the mix is right whatever the residency; a deciding workgroup waits for nobody, a writer only for deciders and
-// the scanner, the scanner only for deciders: no cycle.  The result words travel by sc1 stores (fxg_decide_a) and sc1 loads, ordered
-// by the totals' granule (every store of the tile is complete -- s_waitcnt vmcnt(0) and the scan's barrier -- before thread 0 publishes).
-// ------------------------------------------------------------------------------------------------
-#ifndef FXG_HOST_EMULATION
-template <int TBN, int GK>
-__device__ __forceinline__ void fxg_clip_writer(const FxgKArgs &a, const FxgLds &L, unsigned char *smem, u32 *scratch, u32 *s_tot, u32 *s_ticket, u64 *bc)
-{
-    constexpr u32 TB = (u32)TBN, TW = TB / 64u;
-    const u32 T = a.tile_reads, stride = a.stride, tid = threadIdx.x;
-    if (tid == 0) s_ticket[0] = atomicAdd(a.wr_ticket, 1u);
-    __syncthreads();
-    u32 cur = s_ticket[0], tk = 0;
-    unsigned char *sl = smem;                                // slot 0: one tile at a time
-    u32 *k_off = reinterpret_cast<u32 *>(sl);
-    u32 *k_src = reinterpret_cast<u32 *>(sl + L.so_ksrc);
-    uint16_t *k_idx = reinterpret_cast<uint16_t *>(sl + L.so_kidx);
-    while (cur < a.ntiles) {
-        if (tid == 0) s_ticket[tk ^ 1u] = atomicAdd(a.wr_ticket, 1u);        // the next ticket is in flight meanwhile
-        const u32 r0 = cur * T;
-        const u64 left = a.n - (u64)r0;
-        const u32 nreads = left < (u64)T ? (u32)left : T;
-        if (tid < 64) {                                      // until the tile has been decided: its totals carry this launch's tag
-            u64 g = fxg_granule_load(a.agg + cur);
-            u32 spins = 0;
-            const u64 t0 = __builtin_amdgcn_s_memrealtime();
-            bool ok = true;
-            while ((u32)(g >> FXG_TAG_SHIFT) != a.tag) {
-                __builtin_amdgcn_s_sleep(2);
-                g = fxg_granule_load(a.agg + cur);
-                if ((++spins & 255u) == 0u && fxg_spin_expired(a, t0)) { ok = false; break; }
-            }
-            if (tid == 0) { s_tot[2] = ok ? 1u : 0u; s_tot[3] = (u32)g; s_tot[4] = (u32)(g >> 32) & 0xFFFFu; }
-        }
-        __syncthreads();
-        const bool decided = s_tot[2] != 0u;
-        const u32 want_b = s_tot[3], want_c = s_tot[4];
-        u64 peek = 0;
-        if (tid < 64 && decided) peek = fxg_peek_prefix(a, cur);
-        u32 keep = 0, olen = 0;
-        if (decided && tid < nreads) {
-            const u32 w = __hip_atomic_load(a.res + r0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            keep = (w >> 16) & 1u; olen = w & 0xFFFFu;
-        }
-        u32 exc, exb, totc, totb;
-        fxg_block_scan2<(int)TW>(keep, keep ? olen : 0u, scratch, &exc, &exb, &totc, &totb);   // one __syncthreads inside
-        if (decided && (totc != want_c || totb != want_b) && tid == 0) atomicOr(a.errflag, FXG_DEV_ERR_SCAN_TIMEOUT);      // result words and totals disagree: never silently
-        if (keep) { k_off[exc] = exb; k_src[exc] = tid * stride; k_idx[exc] = (uint16_t)tid; }
-        if (tid == 0) k_off[totc] = totb;
-        if (tid < 64 && decided) fxg_wait_prefix(a, cur, peek, bc);
-        __syncthreads();
-        const u64 base_c = bc[0], base_b = bc[1];
-        if (decided && base_c != ~0ull) {
-            if (tid < totc) fxg_write_kept_meta(a, base_c + tid, k_off[tid + 1] - k_off[tid], r0 + k_idx[tid], base_b + k_off[tid]);
-            (void)fxg_tile_gather<false, false, GK>(a, k_off, k_src, nullptr, totc, (u64)r0 * stride, nreads * stride, base_b, totb, tid, TB);
-        }
-        __syncthreads();                                     // the tables and the ticket word are free again
-        tk ^= 1u;
-        cur = s_ticket[tk];
-    }
-}
-#endif
-
 template <int AMAX, int MODE> struct FxgTileBlock { static constexpr int threads = (MODE == 0 && AMAX < 0 && AMAX >= -16) ? FXG_CLIP_TBLOCK : FXG_TBLOCK; };
 template <int AMAX, int MODE>
 __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? FXG_MIN_WAVES : fxg_clip_waves(AMAX))) void fxg_kernel_tiles(const FxgKArgs a)
@@ -1151,28 +1077,18 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
 #endif
 
     // One workgroup turns the tiles' totals into prefixes (fxg_scanner); the others process tiles.
-    u32 arrival = blockIdx.x + 1u;
     if (a.compact) {
         if (tid == 0) s_ticket[0] = atomicAdd(a.role, 1u);
         __syncthreads();
-        arrival = s_ticket[0];
+        const bool scanner = (s_ticket[0] == 0u);
         __syncthreads();
-        if (arrival == 0u) { if (tid < 64) fxg_scanner(a); return; }
-    }
-    bool dp_only = false;                                    // roles: this workgroup only decides tiles (fxg_clip_writer's counterpart)
-    if constexpr (MODE == 0 && AMAX != 0) {
-        if (a.compact && a.writer_every) {
-            const u32 w = arrival - 1u, E = a.writer_every;
-            if (w % E == E - 1u) { fxg_clip_writer<(int)TB, FXG_CLIP_GATHER_K>(a, L, smem, scratch, s_tot, s_ticket, bc); return; }
-            dp_only = true;
-            arrival = 1u + (w - (w + 1u) / E);              // 1 + index among the deciding workgroups (picks the dispenser below)
-        }
+        if (scanner) { if (tid < 64) fxg_scanner(a); return; }
     }
     // Sharded dispenser: workgroup b draws from counter g = b % groups, which hands out tiles g, g+groups, ...
     // The smallest unfinished tile is always either owned by a running workgroup or the next ticket of its
     // counter (whose earlier tiles are all finished, so a workgroup of that group is about to draw it):
     // progress never depends on residency, dispatch order or placement.
-    const u32 G = a.ticket_groups, grp = (dp_only ? arrival - 1u : blockIdx.x) % G;
+    const u32 G = a.ticket_groups, grp = blockIdx.x % G;
     u32 *my_ticket = a.ticket + grp * FXG_TICKET_STRIDE;
     if (tid == 0) s_ticket[0] = atomicAdd(my_ticket, 1u);
     __syncthreads();
@@ -1217,7 +1133,6 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
             // the -v report counters (a12) are functions of res[]: tally the drop reasons this instance can produce, per wave, as the
             // words go by (popcount of a ballot; one LDS add per wave and reason that occurred) instead of a second pass over res[]
             FXG_TPHASE(1);
-            if (dp_only) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's result word is out before the scan's barrier, i.e. before thread 0 publishes the totals
             if (TICKET_AFTER_DECISION && tid == 0) s_ticket[tk ^ 1u] = atomicAdd(my_ticket, 1u);
             fxg_tile_tally<AMAX, MODE>(word, tid < nreads, tally);
             u32 exc, exb, totc, totb;
@@ -1226,13 +1141,13 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
             if (a.compact) {
                 if (tid == 0) fxg_publish_total(a, cur, totc, totb);     // as early as possible: the scanner and every later tile wait for it
                 u32 *k_off = reinterpret_cast<u32 *>(sl);
-                if (!dp_only && tid < nreads && keep) {              // kept reads only, indexed by their rank inside the tile
+                if (tid < nreads && keep) {                          // kept reads only, indexed by their rank inside the tile
                     k_off[exc] = exb;
                     reinterpret_cast<u32 *>(sl + L.so_ksrc)[exc] = anchor;
                     reinterpret_cast<uint16_t *>(sl + L.so_kidx)[exc] = (uint16_t)tid;
                     if (L.has_tab) fxg_tab_fill(reinterpret_cast<uint16_t *>(sl + L.so_ktab), exc, exb, olen);
                 }
-                if (!dp_only && tid == 0) { k_off[totc] = totb; s_tot[2 * slot] = totc; s_tot[2 * slot + 1] = totb; }
+                if (tid == 0) { k_off[totc] = totb; s_tot[2 * slot] = totc; s_tot[2 * slot + 1] = totb; }
             }
             FXG_TPHASE(2);
         }
@@ -1263,11 +1178,10 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
             }
             FXG_TPHASE(4);
         }
-        if (cur >= a.ntiles && (dp_only || NSLOT == 2u || (mid == FXG_NO_TILE && mid2 == FXG_NO_TILE))) break;
+        if (cur >= a.ntiles && (NSLOT == 2u || (mid == FXG_NO_TILE && mid2 == FXG_NO_TILE))) break;
         __syncthreads();            // ticket written by thread 0 in stage A; also fences slot reuse NSLOT iterations apart
         const u32 done = cur < a.ntiles ? cur : FXG_NO_TILE;
-        if (dp_only) pend = FXG_NO_TILE;
-        else if (NSLOT == 4u) { pend = mid; mid = mid2; mid2 = done; } else if (NSLOT == 3u) { pend = mid; mid = done; } else pend = done;
+        if (NSLOT == 4u) { pend = mid; mid = mid2; mid2 = done; } else if (NSLOT == 3u) { pend = mid; mid = done; } else pend = done;
         if (cur < a.ntiles) { tk ^= 1u; cur = s_ticket[tk] * G + grp; }
         slot = slot + 1u == NSLOT ? 0u : slot + 1u;
     }
