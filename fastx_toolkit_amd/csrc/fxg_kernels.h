@@ -1039,15 +1039,17 @@ __device__ __forceinline__ void fxg_tile_tally(u32 w, bool valid, u64 *tally)
 // waves per SIMD the clip instances are compiled for: the packed forms keep 2-3 registers per adapter column (two-pass: 6 of <= 16).
 // 64 columns at three waves came out WRONG on the GPU in round 3 (19 of 223 reads): ROCm 7.2's register allocator had put the spill
 // stores of the summary loop's live-out values into the loop's exit block ahead of the EXEC restore, where they run for no lane
-// (DESIGN.md section 3).  The budget here is a performance choice; what keeps that miscompile out of the product is the ISA check every
+// (DESIGN.md section 3).  Round 4 took the lane-divergent loops out of the DP (fxg_wave_max), which is what that placement needs.  The budget here is a performance choice; what keeps that miscompile out of the product is the ISA check every
 // built library goes through (scripts/check_exec_zero.py, build.py) and the launch-bounds matrix (tests/test_gpu_clip_matrix.py).
 #ifndef FXG_CLIP_WAVES_WIDE
-#define FXG_CLIP_WAVES_WIDE 2   // 49..99 columns (ablation builds: 3)
+#define FXG_CLIP_WAVES_WIDE 2   // 65..99 columns; at three the instance spills its DP row: 45 -> 115 ms (profiles/r04/q_wide_bucket_waves.txt)
 #endif
 #ifdef FXG_CLIP_WAVES_ALL    // the instance x launch-bounds parity matrix (tests/test_gpu_clip_matrix.py): every packed clip instance at this many waves per SIMD
 __host__ __device__ constexpr int fxg_clip_waves(int amax) { return amax > 0 ? 1 : FXG_CLIP_WAVES_ALL; }
 #else
-__host__ __device__ constexpr int fxg_clip_waves(int amax) { return amax > 0 ? 1 : fxg_clip_cols(amax) <= 32 ? FXG_CLIP_WAVES : fxg_clip_cols(amax) <= 48 ? 3 : FXG_CLIP_WAVES_WIDE; }
+// (round 4, every budget being correct now -- profiles/r04/p_clip_waves_by_adapter_len.txt, 10 M reads: 36 columns 11.1 -> 9.7 ms at four waves,
+//  64 columns 28.4 -> 24.2 ms (100-base reads) / 41.6 -> 35.2 ms (150) at three waves instead of two)
+__host__ __device__ constexpr int fxg_clip_waves(int amax) { return amax > 0 ? 1 : fxg_clip_cols(amax) <= 36 ? FXG_CLIP_WAVES : fxg_clip_cols(amax) <= 64 ? 3 : FXG_CLIP_WAVES_WIDE; }
 #endif
 template <int AMAX, int MODE> struct FxgTileBlock { static constexpr int threads = (MODE == 0 && AMAX < 0 && AMAX >= -16) ? FXG_CLIP_TBLOCK : FXG_TBLOCK; };
 template <int AMAX, int MODE>

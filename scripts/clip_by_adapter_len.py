@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from fastx_toolkit_amd import Engine, make_params  # noqa: E402
 
-FULL = b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACATCACGATCTCGTATGCCGTCTTCTGCTTG"
+FULL = b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACATCACGATCTCGTATGCCGTCTTCTGCTTGAAAAAAAAAAGGGGGGGGGGCCCCCCCCCCTTTTTTTTTTACGT"      # 103 bases (the tool takes up to 99)
 if os.environ.get("WITH_N"):                      # the index of the TruSeq adapter as NNNNNN (and one N in the prefix every length shares)
     FULL = b"AGATCGGAAGNGCACACGTCTGAACTCCAGTCACNNNNNNATCTCGTATGCCGTCTTCTGCTTG"
 lens = [int(x) for x in sys.argv[1:]] or [8, 13, 16, 17, 20, 24, 28, 32, 33, 40, 48, 64]
