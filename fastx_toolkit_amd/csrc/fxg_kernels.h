@@ -403,6 +403,7 @@ FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int 
     }
 #undef FXG_CLIP_CHUNK
     if (rows <= 0) return 0;                                // (only now: the loops above are the wave's, not the lane's)
+    if (FXG_DBG(a, 32u)) { best = b1; bq = (u32)bq1; bw = 0u; return 0; }      // ablation builds: pass 1 alone (wrong results, timing only)
     // ---- pass 2: rows r0 .. bq1 with the path summaries, from the checkpoint; only row bq1 can hold the first maximum ----
     u32 W[AMAX];
 #pragma unroll
@@ -1073,6 +1074,7 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
     if (tid < FXG_NTALLY) tally[tid] = 0ull;
 #ifdef FXG_ABLATION
     u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = __builtin_amdgcn_s_memrealtime();   // 100 MHz clocks per phase (wave 0 of the workgroup), summed over its tiles
+    const u64 clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #define FXG_TPHASE(i) do { const u64 now_ = __builtin_amdgcn_s_memrealtime(); ph[i] += now_ - pt; pt = now_; } while (0)
 #else
 #define FXG_TPHASE(i) do { } while (0)
@@ -1117,7 +1119,7 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
             unsigned char *sl = smem + slot * L.slot_bytes;
             if constexpr (MODE == 0 || MODE == 3 || MODE == 4) {
                 if (use_q && !FXG_DBG(a, 8u)) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, TB);
-                if constexpr (MODE == 0 && AMAX != 0) fxg_phase_stage_bases(a.clip_src, a.clip_total, (u64)r0 * a.clip_stride, nreads * a.clip_stride, sb, tid, TB);
+                if constexpr (MODE == 0 && AMAX != 0) { if (!FXG_DBG(a, 16u) || pend == FXG_NO_TILE) fxg_phase_stage_bases(a.clip_src, a.clip_total, (u64)r0 * a.clip_stride, nreads * a.clip_stride, sb, tid, TB); }   // 16: the DP on the workgroup's first tile over and over (the DP's own rate)
                 if constexpr (MODE == 4) fxg_phase_stage_bases(a.bases, a.total_bytes, tb, tbytes, sb, tid, TB);
                 __syncthreads();
             }
@@ -1134,6 +1136,13 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
             }
             // the -v report counters (a12) are functions of res[]: tally the drop reasons this instance can produce, per wave, as the
             // words go by (popcount of a ballot; one LDS add per wave and reason that occurred) instead of a second pass over res[]
+#ifdef FXG_ABLATION
+            {   // how long the waves of a workgroup wait for its slowest one after the decision (all waves, summed): an extra barrier, timed
+                const u64 b0 = __builtin_amdgcn_s_memrealtime();
+                __syncthreads();
+                if ((tid & 63u) == 0u) atomicAdd(reinterpret_cast<u64 *>(a.errflag + 10) + 5, __builtin_amdgcn_s_memrealtime() - b0);
+            }
+#endif
             FXG_TPHASE(1);
             if (TICKET_AFTER_DECISION && tid == 0) s_ticket[tk ^ 1u] = atomicAdd(my_ticket, 1u);
             fxg_tile_tally<AMAX, MODE>(word, tid < nreads, tally);
@@ -1189,7 +1198,12 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
     }
     __syncthreads();
 #ifdef FXG_ABLATION
-    if (tid == 0) for (int i = 0; i < 8; ++i) atomicAdd(reinterpret_cast<u64 *>(a.errflag + 10) + i, ph[i]);
+    if (tid == 0) for (int i = 0; i < 5; ++i) atomicAdd(reinterpret_cast<u64 *>(a.errflag + 10) + i, ph[i]);
+    // the shader clock this kernel ran at: s_memtime ticks (shader cycles) against the constant 100 MHz counter, one workgroup's whole life
+    if (tid == 0 && blockIdx.x == 5u) {
+        reinterpret_cast<u64 *>(a.errflag + 10)[6] = __builtin_amdgcn_s_memtime() - clk_t0;
+        reinterpret_cast<u64 *>(a.errflag + 10)[7] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
 #endif
     if (tid < FXG_NTALLY && tally[tid]) atomicAdd(&a.tally[tid], tally[tid]);     // one global add per workgroup and non-zero slot
     if constexpr (MODE == 3) {                       // masked reads / nucleotides: wave sums, one atomic pair per wave, once

@@ -36,6 +36,10 @@ for lib in libs:
     names = ("stage", "decide(DP)", "scan+publish", "wait prefix", "meta+gather")
     print(json.dumps(dict(lib=lib, cfg=CFG, compact=COMPACT, reads=R, ms_min=round(min(ms), 3), grid=li["grid"], block=li["block"], tile=li["tile_reads"], lds=li["lds"])))
     print("   per workgroup, ms: " + "  ".join("%s %.3f" % (nm, x / 1e5 / wgs) for nm, x in zip(names, ph)), flush=True)
+    if ph[7]:
+        print("   shader clock over the kernel: %.0f MHz (s_memtime %d ticks in %d x 10 ns)" % (ph[6] / ph[7] * 100.0, ph[6], ph[7]), flush=True)
+    if ph[5]:
+        print("   barrier after the decision: %.3f ms per WAVE (of the decide time above; 4 waves per workgroup)" % (ph[5] / 1e5 / wgs / (li["block"] // 64)), flush=True)
     if ph[8]:
         print("   scanner: %d rounds, %.1f tiles/round, load wait %.2f us/round, scan %.2f us/round, total %.2f ms" %
               (ph[8], (R + li["tile_reads"] - 1) // li["tile_reads"] / ph[8], ph[9] / 100.0 / ph[8], ph[10] / 100.0 / ph[8], (ph[9] + ph[10]) / 1e5), flush=True)

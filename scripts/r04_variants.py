@@ -11,6 +11,7 @@ VARIANTS = {
     "qs_unroll3": ["-DFXG_QS_UNROLL=3u"],
     "qs_unroll4": ["-DFXG_QS_UNROLL=4u"],
     "qs_unroll1": ["-DFXG_QS_UNROLL=1u"],
+    "abl": ["-DFXG_ABLATION"],
 }
 def lib(n): return os.path.join(b.PKG, "libfxg_x_%s.so" % n)
 if sys.argv[1] == "build":
