@@ -37,7 +37,7 @@
 #define FXG_QS_LROW_WORDS FXG_QS_WBINS                     // 256 bytes: class k of a pair lives at byte k << 8 of the pair's block
 #define FXG_QS_LDS_WORDS ((FXG_QS_BLOCK_COLS / 2u) * FXG_QS_LROWS * FXG_QS_LROW_WORDS)   // word = two u16 counters: even column low, odd column high
 #ifndef FXG_QS_UNROLL
-#define FXG_QS_UNROLL 2u                                   // items per lane and trip
+#define FXG_QS_UNROLL 1u                                   // rows per lane and trip (2.71 ms at 1, 2.83 at 2, 2.79 at 3 with the pipelined loop: profiles/r04/ab_stats_pipeline.txt)
 #endif
 
 struct FxgStatsArgs {
@@ -153,8 +153,13 @@ FXG_HD void fxg_stats_accumulate(const FxgStatsArgs &a, const FxgStripRow &o, u3
             // halves of h: class << 8 | offset of base j (low) and of base j + 1 (high) = byte offset inside the pair's block
             const u32 h = fxg_perm(k4[j >> 2], o4[j >> 2], (j & 2u) ? 0x07030602u : 0x05010400u);
             unsigned char *pb = base + (j >> 1) * (FXG_QS_LROWS * FXG_QS_LROW_WORDS * 4u);
+#ifdef FXG_QS_FAKE_BANKS      // timing experiment (wrong counts): every lane of a wave on its own bank -- what the kernel would take without LDS bank conflicts
+            FXG_LDS_ADD(reinterpret_cast<u32 *>(pb + ((h & 0xFF00u) | ((threadIdx.x & 63u) << 2))), 1u);
+            FXG_LDS_ADD(reinterpret_cast<u32 *>(pb + (((h >> 16) & 0xFF00u) | ((threadIdx.x & 63u) << 2))), 0x10000u);
+#else
             FXG_LDS_ADD(reinterpret_cast<u32 *>(pb + (h & 0xFFFFu)), 1u);
             FXG_LDS_ADD(reinterpret_cast<u32 *>(pb + (h >> 16)), 0x10000u);
+#endif
         }
         return;
     }
@@ -227,7 +232,51 @@ __global__ __launch_bounds__(FXG_QS_TBLOCK) void fxg_kernel_quality_stats(const 
     { const u32 c0 = (a.strip0 + sl) * FXG_QS_STRIP; fxg_stats_masks(a.fixed_len > c0 ? (a.fixed_len - c0 < FXG_QS_STRIP ? a.fixed_len - c0 : FXG_QS_STRIP) : 0u, mfix); }
     u32 since = 0;                                            // reads added to the LDS block since it was last cleared
     u64 r0 = lo + rl;
-    for (u64 g0 = 0; g0 < nitems; g0 += (u64)FXG_QS_TBLOCK * FXG_QS_UNROLL, r0 += trip_reads) {
+    // Fixed-length batches, interior trips (every read of the trip and of the next one inside the slice, none of them the batch's last
+    // read): the loads need no test at all, so the rows of trip i + 1 are requested BEFORE the rows of trip i go into the histogram and
+    // stay in flight during the lane's 16 x UNROLL LDS adds -- with a test around every load the compiler waited for vmcnt(0) at the
+    // first use, i.e. for the rows it had just asked for.  A lane whose strip lies past the end of the reads (100-base reads: strips
+    // 7..9) loads its row's first bytes instead and adds nothing.
+    u64 g0 = 0;
+    if (!a.len && a.qual) {
+        const u64 safe = hi < a.n ? hi : (a.n ? a.n - 1 : 0);                     // reads below `safe` may be read 16 bytes at a time from any column
+        const u32 c0 = (a.strip0 + sl) * FXG_QS_STRIP;
+        const u32 nb = a.fixed_len > c0 ? (a.fixed_len - c0 < FXG_QS_STRIP ? a.fixed_len - c0 : FXG_QS_STRIP) : 0u;
+        const u64 tb = (u64)trip_reads * a.stride, sb = (u64)reads_per_step * a.stride;
+        u64 at = r0 * a.stride + (nb ? c0 : 0u), first = lo;                      // `first`: first read of the trip (wave-uniform)
+        if (first + 2ull * trip_reads <= safe) {
+            FxgStripRow cur[FXG_QS_UNROLL], nx[FXG_QS_UNROLL];
+#pragma unroll
+            for (u32 u = 0; u < FXG_QS_UNROLL; ++u) { cur[u].vb = fxg_ld16(a.bases + at + u * sb); cur[u].vq = fxg_ld16(a.qual + at + u * sb); cur[u].nb = nb; }
+            for (; first + 2ull * trip_reads <= safe; first += trip_reads, g0 += (u64)FXG_QS_TBLOCK * FXG_QS_UNROLL, r0 += trip_reads, at += tb) {
+#pragma unroll
+                for (u32 u = 0; u < FXG_QS_UNROLL; ++u) { nx[u].vb = fxg_ld16(a.bases + at + tb + u * sb); nx[u].vq = fxg_ld16(a.qual + at + tb + u * sb); nx[u].nb = nb; }
+                if (since + trip_reads > 65535u) {
+                    __syncthreads();
+                    fxg_stats_flush(qs_h, part, tid, FXG_QS_TBLOCK);
+                    __syncthreads();
+                    since = 0;
+                }
+#pragma unroll
+                for (u32 u = 0; u < FXG_QS_UNROLL; ++u) fxg_stats_accumulate(a, cur[u], sl, c0, mfix, qs_h);
+#pragma unroll
+                for (u32 u = 0; u < FXG_QS_UNROLL; ++u) cur[u] = nx[u];
+                since += trip_reads;
+            }
+            // the trip whose rows are already here
+            if (since + trip_reads > 65535u) {
+                __syncthreads();
+                fxg_stats_flush(qs_h, part, tid, FXG_QS_TBLOCK);
+                __syncthreads();
+                since = 0;
+            }
+#pragma unroll
+            for (u32 u = 0; u < FXG_QS_UNROLL; ++u) fxg_stats_accumulate(a, cur[u], sl, c0, mfix, qs_h);
+            since += trip_reads; g0 += (u64)FXG_QS_TBLOCK * FXG_QS_UNROLL; r0 += trip_reads;
+        }
+    }
+    // everything else (ragged reads, FASTA, the last trips of a slice): every load tested
+    for (; g0 < nitems; g0 += (u64)FXG_QS_TBLOCK * FXG_QS_UNROLL, r0 += trip_reads) {
         if (since + trip_reads > 65535u) {                    // a 16-bit counter could wrap: move the block out (uniform branch)
             __syncthreads();
             fxg_stats_flush(qs_h, part, tid, FXG_QS_TBLOCK);

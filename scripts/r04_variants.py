@@ -8,6 +8,10 @@ VARIANTS = {
     "base": [],
     "ticket_after_dp": ["-DFXG_TICKET_AFTER_DP=1"],
     "ticket_last_moment": ["-DFXG_TICKET_AFTER_DP=2"],
+    "qs_pipe": [],
+    "qs_fake_banks": ["-DFXG_QS_FAKE_BANKS"],
+    "qs_pipe_u1": ["-DFXG_QS_UNROLL=1u"],
+    "qs_pipe_u3": ["-DFXG_QS_UNROLL=3u"],
     "qs_unroll3": ["-DFXG_QS_UNROLL=3u"],
     "qs_unroll4": ["-DFXG_QS_UNROLL=4u"],
     "qs_unroll1": ["-DFXG_QS_UNROLL=1u"],
