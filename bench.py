@@ -59,8 +59,9 @@ CONFIGS = {
                   metric="Mreads/s (150 bp) quality statistics", bound="hbm", what="fastx_quality_stats (per-cycle histogram reduction)"),
 }
 # VALU wave-instructions the clip kernel issues per DP cell of the L x 13 matrix, everything included (both passes, staging, write-out):
-# SQ_INSTS_VALU x 64 / cells of profiles/r03_clip_pmc (scripts/pmc_sq.sh).  The first pass alone is 6.2 per cell (llvm-objdump of the row loop).
-CLIP_VALU_PER_CELL = {"cfg3": 10.6, "cfg5shard": 9.45}
+# SQ_INSTS_VALU x 64 / cells of profiles/r04/aa_clip_sq_counters_cfg{3,5}.txt (scripts/pmc_sq.sh; round 3: 10.6 / 9.45).  The first pass alone is
+# 6.2 per cell (llvm-objdump of the row loop).
+CLIP_VALU_PER_CELL = {"cfg3": 10.45, "cfg5shard": 9.35}
 
 # What the timed launches of the default workloads must produce: (kept reads, kept bases, Result.checksum()).  The same tuples are
 # asserted by tests/test_gpu_parity.py::test_full_size_* on runs whose res[] and packed streams are compared with the oracle in a
@@ -645,8 +646,8 @@ def main():
                 **shape, "hbm": hbm,
                 "note": "bound is VALU issue; peak = 256 CUs x 4 SIMDs x 64 lanes / %.0f cycles x 2.4 GHz (MI355X_MICROARCH.md: one wave64 VALU instruction "
                         "per 2 cycles per SIMD); achieved = cells/s x valu_instr_per_cell, the wave-instructions the kernel issues per cell of the full "
-                        "L x 13 matrix the reference fills (SQ_INSTS_VALU x 64 / cells, whole kernel: both passes, staging, write-out; profiles/r03_clip_pmc, "
-                        "re-measured in profiles/r04 when the kernel changes), so it is what the SIMDs really issued" % VALU_CYCLES,
+                        "L x 13 matrix the reference fills (SQ_INSTS_VALU x 64 / cells, whole kernel: both passes, staging, write-out; "
+                        "profiles/r04/aa_clip_sq_counters_*.txt), so it is what the SIMDs really issued" % VALU_CYCLES,
             }
         else:
             out["roofline"] = {
