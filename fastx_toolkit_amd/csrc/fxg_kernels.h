@@ -352,6 +352,33 @@ FXG_HD float fxg_clip_row_score(const FxgKArgs &a, int A, u32 c, int q, float (&
     return rowmax;
 }
 
+// First 'N' of a read (the -n rule, fastx_clipper.cpp:306-311), for the two-pass forms, whose row loops do not look at it.  Rows that start on
+// a dword boundary (stride a multiple of 4: the staged tile is 16-byte aligned) are scanned four bases at a time: a byte of v ^ "NNNN" is
+// zero where the base is N, (x - 0x01010101) & ~x & 0x80808080 flags zero bytes -- a flag can be false only ABOVE a true one (the borrow), so the
+// lowest flag of a dword is always a true N.  Top down, so the last hit kept is the first N; the trip count is the wave's (fxg_wave_max).
+// (One byte per trip cost the default command line -- fastx_clipper without -n -- 9.5 % of the kernel: profiles/r04/ac_clip_n_rule.txt.)
+FXG_HD int fxg_clip_first_n(const uint8_t *rd, int len, int len_u, u32 stride, int first_n)
+{
+    if ((stride & 3u) == 0u) {
+#pragma unroll 1
+        for (int k = (len_u + 3) / 4 - 1; k >= 0; --k) {
+#ifdef FXG_HOST_EMULATION
+            u32 w; memcpy(&w, rd + 4 * k, 4);                      // (the emulator's rows need not be aligned)
+#else
+            const u32 w = reinterpret_cast<const u32 *>(rd)[k];
+#endif
+            const u32 v = w ^ 0x4E4E4E4Eu;
+            const u32 z = (v - 0x01010101u) & ~v & 0x80808080u;
+            const int pos = 4 * k + (int)((u32)__builtin_ctz(z | 0x80000000u) >> 3);      // the lowest flag (z | top bit: ctz is defined, and a hit there is checked like any other)
+            first_n = (z != 0u && pos < len) ? pos : first_n;
+        }
+    } else {
+#pragma unroll 1
+        for (int k = len_u - 1; k >= 0; --k) first_n = (k < len && rd[k] == (uint8_t)'N') ? k : first_n;
+    }
+    return first_n;
+}
+
 // returns the row the query_start field of bw counts from
 template <int AMAX>
 FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float &best, u32 &bw, u32 &bq, int &first_n, const bool UR = false)
@@ -428,9 +455,7 @@ FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int 
     fxg_clip_row_packed<AMAX, true, false, false, true>(a, A, (u32)rd[bq1], bq1, (u32)(bq1 - r0), S, Sm, W, best, bw, bq);
     // the -n rule needs the first N of the read itself (fastx_clipper.cpp:306-311); nothing else does
     if (!(a.clip_flags & FXG_CLIP_KEEP_N)) {
-        const int len_u = UR ? len : fxg_wave_max(len);
-#pragma unroll 1
-        for (int k = len_u - 1; k >= 0; --k) first_n = (k < len && rd[k] == (uint8_t)'N') ? k : first_n;
+        first_n = fxg_clip_first_n(rd, len, UR ? len : fxg_wave_max(len), a.clip_stride, first_n);
     }
     return r0;
 }
@@ -748,9 +773,7 @@ FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, in
     FXG_CLIP_DBG(12, fxg_dbg_hash(S)); FXG_CLIP_DBG(13, fxg_dbg_hash(W));
 #endif
     if (!(a.clip_flags & FXG_CLIP_KEEP_N)) {                                             // the -n rule needs the first N of the read itself
-        const int len_u = UR ? len : fxg_wave_max(len);
-#pragma unroll 1
-        for (int k = len_u - 1; k >= 0; --k) first_n = (k < len && rd[k] == (uint8_t)'N') ? k : first_n;
+        first_n = fxg_clip_first_n(rd, len, UR ? len : fxg_wave_max(len), a.clip_stride, first_n);
     }
     return r0;
 }

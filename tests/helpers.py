@@ -206,3 +206,36 @@ def adversarial_clip_cases(long_adapters):
         for flags in (0, 4, int(rng.integers(0, 16))):
             pd = dict(stages=1, adapter=ad, clip_min_len=int(rng.integers(0, 12)), clip_min_adapter_len=int(rng.choice([0, 0, 2, 5])), clip_flags=flags)
             yield "clip2.t%d.a%s.s%d.f%d" % (trial, ad.decode(), stride, flags), b, q, pd
+
+
+def first_n_cases(seed=41):
+    """Inputs for the clipper's -n rule (a read with an N before its clip point is dropped unless -n): the first N in every position class of the
+    dword scan -- byte 0..3 of a dword, the last valid base, the byte just PAST the end of a ragged read (must not count), a 0x4F / 0x4D byte right
+    above an N (what the zero-byte trick could mistake), no N at all -- for strides that are and are not multiples of 4, fixed and ragged,
+    short adapters (register form) and a 34-base one (checkpoint form).  Yields (name, bases, quals, lens, fixed_len, params)."""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for stride in (40, 41, 42, 43, 100, 150, 151):
+        for ragged in (False, True):
+            for ad in (b"AGATCGGAAGAGC", b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCAC"):
+                n = 192
+                b = rng.choice(acgt, size=(n, stride)).astype(np.uint8)
+                lens = rng.integers(max(1, stride - 9), stride + 1, size=n).astype(np.uint16) if ragged else None
+                for i in range(n):
+                    L = int(lens[i]) if ragged else stride
+                    kind = i % 8
+                    if kind == 0: continue                                   # no N
+                    if kind == 1: pos = [int(rng.integers(0, L))]
+                    elif kind == 2: pos = [L - 1]
+                    elif kind == 3: pos = [L] if L < stride else [L - 1]     # just past the end (ragged) -- not an N of the read
+                    elif kind == 4: pos = sorted(int(x) for x in rng.integers(0, L, size=3))
+                    elif kind == 5: pos = [4 * int(rng.integers(0, max(1, L // 4))) + int(rng.integers(0, 4))]
+                    elif kind == 6: pos = [int(rng.integers(0, L))]
+                    else: pos = [0]
+                    for x in pos:
+                        if x < stride: b[i, x] = ord("N")
+                    if kind == 6 and pos[0] + 1 < stride: b[i, pos[0] + 1] = ord("O") if i % 16 < 8 else ord("M")   # 'N' ^ 'O' = 1: the borrow case
+                q = rng.integers(33, 74, size=(n, stride), dtype=np.uint8)
+                pd = dict(stages=1, adapter=ad, clip_min_len=5, clip_flags=0)
+                yield ("first_n.s%d.%s.a%d" % (stride, "ragged" if ragged else "fixed", len(ad)), np.ascontiguousarray(b), q, lens, None if ragged else stride, pd)
+

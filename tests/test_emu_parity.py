@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import emu_py as emu
-from helpers import adversarial_clip_cases, assert_same, fuzz_cases, oracle_params
+from helpers import adversarial_clip_cases, assert_same, first_n_cases, fuzz_cases, oracle_params
 from oracle import fxoracle_py as fo
 
 
@@ -79,6 +79,19 @@ def test_emulated_clip_history_across_batches():
         fo.aligner_free(al)
         emu.hist_free(hs)
     assert differs > 1000          # reads aligned on their own would have come out differently
+
+
+def test_emulated_clip_first_n_rule():
+    """the -n rule's scan of the read for its first N (four bases at a time where the rows start on a dword boundary)"""
+    dropped = 0
+    for name, b, q, lens, fl, pd in first_n_cases():
+        hs = emu.hist_new()          # ragged reads: the reference's aligner carries its query buffer from read to read (N3), and so does the oracle
+        o = fo.run_pipeline(b, q, lens, oracle_params(pd), fixed_len=fl)
+        e = emu.run_pipeline(b, q, lens, oracle_params(pd), fixed_len=fl, hist=hs)
+        emu.hist_free(hs)
+        assert_same(o, e, name)
+        dropped += int(len(b) - o["counters"][1])
+    assert dropped > 1000
 
 
 def test_emulated_quality_stats_histogram():

@@ -7,7 +7,7 @@ size-independent properties (prefix/suffix windows vs the oracle, offset algebra
 import numpy as np
 import pytest
 
-from helpers import adversarial_clip_cases, assert_same, fuzz_cases, md5, oracle_params, random_batch
+from helpers import adversarial_clip_cases, assert_same, first_n_cases, fuzz_cases, md5, oracle_params, random_batch
 from oracle import fxoracle_py as fo
 
 pytestmark = pytest.mark.gpu
@@ -98,6 +98,21 @@ def test_fuzz_vs_oracle(engine):
         assert_same(o, e, name)
         kept += int(o["counters"][1])
     assert kept > 10000
+
+
+def test_clip_first_n_rule(engine):
+    """fastx_clipper WITHOUT -n (the default command line): a read with an N ahead of its clip point is dropped; the kernels find the first N of a read
+    four bases at a time where the rows start on a dword boundary (tests/helpers.py: first_n_cases has every position class of that scan)"""
+    dropped = 0
+    for name, b, q, lens, fl, pd in first_n_cases():
+        o = fo.run_pipeline(b, q, lens, oracle_params(pd), fixed_len=fl)
+        engine.set_clip_history(True)      # one aligner per call, as in the oracle (N3 matters for the ragged cases)
+        try:
+            assert_same(o, _run(engine, b, q, lens, pd, fixed_len=fl), name)
+        finally:
+            engine.set_clip_history(False)
+        dropped += int(len(b) - o["counters"][1])
+    assert dropped > 1000
 
 
 @pytest.mark.parametrize("long_adapters", [False, True])
