@@ -220,7 +220,7 @@ def e2e_leg(reads=16_000_000, big_reads=64_000_000, parts=4, lanes=2):
     `pipe`   = fastq_quality_trimmer -t 20 -l 30 | fastq_quality_filter -q 20 -p 80 (two processes, both on the GPU, as a user would type it)
     `fused`  = fastq_quality_trim_filter -t 20 -l 30 -q 20 -p 80 (one process, one pass; byte-identical output)
     `fused_to_devnull` = the same with -o /dev/null: what the tool does when the output file system is not the limit
-    `sharded` = the same command with FXH_PARTS=k (host/fxh_batch.c): k byte ranges of the input cut at record boundaries, k runs side by
+    `sharded` = the same command with FXH_PARTS=k (host/fxh_parts.c): k byte ranges of the input cut at record boundaries, k runs side by
                side in the process (own reader threads, lanes and writer thread each), k output parts; md5 of their concatenation
     `sharded_big` = the sharded run on a sample four times the size (process start and the first HIP context are ~0.2 s of every run),
                checked byte for byte against the one-stream output of the same input

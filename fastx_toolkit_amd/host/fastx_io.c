@@ -523,7 +523,7 @@ void fastx_init_writer(FASTX *fx, const char *filename, OUTPUT_FILE_TYPE output_
     fx->compress_output = compress_output;
     strncpy(fx->output_file_name, filename, sizeof fx->output_file_name - 1);
     {   /* "-o out.%r.fq" names the output parts of a sharded run (FXH_PARTS=k, or chosen by the tool: fxh_run_tool); this writer is
-         * part 0 (fxh_batch.c opens the others) */
+         * part 0 (fxh_parts.c opens the others) */
         char first[PATH_MAX];
         const char *pe = getenv("FXH_PARTS"), *pr = strstr(filename, "%r");
         if ((!pe || atoi(pe) >= 1) && pr && strlen(filename) < sizeof first - 8) {

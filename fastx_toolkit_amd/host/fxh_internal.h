@@ -1,4 +1,4 @@
-/* fxh_internal.h -- shared between fastx_io.c (record API) and fxh_batch.c (batch path). Not installed. */
+/* fxh_internal.h -- shared between fastx_io.c (record API) and the batch path (fxh_batch.c, fxh_io.c, fxh_lanes.c, fxh_parts.c). Not installed. */
 #ifndef FXH_INTERNAL_H
 #define FXH_INTERNAL_H
 #include <stddef.h>
@@ -11,7 +11,7 @@ struct fxh_reader {
     char *buf;
     size_t cap, beg, end;   /* unread bytes are buf[beg, end) */
     int eof;
-    off_t limit;            /* > 0: the input of this reader ends at this file offset (one part of a sharded run, fxh_batch.c) */
+    off_t limit;            /* > 0: the input of this reader ends at this file offset (one part of a sharded run, fxh_parts.c) */
 };
 
 struct fxh_writer {

@@ -286,11 +286,11 @@ int  fxg_set_clip_history(fxg_ctx *ctx, int on);
  * shard's counter block: concatenating the shards' packed outputs in shard order reproduces the single-GPU output.  These three
  * helpers are host arithmetic / I/O; they need no context and no device.  How the counter blocks travel is the caller's
  * business: an RCCL all-gather between processes (fastx_toolkit_amd/distributed.py), plain memory between the threads of one
- * process (host/fxh_batch.c). ---- */
+ * process (host/fxh_lanes.c, host/fxh_parts.c). ---- */
 int  fxg_device_count(void);   /* HIP devices visible to this process (0 if none) */
 /* NUMA node of the host memory nearest to HIP device `device` (its PCI function's /sys/bus/pci/devices/<id>/numa_node), -1 if unknown.
  * The boxes are two-socket machines with four GPUs per node: a host process whose page-locked buffers sit on the other socket uploads
- * across the socket link (host/fxh_batch.c binds a run that uses one GPU to that node's CPUs before it creates its threads and buffers). */
+ * across the socket link (host/fxh_lanes.c binds a run that uses one GPU to that node's CPUs before it creates its threads and buffers). */
 int  fxg_device_numa_node(int device);
 /* reads [*lo, *hi) of an n-read job owned by shard `rank` of `world`:  rank * n / world  ..  (rank + 1) * n / world */
 int  fxg_shard_range(uint64_t n, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi);
