@@ -77,6 +77,7 @@ struct FxgKArgs {
     u32  compact;           // 1 = stream-compact kept reads into out_bases/out_qual
     u32  debug;             // FXG_DEBUG ablation bits (timing experiments only; results are wrong when set)
     u32  depth;             // clip instances: slots = tiles a workgroup keeps between decision and write-out (2 or 3)
+    u32  clip_global;       // register two-pass clip instances: the DP reads the batch in global memory, no tile of bases is staged in LDS (fxg_plan.h)
     // folded tool parameters
     u32  stages;
     u32  tq;                // quality trimmer: byte >= tq  <=>  q >= -t      (0..128)

@@ -352,6 +352,17 @@ FXG_HD float fxg_clip_row_score(const FxgKArgs &a, int A, u32 c, int q, float (&
     return rowmax;
 }
 
+// dword i of a row that starts on a dword boundary, clamped to the array's last dword (the window of fxg_clip_two_pass<.., GL> runs two dwords ahead)
+FXG_HD u32 fxg_ld32(const uint8_t *row, int i, int imax)
+{
+    const int k = i < imax ? i : imax;
+#ifdef FXG_HOST_EMULATION
+    u32 w; memcpy(&w, row + 4 * (size_t)k, 4); return w;
+#else
+    return reinterpret_cast<const u32 *>(row)[k];
+#endif
+}
+
 // First 'N' of a read (the -n rule, fastx_clipper.cpp:306-311), for the two-pass forms, whose row loops do not look at it.  Rows that start on
 // a dword boundary (stride a multiple of 4: the staged tile is 16-byte aligned) are scanned four bases at a time: a byte of v ^ "NNNN" is
 // zero where the base is N, (x - 0x01010101) & ~x & 0x80808080 flags zero bytes -- a flag can be false only ABOVE a true one (the borrow), so the
@@ -380,7 +391,10 @@ FXG_HD int fxg_clip_first_n(const uint8_t *rd, int len, int len_u, u32 stride, i
 }
 
 // returns the row the query_start field of bw counts from
-template <int AMAX>
+// GL: `rd` points into the batch in global memory instead of a staged copy in LDS (fxg_plan.h: clip_global).  Pass 1, whose row number is a
+// scalar, then takes the row's base out of a two-dword window that moves on every fourth row (one 4-byte load per lane and four rows: byte loads,
+// each lane on a line of its own, would cost the CU's vector cache a lookup per lane and row); pass 2 and the N scan touch ~20 rows and read them directly.
+template <int AMAX, bool GL = false>
 FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float &best, u32 &bw, u32 &bq, int &first_n, const bool UR = false)
 {
     constexpr int C = FxgClip2<AMAX>::C;
@@ -396,7 +410,12 @@ FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int 
     // ---- pass 1 ----
     float b1 = -1000000.0f;
     int q = 0, r0 = 0, bq1 = 0;
-    u32 cn = rd[0];
+    u32 cn = 0u, gw0 = 0u, gw1 = 0u;
+    int gmax = 0;                                           // GL: last dword of the array that may be read, counted from this row's first
+    if constexpr (GL) {
+        gmax = (int)((a.clip_total - (u64)(rd - a.clip_src)) >> 2) - 1;
+        gw0 = fxg_ld32(rd, 0, gmax); gw1 = fxg_ld32(rd, 1, gmax);
+    } else cn = rd[0];
     // chunk j = rows [j C, j C + C): saves the row before it in Psave = P[j % 3]; the restart row for a best found in it is
     // Pwin = P[(j + 1) % 3] = the row before chunk j - 2 (before chunk 0 for j < 2: the border, which all three start from)
 #define FXG_CLIP_CHUNK(EARLY, Psave, Pwin)                                                                                   \
@@ -405,8 +424,11 @@ FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int 
         const int q0 = q, qend = q + C < rows_u ? q + C : rows_u;                                                            \
         bool upd = false;                                                                                                    \
         _Pragma("unroll 1") for (; q < qend; ++q) {                                                                          \
-            const u32 c = cn;                                                                                                \
-            cn = rd[q + 1];                                                                                                  \
+            u32 c;                                                                                                           \
+            if constexpr (GL) {                                                                                              \
+                c = (gw0 >> ((u32)(q & 3) << 3)) & 0xFFu;                                                                    \
+                if ((q & 3) == 3) { gw0 = gw1; gw1 = fxg_ld32(rd, (q >> 2) + 2, gmax); }                                     \
+            } else { c = cn; cn = rd[q + 1]; }                                                                               \
             if (!UR && q >= rows) continue;                                                                                  \
             const float rm = fxg_clip_row_score<AMAX, EARLY>(a, A, c, q, S, Sm);                                             \
             const bool g = rm > b1;                                                                                          \
@@ -780,7 +802,7 @@ FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, in
 
 // KFORM: the one-word summary of fxg_clip_row_k (17..99 columns; also 16 columns for reads beyond 255 bases, which the register
 // form of fxg_clip_two_pass cannot describe: its start field is absolute)
-template <int AMAX, bool KFORM, bool TN = false>
+template <int AMAX, bool KFORM, bool TN = false, bool GL = false>
 FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len, int rows,
                                  u32 *out_len, u32 *keep, u32 *reason, u32 *clipped, u32 *adapter_only, float *ck = nullptr, u32 cks = 0u, u32 *dbg = nullptr, const bool UR = false)
 {
@@ -789,7 +811,7 @@ FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len, 
     u32 bw = FXG_INVALID_TUPLE, bq = 0u;
     int first_n = len, qbase = 0;
 #ifndef FXG_CLIP_ONE_PASS
-    if constexpr (!KFORM) qbase = fxg_clip_two_pass<AMAX>(a, rd, len, rows, best, bw, bq, first_n, UR);
+    if constexpr (!KFORM) qbase = fxg_clip_two_pass<AMAX, GL>(a, rd, len, rows, best, bw, bq, first_n, UR);
     else
 #endif
     if constexpr (!KFORM) fxg_clip_rows_packed<AMAX, false>(a, rd, len, rows, best, bw, bq, first_n, UR);
@@ -911,7 +933,8 @@ FXG_HD void fxg_phase_stage_bases(const uint8_t *src, u64 total, u64 tb, u32 tby
 __host__ __device__ constexpr int fxg_clip_cols(int amax) { return amax <= -300 ? -amax - 300 : amax <= -200 ? -amax - 200 : -amax; }
 __host__ __device__ constexpr bool fxg_clip_kform(int amax) { return amax < -16; }
 __host__ __device__ constexpr bool fxg_clip_tn(int amax) { return amax <= -300; }
-template <int AMAX>
+// GL (register two-pass instances only): the DP reads the batch in global memory, nothing was staged (sb unused)
+template <int AMAX, bool GL = false>
 FXG_HD u32 fxg_decide_a(const FxgKArgs &a, const u32 *bm_g, const u32 *bm_l, const uint8_t *sb, u32 r0, u32 tid,
                         u32 *keep_out, u32 *len_out, float *ck = nullptr, u32 cks = 0u)      // ck: this thread's checkpoint scratch (fxg_clip_two_pass_k), cks its stride
 {
@@ -929,8 +952,9 @@ FXG_HD u32 fxg_decide_a(const FxgKArgs &a, const u32 *bm_g, const u32 *bm_l, con
 #else
         u32 *dbg = nullptr;
 #endif
-        if (!a.len && !a.wlen) fxg_clip_read_packed<COLS, KF, TN>(a, sb + tid * a.clip_stride, (int)a.fixed_len, (int)a.fixed_len, &curlen, &keep, &reason, &clipped, &ao, ck, cks, dbg, true);
-        else fxg_clip_read_packed<COLS, KF, TN>(a, sb + tid * a.clip_stride, (int)rl, rows, &curlen, &keep, &reason, &clipped, &ao, ck, cks, dbg);
+        const uint8_t *rd = GL ? a.clip_src + (u64)(r0 + tid) * a.clip_stride : sb + tid * a.clip_stride;
+        if (!a.len && !a.wlen) fxg_clip_read_packed<COLS, KF, TN, GL>(a, rd, (int)a.fixed_len, (int)a.fixed_len, &curlen, &keep, &reason, &clipped, &ao, ck, cks, dbg, true);
+        else fxg_clip_read_packed<COLS, KF, TN, GL>(a, rd, (int)rl, rows, &curlen, &keep, &reason, &clipped, &ao, ck, cks, dbg);
     }
     if (keep && (a.stages & FXG_STAGE_QTRIM)) {             // fastq_quality_trimmer.c:94-101
         const u32 k = fxg_bits_last(bm_g, tid * stride, curlen);
@@ -1085,7 +1109,7 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
     const u32 T = a.tile_reads, stride = a.stride, tid = threadIdx.x;
     const bool use_q = (MODE == 0 && (a.stages & (FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0) || MODE == 3;
     const u32 NSLOT = (MODE == 0 && AMAX != 0) ? a.depth : 2u;        // tiles between decision and write-out (fxg_plan.h)
-    const FxgLds L = fxg_lds_layout(T, stride, fxg_bitmap_count(a, use_q, MODE == 0 && AMAX != 0), (MODE == 0 && AMAX != 0) ? a.clip_stride : (MODE == 4 ? stride : 0u), NSLOT);
+    const FxgLds L = fxg_lds_layout(T, stride, fxg_bitmap_count(a, use_q, MODE == 0 && AMAX != 0), (MODE == 0 && AMAX != 0) ? (a.clip_global ? 0u : a.clip_stride) : (MODE == 4 ? stride : 0u), NSLOT);
     u32 m_reads = 0, m_nt = 0, art_bad = 0;      // MODE 3 report counters / MODE 4 alphabet check, folded once at the end
     u32 *bm_g = reinterpret_cast<u32 *>(smem + L.off_bm_g);
     u32 *bm_l = reinterpret_cast<u32 *>(smem + L.off_bm_l);
@@ -1142,7 +1166,7 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
             unsigned char *sl = smem + slot * L.slot_bytes;
             if constexpr (MODE == 0 || MODE == 3 || MODE == 4) {
                 if (use_q && !FXG_DBG(a, 8u)) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, TB);
-                if constexpr (MODE == 0 && AMAX != 0) { if (!FXG_DBG(a, 16u) || pend == FXG_NO_TILE) fxg_phase_stage_bases(a.clip_src, a.clip_total, (u64)r0 * a.clip_stride, nreads * a.clip_stride, sb, tid, TB); }   // 16: the DP on the workgroup's first tile over and over (the DP's own rate)
+                if constexpr (MODE == 0 && AMAX != 0) { if (!a.clip_global && (!FXG_DBG(a, 16u) || pend == FXG_NO_TILE)) fxg_phase_stage_bases(a.clip_src, a.clip_total, (u64)r0 * a.clip_stride, nreads * a.clip_stride, sb, tid, TB); }   // 16: the DP on the workgroup's first tile over and over (the DP's own rate)
                 if constexpr (MODE == 4) fxg_phase_stage_bases(a.bases, a.total_bytes, tb, tbytes, sb, tid, TB);
                 __syncthreads();
             }
@@ -1152,6 +1176,9 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
                 if constexpr (MODE == 0 && AMAX < -16) {
                     float *ck = a.clip_ck ? a.clip_ck + (size_t)blockIdx.x * ((size_t)FXG_CK_SLOTS * (u32)fxg_clip_cols(AMAX) * TB) + tid : nullptr;
                     word = fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen, ck, TB);
+                } else if constexpr (MODE == 0 && AMAX < 0) {     // register two-pass instances: the DP over the staged tile, or straight over the batch (fxg_plan.h: clip_global)
+                    if (a.clip_global) word = fxg_decide_a<AMAX, true>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen);
+                    else word = fxg_decide_a<AMAX, false>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen);
                 } else if constexpr (MODE == 0) word = fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen);
                 else if constexpr (MODE == 3) { u32 nl; word = fxg_decide_mask(a, bm_l, r0, tid, &keep, &olen, &nl); m_nt += nl; m_reads += (nl != 0u); }
                 else if constexpr (MODE == 4) word = fxg_decide_census(a, sb + tid * stride, r0, tid, &keep, &olen, &art_bad);

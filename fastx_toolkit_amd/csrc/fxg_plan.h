@@ -40,7 +40,7 @@ static inline u32 fxg_pick_tile(u32 stride, bool clip, u32 block = FXG_TBLOCK)
 static inline FxgLds fxg_plan_layout(const FxgPlan *pl)
 {
     const FxgKArgs &ka = pl->ka;
-    return pl->group_a ? fxg_lds_layout(ka.tile_reads, ka.stride, fxg_bitmap_count(ka, pl->use_q, pl->clip), pl->clip ? ka.clip_stride : 0u, pl->clip ? ka.depth : 2u)
+    return pl->group_a ? fxg_lds_layout(ka.tile_reads, ka.stride, fxg_bitmap_count(ka, pl->use_q, pl->clip), (pl->clip && !ka.clip_global) ? ka.clip_stride : 0u, pl->clip ? ka.depth : 2u)
          : pl->mask ? fxg_lds_layout(ka.tile_reads, ka.stride, 2u, 0u)
          : pl->artifacts ? fxg_lds_layout(ka.tile_reads, ka.stride, 0u, ka.stride) : fxg_lds_layout(ka.tile_reads, ka.stride, 0u, 0u);
 }
@@ -146,7 +146,24 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
         }
     }
     pl->block = pl->rows_nw ? 64u : (ga && pl->amax < 0 && pl->amax >= -16) ? (u32)FXG_CLIP_TBLOCK : (u32)FXG_TBLOCK;     // FxgTileBlock
-    const u32 T = pl->rows_nw ? 64u / (u32)pl->rows_h : fxg_pick_tile(pl->clip ? ka.clip_stride : in->stride, pl->clip || gf, pl->block);
+    // Register two-pass clip instances can run their DP straight over the batch in global memory (fxg_clip_two_pass<.., GL>): no tile of
+    // bases in LDS, so the tile stays at one read per thread whatever the read length.  Staged, a 256-thread workgroup holds 128 reads at
+    // 250-300 bases and 32 at 1 000 (the other lanes idle), and from about 180 bases on a CU holds two workgroups instead of three or four.
+    // The staged form is the faster one while it keeps three workgroups per CU (the window costs the row loop a branch and a shift:
+    // 100 bases 5.56 against 6.13 ms per 20 M reads, 176 bases 4.37 / 4.81 per 10 M), the other one from there on (188 bases 5.81 / 5.14,
+    // 300 bases 6.26 / 4.66 per 6 M, 1 000 bases 13.1 / 5.95 per 2 M: profiles/r04/ae_clip_global_vs_staged*.txt).  Rows must start on dword
+    // boundaries; runs with clip history (ragged input of the tools) keep the staged form.  FXG_CLIP_GLOBAL=0 / 1 overrides (tests run both).
+    ka.clip_global = 0u;
+    u32 T = pl->rows_nw ? 64u / (u32)pl->rows_h : fxg_pick_tile(pl->clip ? ka.clip_stride : in->stride, pl->clip || gf, pl->block);
+#ifndef FXG_CLIP_ONE_PASS
+    if (pl->clip && pl->amax < 0 && pl->amax >= -16 && clip_stride == 0u && (ka.clip_stride & 3u) == 0u && ((uintptr_t)ka.clip_src & 3u) == 0u) {      // (clip_stride != 0: a run with clip history, whose rows are settled after the plan)
+        ka.tile_reads = T; ka.depth = 2u;
+        const bool cramped = T < pl->block || (156u * 1024u) / fxg_plan_lds(pl) < 3u;
+        const char *e = getenv("FXG_CLIP_GLOBAL");
+        ka.clip_global = (e ? atoi(e) != 0 : cramped) ? 1u : 0u;
+        if (ka.clip_global) T = pl->block;
+    }
+#endif
     const u64 ntiles = (in->n + T - 1) / T;
     if (ntiles > 0x7FFFFFFFull || in->n > 0xFFFFFFFFull) FXG_PLAN_FAIL("batch too large (%llu reads): split it", (unsigned long long)in->n);
     ka.tile_reads = T; ka.ntiles = (u32)ntiles;

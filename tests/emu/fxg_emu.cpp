@@ -79,13 +79,15 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
         if (pl.group_a) {
             for (u32 tid = 0; tid < NT; ++tid) {
                 if (pl.use_q) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, NT);
-                if constexpr (AMAX != 0) fxg_phase_stage_bases(a.clip_src, a.clip_total, (u64)r0 * a.clip_stride, nreads * a.clip_stride, sb, tid, NT);
+                if constexpr (AMAX != 0) { if (!a.clip_global) fxg_phase_stage_bases(a.clip_src, a.clip_total, (u64)r0 * a.clip_stride, nreads * a.clip_stride, sb, tid, NT); }
             }
             for (u32 tid = 0; tid < nreads; ++tid) {
                 if (AMAX == 0 && pl.rows_nw) emu_rows_decide(pl.rows_nw, pl.rows_h, a, r0 + tid, &keep[tid], &olen[tid]);   // what a lane of fxg_kernel_rows does
                 else if (AMAX < -16 && pl.ck_per_wg) {        // the two-pass form with its checkpoint scratch (here: one thread's, stride 1)
                     std::vector<float> ck((size_t)FXG_CK_SLOTS * (size_t)(AMAX < 0 ? fxg_clip_cols(AMAX) : 1), (getenv("FXG_EMU_CK_FILL") ? (float)atof(getenv("FXG_EMU_CK_FILL")) : 1.0e30f));   // the device's scratch is not cleared either
                     fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid], ck.data(), 1u);
+                } else if (AMAX < 0 && AMAX >= -16 && a.clip_global) {     // the DP straight over the batch (fxg_plan.h: clip_global), as the kernel calls it
+                    if constexpr (AMAX < 0 && AMAX >= -16) fxg_decide_a<AMAX, true>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid]);
                 } else fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid]);
                 anchor[tid] = tid * stride;
             }

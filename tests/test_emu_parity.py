@@ -94,6 +94,31 @@ def test_emulated_clip_first_n_rule():
     assert dropped > 1000
 
 
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_emulated_clip_over_the_batch_and_over_the_staged_tile(monkeypatch, mode):
+    """fxg_plan.h clip_global: the register two-pass clip instances run their DP over a staged tile in LDS (0) or straight over the batch through a
+    two-dword window (1); the default picks by row length and stages.  Both forms, forced, on everything the clip tests have for fixed-length
+    batches and for ragged ones without history: configs 3 and 5, the clip fuzz, the adversarial corpus of the short adapters, the N-rule cases."""
+    monkeypatch.setenv("FXG_CLIP_GLOBAL", mode)
+    for args, pd in (((3, 0, 3000, 100, True), dict(stages=1, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=4)),
+                     ((5, 0, 3000, 150, True), dict(stages=7, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=4, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80)),
+                     ((5, 0, 1500, 300, True), dict(stages=1, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=0))):
+        b, q = fo.synth_batch(*args)
+        assert_same(fo.run_pipeline(b, q, None, oracle_params(pd)), emu.run_pipeline(b, q, None, oracle_params(pd)), "cfg%d.global%s" % (args[0], mode))
+    n = 0
+    for name, b, q, lens, fl, pd in fuzz_cases(23, trials=0, clip_trials=24):
+        assert_same(fo.run_pipeline(b, q, lens, oracle_params(pd), fixed_len=fl), emu.run_pipeline(b, q, lens, oracle_params(pd), fixed_len=fl), name + ".global" + mode)
+        n += 1
+    for name, b, q, pd in adversarial_clip_cases(False):
+        assert_same(fo.run_pipeline(b, q, None, oracle_params(pd)), emu.run_pipeline(b, q, None, oracle_params(pd)), name + ".global" + mode)
+        n += 1
+    for name, b, q, lens, fl, pd in first_n_cases():
+        if lens is None:
+            assert_same(fo.run_pipeline(b, q, None, oracle_params(pd), fixed_len=fl), emu.run_pipeline(b, q, None, oracle_params(pd), fixed_len=fl), name + ".global" + mode)
+            n += 1
+    assert n > 60
+
+
 def test_emulated_quality_stats_histogram():
     """fastx_quality_stats: the strip bodies of the reduction kernel against the oracle's per-cycle records, two batches of different width."""
     import ctypes as C

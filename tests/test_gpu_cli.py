@@ -276,6 +276,27 @@ def test_output_longer_than_input_and_ragged_blocks(tools):
 
 
 @pytest.mark.skipif(REF is None, reason="oracle/_ref/fxref not built")
+def test_clipper_long_fixed_length_reads_on_the_gpu_build(tools):
+    """fastx_clipper / fastx_clip_trim_filter on reads of ONE length beyond 160 bases: the lanes pack the rows with a stride rounded up to a
+    multiple of four (host/fxh_lanes.c) so that the clip kernel may read them where they are (csrc/fxg_plan.h: clip_global).  Lengths that are
+    and are not multiples of four, with and without -n, against the real libfastx."""
+    ad = "AGATCGGAAGAGC"
+    for L in (161, 250, 251, 300, 301):
+        data = fo.synth_fastq(70 + L, 0, 3000, L, True)
+        for argv in (["fastx_clipper", "-a", ad, "-l", "15", "-v"], ["fastx_clipper", "-a", ad, "-l", "15", "-n", "-v"]):
+            ref = _run([REF] + argv, data)
+            got = _run([os.path.join(tools, argv[0])] + argv[1:], data, dict(os.environ, FXH_TIMING="1"))
+            assert (got[0], got[1]) == (0, ref[1]), (L, argv, got[2][-300:])
+            assert b" 0 host-parsed blocks" in got[2], got[2][-300:]
+        chain = [["fastx_clipper", "-a", ad, "-l", "15", "-n"], ["fastq_quality_trimmer", "-t", "20", "-l", "30"], ["fastq_quality_filter", "-q", "20", "-p", "80"]]
+        want = data
+        for c in chain:
+            want = _run([REF] + c, want)[1]
+        got = _run([os.path.join(tools, "fastx_clip_trim_filter"), "-a", ad, "-l", "15", "-n", "-t", "20", "-m", "30", "-q", "20", "-p", "80"], data)
+        assert (got[0], got[1]) == (0, want), (L, got[2][-300:])
+
+
+@pytest.mark.skipif(REF is None, reason="oracle/_ref/fxref not built")
 def test_clipper_default_command_line_on_ragged_input(tools, tmp_path):
     """fastx_clipper with no environment variable on the real engine: parallel lanes while the reads have one length, the reference's one
     aligner (seeded with the last record before) from the first block that differs -- byte-identical to the real libfastx clipper when

@@ -115,6 +115,32 @@ def test_clip_first_n_rule(engine):
     assert dropped > 1000
 
 
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_clip_over_the_batch_and_over_the_staged_tile(engine, monkeypatch, mode):
+    """fxg_plan.h clip_global, both forms forced (see tests/test_emu_parity.py::test_emulated_clip_over_the_batch_and_over_the_staged_tile): the register
+    two-pass clip instances with their DP over the staged tile (0) and straight over the batch in global memory (1) -- configs 3 and 5 at 200 000 reads,
+    300- and 1 000-base reads, the clip fuzz, the adversarial corpus of the short adapters, the N-rule cases -- against the oracle."""
+    monkeypatch.setenv("FXG_CLIP_GLOBAL", mode)
+    for args, pd in (((3, 0, 200000, 100, True), dict(stages=1, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=4)),
+                     ((5, 0, 200000, 150, True), dict(stages=7, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=4, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80)),
+                     ((5, 0, 20000, 300, True), dict(stages=1, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=0)),
+                     ((7, 0, 6000, 1000, True), dict(stages=1, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=4))):
+        b, q = fo.synth_batch(*args)
+        assert_same(fo.run_pipeline(b, q, None, oracle_params(pd)), _run(engine, b, q, None, pd), "cfg%d.L%d.global%s" % (args[0], args[3], mode))
+    n = 0
+    for name, b, q, lens, fl, pd in fuzz_cases(23, trials=0, clip_trials=24):
+        assert_same(fo.run_pipeline(b, q, lens, oracle_params(pd), fixed_len=fl), _run(engine, b, q, lens, pd, fixed_len=fl), name + ".global" + mode)
+        n += 1
+    for name, b, q, pd in adversarial_clip_cases(False):
+        assert_same(fo.run_pipeline(b, q, None, oracle_params(pd)), _run(engine, b, q, None, pd), name + ".global" + mode)
+        n += 1
+    for name, b, q, lens, fl, pd in first_n_cases():
+        if lens is None:
+            assert_same(fo.run_pipeline(b, q, None, oracle_params(pd), fixed_len=fl), _run(engine, b, q, None, pd, fixed_len=fl), name + ".global" + mode)
+            n += 1
+    assert n > 60
+
+
 @pytest.mark.parametrize("long_adapters", [False, True])
 def test_clip_adversarial_every_adapter_bucket(engine, long_adapters):
     """Every clip instance on the inputs built against its assumptions (helpers.adversarial_clip_cases): adapters of 1..16 bases run

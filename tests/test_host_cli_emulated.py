@@ -444,6 +444,27 @@ def test_regular_files_use_parallel_io_same_bytes(tools, tmp_path):
     assert p.returncode == 0 and outp.read_bytes() == b"HEAD\n" + want[1]
 
 
+@pytest.mark.skipif(REF is None, reason="oracle/_ref/fxref not built")
+def test_clipper_long_fixed_length_reads_get_dword_rows(tools):
+    """fastx_clipper / fastx_clip_trim_filter on reads of ONE length beyond 160 bases: the lanes pack the rows with a stride rounded up to a
+    multiple of four (host/fxh_lanes.c) so that the clip kernel may read them where they are (csrc/fxg_plan.h: clip_global).  Lengths that are
+    and are not multiples of four, with and without -n, against the real libfastx."""
+    ad = "AGATCGGAAGAGC"
+    for L in (161, 250, 251, 300, 301):
+        data = fo.synth_fastq(70 + L, 0, 3000, L, True)
+        for argv in (["fastx_clipper", "-a", ad, "-l", "15", "-v"], ["fastx_clipper", "-a", ad, "-l", "15", "-n", "-v"]):
+            ref = _run([REF] + argv, data)
+            got = _run([os.path.join(tools, argv[0])] + argv[1:], data, extra_env={"FXH_TIMING": "1"})
+            assert (got[0], got[1]) == (0, ref[1]), (L, argv, got[2][-300:])
+            assert b" 0 host-parsed blocks" in got[2], got[2][-300:]
+        chain = [["fastx_clipper", "-a", ad, "-l", "15", "-n"], ["fastq_quality_trimmer", "-t", "20", "-l", "30"], ["fastq_quality_filter", "-q", "20", "-p", "80"]]
+        want = data
+        for c in chain:
+            want = _run([REF] + c, want)[1]
+        got = _run([os.path.join(tools, "fastx_clip_trim_filter"), "-a", ad, "-l", "15", "-n", "-t", "20", "-m", "30", "-q", "20", "-p", "80"], data)
+        assert (got[0], got[1]) == (0, want), (L, got[2][-300:])
+
+
 def test_one_long_read_among_short_ones_does_not_blow_up_the_rows(tools):
     """The SoA rows are n x longest read: the host path cuts a batch at a record boundary when one long read would make the rows
     many times the size of the text (a 20 kb read among 200 k short ones would otherwise ask for gigabytes of pinned memory)."""
