@@ -677,7 +677,7 @@ FXG_HD u32 fxg_fbits(float) { return 0u; }
 #define FXG_CLIP_DBG(i, v) do { } while (0)
 #endif
 // returns r0 (the row the `start` field of bw counts from)
-template <int AMAX, bool TN>
+template <int AMAX, bool TN, bool GL = false>      // GL: as in fxg_clip_two_pass
 FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float *ck, u32 cks, float &best, u32 &bw, u32 &bq, int &first_n, u32 *dbg = nullptr, const bool UR = false)
 {
     (void)dbg;
@@ -695,7 +695,12 @@ FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, in
     float b1 = -1000000.0f;
     int bq1 = 0, next_ck = K, q = 0;
     float *slot = ck;
-    u32 cn = rd[0];
+    u32 cn = 0u, gw0 = 0u, gw1 = 0u;
+    int gmax = 0;
+    if constexpr (GL) {
+        gmax = (int)((a.clip_total - (u64)(rd - a.clip_src)) >> 2) - 1;
+        gw0 = fxg_ld32(rd, 0, gmax); gw1 = fxg_ld32(rd, 1, gmax);
+    } else cn = rd[0];
 #define FXG_CK_ROW(EARLY)                                                                                                    \
     {                                                                                                                        \
         const bool mine = UR || q < rows;                                                                                    \
@@ -703,8 +708,11 @@ FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, in
             if (mine) { _Pragma("unroll") for (int t = 0; t < AMAX; ++t) slot[(size_t)t * cks] = S[t]; }                     \
             slot += (size_t)AMAX * cks; next_ck += K;                                                                        \
         }                                                                                                                    \
-        const u32 c = cn;                                                                                                    \
-        cn = rd[q + 1];                                                                                                      \
+        u32 c;                                                                                                               \
+        if constexpr (GL) {                                                                                                  \
+            c = (gw0 >> ((u32)(q & 3) << 3)) & 0xFFu;                                                                        \
+            if ((q & 3) == 3) { gw0 = gw1; gw1 = fxg_ld32(rd, (q >> 2) + 2, gmax); }                                         \
+        } else { c = cn; cn = rd[q + 1]; }                                                                                   \
         if (mine) {                                                                                                          \
             const float rm = fxg_clip_row_score_k<AMAX, EARLY, TN>(a, A, c, q, S, Sm);                                       \
             const bool g = rm > b1;                                                                                          \
@@ -817,7 +825,7 @@ FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len, 
     if constexpr (!KFORM) fxg_clip_rows_packed<AMAX, false>(a, rd, len, rows, best, bw, bq, first_n, UR);
     if constexpr (KFORM) {
         int r0 = 0;
-        if (ck) r0 = fxg_clip_two_pass_k<AMAX, TN>(a, rd, len, rows, ck, cks, best, bw, bq, first_n, dbg, UR);
+        if (ck) r0 = fxg_clip_two_pass_k<AMAX, TN, GL>(a, rd, len, rows, ck, cks, best, bw, bq, first_n, dbg, UR);
         else fxg_clip_rows_k<AMAX, TN>(a, rd, len, rows, best, bw, bq, first_n, UR);
         const int v = (int)(bw >> 23), matches = (int)(bw & 127u), diag = (int)((bw >> 7) & 127u);
         fxg_clip_finish(a, len, v < 256 ? r0 + v : 0, v < 256 ? 0 : v - 256, diag - matches, (int)((bw >> 14) & 511u), matches,
@@ -933,7 +941,7 @@ FXG_HD void fxg_phase_stage_bases(const uint8_t *src, u64 total, u64 tb, u32 tby
 __host__ __device__ constexpr int fxg_clip_cols(int amax) { return amax <= -300 ? -amax - 300 : amax <= -200 ? -amax - 200 : -amax; }
 __host__ __device__ constexpr bool fxg_clip_kform(int amax) { return amax < -16; }
 __host__ __device__ constexpr bool fxg_clip_tn(int amax) { return amax <= -300; }
-// GL (register two-pass instances only): the DP reads the batch in global memory, nothing was staged (sb unused)
+// GL (two-pass forms only): the DP reads the batch in global memory, nothing was staged (sb unused)
 template <int AMAX, bool GL = false>
 FXG_HD u32 fxg_decide_a(const FxgKArgs &a, const u32 *bm_g, const u32 *bm_l, const uint8_t *sb, u32 r0, u32 tid,
                         u32 *keep_out, u32 *len_out, float *ck = nullptr, u32 cks = 0u)      // ck: this thread's checkpoint scratch (fxg_clip_two_pass_k), cks its stride
@@ -1175,7 +1183,8 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
             if (tid < nreads) {
                 if constexpr (MODE == 0 && AMAX < -16) {
                     float *ck = a.clip_ck ? a.clip_ck + (size_t)blockIdx.x * ((size_t)FXG_CK_SLOTS * (u32)fxg_clip_cols(AMAX) * TB) + tid : nullptr;
-                    word = fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen, ck, TB);
+                    if (a.clip_global) word = fxg_decide_a<AMAX, true>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen, ck, TB);      // (only with checkpoint scratch: fxg_plan.h)
+                    else word = fxg_decide_a<AMAX, false>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen, ck, TB);
                 } else if constexpr (MODE == 0 && AMAX < 0) {     // register two-pass instances: the DP over the staged tile, or straight over the batch (fxg_plan.h: clip_global)
                     if (a.clip_global) word = fxg_decide_a<AMAX, true>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen);
                     else word = fxg_decide_a<AMAX, false>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen);

@@ -146,7 +146,7 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
         }
     }
     pl->block = pl->rows_nw ? 64u : (ga && pl->amax < 0 && pl->amax >= -16) ? (u32)FXG_CLIP_TBLOCK : (u32)FXG_TBLOCK;     // FxgTileBlock
-    // Register two-pass clip instances can run their DP straight over the batch in global memory (fxg_clip_two_pass<.., GL>): no tile of
+    // The two-pass clip forms can run their DP straight over the batch in global memory (fxg_clip_two_pass<.., GL>, fxg_clip_two_pass_k<.., GL>): no tile of
     // bases in LDS, so the tile stays at one read per thread whatever the read length.  Staged, a 256-thread workgroup holds 128 reads at
     // 250-300 bases and 32 at 1 000 (the other lanes idle), and from about 180 bases on a CU holds two workgroups instead of three or four.
     // The staged form is the faster one while it keeps three workgroups per CU (the window costs the row loop a branch and a shift:
@@ -156,7 +156,7 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     ka.clip_global = 0u;
     u32 T = pl->rows_nw ? 64u / (u32)pl->rows_h : fxg_pick_tile(pl->clip ? ka.clip_stride : in->stride, pl->clip || gf, pl->block);
 #ifndef FXG_CLIP_ONE_PASS
-    if (pl->clip && pl->amax < 0 && pl->amax >= -16 && clip_stride == 0u && (ka.clip_stride & 3u) == 0u && ((uintptr_t)ka.clip_src & 3u) == 0u) {      // (clip_stride != 0: a run with clip history, whose rows are settled after the plan)
+    if (pl->clip && pl->amax < 0 && (pl->amax >= -16 || pl->ck_per_wg != 0) && clip_stride == 0u && (ka.clip_stride & 3u) == 0u && ((uintptr_t)ka.clip_src & 3u) == 0u) {      // (clip_stride != 0: a run with clip history, whose rows are settled after the plan)
         ka.tile_reads = T; ka.depth = 2u;
         const bool cramped = T < pl->block || (156u * 1024u) / fxg_plan_lds(pl) < 3u;
         const char *e = getenv("FXG_CLIP_GLOBAL");

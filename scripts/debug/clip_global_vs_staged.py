@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from fastx_toolkit_amd import Engine, make_params
 eng = Engine(0)
-AD = b"AGATCGGAAGAGC"
+AD = os.environ.get("ADAPTER", "AGATCGGAAGAGC").encode()
 SHAPES = ((100, 20_000_000, 1), (150, 20_000_000, 7), (152, 10_000_000, 1), (200, 10_000_000, 1), (252, 8_000_000, 1), (300, 6_000_000, 1), (300, 6_000_000, 7), (1000, 2_000_000, 1))
 if os.environ.get('SHAPES'):
     SHAPES = tuple(tuple(int(x) for x in t.split(':')) for t in os.environ['SHAPES'].split(','))
@@ -23,6 +23,6 @@ for L, R, stages in SHAPES:
         for _ in range(3):
             r = eng.run(b, q, P, fixed_len=L, compact=True, meta=False, outputs=outs); ms.append(eng.last_kernel_ms())
         li = eng.last_launch()
-        row["default" if mode is None else ("global" if mode == "1" else "staged")] = dict(ms=round(min(ms), 3), gcups=round(R * L * 13 / min(ms) / 1e6, 0), tile=li["tile_reads"], lds=li["lds"], kept=int(r.counters[1]))
+        row["default" if mode is None else ("global" if mode == "1" else "staged")] = dict(ms=round(min(ms), 3), gcups=round(R * L * len(AD) / min(ms) / 1e6, 0), kernel=li['kernel'].split()[0], tile=li["tile_reads"], lds=li["lds"], kept=int(r.counters[1]))
     print(json.dumps(row), flush=True)
     del b, q, outs

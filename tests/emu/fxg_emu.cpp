@@ -85,7 +85,8 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
                 if (AMAX == 0 && pl.rows_nw) emu_rows_decide(pl.rows_nw, pl.rows_h, a, r0 + tid, &keep[tid], &olen[tid]);   // what a lane of fxg_kernel_rows does
                 else if (AMAX < -16 && pl.ck_per_wg) {        // the two-pass form with its checkpoint scratch (here: one thread's, stride 1)
                     std::vector<float> ck((size_t)FXG_CK_SLOTS * (size_t)(AMAX < 0 ? fxg_clip_cols(AMAX) : 1), (getenv("FXG_EMU_CK_FILL") ? (float)atof(getenv("FXG_EMU_CK_FILL")) : 1.0e30f));   // the device's scratch is not cleared either
-                    fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid], ck.data(), 1u);
+                    if (a.clip_global) { if constexpr (AMAX < -16) fxg_decide_a<AMAX, true>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid], ck.data(), 1u); }
+                    else fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid], ck.data(), 1u);
                 } else if (AMAX < 0 && AMAX >= -16 && a.clip_global) {     // the DP straight over the batch (fxg_plan.h: clip_global), as the kernel calls it
                     if constexpr (AMAX < 0 && AMAX >= -16) fxg_decide_a<AMAX, true>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid]);
                 } else fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid]);

@@ -102,16 +102,20 @@ def test_emulated_clip_over_the_batch_and_over_the_staged_tile(monkeypatch, mode
     monkeypatch.setenv("FXG_CLIP_GLOBAL", mode)
     for args, pd in (((3, 0, 3000, 100, True), dict(stages=1, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=4)),
                      ((5, 0, 3000, 150, True), dict(stages=7, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=4, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80)),
-                     ((5, 0, 1500, 300, True), dict(stages=1, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=0))):
+                     ((5, 0, 1500, 300, True), dict(stages=1, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=0)),
+                     ((8, 0, 1200, 252, True), dict(stages=1, adapter=b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCAC", clip_min_len=15, clip_flags=0)),
+                     ((9, 0, 800, 300, True), dict(stages=7, adapter=b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCGTATGCCGTCTTCTGCTTG", clip_min_len=15, clip_flags=4,
+                                                   qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80))):
         b, q = fo.synth_batch(*args)
         assert_same(fo.run_pipeline(b, q, None, oracle_params(pd)), emu.run_pipeline(b, q, None, oracle_params(pd)), "cfg%d.global%s" % (args[0], mode))
     n = 0
     for name, b, q, lens, fl, pd in fuzz_cases(23, trials=0, clip_trials=24):
         assert_same(fo.run_pipeline(b, q, lens, oracle_params(pd), fixed_len=fl), emu.run_pipeline(b, q, lens, oracle_params(pd), fixed_len=fl), name + ".global" + mode)
         n += 1
-    for name, b, q, pd in adversarial_clip_cases(False):
-        assert_same(fo.run_pipeline(b, q, None, oracle_params(pd)), emu.run_pipeline(b, q, None, oracle_params(pd)), name + ".global" + mode)
-        n += 1
+    for long_adapters in (False, True):                      # 1..16 columns: the register form; 17..99: the checkpoint form
+        for name, b, q, pd in adversarial_clip_cases(long_adapters):
+            assert_same(fo.run_pipeline(b, q, None, oracle_params(pd)), emu.run_pipeline(b, q, None, oracle_params(pd)), name + ".global" + mode)
+            n += 1
     for name, b, q, lens, fl, pd in first_n_cases():
         if lens is None:
             assert_same(fo.run_pipeline(b, q, None, oracle_params(pd), fixed_len=fl), emu.run_pipeline(b, q, None, oracle_params(pd), fixed_len=fl), name + ".global" + mode)

@@ -124,16 +124,20 @@ def test_clip_over_the_batch_and_over_the_staged_tile(engine, monkeypatch, mode)
     for args, pd in (((3, 0, 200000, 100, True), dict(stages=1, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=4)),
                      ((5, 0, 200000, 150, True), dict(stages=7, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=4, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80)),
                      ((5, 0, 20000, 300, True), dict(stages=1, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=0)),
-                     ((7, 0, 6000, 1000, True), dict(stages=1, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=4))):
+                     ((7, 0, 6000, 1000, True), dict(stages=1, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=4)),
+                     ((8, 0, 20000, 252, True), dict(stages=1, adapter=b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCAC", clip_min_len=15, clip_flags=0)),
+                     ((9, 0, 20000, 300, True), dict(stages=7, adapter=b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCGTATGCCGTCTTCTGCTTG", clip_min_len=15, clip_flags=4,
+                                                     qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80))):
         b, q = fo.synth_batch(*args)
         assert_same(fo.run_pipeline(b, q, None, oracle_params(pd)), _run(engine, b, q, None, pd), "cfg%d.L%d.global%s" % (args[0], args[3], mode))
     n = 0
     for name, b, q, lens, fl, pd in fuzz_cases(23, trials=0, clip_trials=24):
         assert_same(fo.run_pipeline(b, q, lens, oracle_params(pd), fixed_len=fl), _run(engine, b, q, lens, pd, fixed_len=fl), name + ".global" + mode)
         n += 1
-    for name, b, q, pd in adversarial_clip_cases(False):
-        assert_same(fo.run_pipeline(b, q, None, oracle_params(pd)), _run(engine, b, q, None, pd), name + ".global" + mode)
-        n += 1
+    for long_adapters in (False, True):                      # 1..16 columns: the register form; 17..99: the checkpoint form
+        for name, b, q, pd in adversarial_clip_cases(long_adapters):
+            assert_same(fo.run_pipeline(b, q, None, oracle_params(pd)), _run(engine, b, q, None, pd), name + ".global" + mode)
+            n += 1
     for name, b, q, lens, fl, pd in first_n_cases():
         if lens is None:
             assert_same(fo.run_pipeline(b, q, None, oracle_params(pd), fixed_len=fl), _run(engine, b, q, None, pd, fixed_len=fl), name + ".global" + mode)
