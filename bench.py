@@ -585,7 +585,7 @@ def main():
     if os.path.exists(pmc):
         try:
             pj = json.load(open(pmc))
-            if pj.get("reads_per_launch") == R and (compact or is_stats) and pj.get("csrc_sha16") == csrc_sha16() and pj.get("kernel_name", "").split("(")[0].replace(",1>", ">") in launch["kernel"].replace(" ", ""):
+            if pj.get("reads_per_launch") == R and (compact or is_stats) and pj.get("csrc_sha16") == csrc_sha16() and pj.get("kernel_name", "").split("(")[0].replace(",1>", ">").replace(",false>", ">").replace(",true>", ">") in launch["kernel"].replace(" ", ""):
                 traffic = pj.get("hbm_bytes_per_launch")
                 traffic_source = "replayed from profiles/pmc_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of %s on csrc %s); not measured in this run" % (
                     args.config, pj.get("command", "scripts/pmc_run.py"), pj.get("csrc_sha16"))

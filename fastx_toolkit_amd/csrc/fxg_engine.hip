@@ -407,6 +407,7 @@ extern "C" int fxg_run_pipeline(fxg_ctx *c, const fxg_batch *in, const fxg_param
     }
     u64 *ctr = (u64 *)out->counters;
 #define FXG_TILES_A(N) (fxg_kernel_tiles<N, 0>)
+#define FXG_TILES_C(N) (pl.ka.clip_global ? fxg_kernel_tiles<N, 0, true> : fxg_kernel_tiles<N, 0, false>)      // packed clip instances: the DP over the staged tile, or over the batch (fxg_plan.h)
     if (pl.rows_nw) {       // rows of 80..152 bytes through the quality stages: one lane per read, rows in registers (fxg_rows.h)
         if (pl.rows_h == 2) {     // rows of 153..304 bytes: two lanes per read
             if (pl.rows_nw == 26) return fxg_launch_tiles(c, fxg_kernel_rows<26, 2>, "fxg_kernel_rows<26,2> qtrim+qfilter", pl.ka, pl.lds, ctr, 64u, true);
@@ -420,34 +421,34 @@ extern "C" int fxg_run_pipeline(fxg_ctx *c, const fxg_batch *in, const fxg_param
     if (pl.group_a) {
         switch (pl.amax) {
         case 0: return fxg_launch_tiles(c, FXG_TILES_A(0), "fxg_kernel_tiles<0,0> qtrim+qfilter", pl.ka, pl.lds, ctr);
-        case -4: return fxg_launch_tiles(c, FXG_TILES_A(-4), "fxg_kernel_tiles<-4,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
-        case -8: return fxg_launch_tiles(c, FXG_TILES_A(-8), "fxg_kernel_tiles<-8,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
-        case -9: return fxg_launch_tiles(c, FXG_TILES_A(-9), "fxg_kernel_tiles<-9,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
-        case -10: return fxg_launch_tiles(c, FXG_TILES_A(-10), "fxg_kernel_tiles<-10,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
-        case -11: return fxg_launch_tiles(c, FXG_TILES_A(-11), "fxg_kernel_tiles<-11,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
-        case -12: return fxg_launch_tiles(c, FXG_TILES_A(-12), "fxg_kernel_tiles<-12,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
-        case -13: return fxg_launch_tiles(c, FXG_TILES_A(-13), "fxg_kernel_tiles<-13,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
-        case -14: return fxg_launch_tiles(c, FXG_TILES_A(-14), "fxg_kernel_tiles<-14,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
-        case -15: return fxg_launch_tiles(c, FXG_TILES_A(-15), "fxg_kernel_tiles<-15,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
-        case -16: return fxg_launch_tiles(c, FXG_TILES_A(-16), "fxg_kernel_tiles<-16,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
-        case -20: return fxg_launch_tiles(c, FXG_TILES_A(-20), "fxg_kernel_tiles<-20,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
-        case -24: return fxg_launch_tiles(c, FXG_TILES_A(-24), "fxg_kernel_tiles<-24,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
-        case -28: return fxg_launch_tiles(c, FXG_TILES_A(-28), "fxg_kernel_tiles<-28,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
-        case -32: return fxg_launch_tiles(c, FXG_TILES_A(-32), "fxg_kernel_tiles<-32,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
-        case -36: return fxg_launch_tiles(c, FXG_TILES_A(-36), "fxg_kernel_tiles<-36,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
-        case -40: return fxg_launch_tiles(c, FXG_TILES_A(-40), "fxg_kernel_tiles<-40,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
-        case -48: return fxg_launch_tiles(c, FXG_TILES_A(-48), "fxg_kernel_tiles<-48,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
-        case -64: return fxg_launch_tiles(c, FXG_TILES_A(-64), "fxg_kernel_tiles<-64,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
-        case -316: return fxg_launch_tiles(c, FXG_TILES_A(-316), "fxg_kernel_tiles<-316,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
-        case -324: return fxg_launch_tiles(c, FXG_TILES_A(-324), "fxg_kernel_tiles<-324,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
-        case -336: return fxg_launch_tiles(c, FXG_TILES_A(-336), "fxg_kernel_tiles<-336,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
-        case -348: return fxg_launch_tiles(c, FXG_TILES_A(-348), "fxg_kernel_tiles<-348,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
-        case -364: return fxg_launch_tiles(c, FXG_TILES_A(-364), "fxg_kernel_tiles<-364,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
-        case -400: return fxg_launch_tiles(c, FXG_TILES_A(-400), "fxg_kernel_tiles<-400,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -4: return fxg_launch_tiles(c, FXG_TILES_C(-4), "fxg_kernel_tiles<-4,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
+        case -8: return fxg_launch_tiles(c, FXG_TILES_C(-8), "fxg_kernel_tiles<-8,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
+        case -9: return fxg_launch_tiles(c, FXG_TILES_C(-9), "fxg_kernel_tiles<-9,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
+        case -10: return fxg_launch_tiles(c, FXG_TILES_C(-10), "fxg_kernel_tiles<-10,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
+        case -11: return fxg_launch_tiles(c, FXG_TILES_C(-11), "fxg_kernel_tiles<-11,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
+        case -12: return fxg_launch_tiles(c, FXG_TILES_C(-12), "fxg_kernel_tiles<-12,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
+        case -13: return fxg_launch_tiles(c, FXG_TILES_C(-13), "fxg_kernel_tiles<-13,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
+        case -14: return fxg_launch_tiles(c, FXG_TILES_C(-14), "fxg_kernel_tiles<-14,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
+        case -15: return fxg_launch_tiles(c, FXG_TILES_C(-15), "fxg_kernel_tiles<-15,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
+        case -16: return fxg_launch_tiles(c, FXG_TILES_C(-16), "fxg_kernel_tiles<-16,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, pl.block);
+        case -20: return fxg_launch_tiles(c, FXG_TILES_C(-20), "fxg_kernel_tiles<-20,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -24: return fxg_launch_tiles(c, FXG_TILES_C(-24), "fxg_kernel_tiles<-24,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -28: return fxg_launch_tiles(c, FXG_TILES_C(-28), "fxg_kernel_tiles<-28,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -32: return fxg_launch_tiles(c, FXG_TILES_C(-32), "fxg_kernel_tiles<-32,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -36: return fxg_launch_tiles(c, FXG_TILES_C(-36), "fxg_kernel_tiles<-36,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -40: return fxg_launch_tiles(c, FXG_TILES_C(-40), "fxg_kernel_tiles<-40,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -48: return fxg_launch_tiles(c, FXG_TILES_C(-48), "fxg_kernel_tiles<-48,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -64: return fxg_launch_tiles(c, FXG_TILES_C(-64), "fxg_kernel_tiles<-64,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -316: return fxg_launch_tiles(c, FXG_TILES_C(-316), "fxg_kernel_tiles<-316,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -324: return fxg_launch_tiles(c, FXG_TILES_C(-324), "fxg_kernel_tiles<-324,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -336: return fxg_launch_tiles(c, FXG_TILES_C(-336), "fxg_kernel_tiles<-336,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -348: return fxg_launch_tiles(c, FXG_TILES_C(-348), "fxg_kernel_tiles<-348,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -364: return fxg_launch_tiles(c, FXG_TILES_C(-364), "fxg_kernel_tiles<-364,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -400: return fxg_launch_tiles(c, FXG_TILES_C(-400), "fxg_kernel_tiles<-400,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
 #ifdef FXG_CLIP_ONE_PASS     // (ablation build only: reads beyond 255 bases with a short adapter; the regular build's register form takes them)
-        case -216: return fxg_launch_tiles(c, FXG_TILES_A(-216), "fxg_kernel_tiles<-216,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -216: return fxg_launch_tiles(c, FXG_TILES_C(-216), "fxg_kernel_tiles<-216,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
 #endif
-        case -100: return fxg_launch_tiles(c, FXG_TILES_A(-100), "fxg_kernel_tiles<-100,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -100: return fxg_launch_tiles(c, FXG_TILES_C(-100), "fxg_kernel_tiles<-100,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case 16: return fxg_launch_tiles(c, FXG_TILES_A(16), "fxg_kernel_tiles<16,0> clip[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
         case 32: return fxg_launch_tiles(c, FXG_TILES_A(32), "fxg_kernel_tiles<32,0> clip[+qtrim+qfilter]", pl.ka, pl.lds, ctr);
         case 64: return fxg_launch_tiles(c, FXG_TILES_A(64), "fxg_kernel_tiles<64,0> clip[+qtrim+qfilter]", pl.ka, pl.lds, ctr);

@@ -31,13 +31,13 @@ struct FxgLds {
 __host__ __device__ inline u32 fxg_r16(u32 x) { return (x + 15u) & ~15u; }
 // nslots: tiles a workgroup keeps between decision and write-out (FxgTileDepth: 2, the clip instances 3)
 // bitmaps: 0 none, 2 both, 1 = ONE shared by trimmer and filter (same threshold: "below" is the complement of "at least"; off_bm_l == off_bm_g)
-__host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, u32 bitmaps, u32 stage_stride, u32 nslots = 2)   // stage_stride: row stride of the LDS copy of the tile's bases, 0 = none
+__host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, u32 bitmaps, u32 stage_stride, u32 nslots = 2, bool no_tab = false)   // stage_stride: row stride of the LDS copy of the tile's bases, 0 = none
 {
     FxgLds l;
     l.so_ksrc = fxg_r16((T + 1) * 4);
     l.so_kidx = l.so_ksrc + fxg_r16(T * 4);
     l.so_ktab = l.so_kidx + fxg_r16(T * 2);
-    l.has_tab = stage_stride ? 0u : 1u;
+    l.has_tab = (stage_stride || no_tab) ? 0u : 1u;      // (no_tab: the clip instances whose DP reads the batch itself -- the table of a 1 000-base tile would be 32 KB per slot)
     l.slot_bytes = l.so_ktab + (l.has_tab ? fxg_r16(((T * stride + 15) / 16 + 1) * 2) : 0u);
     u32 o = nslots * l.slot_bytes;
     l.off_scratch = o; o += fxg_r16(48 * 4);
@@ -1108,7 +1108,9 @@ __host__ __device__ constexpr int fxg_clip_waves(int amax) { return amax > 0 ? 1
 __host__ __device__ constexpr int fxg_clip_waves(int amax) { return amax > 0 ? 1 : fxg_clip_cols(amax) <= 36 ? FXG_CLIP_WAVES : fxg_clip_cols(amax) <= 64 ? 3 : FXG_CLIP_WAVES_WIDE; }
 #endif
 template <int AMAX, int MODE> struct FxgTileBlock { static constexpr int threads = (MODE == 0 && AMAX < 0 && AMAX >= -16) ? FXG_CLIP_TBLOCK : FXG_TBLOCK; };
-template <int AMAX, int MODE>
+// GL (clip instances, a.clip_global): the DP reads the batch itself (fxg_clip_two_pass<.., GL>) -- a kernel of its own, so that the staged form's code and
+// register allocation are exactly what they are without it (both forms in one kernel cost cfg3 1.6 % and cfg5 2.1 %, profiles/r04/ai_ab_pre_gl_vs_head.txt)
+template <int AMAX, int MODE, bool GL = false>
 __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? FXG_MIN_WAVES : fxg_clip_waves(AMAX))) void fxg_kernel_tiles(const FxgKArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1117,7 +1119,7 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
     const u32 T = a.tile_reads, stride = a.stride, tid = threadIdx.x;
     const bool use_q = (MODE == 0 && (a.stages & (FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0) || MODE == 3;
     const u32 NSLOT = (MODE == 0 && AMAX != 0) ? a.depth : 2u;        // tiles between decision and write-out (fxg_plan.h)
-    const FxgLds L = fxg_lds_layout(T, stride, fxg_bitmap_count(a, use_q, MODE == 0 && AMAX != 0), (MODE == 0 && AMAX != 0) ? (a.clip_global ? 0u : a.clip_stride) : (MODE == 4 ? stride : 0u), NSLOT);
+    const FxgLds L = fxg_lds_layout(T, stride, fxg_bitmap_count(a, use_q, MODE == 0 && AMAX != 0), (MODE == 0 && AMAX != 0) ? (GL ? 0u : a.clip_stride) : (MODE == 4 ? stride : 0u), NSLOT, MODE == 0 && AMAX != 0);
     u32 m_reads = 0, m_nt = 0, art_bad = 0;      // MODE 3 report counters / MODE 4 alphabet check, folded once at the end
     u32 *bm_g = reinterpret_cast<u32 *>(smem + L.off_bm_g);
     u32 *bm_l = reinterpret_cast<u32 *>(smem + L.off_bm_l);
@@ -1174,7 +1176,7 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
             unsigned char *sl = smem + slot * L.slot_bytes;
             if constexpr (MODE == 0 || MODE == 3 || MODE == 4) {
                 if (use_q && !FXG_DBG(a, 8u)) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, TB);
-                if constexpr (MODE == 0 && AMAX != 0) { if (!a.clip_global && (!FXG_DBG(a, 16u) || pend == FXG_NO_TILE)) fxg_phase_stage_bases(a.clip_src, a.clip_total, (u64)r0 * a.clip_stride, nreads * a.clip_stride, sb, tid, TB); }   // 16: the DP on the workgroup's first tile over and over (the DP's own rate)
+                if constexpr (MODE == 0 && AMAX != 0) { if (!GL && (!FXG_DBG(a, 16u) || pend == FXG_NO_TILE)) fxg_phase_stage_bases(a.clip_src, a.clip_total, (u64)r0 * a.clip_stride, nreads * a.clip_stride, sb, tid, TB); }   // 16: the DP on the workgroup's first tile over and over (the DP's own rate)
                 if constexpr (MODE == 4) fxg_phase_stage_bases(a.bases, a.total_bytes, tb, tbytes, sb, tid, TB);
                 __syncthreads();
             }
@@ -1183,11 +1185,9 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
             if (tid < nreads) {
                 if constexpr (MODE == 0 && AMAX < -16) {
                     float *ck = a.clip_ck ? a.clip_ck + (size_t)blockIdx.x * ((size_t)FXG_CK_SLOTS * (u32)fxg_clip_cols(AMAX) * TB) + tid : nullptr;
-                    if (a.clip_global) word = fxg_decide_a<AMAX, true>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen, ck, TB);      // (only with checkpoint scratch: fxg_plan.h)
-                    else word = fxg_decide_a<AMAX, false>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen, ck, TB);
+                    word = fxg_decide_a<AMAX, GL>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen, ck, TB);      // (GL only with checkpoint scratch: fxg_plan.h)
                 } else if constexpr (MODE == 0 && AMAX < 0) {     // register two-pass instances: the DP over the staged tile, or straight over the batch (fxg_plan.h: clip_global)
-                    if (a.clip_global) word = fxg_decide_a<AMAX, true>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen);
-                    else word = fxg_decide_a<AMAX, false>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen);
+                    word = fxg_decide_a<AMAX, GL>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen);
                 } else if constexpr (MODE == 0) word = fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen);
                 else if constexpr (MODE == 3) { u32 nl; word = fxg_decide_mask(a, bm_l, r0, tid, &keep, &olen, &nl); m_nt += nl; m_reads += (nl != 0u); }
                 else if constexpr (MODE == 4) word = fxg_decide_census(a, sb + tid * stride, r0, tid, &keep, &olen, &art_bad);

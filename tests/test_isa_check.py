@@ -35,7 +35,7 @@ def test_shipped_library_is_clean_and_a_bad_one_is_refused(tmp_path):
     b.build_engine()
     rc, out = _run(b.LIBFXG)
     assert rc == 0, out
-    assert " 62 kernels" in out or "kernels, 0 places" in out
+    assert "kernels, 0 places" in out
     b.check_exec_zero(b.LIBFXG)
     with pytest.raises(RuntimeError, match="REJECTED"):
         b.check_exec_zero(os.path.join(ISA, "exec_zero_bad.dis"))
