@@ -91,6 +91,23 @@ def test_tools_under_sanitizers(san, tmp_path):
     bad = tmp_path / "bad.fq"
     bad.write_bytes(text[:k0] + b"#" + text[k0 + 1:])
     runs.append((["fastq_quality_trimmer", "-t", "20", "-l", "30", "-i", str(bad), "-o", str(tmp_path / "b.%r.fq")], b"", {"FXH_READ_BUFFER_MB": "1", "FXH_PARTS": "3"}))
+    # the clipper's automatic mode: lanes in parallel while the reads have one length, the hand-over to one aligner (fxh_clip_go_serial) at the first
+    # ragged block -- here half way through -- and a sharded clipper run that is kept (fixed-length input) / started over as one stream (ragged part);
+    # `-o NAME.%r.fq` without FXH_PARTS (the tool picks the number of parts itself: one, for an input of this size)
+    lines = text.split(b"\n")
+    recs = [lines[4 * i:4 * i + 4] for i in range(len(lines) // 4)]
+    half = len(recs) // 2
+    rag_text = b"".join(b"\n".join(l) + b"\n" for l in recs[:half])
+    for l in recs[half:]:
+        L = int(rng.integers(20, 100))
+        rag_text += b"\n".join([l[0], l[1][:L], l[2], l[3][:L]]) + b"\n"
+    rag = tmp_path / "ragged.fq"
+    rag.write_bytes(rag_text)
+    runs += [(["fastx_clipper", "-a", ad, "-l", "15", "-v"], rag_text, {"FXH_READ_BUFFER_MB": "1", "FXH_LANES": "3"}),
+             (["fastx_clip_trim_filter", "-a", ad, "-l", "15", "-n", "-t", "20", "-m", "30", "-q", "20", "-p", "80", "-v"], rag_text, {"FXH_READ_BUFFER_MB": "1"}),
+             (["fastx_clipper", "-a", ad, "-l", "15", "-v", "-i", str(big), "-o", str(tmp_path / "c.%r.fq")], b"", {"FXH_READ_BUFFER_MB": "1", "FXH_PARTS": "3"}),
+             (["fastx_clipper", "-a", ad, "-l", "15", "-v", "-i", str(rag), "-o", str(tmp_path / "cr.%r.fq")], b"", {"FXH_READ_BUFFER_MB": "1", "FXH_PARTS": "3"}),
+             (["fastq_quality_trimmer", "-t", "20", "-l", "30", "-v", "-i", str(big), "-o", str(tmp_path / "auto.%r.fq")], b"", {"FXH_READ_BUFFER_MB": "1"})]
     for name, data in _corner_inputs().items():
         for argv in (["fastq_quality_trimmer", "-t", "20", "-l", "2"], ["fastx_trimmer", "-f", "2", "-l", "9"], ["fastx_reverse_complement"]):
             runs.append((argv, data, {"FXH_READ_BUFFER_MB": "1"} if len(data) % 2 else {}))
