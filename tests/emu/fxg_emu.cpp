@@ -182,8 +182,9 @@ static void emu_hist_prepass(fxg_emu_hist *hs, const fxg_batch *in, u32 T, u32 e
 }
 
 // what fxg_make_plan chose for the last pipeline call: the clip instance (FxgPlan.amax) and whether it runs its two-pass form with checkpoints in scratch
-static int g_last_amax, g_last_two_pass;
+static int g_last_amax, g_last_two_pass, g_last_clip_global, g_last_tile;
 extern "C" void fxg_emu_last_plan(int *amax, int *two_pass) { *amax = g_last_amax; *two_pass = g_last_two_pass; }
+extern "C" void fxg_emu_last_plan_clip_global(int *on, int *tile_reads) { *on = g_last_clip_global; *tile_reads = g_last_tile; }
 
 #ifdef FXG_CLIP_DEBUG
 static std::vector<u32> g_clip_dbg;
@@ -196,7 +197,7 @@ extern "C" int fxg_emu_run_pipeline_hist(const fxg_batch *in, const fxg_params *
     const u32 estride = hist && hs->wcap > in->stride ? hs->wcap : in->stride;
     const int rc = fxg_make_plan(in, p, out, &pl, err, cap, hist ? estride : 0u);
     if (rc != FXG_OK) return rc;
-    g_last_amax = pl.amax; g_last_two_pass = pl.ck_per_wg != 0;
+    g_last_amax = pl.amax; g_last_two_pass = pl.ck_per_wg != 0; g_last_clip_global = (int)pl.ka.clip_global; g_last_tile = (int)pl.ka.tile_reads;
     if (in->n == 0) return FXG_OK;
 #ifdef FXG_CLIP_DEBUG      // debug builds (scripts/debug/clip64_bisect.py): the per-read dump of fxg_clip_two_pass_k, read back through fxg_emu_clip_debug
     g_clip_dbg.assign((size_t)in->n * FXG_CLIP_DBG_WORDS, 0xEEEEEEEEu);

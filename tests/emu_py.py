@@ -134,6 +134,13 @@ def run_quality_stats(bases, qual, lens, fixed_len=None, hist=None, cols=None):
     return hist
 
 
+def last_plan_clip_global():
+    """(clip_global, tile_reads) of the plan the last emulated run was made with (fxg_plan.h: the DP over the batch instead of a staged tile)"""
+    a, t = C.c_int(), C.c_int()
+    lib().fxg_emu_last_plan_clip_global(C.byref(a), C.byref(t))
+    return bool(a.value), t.value
+
+
 def last_plan():
     """(clip instance, runs its scratch-checkpoint two-pass form) of the last run_pipeline call -- what fxg_make_plan chose."""
     a, t = C.c_int(), C.c_int()

@@ -123,6 +123,27 @@ def test_emulated_clip_over_the_batch_and_over_the_staged_tile(monkeypatch, mode
     assert n > 60
 
 
+def test_clip_global_selection(monkeypatch):
+    """fxg_make_plan (host logic shared with the engine): when the clip DP runs over the batch instead of a staged tile -- where the staged form would
+    shrink its tile or keep fewer than three workgroups on a CU, rows on dword boundaries, no clip history."""
+    monkeypatch.delenv("FXG_CLIP_GLOBAL", raising=False)
+    ad, truseq = b"AGATCGGAAGAGC", b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCAC"
+    q7 = dict(qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80)
+    for stride, stages, adapter, want, tile in ((100, 1, ad, False, 256), (150, 7, ad, False, 256), (152, 7, ad, False, 256), (176, 1, ad, False, 256), (176, 7, ad, True, 256),
+                                                (188, 1, ad, True, 256), (250, 1, ad, False, 128), (252, 1, ad, True, 256), (300, 7, ad, True, 256), (1000, 1, ad, True, 256),
+                                                (100, 1, truseq, False, 256), (152, 1, truseq, False, 256), (200, 1, truseq, True, 256), (300, 1, truseq, True, 256)):
+        b, q = fo.synth_batch(3, 0, 300, stride, True)
+        pd = dict(stages=stages, adapter=adapter, clip_min_len=5, clip_flags=4, **(q7 if stages == 7 else {}))
+        emu.run_pipeline(b, q, None, oracle_params(pd))
+        assert emu.last_plan_clip_global() == (want, tile), (stride, stages, len(adapter), emu.last_plan_clip_global())
+    # a run with clip history keeps the staged form whatever the rows look like
+    b, q = fo.synth_batch(3, 0, 300, 300, True)
+    hs = emu.hist_new()
+    emu.run_pipeline(b, q, np.full(300, 300, dtype=np.uint16), oracle_params(dict(stages=1, adapter=ad, clip_min_len=5, clip_flags=4)), hist=hs)
+    emu.hist_free(hs)
+    assert emu.last_plan_clip_global()[0] is False
+
+
 def test_emulated_quality_stats_histogram():
     """fastx_quality_stats: the strip bodies of the reduction kernel against the oracle's per-cycle records, two batches of different width."""
     import ctypes as C
