@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""CPU: a timed random campaign of the clip kernels' per-thread code (tests/emu) against the oracle -- every adapter class, strides 20..600, fixed and ragged
+(with clip history), all flags, the DP over the staged tile / over the batch / as the plan picks.  `python scripts/fuzz_campaign.py <seed> <seconds>`; not a test (the test
+tiers have fixed seeds), a tool for hunting what they miss."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import emu_py as emu
+from helpers import assert_same, oracle_params, random_batch
+from oracle import fxoracle_py as fo
+rng = np.random.default_rng(int(sys.argv[1]))
+adapters = [b"AGATCGGAAGAGC", b"CCTTAAGG", b"ACGT", b"TGGAATTCTCGGGTGCCAAGGAACTCCAGTCAC", b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCGTATGCCGTCTTCTGCTTG", b"ANNTCGNA", b"GATTACAGATTACAGA", b"A" * 17]
+t0 = time.time(); n = 0
+while time.time() - t0 < float(sys.argv[2]):
+    ad = adapters[int(rng.integers(0, len(adapters)))]
+    stride = int(rng.choice([20, 36, 52, 64, 100, 152, 176, 188, 200, 252, 300, 400, 600]))
+    nreads = int(rng.integers(1, 400))
+    fixed = rng.random() < 0.6
+    b, q, lens = random_batch(rng, nreads, stride, max(1, stride - int(rng.integers(0, stride))), stride, fixed, p_n=float(rng.choice([0.0, 0.02, 0.2])), adapter=ad)
+    stages = int(rng.choice([1, 7, 3, 5]))
+    pd = dict(stages=stages, adapter=ad, clip_min_len=int(rng.integers(0, 25)), clip_flags=int(rng.integers(0, 16)), clip_min_adapter_len=int(rng.choice([0, 0, 3, 8])),
+              qt_threshold=20, qt_min_len=int(rng.integers(0, 40)), qf_min_quality=int(rng.integers(0, 40)), qf_min_percent=int(rng.integers(0, 101)))
+    for mode in ("0", "1", None):
+        if mode is None: os.environ.pop("FXG_CLIP_GLOBAL", None)
+        else: os.environ["FXG_CLIP_GLOBAL"] = mode
+        if fixed:
+            o = fo.run_pipeline(b, q, None, oracle_params(pd), fixed_len=stride); e = emu.run_pipeline(b, q, None, oracle_params(pd), fixed_len=stride)
+        else:
+            hs = emu.hist_new(); o = fo.run_pipeline(b, q, lens, oracle_params(pd)); e = emu.run_pipeline(b, q, lens, oracle_params(pd), hist=hs); emu.hist_free(hs)
+        assert_same(o, e, "seed%s.n%d.ad%d.s%d.fixed%d.mode%s.%r" % (sys.argv[1], n, len(ad), stride, fixed, mode, pd))
+    n += 1
+print("seed", sys.argv[1], "cases", n, "ok")
