@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""CPU: a timed random campaign of the command-line tools (host layer over the emulation stub, tests/emu/stub) against the real libfastx driver
+(oracle/_ref/fxref): random tool and flags, FASTQ text with ragged stretches at random places, N, CRLF, small read buffers, lanes, sharded runs.
+`python scripts/fuzz_campaign_cli.py <seed> <seconds>`; not a test, a tool for hunting what the fixed-seed tiers miss."""
+import os, subprocess, sys, tempfile, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import emu_py
+from oracle import fxoracle_py as fo
+REF = fo.ref_binary()
+assert REF, "oracle/_ref/fxref not built"
+STUB = emu_py.build_stub()
+BIN = os.path.join(ROOT, "fastx_toolkit_amd", "host", "bin")
+rng = np.random.default_rng(int(sys.argv[1]))
+AD = ["AGATCGGAAGAGC", "CCTTAAGG", "TGGAATTCTCGGGTGCCAAGGAACTCCAGTCAC", "ANNTCGNA"]
+
+def run(cmd, data, env=None):
+    e = dict(os.environ, LD_LIBRARY_PATH=STUB, FXH_THREADS="3")
+    e.update(env or {})
+    p = subprocess.run(cmd, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=300)
+    return p.returncode, p.stdout, p.stderr
+
+def text(n, L, ad):
+    lines = fo.synth_fastq(int(rng.integers(1, 1 << 30)), 0, n, L, True).split(b"\n")
+    recs = [lines[4 * i:4 * i + 4] for i in range(n)]
+    a, b = sorted(int(x) for x in rng.integers(0, n + 1, size=2))
+    mode = int(rng.integers(0, 4))                       # 0 fixed, 1 ragged in [a, b), 2 ragged everywhere, 3 ragged from a on
+    out = []
+    for i, l in enumerate(recs):
+        rag = (mode == 1 and a <= i < b) or mode == 2 or (mode == 3 and i >= a)
+        k = int(rng.integers(1, L + 1)) if rag and rng.random() < 0.6 else L
+        out.append(b"\n".join([l[0], l[1][:k], l[2], l[3][:k]]))
+    t = b"\n".join(out) + b"\n"
+    return t.replace(b"\n", b"\r\n") if rng.random() < 0.1 else t
+
+t0 = time.time(); n = 0
+with tempfile.TemporaryDirectory() as tmp:
+    while time.time() - t0 < float(sys.argv[2]):
+        ad = AD[int(rng.integers(0, len(AD)))]
+        L = int(rng.choice([36, 50, 100, 150, 251]))
+        data = text(int(rng.integers(1, 30000)), L, ad)
+        tool = int(rng.integers(0, 4))
+        clipf = ["-a", ad, "-l", str(int(rng.integers(0, 30)))] + [f for f in ("-n", "-c", "-C", "-k") if rng.random() < 0.25] + (["-M", str(int(rng.integers(1, 12)))] if rng.random() < 0.3 else [])
+        if "-c" in clipf and "-C" in clipf: clipf.remove("-C")
+        q = ["-t", str(int(rng.integers(1, 40))), "-l", str(int(rng.integers(0, 60)))]
+        if tool == 0: chain = [["fastx_clipper"] + clipf + ["-v"]]; fused = chain[0]
+        elif tool == 1: chain = [["fastq_quality_trimmer"] + q + ["-v"]]; fused = chain[0]
+        elif tool == 2: chain = [["fastx_reverse_complement"]]; fused = chain[0]
+        else:
+            qq, pp = str(int(rng.integers(0, 40))), str(int(rng.integers(1, 101)))
+            cf = [f for f in clipf if f not in ("-c", "-C", "-k")]
+            chain = [["fastx_clipper"] + cf, ["fastq_quality_trimmer", "-t", q[1], "-l", q[3]], ["fastq_quality_filter", "-q", qq, "-p", pp]]
+            fused = ["fastx_clip_trim_filter"] + cf + ["-t", q[1], "-m", q[3], "-q", qq, "-p", pp]
+        want = data; rc = 0; err = b""; skip = False
+        for i, c in enumerate(chain):
+            rc, want, err = run([REF] + c, want)
+            if rc: break
+            if not want and i + 1 < len(chain): skip = True; break      # an empty intermediate file is an error to the reference's next tool, not to the one-pass tool
+        if skip: continue
+        env = {"FXH_READ_BUFFER_MB": str(int(rng.choice([1, 2, 8])))}
+        if rng.random() < 0.4: env["FXH_LANES"] = str(int(rng.integers(1, 5)))
+        if rng.random() < 0.3:                           # file to file, sharded
+            inp, pat = os.path.join(tmp, "in.fq"), os.path.join(tmp, "o.%r.fq")
+            open(inp, "wb").write(data)
+            k = int(rng.integers(2, 5))
+            got = run([os.path.join(BIN, fused[0])] + [f for f in fused[1:] if f != "-v"] + ["-i", inp, "-o", pat], b"", dict(env, FXH_PARTS=str(k)))
+            files = [pat.replace("%r", str(r)) for r in range(k)]
+            out = b"".join(open(f, "rb").read() for f in files if os.path.exists(f))
+            for f in files:
+                if os.path.exists(f): os.unlink(f)
+            ok = (got[0], out) == (rc, want) if rc == 0 else got[0] == rc
+        else:
+            got = run([os.path.join(BIN, fused[0])] + fused[1:], data, env)
+            ok = (got[0], got[1]) == (rc, want) and (len(chain) > 1 or got[2].split(b": ", 1)[-1] == err.split(b": ", 1)[-1] or rc == 0)
+        if not ok:
+            open("/tmp/fuzz_cli_fail.fq", "wb").write(data)
+            raise SystemExit("MISMATCH seed %s case %d: %r env %r rc %r/%r out %d/%d bytes; input kept in /tmp/fuzz_cli_fail.fq\n%s" % (sys.argv[1], n, fused, env, got[0], rc, len(got[1]), len(want), got[2][-400:].decode(errors="replace")))
+        n += 1
+print("seed", sys.argv[1], "cases", n, "ok")
