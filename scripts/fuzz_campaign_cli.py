@@ -40,13 +40,19 @@ with tempfile.TemporaryDirectory() as tmp:
         ad = AD[int(rng.integers(0, len(AD)))]
         L = int(rng.choice([36, 50, 100, 150, 251]))
         data = text(int(rng.integers(1, 30000)), L, ad)
-        tool = int(rng.integers(0, 4))
+        tool = int(rng.integers(0, 10))
         clipf = ["-a", ad, "-l", str(int(rng.integers(0, 30)))] + [f for f in ("-n", "-c", "-C", "-k") if rng.random() < 0.25] + (["-M", str(int(rng.integers(1, 12)))] if rng.random() < 0.3 else [])
         if "-c" in clipf and "-C" in clipf: clipf.remove("-C")
         q = ["-t", str(int(rng.integers(1, 40))), "-l", str(int(rng.integers(0, 60)))]
         if tool == 0: chain = [["fastx_clipper"] + clipf + ["-v"]]; fused = chain[0]
         elif tool == 1: chain = [["fastq_quality_trimmer"] + q + ["-v"]]; fused = chain[0]
         elif tool == 2: chain = [["fastx_reverse_complement"]]; fused = chain[0]
+        elif tool == 4: chain = [["fastq_quality_filter", "-q", str(int(rng.integers(0, 42))), "-p", str(int(rng.integers(1, 101))), "-v"]]; fused = chain[0]
+        elif tool == 5: chain = [["fastx_trimmer", "-f", str(int(rng.integers(1, 30))), "-l", str(int(rng.integers(30, 300))), "-v"] if rng.random() < 0.5 else ["fastx_trimmer", "-t", str(int(rng.integers(1, 30))), "-m", str(int(rng.integers(1, 60))), "-v"]]; fused = chain[0]
+        elif tool == 6: chain = [["fastq_masker", "-q", str(int(rng.integers(0, 45))), "-r", str(rng.choice(list("N.x"))), "-v"]]; fused = chain[0]
+        elif tool == 7: chain = [["fastx_artifacts_filter", "-v"]]; fused = chain[0]
+        elif tool == 8: chain = [["fastq_to_fasta", "-v"] + (["-r"] if rng.random() < 0.5 else []) + (["-n"] if rng.random() < 0.5 else [])]; fused = chain[0]
+        elif tool == 9: chain = [["fastx_quality_stats"] + (["-N"] if rng.random() < 0.5 else [])]; fused = chain[0]
         else:
             qq, pp = str(int(rng.integers(0, 40))), str(int(rng.integers(1, 101)))
             cf = [f for f in clipf if f not in ("-c", "-C", "-k")]
@@ -60,7 +66,7 @@ with tempfile.TemporaryDirectory() as tmp:
         if skip: continue
         env = {"FXH_READ_BUFFER_MB": str(int(rng.choice([1, 2, 8])))}
         if rng.random() < 0.4: env["FXH_LANES"] = str(int(rng.integers(1, 5)))
-        if rng.random() < 0.3:                           # file to file, sharded
+        if rng.random() < 0.3 and tool not in (9,):      # file to file, sharded
             inp, pat = os.path.join(tmp, "in.fq"), os.path.join(tmp, "o.%r.fq")
             open(inp, "wb").write(data)
             k = int(rng.integers(2, 5))
