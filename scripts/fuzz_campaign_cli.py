@@ -10,13 +10,15 @@ import emu_py
 from oracle import fxoracle_py as fo
 REF = fo.ref_binary()
 assert REF, "oracle/_ref/fxref not built"
-STUB = emu_py.build_stub()
+REAL = os.environ.get("FXG_CAMPAIGN_REAL") == "1"      # on a GPU box: the tools over the real engine (their rpath finds ../../libfxg.so)
+STUB = None if REAL else emu_py.build_stub()
 BIN = os.path.join(ROOT, "fastx_toolkit_amd", "host", "bin")
 rng = np.random.default_rng(int(sys.argv[1]))
 AD = ["AGATCGGAAGAGC", "CCTTAAGG", "TGGAATTCTCGGGTGCCAAGGAACTCCAGTCAC", "ANNTCGNA"]
 
 def run(cmd, data, env=None):
-    e = dict(os.environ, LD_LIBRARY_PATH=STUB, FXH_THREADS="3")
+    e = dict(os.environ, FXH_THREADS="3")
+    if STUB: e["LD_LIBRARY_PATH"] = STUB
     e.update(env or {})
     p = subprocess.run(cmd, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=300)
     return p.returncode, p.stdout, p.stderr
@@ -38,7 +40,7 @@ t0 = time.time(); n = 0
 with tempfile.TemporaryDirectory() as tmp:
     while time.time() - t0 < float(sys.argv[2]):
         ad = AD[int(rng.integers(0, len(AD)))]
-        L = int(rng.choice([36, 50, 100, 150, 251]))
+        L = int(rng.choice([36, 50, 100, 150, 251, 300]))
         data = text(int(rng.integers(1, 30000)), L, ad)
         tool = int(rng.integers(0, 10))
         clipf = ["-a", ad, "-l", str(int(rng.integers(0, 30)))] + [f for f in ("-n", "-c", "-C", "-k") if rng.random() < 0.25] + (["-M", str(int(rng.integers(1, 12)))] if rng.random() < 0.3 else [])
