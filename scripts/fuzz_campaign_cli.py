@@ -33,16 +33,24 @@ def text(n, L, ad):
         rag = (mode == 1 and a <= i < b) or mode == 2 or (mode == 3 and i >= a)
         k = int(rng.integers(1, L + 1)) if rag and rng.random() < 0.6 else L
         out.append(b"\n".join([l[0], l[1][:k], l[2], l[3][:k]]))
+    form = rng.random()
+    collapsed = form < 0.12 and rng.random() < 0.4
+    if form < 0.12:                                      # FASTA (collapsed-read identifiers in some files): the tools that take it
+        out = [b">" + (b"%d-%d" % (i, int(rng.integers(1, 50))) if collapsed and rng.random() < 0.5 else l.split(b"\n")[0][1:]) + b"\n" + l.split(b"\n")[1] for i, l in enumerate(out)]
+    elif form < 0.2:                                     # numeric quality lines
+        out = [b"\n".join([l.split(b"\n")[0], l.split(b"\n")[1], l.split(b"\n")[2], b" ".join(b"%d" % (c - 33) for c in l.split(b"\n")[3])]) for l in out]
     t = b"\n".join(out) + b"\n"
-    return t.replace(b"\n", b"\r\n") if rng.random() < 0.1 else t
+    return (t.replace(b"\n", b"\r\n") if rng.random() < 0.1 else t), form < 0.12, collapsed
 
 t0 = time.time(); n = 0
 with tempfile.TemporaryDirectory() as tmp:
     while time.time() - t0 < float(sys.argv[2]):
         ad = AD[int(rng.integers(0, len(AD)))]
         L = int(rng.choice([36, 50, 100, 150, 251, 300]))
-        data = text(int(rng.integers(1, 30000)), L, ad)
-        tool = int(rng.integers(0, 10))
+        data, fasta, collapsed = text(int(rng.integers(1, 30000)), L, ad)
+        # FASTA: clipper, reverse-complement, fixed trimmer, artifacts filter, statistics -- the statistics tool not on collapsed reads: its percentile walk then leaves the
+        # reference's static array and prints whatever the linker put behind it
+        tool = int(rng.choice([0, 2, 5, 7] if collapsed else [0, 2, 5, 7, 9])) if fasta else int(rng.integers(0, 10))
         clipf = ["-a", ad, "-l", str(int(rng.integers(0, 30)))] + [f for f in ("-n", "-c", "-C", "-k") if rng.random() < 0.25] + (["-M", str(int(rng.integers(1, 12)))] if rng.random() < 0.3 else [])
         if "-c" in clipf and "-C" in clipf: clipf.remove("-C")
         q = ["-t", str(int(rng.integers(1, 40))), "-l", str(int(rng.integers(0, 60)))]
@@ -54,7 +62,7 @@ with tempfile.TemporaryDirectory() as tmp:
         elif tool == 6: chain = [["fastq_masker", "-q", str(int(rng.integers(0, 45))), "-r", str(rng.choice(list("N.x"))), "-v"]]; fused = chain[0]
         elif tool == 7: chain = [["fastx_artifacts_filter", "-v"]]; fused = chain[0]
         elif tool == 8: chain = [["fastq_to_fasta", "-v"] + (["-r"] if rng.random() < 0.5 else []) + (["-n"] if rng.random() < 0.5 else [])]; fused = chain[0]
-        elif tool == 9: chain = [["fastx_quality_stats"] + (["-N"] if rng.random() < 0.5 else [])]; fused = chain[0]
+        elif tool == 9: chain = [["fastx_quality_stats"] + (["-N"] if rng.random() < 0.5 and not fasta else [])]; fused = chain[0]      # (-N on FASTA: the last column's per-class quartiles come from behind the reference's static array)
         else:
             qq, pp = str(int(rng.integers(0, 40))), str(int(rng.integers(1, 101)))
             cf = [f for f in clipf if f not in ("-c", "-C", "-k")]
