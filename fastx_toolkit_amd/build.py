@@ -33,6 +33,9 @@ def check_exec_zero(so):
     for no lane -- silently wrong integers that move with every change of the allocation (scripts/check_exec_zero.py reads the ISA)."""
     tool = os.path.join(ROOT, "scripts", "check_exec_zero.py")
     p = subprocess.run([sys.executable, tool, so], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if p.returncode not in (0, 1):          # 2 (or a crash): the check itself failed -- no tools, no code object, a listing it cannot read
+        raise RuntimeError("%s NOT CHECKED: scripts/check_exec_zero.py could not read the library's ISA (exit code %d); that is a broken check, "
+                           "not a finding, and a library that was not checked is not accepted.\n%s" % (so, p.returncode, p.stdout[-3000:]))
     if p.returncode != 0:
         raise RuntimeError("%s REJECTED: vector/memory code runs with EXEC = 0 at the exit of a lane-divergent loop (compiler bug, DESIGN.md section 3).\n"
                            "Change the register budget of the named instance (fxg_clip_waves / __launch_bounds__) or its source and rebuild.\n%s" % (so, p.stdout[-3000:]))

@@ -59,10 +59,32 @@ extern "C" int fxg_concat_pwrite(int fd, const void *host_buf, uint64_t bytes, u
 // ------------------------------------------------------------------------------------------------
 // RCCL transport of the counter blocks (one process per GPU, C hosts).  librccl.so is opened at run time.
 // Rendezvous: rank 0 publishes the ncclUniqueId through a file (written to a temporary name and renamed into place, so a reader
-// sees all 128 bytes or no file); the other ranks poll for it.  The file belongs to ONE job: rank 0 removes it once the communicator
-// is up (every rank has read it by then), so a later job that reuses the name cannot pick up a stale id.
+// sees a whole record or no file); the other ranks poll for it.  The file belongs to ONE job: rank 0 removes whatever lies under the
+// name BEFORE it makes its id, and removes its own record once the communicator is up (every rank has read it by then).  A job that
+// died between the two leaves a record behind; what keeps a later job's early ranks from taking it: the record carries the world size
+// and a job token (FXG_COMM_JOB in the environment, hashed; launchers export one per job), a reader accepts only a record it has read
+// twice, 100 ms apart, unchanged (rank 0 of its own job replaces or removes a stale one in between), and without a token the name
+// itself has to be the job's own -- INTEGRATION.md says so.
 // ------------------------------------------------------------------------------------------------
 typedef struct { char internal[128]; } fxg_nccl_id;          // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
+typedef struct { char magic[8]; uint32_t world, reserved; uint64_t job; fxg_nccl_id id; } fxg_rdv_record;
+static inline uint64_t fxg_rdv_job_token(void)
+{
+    const char *j = getenv("FXG_COMM_JOB");
+    uint64_t h = 0xcbf29ce484222325ull;                       // FNV-1a; 0 = no token given
+    if (!j || !*j) return 0;
+    for (; *j; ++j) h = (h ^ (unsigned char)*j) * 0x100000001b3ull;
+    return h ? h : 1;
+}
+static inline bool fxg_rdv_read(const char *file, uint32_t world, uint64_t job, fxg_rdv_record *r)
+{
+    const int fd = open(file, O_RDONLY);
+    if (fd < 0) return false;
+    char extra;
+    const bool whole = read(fd, r, sizeof *r) == (ssize_t)sizeof *r && read(fd, &extra, 1) == 0;
+    close(fd);
+    return whole && memcmp(r->magic, "FXGRDV1", 8) == 0 && r->world == world && r->job == job;
+}
 struct fxg_comm {
     void *lib, *comm;
     uint32_t rank, world;
@@ -102,32 +124,45 @@ extern "C" int fxg_comm_create(fxg_ctx *c, const char *file, uint32_t rank, uint
     const int wait_s = timeout_s > 0 ? timeout_s : 60;
     fxg_nccl_id id;
     memset(&id, 0, sizeof id);
+    const uint64_t job = fxg_rdv_job_token();
     if (rank == 0) {                                          // publish the id atomically: write a temporary, rename it into place
+        (void)unlink(file);                                   // whatever a dead job left under the name goes first
         const int rc = m->get_id(&id);
         if (rc != 0) {                                        // (the message is formatted before the library that owns the text is closed)
             const int frc = FXG_COMM_FAIL(c, FXG_E_HIP, "ncclGetUniqueId: %s", m->err_string ? m->err_string(rc) : "error");
             fxg_comm_destroy(m);
             return frc;
         }
+        fxg_rdv_record rec;
+        memset(&rec, 0, sizeof rec);
+        memcpy(rec.magic, "FXGRDV1", 8); rec.world = world; rec.job = job; rec.id = id;
         char tmp[4096];
         snprintf(tmp, sizeof tmp, "%s.tmp.%d", file, (int)getpid());
+        errno = 0;
         const int fd = open(tmp, O_CREAT | O_WRONLY | O_TRUNC, 0600);
-        const bool ok = fd >= 0 && write(fd, &id, sizeof id) == (ssize_t)sizeof id;
-        const bool closed = fd < 0 || close(fd) == 0;
-        if (!ok || !closed || rename(tmp, file) != 0) {
-            const int e = errno;
+        int e = errno;
+        bool ok = fd >= 0;
+        if (ok) { const ssize_t k = write(fd, &rec, sizeof rec); if (k != (ssize_t)sizeof rec) { ok = false; e = k < 0 ? errno : EIO; } }      // a short write sets no errno
+        if (fd >= 0 && close(fd) != 0 && ok) { ok = false; e = errno; }
+        if (ok && rename(tmp, file) != 0) { ok = false; e = errno; }
+        if (!ok) {
             (void)unlink(tmp);
             fxg_comm_destroy(m);
             return FXG_COMM_FAIL(c, FXG_E_INVALID, "cannot write the rendezvous file %s: %s", file, strerror(e));
         }
     } else {
         bool got = false;
+        fxg_rdv_record a, b;
         for (int tries = 0; tries < wait_s * 20 && !got; ++tries) {
-            const int fd = open(file, O_RDONLY);
-            if (fd >= 0) { got = read(fd, &id, sizeof id) == (ssize_t)sizeof id; close(fd); }
+            if (fxg_rdv_read(file, world, job, &a)) {         // twice, 100 ms apart, unchanged: not a leftover that this job's rank 0 is about to replace
+                usleep(100000);
+                got = fxg_rdv_read(file, world, job, &b) && memcmp(&a, &b, sizeof a) == 0;
+                tries += 2;
+            }
             if (!got) usleep(50000);
         }
         if (!got) { fxg_comm_destroy(m); return FXG_COMM_FAIL(c, FXG_E_INVALID, "rank %u: no RCCL id in %s after %d s", rank, file, wait_s); }
+        id = a.id;
     }
     if (!FXG_COMM_SET_DEVICE(c) || !FXG_COMM_MALLOC(&m->d_gather, (size_t)world * FXG_NCOUNTERS * sizeof(uint64_t))) {
         m->d_gather = nullptr;

@@ -26,6 +26,7 @@ struct fxg_ctx {
     hipEvent_t kev0[FXG_KEV_RING], kev1[FXG_KEV_RING];  // around the dominant kernel of the last FXG_KEV_RING launches when profiling
     int profiling;
     u64 kev_count;          // profiled launches since fxg_set_profiling(1)
+    int kev_ready;          // every event of both rings exists
     u64 *status;            // FXG_STATUS_WORDS(status_cap) granules: tile totals [cap], prefixes [2 * cap], batch bases
     size_t status_cap;      // in tiles
     u32 epoch;              // tag of the granules of the current launch (1..255); 0 = never valid
@@ -813,9 +814,20 @@ static const char *fxg_comm_d2h_sync(fxg_ctx *c, void *dst, const void *src, siz
 extern "C" int fxg_set_profiling(fxg_ctx *c, int enabled)
 {
     if (!c) return FXG_E_INVALID;
-    if (enabled && !c->kev0[0]) {                            // the event ring is made on first use
+    if (enabled && !c->kev_ready) {                          // the event ring is made on first use: all 2 x FXG_KEV_RING events, or none
         FXG_HIP(c, hipSetDevice(c->device));
-        for (int i = 0; i < FXG_KEV_RING; ++i) { FXG_HIP(c, hipEventCreate(&c->kev0[i])); FXG_HIP(c, hipEventCreate(&c->kev1[i])); }
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < FXG_KEV_RING && e == hipSuccess; ++i) { e = hipEventCreate(&c->kev0[i]); if (e == hipSuccess) e = hipEventCreate(&c->kev1[i]); }
+        if (e != hipSuccess) {                               // a ring with holes would be recorded into and waited on through null events
+            for (int i = 0; i < FXG_KEV_RING; ++i) {
+                if (c->kev0[i]) (void)hipEventDestroy(c->kev0[i]);
+                if (c->kev1[i]) (void)hipEventDestroy(c->kev1[i]);
+                c->kev0[i] = c->kev1[i] = nullptr;
+            }
+            c->profiling = 0;
+            return fxg_fail(c, FXG_E_HIP, "hipEventCreate failed: %s (profiling stays off)", hipGetErrorString(e));
+        }
+        c->kev_ready = 1;
     }
     c->profiling = enabled ? 1 : 0;
     c->kev_count = 0;

@@ -352,6 +352,15 @@ FXG_HD float fxg_clip_row_score(const FxgKArgs &a, int A, u32 c, int q, float (&
     return rowmax;
 }
 
+// GL window: index of the array's last readable dword counted from a row that starts `off` bytes into it.  The count is 64-bit -- a batch
+// of 8 GiB and more (30 M reads at a 300-byte stride) has more than 2^31 dwords behind its early rows -- and the window never looks
+// further than a row's own length ahead, so it is clamped to what an int index can hold instead of being truncated.
+FXG_HD int fxg_gl_last_dword(u64 total, u64 off)
+{
+    const u64 left = total > off ? (total - off) >> 2 : 0;
+    return left == 0 ? 0 : (left - 1 > (u64)0x7FFFFFFF ? 0x7FFFFFFF : (int)(left - 1));
+}
+
 // dword i of a row that starts on a dword boundary, clamped to the array's last dword (the window of fxg_clip_two_pass<.., GL> runs two dwords ahead)
 FXG_HD u32 fxg_ld32(const uint8_t *row, int i, int imax)
 {
@@ -413,7 +422,7 @@ FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int 
     u32 cn = 0u, gw0 = 0u, gw1 = 0u;
     int gmax = 0;                                           // GL: last dword of the array that may be read, counted from this row's first
     if constexpr (GL) {
-        gmax = (int)((a.clip_total - (u64)(rd - a.clip_src)) >> 2) - 1;
+        gmax = fxg_gl_last_dword(a.clip_total, (u64)(rd - a.clip_src));
         gw0 = fxg_ld32(rd, 0, gmax); gw1 = fxg_ld32(rd, 1, gmax);
     } else cn = rd[0];
     // chunk j = rows [j C, j C + C): saves the row before it in Psave = P[j % 3]; the restart row for a best found in it is
@@ -698,7 +707,7 @@ FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, in
     u32 cn = 0u, gw0 = 0u, gw1 = 0u;
     int gmax = 0;
     if constexpr (GL) {
-        gmax = (int)((a.clip_total - (u64)(rd - a.clip_src)) >> 2) - 1;
+        gmax = fxg_gl_last_dword(a.clip_total, (u64)(rd - a.clip_src));
         gw0 = fxg_ld32(rd, 0, gmax); gw1 = fxg_ld32(rd, 1, gmax);
     } else cn = rd[0];
 #define FXG_CK_ROW(EARLY)                                                                                                    \

@@ -444,7 +444,9 @@ void fxh_writer_close(struct fxh_writer *w)
 static int fxh_open_output(const char *filename)
 {
     if (strcmp(filename, "-") == 0) return STDOUT_FILENO;
-    int fd = open(filename, O_CREAT | O_WRONLY | O_TRUNC, 0666);
+    /* read-write where that is allowed: the many-strand run maps its one output file (fxh_strands.c); a file that may only be written still opens */
+    int fd = open(filename, O_CREAT | O_RDWR | O_TRUNC, 0666);
+    if (fd == -1 && errno == EACCES) fd = open(filename, O_CREAT | O_WRONLY | O_TRUNC, 0666);
     if (fd == -1) err(1, "Failed to create output file (%s)", filename);
     return fd;
 }
@@ -516,6 +518,17 @@ void fastx_init_reader(FASTX *fx, const char *filename, ALLOWED_INPUT_FILE_TYPES
     }
 }
 
+/* Set by fxh_init_writer (the batch tools) around its call of fastx_init_writer: only there does "%r" in the output name stand for the part
+ * number of a sharded run.  A per-record caller of the libfastx API opens exactly the name it gave. */
+static int g_fxh_batch_writer;
+
+void fxh_init_writer(FASTX *fx, const char *filename, OUTPUT_FILE_TYPE output_type, int compress_output)
+{
+    g_fxh_batch_writer = 1;
+    fastx_init_writer(fx, filename, output_type, compress_output);
+    g_fxh_batch_writer = 0;
+}
+
 void fastx_init_writer(FASTX *fx, const char *filename, OUTPUT_FILE_TYPE output_type, int compress_output)
 {
     if (fx == NULL) errx(1, "Internal error: pFASTX==NULL (%s:%d)", __FILE__, __LINE__);
@@ -525,7 +538,7 @@ void fastx_init_writer(FASTX *fx, const char *filename, OUTPUT_FILE_TYPE output_
     {   /* "-o out.%r.fq" names the output parts of a sharded run (FXH_PARTS=k, or chosen by the tool: fxh_run_tool); this writer is
          * part 0 (fxh_parts.c opens the others) */
         char first[PATH_MAX];
-        const char *pe = getenv("FXH_PARTS"), *pr = strstr(filename, "%r");
+        const char *pe = getenv("FXH_PARTS"), *pr = g_fxh_batch_writer ? strstr(filename, "%r") : NULL;     /* record-API callers get the literal name, like fastx.c:251-271 */
         if ((!pe || atoi(pe) >= 1) && pr && strlen(filename) < sizeof first - 8) {
             snprintf(first, sizeof first, "%.*s0%s", (int)(pr - filename), filename, pr + 2);
             fx->writer = fxh_writer_open(first, compress_output);

@@ -666,6 +666,8 @@ int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *tot)
     int k = pe ? atoi(pe) : fxh_auto_parts(fx);
     if (k > FXH_MAX_LANES) k = FXH_MAX_LANES;
     if (k > 1 && fxh_run_parts(fx, p, tot, k) == 0) return 0;
+    /* `-o ONE_FILE` on a large regular input: the same parallel run into one file (fxh_strands.c); anything it does not take comes back here */
+    if (k <= 1 && !pe && fxh_run_one_file(fx, p, tot) == 0) return 0;
     const int rc = fxh_run_impl(fx, p, tot, NULL, NULL, NULL, 0, 1);
     if (k > 1 && strcmp(fx->output_file_name, "-") != 0) {
         /* asked for k parts but run as one stream (a pipe, a small file, -z, the serial clipper): part 0 holds everything, the others

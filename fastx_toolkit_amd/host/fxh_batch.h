@@ -35,6 +35,10 @@ typedef struct fxh_totals {
  * inside fastx_read_next_record).  Returns 0. */
 int fxh_run_tool(FASTX *fx, const fxg_params *p, fxh_totals *totals);
 
+/* fastx_init_writer for the batch tools: the same, except that "%r" in the name stands for the part number of a sharded run (FXH_PARTS, or parts
+ * chosen by the tool) -- this writer is then part 0.  fastx_init_writer itself opens the literal name, as the reference does (fastx.c:251-271). */
+void fxh_init_writer(FASTX *fx, const char *filename, OUTPUT_FILE_TYPE output_type, int compress_output);
+
 /* fastx_quality_stats over the whole FASTQ input of `fx` (reader initialised, no writer needed): the per-column histogram of
  * include/fxg.h's fxg_run_quality_stats summed over all batches, copied to a malloc'ed array hist[cols][FXG_QS_CLASSES][FXG_QS_BINS]
  * whose bin index is quality value + 33 whatever -Q was.  Malformed input ends the process like fxh_run_tool. */

@@ -16,7 +16,7 @@ pthread_mutex_t g_first_ctx_mu = PTHREAD_MUTEX_INITIALIZER;
 static int g_first_ctx_done;
 int g_hip_touched;
 
-static void fxh_lane_run(fxh_lane *ln)
+void fxh_lane_run(fxh_lane *ln)
 {
     fxh_state *st = &ln->st;
     const size_t len = ln->len;
@@ -53,7 +53,9 @@ static void fxh_lane_run(fxh_lane *ln)
     fxg_text_info info;
     FXG_CHECK(st, fxg_fastq_index(st->ctx, st->d_text, len, 1, lpr, st->d_ls, st->d_ls_cap, st->d_len16, st->d_flags, &info));
     FXH_TCALL(1);
-    if (info.irregular || info.records == 0 || info.records != ln->records || info.consumed != len) return;
+    if (info.irregular || info.records == 0 || info.consumed != len) return;
+    if (ln->records == FXH_RECORDS_UNKNOWN) ln->records = info.records;      /* a chunk of the one-file sharded run: its cut is proven by being whole records (fxh_strands.c) */
+    else if (info.records != ln->records) return;
     const uint64_t n = info.records;
     uint32_t stride = info.max_len;
     /* long reads of one length through the clipper: rows on dword boundaries, so that the clip kernel can read them where they are instead of staging
@@ -92,6 +94,7 @@ static void fxh_lane_run(fxh_lane *ln)
                                    revcomp ? st->d_out_bases : NULL, (revcomp && ln->has_q) ? st->d_out_qual : NULL, revcomp ? st->d_out_off : NULL,
                                    ln->has_q ? st->d_qual : NULL, stride, ln->qoffset, ln->out_fasta, st->d_out_text, &out_bytes));
     FXH_TCALL(5);
+    if (ln->on_size) ln->on_size(ln, out_bytes);           /* the block's place in ONE output file depends only on the sizes before it: known here, before the download */
     const int s = ln->slot;
     if (ln->out_cap[s] < out_bytes + 16) {
         if (ln->out[s]) fxg_free_host(st->ctx, ln->out[s]);
@@ -107,14 +110,10 @@ static void fxh_lane_run(fxh_lane *ln)
     ln->handled = 1;
 }
 
-static void *fxh_lane_main(void *arg)
+/* the lane's context, created by the lane's own thread: the process-wide first context comes alone (two threads inside the runtime's
+ * first-use initialisation take twice as long as one after the other) */
+void fxh_lane_open_ctx(fxh_lane *ln)
 {
-    fxh_lane *ln = (fxh_lane *)arg;
-    if (ln->first && ln->first != ln) {
-        pthread_mutex_lock(&ln->first->mu);
-        while (!ln->first->ready) pthread_cond_wait(&ln->first->cv, &ln->first->mu);
-        pthread_mutex_unlock(&ln->first->mu);
-    }
     double t0 = fxh_now();
     int rc;
     pthread_mutex_lock(&g_first_ctx_mu);    /* the parts of a sharded run each have a lane 0: the process-wide first context still comes alone */
@@ -127,6 +126,32 @@ static void *fxh_lane_main(void *arg)
      * SURVEY N3): every block of the run, host-parsed ones included, goes through this one context in input order */
     if (ln->clip_history) FXG_CHECK(&ln->st, fxg_set_clip_history(ln->st.ctx, 1));
     ln->t_init = fxh_now() - t0;
+}
+
+/* everything the lane holds on the device and page-locked on the host, then its context: by the lane's own thread, so that the lanes of a run let go
+ * side by side instead of the kernel doing it for all of them, one after the other, when the process exits */
+void fxh_lane_release(fxh_lane *ln)
+{
+    fxh_state *st = &ln->st;
+    if (!st->ctx) return;
+    (void)fxg_sync(st->ctx);
+    void *dev[] = {st->d_text, st->d_out_text, st->d_ls, st->d_len16, st->d_flags, st->d_bases, st->d_qual, st->d_len, st->d_res, st->d_out_bases, st->d_out_qual, st->d_out_off, st->d_counters};
+    for (size_t i = 0; i < sizeof dev / sizeof dev[0]; ++i) if (dev[i]) (void)fxg_free_device(st->ctx, dev[i]);
+    for (int i = 0; i < FXH_LANE_OUT_SLOTS; ++i) if (ln->out[i]) { (void)fxg_free_host(st->ctx, ln->out[i]); ln->out[i] = NULL; ln->out_cap[i] = 0; }
+    fxg_ctx_destroy(st->ctx);
+    memset(st, 0, sizeof *st);
+}
+
+static void *fxh_lane_main(void *arg)
+{
+    fxh_lane *ln = (fxh_lane *)arg;
+    if (ln->first && ln->first != ln) {
+        pthread_mutex_lock(&ln->first->mu);
+        while (!ln->first->ready) pthread_cond_wait(&ln->first->cv, &ln->first->mu);
+        pthread_mutex_unlock(&ln->first->mu);
+    }
+    double t0;
+    fxh_lane_open_ctx(ln);
     pthread_mutex_lock(&ln->mu);
     ln->ready = 1;
     pthread_cond_broadcast(&ln->cv);
@@ -167,13 +192,67 @@ static void fxh_lane_wait(fxh_lane *ln)
  * sharded run of 64 M reads (profiles/r03/z_e2e_numa.txt, bench.py e2e).  The calling thread only; threads it creates inherit it.
  * FXH_NO_NUMA=1 leaves the placement to the caller (taskset / numactl / a job scheduler that already did it). */
 /* returns 1 and the previous CPU set in *before when the calling thread was moved (the caller puts it back when the run is over) */
+/* The NUMA node of GPU `device` without starting the HIP runtime (tens of milliseconds that the first context pays anyway, but off this thread):
+ * the driver lists its nodes under /sys/class/kfd/kfd/topology/nodes/<i>/properties; the ones with SIMDs are the GPUs, in the runtime's device
+ * order as long as no *_VISIBLE_DEVICES variable reorders or hides any; domain + location_id name the PCI function, whose numa_node sysfs has.
+ * -1 = not found this way (no such driver node, a visibility variable, an emulated device): the caller asks the runtime. */
+static int fxh_numa_node_sysfs(int device)
+{
+    if (getenv("HIP_VISIBLE_DEVICES") || getenv("ROCR_VISIBLE_DEVICES") || getenv("CUDA_VISIBLE_DEVICES") || getenv("GPU_DEVICE_ORDINAL")) return -1;
+    int seen = 0;
+    for (int i = 0; i < 256; ++i) {
+        char path[160], key[64];
+        snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d", i);
+        if (access(path, F_OK) != 0) return -1;  /* nodes are numbered without gaps: the device is not there */
+        snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/properties", i);
+        FILE *f = fopen(path, "r");
+        if (!f) continue;                        /* a node this process may not see (a container with some of the box's GPUs): the runtime does not count it either */
+        unsigned long long v, simd = 0, loc = 0, dom = 0;
+        while (fscanf(f, "%63s %llu", key, &v) == 2) {
+            if (strcmp(key, "simd_count") == 0) simd = v;
+            else if (strcmp(key, "location_id") == 0) loc = v;
+            else if (strcmp(key, "domain") == 0) dom = v;
+        }
+        fclose(f);
+        if (!simd) continue;                     /* a CPU node */
+        if (seen++ != device) continue;
+        snprintf(path, sizeof path, "/sys/bus/pci/devices/%04llx:%02llx:%02llx.%llx/numa_node", dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7);
+        int node = -1;
+        f = fopen(path, "r");
+        if (f) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+        if (node >= 0) return node;
+        /* a guest or a container whose PCI tree does not show the function under that name: the driver's own link table does -- the GPU's PCIe
+         * link (type 2) ends at the CPU node it hangs off, and the driver makes its CPU nodes one per NUMA node, in NUMA order, ahead of the GPUs */
+        for (int l = 0; l < 32; ++l) {
+            unsigned long long type = 0, to = ~0ull;
+            snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/io_links/%d/properties", i, l);
+            f = fopen(path, "r");
+            if (!f) break;
+            while (fscanf(f, "%63s %llu", key, &v) == 2) { if (strcmp(key, "type") == 0) type = v; else if (strcmp(key, "node_to") == 0) to = v; }
+            fclose(f);
+            if (type == 2 && to < (unsigned long long)i) {
+                snprintf(path, sizeof path, "/sys/devices/system/node/node%llu/cpulist", to);
+                return access(path, R_OK) == 0 ? (int)to : -1;
+            }
+        }
+        return -1;
+    }
+    return -1;
+}
+
 int fxh_bind_near_device(int device, cpu_set_t *before)
 {
     if (getenv("FXH_NO_NUMA")) return 0;
-    pthread_mutex_lock(&g_first_ctx_mu);         /* the query is a first use of the HIP runtime: one thread at a time, like the first context */
-    const int node = fxg_device_numa_node(device);
-    g_hip_touched = 1;                           /* (no fork() over an initialised runtime from here on, fxh_run_parts) */
-    pthread_mutex_unlock(&g_first_ctx_mu);
+    const double t0 = fxh_now();
+    int node = fxh_numa_node_sysfs(device);
+    const int from_sysfs = node >= 0;
+    if (node < 0) {
+        pthread_mutex_lock(&g_first_ctx_mu);     /* the query is a first use of the HIP runtime: one thread at a time, like the first context */
+        node = fxg_device_numa_node(device);
+        g_hip_touched = 1;                       /* (no fork() over an initialised runtime from here on, fxh_run_parts) */
+        pthread_mutex_unlock(&g_first_ctx_mu);
+    }
+    if (getenv("FXH_TIMING")) fprintf(stderr, "fxh timing placement: GPU %d is on NUMA node %d (%s, %.1f ms)\n", device, node, from_sysfs ? "from sysfs" : "asked the runtime", 1e3 * (fxh_now() - t0));
     if (node < 0) return 0;
     char path[96], line[4096];
     snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);

@@ -17,9 +17,10 @@ uint32_t g_part_clip_len[FXH_MAX_LANES];
 /* empties the parts and exits, and the parent runs the input as one stream: messages, exit codes and partial output are the         */
 /* reference's in every case.                                                                                                         */
 /* ---------------------------------------------------------------------------------------------- */
-static off_t fxh_find_cut(int fd, off_t from, off_t size, int lpr)
+/* first record start after `from`, looked for in `window` bytes of text (-1: none found there) */
+off_t fxh_find_cut(int fd, off_t from, off_t size, int lpr, size_t window)
 {
-    const size_t W = (size_t)4 << 20;
+    const size_t W = window ? window : (size_t)4 << 20;
     char *w = (char *)malloc(W);
     if (!w) err(1, "out of memory");
     ssize_t got = pread(fd, w, W, from);
@@ -75,7 +76,7 @@ int fxh_run_parts(FASTX *fx, const fxg_params *p, fxh_totals *tot, int k)
     off_t cut[FXH_MAX_LANES + 1];
     cut[0] = 0; cut[k] = size;
     for (int r = 1; r < k; ++r) {
-        cut[r] = fxh_find_cut(rd->fd, (off_t)((unsigned long long)size * (unsigned)r / (unsigned)k), size, lpr);
+        cut[r] = fxh_find_cut(rd->fd, (off_t)((unsigned long long)size * (unsigned)r / (unsigned)k), size, lpr, 0);
         if (cut[r] < 0 || cut[r] <= cut[r - 1] || (r == 1 && cut[r] < here)) return -1;       /* small or odd input: one run */
     }
     /* The sharded attempt runs in a CHILD process.  Irregular input anywhere (or a cut that was no record boundary) abandons it: the

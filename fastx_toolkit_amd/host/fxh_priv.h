@@ -132,6 +132,8 @@ typedef struct {
 
 /* lanes (fxh_lanes.c) */
 #define FXH_MAX_LANES 32
+#define FXH_LANE_OUT_SLOTS 8
+#define FXH_RECORDS_UNKNOWN ((uint64_t)-1)      /* fxh_lane.records: take what the device index finds (it still has to be whole records) */
 extern int g_parts_abort;                  /* sharded run: some part met input it does not handle (fxh_run_parts); relaxed atomics, it is only a "stop soon" */
 #define FXH_ABORT_SET() __atomic_store_n(&g_parts_abort, 1, __ATOMIC_RELAXED)
 #define FXH_ABORTED()   __atomic_load_n(&g_parts_abort, __ATOMIC_RELAXED)
@@ -164,9 +166,11 @@ typedef struct fxh_lane {
     uint32_t fixed_len;                    /* result: the one length of the block's reads, 0 = they differ (or the block was not indexed) */
     int slot;                              /* which of out[] receives the text (the other may still be with the writer) */
     int handled;                           /* result: 0 = irregular block, parse it on the host */
-    char *out[2]; size_t out_cap[2]; size_t out_len;
+    char *out[FXH_LANE_OUT_SLOTS]; size_t out_cap[FXH_LANE_OUT_SLOTS]; size_t out_len;      /* (the lanes loop uses two, the strands of the one-file run more) */
     uint64_t ctr[FXG_NCOUNTERS];
     uint64_t weighted[8];                  /* FASTA: tallies weighted by the records' read counts (fxg_fasta_weights) */
+    void (*on_size)(struct fxh_lane *, uint64_t out_bytes);      /* one-file sharded run: called once the block's formatted size is known, before its download */
+    void *owner;
     double t_busy, t_init;
     double t_call[8];                        /* FXH_TIMING: seconds inside h2d, index, pack, pipeline, counters, format, d2h+sync, blocks */
 } fxh_lane;
@@ -238,6 +242,11 @@ int fxh_bind_near_device(int device, cpu_set_t *before);
 int fxh_device_list(int *dev, int cap);
 void fxh_host_block(fxh_run *R);
 void fxh_add_counters(fxh_totals *tot, const uint64_t *ctr, uint64_t n, const uint64_t *weighted);
+void fxh_lane_run(fxh_lane *ln);
+void fxh_lane_open_ctx(fxh_lane *ln);
+void fxh_lane_release(fxh_lane *ln);
+int fxh_run_one_file(FASTX *fx, const fxg_params *p, fxh_totals *tot);
+off_t fxh_find_cut(int fd, off_t from, off_t size, int lpr, size_t window);
 void fxh_lanes_stop(fxh_run *R, fxh_lane *lanes, int nlanes, double *t_lane_init);
 void fxh_run_lanes(fxh_run *R, fxh_prefetch *pf, int nlanes, const int *lane_dev, double *t_read, double *t_lane_init);
 int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_stats_run *stats, uint64_t **hist_out, uint32_t *cols_out, int part, int nparts);

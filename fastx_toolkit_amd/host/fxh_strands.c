@@ -1,0 +1,649 @@
+/* fxh_strands.c -- `tool -i in.fq -o out.fq`, ONE output file, at the speed of the sharded run (fxh_priv.h). */
+/* ---------------------------------------------------------------------------------------------- */
+/* The reference writes one output stream (fastx.c:251-271: one fdopen; fastx.c:440-473).  The sharded run of fxh_parts.c is fast because */
+/* it has k of everything -- k byte ranges read side by side, k x lanes on the device, k output FILES -- and that last k is what no        */
+/* reference command line has.  Here the same input goes to ONE file, written at exact offsets by many threads:                             */
+/*   * the input file is cut into CHUNKS (16 MB) at record boundaries found by pattern and proven by induction, exactly like the parts       */
+/*     (chunk c ends where chunk c + 1 begins; a chunk that is not a whole number of regular records stops the attempt);                   */
+/*   * STRANDS (one thread + one engine context each, FXH_STRANDS per GPU) draw chunk numbers from one counter, so the chunk order IS the   */
+/*     output order; a strand reads its chunk with parallel pread(), uploads, indexes, decides and formats it on the device;                */
+/*   * the formatted SIZE of a chunk is known before its text comes down.  Sizes are published in an array; the file offset of chunk c is   */
+/*     the sum of the sizes before it (a running scan advanced by whoever publishes), so it is known as soon as every earlier chunk has     */
+/*     been DECIDED -- not written, not even downloaded.  The smallest unfinished chunk never waits for anybody, every strand owns its      */
+/*     buffers, so there is no deadlock by construction.  No second pass over the input, no text held back in HBM: the two-phase form       */
+/*     (sizes first, text later) would serialise upload and download on the PCIe link, which is the resource the run is bound by;           */
+/*   * the SINK.  One inode of a tmpfs (or any page cache) takes fresh pages from ONE thread at a time: concurrent pwrite() serialise on    */
+/*     the inode lock (4 GB/s with 8 threads against 9 with one), concurrent faults on a shared mapping on the mapping's locks (5 GB/s),     */
+/*     k files take 30-90 GB/s (profiles/r05/a_one_file_write.txt).  What does scale is copying into pages that EXIST: fallocate()          */
+/*     allocates without zeroing or copying at 18 GB/s as long as nobody faults on the file meanwhile, and 16 threads then copy into the     */
+/*     mapping at 30 GB/s.  So allocation and copies take turns behind a gate (fxh_sf_alloc_main), the allocator runs ahead in 128 MB        */
+/*     windows -- from the first milliseconds of the process, while the device is still starting and nothing is there to be written --       */
+/*     and the copies drop their page-table entries themselves (MADV_DONTNEED, shared mmap_lock), so the process does not spend 0.2 s        */
+/*     unmapping at exit.  Measured with the tool's own access pattern: 10 GB into one tmpfs file in 0.65 s after a 0.25 s head start,       */
+/*     against 1.4 s through one pwrite() stream and 1.6 s ungated (profiles/r05/d_one_file_gate.txt).  Other file systems get pwrite().    */
+/* Anything irregular (a malformed record, a cut that was not a boundary, a clipper input whose reads are not all of one length) abandons   */
+/* the attempt exactly like the sharded run: it lives in a forked child, which empties the file and leaves with FXH_EXIT_ABANDON, and the   */
+/* parent -- which has not touched the GPU -- runs the input as one stream, so messages, exit codes and partial output are the reference's. */
+/* ---------------------------------------------------------------------------------------------- */
+#include "fxh_priv.h"
+#include <sys/mman.h>
+#include <sys/vfs.h>
+#ifndef TMPFS_MAGIC
+#define TMPFS_MAGIC 0x01021994
+#endif
+
+#define FXH_TICKET_DONE ((uint64_t)-1)
+#define FXH_MAX_STRANDS FXH_MAX_LANES
+
+/* ---- a small pool of worker threads: tasks never wait for other tasks ---- */
+typedef struct { void (*fn)(void *); void *arg; } fxh_task;
+typedef struct fxh_pool {
+    pthread_mutex_t mu;
+    pthread_cond_t cv_work, cv_space;
+    fxh_task *q;
+    unsigned cap, head, count;
+    int quit, nth;
+    pthread_t th[64];
+} fxh_pool;
+
+static void *fxh_pool_main(void *arg)
+{
+    fxh_pool *P = (fxh_pool *)arg;
+    pthread_mutex_lock(&P->mu);
+    for (;;) {
+        while (P->count == 0 && !P->quit) pthread_cond_wait(&P->cv_work, &P->mu);
+        if (P->count == 0) break;
+        const fxh_task t = P->q[P->head];
+        P->head = (P->head + 1) % P->cap; P->count--;
+        pthread_cond_signal(&P->cv_space);
+        pthread_mutex_unlock(&P->mu);
+        t.fn(t.arg);
+        pthread_mutex_lock(&P->mu);
+    }
+    pthread_mutex_unlock(&P->mu);
+    return NULL;
+}
+
+static void fxh_pool_start(fxh_pool *P, int nth, unsigned cap)
+{
+    memset(P, 0, sizeof *P);
+    pthread_mutex_init(&P->mu, NULL); pthread_cond_init(&P->cv_work, NULL); pthread_cond_init(&P->cv_space, NULL);
+    P->cap = cap; P->q = (fxh_task *)calloc(cap, sizeof(fxh_task));
+    if (!P->q) err(1, "out of memory");
+    if (nth > 64) nth = 64;
+    if (nth < 1) nth = 1;
+    P->nth = nth;
+    for (int i = 0; i < nth; ++i) if (pthread_create(&P->th[i], NULL, fxh_pool_main, P) != 0) err(1, "pthread_create");
+}
+
+static void fxh_pool_submit(fxh_pool *P, void (*fn)(void *), void *arg)
+{
+    pthread_mutex_lock(&P->mu);
+    while (P->count == P->cap) pthread_cond_wait(&P->cv_space, &P->mu);
+    P->q[(P->head + P->count) % P->cap].fn = fn;
+    P->q[(P->head + P->count) % P->cap].arg = arg;
+    P->count++;
+    pthread_cond_signal(&P->cv_work);
+    pthread_mutex_unlock(&P->mu);
+}
+
+static void fxh_pool_stop(fxh_pool *P)       /* queued tasks are still run */
+{
+    pthread_mutex_lock(&P->mu);
+    P->quit = 1;
+    pthread_cond_broadcast(&P->cv_work);
+    pthread_mutex_unlock(&P->mu);
+    for (int i = 0; i < P->nth; ++i) pthread_join(P->th[i], NULL);
+    free(P->q);
+}
+
+/* ---- the run ---- */
+typedef struct fxh_sf fxh_sf;
+typedef struct fxh_strand fxh_strand;
+typedef struct { fxh_strand *s; int fd; char *dst; size_t n; off_t off; } fxh_rjob;
+typedef struct { fxh_strand *s; int slot; } fxh_wjob;
+
+struct fxh_strand {
+    int id;
+    fxh_sf *S;
+    fxh_lane ln;                           /* the engine context, its device buffers and the two page-locked output buffers (fxh_lanes.c) */
+    pthread_t th_gpu, th_rd;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    /* input slots: filled by the strand's reader in ticket order, emptied by its device thread */
+    char *in[2];
+    size_t in_len[2];
+    uint64_t in_ticket[2];
+    int in_full[2];
+    int rd_pending;                        /* pread slices of the chunk being read that have not finished */
+    fxh_rjob rjob[16];
+    /* output slots: ln.out[0 .. nout), from the device thread to the copy tasks */
+    size_t out_len[FXH_LANE_OUT_SLOTS];
+    uint64_t out_off[FXH_LANE_OUT_SLOTS];
+    int out_full[FXH_LANE_OUT_SLOTS];
+    fxh_wjob wjob[FXH_LANE_OUT_SLOTS];
+    uint64_t cur_ticket;
+    fxh_totals tot;
+    uint64_t chunks;
+    double t_read, t_wait_in, t_gpu, t_wait_out, t_wait_off, t_release;
+};
+
+struct fxh_sf {
+    FASTX *fx;
+    const fxg_params *p;
+    int in_fd, lpr, clip_auto;
+    off_t *cut;                            /* chunk c is the input bytes [cut[c], cut[c + 1]) */
+    uint64_t nchunks, in_total;
+    size_t in_cap;
+    uint64_t next_ticket;                  /* atomic: the next chunk nobody has taken */
+    int nstrands, nread_slices, nout, release;
+    fxh_strand *st;
+    fxh_pool rpool, wpool;
+    /* sizes -> offsets, the clipper's one read length, the allocator's state: all under mu / cv */
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    uint64_t *size, *offset;
+    uint8_t *have;
+    uint64_t scanned, scan_off, published, in_done, out_done;
+    uint32_t clip_len;
+    /* sink */
+    int out_fd, mapped;
+    char *map;
+    uint64_t map_len, alloc_end, need, window;
+    int alloc_errno, alloc_stop;
+    pthread_t th_alloc;
+    pthread_rwlock_t gate;                 /* fallocate() exclusive, copies shared; writer-preferring */
+    double t_alloc, t_copy, t_copy_wait;   /* t_copy*: summed over the copy tasks, under mu */
+    uint64_t alloc_calls;
+};
+
+static void fxh_sf_abort(fxh_sf *S)
+{
+    FXH_ABORT_SET();
+    for (int i = 0; i < S->nstrands; ++i) { pthread_mutex_lock(&S->st[i].mu); pthread_cond_broadcast(&S->st[i].cv); pthread_mutex_unlock(&S->st[i].mu); }
+    pthread_mutex_lock(&S->mu); pthread_cond_broadcast(&S->cv); pthread_mutex_unlock(&S->mu);
+}
+
+/* how far the allocation should reach now (mu held): everything, once every size is known; before that the output expected from the
+ * chunks decided so far -- and, while there are none, a quarter of the input (at most 8 GB): the head start the device's start-up gives */
+static uint64_t fxh_sf_alloc_goal(const fxh_sf *S)
+{
+    uint64_t goal;
+    if (S->published == S->nchunks) goal = S->scan_off;
+    else if (S->in_done >= ((uint64_t)64 << 20)) {
+        const long double r = (long double)S->out_done / (long double)S->in_done;
+        goal = (uint64_t)(r * 1.02L * (long double)S->in_total) + ((uint64_t)32 << 20);
+    } else {
+        goal = S->in_total / 4;
+        if (goal > ((uint64_t)8 << 30)) goal = (uint64_t)8 << 30;
+    }
+    if (S->published != S->nchunks && goal < S->need) goal = S->need;
+    if (goal > S->map_len) goal = S->map_len;
+    return goal;
+}
+
+/* The allocator.  Allocation and copies exclude each other (S->gate: fallocate() exclusive, every copied megabyte shared, the allocator preferred),
+ * and the allocator is EAGER: it runs ahead of the copies towards the expected size of the output whenever it gets the file.  What it allocates before
+ * the first chunk comes back from the device costs nothing, and the sooner it is through, the longer the copies have the file to themselves at full
+ * parallelism.  (Measured alternative: copies first while their pages exist, the allocator only in the sink's idle moments and with priority when a
+ * copy waits for pages -- 45 against 53-56 Mreads/s: the sink then spends the run switching, each switch waiting for the running copies to drain;
+ * profiles/r05/g_e2e_one_file_copies_first.txt.) */
+static void *fxh_sf_alloc_main(void *arg)
+{
+    fxh_sf *S = (fxh_sf *)arg;
+    pthread_mutex_lock(&S->mu);
+    while (!S->alloc_stop && !FXH_ABORTED() && !S->alloc_errno) {
+        const uint64_t goal = fxh_sf_alloc_goal(S);
+        if (S->alloc_end >= goal) {
+            if (S->published == S->nchunks) break;          /* the whole output has its pages */
+            pthread_cond_wait(&S->cv, &S->mu);
+            continue;
+        }
+        const uint64_t a = S->alloc_end;
+        uint64_t step = goal - a < S->window ? goal - a : S->window;
+        step = (step + 4095u) & ~(uint64_t)4095u;
+        if (a + step > S->map_len) step = S->map_len - a;
+        pthread_mutex_unlock(&S->mu);
+        pthread_rwlock_wrlock(&S->gate);                     /* no copy faults on the file while its pages are being made */
+        const double t0 = fxh_now();
+        int rc;
+        do rc = fallocate(S->out_fd, 0, (off_t)a, (off_t)step); while (rc != 0 && errno == EINTR);
+        const int e = rc != 0 ? errno : 0;
+        const double dt = fxh_now() - t0;
+        pthread_rwlock_unlock(&S->gate);
+        pthread_mutex_lock(&S->mu);
+        S->t_alloc += dt; S->alloc_calls++;
+        if (e) S->alloc_errno = e; else S->alloc_end = a + step;
+        pthread_cond_broadcast(&S->cv);
+    }
+    pthread_mutex_unlock(&S->mu);
+    return NULL;
+}
+
+/* the lane's hook: the chunk's formatted size is known (fxh_lane_run, after the format kernels, before the download) */
+static void fxh_sf_publish(fxh_lane *ln, uint64_t bytes)
+{
+    fxh_strand *s = (fxh_strand *)ln->owner;
+    fxh_sf *S = s->S;
+    const uint64_t t = s->cur_ticket;
+    pthread_mutex_lock(&S->mu);
+    S->size[t] = bytes; S->have[t] = 1; S->published++;
+    S->in_done += (uint64_t)(S->cut[t + 1] - S->cut[t]); S->out_done += bytes;
+    while (S->scanned < S->nchunks && S->have[S->scanned]) { S->offset[S->scanned] = S->scan_off; S->scan_off += S->size[S->scanned]; S->scanned++; }
+    pthread_cond_broadcast(&S->cv);
+    pthread_mutex_unlock(&S->mu);
+}
+
+static void fxh_sf_read_task(void *arg)
+{
+    fxh_rjob *j = (fxh_rjob *)arg;
+    size_t got = 0;
+    while (got < j->n) {
+        const ssize_t k = pread(j->fd, j->dst + got, j->n - got, j->off + (off_t)got);
+        if (k < 0) { if (errno == EINTR) continue; err(1, "read failed"); }
+        if (k == 0) break;                                   /* the file shrank under the run */
+        got += (size_t)k;
+    }
+    fxh_strand *s = j->s;
+    if (got < j->n) fxh_sf_abort(s->S);
+    pthread_mutex_lock(&s->mu);
+    s->rd_pending--;
+    pthread_cond_broadcast(&s->cv);
+    pthread_mutex_unlock(&s->mu);
+}
+
+static void *fxh_strand_reader(void *arg)
+{
+    fxh_strand *s = (fxh_strand *)arg;
+    fxh_sf *S = s->S;
+    for (int k = 0;; k ^= 1) {
+        pthread_mutex_lock(&s->mu);
+        while (s->in_full[k] && !FXH_ABORTED()) pthread_cond_wait(&s->cv, &s->mu);
+        pthread_mutex_unlock(&s->mu);
+        if (FXH_ABORTED()) break;
+        const uint64_t t = __atomic_fetch_add(&S->next_ticket, 1, __ATOMIC_RELAXED);      /* drawn with a free buffer in hand: the smallest open chunk always has one */
+        if (t >= S->nchunks) {
+            pthread_mutex_lock(&s->mu);
+            s->in_ticket[k] = FXH_TICKET_DONE; s->in_full[k] = 1;
+            pthread_cond_broadcast(&s->cv);
+            pthread_mutex_unlock(&s->mu);
+            break;
+        }
+        const double t0 = fxh_now();
+        const off_t off = S->cut[t];
+        size_t n = (size_t)(S->cut[t + 1] - off);
+        int ns = S->nread_slices;
+        if ((size_t)ns > n / ((size_t)1 << 20)) ns = (int)(n / ((size_t)1 << 20));
+        if (ns < 1) ns = 1;
+        const size_t per = (n + (size_t)ns - 1) / (size_t)ns;
+        pthread_mutex_lock(&s->mu); s->rd_pending = ns; pthread_mutex_unlock(&s->mu);
+        for (int i = 0; i < ns; ++i) {
+            const size_t o = (size_t)i * per;
+            fxh_rjob *j = &s->rjob[i];
+            j->s = s; j->fd = S->in_fd; j->dst = s->in[k] + o; j->off = off + (off_t)o; j->n = o >= n ? 0 : (n - o < per ? n - o : per);
+            if (i + 1 < ns) fxh_pool_submit(&S->rpool, fxh_sf_read_task, j);
+        }
+        fxh_sf_read_task(&s->rjob[ns - 1]);                 /* the last slice on this thread */
+        pthread_mutex_lock(&s->mu);
+        while (s->rd_pending > 0) pthread_cond_wait(&s->cv, &s->mu);
+        pthread_mutex_unlock(&s->mu);
+        if (FXH_ABORTED()) break;
+        if (t + 1 == S->nchunks && s->in[k][n - 1] != '\n') s->in[k][n++] = '\n';       /* the reference takes a last line without its newline (chomp.c:36-41) */
+        s->t_read += fxh_now() - t0;
+        pthread_mutex_lock(&s->mu);
+        s->in_len[k] = n; s->in_ticket[k] = t; s->in_full[k] = 1;
+        pthread_cond_broadcast(&s->cv);
+        pthread_mutex_unlock(&s->mu);
+    }
+    return NULL;
+}
+
+static void fxh_sf_write_task(void *arg)
+{
+    fxh_wjob *j = (fxh_wjob *)arg;
+    fxh_strand *s = j->s;
+    fxh_sf *S = s->S;
+    const char *src = s->ln.out[j->slot];
+    const size_t len = s->out_len[j->slot];
+    const uint64_t off = s->out_off[j->slot];
+    double t0 = fxh_now(), t_wait = 0;
+    if (len && S->mapped && off + len > S->map_len) fxh_sf_abort(S);      /* (cannot happen: 8/7 of the input bounds the output; one stream if it ever does) */
+    else if (len && S->mapped) {
+        pthread_mutex_lock(&S->mu);
+        while (S->alloc_end < off + len && !S->alloc_errno && !FXH_ABORTED()) {
+            if (S->need < off + len) { S->need = off + len; pthread_cond_broadcast(&S->cv); }
+            pthread_cond_wait(&S->cv, &S->mu);
+        }
+        const int e = S->alloc_errno;
+        pthread_mutex_unlock(&S->mu);
+        t_wait = fxh_now() - t0;
+        if (e) { errno = e; err(1, "writing output failed"); }
+        if (!FXH_ABORTED()) {
+            /* the whole buffer under one hold of the gate.  The allocator is preferred, so the sink strictly alternates: a window of pages, then
+             * EVERY copy that has piled up meanwhile side by side (copies are only fast many at a time), then the next window.  (A megabyte per
+             * hold let the allocator in sooner and the copies trickle: 48.7 against 54.6 Mreads/s, profiles/r05/h_e2e_one_file_piecewise.txt.) */
+            const double tw = fxh_now();
+            pthread_rwlock_rdlock(&S->gate);
+            t_wait += fxh_now() - tw;
+            memcpy(S->map + off, src, len);
+            /* the pages stay in the file; only this process's view of them goes, now and by this thread, instead of at exit and by one */
+            const uint64_t a = (off + 4095u) & ~(uint64_t)4095u, b = (off + len) & ~(uint64_t)4095u;
+            if (b > a) (void)madvise(S->map + a, (size_t)(b - a), MADV_DONTNEED);
+            pthread_rwlock_unlock(&S->gate);
+        }
+    } else if (len) {
+        size_t done = 0;
+        while (done < len && !FXH_ABORTED()) {
+            const ssize_t k = pwrite(S->out_fd, src + done, len - done, (off_t)(off + done));
+            if (k < 0) { if (errno == EINTR) continue; err(1, "writing output failed"); }
+            done += (size_t)k;
+        }
+    }
+    const double dt = fxh_now() - t0 - t_wait;
+    pthread_mutex_lock(&S->mu); S->t_copy += dt; S->t_copy_wait += t_wait; pthread_mutex_unlock(&S->mu);
+    pthread_mutex_lock(&s->mu);
+    s->out_full[j->slot] = 0;
+    pthread_cond_broadcast(&s->cv);
+    pthread_mutex_unlock(&s->mu);
+}
+
+static void *fxh_strand_gpu(void *arg)
+{
+    fxh_strand *s = (fxh_strand *)arg;
+    fxh_sf *S = s->S;
+    fxh_lane *ln = &s->ln;
+    fxh_lane_open_ctx(ln);
+    for (int k = 0; k < 2; ++k) (void)fxg_host_register(ln->st.ctx, s->in[k], S->in_cap);      /* page-locked: the upload is real DMA */
+    int j = 0;
+    for (int k = 0;; k ^= 1) {
+        double t0 = fxh_now();
+        pthread_mutex_lock(&s->mu);
+        while (!s->in_full[k] && !FXH_ABORTED()) pthread_cond_wait(&s->cv, &s->mu);
+        const uint64_t t = s->in_ticket[k];
+        const size_t len = s->in_len[k];
+        pthread_mutex_unlock(&s->mu);
+        s->t_wait_in += fxh_now() - t0;
+        if (FXH_ABORTED() || t == FXH_TICKET_DONE) break;
+        t0 = fxh_now();
+        pthread_mutex_lock(&s->mu);
+        while (s->out_full[j] && !FXH_ABORTED()) pthread_cond_wait(&s->cv, &s->mu);
+        pthread_mutex_unlock(&s->mu);
+        s->t_wait_out += fxh_now() - t0;
+        if (FXH_ABORTED()) break;
+        t0 = fxh_now();
+        ln->text_base = NULL; ln->text_cap = 0;
+        ln->text = s->in[k]; ln->len = len; ln->records = FXH_RECORDS_UNKNOWN; ln->slot = j;
+        s->cur_ticket = t;
+        fxh_lane_run(ln);
+        s->t_gpu += fxh_now() - t0;
+        int ok = ln->handled;
+        if (ok && S->clip_auto) {                            /* the clipper's lanes are exact while ALL reads have one length: every chunk the same one */
+            pthread_mutex_lock(&S->mu);
+            if (!ln->fixed_len) ok = 0;
+            else if (!S->clip_len) S->clip_len = ln->fixed_len;
+            else if (S->clip_len != ln->fixed_len) ok = 0;
+            pthread_mutex_unlock(&S->mu);
+        }
+        if (!ok) { fxh_sf_abort(S); break; }                 /* whatever it is, the one-stream run owns the reference's behaviour for it */
+        fxh_add_counters(&s->tot, ln->ctr, ln->records, ln->lpr == 2 ? ln->weighted : NULL);
+        s->chunks++;
+        pthread_mutex_lock(&s->mu);                          /* the text is on the device: the reader may fill the buffer again */
+        s->in_full[k] = 0;
+        pthread_cond_broadcast(&s->cv);
+        pthread_mutex_unlock(&s->mu);
+        t0 = fxh_now();
+        pthread_mutex_lock(&S->mu);
+        while (S->scanned <= t && !FXH_ABORTED()) pthread_cond_wait(&S->cv, &S->mu);
+        const uint64_t off = S->offset[t];
+        pthread_mutex_unlock(&S->mu);
+        s->t_wait_off += fxh_now() - t0;
+        if (FXH_ABORTED()) break;
+        pthread_mutex_lock(&s->mu);
+        s->out_len[j] = ln->out_len; s->out_off[j] = off; s->out_full[j] = 1;
+        pthread_cond_broadcast(&s->cv);
+        pthread_mutex_unlock(&s->mu);
+        s->wjob[j].s = s; s->wjob[j].slot = j;
+        fxh_pool_submit(&S->wpool, fxh_sf_write_task, &s->wjob[j]);
+        j = (j + 1) % S->nout;
+    }
+    pthread_mutex_lock(&s->mu);                              /* the strand's text is in the file (or the run is over) before its buffers may go */
+    for (;;) {
+        int busy = 0;
+        for (int q = 0; q < S->nout; ++q) busy |= s->out_full[q];
+        if (!busy || FXH_ABORTED()) break;
+        pthread_cond_wait(&s->cv, &s->mu);
+    }
+    pthread_mutex_unlock(&s->mu);
+    if (S->release && !FXH_ABORTED()) {
+        const double t0 = fxh_now();
+        for (int k = 0; k < 2; ++k) (void)fxg_host_unregister(ln->st.ctx, s->in[k]);
+        fxh_lane_release(ln);
+        s->t_release = fxh_now() - t0;
+    }
+    return NULL;
+}
+
+/* the cuts, found side by side before anything runs */
+typedef struct { int fd, lpr; off_t start, size; size_t chunk; off_t *cut; uint64_t c0, c1; int bad; } fxh_cutjob;
+static void *fxh_cut_main(void *arg)
+{
+    fxh_cutjob *j = (fxh_cutjob *)arg;
+    for (uint64_t c = j->c0; c < j->c1 && !j->bad; ++c) {
+        const off_t from = j->start + (off_t)(c * (uint64_t)j->chunk);
+        off_t f = fxh_find_cut(j->fd, from, j->size, j->lpr, (size_t)64 << 10);
+        if (f < 0) f = fxh_find_cut(j->fd, from, j->size, j->lpr, 0);
+        if (f < 0) j->bad = 1;
+        j->cut[c] = f;
+    }
+    return NULL;
+}
+
+static long fxh_env_long(const char *name, long dflt, long lo, long hi)
+{
+    const char *e = getenv(name);
+    long v = e && *e ? atol(e) : dflt;
+    if (v < lo) v = lo;
+    if (v > hi) v = hi;
+    return v;
+}
+
+/* 0 = done (in the child of the fork below: the caller goes on to print its reports); -1 = run as one stream (not eligible, or the attempt was abandoned) */
+int fxh_run_one_file(FASTX *fx, const fxg_params *p, fxh_totals *tot)
+{
+    struct fxh_reader *rd = fx->reader;
+    struct fxh_writer *w0 = fx->writer;
+    struct stat sb, ob;
+    const char *sw = getenv("FXH_ONE_FILE");
+    if (sw && atoi(sw) == 0) return -1;
+    if (fstat(rd->fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return -1;
+    if (strcmp(fx->output_file_name, "-") == 0 || fx->compress_output || g_rename_ids || getenv("FXH_HOST_PARSE")) return -1;
+    if (!w0 || w0->fd < 0 || !w0->positional || w0->len != 0 || fstat(w0->fd, &ob) != 0 || !S_ISREG(ob.st_mode)) return -1;
+    if (ob.st_dev == sb.st_dev && ob.st_ino == sb.st_ino) return -1;
+    const int clip = (p->stages & FXG_STAGE_CLIP) != 0;
+    if (clip && getenv("FXH_CLIP_SERIAL") != NULL && getenv("FXH_CLIP_PARALLEL") == NULL) return -1;      /* one aligner asked for */
+    if (g_hip_touched) return -1;                /* no fork over a live runtime (a host that calls in twice) */
+    const off_t pos = lseek(rd->fd, 0, SEEK_CUR);
+    if (pos < 0) return -1;
+    const off_t start = pos - (off_t)(rd->end - rd->beg), size = sb.st_size;      /* where the unread input begins in the file */
+    if (start < 0 || start >= size) return -1;
+    const long min_mb = fxh_env_long("FXH_ONE_FILE_MIN_MB", 1024, 0, 1 << 30);
+    if ((long long)(size - start) < ((long long)min_mb << 20)) return -1;
+    const int lpr = fx->read_fastq ? 4 : 2;
+    size_t chunk = (size_t)fxh_env_long("FXH_STRAND_KB", 0, 0, 1 << 22) << 10;     /* (tests: chunks of a few KB) */
+    if (!chunk) chunk = (size_t)fxh_env_long("FXH_STRAND_MB", 16, 1, 1024) << 20;      /* 16 MB: 54.6 against 51.7 Mreads/s with 8 (profiles/r05/f_e2e_one_file_timeline.txt) */
+    const uint64_t nchunks = ((uint64_t)(size - start) + chunk - 1) / chunk;
+    if (nchunks < 2) return -1;
+    off_t *cut = (off_t *)calloc(nchunks + 1, sizeof(off_t));
+    if (!cut) err(1, "out of memory");
+    cut[0] = start; cut[nchunks] = size;
+    {
+        fxh_cutjob cj[8];
+        pthread_t th[8];
+        const int nt = nchunks > 64 ? 8 : 1;
+        for (int i = 0; i < nt; ++i) {
+            cj[i].fd = rd->fd; cj[i].lpr = lpr; cj[i].start = start; cj[i].size = size; cj[i].chunk = chunk; cj[i].cut = cut; cj[i].bad = 0;
+            cj[i].c0 = 1 + (nchunks - 1) * (uint64_t)i / (uint64_t)nt; cj[i].c1 = 1 + (nchunks - 1) * (uint64_t)(i + 1) / (uint64_t)nt;
+        }
+        for (int i = 1; i < nt; ++i) if (pthread_create(&th[i], NULL, fxh_cut_main, &cj[i]) != 0) err(1, "pthread_create");
+        fxh_cut_main(&cj[0]);
+        for (int i = 1; i < nt; ++i) pthread_join(th[i], NULL);
+        int bad = 0;
+        for (int i = 0; i < nt; ++i) bad |= cj[i].bad;
+        size_t longest = 0;
+        for (uint64_t c = 0; c < nchunks && !bad; ++c) {
+            if (cut[c + 1] <= cut[c]) bad = 1;               /* records longer than a chunk, or no record pattern in reach: one stream */
+            else if ((size_t)(cut[c + 1] - cut[c]) > longest) longest = (size_t)(cut[c + 1] - cut[c]);
+        }
+        if (bad || longest > chunk + chunk / 2) { free(cut); return -1; }
+        chunk = longest;                                     /* (now: the buffer a chunk needs) */
+    }
+    /* The attempt runs in a CHILD process, like the sharded run's (fxh_parts.c): anything irregular abandons it, the child empties the
+     * file and exits with FXH_EXIT_ABANDON, and this process -- which has not touched the GPU -- runs the same input as one stream. */
+    fflush(NULL);
+    const double t_fork = fxh_now();
+    const pid_t child = fork();
+    if (child < 0) { free(cut); return -1; }
+    if (child > 0) {
+        int st = 0;
+        free(cut);
+        while (waitpid(child, &st, 0) < 0) { if (errno != EINTR) err(1, "waitpid"); }
+        if (getenv("FXH_TIMING")) fprintf(stderr, "fxh timing one file: the child was gone %.3f s after the fork, at %.3f (CLOCK_MONOTONIC)\n", fxh_now() - t_fork, fxh_now());
+        if (WIFEXITED(st) && WEXITSTATUS(st) == FXH_EXIT_ABANDON) {
+            if (ftruncate(w0->fd, w0->off) != 0) warn("%s", fx->output_file_name);
+            return -1;
+        }
+        if (WIFSIGNALED(st)) { signal(WTERMSIG(st), SIG_DFL); raise(WTERMSIG(st)); _exit(128 + WTERMSIG(st)); }
+        _exit(WIFEXITED(st) ? WEXITSTATUS(st) : 1);          /* the child printed the reports and closed the file */
+    }
+    (void)prctl(PR_SET_PDEATHSIG, SIGTERM);      /* the child: a tool process that was killed takes its attempt along */
+    const int timing = getenv("FXH_TIMING") != NULL;
+    const double t_run0 = fxh_now();
+    static fxh_sf S_;                            /* (static: zeroed, and alive for the whole child) */
+    fxh_sf *S = &S_;
+    S->fx = fx; S->p = p; S->in_fd = rd->fd; S->lpr = lpr; S->cut = cut; S->nchunks = nchunks; S->in_total = (uint64_t)(size - start);
+    S->in_cap = (chunk + 4096 + 4095) & ~(size_t)4095;
+    S->clip_auto = clip && getenv("FXH_CLIP_PARALLEL") == NULL;
+    S->out_fd = w0->fd;
+    pthread_mutex_init(&S->mu, NULL); pthread_cond_init(&S->cv, NULL);
+    S->size = (uint64_t *)calloc(nchunks, sizeof(uint64_t)); S->offset = (uint64_t *)calloc(nchunks, sizeof(uint64_t)); S->have = (uint8_t *)calloc(nchunks, 1);
+    if (!S->size || !S->offset || !S->have) err(1, "out of memory");
+    __atomic_store_n(&g_parts_abort, 0, __ATOMIC_RELAXED);
+    g_parts_mode = 1;
+
+    int dev[FXH_MAX_LANES];
+    const int ndev = fxh_device_list(dev, FXH_MAX_LANES);
+    cpu_set_t cpus_before;
+    const double t_dev = fxh_now();
+    if (ndev == 1) (void)fxh_bind_near_device(dev[0], &cpus_before);      /* buffers and the output's pages are touched (and page-locked) on the GPU's node; every thread below inherits it */
+    const double t_bound = fxh_now();
+
+    /* the sink: a tmpfs file written from offset 0 gets the gated mapping, everything else positional writes */
+    {
+        struct statfs fs;
+        const char *sk = getenv("FXH_ONE_FILE_SINK");        /* "map" | "pwrite": force one (tests) */
+        int want_map = sk ? strcmp(sk, "map") == 0 : (fstatfs(w0->fd, &fs) == 0 && (unsigned long)fs.f_type == (unsigned long)TMPFS_MAGIC);
+        if (w0->off != 0) want_map = 0;
+        if (want_map) {
+            S->map_len = (S->in_total + S->in_total / 7 + (1u << 20) + 4095u) & ~(uint64_t)4095u;      /* an empty third line still gets its '+': at most 8/7 of the input */
+            S->window = (uint64_t)fxh_env_long("FXH_ONE_FILE_WINDOW_MB", 128, 1, 1 << 16) << 20;
+            void *m = MAP_FAILED;
+            if (ftruncate(w0->fd, (off_t)S->map_len) == 0) m = mmap(NULL, (size_t)S->map_len, PROT_READ | PROT_WRITE, MAP_SHARED, w0->fd, 0);
+            if (m != MAP_FAILED && fallocate(w0->fd, 0, 0, 4096) == 0) {
+                S->map = (char *)m; S->mapped = 1; S->alloc_end = 4096;
+                pthread_rwlockattr_t ra;
+                pthread_rwlockattr_init(&ra);
+                pthread_rwlockattr_setkind_np(&ra, PTHREAD_RWLOCK_PREFER_WRITER_NONRECURSIVE_NP);      /* the allocator is one against many: it goes first */
+                pthread_rwlock_init(&S->gate, &ra);
+                if (pthread_create(&S->th_alloc, NULL, fxh_sf_alloc_main, S) != 0) err(1, "pthread_create");      /* from the first millisecond on */
+            } else {                                          /* no mapping or no fallocate() here: positional writes */
+                if (m != MAP_FAILED) munmap(m, (size_t)S->map_len);
+                if (ftruncate(w0->fd, 0) != 0) warn("%s", fx->output_file_name);
+            }
+        }
+    }
+
+    int per = (int)fxh_env_long("FXH_STRANDS", 8, 1, FXH_MAX_STRANDS);
+    int ns = per * ndev;
+    if (ns > FXH_MAX_STRANDS) ns = FXH_MAX_STRANDS;
+    if ((uint64_t)ns > nchunks) ns = (int)nchunks;
+    S->nstrands = ns;
+    S->nread_slices = (int)fxh_env_long("FXH_STRAND_READERS", 2, 1, 16);
+    S->st = (fxh_strand *)calloc((size_t)ns, sizeof(fxh_strand));
+    if (!S->st) err(1, "out of memory");
+    fxh_pool_start(&S->rpool, (int)fxh_env_long("FXH_IO_THREADS", ns * (S->nread_slices - 1) > 0 ? ns * (S->nread_slices - 1) : 1, 1, 64), (unsigned)(ns * 16));
+    /* copies into the mapping: one thread per output buffer; positional writes: ONE stream (more of them only queue at the inode lock, 27 against 40 Mreads/s) */
+    S->release = (int)fxh_env_long("FXH_STRAND_RELEASE", 0, 0, 1);
+    S->nout = (int)fxh_env_long("FXH_STRAND_OUT_SLOTS", 4, 2, FXH_LANE_OUT_SLOTS);      /* output buffers per strand: what the strands can put aside while the allocator has the file */
+    fxh_pool_start(&S->wpool, S->mapped ? (int)fxh_env_long("FXH_COPY_THREADS", 16, 1, 64) : 1, (unsigned)(S->nout * ns));
+    const int revcomp = (p->stages & (FXG_STAGE_REVCOMP | FXG_STAGE_MASK)) != 0;
+    for (int i = 0; i < ns; ++i) {
+        fxh_strand *s = &S->st[i];
+        s->id = i; s->S = S;
+        pthread_mutex_init(&s->mu, NULL); pthread_cond_init(&s->cv, NULL);
+        for (int k = 0; k < 2; ++k) if (posix_memalign((void **)&s->in[k], 4096, S->in_cap) != 0) err(1, "out of memory");
+        fxh_lane *ln = &s->ln;
+        ln->id = i; ln->device = dev[i % ndev]; ln->p = p; ln->revcomp = revcomp;
+        ln->fwd_start = (p->stages & FXG_STAGE_FTRIM) && p->ft_first > 1 ? (uint32_t)p->ft_first - 1u : 0u;
+        ln->qoffset = fx->fastq_ascii_quality_offset;
+        ln->reverse = (p->stages & FXG_STAGE_REVCOMP) != 0; ln->lpr = lpr; ln->has_q = fx->read_fastq; ln->out_fasta = !fx->write_fastq;
+        ln->clip_guard = S->clip_auto;
+        ln->on_size = fxh_sf_publish; ln->owner = s;
+        if (pthread_create(&s->th_rd, NULL, fxh_strand_reader, s) != 0) err(1, "pthread_create");      /* reading starts while the device does */
+    }
+    for (int i = 0; i < ns; ++i) if (pthread_create(&S->st[i].th_gpu, NULL, fxh_strand_gpu, &S->st[i]) != 0) err(1, "pthread_create");
+    for (int i = 0; i < ns; ++i) { pthread_join(S->st[i].th_gpu, NULL); }
+    int bad = FXH_ABORTED();
+    if (bad) fxh_sf_abort(S);                    /* (readers that were between two checks) */
+    for (int i = 0; i < ns; ++i) pthread_join(S->st[i].th_rd, NULL);
+    fxh_pool_stop(&S->rpool);
+    fxh_pool_stop(&S->wpool);
+    pthread_mutex_lock(&S->mu);
+    if (!bad && S->scanned != nchunks) bad = 1;
+    S->alloc_stop = 1;
+    pthread_cond_broadcast(&S->cv);
+    pthread_mutex_unlock(&S->mu);
+    if (S->mapped) pthread_join(S->th_alloc, NULL);
+    if (bad) {
+        /* Abandoned.  Every thread has been joined, the contexts go, the file is emptied through its own descriptor -- which the parent
+         * shares -- and the process leaves with _exit: no exit handler of this half-finished attempt gets to run. */
+        for (int i = 0; i < ns; ++i) if (S->st[i].ln.st.ctx) fxg_ctx_destroy(S->st[i].ln.st.ctx);
+        if (S->mapped) munmap(S->map, (size_t)S->map_len);
+        w0->len = 0;
+        if (ftruncate(w0->fd, w0->off) != 0 || lseek(w0->fd, w0->off, SEEK_SET) < 0) warn("%s", fx->output_file_name);
+        if (timing) fprintf(stderr, "fxh timing one file: abandoned, contexts destroyed, output emptied\n");
+        fflush(NULL);
+        _exit(FXH_EXIT_ABANDON);
+    }
+    const uint64_t total = S->scan_off;
+    if (S->mapped) {
+        munmap(S->map, (size_t)S->map_len);
+        if (ftruncate(w0->fd, (off_t)total) != 0) err(1, "writing output failed");
+    }
+    w0->off += (off_t)total;                     /* the writer closes with the descriptor where a write() stream would have left it */
+    memset(tot, 0, sizeof *tot);
+    for (int i = 0; i < ns; ++i) {
+        const fxh_totals *t = &S->st[i].tot;
+        tot->input_sequences += t->input_sequences; tot->input_reads += t->input_reads; tot->output_sequences += t->output_sequences; tot->output_reads += t->output_reads;
+        tot->clip_input += t->clip_input; tot->clip_too_short += t->clip_too_short; tot->clip_adapter_only += t->clip_adapter_only;
+        tot->clip_no_adapter += t->clip_no_adapter; tot->clip_adapter_found += t->clip_adapter_found; tot->clip_n += t->clip_n;
+        tot->masked_reads += t->masked_reads; tot->masked_nucleotides += t->masked_nucleotides; tot->qtrim_dropped += t->qtrim_dropped;
+    }
+    fx->num_input_sequences = tot->input_sequences; fx->num_input_reads = tot->input_reads;
+    fx->num_output_sequences = tot->output_sequences; fx->num_output_reads = tot->output_reads;
+    if (timing) {
+        double rd_s = 0, gpu_s = 0, win = 0, wout = 0, woff = 0, init = 0, rel = 0;
+        for (int i = 0; i < ns; ++i) {
+            const fxh_strand *s = &S->st[i];
+            rd_s += s->t_read; gpu_s += s->t_gpu; win += s->t_wait_in; wout += s->t_wait_out; woff += s->t_wait_off; init += s->ln.t_init; rel += s->t_release;
+            if (s->ln.t_call[7] > 0)
+                fprintf(stderr, "fxh timing strand %d: %.0f chunks, ms per chunk: h2d %.3f index %.3f pack %.3f pipeline %.3f counters %.3f format %.3f d2h+sync %.3f\n", i, s->ln.t_call[7],
+                        1e3 * s->ln.t_call[0] / s->ln.t_call[7], 1e3 * s->ln.t_call[1] / s->ln.t_call[7], 1e3 * s->ln.t_call[2] / s->ln.t_call[7], 1e3 * s->ln.t_call[3] / s->ln.t_call[7],
+                        1e3 * s->ln.t_call[4] / s->ln.t_call[7], 1e3 * s->ln.t_call[5] / s->ln.t_call[7], 1e3 * s->ln.t_call[6] / s->ln.t_call[7]);
+        }
+        fprintf(stderr, "fxh timing one file (%d strands on %d GPU(s), %llu chunks, sink %s): run %.3f s (set-up %.3f, placement %.3f); summed over strands: context %.3f read %.3f wait-input %.3f device %.3f wait-outbuf %.3f wait-offset %.3f release %.3f; "
+                        "sink: %llu fallocate calls %.3f s (to %.2f GB for %.2f GB of output), copies %.3f s + %.3f s at the gate (summed over %d threads)\n",
+                ns, ndev, (unsigned long long)nchunks, S->mapped ? "gated mapping" : "pwrite", fxh_now() - t_run0, t_dev - t_run0, t_bound - t_dev, init, rd_s, win, gpu_s, wout, woff, rel,
+                (unsigned long long)S->alloc_calls, S->t_alloc, 1e-9 * (double)S->alloc_end, 1e-9 * (double)total, S->t_copy, S->t_copy_wait, S->wpool.nth);
+    }
+    return 0;
+}

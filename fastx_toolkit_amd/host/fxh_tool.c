@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "fastx_args.h"
@@ -95,7 +96,7 @@ int fxh_tool_main(const fxh_tool *tool, int argc, char *argv[])
     fastx_parse_cmdline(argc, argv, tool->optstring, tool->nopts || tool->optstring[0] ? fxh_tool_option : NULL);
     if (tool->check) tool->check(g_v, g_s);
     fastx_init_reader(&fastx, get_input_filename(), tool->input_types, ALLOW_N, REQUIRE_UPPERCASE, get_fastq_ascii_quality_offset());
-    fastx_init_writer(&fastx, get_output_filename(), tool->output_type, compress_output_flag());
+    fxh_init_writer(&fastx, get_output_filename(), tool->output_type, compress_output_flag());
     fxh_default_params(&p, get_fastq_ascii_quality_offset());
     tool->configure(g_v, g_s, &p);
     fxh_run_tool(&fastx, &p, &tot);
@@ -114,6 +115,7 @@ int fxh_tool_main(const fxh_tool *tool, int argc, char *argv[])
     /* Everything is written and flushed.  Returning would run the HIP runtime's exit handlers (tens of milliseconds of
      * teardown for a process that is gone anyway); FXH_SLOW_EXIT=1 takes that path, for leak checkers. */
     fflush(NULL);
+    if (getenv("FXH_TIMING")) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "fxh timing exit: _exit at %.3f (CLOCK_MONOTONIC)\n", (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec); }
     if (!getenv("FXH_SLOW_EXIT")) _exit(0);
     return 0;
 }

@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "../fastx.h"
@@ -82,7 +83,7 @@ int main(int argc, char *argv[])
     fastx_parse_cmdline(argc, argv, "a:l:ncCM:t:m:q:p:", parse_program_args);
     if (trim_threshold == 0) errx(1, "Missing minimum quality threshold value (-t)");
     fastx_init_reader(&fastx, get_input_filename(), FASTQ_ONLY, ALLOW_N, REQUIRE_UPPERCASE, get_fastq_ascii_quality_offset());
-    fastx_init_writer(&fastx, get_output_filename(), OUTPUT_SAME_AS_INPUT, compress_output_flag());
+    fxh_init_writer(&fastx, get_output_filename(), OUTPUT_SAME_AS_INPUT, compress_output_flag());
     fxh_default_params(&p, get_fastq_ascii_quality_offset());
     p.stages = FXG_STAGE_CLIP | FXG_STAGE_QTRIM | FXG_STAGE_QFILTER;
     memcpy(p.adapter, adapter, sizeof p.adapter);          /* both are char[100], NUL-terminated */
@@ -123,6 +124,7 @@ int main(int argc, char *argv[])
     }
     fastx_finish(&fastx);
     fflush(NULL);
+    if (getenv("FXH_TIMING")) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "fxh timing exit: _exit at %.3f (CLOCK_MONOTONIC)\n", (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec); }
     if (!getenv("FXH_SLOW_EXIT")) _exit(0);      /* as fxh_tool_main: skip the HIP runtime's exit handlers */
     return 0;
 }

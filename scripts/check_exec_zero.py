@@ -180,13 +180,25 @@ def check(so, joins=False):
     for name, (ins, full) in ks.items():
         for addr, dead in check_kernel(name, ins, full, joins):
             report.append((name, addr, dead))
+    check.last_instructions = sum(len(ins) for ins, _ in ks.values())
     return report, len(ks)
 
 
+# exit codes: 0 = every kernel read and none has the pattern; 1 = the pattern was found (a real finding); 2 = the check could not do its
+# job -- the tools are missing, the code object could not be taken out, or the listing did not parse into kernels with instructions (a
+# changed llvm-objdump format must not pass as "0 kernels, 0 places")
 def main(paths):
     bad = 0
     for so in paths:
-        report, nk = check(so)
+        try:
+            report, nk = check(so)
+            ni = check.last_instructions
+        except Exception as e:                                     # noqa: BLE001 -- any tool failure is "could not check", never "clean"
+            print("%s: the ISA check could not run: %s: %s" % (os.path.basename(so), type(e).__name__, e))
+            return 2
+        if nk == 0 or ni < 8 * nk:
+            print("%s: the ISA check read %d kernels with %d instructions -- the disassembly was not understood" % (os.path.basename(so), nk, ni))
+            return 2
         for name, addr, dead in report:
             bad += 1
             mem = [d for d in dead if d.startswith(MEM_PREFIX)]
@@ -195,6 +207,9 @@ def main(paths):
                 os.path.basename(so), name, where, len(dead), len(mem), "\n      ".join(dead[:4])))
         print("%s: %d kernels, %d places with vector/memory code ahead of the EXEC restore" % (os.path.basename(so), nk, len(report)))
     return 1 if bad else 0
+
+
+check.last_instructions = 0
 
 
 if __name__ == "__main__":

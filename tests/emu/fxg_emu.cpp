@@ -257,6 +257,8 @@ extern "C" int fxg_emu_run_pipeline(const fxg_batch *in, const fxg_params *p, co
 }
 
 extern "C" unsigned fxg_emu_tile_reads(unsigned stride, int clip) { return fxg_pick_tile(stride, clip != 0); }
+// the GL window's clamp (fxg_kernels.h: fxg_gl_last_dword), so that batches of 8 GiB and more can be checked without allocating one
+extern "C" int fxg_emu_gl_last_dword(uint64_t total, uint64_t off) { return fxg_gl_last_dword(total, off); }
 
 // fastx_quality_stats: the per-thread bodies of fxg_kernel_quality_stats / _fold, one "workgroup" after the other
 extern "C" int fxg_emu_run_quality_stats(const fxg_batch *in, uint64_t *hist, uint32_t hist_cols)

@@ -104,9 +104,36 @@ def test_rank_without_rank0_times_out(libs, tmp_path):
 
 
 def test_truncated_id_file_is_not_an_id(libs, tmp_path):
-    """A reader sees all 128 bytes or nothing: a short file (a writer that is not the transport's rename) is never taken for an id."""
+    """A reader sees a whole record or nothing: a short file (a writer that is not the transport's rename) is never taken for an id."""
     (tmp_path / "job.id").write_bytes(b"x" * 17)
     outs, _, log = _spawn(libs, tmp_path, 2, ranks=[1], timeout=1)
+    assert outs[0]["create_rc"] != 0 and "no RCCL id" in outs[0]["error"] and "init" not in log
+
+
+def _record(world, job_token, fill=b"S"):
+    h = 0
+    if job_token:
+        h = 0xcbf29ce484222325
+        for ch in job_token.encode():
+            h = ((h ^ ch) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    import struct
+    return b"FXGRDV1\0" + struct.pack("<IIQ", world, 0, h) + fill * 128
+
+
+@pytest.mark.parametrize("stale,env", [((3, None), {}), ((2, "job-of-yesterday"), {"FXG_COMM_JOB": "job-of-today"}), ((2, None), {"FXG_COMM_JOB": "job-of-today"})])
+def test_record_of_a_dead_job_is_not_taken(libs, tmp_path, stale, env):
+    """A job that died between publishing its id and removing it leaves a record under the name.  The next job's early ranks must not join on it:
+    a record for another world size, or with another job token (FXG_COMM_JOB), is not an id for this job -- the ranks wait for their own rank 0,
+    which removes the leftover before it makes its id (here it is 0.6 s late on purpose)."""
+    (tmp_path / "job.id").write_bytes(_record(*stale))
+    outs, idfile, log = _spawn(libs, tmp_path, 2, delays={0: 0.6}, env_extra=env)
+    assert log.count("getid") == 1 and sorted(l for l in log.splitlines() if l.startswith("init")) == ["init rank 0 world 2", "init rank 1 world 2"], log
+    assert all(o["create_rc"] == 0 and o["rounds"][0]["rc"] == 0 for o in outs), outs
+    assert outs[0]["rounds"][0]["gathered"] == outs[1]["rounds"][0]["gathered"] == _block(0, 0) + _block(1, 0)
+    assert not os.path.exists(idfile)
+    # and with nobody to replace it, the leftover alone never becomes an id
+    (tmp_path / "job2.id").write_bytes(_record(*stale))
+    outs, _, log = _spawn(libs, tmp_path, 2, ranks=[1], timeout=1, env_extra=env, tag="job2")
     assert outs[0]["create_rc"] != 0 and "no RCCL id" in outs[0]["error"] and "init" not in log
 
 

@@ -123,6 +123,23 @@ def test_emulated_clip_over_the_batch_and_over_the_staged_tile(monkeypatch, mode
     assert n > 60
 
 
+def test_clip_global_window_clamp_on_huge_batches():
+    """The over-the-batch clip form clamps its two-dword window to the array's last dword.  The number of dwords behind a row is a 64-bit count:
+    a batch of 8 GiB and more (30 M reads at a 300-byte stride) used to wrap it into a negative int for its early rows, and every window load
+    then went to a negative index.  The helper the kernels call, on totals no test could allocate."""
+    import ctypes as C
+    f = emu.lib().fxg_emu_gl_last_dword
+    f.argtypes = [C.c_uint64, C.c_uint64]
+    f.restype = C.c_int
+    assert f(1200, 0) == 299 and f(1200, 900) == 74 and f(1200, 1196) == 0 and f(1200, 1200) == 0 and f(4, 0) == 0
+    for total in (8 << 30, (8 << 30) + 4, 30_000_000 * 300, 1 << 40, (1 << 64) - 4):
+        assert f(total, 0) == 0x7FFFFFFF, total                 # far more than an int of dwords left: "no clamp within reach", never negative
+        assert f(total, total - 400) == 99
+        assert f(total, total - 4) == 0
+        assert f(total, total - (4 << 31)) == 0x7FFFFFFF - 0    # exactly 2^31 dwords left -> last index 2^31 - 1
+        assert f(total, total - (4 << 31) - 4) == 0x7FFFFFFF
+
+
 def test_clip_global_selection(monkeypatch):
     """fxg_make_plan (host logic shared with the engine): when the clip DP runs over the batch instead of a staged tile -- where the staged form would
     shrink its tile or keep fewer than three workgroups on a CU, rows on dword boundaries, no clip history."""

@@ -544,3 +544,104 @@ def test_corner_case_inputs_vs_reference(tools):
     with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as ex:
         checked = sum(ex.map(one, jobs))
     assert checked > 1500
+
+
+def _one_file_env(sink, kb="512", strands="3", **more):
+    env = {"FXH_ONE_FILE_MIN_MB": "0", "FXH_STRAND_KB": kb, "FXH_STRANDS": strands, "FXH_ONE_FILE_SINK": sink, "FXH_ONE_FILE_WINDOW_MB": "1", "FXH_TIMING": "1"}
+    env.update(more)
+    return env
+
+
+@pytest.mark.parametrize("sink", ["map", "pwrite"])
+def test_one_output_file_written_by_many_strands(tools, tmp_path, sink):
+    """`tool -i in.fq -o out.fq` with NO %r and no FXH_PARTS (fxh_strands.c): chunks of the input dealt to strands by a ticket counter, sizes published
+    in chunk order, every chunk's text copied into the ONE output file at the sum of the sizes before it -- through the gated mapping (allocator
+    and copies taking turns) and through positional writes.  Same bytes, same -v report as the one-stream run for every tool shape (forward
+    slices, reverse-complemented / masked output from the packed arrays, FASTA out, FASTA in with collapsed ids, the clipper on reads of one
+    length); two fake devices share the strands; input on stdin as a regular file works, a pipe runs as one stream."""
+    text = fo.synth_fastq(47, 0, 60000, 100, False)                     # ~13 MB: 26 chunks of 512 KB
+    inp = tmp_path / "in.fq"
+    inp.write_bytes(text)
+    clip_text = fo.synth_fastq(3, 0, 30000, 100, True)
+    fa = b"".join(b">%d-%d\n%s\n" % (i, 1 + i % 7, b"ACGTTGCANN"[: 4 + i % 7] * 3) for i in range(120000))
+    shapes = [(["fastq_quality_trim_filter", "-t", "20", "-l", "30", "-q", "20", "-p", "80", "-v"], text),
+              (["fastx_reverse_complement", "-v"], text), (["fastq_masker", "-q", "20", "-v"], text), (["fastq_to_fasta", "-v"], text),
+              (["fastx_trimmer", "-f", "5", "-l", "80"], text), (["fastx_clipper", "-a", "AGATCGGAAGAGC", "-l", "15", "-v"], clip_text),
+              (["fastx_clip_trim_filter", "-a", "AGATCGGAAGAGC", "-l", "15", "-t", "20", "-m", "30", "-q", "20", "-p", "80", "-v"], clip_text),
+              (["fastx_reverse_complement", "-v"], fa), (["fastx_artifacts_filter", "-v"], fa)]
+    for i, (argv, data) in enumerate(shapes):
+        inp.write_bytes(data)
+        single, multi = tmp_path / ("single%d" % i), tmp_path / ("multi%d" % i)
+        want = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", str(single)], b"", buf_mb="1", extra_env={"FXH_ONE_FILE": "0"})
+        log = tmp_path / ("ctx%d.log" % i)
+        got = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", str(multi)], b"", buf_mb="1",
+                   extra_env=_one_file_env(sink, FXG_EMU_DEVICES="2", FXG_DEVICES="0,1", FXG_EMU_LOG=str(log)))
+        assert want[0] == 0 and got[0] == 0, (argv, got[2][-400:])
+        assert b"fxh timing one file (6 strands on 2 GPU(s)" in got[2] and (b"sink gated mapping" if sink == "map" else b"sink pwrite") in got[2], got[2][-400:]
+        assert b"fxh timing part" not in got[2]                         # the one-stream loop never ran
+        assert got[1] == want[1], argv                                  # the -v report
+        assert multi.read_bytes() == single.read_bytes(), argv
+        assert {int(l.split()[-1]) for l in open(log).read().splitlines()} == {0, 1}
+    inp.write_bytes(text)
+    argv = shapes[0][0]
+    single = (tmp_path / "single0").read_bytes()
+    # the input as stdin, a regular file: the same run; as a pipe: one stream, the same bytes
+    with open(inp, "rb") as f:
+        env = dict(os.environ, LD_LIBRARY_PATH=STUB_DIR, FXH_THREADS="4", **_one_file_env(sink))
+        p = subprocess.run([os.path.join(tools, argv[0])] + argv[1:] + ["-o", str(tmp_path / "stdin.fq")], stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+    assert p.returncode == 0 and b"fxh timing one file (3 strands" in p.stderr and (tmp_path / "stdin.fq").read_bytes() == single
+    g = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-o", str(tmp_path / "pipe1.fq")], text, extra_env=_one_file_env(sink))
+    assert g[0] == 0 and b"fxh timing one file" not in g[2] and (tmp_path / "pipe1.fq").read_bytes() == single
+    # one strand, many strands, chunks of 64 KB (800 of them) and of 5 MB (three); more strands than chunks
+    for kb, strands in (("64", "1"), ("64", "8"), ("5120", "4"), ("7000", "16")):
+        out = tmp_path / ("o_%s_%s.fq" % (kb, strands))
+        g = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", str(out)], b"", extra_env=_one_file_env(sink, kb=kb, strands=strands))
+        assert g[0] == 0 and b"fxh timing one file" in g[2] and out.read_bytes() == single, (kb, strands, g[2][-300:])
+    # below the size from which it pays (the default: 1 GB) the run is one stream; -z, /dev/null and FXH_ONE_FILE=0 as well
+    for extra, args in (({"FXH_TIMING": "1"}, []), (dict(_one_file_env(sink), FXH_ONE_FILE="0"), []), (_one_file_env(sink), ["-z"])):
+        out = tmp_path / "plain.out"
+        g = _run([os.path.join(tools, argv[0])] + argv[1:] + args + ["-i", str(inp), "-o", str(out)], b"", extra_env=extra)
+        assert g[0] == 0 and b"fxh timing one file" not in g[2] and b"fxh timing part 0/1" in g[2]
+    g = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", "/dev/null"], b"", extra_env=_one_file_env(sink))
+    assert g[0] == 0 and b"fxh timing one file" not in g[2]
+
+
+@pytest.mark.parametrize("sink", ["map", "pwrite"])
+def test_one_output_file_attempt_abandoned_on_irregular_input(tools, tmp_path, sink):
+    """Anything the device path does not take -- a damaged record, a ragged end, a record of another format, a clipper input whose reads stop being of
+    one length, quality lines starting with '@' where the cuts are looked for -- abandons the many-strand attempt: the file is emptied and the
+    input runs as one stream, so exit code, message and the bytes written before the bad record are the reference's."""
+    text = fo.synth_fastq(47, 0, 60000, 100, False)
+    inp = tmp_path / "in.fq"
+    argv = ["fastq_quality_trim_filter", "-t", "20", "-l", "30", "-q", "20", "-p", "80", "-v"]
+    k0 = text.index(b"\n@", int(len(text) * 0.6)) + 1
+    for n, bad in enumerate((text[:k0] + b"#" + text[k0 + 1:], text[:-200], text[:k0] + b">x\nACGT\n" + text[k0:], text[:k0] + b"@x\nACGT\n+\nII\n" + text[k0:])):
+        inp.write_bytes(bad)
+        ref_out, out = tmp_path / ("bad_single%d.fq" % n), tmp_path / ("bad%d.fq" % n)
+        w = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", str(ref_out)], b"", buf_mb="1", extra_env={"FXH_ONE_FILE": "0"})
+        g = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", str(out)], b"", buf_mb="1", extra_env=_one_file_env(sink))
+        if n < 3:
+            assert w[0] == 1 and b"fxh timing one file: abandoned, contexts destroyed, output emptied" in g[2], g[2][-300:]
+        assert (g[0], g[1]) == (w[0], w[1]) and _msg(g[2].split(b"\n", g[2].count(b"\n") - 1)[-1]) == _msg(w[2].split(b"\n", w[2].count(b"\n") - 1)[-1]), (n, g[2][-300:], w[2][-300:])
+        assert out.read_bytes() == ref_out.read_bytes(), n
+        if REF and n < 3:
+            r1 = _run([REF, "fastq_quality_trimmer", "-t", "20", "-l", "30"], bad)
+            assert r1[0] == 1 and out.read_bytes() == _run([REF, "fastq_quality_filter", "-q", "20", "-p", "80"], r1[1])[1]
+    # the clipper: reads of one length up to 70 % of the file, shorter ones from there on -> one aligner with history, as the reference
+    lines = fo.synth_fastq(3, 0, 30000, 100, True).split(b"\n")[:-1]
+    for i in range(len(lines) // 4 * 7 // 10 * 4, len(lines), 8):
+        lines[i + 1] = lines[i + 1][:61]; lines[i + 3] = lines[i + 3][:61]
+    data = b"\n".join(lines) + b"\n"
+    inp.write_bytes(data)
+    cargv = ["fastx_clipper", "-a", "AGATCGGAAGAGC", "-l", "15", "-v"]
+    g = _run([os.path.join(tools, cargv[0])] + cargv[1:] + ["-i", str(inp), "-o", str(tmp_path / "clip.fq")], b"", buf_mb="1", extra_env=_one_file_env(sink))
+    assert g[0] == 0 and b"fxh timing one file: abandoned" in g[2] and b"one aligner with history from there on" in g[2], g[2][-400:]
+    if REF:
+        ref = _run([REF] + cargv, data)
+        assert g[1] == ref[2] and (tmp_path / "clip.fq").read_bytes() == ref[1]
+    # quality lines that start with '@': a cut may be found on a wrong line; the chunk before it is then not whole records
+    tricky = b"".join(b"@r%d\nACGTACGTACGTACGTACGT\n+\n@IIIIIIIIIIIIIIIIIII\n" % i for i in range(120000))
+    inp.write_bytes(tricky)
+    w = _run([os.path.join(tools, "fastq_quality_trimmer"), "-t", "20", "-l", "5", "-i", str(inp), "-o", str(tmp_path / "t_single.fq")], b"", buf_mb="1", extra_env={"FXH_ONE_FILE": "0"})
+    g = _run([os.path.join(tools, "fastq_quality_trimmer"), "-t", "20", "-l", "5", "-i", str(inp), "-o", str(tmp_path / "t.fq")], b"", buf_mb="1", extra_env=_one_file_env(sink, kb="100"))
+    assert w[0] == 0 and g[0] == 0 and (tmp_path / "t.fq").read_bytes() == (tmp_path / "t_single.fq").read_bytes()

@@ -41,6 +41,21 @@ def test_shipped_library_is_clean_and_a_bad_one_is_refused(tmp_path):
         b.check_exec_zero(os.path.join(ISA, "exec_zero_bad.dis"))
 
 
+def test_check_fails_closed(tmp_path):
+    """A check that could not read the ISA is not a clean library: no code object, a listing the parser finds no kernels in, a missing file --
+    exit code 2 from the tool and NOT CHECKED (not REJECTED, not accepted) from the build."""
+    from fastx_toolkit_amd import build as b
+    empty = tmp_path / "nothing.dis"
+    empty.write_text("this is not a disassembly\n")
+    odd = tmp_path / "odd_format.dis"                         # kernels whose instruction lines the parser no longer recognises
+    odd.write_text("0000000000001000 <kernel_a>:\n  s_endpgm ; 1000: BF810000\n")
+    for path in (str(empty), str(odd), "/bin/ls", str(tmp_path / "missing.so")):
+        rc, out = _run(path)
+        assert rc == 2, (path, out)
+        with pytest.raises(RuntimeError, match="NOT CHECKED"):
+            b.check_exec_zero(path)
+
+
 def test_matrix_libraries_carry_their_verdict():
     """Where the launch-bounds matrix has been built (scripts/build_clip_matrix.py), every library has a recorded verdict, the verdict is
     what the checker says now, and the two-wave ... four-wave builds of the shipped sources are listed for the GPU tier to use."""
