@@ -62,6 +62,7 @@ CONFIGS = {
 # SQ_INSTS_VALU x 64 / cells of profiles/r04/aa_clip_sq_counters_cfg{3,5}.txt (scripts/pmc_sq.sh; round 3: 10.6 / 9.45).  The first pass alone is
 # 6.2 per cell (llvm-objdump of the row loop).
 CLIP_VALU_PER_CELL = {"cfg3": 10.45, "cfg5shard": 9.35}
+CLIP_MIN_VALU_PER_CELL = 5.0
 
 # What the timed launches of the default workloads must produce: (kept reads, kept bases, Result.checksum()).  The same tuples are
 # asserted by tests/test_gpu_parity.py::test_full_size_* on runs whose res[] and packed streams are compared with the oracle in a
@@ -166,6 +167,8 @@ def cpu_baseline(config="cfg2", reads_per_pipe=250_000, one_pipe_reads=1_000_000
             if ok1 and okp:
                 n = pipes * reads_per_pipe
                 return dict(value=round(n / dtp / 1e6, 4), unit="Mreads/s", cores=per_pipe * pipes, kind="reference",
+                            kind_detail="the reference's libfastx object code (reader, writer, argument parsing, aligner: compiled in place from /root/reference/src/libfastx) under the tools' "
+                                        "loop bodies as restated in oracle/ref_driver.cpp -- the tools' own main()s need an autoconf-generated config.h, for which no stand-in is written",
                             one_pipe_value=round(n_one * reads_per_pipe / dt1 / 1e6, 4), one_pipe_cores=per_pipe, one_pipe_reads=n_one * reads_per_pipe,
                             host_logical_cpus=logical, host_physical_cores=phys,
                             sample="%s: `%s`; first %d reads of the same seed-%d %d bp set as FASTQ text on tmpfs, split into %d chunks; each chunk piped "
@@ -272,7 +275,11 @@ def e2e_leg(reads=16_000_000, big_reads=64_000_000, parts=4, lanes=2):
             fa = [fused, "-t", "20", "-l", "30", "-q", "20", "-p", "80", "-i", inp]
             penv = dict(os.environ, FXH_PARTS=str(parts), FXH_LANES=str(lanes))
             pnames = [os.path.join(td, "part.%d.fq" % r) for r in range(parts)]
+            one_env = dict(os.environ, FXH_ONE_FILE="0")       # the one-stream loop (one reader, lanes, ONE writer stream): what `-o FILE` was before round 5
             timed(out, "fused", lambda: subprocess.call(fa + ["-o", os.path.join(td, "fused.fq")]) == 0, [os.path.join(td, "fused.fq")], reads)
+            timed(out, "fused_one_stream", lambda: subprocess.call(fa + ["-o", os.path.join(td, "fused1.fq")], env=one_env) == 0, [os.path.join(td, "fused1.fq")], reads)
+            if "fused" in out and "fused_one_stream" in out:
+                out["fused"]["identical_to_one_stream"] = out["fused"]["output_md5"] == out["fused_one_stream"]["output_md5"]
             timed(out, "fused_to_devnull", lambda: subprocess.call(fa + ["-o", "/dev/null"]) == 0, None, reads)
             timed(out, "sharded", lambda: subprocess.call(fa + ["-o", os.path.join(td, "part.%r.fq")], env=penv) == 0, pnames, reads)
             if "sharded" in out:
@@ -283,7 +290,17 @@ def e2e_leg(reads=16_000_000, big_reads=64_000_000, parts=4, lanes=2):
                 _gen_fastq(inp, big_reads)
                 big = {"reads": big_reads, "input_bytes": os.path.getsize(inp), "parts": parts, "lanes_per_part": lanes}
                 single = os.path.join(td, "single.fq")
-                timed(big, "one_stream", lambda: subprocess.call(fa + ["-o", single]) == 0, [single], big_reads, want_md5=False)
+                timed(big, "one_stream", lambda: subprocess.call(fa + ["-o", single], env=one_env) == 0, [single], big_reads, want_md5=False)
+                onef = os.path.join(td, "one_file.fq")
+                timed(big, "one_file", lambda: subprocess.call(fa + ["-o", onef]) == 0, [onef], big_reads, want_md5=False)
+                if "one_file" in big and "one_stream" in big:
+                    big["one_file"]["identical_to_one_stream"] = _same_bytes([onef], single)
+                    # what crossed the PCIe link, per read and per second, in the default command: the text goes up once, the formatted text comes down once
+                    ob, dtw = big["one_file"]["output_bytes"], big["one_file"]["wall_s"]
+                    big["one_file"]["link"] = dict(bytes_up_per_read=round(big["input_bytes"] / big_reads, 1), bytes_down_per_read=round(ob / big_reads, 1),
+                                                   up_gbs_over_wall=round(big["input_bytes"] / dtw / 1e9, 1), down_gbs_over_wall=round(ob / dtw / 1e9, 1))
+                if os.path.exists(onef):
+                    os.unlink(onef)
                 timed(big, "sharded", lambda: subprocess.call(fa + ["-o", os.path.join(td, "part.%r.fq")], env=penv) == 0, pnames, big_reads, want_md5=False)
                 if "sharded" in big and "one_stream" in big:
                     big["concatenation_identical_to_one_stream"] = _same_bytes(pnames, single)
@@ -292,6 +309,9 @@ def e2e_leg(reads=16_000_000, big_reads=64_000_000, parts=4, lanes=2):
                 if share:
                     timed(big, "sharded_host_share_16c", lambda: subprocess.call(fa + ["-o", os.path.join(td, "part.%r.fq")], env=penv,
                                                                                   preexec_fn=lambda: os.sched_setaffinity(0, share)) == 0, pnames, big_reads, want_md5=False)
+                    timed(big, "one_file_host_share_16c", lambda: subprocess.call(fa + ["-o", onef], preexec_fn=lambda: os.sched_setaffinity(0, share)) == 0, [onef], big_reads, want_md5=False)
+                    if os.path.exists(onef):
+                        os.unlink(onef)
                     if "sharded_host_share_16c" in big:
                         big["sharded_host_share_16c"].update(cpus=len(share), cores=16, note="the same sharded command restricted to 16 physical cores (with their SMT siblings) of the "
                                                              "GPU's NUMA node: what each GPU's tool chain has on an 8-GPU box with 2 x 64 cores")
@@ -299,11 +319,16 @@ def e2e_leg(reads=16_000_000, big_reads=64_000_000, parts=4, lanes=2):
         if "pipe" in out and "fused" in out:
             out["fused_equals_pipe"] = out["pipe"]["output_md5"] == out["fused"]["output_md5"]
         if "fused" in out:
-            # what a user gets WITHOUT knowing any knob: the plain command line, one process, no environment variables.  Since round 4 a
-            # regular-file input of >= 1 GB with `-o NAME` is sharded by the tool itself (fxh_auto_parts), so this is the tuned path's number
-            # minus the choice of the part names; `fused` above is the same command on the 16 M-read sample.
+            # what a user gets WITHOUT knowing any knob: the reference's own command line, one process, no environment variables, ONE output file.
+            # Since round 5 a regular-file input of >= 512 MB is run by many strands into that one file (host/fxh_strands.c); `one_stream` is the
+            # loop it replaces (FXH_ONE_FILE=0), `sharded` the k-part form that no reference caller would type (-o out.%r.fq).
+            bigd = out.get("sharded_big", {})
             out["default_invocation"] = dict(command="fastq_quality_trim_filter -t 20 -l 30 -q 20 -p 80 -i in.fq -o out.fq", env="none",
-                                             sample_16m=out["fused"], sample_64m=out.get("sharded_big", {}).get("one_stream"))
+                                             sample_16m=out["fused"], sample_64m=bigd.get("one_file"),
+                                             sample_64m_one_stream_before=bigd.get("one_stream"), sample_64m_four_part_files=bigd.get("sharded"),
+                                             sink_note="one tmpfs file takes fresh pages from one thread at a time: 9 GB/s through one pwrite() stream, 4-5 GB/s through many, "
+                                                       "10.5 GB/s with fallocate() and parallel copies taking turns (this tool's sink; 15 GB/s after a head start), 30-90 GB/s into "
+                                                       "k files -- profiles/r05/a_one_file_write.txt, d_one_file_gate.txt")
         return out
 
 
@@ -484,8 +509,10 @@ def main():
     ap.add_argument("--e2e", action="store_true", help="also time the config's command line end to end, one tool chain per GPU (weak scaling; any --gpus)")
     ap.add_argument("--e2e-reads", type=int, default=32_000_000, help="reads per rank of the --e2e leg")
     ap.add_argument("--decision-only", action="store_true", help="no compaction: 154 B/read variant (not the headline)")
+    ap.add_argument("--headline-only", action="store_true", help="the default config alone, without the other BASELINE configs behind it")
     args = ap.parse_args()
-    cfg = CONFIGS[args.config]
+    if args.steps < 1:
+        raise SystemExit("--steps must be at least 1")
 
     import torch
     import torch.distributed as dist
@@ -502,166 +529,202 @@ def main():
     # RCCL all-gather, which orders itself after that stream -- so the gather reads the counters of the pass just enqueued.
     torch.cuda.set_stream(torch.cuda.Stream(device=local))
     eng = Engine(local)
-    R, L = (args.reads or cfg["reads"]), cfg["L"]
-    lo = rank * R                                  # weak scaling: rank g owns reads [g*R, (g+1)*R) of the global set
-    bases, qual = eng.synth(cfg["seed"], lo, R, L, cfg["adapter"])
-    is_stats = cfg["params"] is None
-    compact = not args.decision_only and not is_stats
-    if is_stats:
-        hist = torch.zeros((L, 5, 128), dtype=torch.int64, device=eng.device)
-        counters_dev = torch.zeros(24, dtype=torch.int64, device=eng.device)
-    else:
-        params = make_params(**cfg["params"])
-        # per-kept-read metadata (out_len / kept_index / out_off, 14 B per kept read) is not requested: the packed stream and res[] are
-        outs = eng.alloc_outputs(R, L, compact=compact, meta=False)
-    torch.cuda.synchronize()
 
-    gathered = [None]
-
-    def step():
+    def measure(config, steps, warmup, reads, want_e2e):
+        cfg = CONFIGS[config]
+        R, L = (reads or cfg["reads"]), cfg["L"]
+        lo = rank * R                                  # weak scaling: rank g owns reads [g*R, (g+1)*R) of the global set
+        bases, qual = eng.synth(cfg["seed"], lo, R, L, cfg["adapter"])
+        is_stats = cfg["params"] is None
+        compact = not args.decision_only and not is_stats
         if is_stats:
-            eng.quality_stats(bases, qual, fixed_len=L, hist=hist, sync=False)
-            return None
-        r = eng.run(bases, qual, params, fixed_len=L, compact=compact, meta=False, outputs=outs)
-        if world > 1:
-            gathered[0] = fxd.gather_counters(outs["counters"])   # 192-byte all-gather, enqueued after the kernels, no host sync
-        return r
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    # HIP events around the dominant kernel of every TIMED launch (two event records per step on the launch stream, read after the final
-    # synchronisation: a ring of the last 64 launches in the context) -- kernel_ms_avg below is of these very launches
-    eng.set_profiling(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    kms = eng.profiled_kernel_ms(min(args.steps, 64))
-    eng.set_profiling(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=eng.device if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    if is_stats:
-        kept, kept_bytes = R, R * L
-        assert int(hist.sum().item()) == R * L * (args.warmup + args.steps)
-    else:
-        counters = res.counters
-        kept, kept_bytes = int(counters[1]), int(counters[2])
-        if world > 1:                              # job totals and this rank's offsets in the global output, from the last step's gather
-            totals, read_off, byte_off, _ = fxd.offsets_from_gathered(gathered[0], rank)
-            assert int(totals[0]) == R * world
-
-    kavg = sum(kms) / len(kms)          # the timed loop's own launches (the last min(steps, 64) of them)
-    launch = eng.last_launch()
-    # algorithmic bytes per launch: read 2L per read, write 4 B result per read + 2*new_len per kept read
-    if is_stats:
-        alg_bytes = R * 2 * L
-    else:
-        alg_bytes = R * (2 * L + 4) + 2 * kept_bytes if compact else R * (L + 4)
-    achieved = alg_bytes / (kavg * 1e-3) / 1e9
-    # what the launches produced: counters and a device-side checksum of res[] + the packed stream, against the pinned tuple
-    self_check = None
-    if not is_stats and compact and rank == 0:
-        exp = EXPECTED.get(args.config) if R == cfg["reads"] else None
-        got = (kept, kept_bytes, res.checksum())
-        self_check = dict(kept=got[0], kept_bases=got[1], checksum=got[2], pinned=list(exp) if exp else None,
-                          matches_pinned=(exp is not None and got[:2] == tuple(exp[:2]) and (exp[2] is None or got[2] == exp[2])) if exp else None)
-        if exp is not None and not self_check["matches_pinned"]:
-            raise SystemExit("bench self-check failed: launches produced %r, pinned %r" % (got, exp))
-    # HBM traffic: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this config (scripts/pmc_traffic.py), attached only when they were
-    # collected on the SAME kernel sources (hash of fastx_toolkit_amd/csrc) and the same launch shape
-    traffic, traffic_source = None, None
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.config)
-    if os.path.exists(pmc):
-        try:
-            pj = json.load(open(pmc))
-            if pj.get("reads_per_launch") == R and (compact or is_stats) and pj.get("csrc_sha16") == csrc_sha16() and pj.get("kernel_name", "").split("(")[0].replace(",1>", ">").replace(",false>", ">").replace(",true>", ">") in launch["kernel"].replace(" ", ""):
-                traffic = pj.get("hbm_bytes_per_launch")
-                traffic_source = "replayed from profiles/pmc_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of %s on csrc %s); not measured in this run" % (
-                    args.config, pj.get("command", "scripts/pmc_run.py"), pj.get("csrc_sha16"))
-            else:
-                traffic_source = "profiles/pmc_traffic_%s.json is of other kernel sources or another launch shape: not attached" % args.config
-        except Exception:
-            traffic = None
-
-    e2e_r = None
-    if args.e2e and not is_stats:
-        try:
-            with _on_gpu_node(local) as place:
-                e2e_r = e2e_ranks(args.config, rank, local, world, args.e2e_reads, dist, eng.device)
-            if isinstance(e2e_r, dict):
-                e2e_r["numa_node"] = place.node                 # the tool chain ran on its GPU's NUMA node (None: not pinned)
-        except Exception as e:
-            e2e_r = {"error": repr(e)[:200]}
-    if rank == 0:
-        total_reads = R * world * args.steps
-        out = {
-            "metric": cfg["metric"],
-            "value": round(total_reads / dt / 1e6, 2),
-            "unit": "Mreads/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if cfg["bound"] == "valu" else "u8", "data": "synthetic",
-            "config": {
-                "workload": "%s: %s, %d x %d bp Phred+33 reads per GPU, %s" % (
-                    args.config, cfg["what"], R, L,
-                    "histogram hist[column][A,C,G,T,N][quality] accumulated on the device" if is_stats else
-                    "one fused pass with order-preserving compaction of the kept trimmed reads (packed bases + qualities and the 4-byte per-read "
-                    "result res[]; the optional per-kept-read out_len/kept_index/out_off arrays are not requested)" if compact
-                    else "decision-only pass (no compaction)"),
-                "reads_per_gpu": R, "read_len": L, "seed": cfg["seed"], "kept_reads_per_gpu": kept, "kept_bases_per_gpu": kept_bytes,
-                "gbases_per_s_in": round(total_reads * L / dt / 1e9, 2), "parallelism": "reads sharded x%d, no data-path collective" % world,
-            },
-        }
-        hbm = {
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "traffic_source": traffic_source,
-            "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_read": round(alg_bytes / R, 2),
-            "traffic_over_algorithmic": round(traffic / alg_bytes, 4) if traffic else None,
-        }
-        shape = {"kernel": launch["kernel"], "kernel_ms_avg": round(kavg, 4), "kernel_ms_min": round(min(kms), 4), "kernel_ms_launches": len(kms),
-                 "kernel_ms_source": "HIP events around the dominant kernel of the timed loop's own launches (fxg_profiled_kernel_ms)",
-                 "grid": launch["grid"], "block": launch["block"], "lds_bytes": launch["lds"], "tile_reads": launch["tile_reads"]}
-        if cfg["bound"] == "valu":
-            # the aligner is a per-thread fp32 dynamic program: L x 13 cells per read, bounded by VALU issue, not by HBM -- the roofline object
-            # describes THAT resource; the HBM figures (low by construction) sit in the sub-object
-            cells = R * L * len(ADAPTER)
-            gcups = cells / (kavg * 1e-3) / 1e9
-            glane = gcups * CLIP_VALU_PER_CELL[args.config]
-            out["roofline"] = {
-                "bound": "valu", "achieved": round(glane, 1), "peak": round(VALU_PEAK_GLANEOPS, 1), "unit": "G lane-ops/s",
-                "frac": round(glane / VALU_PEAK_GLANEOPS, 4), "traffic": traffic,
-                "gcups": round(gcups, 1), "cells_per_launch": cells, "valu_instr_per_cell": CLIP_VALU_PER_CELL[args.config],
-                **shape, "hbm": hbm,
-                "note": "bound is VALU issue; peak = 256 CUs x 4 SIMDs x 64 lanes / %.0f cycles x 2.4 GHz (MI355X_MICROARCH.md: one wave64 VALU instruction "
-                        "per 2 cycles per SIMD); achieved = cells/s x valu_instr_per_cell, the wave-instructions the kernel issues per cell of the full "
-                        "L x 13 matrix the reference fills (SQ_INSTS_VALU x 64 / cells, whole kernel: both passes, staging, write-out; "
-                        "profiles/r04/aa_clip_sq_counters_*.txt), so it is what the SIMDs really issued" % VALU_CYCLES,
-            }
+            hist = torch.zeros((L, 5, 128), dtype=torch.int64, device=eng.device)
+            counters_dev = torch.zeros(24, dtype=torch.int64, device=eng.device)
         else:
-            out["roofline"] = {
-                "bound": "hbm", **hbm, **shape,
-                **({"note": "not measured in this run: a plain streaming kernel that reads 15 GB and writes 7.3 GB (this config's algorithmic bytes, nothing "
-                            "else) takes 4.25-4.56 ms on this part, read alone 2.34-2.50 ms, write alone 1.17-1.25 ms (scripts/ubench/mix_rw.hip, profiles/r02/z_mix_rw.txt)"}
-                   if args.config == "cfg2" and compact else {}),
+            params = make_params(**cfg["params"])
+            # per-kept-read metadata (out_len / kept_index / out_off, 14 B per kept read) is not requested: the packed stream and res[] are
+            outs = eng.alloc_outputs(R, L, compact=compact, meta=False)
+        torch.cuda.synchronize()
+
+        gathered = [None]
+
+        def step():
+            if is_stats:
+                eng.quality_stats(bases, qual, fixed_len=L, hist=hist, sync=False)
+                return None
+            r = eng.run(bases, qual, params, fixed_len=L, compact=compact, meta=False, outputs=outs)
+            if world > 1:
+                gathered[0] = fxd.gather_counters(outs["counters"])   # 192-byte all-gather, enqueued after the kernels, no host sync
+            return r
+
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        # HIP events around the dominant kernel of every TIMED launch (two event records per step on the launch stream, read after the final
+        # synchronisation: a ring of the last 64 launches in the context) -- kernel_ms_avg below is of these very launches
+        eng.set_profiling(True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        kms = eng.profiled_kernel_ms(min(steps, 64))
+        eng.set_profiling(False)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=eng.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+
+        if is_stats:
+            kept, kept_bytes = R, R * L
+            assert int(hist.sum().item()) == R * L * (warmup + steps)
+        else:
+            counters = res.counters
+            kept, kept_bytes = int(counters[1]), int(counters[2])
+            if world > 1:                              # job totals and this rank's offsets in the global output, from the last step's gather
+                totals, read_off, byte_off, _ = fxd.offsets_from_gathered(gathered[0], rank)
+                assert int(totals[0]) == R * world
+
+        kavg = sum(kms) / len(kms)          # the timed loop's own launches (the last min(steps, 64) of them)
+        launch = eng.last_launch()
+        # algorithmic bytes per launch: read 2L per read, write 4 B result per read + 2*new_len per kept read
+        if is_stats:
+            alg_bytes = R * 2 * L
+        else:
+            alg_bytes = R * (2 * L + 4) + 2 * kept_bytes if compact else R * (L + 4)
+        achieved = alg_bytes / (kavg * 1e-3) / 1e9
+        # what the launches produced: counters and a device-side checksum of res[] + the packed stream, against the pinned tuple
+        self_check = None
+        if not is_stats and compact and rank == 0:
+            exp = EXPECTED.get(config) if R == cfg["reads"] else None
+            got = (kept, kept_bytes, res.checksum())
+            self_check = dict(kept=got[0], kept_bases=got[1], checksum=got[2], pinned=list(exp) if exp else None,
+                              matches_pinned=(exp is not None and got[:2] == tuple(exp[:2]) and (exp[2] is None or got[2] == exp[2])) if exp else None)
+            if exp is not None and not self_check["matches_pinned"]:
+                raise SystemExit("bench self-check failed: launches produced %r, pinned %r" % (got, exp))
+        # HBM traffic: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this config (scripts/pmc_traffic.py), attached only when they were
+        # collected on the SAME kernel sources (hash of fastx_toolkit_amd/csrc) and the same launch shape
+        traffic, traffic_source = None, None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % config)
+        if os.path.exists(pmc):
+            try:
+                pj = json.load(open(pmc))
+                if pj.get("reads_per_launch") == R and (compact or is_stats) and pj.get("csrc_sha16") == csrc_sha16() and pj.get("kernel_name", "").split("(")[0].replace(",1>", ">").replace(",false>", ">").replace(",true>", ">") in launch["kernel"].replace(" ", ""):
+                    traffic = pj.get("hbm_bytes_per_launch")
+                    traffic_source = "replayed from profiles/pmc_traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of %s on csrc %s); not measured in this run" % (
+                        config, pj.get("command", "scripts/pmc_run.py"), pj.get("csrc_sha16"))
+                else:
+                    traffic_source = "profiles/pmc_traffic_%s.json is of other kernel sources or another launch shape: not attached" % config
+            except Exception:
+                traffic = None
+
+        e2e_r = None
+        if want_e2e and not is_stats:
+            try:
+                with _on_gpu_node(local) as place:
+                    e2e_r = e2e_ranks(config, rank, local, world, args.e2e_reads, dist, eng.device)
+                if isinstance(e2e_r, dict):
+                    e2e_r["numa_node"] = place.node                 # the tool chain ran on its GPU's NUMA node (None: not pinned)
+            except Exception as e:
+                e2e_r = {"error": repr(e)[:200]}
+        if rank == 0:
+            total_reads = R * world * steps
+            out = {
+                "metric": cfg["metric"],
+                "value": round(total_reads / dt / 1e6, 2),
+                "unit": "Mreads/s",
+                "n_gpus": world, "steps": steps, "warmup": warmup,
+                "ms_per_step": round(dt / steps * 1e3, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32" if cfg["bound"] == "valu" else "u8", "data": "synthetic",
+                "config": {
+                    "workload": "%s: %s, %d x %d bp Phred+33 reads per GPU, %s" % (
+                        config, cfg["what"], R, L,
+                        "histogram hist[column][A,C,G,T,N][quality] accumulated on the device" if is_stats else
+                        "one fused pass with order-preserving compaction of the kept trimmed reads (packed bases + qualities and the 4-byte per-read "
+                        "result res[]; the optional per-kept-read out_len/kept_index/out_off arrays are not requested)" if compact
+                        else "decision-only pass (no compaction)"),
+                    "reads_per_gpu": R, "read_len": L, "seed": cfg["seed"], "kept_reads_per_gpu": kept, "kept_bases_per_gpu": kept_bytes,
+                    "gbases_per_s_in": round(total_reads * L / dt / 1e9, 2), "parallelism": "reads sharded x%d, no data-path collective" % world,
+                },
             }
-        if self_check is not None:
-            out["self_check"] = self_check
-        if e2e_r is not None:
-            out["e2e_ranks"] = e2e_r
+            hbm = {
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "traffic_source": traffic_source,
+                "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_read": round(alg_bytes / R, 2),
+                "traffic_over_algorithmic": round(traffic / alg_bytes, 4) if traffic else None,
+            }
+            shape = {"kernel": launch["kernel"], "kernel_ms_avg": round(kavg, 4), "kernel_ms_min": round(min(kms), 4), "kernel_ms_launches": len(kms),
+                     "kernel_ms_source": "HIP events around the dominant kernel of the timed loop's own launches (fxg_profiled_kernel_ms)",
+                     "grid": launch["grid"], "block": launch["block"], "lds_bytes": launch["lds"], "tile_reads": launch["tile_reads"]}
+            if cfg["bound"] == "valu":
+                # the aligner is a per-thread fp32 dynamic program: L x 13 cells per read, bounded by VALU issue, not by HBM -- the roofline object
+                # describes THAT resource; the HBM figures (low by construction) sit in the sub-object
+                cells = R * L * len(ADAPTER)
+                gcups = cells / (kavg * 1e-3) / 1e9
+                glane = gcups * CLIP_VALU_PER_CELL[config]
+                out["roofline"] = {
+                    "bound": "valu", "achieved": round(glane, 1), "peak": round(VALU_PEAK_GLANEOPS, 1), "unit": "G lane-ops/s",
+                    "frac": round(glane / VALU_PEAK_GLANEOPS, 4), "traffic": traffic,
+                    "gcups": round(gcups, 1), "cells_per_launch": cells, "valu_instr_per_cell": CLIP_VALU_PER_CELL[config],
+                    # frac multiplies by what the kernel ISSUES, so a kernel that issued more would score higher; useful_frac prices the same cells at
+                    # the fewest VALU instructions the reference's cell can be done in on this ISA
+                    "useful_valu_instr_per_cell": CLIP_MIN_VALU_PER_CELL, "useful_frac": round(gcups * CLIP_MIN_VALU_PER_CELL / VALU_PEAK_GLANEOPS, 4),
+                    "useful_note": "5 = v_cmp_eq (read base == adapter base) + v_cndmask (pair score +1 / -1) + v_add_f32 (diagonal candidate) + v_max3_f32 "
+                                   "(diag, up, left; the -5 of `up` and `left` comes from one shared subtraction) + v_add_f32 (S - 5 kept beside S): the score "
+                                   "recurrence of sequence_alignment.cpp:380-417 alone, no path summary, no staging, no write-out",
+                    **shape, "hbm": hbm,
+                    "note": "bound is VALU issue; peak = 256 CUs x 4 SIMDs x 64 lanes / %.0f cycles x 2.4 GHz (MI355X_MICROARCH.md: one wave64 VALU instruction "
+                            "per 2 cycles per SIMD); achieved = cells/s x valu_instr_per_cell, the wave-instructions the kernel issues per cell of the full "
+                            "L x 13 matrix the reference fills (SQ_INSTS_VALU x 64 / cells, whole kernel: both passes, staging, write-out; "
+                            "profiles/r04/aa_clip_sq_counters_*.txt), so it is what the SIMDs really issued" % VALU_CYCLES,
+                }
+            else:
+                out["roofline"] = {
+                    "bound": "hbm", **hbm, **shape,
+                    **({"note": "not measured in this run: a plain streaming kernel that reads 15 GB and writes 7.3 GB (this config's algorithmic bytes, nothing "
+                                "else) takes 4.25-4.56 ms on this part, read alone 2.34-2.50 ms, write alone 1.17-1.25 ms (scripts/ubench/mix_rw.hip, profiles/r02/z_mix_rw.txt)"}
+                       if config == "cfg2" and compact else {}),
+                }
+            if self_check is not None:
+                out["self_check"] = self_check
+            if e2e_r is not None:
+                out["e2e_ranks"] = e2e_r
+            return out
+        return None
+
+    out = measure(args.config, args.steps, args.warmup, args.reads, args.e2e)
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config)
+        # Every BASELINE config in the one invocation the driver times (round-4 verdict item 3): after the headline line's own measurement the other
+        # workloads run in this process at their stated sizes (buffers freed in between: config 4 alone needs 120 GB), each with its roofline object,
+        # its self-check against the oracle-verified tuple and the reference's CPU rate on a bounded sample.  The headline keys stay what they were.
+        if world == 1 and args.config == "cfg2" and not args.reads and not args.decision_only and not args.headline_only:
+            out["configs"] = {}
+            for c in ("cfg3", "cfg4", "cfg5shard", "stats"):
+                torch.cuda.empty_cache()
+                try:
+                    t0 = time.perf_counter()
+                    o = measure(c, max(5, args.steps // 2), min(args.warmup, 2), 0, False)
+                    line = {k: o[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline") if k in o}
+                    if "self_check" in o:
+                        line["self_check"] = o["self_check"]
+                    if not args.no_cpu_baseline:
+                        line["cpu_baseline"] = cpu_baseline(c)
+                    line["wall_s_incl_generation_and_cpu_baseline"] = round(time.perf_counter() - t0, 1)
+                    out["configs"][c] = line
+                except SystemExit:
+                    raise
+                except Exception as e:                     # a failing extra config must not take the headline line down -- but it must be seen
+                    out["configs"][c] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_e2e and args.config == "cfg2":
             try:
                 with _on_gpu_node(local) as place:

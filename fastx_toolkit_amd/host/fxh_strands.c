@@ -466,7 +466,9 @@ int fxh_run_one_file(FASTX *fx, const fxg_params *p, fxh_totals *tot)
     if (pos < 0) return -1;
     const off_t start = pos - (off_t)(rd->end - rd->beg), size = sb.st_size;      /* where the unread input begins in the file */
     if (start < 0 || start >= size) return -1;
-    const long min_mb = fxh_env_long("FXH_ONE_FILE_MIN_MB", 1024, 0, 1 << 30);
+    /* from about half a gigabyte on the strands pay for their contexts: 0.64 GB 0.193 against 0.197 s, 1.3 GB 0.246 / 0.197, 2.6 GB 0.361 / 0.239,
+     * 5.1 GB 0.660 / 0.364, 20.5 GB 1.79 / 1.13 (one stream / this run, profiles/r05/l_e2e_one_file_by_size.txt) */
+    const long min_mb = fxh_env_long("FXH_ONE_FILE_MIN_MB", 512, 0, 1 << 30);
     if ((long long)(size - start) < ((long long)min_mb << 20)) return -1;
     const int lpr = fx->read_fastq ? 4 : 2;
     size_t chunk = (size_t)fxh_env_long("FXH_STRAND_KB", 0, 0, 1 << 22) << 10;     /* (tests: chunks of a few KB) */
@@ -562,7 +564,9 @@ int fxh_run_one_file(FASTX *fx, const fxg_params *p, fxh_totals *tot)
         }
     }
 
-    int per = (int)fxh_env_long("FXH_STRANDS", 8, 1, FXH_MAX_STRANDS);
+    /* four strands feed the sink of a small file as well as eight and start faster (2.6 GB: 0.239 against 0.268 s); large inputs take eight, so that
+     * a tool that keeps little of its input still fills the link */
+    int per = (int)fxh_env_long("FXH_STRANDS", S->in_total < ((uint64_t)4 << 30) ? 4 : 8, 1, FXH_MAX_STRANDS);
     int ns = per * ndev;
     if (ns > FXH_MAX_STRANDS) ns = FXH_MAX_STRANDS;
     if ((uint64_t)ns > nchunks) ns = (int)nchunks;
