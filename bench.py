@@ -394,9 +394,13 @@ class _on_gpu_node:
 
 
 def e2e_ranks(config, rank, local, world, reads_per_rank, dist, device):
-    """--e2e: the config's command line end to end, one process per GPU as in the kernel-level run: every rank generates ITS shard of
-    the synthetic set as FASTQ text on tmpfs, runs the tools of the config on its GPU (FXG_DEVICE = local rank; pipes where the
-    reference uses pipes), file to file; barrier on both sides, the slowest rank's wall time counts.  Weak scaling, like the kernel line."""
+    """--e2e: the config's command line end to end, one process per GPU, weak scaling like the kernel line (reads_per_rank x world reads in all).
+
+    A config that is ONE tool (cfg2, cfg3, cfg5shard) runs the way a user of a multi-GPU node runs it: ONE input file, ONE output file, the same command
+    line on every rank with FXH_RANK / FXH_WORLD in the environment (host/fxh_strands.c: rank g takes byte range g of the input, keeps its formatted text
+    on its GPU, the ranks exchange their counter blocks in one RCCL all-gather opened by the tool itself, every rank writes its slice of the output at the
+    sum of the bytes before it; rank 0 prints the report).  A config that is a pipe of reference tools (cfg4) has no file for ranks to share: every rank
+    runs the pipe on its own shard.  Barrier on both sides, the slowest rank's wall time counts; FASTQ text on tmpfs in and out."""
     import torch
     cfg = CONFIGS[config]
     bindir = os.path.join(ROOT, "fastx_toolkit_amd", "host", "bin")
@@ -409,33 +413,47 @@ def e2e_ranks(config, rank, local, world, reads_per_rank, dist, device):
     from oracle import fxoracle_py as fo
     import hashlib
     import shutil
-    # one directory for the job (every rank's files side by side, so that rank 0 can hash the outputs in rank order at the end)
+    one_job = len(chain) == 1
+    cpu_or_dev = device if (world > 1 and dist.get_backend() == "nccl") else "cpu"
     shared = [tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)] if rank == 0 else [None]
     if world > 1:
         dist.broadcast_object_list(shared, src=0)
     jobdir = shared[0]
-    td = os.path.join(jobdir, "rank%d" % rank)
+    td = jobdir if one_job else os.path.join(jobdir, "rank%d" % rank)
     os.makedirs(td, exist_ok=True)
     try:
         inp, outp = os.path.join(td, "in.fq"), os.path.join(td, "out.fq")
         chunk = 250_000
         first = rank * reads_per_rank
-        with open(inp, "wb") as f:
-            with ThreadPoolExecutor(max_workers=max(2, min(32, (os.cpu_count() or 2) // max(1, world)))) as ex:
-                for part in ex.map(lambda k: fo.synth_fastq(cfg["seed"], first + k * chunk, chunk, cfg["L"], cfg["adapter"]), range(reads_per_rank // chunk)):
-                    f.write(part)
-        env = dict(os.environ, FXG_DEVICE=str(local), FXH_CLIP_PARALLEL="1")     # fixed-length shard: the clipper needs no history
+        with ThreadPoolExecutor(max_workers=max(2, min(32, (os.cpu_count() or 2) // max(1, world)))) as ex:
+            parts = list(ex.map(lambda k: fo.synth_fastq(cfg["seed"], first + k * chunk, chunk, cfg["L"], cfg["adapter"]), range(reads_per_rank // chunk)))
+        my_bytes = sum(len(x) for x in parts)
+        off = 0
+        if one_job and world > 1:                 # the ranks' shards side by side in the ONE input file
+            sizes = [None] * world
+            dist.all_gather_object(sizes, my_bytes)
+            off = sum(sizes[:rank])
+            if rank == 0:
+                open(inp, "wb").close()
+            dist.barrier()
+        with open(inp, "r+b" if (one_job and world > 1) else "wb") as f:
+            f.seek(off)
+            for x in parts:
+                f.write(x)
+        del parts
+        env = dict(os.environ, FXG_DEVICE=str(local))
         env.pop("FXG_DEVICES", None)
-        if len(chain) == 1:                      # one tool, file to file: its sharded run (four input ranges, four writer streams) on this GPU
-            env.update(FXH_PARTS="4", FXH_LANES="2")
-            outp = os.path.join(td, "out.%r.fq")
-
-        outs = [outp.replace("%r", str(r)) for r in range(4)] if "%r" in outp else [outp]
+        if one_job:
+            env.update(FXH_RANK=str(rank), FXH_WORLD=str(world), FXH_RENDEZVOUS=os.path.join(td, "job.rdv"), FXG_COMM_JOB=os.path.basename(jobdir))
+            if os.environ.get("FXG_BENCH_FAKE_RCCL"):     # ranks sharing ONE GPU (the test box): RCCL refuses two ranks on a device, the test-only transport does not
+                env["LD_LIBRARY_PATH"] = os.environ["FXG_BENCH_FAKE_RCCL"] + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+                env["FXG_FAKE_RCCL_HIP"] = "1"
+        else:
+            env["FXH_CLIP_PARALLEL"] = "1"
 
         def once():
-            for f in outs:
-                if os.path.exists(f):
-                    os.unlink(f)
+            if (rank == 0 or not one_job) and os.path.exists(outp):
+                os.unlink(outp)
             if world > 1:
                 dist.barrier()
             t0 = time.perf_counter()
@@ -449,7 +467,7 @@ def e2e_ranks(config, rank, local, world, reads_per_rank, dist, device):
                 prev = p
             ok = all(p.wait() == 0 for p in procs)
             dt = time.perf_counter() - t0
-            t = torch.tensor([dt, 0.0 if ok else 1.0], dtype=torch.float64, device=device if (world > 1 and dist.get_backend() == "nccl") else "cpu")
+            t = torch.tensor([dt, 0.0 if ok else 1.0], dtype=torch.float64, device=cpu_or_dev)
             if world > 1:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t[0]), float(t[1]) == 0.0
@@ -459,37 +477,35 @@ def e2e_ranks(config, rank, local, world, reads_per_rank, dist, device):
             if not ok:
                 return {"error": "a tool of the chain failed"}
             best = dt if best is None else min(best, dt)
-        recs = 0
-        for fn in outs:
-            with open(fn, "rb") as f:
+        recs, nbytes = 0, 0
+        if rank == 0 or not one_job:
+            with open(outp, "rb") as f:
                 for blk in iter(lambda: f.read(1 << 24), b""):
-                    recs += blk.count(b"\n")
-        t = torch.tensor([recs // 4, sum(os.path.getsize(fn) for fn in outs)], dtype=torch.int64, device=device if (world > 1 and dist.get_backend() == "nccl") else "cpu")
+                    recs += blk.count(b"\n"); nbytes += len(blk)
+        t = torch.tensor([recs // 4, nbytes], dtype=torch.int64, device=cpu_or_dev)
         if world > 1:
             dist.all_reduce(t)
         total = reads_per_rank * world
-        # the job's output = the ranks' outputs in rank order (each rank's parts in part order): its md5 must not depend on the number of ranks
-        names = [outs]
-        if world > 1:
-            gathered = [None] * world
-            dist.all_gather_object(gathered, outs)
-            names = gathered
+        # the job's output: the one file, or the ranks' private outputs in rank order -- its md5 must not depend on the number of ranks
+        names = [outp]
+        if world > 1 and not one_job:
+            names = [None] * world
+            dist.all_gather_object(names, outp)
         md5 = None
         if rank == 0:
             h = hashlib.md5()
-            for per_rank in names:
-                for fn in per_rank:
-                    with open(fn, "rb") as f:
-                        for blk in iter(lambda: f.read(1 << 24), b""):
-                            h.update(blk)
+            for fn in names:
+                with open(fn, "rb") as f:
+                    for blk in iter(lambda: f.read(1 << 24), b""):
+                        h.update(blk)
             md5 = h.hexdigest()
         if world > 1:
             dist.barrier()
         return dict(command=" | ".join(" ".join(st) for st in chain), reads_per_rank=reads_per_rank, ranks=world, wall_s=round(best, 3),
                     mreads_s=round(total / best / 1e6, 2), gbases_s=round(total * cfg["L"] / best / 1e9, 3), kept_reads=int(t[0]), output_bytes=int(t[1]),
-                    output_md5=md5,
-                    note="one tool chain per GPU on its own shard of the input (FASTQ text on tmpfs in and out; a single tool runs sharded, FXH_PARTS=4), barrier to barrier, slowest rank; best of two; "
-                         "output_md5 = md5 of the ranks' outputs concatenated in rank order (equal for every number of ranks over the same reads)")
+                    output_md5=md5, mode="one input file, one output file, the tool's own rank mode (FXH_RANK / FXH_WORLD, RCCL epilogue inside the tool)" if one_job else
+                    "one pipe of reference tools per rank on its own shard",
+                    note="barrier to barrier, slowest rank, best of two; output_md5 is equal for every number of ranks over the same reads")
     finally:
         if world > 1:
             dist.barrier()

@@ -308,6 +308,7 @@ int fxh_reads_count(const FASTX *fx, const char *name, size_t name_len)   /* fas
 /* writer                                                                                         */
 /* ---------------------------------------------------------------------------------------------- */
 static struct fxh_writer *g_writers[8];
+static int g_fxh_batch_writer;          /* set by fxh_init_writer (the batch tools) around its call of fastx_init_writer */
 
 static void fxh_flush_all(void)
 {
@@ -445,8 +446,11 @@ static int fxh_open_output(const char *filename)
 {
     if (strcmp(filename, "-") == 0) return STDOUT_FILENO;
     /* read-write where that is allowed: the many-strand run maps its one output file (fxh_strands.c); a file that may only be written still opens */
-    int fd = open(filename, O_CREAT | O_RDWR | O_TRUNC, 0666);
-    if (fd == -1 && errno == EACCES) fd = open(filename, O_CREAT | O_WRONLY | O_TRUNC, 0666);
+    /* one process per GPU over one job (FXH_WORLD > 1, fxh_strands.c): the file is rank 0's to empty; the others only open it */
+    const char *we = getenv("FXH_WORLD"), *re = getenv("FXH_RANK");
+    const int trunc = (g_fxh_batch_writer && we && atoi(we) > 1 && re && atoi(re) > 0) ? 0 : O_TRUNC;
+    int fd = open(filename, O_CREAT | O_RDWR | trunc, 0666);
+    if (fd == -1 && errno == EACCES) fd = open(filename, O_CREAT | O_WRONLY | trunc, 0666);
     if (fd == -1) err(1, "Failed to create output file (%s)", filename);
     return fd;
 }
@@ -520,8 +524,6 @@ void fastx_init_reader(FASTX *fx, const char *filename, ALLOWED_INPUT_FILE_TYPES
 
 /* Set by fxh_init_writer (the batch tools) around its call of fastx_init_writer: only there does "%r" in the output name stand for the part
  * number of a sharded run.  A per-record caller of the libfastx API opens exactly the name it gave. */
-static int g_fxh_batch_writer;
-
 void fxh_init_writer(FASTX *fx, const char *filename, OUTPUT_FILE_TYPE output_type, int compress_output)
 {
     g_fxh_batch_writer = 1;

@@ -95,6 +95,14 @@ void fxh_lane_run(fxh_lane *ln)
                                    ln->has_q ? st->d_qual : NULL, stride, ln->qoffset, ln->out_fasta, st->d_out_text, &out_bytes));
     FXH_TCALL(5);
     if (ln->on_size) ln->on_size(ln, out_bytes);           /* the block's place in ONE output file depends only on the sizes before it: known here, before the download */
+    if (ln->on_place) {                                     /* rank mode of the one-file run: the text stays on the device for now */
+        if (ln->on_place(ln, out_bytes) < 0) return;
+        FXH_TCALL(6);
+        ln->t_call[7] += 1.0;
+        ln->out_len = (size_t)out_bytes;
+        ln->handled = 1;
+        return;
+    }
     const int s = ln->slot;
     if (ln->out_cap[s] < out_bytes + 16) {
         if (ln->out[s]) fxg_free_host(st->ctx, ln->out[s]);

@@ -170,6 +170,7 @@ typedef struct fxh_lane {
     uint64_t ctr[FXG_NCOUNTERS];
     uint64_t weighted[8];                  /* FASTA: tallies weighted by the records' read counts (fxg_fasta_weights) */
     void (*on_size)(struct fxh_lane *, uint64_t out_bytes);      /* one-file sharded run: called once the block's formatted size is known, before its download */
+    int (*on_place)(struct fxh_lane *, uint64_t out_bytes);      /* one-file run in rank mode: takes the formatted text on the device (1) instead of the download; -1 = stop */
     void *owner;
     double t_busy, t_init;
     double t_call[8];                        /* FXH_TIMING: seconds inside h2d, index, pack, pipeline, counters, format, d2h+sync, blocks */

@@ -147,6 +147,13 @@ struct fxh_sf {
     uint64_t scanned, scan_off, published, in_done, out_done;
     uint32_t clip_len;
     /* sink */
+    /* rank mode (FXH_RANK / FXH_WORLD): one process per GPU, each over its byte range of the input.  Where a rank's text goes in the ONE file is only
+     * known once every rank has decided its range, so the formatted chunks stay on the device (the arena: HBM holds any realistic range) until the
+     * ranks have exchanged their counter blocks -- one RCCL all-gather (fxg_epilogue_rccl) -- and then go down and out at base + local offset */
+    int rank, world;
+    fxg_ctx *main_ctx;
+    uint8_t *arena;
+    uint64_t arena_cap;
     int out_fd, mapped;
     char *map;
     uint64_t map_len, alloc_end, need, window;
@@ -232,6 +239,26 @@ static void fxh_sf_publish(fxh_lane *ln, uint64_t bytes)
     while (S->scanned < S->nchunks && S->have[S->scanned]) { S->offset[S->scanned] = S->scan_off; S->scan_off += S->size[S->scanned]; S->scanned++; }
     pthread_cond_broadcast(&S->cv);
     pthread_mutex_unlock(&S->mu);
+}
+
+/* rank mode: the chunk's text stays on the device -- copied behind the format kernels into the arena at the sum of the sizes before it (the local
+ * offset: known once every earlier chunk of THIS rank has been decided).  1 = placed, -1 = the run is being abandoned. */
+static int fxh_sf_place(fxh_lane *ln, uint64_t bytes)
+{
+    fxh_strand *s = (fxh_strand *)ln->owner;
+    fxh_sf *S = s->S;
+    const uint64_t t = s->cur_ticket;
+    const double t0 = fxh_now();
+    pthread_mutex_lock(&S->mu);
+    while (S->scanned <= t && !FXH_ABORTED()) pthread_cond_wait(&S->cv, &S->mu);
+    const uint64_t off = S->offset[t];
+    pthread_mutex_unlock(&S->mu);
+    s->t_wait_off += fxh_now() - t0;
+    if (FXH_ABORTED()) return -1;
+    if (off + bytes > S->arena_cap) { fxh_sf_abort(S); return -1; }      /* (cannot happen: 8/7 of the range bounds its output) */
+    FXG_CHECK(&ln->st, fxg_concat_peer(S->main_ctx, S->arena, off, ln->st.ctx, ln->st.d_out_text, bytes));
+    FXG_CHECK(&ln->st, fxg_sync(ln->st.ctx));
+    return 1;
 }
 
 static void fxh_sf_read_task(void *arg)
@@ -366,7 +393,7 @@ static void *fxh_strand_gpu(void *arg)
         if (FXH_ABORTED() || t == FXH_TICKET_DONE) break;
         t0 = fxh_now();
         pthread_mutex_lock(&s->mu);
-        while (s->out_full[j] && !FXH_ABORTED()) pthread_cond_wait(&s->cv, &s->mu);
+        while (!S->arena && s->out_full[j] && !FXH_ABORTED()) pthread_cond_wait(&s->cv, &s->mu);
         pthread_mutex_unlock(&s->mu);
         s->t_wait_out += fxh_now() - t0;
         if (FXH_ABORTED()) break;
@@ -391,6 +418,7 @@ static void *fxh_strand_gpu(void *arg)
         s->in_full[k] = 0;
         pthread_cond_broadcast(&s->cv);
         pthread_mutex_unlock(&s->mu);
+        if (S->arena) continue;                              /* rank mode: the text is in the arena already (fxh_sf_place) */
         t0 = fxh_now();
         pthread_mutex_lock(&S->mu);
         while (S->scanned <= t && !FXH_ABORTED()) pthread_cond_wait(&S->cv, &S->mu);
@@ -432,7 +460,7 @@ static void *fxh_cut_main(void *arg)
         const off_t from = j->start + (off_t)(c * (uint64_t)j->chunk);
         off_t f = fxh_find_cut(j->fd, from, j->size, j->lpr, (size_t)64 << 10);
         if (f < 0) f = fxh_find_cut(j->fd, from, j->size, j->lpr, 0);
-        if (f < 0) j->bad = 1;
+        if (f < 0) f = j->size;                              /* no record starts behind it: the chunk in front runs to the end (and is then checked like any other) */
         j->cut[c] = f;
     }
     return NULL;
@@ -447,10 +475,53 @@ static long fxh_env_long(const char *name, long dflt, long lo, long hi)
     return v;
 }
 
-/* 0 = done (in the child of the fork below: the caller goes on to print its reports); -1 = run as one stream (not eligible, or the attempt was abandoned) */
+/* the counter block a rank contributes to the job's one all-gather (u64[FXG_NCOUNTERS], text level): records and reads in and out, the BYTES of its
+ * formatted output where the batch ABI has kept bases -- so that fxg_epilogue's exclusive scan is the rank's offset in the file -- and the -v tallies */
+enum { FXH_B_IN_SEQ = FXG_C_INPUT, FXH_B_OUT_SEQ = FXG_C_KEPT, FXH_B_OUT_BYTES = FXG_C_KEPT_BASES, FXH_B_BAD = FXG_C_ERRORS,
+       FXH_B_IN_READS = 17, FXH_B_OUT_READS = 18, FXH_B_CLIP_IN = 19, FXH_B_CLIP_LEN = 20 };
+#define FXH_BAD_IRREGULAR ((uint64_t)1 << 40)      /* (above the device's own error bits) */
+
+static void fxh_totals_add(fxh_totals *tot, const fxh_totals *t)
+{
+    tot->input_sequences += t->input_sequences; tot->input_reads += t->input_reads; tot->output_sequences += t->output_sequences; tot->output_reads += t->output_reads;
+    tot->clip_input += t->clip_input; tot->clip_too_short += t->clip_too_short; tot->clip_adapter_only += t->clip_adapter_only;
+    tot->clip_no_adapter += t->clip_no_adapter; tot->clip_adapter_found += t->clip_adapter_found; tot->clip_n += t->clip_n;
+    tot->masked_reads += t->masked_reads; tot->masked_nucleotides += t->masked_nucleotides; tot->qtrim_dropped += t->qtrim_dropped;
+}
+
+typedef struct { fxh_sf *S; const char *src; size_t len; uint64_t off; int *busy; } fxh_djob;
+static void fxh_sf_drain_task(void *arg)
+{
+    fxh_djob *j = (fxh_djob *)arg;
+    if (fxg_concat_pwrite(j->S->out_fd, j->src, j->len, j->off) != 0) err(1, "writing output failed");
+    pthread_mutex_lock(&j->S->mu);
+    *j->busy = 0;
+    pthread_cond_broadcast(&j->S->cv);
+    pthread_mutex_unlock(&j->S->mu);
+}
+
+static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot, int rank, int world);
+
+/* 0 = done (in the child of the fork below: the caller goes on to print its reports); -1 = run as one stream (not eligible, or the attempt was abandoned).
+ * FXH_WORLD = n > 1 with FXH_RANK = 0 .. n-1: n processes, one per GPU (FXG_DEVICE, default rank mod #GPUs), started by any launcher -- or by hand --
+ * with the SAME command line; they meet through FXH_RENDEZVOUS (default: <output>.rdv).  Rank 0 prints the -v report of the whole job. */
 int fxh_run_one_file(FASTX *fx, const fxg_params *p, fxh_totals *tot)
 {
+    const int world = (int)fxh_env_long("FXH_WORLD", 1, 1, 4096), rank = (int)fxh_env_long("FXH_RANK", 0, 0, world - 1);
+    const int rc = fxh_one_file_attempt(fx, p, tot, rank, world);
+    if (world > 1 && rc != 0 && rank > 0) {      /* not a job for ranks (a pipe, a tiny input) or abandoned: rank 0 runs it as one stream, the reference's way */
+        if (fx->writer && fx->writer->fd >= 0 && fx->writer->fd != STDOUT_FILENO) close(fx->writer->fd);
+        fx->writer->fd = -1;
+        fflush(NULL);
+        _exit(0);
+    }
+    return rc;
+}
+
+static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot, const int rank, const int world)
+{
     struct fxh_reader *rd = fx->reader;
+    const int ranked = world > 1 || getenv("FXH_RANK_MODE") != NULL;      /* (FXH_RANK_MODE=1: the rank path with a world of one -- the GPU tier's way to the real RCCL) */
     struct fxh_writer *w0 = fx->writer;
     struct stat sb, ob;
     const char *sw = getenv("FXH_ONE_FILE");
@@ -469,21 +540,35 @@ int fxh_run_one_file(FASTX *fx, const fxg_params *p, fxh_totals *tot)
     /* from about half a gigabyte on the strands pay for their contexts: 0.64 GB 0.193 against 0.197 s, 1.3 GB 0.246 / 0.197, 2.6 GB 0.361 / 0.239,
      * 5.1 GB 0.660 / 0.364, 20.5 GB 1.79 / 1.13 (one stream / this run, profiles/r05/l_e2e_one_file_by_size.txt) */
     const long min_mb = fxh_env_long("FXH_ONE_FILE_MIN_MB", 512, 0, 1 << 30);
-    if ((long long)(size - start) < ((long long)min_mb << 20)) return -1;
+    if (!ranked && (long long)(size - start) < ((long long)min_mb << 20)) return -1;
     const int lpr = fx->read_fastq ? 4 : 2;
+    /* rank mode: this process takes byte range `rank` of `world` (cut at record starts found by pattern, as the parts of fxh_parts.c; every rank computes
+     * the same cuts); from here on `start` .. `size` is that range */
+    const off_t file_size = size;
+    off_t my_start = start, my_end = size;
+    if (world > 1) {
+        off_t lo = start;
+        for (int g = 1; g <= world; ++g) {
+            const off_t hi = g == world ? file_size : fxh_find_cut(rd->fd, start + (off_t)((unsigned long long)(file_size - start) * (unsigned)g / (unsigned)world), file_size, lpr, 0);
+            if (hi < 0 || hi <= lo) return -1;           /* an input too small for that many ranks */
+            if (g - 1 == rank) { my_start = lo; my_end = hi; }
+            lo = hi;
+        }
+    }
+
     size_t chunk = (size_t)fxh_env_long("FXH_STRAND_KB", 0, 0, 1 << 22) << 10;     /* (tests: chunks of a few KB) */
     if (!chunk) chunk = (size_t)fxh_env_long("FXH_STRAND_MB", 16, 1, 1024) << 20;      /* 16 MB: 54.6 against 51.7 Mreads/s with 8 (profiles/r05/f_e2e_one_file_timeline.txt) */
-    const uint64_t nchunks = ((uint64_t)(size - start) + chunk - 1) / chunk;
-    if (nchunks < 2) return -1;
+    uint64_t nchunks = ((uint64_t)(my_end - my_start) + chunk - 1) / chunk;
+    if (nchunks < 2 && !ranked) return -1;
     off_t *cut = (off_t *)calloc(nchunks + 1, sizeof(off_t));
     if (!cut) err(1, "out of memory");
-    cut[0] = start; cut[nchunks] = size;
+    cut[0] = my_start; cut[nchunks] = my_end;
     {
         fxh_cutjob cj[8];
         pthread_t th[8];
         const int nt = nchunks > 64 ? 8 : 1;
         for (int i = 0; i < nt; ++i) {
-            cj[i].fd = rd->fd; cj[i].lpr = lpr; cj[i].start = start; cj[i].size = size; cj[i].chunk = chunk; cj[i].cut = cut; cj[i].bad = 0;
+            cj[i].fd = rd->fd; cj[i].lpr = lpr; cj[i].start = my_start; cj[i].size = file_size; cj[i].chunk = chunk; cj[i].cut = cut; cj[i].bad = 0;
             cj[i].c0 = 1 + (nchunks - 1) * (uint64_t)i / (uint64_t)nt; cj[i].c1 = 1 + (nchunks - 1) * (uint64_t)(i + 1) / (uint64_t)nt;
         }
         for (int i = 1; i < nt; ++i) if (pthread_create(&th[i], NULL, fxh_cut_main, &cj[i]) != 0) err(1, "pthread_create");
@@ -491,6 +576,8 @@ int fxh_run_one_file(FASTX *fx, const fxg_params *p, fxh_totals *tot)
         for (int i = 1; i < nt; ++i) pthread_join(th[i], NULL);
         int bad = 0;
         for (int i = 0; i < nt; ++i) bad |= cj[i].bad;
+        while (!bad && nchunks > 1 && cut[nchunks - 1] >= my_end) nchunks--;      /* a last nominal cut whose record start is the range's end: no chunk there */
+        cut[nchunks] = my_end;
         size_t longest = 0;
         for (uint64_t c = 0; c < nchunks && !bad; ++c) {
             if (cut[c + 1] <= cut[c]) bad = 1;               /* records longer than a chunk, or no record pattern in reach: one stream */
@@ -511,7 +598,7 @@ int fxh_run_one_file(FASTX *fx, const fxg_params *p, fxh_totals *tot)
         while (waitpid(child, &st, 0) < 0) { if (errno != EINTR) err(1, "waitpid"); }
         if (getenv("FXH_TIMING")) fprintf(stderr, "fxh timing one file: the child was gone %.3f s after the fork, at %.3f (CLOCK_MONOTONIC)\n", fxh_now() - t_fork, fxh_now());
         if (WIFEXITED(st) && WEXITSTATUS(st) == FXH_EXIT_ABANDON) {
-            if (ftruncate(w0->fd, w0->off) != 0) warn("%s", fx->output_file_name);
+            if (rank == 0 && ftruncate(w0->fd, w0->off) != 0) warn("%s", fx->output_file_name);      /* (no rank has written: the file is rank 0's again) */
             return -1;
         }
         if (WIFSIGNALED(st)) { signal(WTERMSIG(st), SIG_DFL); raise(WTERMSIG(st)); _exit(128 + WTERMSIG(st)); }
@@ -522,7 +609,7 @@ int fxh_run_one_file(FASTX *fx, const fxg_params *p, fxh_totals *tot)
     const double t_run0 = fxh_now();
     static fxh_sf S_;                            /* (static: zeroed, and alive for the whole child) */
     fxh_sf *S = &S_;
-    S->fx = fx; S->p = p; S->in_fd = rd->fd; S->lpr = lpr; S->cut = cut; S->nchunks = nchunks; S->in_total = (uint64_t)(size - start);
+    S->fx = fx; S->p = p; S->in_fd = rd->fd; S->lpr = lpr; S->cut = cut; S->nchunks = nchunks; S->in_total = (uint64_t)(my_end - my_start);
     S->in_cap = (chunk + 4096 + 4095) & ~(size_t)4095;
     S->clip_auto = clip && getenv("FXH_CLIP_PARALLEL") == NULL;
     S->out_fd = w0->fd;
@@ -533,7 +620,12 @@ int fxh_run_one_file(FASTX *fx, const fxg_params *p, fxh_totals *tot)
     g_parts_mode = 1;
 
     int dev[FXH_MAX_LANES];
-    const int ndev = fxh_device_list(dev, FXH_MAX_LANES);
+    int ndev = fxh_device_list(dev, FXH_MAX_LANES);
+    S->rank = rank; S->world = world;
+    if (ranked) {                                /* one process per GPU: FXG_DEVICE if the launcher set it, else the rank's turn among the GPUs of the box */
+        if (!getenv("FXG_DEVICE") && !getenv("FXG_DEVICES")) { const int nd = fxg_device_count(); g_hip_touched = 1; dev[0] = nd > 0 ? rank % nd : 0; }
+        ndev = 1;
+    }
     cpu_set_t cpus_before;
     const double t_dev = fxh_now();
     if (ndev == 1) (void)fxh_bind_near_device(dev[0], &cpus_before);      /* buffers and the output's pages are touched (and page-locked) on the GPU's node; every thread below inherits it */
@@ -544,7 +636,7 @@ int fxh_run_one_file(FASTX *fx, const fxg_params *p, fxh_totals *tot)
         struct statfs fs;
         const char *sk = getenv("FXH_ONE_FILE_SINK");        /* "map" | "pwrite": force one (tests) */
         int want_map = sk ? strcmp(sk, "map") == 0 : (fstatfs(w0->fd, &fs) == 0 && (unsigned long)fs.f_type == (unsigned long)TMPFS_MAGIC);
-        if (w0->off != 0) want_map = 0;
+        if (w0->off != 0 || ranked) want_map = 0;
         if (want_map) {
             S->map_len = (S->in_total + S->in_total / 7 + (1u << 20) + 4095u) & ~(uint64_t)4095u;      /* an empty third line still gets its '+': at most 8/7 of the input */
             S->window = (uint64_t)fxh_env_long("FXH_ONE_FILE_WINDOW_MB", 128, 1, 1 << 16) << 20;
@@ -580,6 +672,25 @@ int fxh_run_one_file(FASTX *fx, const fxg_params *p, fxh_totals *tot)
     S->nout = (int)fxh_env_long("FXH_STRAND_OUT_SLOTS", 4, 2, FXH_LANE_OUT_SLOTS);      /* output buffers per strand: what the strands can put aside while the allocator has the file */
     fxh_pool_start(&S->wpool, S->mapped ? (int)fxh_env_long("FXH_COPY_THREADS", 16, 1, 64) : 1, (unsigned)(S->nout * ns));
     const int revcomp = (p->stages & (FXG_STAGE_REVCOMP | FXG_STAGE_MASK)) != 0;
+    fxg_comm *comm = NULL;
+    fxh_lane rank_lane;                          /* rank mode: the context that owns the arena and the communicator */
+    memset(&rank_lane, 0, sizeof rank_lane);
+    uint64_t *d_block = NULL;
+    if (ranked) {
+        rank_lane.device = dev[0];
+        fxh_lane_open_ctx(&rank_lane);
+        S->main_ctx = rank_lane.st.ctx;
+        S->arena_cap = S->in_total + S->in_total / 7 + (1u << 20);
+        if (fxg_malloc_device(S->main_ctx, (size_t)S->arena_cap, (void **)&S->arena) != 0 || !S->arena)
+            errx(1, "rank %d of %d: %.1f GB of device memory for this rank's share of the output are not to be had (%s); start more ranks", rank, world,
+                 1e-9 * (double)S->arena_cap, fxg_last_error(S->main_ctx));
+        FXG_CHECK(&rank_lane.st, fxg_malloc_device(S->main_ctx, FXG_NCOUNTERS * sizeof(uint64_t), (void **)&d_block));
+        char rdv[PATH_MAX + 16];
+        const char *re = getenv("FXH_RENDEZVOUS");
+        if (re && *re) snprintf(rdv, sizeof rdv, "%s", re); else snprintf(rdv, sizeof rdv, "%s.rdv", fx->output_file_name);
+        const int crc = fxg_comm_create(S->main_ctx, rdv, (uint32_t)rank, (uint32_t)world, (int)fxh_env_long("FXH_RENDEZVOUS_TIMEOUT", 120, 1, 86400), &comm);
+        if (crc != 0) errx(1, "rank %d of %d: no communicator (%d): %s", rank, world, crc, fxg_last_error(S->main_ctx));
+    }
     for (int i = 0; i < ns; ++i) {
         fxh_strand *s = &S->st[i];
         s->id = i; s->S = S;
@@ -592,6 +703,7 @@ int fxh_run_one_file(FASTX *fx, const fxg_params *p, fxh_totals *tot)
         ln->reverse = (p->stages & FXG_STAGE_REVCOMP) != 0; ln->lpr = lpr; ln->has_q = fx->read_fastq; ln->out_fasta = !fx->write_fastq;
         ln->clip_guard = S->clip_auto;
         ln->on_size = fxh_sf_publish; ln->owner = s;
+        if (ranked) ln->on_place = fxh_sf_place;
         if (pthread_create(&s->th_rd, NULL, fxh_strand_reader, s) != 0) err(1, "pthread_create");      /* reading starts while the device does */
     }
     for (int i = 0; i < ns; ++i) if (pthread_create(&S->st[i].th_gpu, NULL, fxh_strand_gpu, &S->st[i]) != 0) err(1, "pthread_create");
@@ -607,31 +719,81 @@ int fxh_run_one_file(FASTX *fx, const fxg_params *p, fxh_totals *tot)
     pthread_cond_broadcast(&S->cv);
     pthread_mutex_unlock(&S->mu);
     if (S->mapped) pthread_join(S->th_alloc, NULL);
+    uint64_t base = 0, job_total = S->scan_off;
+    fxh_totals mine;
+    memset(&mine, 0, sizeof mine);
+    for (int i = 0; i < ns; ++i) fxh_totals_add(&mine, &S->st[i].tot);
+    if (ranked) {
+        /* The one exchange of the job: every rank's counter block, one ncclAllGather behind nothing (the strands have synchronised).  A rank that met
+         * something irregular still takes part -- with its flag up -- so that ALL ranks leave together and rank 0 alone runs the input as one stream. */
+        uint64_t blk[FXG_NCOUNTERS] = {0}, totals[FXG_NCOUNTERS], read_off = 0, byte_off = 0;
+        uint64_t *gathered = (uint64_t *)calloc((size_t)world * FXG_NCOUNTERS, sizeof(uint64_t));
+        if (!gathered) err(1, "out of memory");
+        blk[FXH_B_IN_SEQ] = mine.input_sequences; blk[FXH_B_OUT_SEQ] = mine.output_sequences; blk[FXH_B_OUT_BYTES] = S->scan_off;
+        blk[FXH_B_IN_READS] = mine.input_reads; blk[FXH_B_OUT_READS] = mine.output_reads; blk[FXH_B_CLIP_IN] = mine.clip_input;
+        blk[FXG_C_CLIP_TOO_SHORT] = mine.clip_too_short; blk[FXG_C_CLIP_ADAPTER_ONLY] = mine.clip_adapter_only; blk[FXG_C_CLIP_NO_ADAPTER] = mine.clip_no_adapter;
+        blk[FXG_C_CLIP_ADAPTER_FOUND] = mine.clip_adapter_found; blk[FXG_C_CLIP_N] = mine.clip_n; blk[FXG_C_QTRIM_DROPPED] = mine.qtrim_dropped;
+        blk[FXG_C_MASKED_READS] = mine.masked_reads; blk[FXG_C_MASKED_NT] = mine.masked_nucleotides;
+        blk[FXH_B_CLIP_LEN] = S->clip_len; blk[FXH_B_BAD] = bad ? FXH_BAD_IRREGULAR : 0;
+        FXG_CHECK(&rank_lane.st, fxg_memcpy_h2d(S->main_ctx, d_block, blk, sizeof blk));
+        const int erc = fxg_epilogue_rccl(S->main_ctx, comm, d_block, totals, &read_off, &byte_off, gathered);
+        if (erc != 0) errx(1, "rank %d of %d: the exchange of the counter blocks failed (%d): %s", rank, world, erc, fxg_last_error(S->main_ctx));
+        if (totals[FXH_B_BAD]) bad = 1;
+        if (S->clip_auto) {                      /* the clipper is exact across ranks while ALL reads of the job have one length */
+            uint64_t len0 = 0;
+            for (int g = 0; g < world; ++g) { const uint64_t l = gathered[(size_t)g * FXG_NCOUNTERS + FXH_B_CLIP_LEN]; if (!l) continue; if (!len0) len0 = l; else if (l != len0) bad = 1; }
+        }
+        base = byte_off; job_total = totals[FXH_B_OUT_BYTES];
+        memset(&mine, 0, sizeof mine);           /* rank 0 reports the JOB */
+        mine.input_sequences = totals[FXH_B_IN_SEQ]; mine.output_sequences = totals[FXH_B_OUT_SEQ]; mine.input_reads = totals[FXH_B_IN_READS]; mine.output_reads = totals[FXH_B_OUT_READS];
+        mine.clip_input = (unsigned)totals[FXH_B_CLIP_IN]; mine.clip_too_short = (unsigned)totals[FXG_C_CLIP_TOO_SHORT]; mine.clip_adapter_only = (unsigned)totals[FXG_C_CLIP_ADAPTER_ONLY];
+        mine.clip_no_adapter = (unsigned)totals[FXG_C_CLIP_NO_ADAPTER]; mine.clip_adapter_found = (unsigned)totals[FXG_C_CLIP_ADAPTER_FOUND]; mine.clip_n = (unsigned)totals[FXG_C_CLIP_N];
+        mine.qtrim_dropped = totals[FXG_C_QTRIM_DROPPED]; mine.masked_reads = totals[FXG_C_MASKED_READS]; mine.masked_nucleotides = totals[FXG_C_MASKED_NT];
+        free(gathered);
+        fxg_comm_destroy(comm);
+        if (!bad) {
+            /* this rank's text: down from the arena in pieces, each written where it belongs -- base (the bytes of the ranks before) + its place in the arena */
+            if (ftruncate(w0->fd, (off_t)job_total) != 0) err(1, "writing output failed");      /* (every rank says the same size; no rank's bytes lie beyond it) */
+            enum { NB = 3 };
+            const size_t piece = (size_t)fxh_env_long("FXH_DRAIN_MB", 32, 1, 1024) << 20;
+            char *hb[NB]; int busy[NB] = {0, 0, 0}; fxh_djob dj[NB];
+            fxh_pool dpool;
+            fxh_pool_start(&dpool, 2, NB);
+            for (int k = 0; k < NB; ++k) FXG_CHECK(&rank_lane.st, fxg_malloc_host(S->main_ctx, piece, (void **)&hb[k]));
+            int k = 0;
+            for (uint64_t o = 0; o < S->scan_off; o += piece, k = (k + 1) % NB) {
+                const size_t n = S->scan_off - o < piece ? (size_t)(S->scan_off - o) : piece;
+                pthread_mutex_lock(&S->mu);
+                while (busy[k]) pthread_cond_wait(&S->cv, &S->mu);
+                busy[k] = 1;
+                pthread_mutex_unlock(&S->mu);
+                FXG_CHECK(&rank_lane.st, fxg_memcpy_d2h(S->main_ctx, hb[k], S->arena + o, n));
+                FXG_CHECK(&rank_lane.st, fxg_sync(S->main_ctx));
+                dj[k].S = S; dj[k].src = hb[k]; dj[k].len = n; dj[k].off = base + o; dj[k].busy = &busy[k];
+                fxh_pool_submit(&dpool, fxh_sf_drain_task, &dj[k]);
+            }
+            fxh_pool_stop(&dpool);
+        }
+    }
     if (bad) {
         /* Abandoned.  Every thread has been joined, the contexts go, the file is emptied through its own descriptor -- which the parent
          * shares -- and the process leaves with _exit: no exit handler of this half-finished attempt gets to run. */
         for (int i = 0; i < ns; ++i) if (S->st[i].ln.st.ctx) fxg_ctx_destroy(S->st[i].ln.st.ctx);
         if (S->mapped) munmap(S->map, (size_t)S->map_len);
+        if (S->main_ctx) fxg_ctx_destroy(S->main_ctx);
         w0->len = 0;
-        if (ftruncate(w0->fd, w0->off) != 0 || lseek(w0->fd, w0->off, SEEK_SET) < 0) warn("%s", fx->output_file_name);
+        if (rank == 0 && (ftruncate(w0->fd, w0->off) != 0 || lseek(w0->fd, w0->off, SEEK_SET) < 0)) warn("%s", fx->output_file_name);
         if (timing) fprintf(stderr, "fxh timing one file: abandoned, contexts destroyed, output emptied\n");
         fflush(NULL);
         _exit(FXH_EXIT_ABANDON);
     }
-    const uint64_t total = S->scan_off;
+    const uint64_t total = job_total;
     if (S->mapped) {
         munmap(S->map, (size_t)S->map_len);
         if (ftruncate(w0->fd, (off_t)total) != 0) err(1, "writing output failed");
     }
     w0->off += (off_t)total;                     /* the writer closes with the descriptor where a write() stream would have left it */
-    memset(tot, 0, sizeof *tot);
-    for (int i = 0; i < ns; ++i) {
-        const fxh_totals *t = &S->st[i].tot;
-        tot->input_sequences += t->input_sequences; tot->input_reads += t->input_reads; tot->output_sequences += t->output_sequences; tot->output_reads += t->output_reads;
-        tot->clip_input += t->clip_input; tot->clip_too_short += t->clip_too_short; tot->clip_adapter_only += t->clip_adapter_only;
-        tot->clip_no_adapter += t->clip_no_adapter; tot->clip_adapter_found += t->clip_adapter_found; tot->clip_n += t->clip_n;
-        tot->masked_reads += t->masked_reads; tot->masked_nucleotides += t->masked_nucleotides; tot->qtrim_dropped += t->qtrim_dropped;
-    }
+    *tot = mine;
     fx->num_input_sequences = tot->input_sequences; fx->num_input_reads = tot->input_reads;
     fx->num_output_sequences = tot->output_sequences; fx->num_output_reads = tot->output_reads;
     if (timing) {
@@ -648,6 +810,14 @@ int fxh_run_one_file(FASTX *fx, const fxg_params *p, fxh_totals *tot)
                         "sink: %llu fallocate calls %.3f s (to %.2f GB for %.2f GB of output), copies %.3f s + %.3f s at the gate (summed over %d threads)\n",
                 ns, ndev, (unsigned long long)nchunks, S->mapped ? "gated mapping" : "pwrite", fxh_now() - t_run0, t_dev - t_run0, t_bound - t_dev, init, rd_s, win, gpu_s, wout, woff, rel,
                 (unsigned long long)S->alloc_calls, S->t_alloc, 1e-9 * (double)S->alloc_end, 1e-9 * (double)total, S->t_copy, S->t_copy_wait, S->wpool.nth);
+        if (ranked) fprintf(stderr, "fxh timing rank %d of %d: input bytes [%lld, %lld), %.3f GB of text held on the device, written at offset %llu of %llu\n", rank, world,
+                               (long long)my_start, (long long)my_end, 1e-9 * (double)S->scan_off, (unsigned long long)base, (unsigned long long)job_total);
+    }
+    if (rank > 0) {                              /* the job's report is rank 0's */
+        if (w0->fd != STDOUT_FILENO) close(w0->fd);
+        w0->fd = -1;
+        fflush(NULL);
+        _exit(0);
     }
     return 0;
 }

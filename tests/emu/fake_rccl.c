@@ -3,10 +3,14 @@
  * shared-memory file per communicator; "device" pointers are host pointers (the emulation stub's), the stream is ignored.
  * Built into tests/emu/fakerccl/librccl.so.1 by tests/test_comm_cpu.py and reached only through LD_LIBRARY_PATH.  Never shipped.
  *
+ * Under the REAL engine (GPU tier: two ranks of a job sharing the test box's one GPU, which RCCL itself refuses) the blocks are real device memory:
+ * with FXG_FAKE_RCCL_HIP=1 copies go through the process's own HIP runtime (dlopen RTLD_NOLOAD): hipMemcpy behind a hipStreamSynchronize of the caller's stream.
+ *
  *   FXG_FAKE_RCCL_LOG=<file>      one line per call (the test counts them)
  *   FXG_FAKE_RCCL_FAIL=id|init|gather   the named call returns ncclInternalError (error paths of the transport)
  */
 #define _GNU_SOURCE
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -76,19 +80,45 @@ static int barrier(struct comm *c)
     return 0;
 }
 
+static int (*hip_memcpy)(void *, const void *, size_t, int);
+static int (*hip_stream_sync)(void *);
+static void hip_lookup(void)
+{
+    static int done;
+    if (done) return;
+    done = 1;
+    if (!getenv("FXG_FAKE_RCCL_HIP")) return;            /* (the emulation stub links the runtime too, but its "device" memory is host memory) */
+    void *h = dlopen("libamdhip64.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("libamdhip64.so.7", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("libamdhip64.so.6", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) return;
+    hip_memcpy = (int (*)(void *, const void *, size_t, int))dlsym(h, "hipMemcpy");
+    hip_stream_sync = (int (*)(void *))dlsym(h, "hipStreamSynchronize");
+    if (!hip_memcpy || !hip_stream_sync) hip_memcpy = NULL;
+}
+static int copy(void *dst, const void *src, size_t n)
+{
+    if (hip_memcpy) return hip_memcpy(dst, src, n, 4 /* hipMemcpyDefault */) == 0 ? 0 : 3;
+    memcpy(dst, src, n);
+    return 0;
+}
+
 int ncclAllGather(const void *send, void *recv, size_t count, int dtype, void *comm, void *stream)
 {
     struct comm *c = comm;
-    (void)stream;
+    hip_lookup();
+    if (hip_memcpy && hip_stream_sync(stream) != 0) return 3;          /* "behind the pass on the same stream" */
     logline("gather rank %d count %d\n", c ? c->rank : -1, (int)count);
     if (failing("gather")) return 3;
     static const size_t width[] = {1, 1, 4, 4, 8, 8, 2, 4, 8};          /* ncclInt8 .. ncclFloat64 */
     if (!c || dtype < 0 || dtype > 8 || count * width[dtype] > SLOT_BYTES) return 4;
     const size_t bytes = count * width[dtype];
-    memcpy(c->sh->slot[c->rank], send, bytes);
+    unsigned char tmp[SLOT_BYTES];
+    if (copy(tmp, send, bytes)) return 3;
+    memcpy((void *)c->sh->slot[c->rank], tmp, bytes);
     __sync_synchronize();
     if (barrier(c)) return 3;
-    for (int g = 0; g < c->world; ++g) memcpy((char *)recv + (size_t)g * bytes, c->sh->slot[g], bytes);
+    for (int g = 0; g < c->world; ++g) { memcpy(tmp, (const void *)c->sh->slot[g], bytes); if (copy((char *)recv + (size_t)g * bytes, tmp, bytes)) return 3; }
     return barrier(c);                                                     /* nobody overwrites a slot another rank still reads */
 }
 

@@ -56,7 +56,7 @@ def build_fake_rccl():
     os.makedirs(d, exist_ok=True)
     so, src = os.path.join(d, "librccl.so.1"), os.path.join(_EMU, "fake_rccl.c")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-O1", "-std=gnu11", "-Wall", "-Wextra", "-fPIC", "-shared", src, "-o", so])
+        subprocess.check_call(["gcc", "-O1", "-std=gnu11", "-Wall", "-Wextra", "-fPIC", "-shared", src, "-o", so, "-ldl"])
     return d
 
 

@@ -367,3 +367,39 @@ def test_sharded_run_abandoned_on_the_real_runtime(tools, tmp_path):
     assert p.stdout == ref[2]                                             # the -v report (on stdout when -o names a file) is the reference's
     assert b"".join(open(pat.replace("%r", str(r)), "rb").read() for r in range(4)) == ref[1]
 
+
+
+def test_one_output_file_by_many_strands_on_the_real_engine(tools, tmp_path):
+    """`tool -i in.fq -o out.fq`, no environment that a user would set, on a tmpfs (the gated mapping: fallocate and parallel copies taking turns) and on
+    the test directory's file system (positional writes): the many-strand run (host/fxh_strands.c) writes the bytes of the one-stream loop and prints its
+    report, for forward slices, packed (reverse-complemented) output and the clipper; damaged input abandons the attempt on the real runtime -- contexts
+    destroyed, file emptied, one stream from the top -- with the reference's exit code, message and partial output."""
+    if PARSE_ENV:
+        pytest.skip("the many-strand run is the device text path")
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    text = fo.synth_fastq(2, 0, 400000, 150, False)                       # 128 MB
+    clip_text = fo.synth_fastq(3, 0, 300000, 100, True)
+    import tempfile
+    for where in ([shm] if shm else []) + [str(tmp_path)]:
+        with tempfile.TemporaryDirectory(dir=where) as td:
+            inp = os.path.join(td, "in.fq")
+            for i, (argv, data) in enumerate([(["fastq_quality_trim_filter", "-t", "20", "-l", "30", "-q", "20", "-p", "80", "-v"], text), (["fastx_reverse_complement", "-v"], text),
+                                              (["fastx_clipper", "-a", "AGATCGGAAGAGC", "-l", "15", "-v"], clip_text)]):
+                open(inp, "wb").write(data)
+                single, multi = os.path.join(td, "single%d" % i), os.path.join(td, "multi%d" % i)
+                w = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", inp, "-o", single], b"", env=dict(os.environ, FXH_ONE_FILE="0"))
+                g = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", inp, "-o", multi], b"", env=dict(os.environ, FXH_ONE_FILE_MIN_MB="0", FXH_STRAND_MB="4", FXH_TIMING="1"))
+                assert w[0] == 0 and g[0] == 0, g[2][-500:]
+                assert (b"sink gated mapping" if where == shm else b"sink pwrite") in g[2], g[2][-500:]
+                assert g[1] == w[1] and open(multi, "rb").read() == open(single, "rb").read(), (where, argv)
+                # the rank path with a world of one: arena on the device, the REAL ncclAllGather, drain at offset 0
+                r = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", inp, "-o", multi + ".r"], b"", env=dict(os.environ, FXH_RANK_MODE="1", FXH_STRAND_MB="4", FXH_TIMING="1"))
+                assert r[0] == 0 and b"fxh timing rank 0 of 1" in r[2], r[2][-500:]
+                assert r[1] == w[1] and open(multi + ".r", "rb").read() == open(single, "rb").read(), (where, argv)
+            k0 = text.index(b"\n@", int(len(text) * 0.6)) + 1
+            open(inp, "wb").write(text[:k0] + b"#" + text[k0 + 1:])
+            argv = ["fastq_quality_trim_filter", "-t", "20", "-l", "30", "-q", "20", "-p", "80", "-v"]
+            w = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", inp, "-o", os.path.join(td, "bs")], b"", env=dict(os.environ, FXH_ONE_FILE="0"))
+            g = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", inp, "-o", os.path.join(td, "bm")], b"", env=dict(os.environ, FXH_ONE_FILE_MIN_MB="0", FXH_STRAND_MB="4", FXH_TIMING="1"))
+            assert w[0] == 1 and g[0] == 1 and b"fxh timing one file: abandoned, contexts destroyed, output emptied" in g[2]
+            assert _msg(g[2]) .splitlines()[-1] == _msg(w[2]).splitlines()[-1] and open(os.path.join(td, "bm"), "rb").read() == open(os.path.join(td, "bs"), "rb").read()

@@ -411,7 +411,9 @@ def test_bench_two_ranks_on_one_gpu_via_gloo():
     import sys
     from conftest import ROOT
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, FXG_BENCH_SHARED_GPU="1", FXG_DIST_BACKEND="gloo")
+    import emu_py
+    # (the tool's own rank mode opens RCCL itself; two ranks on this box's ONE GPU are something RCCL refuses, so the test-only transport stands in)
+    env = dict(os.environ, FXG_BENCH_SHARED_GPU="1", FXG_DIST_BACKEND="gloo", FXG_BENCH_FAKE_RCCL=emu_py.build_fake_rccl())
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--reads", "2000000", "--e2e", "--e2e-reads", "500000"]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
@@ -420,7 +422,8 @@ def test_bench_two_ranks_on_one_gpu_via_gloo():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
     assert d["config"]["reads_per_gpu"] == 2000000
-    er = d["e2e_ranks"]                                          # one tool chain per rank on its own shard, barrier to barrier
+    er = d["e2e_ranks"]                                          # the tool's rank mode: one input, one output, two processes, barrier to barrier
+    assert "rank mode" in er["mode"], er
     assert er["ranks"] == 2 and er["reads_per_rank"] == 500000 and 0 < er["kept_reads"] < 1000000 and er["mreads_s"] > 0, er
     # the same million reads through ONE rank: the job's kept reads and the md5 of its output (the ranks' outputs in rank order) must not
     # depend on how many ranks shared the work

@@ -592,6 +592,12 @@ def test_one_output_file_written_by_many_strands(tools, tmp_path, sink):
     assert p.returncode == 0 and b"fxh timing one file (3 strands" in p.stderr and (tmp_path / "stdin.fq").read_bytes() == single
     g = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-o", str(tmp_path / "pipe1.fq")], text, extra_env=_one_file_env(sink))
     assert g[0] == 0 and b"fxh timing one file" not in g[2] and (tmp_path / "pipe1.fq").read_bytes() == single
+    # the rank path with a world of one (what the GPU tier runs against the real RCCL): arena, one all-gather over the fake library, drain at offset 0
+    import emu_py
+    out = tmp_path / "rank_mode_world1.fq"
+    g = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", str(out)], b"",
+             extra_env=dict(_one_file_env(sink), FXH_RANK_MODE="1", LD_LIBRARY_PATH=STUB_DIR + os.pathsep + emu_py.build_fake_rccl()))
+    assert g[0] == 0 and b"fxh timing rank 0 of 1" in g[2] and out.read_bytes() == single, g[2][-300:]
     # one strand, many strands, chunks of 64 KB (800 of them) and of 5 MB (three); more strands than chunks
     for kb, strands in (("64", "1"), ("64", "8"), ("5120", "4"), ("7000", "16")):
         out = tmp_path / ("o_%s_%s.fq" % (kb, strands))
@@ -645,3 +651,78 @@ def test_one_output_file_attempt_abandoned_on_irregular_input(tools, tmp_path, s
     w = _run([os.path.join(tools, "fastq_quality_trimmer"), "-t", "20", "-l", "5", "-i", str(inp), "-o", str(tmp_path / "t_single.fq")], b"", buf_mb="1", extra_env={"FXH_ONE_FILE": "0"})
     g = _run([os.path.join(tools, "fastq_quality_trimmer"), "-t", "20", "-l", "5", "-i", str(inp), "-o", str(tmp_path / "t.fq")], b"", buf_mb="1", extra_env=_one_file_env(sink, kb="100"))
     assert w[0] == 0 and g[0] == 0 and (tmp_path / "t.fq").read_bytes() == (tmp_path / "t_single.fq").read_bytes()
+
+
+def _rank_job(tools, argv, inp, out, world, tmp_path, extra=None, delays=None):
+    """One process per rank, the SAME command line, FXH_RANK / FXH_WORLD in the environment (what mpirun, srun or a shell loop would start)."""
+    import emu_py
+    fake = emu_py.build_fake_rccl()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, LD_LIBRARY_PATH=STUB_DIR + os.pathsep + fake, FXH_THREADS="2", FXH_RANK=str(r), FXH_WORLD=str(world), FXH_TIMING="1", FXH_STRAND_KB="256",
+                   FXH_STRANDS="2", FXH_DRAIN_MB="1", FXG_EMU_DEVICES="2")
+        env.update(extra or {})
+        cmd = [os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", str(out)]
+        if delays and r in delays:
+            cmd = ["sh", "-c", "sleep %s; exec \"$@\"" % delays[r], "sh"] + cmd
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env))
+    res = []
+    for p in procs:
+        o, e = p.communicate(timeout=180)
+        res.append((p.returncode, o, e))
+    return res
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_rank_per_gpu_job_writes_the_one_file_and_rank0_reports(tools, tmp_path, world):
+    """north_star's multi-GPU form at the level users run (round-4 verdict item 2): `world` processes, one per GPU, the same command line each; rank g takes byte
+    range g of the input (cut at record starts), keeps its formatted text on its device, the ranks exchange their counter blocks in ONE all-gather
+    (the product's fxg_comm_create / fxg_epilogue_rccl, here over tests/emu/fake_rccl.c) and every rank writes its slice of the ONE output file at the
+    sum of the bytes of the ranks before it; rank 0 prints the -v report of the whole job.  Bytes and report equal the single-process run's."""
+    text = fo.synth_fastq(47, 0, 40000, 100, False)
+    clip_text = fo.synth_fastq(3, 0, 20000, 100, True)
+    inp = tmp_path / "in.fq"
+    for i, (argv, data) in enumerate([(["fastq_quality_trim_filter", "-t", "20", "-l", "30", "-q", "20", "-p", "80", "-v"], text),
+                                      (["fastx_reverse_complement", "-v"], text),
+                                      (["fastx_clipper", "-a", "AGATCGGAAGAGC", "-l", "15", "-v"], clip_text)]):
+        inp.write_bytes(data)
+        single, multi = tmp_path / ("single%d" % i), tmp_path / ("ranks%d" % i)
+        want = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", str(single)], b"", extra_env={"FXH_ONE_FILE": "0"})
+        multi.write_bytes(b"stale bytes of an earlier run, longer than nothing\n" * 3)
+        res = _rank_job(tools, argv, inp, multi, world, tmp_path, delays={0: 0.3} if i == 1 else None)      # (once with a late rank 0: the others wait at the rendezvous)
+        assert want[0] == 0 and all(rc == 0 for rc, _, _ in res), [e[-300:] for _, _, e in res]
+        assert multi.read_bytes() == single.read_bytes(), (argv, world)
+        assert res[0][1] == want[1] and all(o == b"" for _, o, _ in res[1:])          # the job's report, from rank 0 alone
+        lines = [l for _, _, e in res for l in e.decode().splitlines() if l.startswith("fxh timing rank ")]
+        assert len(lines) == world
+        spans = sorted((int(l.split("[")[1].split(",")[0]), int(l.split(", ")[1].split(")")[0])) for l in lines)
+        assert spans[0][0] == 0 and spans[-1][1] == len(data) and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))      # the ranges tile the input
+        assert not os.path.exists(str(multi) + ".rdv")
+    # irregular input in one rank's range: EVERY rank leaves (flag in the exchanged block), rank 0 runs the input as one stream -> the reference's behaviour
+    k0 = text.index(b"\n@", int(len(text) * 0.7)) + 1
+    bad = text[:k0] + b"#" + text[k0 + 1:]
+    inp.write_bytes(bad)
+    argv = ["fastq_quality_trim_filter", "-t", "20", "-l", "30", "-q", "20", "-p", "80", "-v"]
+    w = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", str(tmp_path / "bad_single.fq")], b"", extra_env={"FXH_ONE_FILE": "0"})
+    res = _rank_job(tools, argv, inp, tmp_path / "bad_ranks.fq", world, tmp_path)
+    assert w[0] == 1 and res[0][0] == 1 and all(rc == 0 for rc, _, _ in res[1:]), [e[-300:] for _, _, e in res]
+    assert _msg(res[0][2].splitlines()[-1]) == _msg(w[2].splitlines()[-1])
+    assert (tmp_path / "bad_ranks.fq").read_bytes() == (tmp_path / "bad_single.fq").read_bytes()
+    # the clipper on reads that are not all of one length: the same way out, and the one-stream run goes serial where it must
+    lines = clip_text.split(b"\n")[:-1]
+    for i in range(len(lines) // 4 * 6 // 10 * 4, len(lines), 8):
+        lines[i + 1] = lines[i + 1][:61]; lines[i + 3] = lines[i + 3][:61]
+    data = b"\n".join(lines) + b"\n"
+    inp.write_bytes(data)
+    cargv = ["fastx_clipper", "-a", "AGATCGGAAGAGC", "-l", "15", "-v"]
+    res = _rank_job(tools, cargv, inp, tmp_path / "clip_ranks.fq", world, tmp_path)
+    assert all(rc == 0 for rc, _, _ in res), [e[-300:] for _, _, e in res]
+    if REF:
+        ref = _run([REF] + cargv, data)
+        assert res[0][1] == ref[2] and (tmp_path / "clip_ranks.fq").read_bytes() == ref[1]
+    # an input no rank mode takes (a pipe): rank 0 does the job, the others step aside without touching the file
+    env = dict(os.environ, LD_LIBRARY_PATH=STUB_DIR, FXH_THREADS="2", FXH_WORLD=str(world))
+    outp = tmp_path / "pipe_ranks.fq"
+    ps = [subprocess.Popen([os.path.join(tools, argv[0])] + argv[1:] + ["-o", str(outp)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(env, FXH_RANK=str(r))) for r in range(world)]
+    outs = [p.communicate(text, timeout=120) for p in ps]
+    assert all(p.returncode == 0 for p in ps) and outp.read_bytes() == (tmp_path / "single0").read_bytes() and all(o == b"" for o, _ in outs[1:])
