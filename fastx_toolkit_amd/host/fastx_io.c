@@ -21,6 +21,7 @@
 #include <string.h>
 #include <sys/stat.h>
 #include <sys/types.h>
+#include <sys/uio.h>
 #include <sys/wait.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -28,6 +29,24 @@
 /* ---------------------------------------------------------------------------------------------- */
 /* reader                                                                                         */
 /* ---------------------------------------------------------------------------------------------- */
+/* Pipes as the reference's users run them (`trimmer | filter`, `cat in | tool > out`): the default capacity of a Linux pipe is 64 KB -- sixteen
+ * pages per wake-up of the other side.  A FIFO end is raised to the system's limit (/proc/sys/fs/pipe-max-size, 1 MB unless the administrator
+ * changed it; less if that is refused). */
+size_t fxh_tune_pipe(int fd)
+{
+    struct stat sb;
+    if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISFIFO(sb.st_mode)) return 0;
+    if (!getenv("FXH_NO_PIPE_TUNING")) {
+        long want = 1 << 20;
+        FILE *f = fopen("/proc/sys/fs/pipe-max-size", "r");
+        if (f) { long v; if (fscanf(f, "%ld", &v) == 1 && v >= 4096) want = v; fclose(f); }
+        if (want > (64L << 20)) want = 64L << 20;
+        for (; want >= (128 << 10); want >>= 1) if (fcntl(fd, F_SETPIPE_SZ, (int)want) >= 0) break;      /* (EPERM above the limit of an unprivileged user, EBUSY: take less) */
+    }
+    const int have = fcntl(fd, F_GETPIPE_SZ);
+    return have > 0 ? (size_t)have : 65536u;
+}
+
 struct fxh_reader *fxh_reader_open(const char *filename, size_t capacity)
 {
     struct fxh_reader *r = (struct fxh_reader *)calloc(1, sizeof *r);
@@ -37,6 +56,7 @@ struct fxh_reader *fxh_reader_open(const char *filename, size_t capacity)
         r->fd = open(filename, O_RDONLY);
         if (r->fd < 0) err(1, "failed to open input file '%s'", filename);
     }
+    (void)fxh_tune_pipe(r->fd);                 /* `cat in.fq | tool` (the Galaxy wrappers): a megabyte per wake-up instead of 64 KB */
     r->cap = capacity ? capacity : (4u << 20);
     r->buf = (char *)malloc(r->cap + 1);
     if (!r->buf) err(1, "out of memory");
@@ -381,9 +401,32 @@ static void fxh_pwrite_all(int fd, const char *buf, size_t n, off_t off)
     }
 }
 
+/* A buffer into a pipe.  write() copies every byte into the pipe's pages; vmsplice() hands the pipe the buffer's own pages instead -- but then those
+ * pages belong to the pipe until the reader has taken them, and the buffers here are used again.  So the front of the buffer is spliced and its LAST
+ * pipe-capacity bytes are written the ordinary way: a pipe holds at most its capacity, so once that write() has returned everything still inside it is
+ * copied tail, and no page of the buffer is referenced any more.  (`trimmer | filter` on 16 M reads: bench.py e2e.pipe.) */
+static void fxh_pipe_write_all(int fd, const char *buf, size_t n, size_t pipe_size)
+{
+    size_t off = 0;
+    const size_t front = (n > 2 * pipe_size && !getenv("FXH_NO_VMSPLICE")) ? n - pipe_size : 0;
+    while (off < front) {
+        struct iovec iov;
+        iov.iov_base = (void *)(uintptr_t)(buf + off); iov.iov_len = front - off;
+        const ssize_t k = vmsplice(fd, &iov, 1, 0);
+        if (k < 0) { if (errno == EINTR) continue; if (errno == EPIPE) err(1, "writing output failed"); break; }      /* (not spliceable after all: write the rest) */
+        off += (size_t)k;
+    }
+    fxh_write_all(fd, buf + off, n - off);
+}
+
 void fxh_writer_emit(struct fxh_writer *w, const char *buf, size_t n)
 {
-    if (!w->gz) { if (w->positional) { fxh_pwrite_all(w->fd, buf, n, w->off); w->off += (off_t)n; } else fxh_write_all(w->fd, buf, n); return; }
+    if (!w->gz) {
+        if (w->positional) { fxh_pwrite_all(w->fd, buf, n, w->off); w->off += (off_t)n; }
+        else if (w->pipe_size) fxh_pipe_write_all(w->fd, buf, n, w->pipe_size);
+        else fxh_write_all(w->fd, buf, n);
+        return;
+    }
     if (n == 0) return;
     struct fxh_gz_job job;
     job.in = buf; job.n = n; job.nchunks = (n + FXH_GZ_CHUNK - 1) / FXH_GZ_CHUNK;
@@ -478,6 +521,7 @@ static struct fxh_writer *fxh_writer_from_fd(int fd, int gzip)
         const int fl = fcntl(w->fd, F_GETFL);
         w->positional = (!w->gz && pos >= 0 && fl >= 0 && !(fl & O_APPEND) && fstat(w->fd, &sb) == 0 && S_ISREG(sb.st_mode)) ? 1 : 0;
         w->off = pos;
+        w->pipe_size = fxh_tune_pipe(w->fd);
     }
     static int registered;
     if (!registered) { atexit(fxh_flush_all); registered = 1; }

@@ -563,7 +563,12 @@ int fxh_run_impl(FASTX *fx, const fxg_params *p, fxh_totals *tot, fxh_stats_run 
     struct fxh_reader *rd = fx->reader;
     /* one engine call per 64 MB of text; the parts of a sharded run take 8 MB blocks (four parts x two lanes keep the link busy with
      * less to allocate, page-lock and touch first: 52 -> 62 Mreads/s on the 64 M read sample, profiles/r03/p_e2e_parts_block_size.txt) */
-    if (!getenv("FXH_READ_BUFFER_MB")) fxh_reader_reserve(rd, (size_t)(nparts > 1 ? 8 : 64) << 20);
+    /* (a pipe: 16 MB -- the process downstream of another tool should start on its first block while the rest is still being produced) */
+    if (!getenv("FXH_READ_BUFFER_MB")) {
+        struct stat isb;
+        const int fifo = fstat(rd->fd, &isb) == 0 && S_ISFIFO(isb.st_mode);
+        fxh_reader_reserve(rd, (size_t)(nparts > 1 ? 8 : fifo ? 16 : 64) << 20);
+    }
     fxh_job *job = &R.job;
     job->fx = fx; job->st = &R.st; job->p = p;
     job->revcomp = (p->stages & (FXG_STAGE_REVCOMP | FXG_STAGE_MASK)) != 0;   /* stages whose output is not a slice of the input text */

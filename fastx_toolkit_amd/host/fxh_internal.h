@@ -22,6 +22,7 @@ struct fxh_writer {
     unsigned long gz_members;
     int positional;         /* plain output to a regular file: positional writes from `off` on */
     off_t off;
+    size_t pipe_size;       /* > 0: the output is a pipe of this capacity (enlarged to the system's limit when the writer was opened) */
 };
 
 /* one record as slices of the reader's buffer (valid until the next fill) */
@@ -52,4 +53,5 @@ void   fxh_writer_flush(struct fxh_writer *w);
 void   fxh_writer_emit(struct fxh_writer *w, const char *buf, size_t n);   /* raw bytes to the file, or gzip members when w->gz */
 char  *fxh_writer_reserve(struct fxh_writer *w, size_t n);
 void   fxh_writer_close(struct fxh_writer *w);
+size_t fxh_tune_pipe(int fd);       /* a FIFO: capacity raised to /proc/sys/fs/pipe-max-size where allowed; returns the capacity, 0 = not a pipe */
 #endif

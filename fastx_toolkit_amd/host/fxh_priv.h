@@ -165,6 +165,7 @@ typedef struct fxh_lane {
     int clip_guard;                        /* clipper run in its parallel phase (fxh_run.clip_auto): a block whose reads are not all of one length is handed back untouched */
     uint32_t fixed_len;                    /* result: the one length of the block's reads, 0 = they differ (or the block was not indexed) */
     int slot;                              /* which of out[] receives the text (the other may still be with the writer) */
+    int out_plain;                         /* out[] are ordinary page-locked pages (malloc + register) instead of the runtime's host allocations: the output is a pipe (vmsplice) */
     int handled;                           /* result: 0 = irregular block, parse it on the host */
     char *out[FXH_LANE_OUT_SLOTS]; size_t out_cap[FXH_LANE_OUT_SLOTS]; size_t out_len;      /* (the lanes loop uses two, the strands of the one-file run more) */
     uint64_t ctr[FXG_NCOUNTERS];

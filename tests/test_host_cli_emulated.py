@@ -726,3 +726,40 @@ def test_rank_per_gpu_job_writes_the_one_file_and_rank0_reports(tools, tmp_path,
     ps = [subprocess.Popen([os.path.join(tools, argv[0])] + argv[1:] + ["-o", str(outp)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(env, FXH_RANK=str(r))) for r in range(world)]
     outs = [p.communicate(text, timeout=120) for p in ps]
     assert all(p.returncode == 0 for p in ps) and outp.read_bytes() == (tmp_path / "single0").read_bytes() and all(o == b"" for o, _ in outs[1:])
+
+
+def test_pipes_as_the_references_users_run_them(tools, tmp_path):
+    """`trimmer | filter` and `cat in | tool > out` (the Galaxy wrappers' form): both ends of a pipe are raised to the system's limit (F_SETPIPE_SZ), blocks go into
+    the pipe by vmsplice() except for their last pipe-capacity bytes (so that no page of a buffer is still in the pipe when the buffer is used again), the
+    reader takes what a pipe holds per wake-up.  Same bytes with the default 64 KB pipe, without vmsplice, with tiny and with large blocks; a reader that
+    stops early (head) ends the writer like any tool."""
+    text = fo.synth_fastq(47, 0, 60000, 100, False)
+    inp = tmp_path / "in.fq"
+    inp.write_bytes(text)
+    t1 = [os.path.join(tools, "fastq_quality_trimmer"), "-t", "20", "-l", "30"]
+    t2 = [os.path.join(tools, "fastq_quality_filter"), "-q", "20", "-p", "80", "-v"]
+    ref = _run(t2, _run(t1, text)[1])
+    assert ref[0] == 0 and len(ref[1]) > 1_000_000
+    base = dict(os.environ, LD_LIBRARY_PATH=STUB_DIR, FXH_THREADS="2")
+    for extra in ({}, {"FXH_NO_PIPE_TUNING": "1"}, {"FXH_NO_VMSPLICE": "1"}, {"FXH_READ_BUFFER_MB": "1"}, {"FXH_READ_BUFFER_MB": "1", "FXH_NO_PIPE_TUNING": "1"}, {"FXH_HOST_PARSE": "1"}):
+        env = dict(base, **extra)
+        out = tmp_path / "piped.fq"
+        p1 = subprocess.Popen(t1 + ["-i", str(inp)], stdout=subprocess.PIPE, env=env)
+        p2 = subprocess.Popen(t2 + ["-o", str(out)], stdin=p1.stdout, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        p1.stdout.close()
+        o, e = p2.communicate(timeout=120)
+        assert p1.wait() == 0 and p2.returncode == 0, e[-300:]
+        assert out.read_bytes() == ref[1] and o == ref[2], extra              # (-v goes to stdout when -o names a file)
+        # cat in | tool > out
+        with open(inp, "rb") as f, open(tmp_path / "redir.fq", "wb") as g:
+            c = subprocess.Popen(["cat"], stdin=f, stdout=subprocess.PIPE)
+            p = subprocess.Popen(t1, stdin=c.stdout, stdout=g, env=env)
+            c.stdout.close()
+            assert p.wait(timeout=120) == 0 and c.wait() == 0
+        assert (tmp_path / "redir.fq").read_bytes() == _run(t1, text)[1]
+    # the downstream side stops reading: the tool dies of SIGPIPE (or reports the failed write), it does not hang
+    p1 = subprocess.Popen(t1 + ["-i", str(inp)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=base)
+    h = subprocess.Popen(["head", "-c", "100000"], stdin=p1.stdout, stdout=subprocess.PIPE)
+    p1.stdout.close()
+    got = h.communicate(timeout=60)[0]
+    assert got == _run(t1, text)[1][:100000] and p1.wait(timeout=60) != 0
