@@ -15,6 +15,7 @@
 #include "fxg_history.h"
 #include "fxg_stats.h"
 #include "fxg_rows.h"
+#include "fxg_fallback.h"
 
 struct fxg_ctx {
     int device;
@@ -58,6 +59,11 @@ struct fxg_ctx {
     char err[512];
     char last_kernel[96];
     u32 last_grid, last_block, last_lds, last_tile;
+    // the last compacting launch, kept so that it can be done again without the scanner when its waits timed out (fxg_fallback.h)
+    struct { const void *fn; FxgKArgs ka; u32 lds, block, workers; u64 *counters; int valid, rev, mask; } fb;
+    u64 *fb_blk; size_t fb_blk_cap;     // block sums / prefixes of the fallback
+    int recoveries;                     // launches redone that way since the context was made (fxg_scan_recoveries)
+    int test_force_timeout;             // FXG_TEST_SCAN_TIMEOUT=1: every compacting launch starts with the time-out flag up (GPU tier)
 };
 
 static int fxg_fail(fxg_ctx *ctx, int code, const char *fmt, ...)
@@ -97,6 +103,7 @@ extern "C" int fxg_ctx_create(int device_id, fxg_ctx **out)
     { const char *e = getenv("FXG_BLOCKS_PER_CU"); c->env_blocks_per_cu = (e && atoi(e) > 0 && atoi(e) <= 16) ? atoi(e) : 0; }
     { const char *e = getenv("FXG_WORKERS"); c->env_workers = (e && atoi(e) > 0) ? atoi(e) : 0; }
     { const char *e = getenv("FXG_NSCAN"); c->env_nscan = (e && atoi(e) > 0 && atoi(e) <= 64) ? atoi(e) : 0; }
+    { const char *e = getenv("FXG_TEST_SCAN_TIMEOUT"); c->test_force_timeout = (e && atoi(e) > 0) ? 1 : 0; }
     { const char *e = getenv("FXG_TICKET_GROUPS"); c->env_ticket_groups = (e && atoi(e) > 0 && atoi(e) <= FXG_TICKET_GROUPS) ? atoi(e) : 0; }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipMalloc((void **)&c->errflag, (FXG_CTRL_WORDS + FXG_TICKET_GROUPS * FXG_TICKET_STRIDE) * sizeof(u32)) != hipSuccess ||
@@ -114,7 +121,7 @@ extern "C" void fxg_ctx_destroy(fxg_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->status); (void)hipFree(c->errflag); (void)hipFree(c->counters_scratch);
-    (void)hipFree(c->text_ws); (void)hipFree(c->text_state);
+    (void)hipFree(c->text_ws); (void)hipFree(c->text_state); (void)hipFree(c->fb_blk);
     (void)hipFree(c->hist_buf[0]); (void)hipFree(c->hist_buf[1]); (void)hipFree(c->hist_w); (void)hipFree(c->hist_ws); (void)hipFree(c->stats_ws); (void)hipFree(c->clip_ck);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     for (int i = 0; i < FXG_KEV_RING; ++i) { if (c->kev0[i]) (void)hipEventDestroy(c->kev0[i]); if (c->kev1[i]) (void)hipEventDestroy(c->kev1[i]); }
@@ -296,6 +303,15 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
     // falls to its members: eight groups only when each has more workgroups than there are scanners.
     { u32 g = c->env_ticket_groups > 0 ? (u32)c->env_ticket_groups : FXG_TICKET_GROUPS; ka.ticket_groups = grid >= (u64)(ka.nscan + 1u) * g ? g : 1u; }
     FXG_HIP(c, hipMemsetAsync(c->errflag, 0, (FXG_CTRL_WORDS + FXG_TICKET_GROUPS * FXG_TICKET_STRIDE) * sizeof(u32), c->stream));
+    c->fb.valid = 0;
+    if (ka.compact) {                            // what fxg_read_counters needs to do this launch again should its waits time out
+        c->fb.fn = (const void *)kernel; c->fb.ka = ka; c->fb.lds = lds; c->fb.block = block; c->fb.workers = (u32)workers; c->fb.counters = counters; c->fb.valid = 1;
+        c->fb.rev = (ka.stages & FXG_STAGE_REVCOMP) != 0; c->fb.mask = (ka.stages & FXG_STAGE_MASK) != 0;
+        if (c->test_force_timeout) {             // "somebody already gave up": every wait of this launch that lasts ends without a result
+            static const u32 up = FXG_DEV_ERR_SCAN_TIMEOUT;
+            FXG_HIP(c, hipMemcpyAsync(c->errflag, &up, sizeof up, hipMemcpyHostToDevice, c->stream));
+        }
+    }
 
     if (c->profiling) FXG_HIP(c, hipEventRecord(c->kev0[c->kev_count % FXG_KEV_RING], c->stream));
     hipLaunchKernelGGL(kernel, dim3((u32)grid), dim3(block), lds, c->stream, ka);
@@ -439,12 +455,16 @@ extern "C" int fxg_run_pipeline(fxg_ctx *c, const fxg_batch *in, const fxg_param
         case -36: return fxg_launch_tiles(c, FXG_TILES_C(-36), "fxg_kernel_tiles<-36,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case -40: return fxg_launch_tiles(c, FXG_TILES_C(-40), "fxg_kernel_tiles<-40,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case -48: return fxg_launch_tiles(c, FXG_TILES_C(-48), "fxg_kernel_tiles<-48,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -56: return fxg_launch_tiles(c, FXG_TILES_C(-56), "fxg_kernel_tiles<-56,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case -64: return fxg_launch_tiles(c, FXG_TILES_C(-64), "fxg_kernel_tiles<-64,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -80: return fxg_launch_tiles(c, FXG_TILES_C(-80), "fxg_kernel_tiles<-80,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case -316: return fxg_launch_tiles(c, FXG_TILES_C(-316), "fxg_kernel_tiles<-316,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case -324: return fxg_launch_tiles(c, FXG_TILES_C(-324), "fxg_kernel_tiles<-324,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case -336: return fxg_launch_tiles(c, FXG_TILES_C(-336), "fxg_kernel_tiles<-336,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case -348: return fxg_launch_tiles(c, FXG_TILES_C(-348), "fxg_kernel_tiles<-348,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -356: return fxg_launch_tiles(c, FXG_TILES_C(-356), "fxg_kernel_tiles<-356,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case -364: return fxg_launch_tiles(c, FXG_TILES_C(-364), "fxg_kernel_tiles<-364,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
+        case -380: return fxg_launch_tiles(c, FXG_TILES_C(-380), "fxg_kernel_tiles<-380,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case -400: return fxg_launch_tiles(c, FXG_TILES_C(-400), "fxg_kernel_tiles<-400,0> clip(packed, N in the adapter)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
 #ifdef FXG_CLIP_ONE_PASS     // (ablation build only: reads beyond 255 bases with a short adapter; the regular build's register form takes them)
         case -216: return fxg_launch_tiles(c, FXG_TILES_C(-216), "fxg_kernel_tiles<-216,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
@@ -549,12 +569,59 @@ extern "C" int fxg_run_revcomp_trim(fxg_ctx *c, const fxg_batch *in, int reverse
     return fxg_run_pipeline(c, in, &p, out);
 }
 
+// The last compacting launch once more, in the form that cannot wait (fxg_fallback.h).  Everything goes behind the failed launch on the same stream.
+static int fxg_redo_without_scanner(fxg_ctx *c)
+{
+    FxgFbArgs f;
+    f.ka = c->fb.ka;
+    f.ka.compact = 0u; f.ka.nscan = 0u;
+    { const u32 g = c->env_ticket_groups > 0 ? (u32)c->env_ticket_groups : FXG_TICKET_GROUPS; f.ka.ticket_groups = c->fb.workers >= g ? g : 1u; }
+    FXG_HIP(c, hipSetDevice(c->device));
+    FXG_HIP(c, hipMemsetAsync(c->errflag, 0, (FXG_CTRL_WORDS + FXG_TICKET_GROUPS * FXG_TICKET_STRIDE) * sizeof(u32), c->stream));
+    FxgKArgs ka = f.ka;
+    void *args[] = {&ka};
+    FXG_HIP(c, hipLaunchKernel(c->fb.fn, dim3(c->fb.workers), dim3(c->fb.block), args, c->fb.lds, c->stream));      // 1. decisions: res[], tallies
+    f.nblk = (u32)((f.ka.n + FXG_FB_BLOCK - 1u) / FXG_FB_BLOCK);
+    const size_t need = 2 * (size_t)f.nblk + 2;
+    if (c->fb_blk_cap < need) {
+        (void)hipFree(c->fb_blk);
+        c->fb_blk = nullptr; c->fb_blk_cap = 0;
+        FXG_HIP(c, hipMalloc((void **)&c->fb_blk, need * sizeof(u64)));
+        c->fb_blk_cap = need;
+    }
+    f.blk = c->fb_blk;
+    f.ka.compact = 1u;                                                                                                  // (the tallies of kept reads / bytes come from the decisions either way)
+    hipLaunchKernelGGL(fxg_kernel_fb_sums, dim3(f.nblk), dim3(FXG_FB_BLOCK), 0, c->stream, f);                          // 2. block sums -> prefixes
+    FXG_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(fxg_kernel_fb_scan, dim3(1), dim3(FXG_FB_BLOCK), 0, c->stream, f);
+    FXG_HIP(c, hipGetLastError());
+    if (c->fb.rev) hipLaunchKernelGGL((fxg_kernel_fb_gather<true, false>), dim3(f.nblk), dim3(FXG_FB_BLOCK), 0, c->stream, f);      // 3. every read to its place
+    else if (c->fb.mask) hipLaunchKernelGGL((fxg_kernel_fb_gather<false, true>), dim3(f.nblk), dim3(FXG_FB_BLOCK), 0, c->stream, f);
+    else hipLaunchKernelGGL((fxg_kernel_fb_gather<false, false>), dim3(f.nblk), dim3(FXG_FB_BLOCK), 0, c->stream, f);
+    FXG_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(fxg_kernel_finish_counters, dim3(1), dim3(64), 0, c->stream, (const u64 *)f.ka.tally, f.ka.stages, (const u32 *)c->errflag,
+                       (const u64 *)(c->errflag + 2), c->fb.counters ? c->fb.counters : c->counters_scratch);
+    FXG_HIP(c, hipGetLastError());
+    c->recoveries++;
+    return FXG_OK;
+}
+
+extern "C" int fxg_scan_recoveries(const fxg_ctx *c) { return c ? c->recoveries : 0; }
+
 extern "C" int fxg_read_counters(fxg_ctx *c, const uint64_t *d_counters, uint64_t host[FXG_NCOUNTERS])
 {
     if (!c || !host) return FXG_E_INVALID;
     const u64 *src = d_counters ? (const u64 *)d_counters : c->counters_scratch;
     FXG_HIP(c, hipMemcpyAsync(host, src, FXG_NCOUNTERS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     FXG_HIP(c, hipStreamSynchronize(c->stream));
+    if ((host[FXG_C_ERRORS] & FXG_DEV_ERR_SCAN_TIMEOUT) && c->fb.valid && src == (c->fb.counters ? c->fb.counters : c->counters_scratch) && !getenv("FXG_NO_SCAN_FALLBACK")) {
+        // the launch these counters belong to gave up waiting (its workgroups were not being scheduled): the same work again without anything that waits
+        c->fb.valid = 0;
+        const int rc = fxg_redo_without_scanner(c);
+        if (rc != FXG_OK) return rc;
+        FXG_HIP(c, hipMemcpyAsync(host, src, FXG_NCOUNTERS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        FXG_HIP(c, hipStreamSynchronize(c->stream));
+    }
     if (host[FXG_C_ERRORS] & FXG_DEV_ERR_SCAN_TIMEOUT) return fxg_fail(c, FXG_E_DEVICE, "device: look-back scan timed out");
     if (host[FXG_C_ERRORS] & FXG_DEV_ERR_BAD_BASE)
         return fxg_fail(c, FXG_E_DEVICE, "Invalid nucleotide value in reverse_complement_base()");   // fastx_reverse_complement.c:67-68

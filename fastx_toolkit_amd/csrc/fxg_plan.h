@@ -120,8 +120,10 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     ka.clip_ck = nullptr;
     ka.clip_ck_rows = (ka.clip_stride + 7u) / 8u < 4u ? 4u : (ka.clip_stride + 7u) / 8u;      // (rows - 1) / clip_ck_rows <= FXG_CK_SLOTS
     if (pl->clip && (ka.clip_stride <= 255u || two_pass_k || (!kform && reg_any_len)) && !getenv("FXG_NO_PACKED_CLIP")) {
-        static const int pk[] = {4, 8, 9, 10, 11, 12, 13, 14, 15, 16, 20, 24, 28, 32, 36, 40, 48, 64, 100};      // 36: the 33/34-base TruSeq adapters
-        static const int pn[] = {16, 24, 36, 48, 64, 100};
+        // 36: the 33/34-base TruSeq adapters; 56 and 80 (round 5): 49..56 columns no longer pay for 64 (17.4 -> 27.7 ms between 48 and 49 bases,
+        // profiles/r04/p_clip_waves_by_adapter_len.txt) and 65..80 no longer for 100
+        static const int pk[] = {4, 8, 9, 10, 11, 12, 13, 14, 15, 16, 20, 24, 28, 32, 36, 40, 48, 56, 64, 80, 100};
+        static const int pn[] = {16, 24, 36, 48, 56, 64, 80, 100};
         int b = 100;
         if (ka.adapter_has_n) { for (unsigned i = 0; i < sizeof pn / sizeof pn[0]; ++i) if (ka.alen <= pn[i]) { b = pn[i]; break; } }
         else { for (unsigned i = 0; i < sizeof pk / sizeof pk[0]; ++i) if (ka.alen <= pk[i]) { b = pk[i]; break; } }

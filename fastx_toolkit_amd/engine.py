@@ -22,7 +22,7 @@ EXPORTS = [
     "fxg_abi_version", "fxg_ctx_create", "fxg_ctx_destroy", "fxg_last_error", "fxg_set_stream", "fxg_sync",
     "fxg_device_info", "fxg_malloc_device", "fxg_free_device", "fxg_malloc_host", "fxg_free_host", "fxg_memcpy_h2d",
     "fxg_memcpy_d2h", "fxg_memset_device", "fxg_timer_start", "fxg_timer_stop", "fxg_run_pipeline",
-    "fxg_run_qtrim_qfilter", "fxg_run_clip", "fxg_run_revcomp_trim", "fxg_read_counters", "fxg_synth_generate",
+    "fxg_run_qtrim_qfilter", "fxg_run_clip", "fxg_run_revcomp_trim", "fxg_read_counters", "fxg_scan_recoveries", "fxg_synth_generate",
     "fxg_last_launch_info", "fxg_set_profiling", "fxg_last_kernel_ms", "fxg_profiled_kernel_ms", "fxg_set_clip_history", "fxg_run_quality_stats",
     "fxg_fastq_index", "fxg_fastq_pack", "fxg_fastq_format", "fxg_fasta_weights", "fxg_host_register", "fxg_host_unregister",
     "fxg_shard_range", "fxg_epilogue", "fxg_concat_pwrite", "fxg_concat_peer", "fxg_device_count", "fxg_device_numa_node", "fxg_comm_create", "fxg_comm_destroy", "fxg_epilogue_rccl",
@@ -113,6 +113,7 @@ def load_library(path=None):
     L.fxg_run_clip.argtypes = [vp, C.POINTER(FxgBatch), C.c_char_p, u32, i32, i32, u32, C.POINTER(FxgOut)]
     L.fxg_run_revcomp_trim.argtypes = [vp, C.POINTER(FxgBatch), i32, i32, i32, C.POINTER(FxgOut)]
     L.fxg_read_counters.argtypes = [vp, vp, C.POINTER(u64 * NCOUNTERS)]
+    L.fxg_scan_recoveries.argtypes = [vp]
     L.fxg_synth_generate.argtypes = [vp, u64, u64, u64, u32, i32, vp, vp, u32]
     L.fxg_last_launch_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.fxg_fastq_index.argtypes = [vp, vp, u64, i32, i32, vp, u64, vp, vp, C.POINTER(FxgTextInfo)]
@@ -280,6 +281,10 @@ class Engine:
         name = C.create_string_buffer(128)
         self._check(self.lib.fxg_device_info(self.ctx, C.byref(cus), C.byref(mem), name, 128))
         return dict(compute_units=cus.value, total_mem=mem.value, name=name.value.decode())
+
+    def scan_recoveries(self):
+        """Compacting launches of this context whose waits ran out and that were done again without the scanner (include/fxg.h)."""
+        return int(self.lib.fxg_scan_recoveries(self.ctx))
 
     def last_launch(self):
         name = C.create_string_buffer(128)

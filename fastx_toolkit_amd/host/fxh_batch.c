@@ -458,6 +458,7 @@ static int fxh_host_engine(fxh_run *R, fxh_hb *hb)
         if (rc == FXG_E_DEVICE && (ctr[FXG_C_ERRORS] & FXG_DEV_ERR_BAD_BASE)) errx(1, "%s", fxg_last_error(st->ctx));
         if (rc != 0) errx(1, "GPU engine error %d: %s", rc, fxg_last_error(st->ctx));
     }
+    fxh_note_recoveries(st);
     tot->masked_reads += ctr[FXG_C_MASKED_READS]; tot->masked_nucleotides += ctr[FXG_C_MASKED_NT];
     if (job->revcomp) {
         FXG_CHECK(st, fxg_memcpy_d2h(st->ctx, st->h_out_bases, st->d_out_bases, ctr[FXG_C_KEPT_BASES]));

@@ -16,6 +16,19 @@ pthread_mutex_t g_first_ctx_mu = PTHREAD_MUTEX_INITIALIZER;
 static int g_first_ctx_done;
 int g_hip_touched;
 
+/* A launch whose waits ran out is done again by the engine in a form that cannot wait (include/fxg.h: fxg_scan_recoveries): the run goes on, the user is
+ * told once -- it means the GPU was not scheduling this process's work for seconds at a time */
+void fxh_note_recoveries(fxh_state *st)
+{
+    static int told;
+    const int now = fxg_scan_recoveries(st->ctx);
+    if (now > st->recoveries_seen) {
+        st->recoveries_seen = now;
+        if (!__atomic_exchange_n(&told, 1, __ATOMIC_RELAXED))
+            warnx("the GPU stopped running this process's work for a while (shared with another process?); a block was done again without the fast path's waits -- the output is not affected");
+    }
+}
+
 void fxh_lane_run(fxh_lane *ln)
 {
     fxh_state *st = &ln->st;
@@ -88,6 +101,7 @@ void fxh_lane_run(fxh_lane *ln)
         if (rc != 0) errx(1, "GPU engine error %d: %s", rc, fxg_last_error(st->ctx));
     }
     FXH_TCALL(4);
+    fxh_note_recoveries(st);
     if (lpr == 2) FXG_CHECK(st, fxg_fasta_weights(st->ctx, st->d_text, st->d_ls, st->d_ls_cap, n, st->d_res, ln->weighted));
     uint64_t out_bytes = 0;
     FXG_CHECK(st, fxg_fastq_format(st->ctx, st->d_text, lpr, st->d_ls, st->d_ls_cap, st->d_flags, n, st->d_res, ln->fwd_start, ln->reverse,

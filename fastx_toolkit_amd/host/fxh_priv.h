@@ -58,6 +58,7 @@ typedef struct {
     uint64_t *d_out_off;
     size_t d_text_cap, d_ls_cap, d_off_cap;
     const void *registered[4];
+    int recoveries_seen;                   /* fxg_scan_recoveries at the last look (fxh_note_recoveries) */
 } fxh_state;
 
 #define FXG_CHECK(st, call)                                                                     \
@@ -245,6 +246,7 @@ int fxh_device_list(int *dev, int cap);
 void fxh_host_block(fxh_run *R);
 void fxh_add_counters(fxh_totals *tot, const uint64_t *ctr, uint64_t n, const uint64_t *weighted);
 void fxh_lane_run(fxh_lane *ln);
+void fxh_note_recoveries(fxh_state *st);
 void fxh_lane_open_ctx(fxh_lane *ln);
 void fxh_lane_release(fxh_lane *ln);
 int fxh_run_one_file(FASTX *fx, const fxg_params *p, fxh_totals *tot);

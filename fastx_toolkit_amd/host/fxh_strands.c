@@ -685,6 +685,9 @@ static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot,
             errx(1, "rank %d of %d: %.1f GB of device memory for this rank's share of the output are not to be had (%s); start more ranks", rank, world,
                  1e-9 * (double)S->arena_cap, fxg_last_error(S->main_ctx));
         FXG_CHECK(&rank_lane.st, fxg_malloc_device(S->main_ctx, FXG_NCOUNTERS * sizeof(uint64_t), (void **)&d_block));
+        /* stdout is the tool's data and report channel (the -v report goes there when -o names a file): a collective library told to talk
+         * (NCCL_DEBUG=VERSION / INFO in the job's environment) talks to stderr, unless the user has sent it somewhere already */
+        if (getenv("NCCL_DEBUG") && !getenv("NCCL_DEBUG_FILE")) (void)setenv("NCCL_DEBUG_FILE", "/dev/stderr", 0);
         char rdv[PATH_MAX + 16];
         const char *re = getenv("FXH_RENDEZVOUS");
         if (re && *re) snprintf(rdv, sizeof rdv, "%s", re); else snprintf(rdv, sizeof rdv, "%s.rdv", fx->output_file_name);

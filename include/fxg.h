@@ -207,6 +207,11 @@ int  fxg_run_revcomp_trim(fxg_ctx *ctx, const fxg_batch *in, int reverse_complem
 /* Copies the counter block to the host after synchronising; returns FXG_E_DEVICE if the kernels
  * raised an error bit (counters[FXG_C_ERRORS]). */
 int  fxg_read_counters(fxg_ctx *ctx, const uint64_t *d_counters, uint64_t host_counters[FXG_NCOUNTERS]);
+/* A compacting launch whose bounded waits ran out (FXG_DEV_ERR_SCAN_TIMEOUT: the launch's workgroups were not being scheduled -- a GPU shared with
+ * another process) is not an error any more: fxg_read_counters does the launch again in a form that cannot wait on another workgroup (decisions, block
+ * sums, scan, gather: csrc/fxg_fallback.h) and returns the counters of that.  This is how many launches of the context went that way; a host that
+ * wants to tell its user compares it before and after.  (The caller's batch and output arrays must still be what the launch was given.) */
+int  fxg_scan_recoveries(const fxg_ctx *ctx);
 
 /* Deterministic synthetic reads generated straight into device memory. */
 int  fxg_synth_generate(fxg_ctx *ctx, uint64_t seed, uint64_t first_read, uint64_t n, uint32_t read_len,

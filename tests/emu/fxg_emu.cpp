@@ -229,7 +229,9 @@ extern "C" int fxg_emu_run_pipeline_hist(const fxg_batch *in, const fxg_params *
         case -36: return emu_run<-36, false>(pl, ctr, err, cap);
         case -40: return emu_run<-40, false>(pl, ctr, err, cap);
         case -48: return emu_run<-48, false>(pl, ctr, err, cap);
+        case -56: return emu_run<-56, false>(pl, ctr, err, cap);
         case -64: return emu_run<-64, false>(pl, ctr, err, cap);
+        case -80: return emu_run<-80, false>(pl, ctr, err, cap);
         case -100: return emu_run<-100, false>(pl, ctr, err, cap);
 #ifdef FXG_CLIP_ONE_PASS
         case -216: return emu_run<-216, false>(pl, ctr, err, cap);
@@ -238,7 +240,9 @@ extern "C" int fxg_emu_run_pipeline_hist(const fxg_batch *in, const fxg_params *
         case -324: return emu_run<-324, false>(pl, ctr, err, cap);
         case -336: return emu_run<-336, false>(pl, ctr, err, cap);
         case -348: return emu_run<-348, false>(pl, ctr, err, cap);
+        case -356: return emu_run<-356, false>(pl, ctr, err, cap);
         case -364: return emu_run<-364, false>(pl, ctr, err, cap);
+        case -380: return emu_run<-380, false>(pl, ctr, err, cap);
         case -400: return emu_run<-400, false>(pl, ctr, err, cap);
         case 16: return emu_run<16, false>(pl, ctr, err, cap);
         case 32: return emu_run<32, false>(pl, ctr, err, cap);

@@ -86,6 +86,7 @@ int fxg_host_unregister(fxg_ctx *, void *) { return 0; }
 int fxg_set_profiling(fxg_ctx *, int) { return 0; }
 int fxg_last_kernel_ms(fxg_ctx *, float *ms) { *ms = 0; return 0; }
 int fxg_profiled_kernel_ms(fxg_ctx *, float *, uint32_t, uint32_t *n) { *n = 0; return 0; }
+int fxg_scan_recoveries(const fxg_ctx *) { return 0; }      /* (nothing waits in the serial emulation) */
 int fxg_last_launch_info(const fxg_ctx *, char *name, size_t cap, uint32_t *g, uint32_t *b, uint32_t *l, uint32_t *t) { if (name && cap) name[0] = 0; if (g) *g = 0; if (b) *b = 0; if (l) *l = 0; if (t) *t = 0; return 0; }
 }
 

@@ -403,3 +403,17 @@ def test_one_output_file_by_many_strands_on_the_real_engine(tools, tmp_path):
             g = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", inp, "-o", os.path.join(td, "bm")], b"", env=dict(os.environ, FXH_ONE_FILE_MIN_MB="0", FXH_STRAND_MB="4", FXH_TIMING="1"))
             assert w[0] == 1 and g[0] == 1 and b"fxh timing one file: abandoned, contexts destroyed, output emptied" in g[2]
             assert _msg(g[2]) .splitlines()[-1] == _msg(w[2]).splitlines()[-1] and open(os.path.join(td, "bm"), "rb").read() == open(os.path.join(td, "bs"), "rb").read()
+
+
+def test_tool_survives_a_scan_timeout(tools, tmp_path):
+    """The same at the level of a command line: fastx_reverse_complement and fastq_masker (the tools whose output comes from the engine's compaction) with every
+    compacting launch timing out: exit code 0, the bytes of the undisturbed run, one line on stderr that says what happened."""
+    text = fo.synth_fastq(2, 0, 120000, 150, False)
+    inp = tmp_path / "in.fq"
+    inp.write_bytes(text)
+    for argv in (["fastx_reverse_complement", "-v"], ["fastq_masker", "-q", "20", "-v"]):
+        w = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", str(tmp_path / "calm.fq")], b"")
+        g = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", str(tmp_path / "shaken.fq")], b"", env=dict(os.environ, FXG_TEST_SCAN_TIMEOUT="1", FXH_READ_BUFFER_MB="8"))
+        assert w[0] == 0 and g[0] == 0, g[2][-400:]
+        assert g[1] == w[1] and (tmp_path / "shaken.fq").read_bytes() == (tmp_path / "calm.fq").read_bytes()
+        assert g[2].count(b"the GPU stopped running this process's work for a while") == 1 and b"stopped running" not in w[2]
