@@ -60,7 +60,8 @@ struct fxg_ctx {
     char last_kernel[96];
     u32 last_grid, last_block, last_lds, last_tile;
     // the last compacting launch, kept so that it can be done again without the scanner when its waits timed out (fxg_fallback.h)
-    struct { const void *fn; FxgKArgs ka; u32 lds, block, workers; u64 *counters; int valid, rev, mask; } fb;
+    struct { FxgKArgs ka; u64 *counters; int valid; } fb;                                      // the launch (fxg_launch_tiles): its arguments as the kernel got them
+    struct { fxg_batch in; fxg_params p; fxg_out out; bool hist; u32 estride; int valid; } fb_req;      // the request (fxg_run_pipeline)
     u64 *fb_blk; size_t fb_blk_cap;     // block sums / prefixes of the fallback
     int recoveries;                     // launches redone that way since the context was made (fxg_scan_recoveries)
     int test_force_timeout;             // FXG_TEST_SCAN_TIMEOUT=1: every compacting launch starts with the time-out flag up (GPU tier)
@@ -305,8 +306,7 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
     FXG_HIP(c, hipMemsetAsync(c->errflag, 0, (FXG_CTRL_WORDS + FXG_TICKET_GROUPS * FXG_TICKET_STRIDE) * sizeof(u32), c->stream));
     c->fb.valid = 0;
     if (ka.compact) {                            // what fxg_read_counters needs to do this launch again should its waits time out
-        c->fb.fn = (const void *)kernel; c->fb.ka = ka; c->fb.lds = lds; c->fb.block = block; c->fb.workers = (u32)workers; c->fb.counters = counters; c->fb.valid = 1;
-        c->fb.rev = (ka.stages & FXG_STAGE_REVCOMP) != 0; c->fb.mask = (ka.stages & FXG_STAGE_MASK) != 0;
+        c->fb.ka = ka; c->fb.counters = counters; c->fb.valid = 1;
         if (c->test_force_timeout) {             // "somebody already gave up": every wait of this launch that lasts ends without a result
             static const u32 up = FXG_DEV_ERR_SCAN_TIMEOUT;
             FXG_HIP(c, hipMemcpyAsync(c->errflag, &up, sizeof up, hipMemcpyHostToDevice, c->stream));
@@ -402,6 +402,8 @@ static int fxg_hist_prepass(fxg_ctx *c, const fxg_batch *in, u32 T, u32 estride,
     return FXG_OK;
 }
 
+static int fxg_launch_plan(fxg_ctx *c, FxgPlan &pl, u64 *ctr);
+
 extern "C" int fxg_run_pipeline(fxg_ctx *c, const fxg_batch *in, const fxg_params *p, const fxg_out *out)
 {
     if (!c || !in || !p || !out) return FXG_E_INVALID;
@@ -422,7 +424,15 @@ extern "C" int fxg_run_pipeline(fxg_ctx *c, const fxg_batch *in, const fxg_param
         if (hrc != FXG_OK) return hrc;
         if (!use) { pl.ka.clip_src = in->bases; pl.ka.clip_stride = in->stride; pl.ka.clip_total = in->n * (u64)in->stride; pl.ka.wlen = nullptr; pl.lds = fxg_plan_lds(&pl); }
     }
-    u64 *ctr = (u64 *)out->counters;
+    // what fxg_read_counters needs to do a compacting pass again, should its waits time out (fxg_fallback.h)
+    c->fb_req.valid = 0;
+    if (pl.ka.compact) { c->fb_req.in = *in; c->fb_req.p = *p; c->fb_req.out = *out; c->fb_req.hist = hist; c->fb_req.estride = estride; c->fb_req.valid = 1; }
+    return fxg_launch_plan(c, pl, (u64 *)out->counters);
+}
+
+// the launch of a planned pass: which instance of which kernel family
+static int fxg_launch_plan(fxg_ctx *c, FxgPlan &pl, u64 *ctr)
+{
 #define FXG_TILES_A(N) (fxg_kernel_tiles<N, 0>)
 #define FXG_TILES_C(N) (pl.ka.clip_global ? fxg_kernel_tiles<N, 0, true> : fxg_kernel_tiles<N, 0, false>)      // packed clip instances: the DP over the staged tile, or over the batch (fxg_plan.h)
     if (pl.rows_nw) {       // rows of 80..152 bytes through the quality stages: one lane per read, rows in registers (fxg_rows.h)
@@ -569,18 +579,27 @@ extern "C" int fxg_run_revcomp_trim(fxg_ctx *c, const fxg_batch *in, int reverse
     return fxg_run_pipeline(c, in, &p, out);
 }
 
-// The last compacting launch once more, in the form that cannot wait (fxg_fallback.h).  Everything goes behind the failed launch on the same stream.
+// The last compacting pass once more, in the form that cannot wait (fxg_fallback.h).  Everything goes behind the failed launch on the same stream.
 static int fxg_redo_without_scanner(fxg_ctx *c)
 {
-    FxgFbArgs f;
-    f.ka = c->fb.ka;
-    f.ka.compact = 0u; f.ka.nscan = 0u;
-    { const u32 g = c->env_ticket_groups > 0 ? (u32)c->env_ticket_groups : FXG_TICKET_GROUPS; f.ka.ticket_groups = c->fb.workers >= g ? g : 1u; }
+    const FxgKArgs failed = c->fb.ka;
+    u64 *const counters = c->fb.counters;
+    // 1. the decisions: the same request planned without the packed outputs -- the kernel instance the plan picks for a decision-only pass has no scanner
+    //    and no wait (the row-per-lane kernel of fxg_rows.h only exists in its compacting form).  A run with clip history keeps the extended queries the
+    //    failed pass built: the aligner's buffer has moved on once for this batch and must not move again.
+    fxg_out o2 = c->fb_req.out;
+    o2.out_bases = o2.out_qual = nullptr; o2.out_len = nullptr; o2.kept_index = nullptr; o2.out_off = nullptr;
+    FxgPlan pl;
+    const int prc = fxg_make_plan(&c->fb_req.in, &c->fb_req.p, &o2, &pl, c->err, sizeof c->err, c->fb_req.hist ? c->fb_req.estride : 0u);
+    if (prc != FXG_OK) return prc;
+    if (c->fb_req.hist) { pl.ka.clip_src = failed.clip_src; pl.ka.clip_stride = failed.clip_stride; pl.ka.clip_total = failed.clip_total; pl.ka.wlen = failed.wlen; pl.lds = fxg_plan_lds(&pl); }
     FXG_HIP(c, hipSetDevice(c->device));
-    FXG_HIP(c, hipMemsetAsync(c->errflag, 0, (FXG_CTRL_WORDS + FXG_TICKET_GROUPS * FXG_TICKET_STRIDE) * sizeof(u32), c->stream));
-    FxgKArgs ka = f.ka;
-    void *args[] = {&ka};
-    FXG_HIP(c, hipLaunchKernel(c->fb.fn, dim3(c->fb.workers), dim3(c->fb.block), args, c->fb.lds, c->stream));      // 1. decisions: res[], tallies
+    const int lrc = fxg_launch_plan(c, pl, counters);
+    if (lrc != FXG_OK) return lrc;
+    // 2. + 3. block sums -> prefixes -> every kept read to its place
+    FxgFbArgs f;
+    f.ka = failed;                               // the arrays and folded parameters of the pass as it was asked for
+    f.ka.errflag = c->errflag;
     f.nblk = (u32)((f.ka.n + FXG_FB_BLOCK - 1u) / FXG_FB_BLOCK);
     const size_t need = 2 * (size_t)f.nblk + 2;
     if (c->fb_blk_cap < need) {
@@ -590,18 +609,18 @@ static int fxg_redo_without_scanner(fxg_ctx *c)
         c->fb_blk_cap = need;
     }
     f.blk = c->fb_blk;
-    f.ka.compact = 1u;                                                                                                  // (the tallies of kept reads / bytes come from the decisions either way)
-    hipLaunchKernelGGL(fxg_kernel_fb_sums, dim3(f.nblk), dim3(FXG_FB_BLOCK), 0, c->stream, f);                          // 2. block sums -> prefixes
+    hipLaunchKernelGGL(fxg_kernel_fb_sums, dim3(f.nblk), dim3(FXG_FB_BLOCK), 0, c->stream, f);
     FXG_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(fxg_kernel_fb_scan, dim3(1), dim3(FXG_FB_BLOCK), 0, c->stream, f);
     FXG_HIP(c, hipGetLastError());
-    if (c->fb.rev) hipLaunchKernelGGL((fxg_kernel_fb_gather<true, false>), dim3(f.nblk), dim3(FXG_FB_BLOCK), 0, c->stream, f);      // 3. every read to its place
-    else if (c->fb.mask) hipLaunchKernelGGL((fxg_kernel_fb_gather<false, true>), dim3(f.nblk), dim3(FXG_FB_BLOCK), 0, c->stream, f);
+    if (f.ka.stages & FXG_STAGE_REVCOMP) hipLaunchKernelGGL((fxg_kernel_fb_gather<true, false>), dim3(f.nblk), dim3(FXG_FB_BLOCK), 0, c->stream, f);
+    else if (f.ka.stages & FXG_STAGE_MASK) hipLaunchKernelGGL((fxg_kernel_fb_gather<false, true>), dim3(f.nblk), dim3(FXG_FB_BLOCK), 0, c->stream, f);
     else hipLaunchKernelGGL((fxg_kernel_fb_gather<false, false>), dim3(f.nblk), dim3(FXG_FB_BLOCK), 0, c->stream, f);
     FXG_HIP(c, hipGetLastError());
-    hipLaunchKernelGGL(fxg_kernel_finish_counters, dim3(1), dim3(64), 0, c->stream, (const u64 *)f.ka.tally, f.ka.stages, (const u32 *)c->errflag,
-                       (const u64 *)(c->errflag + 2), c->fb.counters ? c->fb.counters : c->counters_scratch);
-    FXG_HIP(c, hipGetLastError());
+    if (f.ka.stages & FXG_STAGE_REVCOMP) {       // a base that has no complement: found by the gather, reported like the tile kernels do
+        hipLaunchKernelGGL(fxg_kernel_fb_errors, dim3(1), dim3(1), 0, c->stream, (const u32 *)c->errflag, counters ? counters : c->counters_scratch);
+        FXG_HIP(c, hipGetLastError());
+    }
     c->recoveries++;
     return FXG_OK;
 }
@@ -614,9 +633,9 @@ extern "C" int fxg_read_counters(fxg_ctx *c, const uint64_t *d_counters, uint64_
     const u64 *src = d_counters ? (const u64 *)d_counters : c->counters_scratch;
     FXG_HIP(c, hipMemcpyAsync(host, src, FXG_NCOUNTERS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     FXG_HIP(c, hipStreamSynchronize(c->stream));
-    if ((host[FXG_C_ERRORS] & FXG_DEV_ERR_SCAN_TIMEOUT) && c->fb.valid && src == (c->fb.counters ? c->fb.counters : c->counters_scratch) && !getenv("FXG_NO_SCAN_FALLBACK")) {
+    if ((host[FXG_C_ERRORS] & FXG_DEV_ERR_SCAN_TIMEOUT) && c->fb.valid && c->fb_req.valid && src == (c->fb.counters ? c->fb.counters : c->counters_scratch) && !getenv("FXG_NO_SCAN_FALLBACK")) {
         // the launch these counters belong to gave up waiting (its workgroups were not being scheduled): the same work again without anything that waits
-        c->fb.valid = 0;
+        c->fb.valid = 0; c->fb_req.valid = 0;
         const int rc = fxg_redo_without_scanner(c);
         if (rc != FXG_OK) return rc;
         FXG_HIP(c, hipMemcpyAsync(host, src, FXG_NCOUNTERS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));

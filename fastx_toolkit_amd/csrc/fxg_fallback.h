@@ -4,7 +4,7 @@
 // (fxg_device.h).  Every wait is bounded -- two seconds without progress raise FXG_DEV_ERR_SCAN_TIMEOUT and the launch writes nothing more -- and by
 // construction a wait only ends that way when the workgroups stop being scheduled: two tool processes of a pipe sharing one GPU, a debugger, a hung
 // neighbour.  Until round 5 that cost the user the run.  Now the launch is done again in a form that cannot wait on another workgroup:
-//   1. the same kernel instance, decision only (compact = 0: no scanner, no prefix, every tile independent) -- res[] and the -v tallies;
+//   1. the same request planned as a decision-only pass (no packed outputs: no scanner, no prefix, every tile independent) -- res[] and the -v tallies;
 //   2. per block of FXG_FB_BLOCK reads the kept reads and kept bytes (fxg_kernel_fb_sums), one workgroup turns the block sums into exclusive
 //      prefixes (fxg_kernel_fb_scan);
 //   3. every read copies itself to its place (fxg_kernel_fb_gather): the byte mapping is the tile kernels' own (fxg_gather_byte: forward slice,
@@ -95,3 +95,6 @@ __global__ void __launch_bounds__(FXG_FB_BLOCK) fxg_kernel_fb_gather(FxgFbArgs f
     if (REV && bad) atomicOr(a.errflag, FXG_DEV_ERR_BAD_BASE);
     fxg_write_kept_meta(a, rank, olen, (u32)r, off);
 }
+
+// error bits the gather raised (after the decision pass laid out its counters): OR-ed into the counter block
+__global__ void fxg_kernel_fb_errors(const u32 *errflag, u64 *counters) { counters[FXG_C_ERRORS] |= (u64)errflag[0]; }

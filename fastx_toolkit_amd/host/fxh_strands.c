@@ -691,7 +691,14 @@ static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot,
         char rdv[PATH_MAX + 16];
         const char *re = getenv("FXH_RENDEZVOUS");
         if (re && *re) snprintf(rdv, sizeof rdv, "%s", re); else snprintf(rdv, sizeof rdv, "%s.rdv", fx->output_file_name);
+        /* (and whatever it prints unasked -- RCCL 2.26 greets with its version, the runtime's and the host name on stdout -- goes to stderr as well:
+         * descriptor 1 is descriptor 2 while the communicator is made) */
+        fflush(stdout);
+        const int saved_out = dup(STDOUT_FILENO);
+        if (saved_out >= 0) (void)dup2(STDERR_FILENO, STDOUT_FILENO);
         const int crc = fxg_comm_create(S->main_ctx, rdv, (uint32_t)rank, (uint32_t)world, (int)fxh_env_long("FXH_RENDEZVOUS_TIMEOUT", 120, 1, 86400), &comm);
+        fflush(stdout);
+        if (saved_out >= 0) { (void)dup2(saved_out, STDOUT_FILENO); close(saved_out); }
         if (crc != 0) errx(1, "rank %d of %d: no communicator (%d): %s", rank, world, crc, fxg_last_error(S->main_ctx));
     }
     for (int i = 0; i < ns; ++i) {
