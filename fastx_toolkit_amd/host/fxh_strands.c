@@ -626,11 +626,6 @@ static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot,
         if (!getenv("FXG_DEVICE") && !getenv("FXG_DEVICES")) { const int nd = fxg_device_count(); g_hip_touched = 1; dev[0] = nd > 0 ? rank % nd : 0; }
         ndev = 1;
     }
-    cpu_set_t cpus_before;
-    const double t_dev = fxh_now();
-    if (ndev == 1) (void)fxh_bind_near_device(dev[0], &cpus_before);      /* buffers and the output's pages are touched (and page-locked) on the GPU's node; every thread below inherits it */
-    const double t_bound = fxh_now();
-
     /* the sink: a tmpfs file written from offset 0 gets the gated mapping, everything else positional writes */
     {
         struct statfs fs;
@@ -655,6 +650,15 @@ static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot,
             }
         }
     }
+
+    /* Placement AFTER the allocator has started: finding the GPU's NUMA node can take 50 ms (the runtime has to be asked where visibility variables hide the
+     * topology), which is a gigabyte of pages at the allocator's rate.  The allocator thread then follows the calling thread onto the GPU's node. */
+    cpu_set_t cpus_before;
+    const double t_dev = fxh_now();
+    if (ndev == 1) (void)fxh_bind_near_device(dev[0], &cpus_before);      /* buffers and the output's pages are touched (and page-locked) on the GPU's node; every thread below inherits it */
+    if (S->mapped) { cpu_set_t now_set; if (sched_getaffinity(0, sizeof now_set, &now_set) == 0) (void)pthread_setaffinity_np(S->th_alloc, sizeof now_set, &now_set); }
+    const double t_bound = fxh_now();
+
 
     /* four strands feed the sink of a small file as well as eight and start faster (2.6 GB: 0.239 against 0.268 s); large inputs take eight, so that
      * a tool that keeps little of its input still fills the link */
