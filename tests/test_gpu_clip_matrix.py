@@ -70,7 +70,7 @@ ADS = {"-48": b"ACGTTGCAAGGCTTAACCGGATATCGCGTATAGCTAGCTAGGATCCA"[:44], "-64": b"
        "-56": b"GTCGTAGACCGATCGGGGACCCCTTGTTTCACGCGTCGTATAGCTGCTATGTCATTAGC"[:53], "-80": (b"ACGTTGCAAGGCTTAACCGGATATCGCGTATAG" * 3)[:77],
        "-356": b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCGTATGCCGTCTTC"[:51], "-380": b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCGTATGCCGTCTTCTGCTTGAAAAAAAAAAGGGGGG"[:72],
        "-100": (b"ACGTTGCA" * 12)[:91], "-348": b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCG"[:46], "-364": b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCGTATGCCGTCTTC"[:58],
-       "-400": b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCGTATGCCGTCTTCTGCTTGAAAAAAAAAAGGGGGG"[:80]}
+       "-400": b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCGTATGCCGTCTTCTGCTTGAAAAAAAAAAGGGGGGGGGGCCCCCCCCCCTTTTT"[:93]}
 for tag, ad in ADS.items():
     for stride in (150, 151, 250, 300):
         for fixed in (True, False):
