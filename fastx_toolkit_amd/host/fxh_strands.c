@@ -344,7 +344,7 @@ static void fxh_sf_write_task(void *arg)
         const int e = S->alloc_errno;
         pthread_mutex_unlock(&S->mu);
         t_wait = fxh_now() - t0;
-        if (e) { errno = e; err(1, "writing output failed"); }
+        if (e) fxh_sf_abort(S);                      /* no room for the pages (ENOSPC): the one-stream run meets the same wall and reports it the way it always did, with the output it got that far */
         if (!FXH_ABORTED()) {
             /* the whole buffer under one hold of the gate.  The allocator is preferred, so the sink strictly alternates: a window of pages, then
              * EVERY copy that has piled up meanwhile side by side (copies are only fast many at a time), then the next window.  (A megabyte per
@@ -660,14 +660,15 @@ static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot,
     const double t_bound = fxh_now();
 
 
-    /* four strands feed the sink of a small file as well as eight and start faster (2.6 GB: 0.239 against 0.268 s); large inputs take eight, so that
-     * a tool that keeps little of its input still fills the link */
-    int per = (int)fxh_env_long("FXH_STRANDS", S->in_total < ((uint64_t)4 << 30) ? 4 : 8, 1, FXH_MAX_STRANDS);
+    /* Four strands per GPU, four preads in flight each (16 reading threads: what one tmpfs file gives, 31 GB/s).  Four feed the sink as well as six or eight -- it is the
+     * sink that bounds a run whose output is large -- and cost less to start and to take down: 64 M reads 60.8 / 59.3 / 54.9 Mreads/s with 4 / 6 / 8 strands, the child gone
+     * 1.04 / 1.06 / 1.15 s after the fork (profiles/r05/r_e2e_one_file_strands.txt); 2.6 GB of input 0.239 against 0.268 s (l_). */
+    int per = (int)fxh_env_long("FXH_STRANDS", 4, 1, FXH_MAX_STRANDS);
     int ns = per * ndev;
     if (ns > FXH_MAX_STRANDS) ns = FXH_MAX_STRANDS;
     if ((uint64_t)ns > nchunks) ns = (int)nchunks;
     S->nstrands = ns;
-    S->nread_slices = (int)fxh_env_long("FXH_STRAND_READERS", 2, 1, 16);
+    S->nread_slices = (int)fxh_env_long("FXH_STRAND_READERS", 4, 1, 16);
     S->st = (fxh_strand *)calloc((size_t)ns, sizeof(fxh_strand));
     if (!S->st) err(1, "out of memory");
     fxh_pool_start(&S->rpool, (int)fxh_env_long("FXH_IO_THREADS", ns * (S->nread_slices - 1) > 0 ? ns * (S->nread_slices - 1) : 1, 1, 64), (unsigned)(ns * 16));

@@ -108,6 +108,17 @@ def test_tools_under_sanitizers(san, tmp_path):
              (["fastx_clipper", "-a", ad, "-l", "15", "-v", "-i", str(big), "-o", str(tmp_path / "c.%r.fq")], b"", {"FXH_READ_BUFFER_MB": "1", "FXH_PARTS": "3"}),
              (["fastx_clipper", "-a", ad, "-l", "15", "-v", "-i", str(rag), "-o", str(tmp_path / "cr.%r.fq")], b"", {"FXH_READ_BUFFER_MB": "1", "FXH_PARTS": "3"}),
              (["fastq_quality_trimmer", "-t", "20", "-l", "30", "-v", "-i", str(big), "-o", str(tmp_path / "auto.%r.fq")], b"", {"FXH_READ_BUFFER_MB": "1"})]
+    # round 5: ONE output file written by many strands (tickets, published sizes, the gated allocator and the copy pool; positional writes), its
+    # abandon path on a damaged record and on ragged clipper input, the rank path with a world of one (arena, all-gather over the test transport, drain)
+    import emu_py
+    one = {"FXH_ONE_FILE_MIN_MB": "0", "FXH_STRAND_KB": "256", "FXH_STRANDS": "3", "FXH_ONE_FILE_WINDOW_MB": "1", "FXH_READ_BUFFER_MB": "1"}
+    for sink in ("map", "pwrite"):
+        runs += [(["fastq_quality_trim_filter", "-t", "20", "-l", "30", "-q", "20", "-p", "80", "-v", "-i", str(big), "-o", str(tmp_path / ("one_%s.fq" % sink))], b"", dict(one, FXH_ONE_FILE_SINK=sink)),
+                 (["fastx_reverse_complement", "-v", "-i", str(big), "-o", str(tmp_path / ("one_rc_%s.fq" % sink))], b"", dict(one, FXH_ONE_FILE_SINK=sink, FXG_EMU_DEVICES="2", FXG_DEVICES="0,1")),
+                 (["fastq_quality_trimmer", "-t", "20", "-l", "30", "-i", str(bad), "-o", str(tmp_path / ("one_bad_%s.fq" % sink))], b"", dict(one, FXH_ONE_FILE_SINK=sink)),
+                 (["fastx_clipper", "-a", ad, "-l", "15", "-v", "-i", str(rag), "-o", str(tmp_path / ("one_rag_%s.fq" % sink))], b"", dict(one, FXH_ONE_FILE_SINK=sink))]
+    runs.append((["fastq_quality_trim_filter", "-t", "20", "-l", "30", "-q", "20", "-p", "80", "-v", "-i", str(big), "-o", str(tmp_path / "rankmode.fq")], b"",
+                 dict(one, FXH_RANK_MODE="1", FXH_DRAIN_MB="1", LD_LIBRARY_PATH=STUB_DIR + os.pathsep + emu_py.build_fake_rccl())))
     for name, data in _corner_inputs().items():
         for argv in (["fastq_quality_trimmer", "-t", "20", "-l", "2"], ["fastx_trimmer", "-f", "2", "-l", "9"], ["fastx_reverse_complement"]):
             runs.append((argv, data, {"FXH_READ_BUFFER_MB": "1"} if len(data) % 2 else {}))
