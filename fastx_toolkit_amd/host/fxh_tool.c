@@ -22,9 +22,10 @@ static int fxh_tool_option(int optind_, int optc, char *arg)
         const fxh_option *o = &g_tool->opts[i];
         if (o->letter != optc) continue;
         long v = 0;
-        if (o->kind != FXH_K_FLAG && arg == NULL) errx(1, "%s", o->missing ? o->missing : "option requires an argument value");
+        if (o->kind != FXH_K_FLAG && o->kind != FXH_K_COUNT && arg == NULL) errx(1, "%s", o->missing ? o->missing : "option requires an argument value");
         switch (o->kind) {
         case FXH_K_FLAG: v = o->value; break;
+        case FXH_K_COUNT: v = g_v[o->slot] + 1; break;
         case FXH_K_STRTOL: v = (int)strtol(arg, NULL, 10); break;
         case FXH_K_STRTOUL_INT: v = (int)strtoul(arg, NULL, 10); break;
         case FXH_K_STRTOUL_U32: v = (long)(unsigned int)strtoul(arg, NULL, 10); break;
@@ -99,7 +100,7 @@ int fxh_tool_main(const fxh_tool *tool, int argc, char *argv[])
     fxh_init_writer(&fastx, get_output_filename(), tool->output_type, compress_output_flag());
     fxh_default_params(&p, get_fastq_ascii_quality_offset());
     tool->configure(g_v, g_s, &p);
-    fxh_run_tool(&fastx, &p, &tot);
+    if (!(tool->alt_run && tool->alt_run(g_v, &fastx, &p, &tot))) fxh_run_tool(&fastx, &p, &tot);
     if (verbose_flag()) {
         FILE *rf = get_report_file();
         for (int i = 0; i < tool->nreport; ++i) {

@@ -16,6 +16,7 @@
 
 typedef enum {
     FXH_K_FLAG,        /* no argument: v[slot] = value */
+    FXH_K_COUNT,       /* no argument: v[slot] += 1 (fastx_clipper -D -D) */
     FXH_K_STRTOL,      /* (int)strtol(arg)   -- negatives accepted */
     FXH_K_STRTOUL_INT, /* (int)strtoul(arg)  -- the reference stores strtoul's result in an int */
     FXH_K_STRTOUL_U32, /* (unsigned int)strtoul(arg) */
@@ -66,6 +67,7 @@ typedef struct fxh_tool {
     void (*check)(const long *v, const char *s);                        /* cross-option rules; may errx */
     void (*configure)(const long *v, const char *s, fxg_params *p);     /* stage chain and parameters */
     const fxh_report_line *report; int nreport;
+    int (*alt_run)(const long *v, FASTX *fx, const fxg_params *p, fxh_totals *tot);      /* optional: a mode of the tool that is not an engine run (1 = it ran) */
 } fxh_tool;
 
 int fxh_tool_main(const fxh_tool *tool, int argc, char *argv[]);

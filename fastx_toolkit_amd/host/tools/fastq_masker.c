@@ -37,6 +37,6 @@ static const fxh_tool tool = {
     "   -i INFILE   FASTQ input, default stdin\n"
     "   -o OUTFILE  FASTQ output, default stdout\n"
     "   -v          verbose report (to stdout if -o is given, else to stderr)\n\n",
-    "q:r:", options, 2, NULL, {10, 'N'}, NULL, FASTQ_ONLY, OUTPUT_SAME_AS_INPUT, NULL, configure, report, 6,
+    "q:r:", options, 2, NULL, {10, 'N'}, NULL, FASTQ_ONLY, OUTPUT_SAME_AS_INPUT, NULL, configure, report, 6, NULL,
 };
 int main(int argc, char *argv[]) { return fxh_tool_main(&tool, argc, argv); }

@@ -37,6 +37,6 @@ static const fxh_tool tool = {
     "   -o OUTFILE  FASTQ output, default stdout\n"
     "   -v          verbose report (to stdout if -o is given, else to stderr)\n"
     "   -Q N        ASCII quality offset, default 33\n\n",
-    "q:p:", options, 2, NULL, {0, 0}, NULL, FASTQ_ONLY, OUTPUT_SAME_AS_INPUT, NULL, configure, report, 5,
+    "q:p:", options, 2, NULL, {0, 0}, NULL, FASTQ_ONLY, OUTPUT_SAME_AS_INPUT, NULL, configure, report, 5, NULL,
 };
 int main(int argc, char *argv[]) { return fxh_tool_main(&tool, argc, argv); }

@@ -34,6 +34,6 @@ static const fxh_tool tool = {
     "   -z          compress output with gzip\n"
     "   -i INFILE   FASTQ input, default stdin\n"
     "   -o OUTFILE  FASTA output, default stdout\n\n",
-    "rn", options, 2, NULL, {0, 0}, NULL, FASTQ_ONLY, OUTPUT_FASTA, NULL, configure, report, 3,
+    "rn", options, 2, NULL, {0, 0}, NULL, FASTQ_ONLY, OUTPUT_FASTA, NULL, configure, report, 3, NULL,
 };
 int main(int argc, char *argv[]) { return fxh_tool_main(&tool, argc, argv); }

@@ -20,6 +20,6 @@ static const fxh_tool tool = {
     "   -o OUTFILE  FASTA/Q output, default stdout\n"
     "   -z          compress output with gzip\n"
     "   -v          verbose report (to stdout if -o is given, else to stderr)\n\n",
-    "", NULL, 0, NULL, {0}, NULL, FASTA_OR_FASTQ, OUTPUT_SAME_AS_INPUT, NULL, configure, report, 3,
+    "", NULL, 0, NULL, {0}, NULL, FASTA_OR_FASTQ, OUTPUT_SAME_AS_INPUT, NULL, configure, report, 3, NULL,
 };
 int main(int argc, char *argv[]) { return fxh_tool_main(&tool, argc, argv); }

@@ -11,7 +11,7 @@ enum { MIN_LENGTH, KEEP_N, KEEP_DELTA, ONLY_CLIPPED, ONLY_NON_CLIPPED, ADAPTER_O
 static const fxh_option options[] = {
     {'M', FXH_K_ATOI, MIN_ADAPTER, 0, "[-M] parameter requires an argument value", 1, 1, INT_MAX, "Invalid minimum adapter length (-M %s)", -1, 0},
     {'k', FXH_K_FLAG, ADAPTER_ONLY, 1, NULL, 0, 0, 0, NULL, -1, 0},
-    {'D', FXH_K_FLAG, DEBUG_DUMP, 1, NULL, 0, 0, 0, NULL, -1, 0},           /* rejected in check(): see there */
+    {'D', FXH_K_COUNT, DEBUG_DUMP, 1, NULL, 0, 0, 0, NULL, -1, 0},          /* -D, -D -D: the reference's debug++ (fastx_clipper.cpp:130) */
     {'c', FXH_K_FLAG, ONLY_CLIPPED, 1, NULL, 0, 0, 0, NULL, -1, 0},
     {'C', FXH_K_FLAG, ONLY_NON_CLIPPED, 1, NULL, 0, 0, 0, NULL, -1, 0},
     {'d', FXH_K_STRTOUL_INT, KEEP_DELTA, 0, "[-d] parameter requires an argument value", 1, 0, INT_MAX, "Invalid number bases to keep (-d %s)", -1, 0},
@@ -33,12 +33,15 @@ static const fxh_report_line report[] = {
     {FXH_W_Z, KEEP_N, 0, {{"discarded ", FXH_V_CLIP_N, 0}, {" N reads.\n", FXH_V_NONE, 0}}},
 };
 /* -D makes the reference print every read's alignment (and with -D -D its whole score matrix) to stdout, in between the records
- * (fastx_clipper.cpp:272-275, sequence_alignment.cpp:169-230): a developer's view of the CPU aligner's state.  The engine keeps no
- * matrix and no alignment strings, so it cannot print them; silently ignoring the flag would look like "nothing to report".  */
-static void check(const long *v, const char *s)
+ * (fastx_clipper.cpp:272-275, sequence_alignment.cpp:15-84, :169-230): a developer's view of the CPU aligner's state, which the engine does not
+ * have (no matrix, no alignment strings).  With -D the tool therefore runs the reference's own record loop with one aligner on the host, which
+ * exists for this dump alone (host/fxh_clip_debug.c); every other run of the tool is the GPU path. */
+void fxh_clipper_debug_run(FASTX *fx, const fxg_params *p, int level, fxh_totals *tot);
+static int debug_dump(const long *v, FASTX *fx, const fxg_params *p, fxh_totals *tot)
 {
-    (void)s;
-    if (v[DEBUG_DUMP]) errx(1, "[-D] (debug dump of every alignment and score matrix) is not available in the MI355X build: use the reference fastx_clipper to inspect alignments");
+    if (v[DEBUG_DUMP] <= 0) return 0;
+    fxh_clipper_debug_run(fx, p, (int)v[DEBUG_DUMP], tot);
+    return 1;
 }
 static void configure(const long *v, const char *s, fxg_params *p)
 {
@@ -63,11 +66,11 @@ static const fxh_tool tool = {
     "   -n          keep sequences with unknown (N) nucleotides, default is to discard them\n"
     "   -v          verbose report (to stdout if -o is given, else to stderr)\n"
     "   -z          compress output with gzip\n"
-    "   -D          not available in this build (the reference's debug dump of alignments and score matrices); exits with an error\n"
+    "   -D          debug dump of every read's alignment to stdout (twice: with the score matrix); runs on the host\n"
     "   -M N        require a minimum adapter alignment length of N\n"
     "   -i INFILE   FASTA/Q input, default stdin\n"
     "   -o OUTFILE  FASTA/Q output, default stdout\n\n",
     "M:kDCcd:a:s:l:n", options, 9, "Unknown argument (%c)",     /* 's' is in the option string but has no handler, there as here (F3) */
-    {5, 0, 0, 0, 0, 0, 0}, "CCTTAAGG", FASTA_OR_FASTQ, OUTPUT_SAME_AS_INPUT, check, configure, report, 11,
+    {5, 0, 0, 0, 0, 0, 0}, "CCTTAAGG", FASTA_OR_FASTQ, OUTPUT_SAME_AS_INPUT, NULL, configure, report, 11, debug_dump,
 };
 int main(int argc, char *argv[]) { return fxh_tool_main(&tool, argc, argv); }

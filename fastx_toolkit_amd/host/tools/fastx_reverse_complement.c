@@ -19,6 +19,6 @@ static const fxh_tool tool = {
     "   -z          compress output with gzip\n"
     "   -i INFILE   FASTA/Q input, default stdin\n"
     "   -o OUTFILE  FASTA/Q output, default stdout\n\n",
-    "", NULL, 0, NULL, {0}, NULL, FASTA_OR_FASTQ, OUTPUT_SAME_AS_INPUT, NULL, configure, report, 3,
+    "", NULL, 0, NULL, {0}, NULL, FASTA_OR_FASTQ, OUTPUT_SAME_AS_INPUT, NULL, configure, report, 3, NULL,
 };
 int main(int argc, char *argv[]) { return fxh_tool_main(&tool, argc, argv); }

@@ -51,6 +51,6 @@ static const fxh_tool tool = {
     "   -z          compress output with gzip\n"
     "   -i INFILE   FASTA/Q input, default stdin\n"
     "   -o OUTFILE  FASTA/Q output, default stdout\n\n",
-    "l:f:t:m:", options, 4, NULL, {1, 0, 0, 0, 0, 0}, NULL, FASTA_OR_FASTQ, OUTPUT_SAME_AS_INPUT, check, configure, report, 5,
+    "l:f:t:m:", options, 4, NULL, {1, 0, 0, 0, 0, 0}, NULL, FASTA_OR_FASTQ, OUTPUT_SAME_AS_INPUT, check, configure, report, 5, NULL,
 };
 int main(int argc, char *argv[]) { return fxh_tool_main(&tool, argc, argv); }

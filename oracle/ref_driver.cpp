@@ -243,6 +243,7 @@ static int run_clipper(int argc, char **argv)
     while (fastx_read_next_record(&fx)) {
         int reads = get_reads_count(&fx);
         aligner.align(std::string(fx.nucleotides), std::string(cl_adapter));          /* :265-270 */
+        if (cl_debug > 1) aligner.print_matrix();                                      /* :272-275 */
         if (cl_debug > 0) aligner.results().print();
         n_in += reads;
         int i = cutoff(aligner.results());

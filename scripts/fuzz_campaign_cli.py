@@ -13,12 +13,15 @@ assert REF, "oracle/_ref/fxref not built"
 REAL = os.environ.get("FXG_CAMPAIGN_REAL") == "1"      # on a GPU box: the tools over the real engine (their rpath finds ../../libfxg.so)
 STUB = None if REAL else emu_py.build_stub()
 BIN = os.path.join(ROOT, "fastx_toolkit_amd", "host", "bin")
+FAKE_RCCL = emu_py.build_fake_rccl()                     # rank-mode jobs of the campaign: the product's transport over the test-only library
+if STUB: os.environ["LD_LIBRARY_PATH"] = STUB
+else: os.environ.setdefault("LD_LIBRARY_PATH", "")
 rng = np.random.default_rng(int(sys.argv[1]))
 AD = ["AGATCGGAAGAGC", "CCTTAAGG", "TGGAATTCTCGGGTGCCAAGGAACTCCAGTCAC", "ANNTCGNA"]
 
 def run(cmd, data, env=None):
     e = dict(os.environ, FXH_THREADS="3")
-    if STUB: e["LD_LIBRARY_PATH"] = STUB
+    if STUB and not (env and "LD_LIBRARY_PATH" in env): e["LD_LIBRARY_PATH"] = STUB
     e.update(env or {})
     p = subprocess.run(cmd, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=300)
     return p.returncode, p.stdout, p.stderr
@@ -86,6 +89,27 @@ with tempfile.TemporaryDirectory() as tmp:
             for f in files:
                 if os.path.exists(f): os.unlink(f)
             ok = (got[0], out) == (rc, want) if rc == 0 else got[0] == rc
+        elif rng.random() < 0.45 and tool not in (9,):    # file to ONE file by many strands (round 5: tickets, published sizes, both sinks), or as a job of 2-4 rank processes
+            inp, outp = os.path.join(tmp, "in.fq"), os.path.join(tmp, "one.fq")
+            open(inp, "wb").write(data)
+            e1 = dict(env, FXH_ONE_FILE_MIN_MB="0", FXH_STRAND_KB=str(int(rng.choice([4, 16, 64, 256, 1024]))), FXH_STRANDS=str(int(rng.integers(1, 6))),
+                      FXH_ONE_FILE_SINK=str(rng.choice(["map", "pwrite"])), FXH_ONE_FILE_WINDOW_MB="1", FXH_STRAND_OUT_SLOTS=str(int(rng.integers(2, 5))))
+            argv = [os.path.join(BIN, fused[0])] + fused[1:] + ["-i", inp, "-o", outp]
+            if rng.random() < 0.35:
+                world = int(rng.integers(2, 5))
+                e1.update(FXH_WORLD=str(world), FXH_DRAIN_MB="1", LD_LIBRARY_PATH=os.environ["LD_LIBRARY_PATH"] + os.pathsep + FAKE_RCCL, FXH_THREADS="3", **({"FXG_FAKE_RCCL_HIP": "1"} if REAL else {}))
+                ps = [subprocess.Popen(argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **dict(e1, FXH_RANK=str(r)))) for r in range(world)]
+                res = [(p.communicate(timeout=300), p.returncode) for p in ps]
+                got = (res[0][1], res[0][0][0], res[0][0][1])
+                ok_others = all(c == 0 and o == b"" for (o, _), c in res[1:])
+            else:
+                got = run(argv, b"", e1); ok_others = True
+            out = open(outp, "rb").read() if os.path.exists(outp) else b""
+            if os.path.exists(outp): os.unlink(outp)
+            env = e1
+            # (-v reports go to stdout when -o names a file: compare them with the reference's stderr report when there is one tool)
+            ok = ok_others and ((got[0], out) == (rc, want) if rc == 0 else (got[0] == rc and got[2].split(b": ", 1)[-1].splitlines()[-1:] == err.split(b": ", 1)[-1].splitlines()[-1:]))
+            got = (got[0], out, got[2])
         else:
             got = run([os.path.join(BIN, fused[0])] + fused[1:], data, env)
             ok = (got[0], got[1]) == (rc, want) and (len(chain) > 1 or got[2].split(b": ", 1)[-1] == err.split(b": ", 1)[-1] or rc == 0)

@@ -109,8 +109,8 @@ def test_flag_errors_and_usage(tools):
         rrc, rout, rerr = _run([REF] + argv, data)
         assert rc == 1 and (rc, out) == (rrc, rout), argv
         assert _msg(err) == _msg(rerr), (argv, err, rerr)
-    rc, out, err = _run([os.path.join(tools, "fastx_clipper"), "-a", "ACGT", "-D"], b"@r\nA\n+\nI\n")   # a documented divergence: no silent no-op
-    assert rc == 1 and out == b"" and b"[-D]" in err
+    if REF:                                                     # -D is the reference's dump again (round 5, host/fxh_clip_debug.c): see test_clipper_debug_dump
+        assert _run([os.path.join(tools, "fastx_clipper"), "-a", "ACGT", "-D"], b"@r\nA\n+\nI\n")[:2] == _run([REF, "fastx_clipper", "-a", "ACGT", "-D"], b"@r\nA\n+\nI\n")[:2]
     assert _run([os.path.join(tools, "fastq_quality_trimmer")], b"@r\nA\n+\nI\n")[0] == 1          # missing -t
     assert _run([os.path.join(tools, "fastq_quality_filter"), "-p", "0"], b"")[0] == 1
     assert _run([os.path.join(tools, "fastx_trimmer"), "-f", "2", "-t", "3"], b"@r\nA\n+\nI\n")[0] == 1
@@ -763,3 +763,33 @@ def test_pipes_as_the_references_users_run_them(tools, tmp_path):
     p1.stdout.close()
     got = h.communicate(timeout=60)[0]
     assert got == _run(t1, text)[1][:100000] and p1.wait(timeout=60) != 0
+
+
+@pytest.mark.skipif(REF is None, reason="oracle/_ref/fxref not built")
+def test_clipper_debug_dump(tools, tmp_path):
+    """fastx_clipper -D / -D -D (fastx_clipper.cpp:270-275): every read's SequenceAlignmentResults (sequence_alignment.cpp:15-84) and, given twice, the whole
+    score / origin / match matrix (:169-230) on stdout -- the alignment strings, the float formatting of std::cout (default, then `fixed` with one digit for
+    good once the first matrix cell has been printed), the never-shrinking matrix and the stale query tail on ragged input, adapters with N -- byte for byte
+    against the real libfastx; the records and the -v report as without -D."""
+    rng = np.random.default_rng(5)
+    lines = fo.synth_fastq(3, 0, 400, 60, True).split(b"\n")[:-1]
+    for i in range(0, len(lines), 4):
+        if (i // 4) % 3 == 1:
+            L = int(rng.integers(5, 60)); lines[i + 1] = lines[i + 1][:L]; lines[i + 3] = lines[i + 3][:L]
+    data = b"\n".join(lines) + b"\n"
+    fasta = b"".join(b">%d-%d\n%s\n" % (i, 1 + i % 3, lines[4 * i + 1]) for i in range(60))
+    n = 0
+    for text in (data, fasta):
+        for flags in (["-D"], ["-D", "-D"], ["-D", "-c", "-v"], ["-D", "-D", "-n", "-k"], ["-D", "-M", "6", "-d", "2", "-v"]):
+            for ad in ("AGATCGGAAGAGC", "ANNTCGNA", "TGGAATTCTCGGGTGCCAAGGAACTCCAGTCAC"):
+                argv = ["fastx_clipper", "-a", ad, "-l", "5"] + flags
+                w = _run([REF] + argv + ["-o", str(tmp_path / "ref.out")], text)
+                g = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-o", str(tmp_path / "my.out")], text)
+                assert (g[0], g[1]) == (w[0], w[1]), (flags, ad, len(g[1]), len(w[1]))
+                assert (tmp_path / "my.out").read_bytes() == (tmp_path / "ref.out").read_bytes()
+                n += 1
+    assert n == 30
+    # without -D the same command lines are the engine's: same records, same report, nothing else on stdout
+    g = _run([os.path.join(tools, "fastx_clipper"), "-a", "AGATCGGAAGAGC", "-l", "5", "-v", "-o", str(tmp_path / "gpu.out")], data)
+    w = _run([REF, "fastx_clipper", "-a", "AGATCGGAAGAGC", "-l", "5", "-v", "-o", str(tmp_path / "ref.out")], data)
+    assert (g[0], g[1]) == (w[0], w[1]) and (tmp_path / "gpu.out").read_bytes() == (tmp_path / "ref.out").read_bytes()
