@@ -97,7 +97,7 @@ with tempfile.TemporaryDirectory() as tmp:
             argv = [os.path.join(BIN, fused[0])] + fused[1:] + ["-i", inp, "-o", outp]
             if rng.random() < 0.35:
                 world = int(rng.integers(2, 5))
-                e1.update(FXH_WORLD=str(world), FXH_DRAIN_MB="1", LD_LIBRARY_PATH=os.environ["LD_LIBRARY_PATH"] + os.pathsep + FAKE_RCCL, FXH_THREADS="3", **({"FXG_FAKE_RCCL_HIP": "1"} if REAL else {}))
+                e1.update(FXH_WORLD=str(world), FXH_DRAIN_MB="1", LD_LIBRARY_PATH=FAKE_RCCL + os.pathsep + os.environ["LD_LIBRARY_PATH"], FXH_THREADS="3", **({"FXG_FAKE_RCCL_HIP": "1"} if REAL else {}))
                 ps = [subprocess.Popen(argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **dict(e1, FXH_RANK=str(r)))) for r in range(world)]
                 res = [(p.communicate(timeout=300), p.returncode) for p in ps]
                 got = (res[0][1], res[0][0][0], res[0][0][1])
