@@ -17,7 +17,7 @@ done
 cd /tmp
 for c in $CFGS; do
   rm -rf $R/gpurun_out/prof_$c
-  timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$c -o bench -- python $R/bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline --no-e2e > $O/${c}_bench_under_rocprof.json 2> $O/prof_$c.err
+  timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$c -o bench -- python $R/bench.py --config $c --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --headline-only > $O/${c}_bench_under_rocprof.json 2> $O/prof_$c.err
   echo "rocprof $c rc=$?"
   db=$(find $R/gpurun_out/prof_$c -name "*.db" | head -1)
   if [ -n "$db" ]; then python $R/scripts/rocpd_stats.py $db $O/${c}_kernel_stats.md | head -3; fi
