@@ -41,10 +41,23 @@ def check_exec_zero(so):
                            "Change the register budget of the named instance (fxg_clip_waves / __launch_bounds__) or its source and rebuild.\n%s" % (so, p.stdout[-3000:]))
 
 
+CLIP_UNITS = 7      # csrc/fxg_engine_clip.hip is compiled once per group of clip instances (-DFXG_CLIP_TU=1..7), beside csrc/fxg_engine.hip (-DFXG_SPLIT)
+
+
 def compile_engine(out, extra_flags=(), check=True):
-    """hipcc of csrc/fxg_engine.hip into `out`, through a temporary name: a library that fails the ISA check never appears under `out`."""
+    """The engine into `out`, through a temporary name: a library that fails the ISA check never appears under `out`.  Eight translation units compiled
+    side by side (csrc/fxg_host.h: the clip instances are most of the work; as one unit the build took three and a half minutes), then one link."""
     tmp = out + ".new"
-    subprocess.check_call([hipcc()] + HIPCC_FLAGS + list(extra_flags) + [os.path.join(CSRC, "fxg_engine.hip"), "-o", tmp])
+    objdir = os.path.join(ROOT, "build", "engine_" + os.path.basename(out).replace(".", "_"))
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags) + ["-c"]
+    units = [("fxg_engine.hip", ["-DFXG_SPLIT"], os.path.join(objdir, "engine.o"))]
+    units += [("fxg_engine_clip.hip", ["-DFXG_CLIP_TU=%d" % k], os.path.join(objdir, "clip%d.o" % k)) for k in range(1, CLIP_UNITS + 1)]
+    procs = [(src, subprocess.Popen([hipcc()] + cflags + defs + [os.path.join(CSRC, src), "-o", obj])) for src, defs, obj in units]
+    failed = [src for src, p in procs if p.wait() != 0]
+    if failed:
+        raise RuntimeError("hipcc failed on %s" % ", ".join(failed))
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + [obj for _, _, obj in units] + ["-o", tmp])
     if check:
         try:
             check_exec_zero(tmp)

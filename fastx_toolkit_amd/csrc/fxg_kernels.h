@@ -1281,6 +1281,7 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
     if constexpr (MODE == 4) { if (art_bad) atomicOr(a.errflag, FXG_DEV_ERR_BAD_BASE); }
 }
 
+#if !defined(FXG_CLIP_TU)      // (the translation units of the clip instances have no kernels of their own besides fxg_kernel_tiles: fxg_host.h)
 // tally slots of all workgroups -> counters[FXG_NCOUNTERS]; also folds the device error word and the masker sums in
 __global__ void fxg_kernel_finish_counters(const u64 *tally, u32 stages, const u32 *errflag, const u64 *extra, u64 *counters)
 {
@@ -1368,4 +1369,5 @@ __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_synth(u64 seed, u64 firs
         }
     }
 }
+#endif      // !FXG_CLIP_TU
 #endif  // FXG_HOST_EMULATION

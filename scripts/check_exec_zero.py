@@ -42,18 +42,19 @@ IGNORES_EXEC = ("v_readlane_b32", "v_readfirstlane_b32", "v_writelane_b32", "v_n
 MEM_PREFIX = ("scratch_", "global_", "buffer_", "flat_", "ds_", "tbuffer_")
 
 
-def code_object(so, tmp):
-    """The gfx950 code object embedded in a HIP shared library (or the file itself if it already is one)."""
+def code_objects(so, tmp):
+    """The gfx950 code objects embedded in a HIP shared library -- one per translation unit (the engine is built from eight, csrc/fxg_host.h) -- or the
+    file itself if it already is one."""
     out = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "-h", so], capture_output=True, text=True).stdout
     if "AMDGPU" in out or "amdgpu" in out:
-        return so
+        return [so]
     work = os.path.join(tmp, os.path.basename(so))
     shutil.copy(so, work)
     subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", work], capture_output=True, text=True, cwd=tmp)
-    for f in sorted(os.listdir(tmp)):
-        if f.startswith(os.path.basename(so) + ".") and "amdgcn" in f:
-            return os.path.join(tmp, f)
-    raise RuntimeError("no gfx950 code object found in %s" % so)
+    found = [os.path.join(tmp, f) for f in sorted(os.listdir(tmp)) if f.startswith(os.path.basename(so) + ".") and "amdgcn" in f]
+    if not found:
+        raise RuntimeError("no gfx950 code object found in %s" % so)
+    return found
 
 
 def check_kernel(name, ins, full_lines, joins=False):
@@ -163,8 +164,8 @@ def check(so, joins=False):
         text = open(so).read()
     else:
         with tempfile.TemporaryDirectory() as tmp:
-            co = code_object(os.path.abspath(so), tmp)
-            text = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
+            text = "\n".join(subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
+                             for co in code_objects(os.path.abspath(so), tmp))
     report, cur, lines, name = [], None, None, None
     ks = {}
     for line in text.splitlines():
