@@ -299,6 +299,19 @@ def e2e_leg(reads=16_000_000, big_reads=64_000_000, parts=4, lanes=2):
                     ob, dtw = big["one_file"]["output_bytes"], big["one_file"]["wall_s"]
                     big["one_file"]["link"] = dict(bytes_up_per_read=round(big["input_bytes"] / big_reads, 1), bytes_down_per_read=round(ob / big_reads, 1),
                                                    up_gbs_over_wall=round(big["input_bytes"] / dtw / 1e9, 1), down_gbs_over_wall=round(ob / dtw / 1e9, 1))
+                    # the link's own rate in this call (scripts/ubench/pcie_bw: 64 MB blocks from page-locked memory, four streams, both directions at once)
+                    pb = os.path.join(ROOT, "scripts", "ubench", "pcie_bw")
+                    if os.path.exists(pb):
+                        try:
+                            txt = subprocess.run([pb], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120).stdout.decode()
+                            row = [l for l in txt.splitlines() if l.startswith("4 stream(s), input hipHostRegister")][0]
+                            nums = [float(x) for x in __import__("re").findall(r"[0-9]+\.[0-9]+", row)]
+                            lk = big["one_file"]["link"]
+                            lk.update(ubench_up_alone_gbs=nums[0], ubench_down_alone_gbs=nums[1], ubench_each_way_both_busy_gbs=nums[2],
+                                      up_frac_of_both_busy=round(lk["up_gbs_over_wall"] / nums[2], 3), down_frac_of_both_busy=round(lk["down_gbs_over_wall"] / nums[2], 3),
+                                      note="GB/s over the whole wall time of the command (start-up and exit included), against the link measured in this call")
+                        except Exception:
+                            pass
                 if os.path.exists(onef):
                     os.unlink(onef)
                 timed(big, "sharded", lambda: subprocess.call(fa + ["-o", os.path.join(td, "part.%r.fq")], env=penv) == 0, pnames, big_reads, want_md5=False)
