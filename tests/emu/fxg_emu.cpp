@@ -130,6 +130,115 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
     return FXG_OK;
 }
 
+// The clipper's instances, in groups that tests/emu_py.py compiles side by side (-DFXG_EMU_TU=k: group k alone, 0: everything else; no define:
+// the whole emulator in one unit).  A group answers EMU_NOT_MINE for a plan it holds no instance of.
+enum { EMU_NOT_MINE = -12345, FXG_EMU_CLIP_GROUPS = 7 };
+typedef int emu_clip_group_fn(const FxgPlan &, uint64_t *, char *, size_t);
+#define EMU_HIDDEN __attribute__((visibility("hidden")))
+EMU_HIDDEN emu_clip_group_fn emu_clip_rest;         // the general instance (any adapter length)
+EMU_HIDDEN emu_clip_group_fn emu_clip_group1;
+EMU_HIDDEN emu_clip_group_fn emu_clip_group2;
+EMU_HIDDEN emu_clip_group_fn emu_clip_group3;
+EMU_HIDDEN emu_clip_group_fn emu_clip_group4;
+EMU_HIDDEN emu_clip_group_fn emu_clip_group5;
+EMU_HIDDEN emu_clip_group_fn emu_clip_group6;
+EMU_HIDDEN emu_clip_group_fn emu_clip_group7;
+#if !defined(FXG_EMU_TU) || FXG_EMU_TU == 1
+int emu_clip_group1(const FxgPlan &pl, uint64_t *ctr, char *err, size_t cap)
+{
+    switch (pl.amax) {
+    case -4: return emu_run<-4, false>(pl, ctr, err, cap);
+    case -8: return emu_run<-8, false>(pl, ctr, err, cap);
+    case -9: return emu_run<-9, false>(pl, ctr, err, cap);
+    case -10: return emu_run<-10, false>(pl, ctr, err, cap);
+    case -11: return emu_run<-11, false>(pl, ctr, err, cap);
+    case -12: return emu_run<-12, false>(pl, ctr, err, cap);
+    case -13: return emu_run<-13, false>(pl, ctr, err, cap);
+    case -14: return emu_run<-14, false>(pl, ctr, err, cap);
+    case -15: return emu_run<-15, false>(pl, ctr, err, cap);
+    case -16: return emu_run<-16, false>(pl, ctr, err, cap);
+    case 16: return emu_run<16, false>(pl, ctr, err, cap);
+    case 32: return emu_run<32, false>(pl, ctr, err, cap);
+    case 64: return emu_run<64, false>(pl, ctr, err, cap);
+#ifdef FXG_CLIP_ONE_PASS
+    case -216: return emu_run<-216, false>(pl, ctr, err, cap);
+#endif
+    default: return EMU_NOT_MINE;
+    }
+}
+int emu_clip_rest(const FxgPlan &pl, uint64_t *ctr, char *err, size_t cap) { return emu_run<100, false>(pl, ctr, err, cap); }
+#endif
+#if !defined(FXG_EMU_TU) || FXG_EMU_TU == 2
+int emu_clip_group2(const FxgPlan &pl, uint64_t *ctr, char *err, size_t cap)
+{
+    switch (pl.amax) {
+    case -20: return emu_run<-20, false>(pl, ctr, err, cap);
+    case -24: return emu_run<-24, false>(pl, ctr, err, cap);
+    case -28: return emu_run<-28, false>(pl, ctr, err, cap);
+    case -32: return emu_run<-32, false>(pl, ctr, err, cap);
+    case -36: return emu_run<-36, false>(pl, ctr, err, cap);
+    case -40: return emu_run<-40, false>(pl, ctr, err, cap);
+    default: return EMU_NOT_MINE;
+    }
+}
+#endif
+#if !defined(FXG_EMU_TU) || FXG_EMU_TU == 3
+int emu_clip_group3(const FxgPlan &pl, uint64_t *ctr, char *err, size_t cap)
+{
+    switch (pl.amax) {
+    case -48: return emu_run<-48, false>(pl, ctr, err, cap);
+    case -56: return emu_run<-56, false>(pl, ctr, err, cap);
+    case -64: return emu_run<-64, false>(pl, ctr, err, cap);
+    default: return EMU_NOT_MINE;
+    }
+}
+#endif
+#if !defined(FXG_EMU_TU) || FXG_EMU_TU == 4
+int emu_clip_group4(const FxgPlan &pl, uint64_t *ctr, char *err, size_t cap)
+{
+    switch (pl.amax) {
+    case -80: return emu_run<-80, false>(pl, ctr, err, cap);
+    case -100: return emu_run<-100, false>(pl, ctr, err, cap);
+    default: return EMU_NOT_MINE;
+    }
+}
+#endif
+#if !defined(FXG_EMU_TU) || FXG_EMU_TU == 5
+int emu_clip_group5(const FxgPlan &pl, uint64_t *ctr, char *err, size_t cap)
+{
+    switch (pl.amax) {
+    case -316: return emu_run<-316, false>(pl, ctr, err, cap);
+    case -324: return emu_run<-324, false>(pl, ctr, err, cap);
+    case -336: return emu_run<-336, false>(pl, ctr, err, cap);
+    case -348: return emu_run<-348, false>(pl, ctr, err, cap);
+    default: return EMU_NOT_MINE;
+    }
+}
+#endif
+#if !defined(FXG_EMU_TU) || FXG_EMU_TU == 6
+int emu_clip_group6(const FxgPlan &pl, uint64_t *ctr, char *err, size_t cap)
+{
+    switch (pl.amax) {
+    case -356: return emu_run<-356, false>(pl, ctr, err, cap);
+    case -364: return emu_run<-364, false>(pl, ctr, err, cap);
+    default: return EMU_NOT_MINE;
+    }
+}
+#endif
+#if !defined(FXG_EMU_TU) || FXG_EMU_TU == 7
+int emu_clip_group7(const FxgPlan &pl, uint64_t *ctr, char *err, size_t cap)
+{
+    switch (pl.amax) {
+    case -380: return emu_run<-380, false>(pl, ctr, err, cap);
+    case -400: return emu_run<-400, false>(pl, ctr, err, cap);
+    default: return EMU_NOT_MINE;
+    }
+}
+#endif
+
+#if !defined(FXG_EMU_TU) || FXG_EMU_TU == 0
+static emu_clip_group_fn *const emu_clip_groups[FXG_EMU_CLIP_GROUPS] = {emu_clip_group1, emu_clip_group2, emu_clip_group3, emu_clip_group4, emu_clip_group5, emu_clip_group6, emu_clip_group7};
+
 // clip history (fxg_history.h): the same per-column bodies the pre-pass kernels run, serially
 struct fxg_emu_hist {
     std::vector<uint8_t> buf[2];
@@ -210,45 +319,12 @@ extern "C" int fxg_emu_run_pipeline_hist(const fxg_batch *in, const fxg_params *
     }
     uint64_t *ctr = out->counters;
     if (pl.group_a) {
-        switch (pl.amax) {
-        case 0: return emu_run<0, false>(pl, ctr, err, cap);
-        case -4: return emu_run<-4, false>(pl, ctr, err, cap);
-        case -8: return emu_run<-8, false>(pl, ctr, err, cap);
-        case -9: return emu_run<-9, false>(pl, ctr, err, cap);
-        case -10: return emu_run<-10, false>(pl, ctr, err, cap);
-        case -11: return emu_run<-11, false>(pl, ctr, err, cap);
-        case -12: return emu_run<-12, false>(pl, ctr, err, cap);
-        case -13: return emu_run<-13, false>(pl, ctr, err, cap);
-        case -14: return emu_run<-14, false>(pl, ctr, err, cap);
-        case -15: return emu_run<-15, false>(pl, ctr, err, cap);
-        case -16: return emu_run<-16, false>(pl, ctr, err, cap);
-        case -20: return emu_run<-20, false>(pl, ctr, err, cap);
-        case -24: return emu_run<-24, false>(pl, ctr, err, cap);
-        case -28: return emu_run<-28, false>(pl, ctr, err, cap);
-        case -32: return emu_run<-32, false>(pl, ctr, err, cap);
-        case -36: return emu_run<-36, false>(pl, ctr, err, cap);
-        case -40: return emu_run<-40, false>(pl, ctr, err, cap);
-        case -48: return emu_run<-48, false>(pl, ctr, err, cap);
-        case -56: return emu_run<-56, false>(pl, ctr, err, cap);
-        case -64: return emu_run<-64, false>(pl, ctr, err, cap);
-        case -80: return emu_run<-80, false>(pl, ctr, err, cap);
-        case -100: return emu_run<-100, false>(pl, ctr, err, cap);
-#ifdef FXG_CLIP_ONE_PASS
-        case -216: return emu_run<-216, false>(pl, ctr, err, cap);
-#endif
-        case -316: return emu_run<-316, false>(pl, ctr, err, cap);
-        case -324: return emu_run<-324, false>(pl, ctr, err, cap);
-        case -336: return emu_run<-336, false>(pl, ctr, err, cap);
-        case -348: return emu_run<-348, false>(pl, ctr, err, cap);
-        case -356: return emu_run<-356, false>(pl, ctr, err, cap);
-        case -364: return emu_run<-364, false>(pl, ctr, err, cap);
-        case -380: return emu_run<-380, false>(pl, ctr, err, cap);
-        case -400: return emu_run<-400, false>(pl, ctr, err, cap);
-        case 16: return emu_run<16, false>(pl, ctr, err, cap);
-        case 32: return emu_run<32, false>(pl, ctr, err, cap);
-        case 64: return emu_run<64, false>(pl, ctr, err, cap);
-        default: return emu_run<100, false>(pl, ctr, err, cap);
+        if (pl.amax == 0) return emu_run<0, false>(pl, ctr, err, cap);
+        for (int g = 0; g < FXG_EMU_CLIP_GROUPS; ++g) {
+            const int r = emu_clip_groups[g](pl, ctr, err, cap);
+            if (r != EMU_NOT_MINE) return r;
         }
+        return emu_clip_rest(pl, ctr, err, cap);
     }
     if (pl.mask) return emu_run<0, false, 3>(pl, ctr, err, cap);
     if (pl.artifacts) return emu_run<0, false, 4>(pl, ctr, err, cap);
@@ -420,3 +496,4 @@ extern "C" int fxg_emu_fasta_weights(const uint8_t *text, const uint32_t *d_line
     }
     return FXG_OK;
 }
+#endif      // FXG_EMU_TU == 0

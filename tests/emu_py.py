@@ -21,15 +21,37 @@ class Out(C.Structure):
                 ("kept_index", C.c_void_p), ("out_off", C.c_void_p), ("counters", C.c_void_p)]
 
 
-def build():
+_CXX = ["hipcc", "--cuda-host-only", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-pass-failed", "-DFXG_HOST_EMULATION"]
+_LINK = ["hipcc", "-shared", "-fPIC"]         # (objects only: with --cuda-host-only the driver would read them as sources)
+_CSRC = os.path.join(_HERE, "..", "fastx_toolkit_amd", "csrc")
+_EMU_DEPS = [os.path.join(_CSRC, f) for f in ("fxg_device.h", "fxg_kernels.h", "fxg_plan.h", "fxg_text.h", "fxg_rows.h", "fxg_history.h", "fxg_stats.h")]
+EMU_UNITS = 8               # fxg_emu.cpp: -DFXG_EMU_TU=0 (everything but the clipper's instances) and its seven groups of clip instances
+
+
+def _emu_objects(defs):
+    """fxg_emu.cpp as EMU_UNITS objects compiled side by side (one unit took over three minutes); both libraries below link the same objects."""
     src = os.path.join(_EMU, "fxg_emu.cpp")
+    d = os.path.join(_EMU, "obj%s" % "".join(x.replace("-D", "_").replace("=", "") for x in defs))
+    os.makedirs(d, exist_ok=True)
+    newest = max(os.path.getmtime(x) for x in [src] + _EMU_DEPS)
+    objs = [os.path.join(d, "fxg_emu_%d.o" % k) for k in range(EMU_UNITS)]
+    stale = [k for k, o in enumerate(objs) if not os.path.exists(o) or os.path.getmtime(o) < newest]
+    procs = [(k, subprocess.Popen(_CXX + defs + ["-DFXG_EMU_TU=%d" % k, "-c", src, "-o", objs[k] + ".tmp"])) for k in stale]
+    bad = [k for k, pr in procs if pr.wait() != 0]
+    if bad:
+        raise RuntimeError("emulator units %s did not compile" % bad)
+    for k in stale:
+        os.replace(objs[k] + ".tmp", objs[k])
+    return objs
+
+
+def build():
     defs = os.environ.get("FXG_EMU_DEFS", "").split()           # e.g. "-DFXG_V_TABLE": check a kernel variant on the CPU tier
     so = os.path.join(_EMU, "libfxgemu%s.so" % "".join(d.replace("-D", "_") for d in defs))
-    csrc = os.path.join(_HERE, "..", "fastx_toolkit_amd", "csrc")
-    deps = [src] + [os.path.join(csrc, f) for f in ("fxg_device.h", "fxg_kernels.h", "fxg_plan.h", "fxg_text.h", "fxg_rows.h", "fxg_history.h", "fxg_stats.h")]
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["hipcc", "--cuda-host-only", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-                               "-Wno-pass-failed", "-DFXG_HOST_EMULATION"] + defs + [src, "-o", so])
+    objs = _emu_objects(defs)
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(o) for o in objs):
+        subprocess.check_call(_LINK + objs + ["-o", so + ".tmp"])
+        os.replace(so + ".tmp", so)
     return so
 
 
@@ -40,13 +62,13 @@ def build_stub():
     d = os.path.join(_EMU, "stub")
     os.makedirs(d, exist_ok=True)
     so = os.path.join(d, "libfxg.so")
-    srcs = [os.path.join(_EMU, f) for f in ("fxg_stub.cpp", "fxg_emu.cpp")]
-    root = os.path.join(_HERE, "..")
-    deps = srcs + [os.path.join(root, "fastx_toolkit_amd", "csrc", f) for f in ("fxg_device.h", "fxg_kernels.h", "fxg_plan.h", "fxg_history.h", "fxg_stats.h", "fxg_text.h", "fxg_rows.h", "fxg_comm.h")] + \
-        [os.path.join(root, "include", "fxg.h")]
+    src = os.path.join(_EMU, "fxg_stub.cpp")
+    objs = _emu_objects([])
+    deps = [src, os.path.join(_CSRC, "fxg_comm.h"), os.path.join(_HERE, "..", "include", "fxg.h")] + _EMU_DEPS + objs
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(x) for x in deps):
-        subprocess.check_call(["hipcc", "--cuda-host-only", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-pass-failed",
-                               "-DFXG_HOST_EMULATION"] + srcs + ["-o", so, "-ldl"])
+        subprocess.check_call(_CXX + ["-c", src, "-o", os.path.join(d, "fxg_stub.o")])
+        subprocess.check_call(_LINK + [os.path.join(d, "fxg_stub.o")] + objs + ["-o", so + ".tmp", "-ldl"])
+        os.replace(so + ".tmp", so)
     return d
 
 
