@@ -158,6 +158,7 @@ struct fxh_sf {
     char *map;
     uint64_t map_len, alloc_end, need, window;
     int alloc_errno, alloc_stop;
+    int drain_errno;                       /* rank mode: errno of the first piece of this rank's text that did not get into the file */
     pthread_t th_alloc;
     pthread_rwlock_t gate;                 /* fallocate() exclusive, copies shared; writer-preferring */
     double t_alloc, t_copy, t_copy_wait;   /* t_copy*: summed over the copy tasks, under mu */
@@ -493,11 +494,63 @@ typedef struct { fxh_sf *S; const char *src; size_t len; uint64_t off; int *busy
 static void fxh_sf_drain_task(void *arg)
 {
     fxh_djob *j = (fxh_djob *)arg;
-    if (fxg_concat_pwrite(j->S->out_fd, j->src, j->len, j->off) != 0) err(1, "writing output failed");
+    errno = 0;
+    const int e = fxg_concat_pwrite(j->S->out_fd, j->src, j->len, j->off) != 0 ? (errno ? errno : EIO) : 0;
     pthread_mutex_lock(&j->S->mu);
+    if (e && !j->S->drain_errno) j->S->drain_errno = e;       /* reported to the job (the second exchange), not died of: the other ranks are waiting */
     *j->busy = 0;
     pthread_cond_broadcast(&j->S->cv);
     pthread_mutex_unlock(&j->S->mu);
+}
+
+/* rank mode: nobody waits for a dead rank for ever.  An all-gather that a rank never joins does not return (RCCL has no time-out of its own), so every
+ * exchange runs under a watch: FXH_RANK_TIMEOUT seconds (default 900) without the other ranks' answer end this rank with a message and exit code 1. */
+typedef struct { pthread_mutex_t mu; pthread_cond_t cv; pthread_t th; int done, secs, rank, world; const char *what; } fxh_watch;
+static void *fxh_watch_main(void *arg)
+{
+    fxh_watch *w = (fxh_watch *)arg;
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    ts.tv_sec += w->secs;
+    pthread_mutex_lock(&w->mu);
+    int rc = 0;
+    while (!w->done && rc != ETIMEDOUT) rc = pthread_cond_timedwait(&w->cv, &w->mu, &ts);
+    const int late = !w->done;
+    pthread_mutex_unlock(&w->mu);
+    if (late) {
+        warnx("rank %d of %d: no answer from the other ranks within %d s (%s): a rank has died or is stuck (FXH_RANK_TIMEOUT)", w->rank, w->world, w->secs, w->what);
+        fflush(NULL);
+        _exit(1);
+    }
+    return NULL;
+}
+static void fxh_watch_start(fxh_watch *w, int rank, int world, const char *what)
+{
+    memset(w, 0, sizeof *w);
+    pthread_mutex_init(&w->mu, NULL); pthread_cond_init(&w->cv, NULL);
+    w->secs = (int)fxh_env_long("FXH_RANK_TIMEOUT", 900, 1, 7 * 86400); w->rank = rank; w->world = world; w->what = what;
+    if (pthread_create(&w->th, NULL, fxh_watch_main, w) != 0) err(1, "pthread_create");
+}
+static void fxh_watch_stop(fxh_watch *w)
+{
+    pthread_mutex_lock(&w->mu);
+    w->done = 1;
+    pthread_cond_broadcast(&w->cv);
+    pthread_mutex_unlock(&w->mu);
+    pthread_join(w->th, NULL);
+}
+
+/* one exchange of the job: this rank's block up, ncclAllGather (fxg_epilogue_rccl), every rank's block and the totals back */
+static void fxh_rank_exchange(fxh_sf *S, fxh_lane *rl, fxg_comm *comm, uint64_t *d_block, const uint64_t *blk, uint64_t *totals, uint64_t *byte_off, uint64_t *gathered,
+                              const char *what)
+{
+    fxh_watch w;
+    uint64_t read_off = 0;
+    fxh_watch_start(&w, S->rank, S->world, what);
+    FXG_CHECK(&rl->st, fxg_memcpy_h2d(S->main_ctx, d_block, blk, FXG_NCOUNTERS * sizeof(uint64_t)));
+    const int erc = fxg_epilogue_rccl(S->main_ctx, comm, d_block, totals, &read_off, byte_off, gathered);
+    fxh_watch_stop(&w);
+    if (erc != 0) errx(1, "rank %d of %d: %s failed (%d): %s", S->rank, S->world, what, erc, fxg_last_error(S->main_ctx));
 }
 
 static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot, int rank, int world);
@@ -739,9 +792,9 @@ static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot,
     memset(&mine, 0, sizeof mine);
     for (int i = 0; i < ns; ++i) fxh_totals_add(&mine, &S->st[i].tot);
     if (ranked) {
-        /* The one exchange of the job: every rank's counter block, one ncclAllGather behind nothing (the strands have synchronised).  A rank that met
+        /* The exchange of the job: every rank's counter block, one ncclAllGather behind nothing (the strands have synchronised).  A rank that met
          * something irregular still takes part -- with its flag up -- so that ALL ranks leave together and rank 0 alone runs the input as one stream. */
-        uint64_t blk[FXG_NCOUNTERS] = {0}, totals[FXG_NCOUNTERS], read_off = 0, byte_off = 0;
+        uint64_t blk[FXG_NCOUNTERS] = {0}, totals[FXG_NCOUNTERS], byte_off = 0;
         uint64_t *gathered = (uint64_t *)calloc((size_t)world * FXG_NCOUNTERS, sizeof(uint64_t));
         if (!gathered) err(1, "out of memory");
         blk[FXH_B_IN_SEQ] = mine.input_sequences; blk[FXH_B_OUT_SEQ] = mine.output_sequences; blk[FXH_B_OUT_BYTES] = S->scan_off;
@@ -750,9 +803,7 @@ static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot,
         blk[FXG_C_CLIP_ADAPTER_FOUND] = mine.clip_adapter_found; blk[FXG_C_CLIP_N] = mine.clip_n; blk[FXG_C_QTRIM_DROPPED] = mine.qtrim_dropped;
         blk[FXG_C_MASKED_READS] = mine.masked_reads; blk[FXG_C_MASKED_NT] = mine.masked_nucleotides;
         blk[FXH_B_CLIP_LEN] = S->clip_len; blk[FXH_B_BAD] = bad ? FXH_BAD_IRREGULAR : 0;
-        FXG_CHECK(&rank_lane.st, fxg_memcpy_h2d(S->main_ctx, d_block, blk, sizeof blk));
-        const int erc = fxg_epilogue_rccl(S->main_ctx, comm, d_block, totals, &read_off, &byte_off, gathered);
-        if (erc != 0) errx(1, "rank %d of %d: the exchange of the counter blocks failed (%d): %s", rank, world, erc, fxg_last_error(S->main_ctx));
+        fxh_rank_exchange(S, &rank_lane, comm, d_block, blk, totals, &byte_off, gathered, "the exchange of the counter blocks");
         if (totals[FXH_B_BAD]) bad = 1;
         if (S->clip_auto) {                      /* the clipper is exact across ranks while ALL reads of the job have one length */
             uint64_t len0 = 0;
@@ -764,11 +815,10 @@ static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot,
         mine.clip_input = (unsigned)totals[FXH_B_CLIP_IN]; mine.clip_too_short = (unsigned)totals[FXG_C_CLIP_TOO_SHORT]; mine.clip_adapter_only = (unsigned)totals[FXG_C_CLIP_ADAPTER_ONLY];
         mine.clip_no_adapter = (unsigned)totals[FXG_C_CLIP_NO_ADAPTER]; mine.clip_adapter_found = (unsigned)totals[FXG_C_CLIP_ADAPTER_FOUND]; mine.clip_n = (unsigned)totals[FXG_C_CLIP_N];
         mine.qtrim_dropped = totals[FXG_C_QTRIM_DROPPED]; mine.masked_reads = totals[FXG_C_MASKED_READS]; mine.masked_nucleotides = totals[FXG_C_MASKED_NT];
-        free(gathered);
-        fxg_comm_destroy(comm);
         if (!bad) {
-            /* this rank's text: down from the arena in pieces, each written where it belongs -- base (the bytes of the ranks before) + its place in the arena */
-            if (ftruncate(w0->fd, (off_t)job_total) != 0) err(1, "writing output failed");      /* (every rank says the same size; no rank's bytes lie beyond it) */
+            /* this rank's text: down from the arena in pieces, each written where it belongs -- base (the bytes of the ranks before) + its place in the arena.
+             * A piece that does not get into the file (no space, a file size limit) is not died of here: the other ranks are waiting for this one. */
+            if (ftruncate(w0->fd, (off_t)job_total) != 0) S->drain_errno = errno;      /* (every rank says the same size; no rank's bytes lie beyond it) */
             enum { NB = 3 };
             const size_t piece = (size_t)fxh_env_long("FXH_DRAIN_MB", 32, 1, 1024) << 20;
             char *hb[NB]; int busy[NB] = {0, 0, 0}; fxh_djob dj[NB];
@@ -780,15 +830,34 @@ static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot,
                 const size_t n = S->scan_off - o < piece ? (size_t)(S->scan_off - o) : piece;
                 pthread_mutex_lock(&S->mu);
                 while (busy[k]) pthread_cond_wait(&S->cv, &S->mu);
-                busy[k] = 1;
+                const int failed = S->drain_errno;
+                if (!failed) busy[k] = 1;
                 pthread_mutex_unlock(&S->mu);
+                if (failed) break;
                 FXG_CHECK(&rank_lane.st, fxg_memcpy_d2h(S->main_ctx, hb[k], S->arena + o, n));
                 FXG_CHECK(&rank_lane.st, fxg_sync(S->main_ctx));
                 dj[k].S = S; dj[k].src = hb[k]; dj[k].len = n; dj[k].off = base + o; dj[k].busy = &busy[k];
                 fxh_pool_submit(&dpool, fxh_sf_drain_task, &dj[k]);
             }
             fxh_pool_stop(&dpool);
+            /* The job is done when EVERY rank's text is in the file, and rank 0's exit code says so: a second exchange, each rank's errno (0: written).  A rank
+             * that died on the way never joins it -- the watch (or the transport) ends the wait -- so rank 0 never reports a file that has a hole as done. */
+            uint64_t blk2[FXG_NCOUNTERS] = {0}, totals2[FXG_NCOUNTERS], off2 = 0;
+            blk2[FXH_B_BAD] = (uint64_t)S->drain_errno;
+            fxh_rank_exchange(S, &rank_lane, comm, d_block, blk2, totals2, &off2, gathered, "waiting for every rank to have written its part");
+            if (totals2[FXH_B_BAD]) {
+                if (S->drain_errno) warnx("rank %d of %d: writing output failed: %s", rank, world, strerror(S->drain_errno));
+                if (rank == 0)
+                    for (int g = 1; g < world; ++g) {
+                        const uint64_t e = gathered[(size_t)g * FXG_NCOUNTERS + FXH_B_BAD];
+                        if (e) warnx("rank %d of %d could not write its part of the output (%s): %s is incomplete", g, world, strerror((int)e), fx->output_file_name);
+                    }
+                fflush(NULL);
+                _exit(1);
+            }
         }
+        free(gathered);
+        fxg_comm_destroy(comm);
     }
     if (bad) {
         /* Abandoned.  Every thread has been joined, the contexts go, the file is emptied through its own descriptor -- which the parent

@@ -8,6 +8,7 @@
  *
  *   FXG_FAKE_RCCL_LOG=<file>      one line per call (the test counts them)
  *   FXG_FAKE_RCCL_FAIL=id|init|gather   the named call returns ncclInternalError (error paths of the transport)
+ *   FXG_FAKE_RCCL_TIMEOUT_S=<n>   how long a gather waits for the other ranks before it fails (default 30; 0 = for ever, like the real library)
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
@@ -76,7 +77,9 @@ static int barrier(struct comm *c)
 {
     const uint32_t gen = c->sh->generation;
     if (__sync_add_and_fetch(&c->sh->arrived, 1u) == (uint32_t)c->world) { c->sh->arrived = 0; __sync_synchronize(); c->sh->generation = gen + 1u; return 0; }
-    for (int tries = 0; c->sh->generation == gen; ++tries) { if (tries > 2000 * 30) return 3; usleep(500); }
+    const char *e = getenv("FXG_FAKE_RCCL_TIMEOUT_S");
+    const long limit = e && *e ? atol(e) : 30;
+    for (long tries = 0; c->sh->generation == gen; ++tries) { if (limit > 0 && tries > 2000 * limit) return 3; usleep(500); }
     return 0;
 }
 

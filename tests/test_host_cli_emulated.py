@@ -728,6 +728,52 @@ def test_rank_per_gpu_job_writes_the_one_file_and_rank0_reports(tools, tmp_path,
     assert all(p.returncode == 0 for p in ps) and outp.read_bytes() == (tmp_path / "single0").read_bytes() and all(o == b"" for o, _ in outs[1:])
 
 
+def test_rank_job_is_done_when_every_rank_has_written(tools, tmp_path):
+    """Rank 0's exit code is the job's.  After the ranks have written their parts they meet a second time (each rank's errno, 0 = written): a rank that could not
+    write -- here: a file size limit on rank 1 alone -- says so there, rank 0 names it and leaves with 1; a rank that DIED on the way never arrives, and
+    what ends rank 0's wait is the transport's own failure or, where the transport waits for ever (RCCL does), the watch (FXH_RANK_TIMEOUT)."""
+    import resource
+    import signal
+    import emu_py
+    fake = emu_py.build_fake_rccl()
+    text = fo.synth_fastq(47, 0, 40000, 100, False)
+    inp = tmp_path / "in.fq"
+    inp.write_bytes(text)
+    argv = ["fastx_reverse_complement", "-v"]
+
+    def job(out, limit_rank1, ignore_xfsz, extra):
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, LD_LIBRARY_PATH=STUB_DIR + os.pathsep + fake, FXH_THREADS="2", FXH_RANK=str(r), FXH_WORLD="2", FXH_STRAND_KB="256", FXH_STRANDS="2",
+                       FXH_DRAIN_MB="1", FXG_EMU_DEVICES="2", **extra)
+
+            def pre(r=r):
+                if r == 1 and limit_rank1:
+                    if ignore_xfsz:
+                        signal.signal(signal.SIGXFSZ, signal.SIG_IGN)       # (an ignored signal stays ignored across exec: the write then fails with EFBIG)
+                    resource.setrlimit(resource.RLIMIT_FSIZE, (65536, 65536))
+            procs.append(subprocess.Popen([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", str(out)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                          env=env, preexec_fn=pre))
+        return [(p.returncode, o, e) for p in procs for o, e in [p.communicate(timeout=120)]]
+
+    # the undisturbed job, for reference
+    ok = job(tmp_path / "ok.fq", False, False, {})
+    assert [rc for rc, _, _ in ok] == [0, 0] and len((tmp_path / "ok.fq").read_bytes()) == len(text)
+    # rank 1 cannot write (EFBIG): both ranks learn it in the second exchange; rank 0 names the rank and the reason, prints NO report, exit code 1
+    res = job(tmp_path / "efbig.fq", True, True, {})
+    assert res[0][0] == 1 and res[1][0] == 1, [e[-300:] for _, _, e in res]
+    assert b"rank 1 of 2 could not write its part of the output (File too large)" in res[0][2] and b"is incomplete" in res[0][2] and res[0][1] == b""
+    assert b"rank 1 of 2: writing output failed: File too large" in res[1][2]
+    # rank 1 is killed on the way (SIGXFSZ): it never joins the second exchange.  The fake transport gives up after 2 s ...
+    res = job(tmp_path / "dead.fq", True, False, {"FXG_FAKE_RCCL_TIMEOUT_S": "2"})
+    assert res[1][0] == -signal.SIGXFSZ and res[0][0] == 1 and res[0][1] == b"", [e[-300:] for _, _, e in res]
+    assert b"waiting for every rank to have written its part failed" in res[0][2]
+    # ... and with a transport that waits for ever, the watch ends rank 0
+    res = job(tmp_path / "dead2.fq", True, False, {"FXG_FAKE_RCCL_TIMEOUT_S": "0", "FXH_RANK_TIMEOUT": "2"})
+    assert res[1][0] == -signal.SIGXFSZ and res[0][0] == 1 and res[0][1] == b"", [e[-300:] for _, _, e in res]
+    assert b"no answer from the other ranks within 2 s (waiting for every rank to have written its part)" in res[0][2]
+
+
 def test_pipes_as_the_references_users_run_them(tools, tmp_path):
     """`trimmer | filter` and `cat in | tool > out` (the Galaxy wrappers' form): both ends of a pipe are raised to the system's limit (F_SETPIPE_SZ), blocks go into
     the pipe by vmsplice() except for their last pipe-capacity bytes (so that no page of a buffer is still in the pipe when the buffer is used again), the
