@@ -155,8 +155,12 @@ struct fxh_sf {
     uint8_t *arena;
     uint64_t arena_cap;
     int out_fd, mapped;
+    int prealloc;                          /* rank mode, rank 0, a tmpfs: the allocator makes the JOB's pages while the ranks compute (nobody copies meanwhile) */
     char *map;
     uint64_t map_len, alloc_end, need, window;
+    uint64_t alloc_in_total;               /* the input the allocator's estimate is about: this process's (strands) or the job's (rank 0 of a rank job) */
+    uint64_t alloc_final; int alloc_final_set;      /* the exact size, once known: strands -- every chunk published; rank job -- the exchange */
+    uint64_t map_base;                     /* rank mode: file offset of map[0] (the page this rank's slice starts in) */
     int alloc_errno, alloc_stop;
     int drain_errno;                       /* rank mode: errno of the first piece of this rank's text that did not get into the file */
     pthread_t th_alloc;
@@ -177,15 +181,15 @@ static void fxh_sf_abort(fxh_sf *S)
 static uint64_t fxh_sf_alloc_goal(const fxh_sf *S)
 {
     uint64_t goal;
-    if (S->published == S->nchunks) goal = S->scan_off;
+    if (S->alloc_final_set) goal = S->alloc_final;
     else if (S->in_done >= ((uint64_t)64 << 20)) {
         const long double r = (long double)S->out_done / (long double)S->in_done;
-        goal = (uint64_t)(r * 1.02L * (long double)S->in_total) + ((uint64_t)32 << 20);
+        goal = (uint64_t)(r * 1.02L * (long double)S->alloc_in_total) + ((uint64_t)32 << 20);
     } else {
-        goal = S->in_total / 4;
+        goal = S->alloc_in_total / 4;
         if (goal > ((uint64_t)8 << 30)) goal = (uint64_t)8 << 30;
     }
-    if (S->published != S->nchunks && goal < S->need) goal = S->need;
+    if (!S->alloc_final_set && goal < S->need) goal = S->need;
     if (goal > S->map_len) goal = S->map_len;
     return goal;
 }
@@ -203,7 +207,7 @@ static void *fxh_sf_alloc_main(void *arg)
     while (!S->alloc_stop && !FXH_ABORTED() && !S->alloc_errno) {
         const uint64_t goal = fxh_sf_alloc_goal(S);
         if (S->alloc_end >= goal) {
-            if (S->published == S->nchunks) break;          /* the whole output has its pages */
+            if (S->alloc_final_set) break;                   /* the whole output has its pages */
             pthread_cond_wait(&S->cv, &S->mu);
             continue;
         }
@@ -238,6 +242,7 @@ static void fxh_sf_publish(fxh_lane *ln, uint64_t bytes)
     S->size[t] = bytes; S->have[t] = 1; S->published++;
     S->in_done += (uint64_t)(S->cut[t + 1] - S->cut[t]); S->out_done += bytes;
     while (S->scanned < S->nchunks && S->have[S->scanned]) { S->offset[S->scanned] = S->scan_off; S->scan_off += S->size[S->scanned]; S->scanned++; }
+    if (S->published == S->nchunks && !S->prealloc) { S->alloc_final = S->scan_off; S->alloc_final_set = 1; }      /* (a rank job's size is the exchange's to say) */
     pthread_cond_broadcast(&S->cv);
     pthread_mutex_unlock(&S->mu);
 }
@@ -494,8 +499,16 @@ typedef struct { fxh_sf *S; const char *src; size_t len; uint64_t off; int *busy
 static void fxh_sf_drain_task(void *arg)
 {
     fxh_djob *j = (fxh_djob *)arg;
-    errno = 0;
-    const int e = fxg_concat_pwrite(j->S->out_fd, j->src, j->len, j->off) != 0 ? (errno ? errno : EIO) : 0;
+    int e = 0;
+    if (j->S->map) {                             /* pages that exist (rank 0 made them): a copy, and this thread drops its own page-table entries */
+        char *dst = j->S->map + (j->off - j->S->map_base);
+        memcpy(dst, j->src, j->len);
+        const uintptr_t a = ((uintptr_t)dst + 4095u) & ~(uintptr_t)4095u, b = ((uintptr_t)dst + j->len) & ~(uintptr_t)4095u;
+        if (b > a) (void)madvise((void *)a, (size_t)(b - a), MADV_DONTNEED);
+    } else {
+        errno = 0;
+        e = fxg_concat_pwrite(j->S->out_fd, j->src, j->len, j->off) != 0 ? (errno ? errno : EIO) : 0;
+    }
     pthread_mutex_lock(&j->S->mu);
     if (e && !j->S->drain_errno) j->S->drain_errno = e;       /* reported to the job (the second exchange), not died of: the other ranks are waiting */
     *j->busy = 0;
@@ -684,10 +697,28 @@ static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot,
         struct statfs fs;
         const char *sk = getenv("FXH_ONE_FILE_SINK");        /* "map" | "pwrite": force one (tests) */
         int want_map = sk ? strcmp(sk, "map") == 0 : (fstatfs(w0->fd, &fs) == 0 && (unsigned long)fs.f_type == (unsigned long)TMPFS_MAGIC);
-        if (w0->off != 0 || ranked) want_map = 0;
+        if (w0->off != 0) want_map = 0;
+        S->alloc_in_total = S->in_total;
+        S->window = (uint64_t)fxh_env_long("FXH_ONE_FILE_WINDOW_MB", 128, 1, 1 << 16) << 20;
+        if (want_map && ranked) {
+            /* A rank job: the ranks' text stays in HBM until the exchange, and then every rank wants the file at once -- through the one inode lock if the pages
+             * still have to be made.  So rank 0 makes the JOB's pages meanwhile: the same eager allocator, alone on the file (nobody copies before the exchange),
+             * towards the output expected from the WHOLE input at rank 0's own measured ratio, to the exact size once the exchange has said it.  The ranks then
+             * copy into pages that exist, each through a mapping of its own slice (separate processes: separate page tables). */
+            want_map = 0;
+            if (rank == 0) {
+                const uint64_t whole = (uint64_t)(file_size - start);
+                S->alloc_in_total = whole;
+                S->map_len = (whole + whole / 7 + (1u << 20) + 4095u) & ~(uint64_t)4095u;
+                if (fallocate(w0->fd, 0, 0, 4096) == 0) {
+                    S->prealloc = 1; S->alloc_end = 4096;
+                    pthread_rwlock_init(&S->gate, NULL);
+                    if (pthread_create(&S->th_alloc, NULL, fxh_sf_alloc_main, S) != 0) err(1, "pthread_create");
+                }
+            }
+        }
         if (want_map) {
             S->map_len = (S->in_total + S->in_total / 7 + (1u << 20) + 4095u) & ~(uint64_t)4095u;      /* an empty third line still gets its '+': at most 8/7 of the input */
-            S->window = (uint64_t)fxh_env_long("FXH_ONE_FILE_WINDOW_MB", 128, 1, 1 << 16) << 20;
             void *m = MAP_FAILED;
             if (ftruncate(w0->fd, (off_t)S->map_len) == 0) m = mmap(NULL, (size_t)S->map_len, PROT_READ | PROT_WRITE, MAP_SHARED, w0->fd, 0);
             if (m != MAP_FAILED && fallocate(w0->fd, 0, 0, 4096) == 0) {
@@ -709,7 +740,7 @@ static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot,
     cpu_set_t cpus_before;
     const double t_dev = fxh_now();
     if (ndev == 1) (void)fxh_bind_near_device(dev[0], &cpus_before);      /* buffers and the output's pages are touched (and page-locked) on the GPU's node; every thread below inherits it */
-    if (S->mapped) { cpu_set_t now_set; if (sched_getaffinity(0, sizeof now_set, &now_set) == 0) (void)pthread_setaffinity_np(S->th_alloc, sizeof now_set, &now_set); }
+    if (S->mapped || S->prealloc) { cpu_set_t now_set; if (sched_getaffinity(0, sizeof now_set, &now_set) == 0) (void)pthread_setaffinity_np(S->th_alloc, sizeof now_set, &now_set); }
     const double t_bound = fxh_now();
 
 
@@ -783,11 +814,13 @@ static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot,
     fxh_pool_stop(&S->wpool);
     pthread_mutex_lock(&S->mu);
     if (!bad && S->scanned != nchunks) bad = 1;
-    S->alloc_stop = 1;
+    if (!S->prealloc) S->alloc_stop = 1;        /* (a rank job's allocator goes on until the exchange has said the size) */
     pthread_cond_broadcast(&S->cv);
     pthread_mutex_unlock(&S->mu);
     if (S->mapped) pthread_join(S->th_alloc, NULL);
     uint64_t base = 0, job_total = S->scan_off;
+    double t_drain = 0, t_drain0 = 0;
+    int drained_by_copy = 0;
     fxh_totals mine;
     memset(&mine, 0, sizeof mine);
     for (int i = 0; i < ns; ++i) fxh_totals_add(&mine, &S->st[i].tot);
@@ -815,15 +848,45 @@ static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot,
         mine.clip_input = (unsigned)totals[FXH_B_CLIP_IN]; mine.clip_too_short = (unsigned)totals[FXG_C_CLIP_TOO_SHORT]; mine.clip_adapter_only = (unsigned)totals[FXG_C_CLIP_ADAPTER_ONLY];
         mine.clip_no_adapter = (unsigned)totals[FXG_C_CLIP_NO_ADAPTER]; mine.clip_adapter_found = (unsigned)totals[FXG_C_CLIP_ADAPTER_FOUND]; mine.clip_n = (unsigned)totals[FXG_C_CLIP_N];
         mine.qtrim_dropped = totals[FXG_C_QTRIM_DROPPED]; mine.masked_reads = totals[FXG_C_MASKED_READS]; mine.masked_nucleotides = totals[FXG_C_MASKED_NT];
+        /* rank 0: the job's pages, to the byte (or, abandoned: the allocator stops where it is; the file is emptied below) */
+        int pages = 0, alloc_e = 0;
+        if (S->prealloc) {
+            pthread_mutex_lock(&S->mu);
+            if (bad) S->alloc_stop = 1; else { S->alloc_final = job_total; S->alloc_final_set = 1; }
+            pthread_cond_broadcast(&S->cv);
+            pthread_mutex_unlock(&S->mu);
+            pthread_join(S->th_alloc, NULL);
+            alloc_e = S->alloc_errno;
+            if (!bad && !alloc_e && ftruncate(w0->fd, (off_t)job_total) != 0) alloc_e = errno;      /* what the estimate overshot goes back */
+            pages = !bad && !alloc_e;
+        }
         if (!bad) {
-            /* this rank's text: down from the arena in pieces, each written where it belongs -- base (the bytes of the ranks before) + its place in the arena.
+            /* "the pages are there" (or not: another file system -- positional writes then): rank 0 says, everybody hears; also the barrier between the last
+             * fallocate() and the first copy */
+            uint64_t blkp[FXG_NCOUNTERS] = {0}, totalsp[FXG_NCOUNTERS], offp = 0;
+            blkp[FXH_B_IN_SEQ] = (uint64_t)pages; blkp[FXH_B_BAD] = (uint64_t)alloc_e;
+            fxh_rank_exchange(S, &rank_lane, comm, d_block, blkp, totalsp, &offp, gathered, "waiting for rank 0 to have made the output file's pages");
+            if (totalsp[FXH_B_BAD]) {
+                if (rank == 0) warnx("writing output failed: %s", strerror(alloc_e));
+                fflush(NULL);
+                _exit(1);
+            }
+            pages = gathered[FXH_B_IN_SEQ] != 0;         /* (rank 0's block) */
+            /* this rank's text: down from the arena in pieces, each put where it belongs -- base (the bytes of the ranks before) + its place in the arena.
              * A piece that does not get into the file (no space, a file size limit) is not died of here: the other ranks are waiting for this one. */
-            if (ftruncate(w0->fd, (off_t)job_total) != 0) S->drain_errno = errno;      /* (every rank says the same size; no rank's bytes lie beyond it) */
-            enum { NB = 3 };
+            t_drain0 = fxh_now();
+            if (pages && S->scan_off) {
+                S->map_base = base & ~(uint64_t)4095u;
+                void *m = mmap(NULL, (size_t)(base + S->scan_off - S->map_base), PROT_READ | PROT_WRITE, MAP_SHARED, w0->fd, (off_t)S->map_base);
+                if (m != MAP_FAILED) S->map = (char *)m;      /* (no mapping -- a descriptor without read access --: positional writes into the same pages) */
+            }
+            if (!pages && ftruncate(w0->fd, (off_t)job_total) != 0) S->drain_errno = errno;      /* (every rank says the same size; no rank's bytes lie beyond it) */
+            enum { NBMAX = 9 };
             const size_t piece = (size_t)fxh_env_long("FXH_DRAIN_MB", 32, 1, 1024) << 20;
-            char *hb[NB]; int busy[NB] = {0, 0, 0}; fxh_djob dj[NB];
+            const int nth = (int)fxh_env_long("FXH_DRAIN_THREADS", S->map ? 4 : 2, 1, NBMAX - 1), NB = nth + 1;      /* copies want company, writers only queue at the inode */
+            char *hb[NBMAX]; int busy[NBMAX] = {0}; fxh_djob dj[NBMAX];
             fxh_pool dpool;
-            fxh_pool_start(&dpool, 2, NB);
+            fxh_pool_start(&dpool, nth, (unsigned)NB);
             for (int k = 0; k < NB; ++k) FXG_CHECK(&rank_lane.st, fxg_malloc_host(S->main_ctx, piece, (void **)&hb[k]));
             int k = 0;
             for (uint64_t o = 0; o < S->scan_off; o += piece, k = (k + 1) % NB) {
@@ -840,6 +903,9 @@ static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot,
                 fxh_pool_submit(&dpool, fxh_sf_drain_task, &dj[k]);
             }
             fxh_pool_stop(&dpool);
+            drained_by_copy = S->map != NULL;
+            if (S->map) { munmap(S->map, (size_t)(base + S->scan_off - S->map_base)); S->map = NULL; }
+            t_drain = fxh_now() - t_drain0;
             /* The job is done when EVERY rank's text is in the file, and rank 0's exit code says so: a second exchange, each rank's errno (0: written).  A rank
              * that died on the way never joins it -- the watch (or the transport) ends the wait -- so rank 0 never reports a file that has a hole as done. */
             uint64_t blk2[FXG_NCOUNTERS] = {0}, totals2[FXG_NCOUNTERS], off2 = 0;
@@ -894,8 +960,10 @@ static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot,
                         "sink: %llu fallocate calls %.3f s (to %.2f GB for %.2f GB of output), copies %.3f s + %.3f s at the gate (summed over %d threads)\n",
                 ns, ndev, (unsigned long long)nchunks, S->mapped ? "gated mapping" : "pwrite", fxh_now() - t_run0, t_dev - t_run0, t_bound - t_dev, init, rd_s, win, gpu_s, wout, woff, rel,
                 (unsigned long long)S->alloc_calls, S->t_alloc, 1e-9 * (double)S->alloc_end, 1e-9 * (double)total, S->t_copy, S->t_copy_wait, S->wpool.nth);
-        if (ranked) fprintf(stderr, "fxh timing rank %d of %d: input bytes [%lld, %lld), %.3f GB of text held on the device, written at offset %llu of %llu\n", rank, world,
-                               (long long)my_start, (long long)my_end, 1e-9 * (double)S->scan_off, (unsigned long long)base, (unsigned long long)job_total);
+        if (ranked) fprintf(stderr, "fxh timing rank %d of %d: input bytes [%lld, %lld), %.3f GB of text held on the device, written at offset %llu of %llu in %.3f s (%s)\n", rank, world,
+                               (long long)my_start, (long long)my_end, 1e-9 * (double)S->scan_off, (unsigned long long)base, (unsigned long long)job_total, t_drain,
+                               drained_by_copy ? "copies into pages rank 0 made" : "positional writes");
+        if (S->prealloc) fprintf(stderr, "fxh timing rank 0: the job's pages: %llu fallocate calls, %.3f s\n", (unsigned long long)S->alloc_calls, S->t_alloc);
     }
     if (rank > 0) {                              /* the job's report is rank 0's */
         if (w0->fd != STDOUT_FILENO) close(w0->fd);

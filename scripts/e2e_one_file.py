@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end matrix of the default command line `tool -i in.fq -o out.fq` on the GPU box (not a test): FASTQ on tmpfs -> fastq_quality_trim_filter -> ONE
 file on tmpfs.  READS (default 64 M); MATRIX = comma-separated runs, each a ':'-separated list of ENV=VAL (empty = the default invocation, no
-environment at all); the first run is the one-stream reference (FXH_ONE_FILE=0) whose md5 the others must have."""
+environment at all); the first run is the one-stream reference (FXH_ONE_FILE=0) whose md5 the others must have.  RANKS=n in an item: a rank job of n processes sharing the GPU."""
 import hashlib
 import os
 import subprocess
@@ -49,9 +49,22 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as td:
             if os.path.exists(out):
                 os.unlink(out)
             t0 = time.perf_counter()
-            p = subprocess.run([tool] + tool_args + ["-i", inp, "-o", out], env=env, stderr=subprocess.PIPE)
-            dt = time.perf_counter() - t0
-            assert p.returncode == 0, p.stderr[-500:]
+            nranks = int(env.get("RANKS", "1"))
+            if nranks > 1:         # a rank job on this box's ONE GPU: the ranks share it, the exchanges go through the test transport (tests/emu/fake_rccl.c, HIP copies)
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import emu_py
+                renv = dict(env, LD_LIBRARY_PATH=emu_py.build_fake_rccl() + os.pathsep + env.get("LD_LIBRARY_PATH", ""), FXG_FAKE_RCCL_HIP="1", FXH_WORLD=str(nranks), FXG_DEVICE="0")
+                ps = [subprocess.Popen([tool] + tool_args + ["-i", inp, "-o", out], env=dict(renv, FXH_RANK=str(r)), stderr=subprocess.PIPE) for r in range(nranks)]
+                errs = [q.communicate()[1] for q in ps]
+                dt = time.perf_counter() - t0
+                assert all(q.returncode == 0 for q in ps), [e[-300:] for e in errs]
+
+                class p:
+                    stderr = b"".join(errs)
+            else:
+                p = subprocess.run([tool] + tool_args + ["-i", inp, "-o", out], env=env, stderr=subprocess.PIPE)
+                dt = time.perf_counter() - t0
+                assert p.returncode == 0, p.stderr[-500:]
             walls.append(dt)
             if best is None or dt < best:
                 best, errtxt = dt, p.stderr

@@ -698,6 +698,17 @@ def test_rank_per_gpu_job_writes_the_one_file_and_rank0_reports(tools, tmp_path,
         spans = sorted((int(l.split("[")[1].split(",")[0]), int(l.split(", ")[1].split(")")[0])) for l in lines)
         assert spans[0][0] == 0 and spans[-1][1] == len(data) and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))      # the ranges tile the input
         assert not os.path.exists(str(multi) + ".rdv")
+        assert all("positional writes" in l for l in lines)              # (not a tmpfs)
+        # the same job with the sink a tmpfs gets: rank 0 makes the JOB's pages while the ranks compute (eager fallocate towards the expected size, exact after the
+        # exchange), a third exchange is the barrier, every rank copies into a mapping of its own slice -- no rank allocates under the one inode lock
+        paged = tmp_path / ("paged%d" % i)
+        paged.write_bytes(b"stale bytes of an earlier run, longer than nothing\n" * 3)
+        res = _rank_job(tools, argv, inp, paged, world, tmp_path, extra={"FXH_ONE_FILE_SINK": "map", "FXH_ONE_FILE_WINDOW_MB": "1"})
+        assert all(rc == 0 for rc, _, _ in res), [e[-300:] for _, _, e in res]
+        assert paged.read_bytes() == single.read_bytes() and res[0][1] == want[1], (argv, world)
+        lines = [l for _, _, e in res for l in e.decode().splitlines() if l.startswith("fxh timing rank ") and " of " in l.split(":")[0]]
+        assert len(lines) == world and all("copies into pages rank 0 made" in l for l in lines), lines
+        assert b"fxh timing rank 0: the job's pages:" in res[0][2]
     # irregular input in one rank's range: EVERY rank leaves (flag in the exchanged block), rank 0 runs the input as one stream -> the reference's behaviour
     k0 = text.index(b"\n@", int(len(text) * 0.7)) + 1
     bad = text[:k0] + b"#" + text[k0 + 1:]
@@ -708,6 +719,8 @@ def test_rank_per_gpu_job_writes_the_one_file_and_rank0_reports(tools, tmp_path,
     assert w[0] == 1 and res[0][0] == 1 and all(rc == 0 for rc, _, _ in res[1:]), [e[-300:] for _, _, e in res]
     assert _msg(res[0][2].splitlines()[-1]) == _msg(w[2].splitlines()[-1])
     assert (tmp_path / "bad_ranks.fq").read_bytes() == (tmp_path / "bad_single.fq").read_bytes()
+    res = _rank_job(tools, argv, inp, tmp_path / "bad_paged.fq", world, tmp_path, extra={"FXH_ONE_FILE_SINK": "map", "FXH_ONE_FILE_WINDOW_MB": "1"})      # (rank 0's allocator is stopped, its pages go)
+    assert res[0][0] == 1 and all(rc == 0 for rc, _, _ in res[1:]) and (tmp_path / "bad_paged.fq").read_bytes() == (tmp_path / "bad_single.fq").read_bytes()
     # the clipper on reads that are not all of one length: the same way out, and the one-stream run goes serial where it must
     lines = clip_text.split(b"\n")[:-1]
     for i in range(len(lines) // 4 * 6 // 10 * 4, len(lines), 8):

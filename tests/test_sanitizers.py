@@ -119,6 +119,9 @@ def test_tools_under_sanitizers(san, tmp_path):
                  (["fastx_clipper", "-a", ad, "-l", "15", "-v", "-i", str(rag), "-o", str(tmp_path / ("one_rag_%s.fq" % sink))], b"", dict(one, FXH_ONE_FILE_SINK=sink))]
     runs.append((["fastq_quality_trim_filter", "-t", "20", "-l", "30", "-q", "20", "-p", "80", "-v", "-i", str(big), "-o", str(tmp_path / "rankmode.fq")], b"",
                  dict(one, FXH_RANK_MODE="1", FXH_DRAIN_MB="1", LD_LIBRARY_PATH=STUB_DIR + os.pathsep + emu_py.build_fake_rccl())))
+    # ... and with the sink a tmpfs gets: rank 0's allocator for the job's pages, the barrier exchange, copies into a mapping of the slice, the watch threads
+    runs.append((["fastx_reverse_complement", "-v", "-i", str(big), "-o", str(tmp_path / "rankmode_paged.fq")], b"",
+                 dict(one, FXH_RANK_MODE="1", FXH_DRAIN_MB="1", FXH_ONE_FILE_SINK="map", LD_LIBRARY_PATH=STUB_DIR + os.pathsep + emu_py.build_fake_rccl())))
     for name, data in _corner_inputs().items():
         for argv in (["fastq_quality_trimmer", "-t", "20", "-l", "2"], ["fastx_trimmer", "-f", "2", "-l", "9"], ["fastx_reverse_complement"]):
             runs.append((argv, data, {"FXH_READ_BUFFER_MB": "1"} if len(data) % 2 else {}))
