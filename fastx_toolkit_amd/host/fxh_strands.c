@@ -159,6 +159,9 @@ struct fxh_sf {
     char *map;
     uint64_t map_len, alloc_end, need, window;
     uint64_t alloc_in_total;               /* the input the allocator's estimate is about: this process's (strands) or the job's (rank 0 of a rank job) */
+    uint64_t ratio_after;                  /* input bytes that must have been decided before the measured output/input ratio counts (64 MB) */
+    int keep_surplus;                      /* FXH_ONE_FILE_KEEP_SURPLUS=1: measurements of the run without it */
+    uint64_t given_back;                   /* pages the head start made and the output turned out not to need, returned during the run */
     uint64_t alloc_final; int alloc_final_set;      /* the exact size, once known: strands -- every chunk published; rank job -- the exchange */
     uint64_t map_base;                     /* rank mode: file offset of map[0] (the page this rank's slice starts in) */
     int alloc_errno, alloc_stop;
@@ -182,9 +185,9 @@ static uint64_t fxh_sf_alloc_goal(const fxh_sf *S)
 {
     uint64_t goal;
     if (S->alloc_final_set) goal = S->alloc_final;
-    else if (S->in_done >= ((uint64_t)64 << 20)) {
+    else if (S->in_done >= S->ratio_after && S->in_done) {
         const long double r = (long double)S->out_done / (long double)S->in_done;
-        goal = (uint64_t)(r * 1.02L * (long double)S->alloc_in_total) + ((uint64_t)32 << 20);
+        goal = (uint64_t)(r * 1.02L * (long double)S->alloc_in_total) + S->window / 4;
     } else {
         goal = S->alloc_in_total / 4;
         if (goal > ((uint64_t)8 << 30)) goal = (uint64_t)8 << 30;
@@ -208,6 +211,22 @@ static void *fxh_sf_alloc_main(void *arg)
         const uint64_t goal = fxh_sf_alloc_goal(S);
         if (S->alloc_end >= goal) {
             if (S->alloc_final_set) break;                   /* the whole output has its pages */
+            /* A tool that keeps little: the head start (a quarter of the input, made before anything was known) is several times what the output will take.
+             * Those pages go back NOW, in the shadow of the run, instead of in the ftruncate() at its end, which the caller waits for.  What stays -- the
+             * estimate plus a window -- lies above every byte a copy can be holding: off + len <= bytes decided so far <= the estimate. */
+            if (S->mapped && !S->keep_surplus && S->in_done >= S->ratio_after && S->in_done && S->alloc_end > 2 * goal + S->window) {
+                const uint64_t keep = (goal + S->window + 4095u) & ~(uint64_t)4095u, end = S->alloc_end;
+                S->alloc_end = keep;                         /* first: nobody starts a copy beyond it from here on */
+                pthread_mutex_unlock(&S->mu);
+                pthread_rwlock_wrlock(&S->gate);
+                const double t0 = fxh_now();
+                (void)fallocate(S->out_fd, FALLOC_FL_PUNCH_HOLE | FALLOC_FL_KEEP_SIZE, (off_t)keep, (off_t)(end - keep));      /* (if it fails the pages stay until the end, as before) */
+                const double dt = fxh_now() - t0;
+                pthread_rwlock_unlock(&S->gate);
+                pthread_mutex_lock(&S->mu);
+                S->t_alloc += dt; S->given_back += end - keep;
+                continue;
+            }
             pthread_cond_wait(&S->cv, &S->mu);
             continue;
         }
@@ -700,6 +719,8 @@ static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot,
         if (w0->off != 0) want_map = 0;
         S->alloc_in_total = S->in_total;
         S->window = (uint64_t)fxh_env_long("FXH_ONE_FILE_WINDOW_MB", 128, 1, 1 << 16) << 20;
+        S->ratio_after = (uint64_t)fxh_env_long("FXH_ONE_FILE_RATIO_MB", 64, 0, 1 << 20) << 20;
+        S->keep_surplus = getenv("FXH_ONE_FILE_KEEP_SURPLUS") != NULL;
         if (want_map && ranked) {
             /* A rank job: the ranks' text stays in HBM until the exchange, and then every rank wants the file at once -- through the one inode lock if the pages
              * still have to be made.  So rank 0 makes the JOB's pages meanwhile: the same eager allocator, alone on the file (nobody copies before the exchange),
@@ -957,9 +978,9 @@ static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot,
                         1e3 * s->ln.t_call[4] / s->ln.t_call[7], 1e3 * s->ln.t_call[5] / s->ln.t_call[7], 1e3 * s->ln.t_call[6] / s->ln.t_call[7]);
         }
         fprintf(stderr, "fxh timing one file (%d strands on %d GPU(s), %llu chunks, sink %s): run %.3f s (set-up %.3f, placement %.3f); summed over strands: context %.3f read %.3f wait-input %.3f device %.3f wait-outbuf %.3f wait-offset %.3f release %.3f; "
-                        "sink: %llu fallocate calls %.3f s (to %.2f GB for %.2f GB of output), copies %.3f s + %.3f s at the gate (summed over %d threads)\n",
+                        "sink: %llu fallocate calls %.3f s (to %.2f GB for %.2f GB of output, %.1f MB given back on the way), copies %.3f s + %.3f s at the gate (summed over %d threads)\n",
                 ns, ndev, (unsigned long long)nchunks, S->mapped ? "gated mapping" : "pwrite", fxh_now() - t_run0, t_dev - t_run0, t_bound - t_dev, init, rd_s, win, gpu_s, wout, woff, rel,
-                (unsigned long long)S->alloc_calls, S->t_alloc, 1e-9 * (double)S->alloc_end, 1e-9 * (double)total, S->t_copy, S->t_copy_wait, S->wpool.nth);
+                (unsigned long long)S->alloc_calls, S->t_alloc, 1e-9 * (double)S->alloc_end, 1e-9 * (double)total, 1e-6 * (double)S->given_back, S->t_copy, S->t_copy_wait, S->wpool.nth);
         if (ranked) fprintf(stderr, "fxh timing rank %d of %d: input bytes [%lld, %lld), %.3f GB of text held on the device, written at offset %llu of %llu in %.3f s (%s)\n", rank, world,
                                (long long)my_start, (long long)my_end, 1e-9 * (double)S->scan_off, (unsigned long long)base, (unsigned long long)job_total, t_drain,
                                drained_by_copy ? "copies into pages rank 0 made" : "positional writes");
