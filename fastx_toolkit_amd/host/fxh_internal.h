@@ -23,6 +23,9 @@ struct fxh_writer {
     int positional;         /* plain output to a regular file: positional writes from `off` on */
     off_t off;
     size_t pipe_size;       /* > 0: the output is a pipe of this capacity (enlarged to the system's limit when the writer was opened) */
+    int fan_n, fan_off;     /* pipe output: private pipes that writer threads fill side by side and whose pages are moved on into the output pipe in order (fxh_pipe_write_all) */
+    int fan_r[4], fan_w[4];
+    size_t fan_piece;
 };
 
 /* one record as slices of the reader's buffer (valid until the next fill) */

@@ -43,6 +43,128 @@ static int fxh_io_threads(void)
     return (int)n;
 }
 
+/* ---- a pipe as input ----
+ * read() copies out of a pipe under the pipe's lock: one thread, 4.7 GB/s, and that was what `trimmer | filter` ran at.  splice() from a pipe into another pipe
+ * moves page references and copies nothing, so the reading thread only deals the incoming pages out -- a pipe-capacity at a time, round robin -- to a few
+ * private pipes, and one thread per private pipe does the copying, side by side, each piece straight to its place in the block.  (The pages may stay in the
+ * private pipes a little longer than they would have stayed in the one they came through; a writer that hands over pages it will write to again is wrong with
+ * any splicing reader -- pv is one -- and the tools here hand over pages of their own, fastx_io.c: fxh_pipe_write_all.) */
+#define FXH_FAN_MAX 8
+typedef struct { char *dst; size_t n; } fxh_fan_piece;
+typedef struct {
+    int rfd, wfd;
+    pthread_t th;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    fxh_fan_piece q[64];
+    unsigned head, count;
+    int quit;
+    size_t pending, newlines;          /* pieces dealt but not yet in the block; '\n' bytes among the finished ones */
+} fxh_fan_lane;
+struct fxh_fan { int n, next; size_t piece; fxh_fan_lane lane[FXH_FAN_MAX]; };
+
+static void *fxh_fan_main(void *arg)
+{
+    fxh_fan_lane *L = (fxh_fan_lane *)arg;
+    pthread_mutex_lock(&L->mu);
+    for (;;) {
+        while (L->count == 0 && !L->quit) pthread_cond_wait(&L->cv, &L->mu);
+        if (L->count == 0) break;
+        const fxh_fan_piece pc = L->q[L->head];
+        L->head = (L->head + 1) % 64u; L->count--;
+        pthread_cond_broadcast(&L->cv);
+        pthread_mutex_unlock(&L->mu);
+        size_t got = 0;
+        while (got < pc.n) {
+            const ssize_t k = read(L->rfd, pc.dst + got, pc.n - got);
+            if (k < 0) { if (errno == EINTR) continue; err(1, "read failed"); }
+            if (k == 0) errx(1, "read failed");      /* (cannot happen: the bytes were in the pipe when the piece was queued) */
+            got += (size_t)k;
+        }
+        const size_t nl = fxh_count_newlines(pc.dst, pc.n);
+        pthread_mutex_lock(&L->mu);
+        L->newlines += nl; L->pending--;
+        pthread_cond_broadcast(&L->cv);
+    }
+    pthread_mutex_unlock(&L->mu);
+    return NULL;
+}
+
+static struct fxh_fan *fxh_fan_open(void)
+{
+    const char *e = getenv("FXH_PIPE_READERS");
+    long n = e ? atol(e) : 3;
+    if (n < 2 || getenv("FXH_NO_PIPE_FANOUT")) return NULL;
+    if (n > FXH_FAN_MAX) n = FXH_FAN_MAX;
+    struct fxh_fan *F = (struct fxh_fan *)calloc(1, sizeof *F);
+    if (!F) return NULL;
+    F->piece = (size_t)1 << 20;
+    for (int i = 0; i < (int)n; ++i) {
+        int pfd[2];
+        if (pipe2(pfd, O_CLOEXEC) != 0) break;
+        fxh_fan_lane *L = &F->lane[i];
+        L->rfd = pfd[0]; L->wfd = pfd[1];
+        const size_t cap = fxh_tune_pipe(L->wfd);
+        if (cap && cap < F->piece) F->piece = cap;
+        pthread_mutex_init(&L->mu, NULL); pthread_cond_init(&L->cv, NULL);
+        if (pthread_create(&L->th, NULL, fxh_fan_main, L) != 0) { close(pfd[0]); close(pfd[1]); break; }
+        F->n = i + 1;
+    }
+    if (F->n < 2) {                    /* (no descriptors, no threads: the plain loop) */
+        for (int i = 0; i < F->n; ++i) { fxh_fan_lane *L = &F->lane[i]; pthread_mutex_lock(&L->mu); L->quit = 1; pthread_cond_broadcast(&L->cv); pthread_mutex_unlock(&L->mu); pthread_join(L->th, NULL); close(L->rfd); close(L->wfd); }
+        free(F);
+        return NULL;
+    }
+    return F;
+}
+
+static void fxh_fan_close(struct fxh_fan *F)
+{
+    if (!F) return;
+    for (int i = 0; i < F->n; ++i) {
+        fxh_fan_lane *L = &F->lane[i];
+        pthread_mutex_lock(&L->mu); L->quit = 1; pthread_cond_broadcast(&L->cv); pthread_mutex_unlock(&L->mu);
+        pthread_join(L->th, NULL);
+        close(L->rfd); close(L->wfd);
+    }
+    free(F);
+}
+
+/* fills dst[0, cap) from the pipe `fd` (less only at its end).  -1: the descriptor cannot be spliced from (nothing has been taken): use read() */
+static long long fxh_fan_fill(struct fxh_fan *F, int fd, char *dst, size_t cap, int *eof, size_t *newlines)
+{
+    size_t got = 0;
+    while (got < cap) {
+        fxh_fan_lane *L = &F->lane[F->next];
+        const size_t want = cap - got < F->piece ? cap - got : F->piece;
+        const ssize_t k = splice(fd, NULL, L->wfd, NULL, want, SPLICE_F_MOVE);
+        if (k < 0) {
+            if (errno == EINTR) continue;
+            if (got == 0 && (errno == EINVAL || errno == ENOSYS || errno == EBADF)) return -1;
+            err(1, "read failed");
+        }
+        if (k == 0) { *eof = 1; break; }
+        pthread_mutex_lock(&L->mu);
+        while (L->count == 64u) pthread_cond_wait(&L->cv, &L->mu);
+        L->q[(L->head + L->count) % 64u].dst = dst + got; L->q[(L->head + L->count) % 64u].n = (size_t)k;
+        L->count++; L->pending++;
+        pthread_cond_broadcast(&L->cv);
+        pthread_mutex_unlock(&L->mu);
+        got += (size_t)k;
+        F->next = (F->next + 1) % F->n;
+    }
+    size_t nl = 0;
+    for (int i = 0; i < F->n; ++i) {   /* the block is whole when every piece is in place */
+        fxh_fan_lane *L = &F->lane[i];
+        pthread_mutex_lock(&L->mu);
+        while (L->pending) pthread_cond_wait(&L->cv, &L->mu);
+        nl += L->newlines; L->newlines = 0;
+        pthread_mutex_unlock(&L->mu);
+    }
+    *newlines = nl;
+    return (long long)got;
+}
+
 static void *fxh_prefetch_main(void *arg)
 {
     fxh_prefetch *pf = (fxh_prefetch *)arg;
@@ -83,7 +205,13 @@ static void *fxh_prefetch_main(void *arg)
                 newlines = nl;
             }
         } else {
-            while (gap + got < cap) {
+            if (pf->fifo && !pf->fan) { pf->fan = fxh_fan_open(); if (!pf->fan) pf->fifo = 0; }
+            if (pf->fan) {
+                const long long k = fxh_fan_fill(pf->fan, pf->fd, buf + gap, cap - gap, &eof, &newlines);
+                if (k < 0) { fxh_fan_close(pf->fan); pf->fan = NULL; pf->fifo = 0; newlines = (size_t)-1; }
+                else got = (size_t)k;
+            }
+            while (!pf->fan && gap + got < cap) {
                 ssize_t k = read(pf->fd, buf + gap + got, cap - gap - got);
                 if (k < 0) { if (errno == EINTR) continue; err(1, "read failed"); }
                 if (k == 0) { eof = 1; break; }
@@ -96,6 +224,8 @@ static void *fxh_prefetch_main(void *arg)
         pthread_cond_broadcast(&pf->cv);
     }
     pthread_mutex_unlock(&pf->mu);
+    fxh_fan_close(pf->fan);
+    pf->fan = NULL;
     return NULL;
 }
 
@@ -105,6 +235,8 @@ static void fxh_prefetch_probe(fxh_prefetch *pf, int fd)
     struct stat sb;
     const off_t pos = lseek(fd, 0, SEEK_CUR);
     pf->regular = (pos >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) ? 1 : 0;
+    pf->fifo = !pf->regular && fstat(fd, &sb) == 0 && S_ISFIFO(sb.st_mode);
+    pf->fan = NULL;
     pf->offset = pos;
     pf->io_threads = fxh_io_threads();
     { const char *e = getenv("FXH_IO_SLICE_MB"); const long v = e ? atol(e) : 0; pf->io_slice = (size_t)(v >= 1 && v <= 1024 ? v : (g_parts_mode ? 2 : 4)) << 20; }

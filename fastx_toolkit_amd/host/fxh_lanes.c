@@ -119,13 +119,9 @@ void fxh_lane_run(fxh_lane *ln)
     }
     const int s = ln->slot;
     if (ln->out_cap[s] < out_bytes + 16) {
-        if (ln->out[s]) { if (ln->out_plain) { (void)fxg_host_unregister(st->ctx, ln->out[s]); free(ln->out[s]); } else fxg_free_host(st->ctx, ln->out[s]); }
+        if (ln->out[s]) fxg_free_host(st->ctx, ln->out[s]);
         ln->out_cap[s] = (size_t)out_bytes + (size_t)out_bytes / 8 + 4096;
-        if (ln->out_plain) {              /* output into a pipe: ordinary pages, page-locked in place, which vmsplice() can hand to the pipe (the runtime's own host allocations are device mappings it cannot) */
-            ln->out_cap[s] = (ln->out_cap[s] + 4095u) & ~(size_t)4095u;
-            if (posix_memalign((void **)&ln->out[s], 4096, ln->out_cap[s]) != 0) err(1, "out of memory");
-            (void)fxg_host_register(st->ctx, ln->out[s], ln->out_cap[s]);
-        } else FXG_CHECK(st, fxg_malloc_host(st->ctx, ln->out_cap[s], (void **)&ln->out[s]));
+        FXG_CHECK(st, fxg_malloc_host(st->ctx, ln->out_cap[s], (void **)&ln->out[s]));
     }
     FXG_CHECK(st, fxg_memcpy_d2h(st->ctx, ln->out[s], st->d_out_text, out_bytes));
     FXG_CHECK(st, fxg_sync(st->ctx));
@@ -164,7 +160,7 @@ void fxh_lane_release(fxh_lane *ln)
     void *dev[] = {st->d_text, st->d_out_text, st->d_ls, st->d_len16, st->d_flags, st->d_bases, st->d_qual, st->d_len, st->d_res, st->d_out_bases, st->d_out_qual, st->d_out_off, st->d_counters};
     for (size_t i = 0; i < sizeof dev / sizeof dev[0]; ++i) if (dev[i]) (void)fxg_free_device(st->ctx, dev[i]);
     for (int i = 0; i < FXH_LANE_OUT_SLOTS; ++i) if (ln->out[i]) {
-        if (ln->out_plain) { (void)fxg_host_unregister(st->ctx, ln->out[i]); free(ln->out[i]); } else (void)fxg_free_host(st->ctx, ln->out[i]);
+        (void)fxg_free_host(st->ctx, ln->out[i]);
         ln->out[i] = NULL; ln->out_cap[i] = 0;
     }
     fxg_ctx_destroy(st->ctx);
@@ -347,7 +343,6 @@ static fxh_lane *fxh_lanes_start(fxh_run *R, int nlanes, const int *lane_dev)
         ln->pinned = pinned; ln->first = &lanes[0];
         if ((R->p->stages & FXG_STAGE_CLIP) && !R->clip_auto) { ln->clip_history = 1; R->st_shared = 1; }      /* (one lane: fxh_run_impl saw to that) */
         ln->clip_guard = R->clip_auto;
-        ln->out_plain = fx->writer && fx->writer->pipe_size > 0;
         pthread_mutex_init(&ln->mu, NULL); pthread_cond_init(&ln->cv, NULL);
         if (pthread_create(&ln->th, NULL, fxh_lane_main, ln) != 0) err(1, "pthread_create");
     }

@@ -119,6 +119,8 @@ typedef struct {
     int regular, io_threads;           /* regular file: parallel pread() from `offset` on */
     size_t io_slice;                   /* smallest piece worth a thread of its own */
     off_t offset, limit;               /* limit > 0: the input ends at this file offset (a part of a sharded run) */
+    int fifo;                          /* the input is a pipe: copied out of it by several threads (fxh_io.c: fxh_fan) */
+    struct fxh_fan *fan;
 } fxh_prefetch;
 
 typedef struct {
@@ -166,7 +168,6 @@ typedef struct fxh_lane {
     int clip_guard;                        /* clipper run in its parallel phase (fxh_run.clip_auto): a block whose reads are not all of one length is handed back untouched */
     uint32_t fixed_len;                    /* result: the one length of the block's reads, 0 = they differ (or the block was not indexed) */
     int slot;                              /* which of out[] receives the text (the other may still be with the writer) */
-    int out_plain;                         /* out[] are ordinary page-locked pages (malloc + register) instead of the runtime's host allocations: the output is a pipe (vmsplice) */
     int handled;                           /* result: 0 = irregular block, parse it on the host */
     char *out[FXH_LANE_OUT_SLOTS]; size_t out_cap[FXH_LANE_OUT_SLOTS]; size_t out_len;      /* (the lanes loop uses two, the strands of the one-file run more) */
     uint64_t ctr[FXG_NCOUNTERS];

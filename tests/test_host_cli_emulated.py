@@ -7,6 +7,8 @@ never installed next to it.  The same comparisons run against the real GPU engin
 """
 import os
 import subprocess
+import sys
+import time
 
 import numpy as np
 import pytest
@@ -798,10 +800,11 @@ def test_rank_job_is_done_when_every_rank_has_written(tools, tmp_path):
 
 
 def test_pipes_as_the_references_users_run_them(tools, tmp_path):
-    """`trimmer | filter` and `cat in | tool > out` (the Galaxy wrappers' form): both ends of a pipe are raised to the system's limit (F_SETPIPE_SZ), blocks go into
-    the pipe by vmsplice() except for their last pipe-capacity bytes (so that no page of a buffer is still in the pipe when the buffer is used again), the
-    reader takes what a pipe holds per wake-up.  Same bytes with the default 64 KB pipe, without vmsplice, with tiny and with large blocks; a reader that
-    stops early (head) ends the writer like any tool."""
+    """`trimmer | filter` and `cat in | tool > out` (the Galaxy wrappers' form): both ends of a pipe are raised to the system's limit (F_SETPIPE_SZ); a block goes
+    into the pipe as pieces that writer threads write() into private pipes side by side and that are moved on into the output pipe in order by splice() -- page
+    references, no copy, and the kernel's own pages, so any reader is safe --; the reading side deals the incoming pages out to private pipes the same way and
+    copies them out by several threads.  Same bytes with the default 64 KB pipe, without the private pipes, with many of them, with tiny and with large blocks; a
+    splicing middleman in between; a reader that stops early (head) ends the writer like any tool."""
     text = fo.synth_fastq(47, 0, 60000, 100, False)
     inp = tmp_path / "in.fq"
     inp.write_bytes(text)
@@ -810,7 +813,8 @@ def test_pipes_as_the_references_users_run_them(tools, tmp_path):
     ref = _run(t2, _run(t1, text)[1])
     assert ref[0] == 0 and len(ref[1]) > 1_000_000
     base = dict(os.environ, LD_LIBRARY_PATH=STUB_DIR, FXH_THREADS="2")
-    for extra in ({}, {"FXH_NO_PIPE_TUNING": "1"}, {"FXH_NO_VMSPLICE": "1"}, {"FXH_READ_BUFFER_MB": "1"}, {"FXH_READ_BUFFER_MB": "1", "FXH_NO_PIPE_TUNING": "1"}, {"FXH_HOST_PARSE": "1"}):
+    for extra in ({}, {"FXH_NO_PIPE_TUNING": "1"}, {"FXH_PIPE_WRITERS": "2", "FXH_PIPE_MB": "1", "FXH_READ_BUFFER_MB": "4"}, {"FXH_READ_BUFFER_MB": "1"}, {"FXH_READ_BUFFER_MB": "1", "FXH_NO_PIPE_TUNING": "1"}, {"FXH_HOST_PARSE": "1"},
+                  {"FXH_NO_PIPE_FANOUT": "1"}, {"FXH_PIPE_READERS": "8", "FXH_PIPE_WRITERS": "4", "FXH_PIPE_MB": "1", "FXH_READ_BUFFER_MB": "4"}):
         env = dict(base, **extra)
         out = tmp_path / "piped.fq"
         p1 = subprocess.Popen(t1 + ["-i", str(inp)], stdout=subprocess.PIPE, env=env)
@@ -826,6 +830,22 @@ def test_pipes_as_the_references_users_run_them(tools, tmp_path):
             c.stdout.close()
             assert p.wait(timeout=120) == 0 and c.wait() == 0
         assert (tmp_path / "redir.fq").read_bytes() == _run(t1, text)[1]
+    # a splicing middleman (what pv does): the pages in the writer's pipe travel on into a second pipe and stay there while the reader dawdles.  They are the
+    # kernel's own pipe pages (the writer's threads copied into them) -- never pages of a buffer the tool writes to again -- so the bytes are right
+    fwd = tmp_path / "fwd.py"
+    fwd.write_text("import os, time, fcntl\nfcntl.fcntl(1, 1031, 1 << 20)\nn = 0\nwhile True:\n    k = os.splice(0, 1, 1 << 20)\n    if k == 0: break\n    n += k\n    if (n >> 20) % 4 == 0: time.sleep(0.002)\n")
+    env = dict(base, FXH_READ_BUFFER_MB="4", FXH_PIPE_MB="1")
+    p1 = subprocess.Popen(t1 + ["-i", str(inp)], stdout=subprocess.PIPE, env=env)
+    pm = subprocess.Popen([sys.executable, str(fwd)], stdin=p1.stdout, stdout=subprocess.PIPE)
+    p1.stdout.close()
+    got = bytearray()
+    while True:
+        b = pm.stdout.read(1 << 16)
+        if not b:
+            break
+        got += b
+        time.sleep(0.0002)
+    assert p1.wait() == 0 and pm.wait() == 0 and bytes(got) == _run(t1, text)[1]
     # the downstream side stops reading: the tool dies of SIGPIPE (or reports the failed write), it does not hang
     p1 = subprocess.Popen(t1 + ["-i", str(inp)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=base)
     h = subprocess.Popen(["head", "-c", "100000"], stdin=p1.stdout, stdout=subprocess.PIPE)
