@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 from oracle import fxoracle_py as fo  # noqa: E402
 
 reads = int(os.environ.get("READS", "16000000"))
-matrix = os.environ.get("MATRIX", ",FXH_NO_VMSPLICE=1,FXH_NO_PIPE_TUNING=1:FXH_NO_VMSPLICE=1").split(",")
+matrix = os.environ.get("MATRIX", ",FXH_NO_PIPE_FANOUT=1,FXH_NO_PIPE_TUNING=1:FXH_NO_PIPE_FANOUT=1").split(",")
 bindir = os.path.join(ROOT, "fastx_toolkit_amd", "host", "bin")
 chunk = 250_000
 with tempfile.TemporaryDirectory(dir="/dev/shm") as td:
