@@ -11,6 +11,11 @@ from helpers import assert_same, oracle_params, random_batch
 from oracle import fxoracle_py as fo
 rng = np.random.default_rng(int(sys.argv[1]))
 adapters = [b"AGATCGGAAGAGC", b"CCTTAAGG", b"ACGT", b"TGGAATTCTCGGGTGCCAAGGAACTCCAGTCAC", b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCGTATGCCGTCTTCTGCTTG", b"ANNTCGNA", b"GATTACAGATTACAGA", b"A" * 17]
+# round 5's buckets (56 and 80 columns, with and without N) and the widest ones, both ends of each
+_r5 = np.random.default_rng(5)
+for _n in (49, 52, 56, 57, 64, 65, 72, 80, 81, 99):
+    _a = bytes(_r5.choice(list(b"ACGT"), size=_n).astype(np.uint8))
+    adapters += [_a, _a[:_n // 2] + b"N" + _a[_n // 2 + 1:]]
 t0 = time.time(); n = 0
 while time.time() - t0 < float(sys.argv[2]):
     ad = adapters[int(rng.integers(0, len(adapters)))]
