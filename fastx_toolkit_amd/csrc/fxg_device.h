@@ -103,6 +103,7 @@ struct FxgKArgs {
     const uint16_t *wlen;   // DP rows per read (null: the read's own length)
     float *clip_ck;         // two-pass clipper for 17..99 adapter columns (fxg_clip_two_pass_k): score-row checkpoints, FXG_CK_SLOTS x bucket x threads floats per workgroup (null: one pass)
     u32  clip_ck_rows;      // a checkpoint every this many rows
+    u32  clip_ptab_rows;    // rows of the workgroup's pair table (fxg_kernels.h: fxg_ptab_rows), 0 = the instance has none
 #ifdef FXG_CLIP_DEBUG
     u32 *clip_dbg;          // debug builds only (scripts/debug/clip64_bisect.py): 16 words per read of fxg_clip_two_pass_k's intermediate state
 #endif

@@ -25,13 +25,14 @@
 #define FXG_NTALLY 16                            // tally slots: [0] reads seen, [1] kept, [2] kept bases, [3] adapter-only, [4 + reason] dropped for that reason
 struct FxgLds {
     u32 slot_bytes, so_ksrc, so_kidx, so_ktab;   // slot k lives at k * slot_bytes: k_off at +0, k_src at +so_ksrc, k_idx at +so_kidx, k_tab at +so_ktab
-    u32 off_scratch, off_tally, off_bm_g, off_bm_l, off_bases, total;
+    u32 off_scratch, off_tally, off_bm_g, off_bm_l, off_bases, off_ptab, total;
     u32 has_tab;                                 // kernels that stage a tile of bases in LDS (clipper, census) spend no LDS on k_tab
 };
 __host__ __device__ inline u32 fxg_r16(u32 x) { return (x + 15u) & ~15u; }
 // nslots: tiles a workgroup keeps between decision and write-out (FxgTileDepth: 2, the clip instances 3)
 // bitmaps: 0 none, 2 both, 1 = ONE shared by trimmer and filter (same threshold: "below" is the complement of "at least"; off_bm_l == off_bm_g)
-__host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, u32 bitmaps, u32 stage_stride, u32 nslots = 2, bool no_tab = false)   // stage_stride: row stride of the LDS copy of the tile's bases, 0 = none
+// ptab_bytes: the clip instances that take their pair values from an LDS table (fxg_clip_ptab_build, fxg_ptab_bytes)
+__host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, u32 bitmaps, u32 stage_stride, u32 nslots = 2, bool no_tab = false, u32 ptab_bytes = 0u)   // stage_stride: row stride of the LDS copy of the tile's bases, 0 = none
 {
     FxgLds l;
     l.so_ksrc = fxg_r16((T + 1) * 4);
@@ -46,6 +47,7 @@ __host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, u32 bitmaps,
     l.off_bm_g = o;    o += bitmaps ? fxg_r16(words * 4) : 0;
     l.off_bm_l = bitmaps == 1u ? l.off_bm_g : o;    o += bitmaps == 2u ? fxg_r16(words * 4) : 0;
     l.off_bases = o;   o += stage_stride ? fxg_r16(T * stage_stride + 16) : 0;
+    l.off_ptab = o;    o += fxg_r16(ptab_bytes);
     l.total = o;
     return l;
 }
@@ -352,6 +354,176 @@ FXG_HD float fxg_clip_row_score(const FxgKArgs &a, int A, u32 c, int q, float (&
     return rowmax;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pair values out of an LDS table (round 6).  A cell's pair score depends on (read base, adapter column) only, and a wave's lanes hold
+// at most a handful of different read bases: instead of a compare and a select per CELL (2 of the 5 VALU instructions of pass 1) a lane
+// fetches the whole row of pair values for its base -- 16 floats, four ds_read_b128 on the LDS pipe, which the DP leaves idle, one row
+// ahead of its use -- and the diagonal candidate is the same v_add_f32 as before with the fetched value as its operand: bit-identical
+// scores (+-1.0f, or 0.1f in every column where the read base is 'N': sequence_alignment.h:157-169, adapter without N).
+// Pass 2 fetches a second row the same way: what a diagonal step adds to the path summary (FXG_PK_DIA1 + match, 0 for 'N'), so that
+// its compare + add-with-carry per cell become one v_add_u32.
+// Table (fxg_clip_ptab_build, one per workgroup): lut u16[256] = byte -> offset of its pair row; R pair rows of 16 floats, then R step
+// rows of 16 u32, 64 bytes apart: row 0 = a byte the adapter does not contain, row 1 = 'N', rows 2.. = the adapter's distinct bytes in
+// order of first appearance (R = 2 + distinct bytes, fxg_ptab_rows: 6 for an adapter over ACGT) -- A, C, G, T sit in rows of different
+// 64-byte bank groups, so a wave's fetch has no bank conflict among them.  Any byte value is served (lower case, IUPAC codes: whatever
+// the caller put into the batch compares as the reference's `==` does).
+// Measured (profiles/r06/): cfg3 5.28 -> 4.49 ms, cfg5 7.66 -> 6.66 ms per 20 M reads with pass 1 alone on the table.  Rows of 16 HALVES and
+// one v_fma_mix_f32 per cell (fma(half, 1.0f or 0.1f, S): exact too, half the fetch) came out slower, 4.80 / 7.19 ms: v_fma_mix_f32 issues
+// at the rate of v_max3_f32 (2.6 cycles at four waves per SIMD, against 1.64 for v_add_f32; scripts/ubench/valu_rate.hip 77-80) and two
+// slow instructions in a row do not overlap.
+// ------------------------------------------------------------------------------------------------
+#define FXG_PTAB_LUT_BYTES 512u
+#define FXG_PTAB_ROW_BYTES 64u
+#define FXG_PTAB_N_ROW (FXG_PTAB_LUT_BYTES + FXG_PTAB_ROW_BYTES)      // offset of the 'N' pair row from the table's first byte
+#ifdef FXG_NO_PTAB      // A/B builds (scripts/clip_ab.py): the compare + select cell of rounds 3-5
+__host__ __device__ constexpr bool fxg_clip_uses_ptab(int) { return false; }
+#else
+__host__ __device__ constexpr bool fxg_clip_uses_ptab(int amax) { return amax < 0 && amax >= -16; }      // the register two-pass instances (no N in the adapter)
+#endif
+// rows of the table for this adapter: "other", 'N', and one per distinct byte of its first 16
+FXG_HD u32 fxg_ptab_rows(const char *adapter, int alen)
+{
+    u32 r = 2u;
+    const int A = alen < 16 ? alen : 16;
+    for (int t = 0; t < A; ++t) {
+        bool seen = false;
+        for (int u = 0; u < t; ++u) seen = seen || (adapter[u] == adapter[t]);
+        r += seen ? 0u : 1u;
+    }
+    return r;
+}
+FXG_HD u32 fxg_ptab_bytes(u32 rows) { return FXG_PTAB_LUT_BYTES + 2u * rows * FXG_PTAB_ROW_BYTES; }
+
+FXG_HD void fxg_clip_ptab_build(const FxgKArgs &a, uint8_t *ptab, u32 tid, u32 nthreads)
+{
+    uint16_t *lut = reinterpret_cast<uint16_t *>(ptab);
+    const int A = a.alen < 16 ? a.alen : 16;
+    const u32 R = a.clip_ptab_rows;
+    for (u32 b = tid; b < 256u; b += nthreads) {
+        int first = -1, rank = 0;                          // first column that holds byte b; distinct bytes in front of it
+        for (int t = 0; t < A; ++t) {
+            const u32 tc = (u32)(uint8_t)a.adapter[t];
+            if (tc == b) { first = t; break; }
+            bool seen = false;
+            for (int u = 0; u < t; ++u) seen = seen || ((u32)(uint8_t)a.adapter[u] == tc);
+            rank += seen ? 0 : 1;
+        }
+        const u32 row = b == (u32)'N' ? 1u : (first < 0 ? 0u : 2u + (u32)rank);
+        lut[b] = (uint16_t)(FXG_PTAB_LUT_BYTES + row * FXG_PTAB_ROW_BYTES);
+        if (b == 0u || b == (u32)'N' || first >= 0) {      // one writer per row (0 is never an adapter byte: the adapter is a C string)
+            float *pv = reinterpret_cast<float *>(ptab + FXG_PTAB_LUT_BYTES + row * FXG_PTAB_ROW_BYTES);
+            u32 *sv = reinterpret_cast<u32 *>(ptab + FXG_PTAB_LUT_BYTES + (R + row) * FXG_PTAB_ROW_BYTES);
+            for (int t = 0; t < 16; ++t) {
+                const bool eq = t < A && (u32)(uint8_t)a.adapter[t] == b;
+                pv[t] = b == (u32)'N' ? 0.1f : (eq ? 1.0f : -1.0f);
+                sv[t] = b == (u32)'N' ? 0u : (1u << 14) + (eq ? 1u : 0u);      // FXG_PK_DIA1 + FXG_PK_MAT1 where the bases are equal
+            }
+        }
+    }
+}
+
+// FXG_PTAB_SCHED (A/B): a scheduling fence on either side of the fetch of the next row's values; left alone the scheduler sinks the fetch to the
+// end of the row -- no difference within the noise once the rows are floats (profiles/r06/)
+#if defined(FXG_PTAB_SCHED) && !defined(FXG_HOST_EMULATION)
+#define FXG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define FXG_SCHED_FENCE() ((void)0)
+#endif
+
+// the table rows at offset `off` into registers: pair values, and (STEPS) what a diagonal step adds to the path summary
+template <int AMAX, bool STEPS>
+FXG_HD void fxg_ptab_fetch(const uint8_t *ptab, u32 off, u32 step_off, u32 (&pr)[16], u32 (&st)[16])
+{
+    const u32x4 *p = reinterpret_cast<const u32x4 *>(ptab + off);
+#pragma unroll
+    for (int k = 0; k < (AMAX + 3) / 4; ++k) { const u32x4 v = p[k]; pr[4 * k] = v.x; pr[4 * k + 1] = v.y; pr[4 * k + 2] = v.z; pr[4 * k + 3] = v.w; }
+    if constexpr (STEPS) {
+        const u32x4 *g = reinterpret_cast<const u32x4 *>(ptab + off + step_off);
+#pragma unroll
+        for (int k = 0; k < (AMAX + 3) / 4; ++k) { const u32x4 v = g[k]; st[4 * k] = v.x; st[4 * k + 1] = v.y; st[4 * k + 2] = v.z; st[4 * k + 3] = v.w; }
+    }
+}
+
+// One row of scores with the pair values in pr (this row's table row).  pr (and st, STEPS) are replaced by the rows at offset `o_next` as soon as
+// the diagonal candidates are taken -- the up/left chain of the row covers the fetch.
+template <int AMAX, bool EARLY, bool STEPS = false>
+FXG_HD float fxg_clip_row_score_t(int A, int q, float (&S)[AMAX], float (&Sm)[AMAX], u32 (&pr)[16], u32 (&st)[16], const uint8_t *ptab, u32 o_next, u32 step_off)
+{
+    constexpr int AMIN = AMAX <= 4 ? 1 : (AMAX <= 8 ? 5 : AMAX);
+    // everything a cell takes from the row above first: ul[t] = S[q-1][t-1] + pair(t); S[q-1][-1] = query_border = 0
+    float ul[AMAX];
+#pragma unroll
+    for (int t = 0; t < AMAX; ++t) ul[t] = (t ? S[t - 1] : 0.0f) + __builtin_bit_cast(float, pr[t]);
+    FXG_SCHED_FENCE();
+    fxg_ptab_fetch<AMAX, STEPS>(ptab, o_next, step_off, pr, st);      // the next row's values, into the registers this row no longer needs
+    FXG_SCHED_FENCE();
+    float uSm = -5.0f, rowmax = -1000000.0f;                                             // S[q][-1] - 5
+#pragma unroll
+    for (int t = 0; t < AMAX; ++t) {
+        float left = Sm[t];
+        if (EARLY && t > 3) left = (t - 3 > q) ? -100000.0f : left;                      // sequence_alignment.cpp:387-389
+        const float sc = fmaxf(fmaxf(ul[t], uSm), left);
+        const float scm = sc + -5.0f;
+        S[t] = sc; Sm[t] = scm; uSm = scm;
+        if (t < AMIN) rowmax = fmaxf(rowmax, sc);
+        else rowmax = (t < A) ? fmaxf(rowmax, sc) : rowmax;
+    }
+    return rowmax;
+}
+
+// One row of pass 2 (fxg_clip_row_packed<.., FIRST = false, TN = false>: the same cell, the same summary word) with the pair values and the
+// diagonal's summary steps out of the table: ul = S[q-1][t-1] + pr[t], wd = W[q-1][t-1] + st[t].
+template <int AMAX, bool EARLY, bool TRACK>
+FXG_HD void fxg_clip_row_packed_t(int A, int q, u32 vstart, float (&S)[AMAX], float (&Sm)[AMAX], u32 (&W)[AMAX], float &best, u32 &bw, u32 &bq,
+                                  u32 (&pr)[16], u32 (&st)[16], const uint8_t *ptab, u32 o_next, u32 step_off)
+{
+    const float best_in = best;
+    float ul[AMAX];
+    u32 wd[AMAX];
+#pragma unroll
+    for (int t = 0; t < AMAX; ++t) {
+        ul[t] = (t ? S[t - 1] : 0.0f) + __builtin_bit_cast(float, pr[t]);                    // S[q-1][-1]: query_border = 0
+        wd[t] = (t ? W[t - 1] : 0u) + st[t];                                                 // no predecessor left of column 0: the step alone
+    }
+    FXG_SCHED_FENCE();
+    fxg_ptab_fetch<AMAX, true>(ptab, o_next, step_off, pr, st);
+    FXG_SCHED_FENCE();
+    float uSm = -5.0f;                                     // S[q][-1] - 5
+    u32 uW = 0u;
+#pragma unroll
+    for (int t = 0; t < AMAX; ++t) {
+        const float up = uSm;
+        float left = Sm[t];
+        if (EARLY && t > 3) left = (t - 3 > q) ? -100000.0f : left;                          // :387-389, only rows q < A-4
+        const float sc = fmaxf(fmaxf(ul[t], up), left);
+        const bool isd = (sc == ul[t]), isu = (sc == up);
+        u32 w;
+        if (t == 0) {                                                                        // diag and up come from outside the matrix: the path enters it here
+            const u32 src = (isd || isu) ? 0u : W[0];
+            const u32 step = isd ? wd[0] : 0u;
+            w = (src == 0u) ? ((vstart << 24) + FXG_PK_SZ1 + step) : (src + step);
+        } else {
+            w = isu ? uW : W[t];
+            w = isd ? wd[t] : w;
+        }
+        const u32 wp = w + FXG_PK_SZ1;
+        const float scm = sc + -5.0f;
+        S[t] = sc; Sm[t] = scm; W[t] = wp;
+        uSm = scm; uW = wp;
+        constexpr int AMIN = AMAX <= 4 ? 1 : (AMAX <= 8 ? 5 : (AMAX <= 16 ? AMAX : AMAX - 3));
+        if (!TRACK) continue;
+        if (t < AMIN) {
+            const bool gb = sc > best;
+            bw = gb ? w : bw;
+            best = fmaxf(best, sc);
+        } else {
+            const bool gb = (sc > best) && (t < A);
+            best = gb ? sc : best; bw = gb ? w : bw;
+        }
+    }
+    if (TRACK) bq = (best > best_in) ? (u32)q : bq;
+}
+
 // GL window: index of the array's last readable dword counted from a row that starts `off` bytes into it.  The count is 64-bit -- a batch
 // of 8 GiB and more (30 M reads at a 300-byte stride) has more than 2^31 dwords behind its early rows -- and the window never looks
 // further than a row's own length ahead, so it is clamped to what an int index can hold instead of being truncated.
@@ -403,8 +575,9 @@ FXG_HD int fxg_clip_first_n(const uint8_t *rd, int len, int len_u, u32 stride, i
 // GL: `rd` points into the batch in global memory instead of a staged copy in LDS (fxg_plan.h: clip_global).  Pass 1, whose row number is a
 // scalar, then takes the row's base out of a two-dword window that moves on every fourth row (one 4-byte load per lane and four rows: byte loads,
 // each lane on a line of its own, would cost the CU's vector cache a lookup per lane and row); pass 2 and the N scan touch ~20 rows and read them directly.
+// ptab (staged form): the workgroup's pair table (fxg_clip_ptab_build) -- pass 1 then takes its pair values from it (fxg_clip_row_score_t)
 template <int AMAX, bool GL = false>
-FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float &best, u32 &bw, u32 &bq, int &first_n, const bool UR = false)
+FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float &best, u32 &bw, u32 &bq, int &first_n, const bool UR = false, const uint8_t *ptab = nullptr)
 {
     constexpr int C = FxgClip2<AMAX>::C;
     float S[AMAX], Sm[AMAX], P0[AMAX], P1[AMAX], P2[AMAX], CB[AMAX];
@@ -421,9 +594,18 @@ FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int 
     int q = 0, r0 = 0, bq1 = 0;
     u32 cn = 0u, gw0 = 0u, gw1 = 0u;
     int gmax = 0;                                           // GL: last dword of the array that may be read, counted from this row's first
+    // staged form: pr / mult = the pair values of row q, on = table offset of row q + 1, cn = the base of row q + 2 -- each fetched a row or more ahead of its use
+    constexpr bool PT = !GL && fxg_clip_uses_ptab(-AMAX);
+    u32 pr[16] = {}, st[16] = {}, on = 0u;
+    const u32 step_off = PT ? a.clip_ptab_rows * FXG_PTAB_ROW_BYTES : 0u;      // from a byte's pair row to its step row
     if constexpr (GL) {
         gmax = fxg_gl_last_dword(a.clip_total, (u64)(rd - a.clip_src));
         gw0 = fxg_ld32(rd, 0, gmax); gw1 = fxg_ld32(rd, 1, gmax);
+    } else if constexpr (PT) {
+        const uint16_t *lut = reinterpret_cast<const uint16_t *>(ptab);
+        const u32 o0 = lut[rd[0]];
+        on = lut[rd[1]]; cn = rd[2];
+        fxg_ptab_fetch<AMAX, false>(ptab, o0, step_off, pr, st);
     } else cn = rd[0];
     // chunk j = rows [j C, j C + C): saves the row before it in Psave = P[j % 3]; the restart row for a best found in it is
     // Pwin = P[(j + 1) % 3] = the row before chunk j - 2 (before chunk 0 for j < 2: the border, which all three start from)
@@ -433,13 +615,24 @@ FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int 
         const int q0 = q, qend = q + C < rows_u ? q + C : rows_u;                                                            \
         bool upd = false;                                                                                                    \
         _Pragma("unroll 1") for (; q < qend; ++q) {                                                                          \
-            u32 c;                                                                                                           \
+            float rm;                                                                                                        \
             if constexpr (GL) {                                                                                              \
-                c = (gw0 >> ((u32)(q & 3) << 3)) & 0xFFu;                                                                    \
+                const u32 c = (gw0 >> ((u32)(q & 3) << 3)) & 0xFFu;                                                          \
                 if ((q & 3) == 3) { gw0 = gw1; gw1 = fxg_ld32(rd, (q >> 2) + 2, gmax); }                                     \
-            } else { c = cn; cn = rd[q + 1]; }                                                                               \
-            if (!UR && q >= rows) continue;                                                                                  \
-            const float rm = fxg_clip_row_score<AMAX, EARLY>(a, A, c, q, S, Sm);                                             \
+                if (!UR && q >= rows) continue;                                                                              \
+                rm = fxg_clip_row_score<AMAX, EARLY>(a, A, c, q, S, Sm);                                                     \
+            } else if constexpr (!PT) {                                                                                      \
+                const u32 c = cn;                                                                                            \
+                cn = rd[q + 1];                                                                                              \
+                if (!UR && q >= rows) continue;                                                                              \
+                rm = fxg_clip_row_score<AMAX, EARLY>(a, A, c, q, S, Sm);                                                     \
+            } else {                                                                                                         \
+                if (!UR && q >= rows) continue;          /* (a lane past its rows never comes back: its fetch state may lapse) */ \
+                const u32 on2 = reinterpret_cast<const uint16_t *>(ptab)[cn];                                                \
+                cn = rd[q + 3];                                                                                              \
+                rm = fxg_clip_row_score_t<AMAX, EARLY>(A, q, S, Sm, pr, st, ptab, on, step_off);                             \
+                on = on2;                                                                                                    \
+            }                                                                                                                \
             const bool g = rm > b1;                                                                                          \
             b1 = g ? rm : b1; bq1 = g ? q : bq1; upd = upd || g;                                                             \
         }                                                                                                                    \
@@ -467,6 +660,52 @@ FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int 
 #pragma unroll
     for (int t = 0; t < AMAX; ++t) { S[t] = CB[t]; Sm[t] = CB[t] + -5.0f; W[t] = ((u32)(t + 1) << 19) + FXG_PK_SZ1; }
     q = r0;
+    if constexpr (PT) {
+        // The best path covers at most SPAN rows (above), i.e. starts in row rs = bq1 - SPAN + 1 or later: rows r0 .. rs - 1 re-run the SCORES only
+        // (the cheap row of pass 1), rows rs .. bq1 carry the summaries, whose start field counts from rs.  Every lane is at rows of its own
+        // here; the fetch pipeline is the one of pass 1 (values of row q in registers, table offset of row q + 1, base of row q + 2).
+        constexpr int SPAN = FxgClip2<AMAX>::SPAN;
+        const int rs = bq1 - SPAN + 1 > r0 ? bq1 - SPAN + 1 : r0;
+        const uint16_t *lut = reinterpret_cast<const uint16_t *>(ptab);
+        {
+            const u32 o0 = lut[rd[q]];
+            on = lut[rd[q + 1]]; cn = rd[q + 2];
+            fxg_ptab_fetch<AMAX, true>(ptab, o0, step_off, pr, st);
+        }
+        const int n0 = rs - r0, n0u = fxg_wave_max(n0);
+#pragma unroll 1
+        for (int i = 0; i < n0u; ++i) {
+            if (i >= n0) continue;
+            const u32 on2 = lut[cn];
+            cn = rd[q + 3];
+            (void)fxg_clip_row_score_t<AMAX, true, true>(A, q, S, Sm, pr, st, ptab, on, step_off);      // (the early form tests the row number itself)
+            on = on2; ++q;
+        }
+        // summary row i is read row rs + i >= i: rows past i = A - 4 are past the early rule, so the first A - 4 run in the early form (which tests the
+        // row number itself) in EVERY lane and the two loops have the same trip counts across the wave -- a split by the lane's own rows would
+        // make the wave issue both forms for as many rows as its slowest lane needs of each
+        const int win = bq1 - rs, n1 = win < early_rows ? win : early_rows, n2 = win - n1;
+        const int n1u = fxg_wave_max(n1), n2u = fxg_wave_max(n2);
+#pragma unroll 1
+        for (int i = 0; i < n1u; ++i) {
+            if (i >= n1) continue;
+            const u32 on2 = lut[cn];
+            cn = rd[q + 3];
+            fxg_clip_row_packed_t<AMAX, true, false>(A, q, (u32)(q - rs), S, Sm, W, best, bw, bq, pr, st, ptab, on, step_off);
+            on = on2; ++q;
+        }
+#pragma unroll 1
+        for (int i = 0; i < n2u; ++i) {
+            if (i >= n2) continue;
+            const u32 on2 = lut[cn];
+            cn = rd[q + 3];
+            fxg_clip_row_packed_t<AMAX, false, false>(A, q, (u32)(q - rs), S, Sm, W, best, bw, bq, pr, st, ptab, on, step_off);
+            on = on2; ++q;
+        }
+        fxg_clip_row_packed_t<AMAX, true, true>(A, bq1, (u32)(bq1 - rs), S, Sm, W, best, bw, bq, pr, st, ptab, on, step_off);
+        if (!(a.clip_flags & FXG_CLIP_KEEP_N)) first_n = fxg_clip_first_n(rd, len, UR ? len : fxg_wave_max(len), a.clip_stride, first_n);
+        return rs;
+    }
     // window row i is read row r0 + i >= i: rows past i = A - 4 are past the early rule.  n1 rows in the early form, n2 in the other;
     // both loops run the wave's maximum, a lane beyond its own count skips the row
     const int win = bq1 - r0, n1 = win < early_rows ? win : early_rows, n2 = win - n1;
@@ -821,14 +1060,15 @@ FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, in
 // form of fxg_clip_two_pass cannot describe: its start field is absolute)
 template <int AMAX, bool KFORM, bool TN = false, bool GL = false>
 FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len, int rows,
-                                 u32 *out_len, u32 *keep, u32 *reason, u32 *clipped, u32 *adapter_only, float *ck = nullptr, u32 cks = 0u, u32 *dbg = nullptr, const bool UR = false)
+                                 u32 *out_len, u32 *keep, u32 *reason, u32 *clipped, u32 *adapter_only, float *ck = nullptr, u32 cks = 0u, u32 *dbg = nullptr, const bool UR = false,
+                                 const uint8_t *ptab = nullptr)
 {
-    (void)dbg;
+    (void)dbg; (void)ptab;
     float best = -1000000.0f;
     u32 bw = FXG_INVALID_TUPLE, bq = 0u;
     int first_n = len, qbase = 0;
 #ifndef FXG_CLIP_ONE_PASS
-    if constexpr (!KFORM) qbase = fxg_clip_two_pass<AMAX, GL>(a, rd, len, rows, best, bw, bq, first_n, UR);
+    if constexpr (!KFORM) qbase = fxg_clip_two_pass<AMAX, GL>(a, rd, len, rows, best, bw, bq, first_n, UR, ptab);
     else
 #endif
     if constexpr (!KFORM) fxg_clip_rows_packed<AMAX, false>(a, rd, len, rows, best, bw, bq, first_n, UR);
@@ -953,7 +1193,7 @@ __host__ __device__ constexpr bool fxg_clip_tn(int amax) { return amax <= -300; 
 // GL (two-pass forms only): the DP reads the batch in global memory, nothing was staged (sb unused)
 template <int AMAX, bool GL = false>
 FXG_HD u32 fxg_decide_a(const FxgKArgs &a, const u32 *bm_g, const u32 *bm_l, const uint8_t *sb, u32 r0, u32 tid,
-                        u32 *keep_out, u32 *len_out, float *ck = nullptr, u32 cks = 0u)      // ck: this thread's checkpoint scratch (fxg_clip_two_pass_k), cks its stride
+                        u32 *keep_out, u32 *len_out, float *ck = nullptr, u32 cks = 0u, const uint8_t *ptab = nullptr)      // ck: this thread's checkpoint scratch (fxg_clip_two_pass_k), cks its stride; ptab: the workgroup's pair table (fxg_clip_ptab_build)
 {
     const u32 stride = a.stride;
     const u32 rl = a.len ? (u32)a.len[r0 + tid] : a.fixed_len;
@@ -970,8 +1210,8 @@ FXG_HD u32 fxg_decide_a(const FxgKArgs &a, const u32 *bm_g, const u32 *bm_l, con
         u32 *dbg = nullptr;
 #endif
         const uint8_t *rd = GL ? a.clip_src + (u64)(r0 + tid) * a.clip_stride : sb + tid * a.clip_stride;
-        if (!a.len && !a.wlen) fxg_clip_read_packed<COLS, KF, TN, GL>(a, rd, (int)a.fixed_len, (int)a.fixed_len, &curlen, &keep, &reason, &clipped, &ao, ck, cks, dbg, true);
-        else fxg_clip_read_packed<COLS, KF, TN, GL>(a, rd, (int)rl, rows, &curlen, &keep, &reason, &clipped, &ao, ck, cks, dbg);
+        if (!a.len && !a.wlen) fxg_clip_read_packed<COLS, KF, TN, GL>(a, rd, (int)a.fixed_len, (int)a.fixed_len, &curlen, &keep, &reason, &clipped, &ao, ck, cks, dbg, true, ptab);
+        else fxg_clip_read_packed<COLS, KF, TN, GL>(a, rd, (int)rl, rows, &curlen, &keep, &reason, &clipped, &ao, ck, cks, dbg, false, ptab);
     }
     if (keep && (a.stages & FXG_STAGE_QTRIM)) {             // fastq_quality_trimmer.c:94-101
         const u32 k = fxg_bits_last(bm_g, tid * stride, curlen);
@@ -1128,7 +1368,8 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
     const u32 T = a.tile_reads, stride = a.stride, tid = threadIdx.x;
     const bool use_q = (MODE == 0 && (a.stages & (FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0) || MODE == 3;
     const u32 NSLOT = (MODE == 0 && AMAX != 0) ? a.depth : 2u;        // tiles between decision and write-out (fxg_plan.h)
-    const FxgLds L = fxg_lds_layout(T, stride, fxg_bitmap_count(a, use_q, MODE == 0 && AMAX != 0), (MODE == 0 && AMAX != 0) ? (GL ? 0u : a.clip_stride) : (MODE == 4 ? stride : 0u), NSLOT, MODE == 0 && AMAX != 0);
+    constexpr bool PTAB = MODE == 0 && !GL && fxg_clip_uses_ptab(AMAX);      // pass 1 takes its pair values from an LDS table
+    const FxgLds L = fxg_lds_layout(T, stride, fxg_bitmap_count(a, use_q, MODE == 0 && AMAX != 0), (MODE == 0 && AMAX != 0) ? (GL ? 0u : a.clip_stride) : (MODE == 4 ? stride : 0u), NSLOT, MODE == 0 && AMAX != 0, PTAB ? fxg_ptab_bytes(a.clip_ptab_rows) : 0u);
     u32 m_reads = 0, m_nt = 0, art_bad = 0;      // MODE 3 report counters / MODE 4 alphabet check, folded once at the end
     u32 *bm_g = reinterpret_cast<u32 *>(smem + L.off_bm_g);
     u32 *bm_l = reinterpret_cast<u32 *>(smem + L.off_bm_l);
@@ -1138,6 +1379,7 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
     u64 *bc = reinterpret_cast<u64 *>(s_tot + 10);                   // [0,2) broadcast of the resolved bases
     u64 *tally = reinterpret_cast<u64 *>(smem + L.off_tally);       // this workgroup's share of the -v report counters
     if (tid < FXG_NTALLY) tally[tid] = 0ull;
+    if constexpr (PTAB) fxg_clip_ptab_build(a, smem + L.off_ptab, tid, TB);      // (visible to every thread after the barrier that follows the first tile's staging)
 #ifdef FXG_ABLATION
     u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = __builtin_amdgcn_s_memrealtime();   // 100 MHz clocks per phase (wave 0 of the workgroup), summed over its tiles
     const u64 clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
@@ -1196,7 +1438,7 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
                     float *ck = a.clip_ck ? a.clip_ck + (size_t)blockIdx.x * ((size_t)FXG_CK_SLOTS * (u32)fxg_clip_cols(AMAX) * TB) + tid : nullptr;
                     word = fxg_decide_a<AMAX, GL>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen, ck, TB);      // (GL only with checkpoint scratch: fxg_plan.h)
                 } else if constexpr (MODE == 0 && AMAX < 0) {     // register two-pass instances: the DP over the staged tile, or straight over the batch (fxg_plan.h: clip_global)
-                    word = fxg_decide_a<AMAX, GL>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen);
+                    word = fxg_decide_a<AMAX, GL>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen, nullptr, 0u, PTAB ? smem + L.off_ptab : nullptr);
                 } else if constexpr (MODE == 0) word = fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen);
                 else if constexpr (MODE == 3) { u32 nl; word = fxg_decide_mask(a, bm_l, r0, tid, &keep, &olen, &nl); m_nt += nl; m_reads += (nl != 0u); }
                 else if constexpr (MODE == 4) word = fxg_decide_census(a, sb + tid * stride, r0, tid, &keep, &olen, &art_bad);

@@ -40,7 +40,8 @@ static inline u32 fxg_pick_tile(u32 stride, bool clip, u32 block = FXG_TBLOCK)
 static inline FxgLds fxg_plan_layout(const FxgPlan *pl)
 {
     const FxgKArgs &ka = pl->ka;
-    return pl->group_a ? fxg_lds_layout(ka.tile_reads, ka.stride, fxg_bitmap_count(ka, pl->use_q, pl->clip), (pl->clip && !ka.clip_global) ? ka.clip_stride : 0u, pl->clip ? ka.depth : 2u, pl->clip)
+    return pl->group_a ? fxg_lds_layout(ka.tile_reads, ka.stride, fxg_bitmap_count(ka, pl->use_q, pl->clip), (pl->clip && !ka.clip_global) ? ka.clip_stride : 0u, pl->clip ? ka.depth : 2u, pl->clip,
+                                        (pl->clip && !ka.clip_global && fxg_clip_uses_ptab(pl->amax)) ? fxg_ptab_bytes(ka.clip_ptab_rows) : 0u)
          : pl->mask ? fxg_lds_layout(ka.tile_reads, ka.stride, 2u, 0u)
          : pl->artifacts ? fxg_lds_layout(ka.tile_reads, ka.stride, 0u, ka.stride) : fxg_lds_layout(ka.tile_reads, ka.stride, 0u, 0u);
 }
@@ -92,6 +93,7 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     ka.adapter[sizeof ka.adapter - 1] = 0;
     ka.alen = (int)strlen(ka.adapter);
     ka.adapter_has_n = strchr(ka.adapter, 'N') != nullptr;
+    ka.clip_ptab_rows = fxg_ptab_rows(ka.adapter, ka.alen);
 
     pl->group_a = ga;
     pl->mask = gm; pl->artifacts = gf;

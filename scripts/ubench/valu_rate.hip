@@ -168,6 +168,25 @@ __global__ __launch_bounds__(1024) void k(unsigned long long *out, unsigned *sin
         if (OP == 74) asm volatile("v_mov_b32 " CLIP_ADDR_ALL ", 0\n" X8(CLIP_LOOP_ALL) : : : "vcc", "memory", CLIP_SGPRS, CLIP_CLOB_ALL);
         if (OP == 75) asm volatile("v_mov_b32 " CLIP_ADDR_BANK0 ", 0\n" X8(CLIP_LOOP_BANK0) : : : "vcc", "memory", CLIP_SGPRS, CLIP_CLOB_BANK0);
         if (OP == 76) asm volatile("v_mov_b32 v123, 0\n v_mov_b32 v17, 0\n" X8(CLIP_LOOP2) : : : "vcc", "memory", CLIP_CLOB2);
+        // ---- round 6: the mixed-precision fma that takes a pair value out of a packed half (pass 1 of the clip DP with its LDS pair table) ----
+        if (OP == 77) asm volatile(X8("v_fma_mix_f32 %0, %8, %9, %0 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %8, %9, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %8, %9, %2 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %8, %9, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %4, %8, %9, %4 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %5, %8, %9, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %6, %8, %9, %6 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %7, %8, %9, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n")
+                                   : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7) : "v"(0x3C00BC00u), "v"(1.0f));
+        if (OP == 78) asm volatile(X8("v_cvt_f32_f16 %0, %8\n v_cvt_f32_f16 %1, %8\n v_cvt_f32_f16 %2, %8\n v_cvt_f32_f16 %3, %8\n v_cvt_f32_f16 %4, %8\n v_cvt_f32_f16 %5, %8\n v_cvt_f32_f16 %6, %8\n v_cvt_f32_f16 %7, %8\n")
+                                   : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7) : "v"(0x3C00BC00u));
+        // the table cell: fma_mix (diagonal candidate) ; max3 ; add -- two cells, as the sweep chains them
+        if (OP == 79) asm volatile(X8("v_fma_mix_f32 %2, %6, %7, %1 op_sel_hi:[1,0,0]\n v_max3_f32 %1, %2, %0, %3\n v_add_f32 %0, %8, %1\n v_fma_mix_f32 %5, %6, %7, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_max3_f32 %4, %5, %0, %3\n v_add_f32 %0, %8, %4\n")
+                                   : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5) : "v"(0x3C00BC00u), "v"(f6), "v"(f7));
+        // the same cell with the pair value as an f32 in a register: add ; max3 ; add
+        if (OP == 80) asm volatile(X8("v_add_f32 %2, %6, %1\n v_max3_f32 %1, %2, %0, %3\n v_add_f32 %0, %8, %1\n v_add_f32 %5, %7, %4\n v_max3_f32 %4, %5, %0, %3\n v_add_f32 %0, %8, %4\n")
+                                   : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5) : "v"(f6), "v"(f6), "v"(f7));
+        // ... and with the f32 table's fetch beside it: 6 cells per ds_read_b128 (13 cells : 4 reads would be 3.25), five distinct rows per wave
+        if (OP == 81) asm volatile(X8("ds_read_b128 %[q0], %[ad]\n v_add_f32 %[c], %[p], %[b]\n v_max3_f32 %[b], %[c], %[a], %[d]\n v_add_f32 %[a], %[m5], %[b]\n v_add_f32 %[f], %[p], %[e]\n v_max3_f32 %[e], %[f], %[a], %[d]\n v_add_f32 %[a], %[m5], %[e]\n v_add_f32 %[c], %[p], %[b]\n v_max3_f32 %[b], %[c], %[a], %[d]\n v_add_f32 %[a], %[m5], %[b]\n ds_read_b128 %[q1], %[ad] offset:16\n v_add_f32 %[f], %[p], %[e]\n v_max3_f32 %[e], %[f], %[a], %[d]\n v_add_f32 %[a], %[m5], %[e]\n v_add_f32 %[c], %[p], %[b]\n v_max3_f32 %[b], %[c], %[a], %[d]\n v_add_f32 %[a], %[m5], %[b]\n v_add_f32 %[f], %[p], %[e]\n v_max3_f32 %[e], %[f], %[a], %[d]\n v_add_f32 %[a], %[m5], %[e]\n s_waitcnt lgkmcnt(0)\n")
+                                   : [a] "+v"(f0), [b] "+v"(f1), [c] "+v"(f2), [d] "+v"(f3), [e] "+v"(f4), [f] "+v"(f5), [q0] "=&v"(*(uint4 *)&d0), [q1] "=&v"(*(uint4 *)&d2)
+                                   : [p] "v"(f6), [m5] "v"(f7), [ad] "v"(((threadIdx.x * 7u) % 5u) * 64u) : "memory");
+        // ... the half table's fetch: 4 cells per ds_read_b128 (13 cells : 2 reads would be 6.5)
+        if (OP == 82) asm volatile(X8("ds_read_b128 %[q0], %[ad]\n v_fma_mix_f32 %[c], %[h], %[p], %[b] op_sel_hi:[1,0,0]\n v_max3_f32 %[b], %[c], %[a], %[d]\n v_add_f32 %[a], %[m5], %[b]\n v_fma_mix_f32 %[f], %[h], %[p], %[e] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_max3_f32 %[e], %[f], %[a], %[d]\n v_add_f32 %[a], %[m5], %[e]\n v_fma_mix_f32 %[c], %[h], %[p], %[b] op_sel_hi:[1,0,0]\n v_max3_f32 %[b], %[c], %[a], %[d]\n v_add_f32 %[a], %[m5], %[b]\n v_fma_mix_f32 %[f], %[h], %[p], %[e] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_max3_f32 %[e], %[f], %[a], %[d]\n v_add_f32 %[a], %[m5], %[e]\n s_waitcnt lgkmcnt(0)\n")
+                                   : [a] "+v"(f0), [b] "+v"(f1), [c] "+v"(f2), [d] "+v"(f3), [e] "+v"(f4), [f] "+v"(f5), [q0] "=&v"(*(uint4 *)&d0)
+                                   : [h] "v"(0x3C00BC00u), [p] "v"(f6), [m5] "v"(f7), [ad] "v"(((threadIdx.x * 7u) % 5u) * 32u) : "memory");
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
@@ -226,6 +245,9 @@ int main(int argc, char **argv)
     if (only == 71) run<71>("shipped pass-1 row loop, registers as allocated (CYCLES PER ROW: 80 VALU + 7)", 8); if (only == 72) run<72>("  renamed: no two sources of an instruction in one bank", 8);
     if (only == 73) run<73>("  renamed: sources and destination in different banks", 8); if (only == 74) run<74>("  renamed: ... and not the bank the previous instruction wrote", 8); if (only == 75) run<75>("  renamed: every register in bank 0", 8);
     if (only == 76) run<76>("shipped pass-2 row loop (CYCLES PER ROW: 153 VALU, 24 s_nop)", 8);
+    RUN(77, "v_fma_mix_f32 (f16 x f32 + f32)"); RUN(78, "v_cvt_f32_f16");
+    if (only == 79) run<79>("table cell: fma_mix, max3, add (chained)", 48); if (only == 80) run<80>("f32-table cell: add, max3, add (chained)", 48);
+    if (only == 81) run<81>("f32-table cells, 6 per ds_read_b128 (VALU instr counted)", 36); if (only == 82) run<82>("half-table cells, 4 per ds_read_b128... (VALU instr counted)", 24);
     RUN(15, "ds_add_u32 conflict-free"); RUN(16, "ds_add_u32 all lanes on one bank"); RUN(17, "ds_read_b128 aligned"); RUN(18, "ds_read_b128 unaligned (+5 B)");
     return 0;
 }

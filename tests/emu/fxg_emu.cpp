@@ -70,6 +70,7 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
     u64 base_c = 0, base_b = 0;
     u32 bad = 0;
     std::vector<u32> keep(T), olen(T), anchor(T);
+    if (pl.group_a && fxg_clip_uses_ptab(AMAX) && !a.clip_global) { for (u32 tid = 0; tid < NT; ++tid) fxg_clip_ptab_build(a, smem + L.off_ptab, tid, NT); }
     for (u32 tile = 0; tile < a.ntiles; ++tile) {
         const u32 r0 = tile * T;
         const u64 left = a.n - (u64)r0;
@@ -89,6 +90,8 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
                     else fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid], ck.data(), 1u);
                 } else if (AMAX < 0 && AMAX >= -16 && a.clip_global) {     // the DP straight over the batch (fxg_plan.h: clip_global), as the kernel calls it
                     if constexpr (AMAX < 0 && AMAX >= -16) fxg_decide_a<AMAX, true>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid]);
+                } else if (fxg_clip_uses_ptab(AMAX)) {                     // the staged register form: pair values out of the workgroup's table
+                    fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid], nullptr, 0u, smem + L.off_ptab);
                 } else fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid]);
                 anchor[tid] = tid * stride;
             }

@@ -239,3 +239,25 @@ def first_n_cases(seed=41):
                 pd = dict(stages=1, adapter=ad, clip_min_len=5, clip_flags=0)
                 yield ("first_n.s%d.%s.a%d" % (stride, "ragged" if ragged else "fixed", len(ad)), np.ascontiguousarray(b), q, lens, None if ragged else stride, pd)
 
+
+
+def odd_alphabet_clip_cases(seed=77):
+    """Clipper batches whose bytes are not all ACGTN (lower case, IUPAC codes, arbitrary letters, in the adapter and in the reads): the reference compares
+    bytes with `==` and treats only 'N' as neutral (sequence_alignment.h:147-169), whatever the alphabet -- the pair table of the register two-pass
+    instances (fxg_kernels.h: fxg_clip_ptab_build) must serve every byte value the same way.  Yields (name, bases, qual, fixed_len, params_dict)."""
+    rng = np.random.default_rng(seed)
+    adapters = [b"agatcggaagagc", b"AGRYCGGAWGAGC", b"ACGTRYKMSWBDHVXZ", b"AcGtAcGtAcG", b"XXXXXXXXXXXXX", b"ACGTacgtACGTa", b"TTTTTTTTTTTTTTTT", b"A", b"zQ"]
+    for k, ad in enumerate(adapters):
+        for stride in (13, 36, 100, 151):
+            n = int(rng.integers(50, 500))
+            b, q, _ = random_batch(rng, n, stride, stride, stride, True, adapter=ad)
+            alpha = np.frombuffer(bytes(sorted(set(ad))) + b"acgtnXRY*", dtype=np.uint8)
+            hit = rng.random((n, stride)) < 0.15
+            b[hit] = rng.choice(alpha, size=int(hit.sum()))
+            for i in range(0, n, 7):                         # a clean copy of the adapter somewhere in every seventh read
+                pos = int(rng.integers(0, stride))
+                m = min(len(ad), stride - pos)
+                b[i, pos:pos + m] = np.frombuffer(ad, dtype=np.uint8)[:m]
+            flags = int(rng.integers(0, 16))
+            yield ("odd%d.s%d.fl%d" % (k, stride, flags), np.ascontiguousarray(b), q, stride,
+                   dict(stages=1, adapter=ad, clip_min_len=int(rng.integers(0, 12)), clip_flags=flags, clip_min_adapter_len=int(rng.choice([0, 0, 4]))))

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import emu_py as emu
-from helpers import adversarial_clip_cases, assert_same, first_n_cases, fuzz_cases, oracle_params
+from helpers import adversarial_clip_cases, assert_same, first_n_cases, fuzz_cases, odd_alphabet_clip_cases, oracle_params
 from oracle import fxoracle_py as fo
 
 
@@ -39,6 +39,18 @@ def test_emulated_kernels_fuzz():
         assert_same(o, e, name)
         kept_total += int(o["counters"][fo.C_KEPT])
     assert kept_total > 10000
+
+
+def test_emulated_clip_odd_alphabets():
+    """Bytes outside ACGTN in the adapter and in the reads: every byte value goes through the pair table's lut like the reference's `==`."""
+    clipped = 0
+    for name, b, q, fl, pd in odd_alphabet_clip_cases():
+        p = oracle_params(pd)
+        o = fo.run_pipeline(b, q, None, p, fixed_len=fl)
+        e = emu.run_pipeline(b, q, None, p, fixed_len=fl)
+        assert_same(o, e, name)
+        clipped += int(((o["res"] >> 21) & 1).sum())
+    assert clipped > 500
 
 
 def test_emulated_decision_only_and_bad_base():

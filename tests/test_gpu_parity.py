@@ -7,7 +7,7 @@ size-independent properties (prefix/suffix windows vs the oracle, offset algebra
 import numpy as np
 import pytest
 
-from helpers import adversarial_clip_cases, assert_same, first_n_cases, fuzz_cases, md5, oracle_params, random_batch
+from helpers import adversarial_clip_cases, assert_same, first_n_cases, fuzz_cases, md5, odd_alphabet_clip_cases, oracle_params, random_batch
 from oracle import fxoracle_py as fo
 
 pytestmark = pytest.mark.gpu
@@ -98,6 +98,19 @@ def test_fuzz_vs_oracle(engine):
         assert_same(o, e, name)
         kept += int(o["counters"][1])
     assert kept > 10000
+
+
+def test_clip_odd_alphabets(engine):
+    """Bytes outside ACGTN in the adapter and in the reads (lower case, IUPAC codes, anything): the pair table's lut serves every byte value as the
+    reference's `==` does (sequence_alignment.h:147-169), and the instance really is one that uses the table."""
+    clipped, tabled = 0, 0
+    for name, b, q, fl, pd in odd_alphabet_clip_cases():
+        o = fo.run_pipeline(b, q, None, oracle_params(pd), fixed_len=fl)
+        e = _run(engine, b, q, None, pd, fixed_len=fl)
+        assert_same(o, e, name)
+        clipped += int(((o["res"] >> 21) & 1).sum())
+        tabled += "clip(packed)" in engine.last_launch()["kernel"]
+    assert clipped > 500 and tabled > 20
 
 
 def test_clip_first_n_rule(engine):
