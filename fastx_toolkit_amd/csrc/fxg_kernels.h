@@ -422,13 +422,26 @@ FXG_HD void fxg_clip_ptab_build(const FxgKArgs &a, uint8_t *ptab, u32 tid, u32 n
     }
 }
 
-// FXG_PTAB_SCHED (A/B): a scheduling fence on either side of the fetch of the next row's values; left alone the scheduler sinks the fetch to the
-// end of the row -- no difference within the noise once the rows are floats (profiles/r06/)
-#if defined(FXG_PTAB_SCHED) && !defined(FXG_HOST_EMULATION)
+// A scheduling fence on either side of the fetch of the next row's values: left alone the scheduler sinks the fetch to the end of the row and the next
+// row begins by waiting for it (FXG_NO_PTAB_SCHED: A/B; pass 1 alone 2.33 -> 2.25 ms per 20 M reads of 100 bases, 1.89 without any fetch: profiles/r06/)
+#if !defined(FXG_NO_PTAB_SCHED) && !defined(FXG_HOST_EMULATION)
 #define FXG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define FXG_SCHED_FENCE() ((void)0)
 #endif
+
+// the gap penalty as a register operand: as a 32-bit literal it makes every `S - 5` an 8-byte instruction (v_add_f32 with a literal issues at 1.83
+// instead of 1.64 cycles at four waves per SIMD, scripts/ubench/valu_rate.hip 58)
+FXG_HD float fxg_minus5()
+{
+    float v = -5.0f;
+#if defined(FXG_M5_SGPR) && !defined(FXG_HOST_EMULATION)
+    asm volatile("" : "+s"(v));
+#elif defined(FXG_M5_VGPR) && !defined(FXG_HOST_EMULATION)
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
 
 // the table rows at offset `off` into registers: pair values, and (STEPS) what a diagonal step adds to the path summary
 template <int AMAX, bool STEPS>
@@ -455,15 +468,18 @@ FXG_HD float fxg_clip_row_score_t(int A, int q, float (&S)[AMAX], float (&Sm)[AM
 #pragma unroll
     for (int t = 0; t < AMAX; ++t) ul[t] = (t ? S[t - 1] : 0.0f) + __builtin_bit_cast(float, pr[t]);
     FXG_SCHED_FENCE();
+#ifndef FXG_ABL_NOFETCH      // (timing experiment: the row without its fetch -- wrong results)
     fxg_ptab_fetch<AMAX, STEPS>(ptab, o_next, step_off, pr, st);      // the next row's values, into the registers this row no longer needs
+#endif
     FXG_SCHED_FENCE();
+    const float m5 = fxg_minus5();
     float uSm = -5.0f, rowmax = -1000000.0f;                                             // S[q][-1] - 5
 #pragma unroll
     for (int t = 0; t < AMAX; ++t) {
         float left = Sm[t];
         if (EARLY && t > 3) left = (t - 3 > q) ? -100000.0f : left;                      // sequence_alignment.cpp:387-389
         const float sc = fmaxf(fmaxf(ul[t], uSm), left);
-        const float scm = sc + -5.0f;
+        const float scm = sc + m5;
         S[t] = sc; Sm[t] = scm; uSm = scm;
         if (t < AMIN) rowmax = fmaxf(rowmax, sc);
         else rowmax = (t < A) ? fmaxf(rowmax, sc) : rowmax;
@@ -488,6 +504,7 @@ FXG_HD void fxg_clip_row_packed_t(int A, int q, u32 vstart, float (&S)[AMAX], fl
     FXG_SCHED_FENCE();
     fxg_ptab_fetch<AMAX, true>(ptab, o_next, step_off, pr, st);
     FXG_SCHED_FENCE();
+    const float m5 = fxg_minus5();
     float uSm = -5.0f;                                     // S[q][-1] - 5
     u32 uW = 0u;
 #pragma unroll
@@ -507,7 +524,7 @@ FXG_HD void fxg_clip_row_packed_t(int A, int q, u32 vstart, float (&S)[AMAX], fl
             w = isd ? wd[t] : w;
         }
         const u32 wp = w + FXG_PK_SZ1;
-        const float scm = sc + -5.0f;
+        const float scm = sc + m5;
         S[t] = sc; Sm[t] = scm; W[t] = wp;
         uSm = scm; uW = wp;
         constexpr int AMIN = AMAX <= 4 ? 1 : (AMAX <= 8 ? 5 : (AMAX <= 16 ? AMAX : AMAX - 3));
@@ -590,6 +607,9 @@ FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int 
     const int rows_u = UR ? rows : fxg_wave_max(rows > 0 ? rows : 0);
     if (rows_u <= 0) return 0;
     // ---- pass 1 ----
+#if defined(FXG_ABL_ROWCLK) && !defined(FXG_HOST_EMULATION)      // timing experiment: shader cycles a wave spends in the row loops of either pass, and the rows it ran
+    const u64 clk_a = __builtin_amdgcn_s_memtime();
+#endif
     float b1 = -1000000.0f;
     int q = 0, r0 = 0, bq1 = 0;
     u32 cn = 0u, gw0 = 0u, gw1 = 0u;
@@ -607,6 +627,11 @@ FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int 
         on = lut[rd[1]]; cn = rd[2];
         fxg_ptab_fetch<AMAX, false>(ptab, o0, step_off, pr, st);
     } else cn = rd[0];
+#ifdef FXG_ABL_NOLUT         // (timing experiment: no base / lut reads in the row loop -- wrong results)
+#define FXG_ABL_LUT_READS const u32 on2 = on;
+#else
+#define FXG_ABL_LUT_READS const u32 on2 = reinterpret_cast<const uint16_t *>(ptab)[cn]; cn = rd[q + 3];
+#endif
     // chunk j = rows [j C, j C + C): saves the row before it in Psave = P[j % 3]; the restart row for a best found in it is
     // Pwin = P[(j + 1) % 3] = the row before chunk j - 2 (before chunk 0 for j < 2: the border, which all three start from)
 #define FXG_CLIP_CHUNK(EARLY, Psave, Pwin)                                                                                   \
@@ -628,8 +653,7 @@ FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int 
                 rm = fxg_clip_row_score<AMAX, EARLY>(a, A, c, q, S, Sm);                                                     \
             } else {                                                                                                         \
                 if (!UR && q >= rows) continue;          /* (a lane past its rows never comes back: its fetch state may lapse) */ \
-                const u32 on2 = reinterpret_cast<const uint16_t *>(ptab)[cn];                                                \
-                cn = rd[q + 3];                                                                                              \
+                FXG_ABL_LUT_READS                                                                                            \
                 rm = fxg_clip_row_score_t<AMAX, EARLY>(A, q, S, Sm, pr, st, ptab, on, step_off);                             \
                 on = on2;                                                                                                    \
             }                                                                                                                \
@@ -653,6 +677,10 @@ FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int 
         FXG_CLIP_CHUNK(false, P1, P2)
     }
 #undef FXG_CLIP_CHUNK
+#if defined(FXG_ABL_ROWCLK) && !defined(FXG_HOST_EMULATION)
+    const u64 clk_b = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63u) == 0u) { atomicAdd(reinterpret_cast<u64 *>(a.errflag + 10) + 0, clk_b - clk_a); atomicAdd(reinterpret_cast<u64 *>(a.errflag + 10) + 1, (u64)rows_u); }
+#endif
     if (rows <= 0) return 0;                                // (only now: the loops above are the wave's, not the lane's)
     if (FXG_DBG(a, 32u)) { best = b1; bq = (u32)bq1; bw = 0u; return 0; }      // ablation builds: pass 1 alone (wrong results, timing only)
     // ---- pass 2: rows r0 .. bq1 with the path summaries, from the checkpoint; only row bq1 can hold the first maximum ----
@@ -703,6 +731,9 @@ FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int 
             on = on2; ++q;
         }
         fxg_clip_row_packed_t<AMAX, true, true>(A, bq1, (u32)(bq1 - rs), S, Sm, W, best, bw, bq, pr, st, ptab, on, step_off);
+#if defined(FXG_ABL_ROWCLK) && !defined(FXG_HOST_EMULATION)
+        if ((threadIdx.x & 63u) == 0u) { atomicAdd(reinterpret_cast<u64 *>(a.errflag + 10) + 2, __builtin_amdgcn_s_memtime() - clk_b); atomicAdd(reinterpret_cast<u64 *>(a.errflag + 10) + 3, (u64)(n0u + n1u + n2u + 1)); atomicAdd(reinterpret_cast<u64 *>(a.errflag + 10) + 4, (u64)n0u); }
+#endif
         if (!(a.clip_flags & FXG_CLIP_KEEP_N)) first_n = fxg_clip_first_n(rd, len, UR ? len : fxg_wave_max(len), a.clip_stride, first_n);
         return rs;
     }
@@ -1169,6 +1200,19 @@ FXG_HD void fxg_phase_bitmaps(const FxgKArgs &a, u64 tb, u32 tbytes, u32 *bm_g, 
 FXG_HD void fxg_phase_stage_bases(const uint8_t *src, u64 total, u64 tb, u32 tbytes, uint8_t *sb, u32 tid, u32 nthreads)
 {
     const u32 nchunks = (tbytes + 15u) >> 4;
+    if ((tb & 15u) == 0u && (tbytes & 15u) == 0u && tb + tbytes <= total) {
+        // whole aligned chunks inside the array (every tile but a batch's last): four independent loads per lane in flight before any is stored --
+        // one after the other the 6-10 trips of a tile each paid a memory round trip
+        constexpr u32 U = 4;
+        for (u32 c0 = tid; c0 < nchunks; c0 += nthreads * U) {
+            u32x4 v[U];
+#pragma unroll
+            for (u32 u = 0; u < U; ++u) { const u32 c = c0 + u * nthreads; if (c < nchunks) v[u] = fxg_ld16(src + tb + ((u64)c << 4)); }
+#pragma unroll
+            for (u32 u = 0; u < U; ++u) { const u32 c = c0 + u * nthreads; if (c < nchunks) *reinterpret_cast<u32x4 *>(sb + (c << 4)) = v[u]; }
+        }
+        return;
+    }
     for (u32 c = tid; c < nchunks; c += nthreads) {
         const u32 o = c << 4;
         const u64 at = tb + o;

@@ -36,6 +36,10 @@
 #define FXG_QS_LROWS 6u                                    // LDS rows per column pair: A C G T N + the spare row (bytes past the end of a read; never flushed)
 #define FXG_QS_LROW_WORDS FXG_QS_WBINS                     // 256 bytes: class k of a pair lives at byte k << 8 of the pair's block
 #define FXG_QS_LDS_WORDS ((FXG_QS_BLOCK_COLS / 2u) * FXG_QS_LROWS * FXG_QS_LROW_WORDS)   // word = two u16 counters: even column low, odd column high
+#ifndef FXG_QS_DEPTH
+#define FXG_QS_DEPTH 1u                                    // trips a lane's loads run ahead of its LDS adds.  1 = the round-4 loop and still the fastest: 2.75 ms against 2.76 / 2.86 / 2.73 at 2 / 3 / 4
+                                                           // (profiles/r06/stats_depth.txt) -- the loads ALONE take 2.49 ms in this decomposition (one add per row: -DFXG_QS_NOACC), 0.75 of the peak
+#endif
 #ifndef FXG_QS_UNROLL
 #define FXG_QS_UNROLL 1u                                   // rows per lane and trip (2.71 ms at 1, 2.83 at 2, 2.79 at 3 with the pipelined loop: profiles/r04/ab_stats_pipeline.txt)
 #endif
@@ -127,6 +131,10 @@ FXG_HD void fxg_stats_masks(u32 nb, u32 (&m)[4])
 // sl: strip of the block (LDS position); m: fxg_stats_masks(o.nb)
 FXG_HD void fxg_stats_accumulate(const FxgStatsArgs &a, const FxgStripRow &o, u32 sl, u32 col0, const u32 (&m)[4], u32 *lds)
 {
+#ifdef FXG_QS_NOACC        // timing experiment (wrong counts): the kernel's loads alone -- one LDS add per row keeps them alive
+    FXG_LDS_ADD(lds + (threadIdx.x & 63u), o.vb.x ^ o.vb.y ^ o.vb.z ^ o.vb.w ^ o.vq.x ^ o.vq.y ^ o.vq.z ^ o.vq.w);
+    return;
+#endif
     if (o.nb == 0u) return;
     u32 wb[4] = {o.vb.x, o.vb.y, o.vb.z, o.vb.w}, wq[4] = {o.vq.x, o.vq.y, o.vq.z, o.vq.w};
     // Fast path: 16 bases A C G T N (either case) whose quality bytes all lie in the window -- no per-base test, no branch.
@@ -238,6 +246,50 @@ __global__ __launch_bounds__(FXG_QS_TBLOCK) void fxg_kernel_quality_stats(const 
     // first use, i.e. for the rows it had just asked for.  A lane whose strip lies past the end of the reads (100-base reads: strips
     // 7..9) loads its row's first bytes instead and adds nothing.
     u64 g0 = 0;
+#if FXG_QS_DEPTH > 1
+    // Round 6 experiment (FXG_QS_DEPTH > 1): the rows of trip i + DEPTH are requested before trip i goes into the histogram (a ring of DEPTH + 1 register
+    // buffers, the loop unrolled DEPTH + 1 times so that every buffer is a fixed set of registers; the ISA waits with vmcnt(2 DEPTH)).  Measured: no gain,
+    // the kernel is not short of bytes in flight.
+    if (!a.len && a.qual && FXG_QS_UNROLL == 1u) {
+        constexpr u32 D = FXG_QS_DEPTH;
+        const u64 safe = hi < a.n ? hi : (a.n ? a.n - 1 : 0);                     // reads below `safe` may be read 16 bytes at a time from any column
+        const u32 c0 = (a.strip0 + sl) * FXG_QS_STRIP;
+        const u32 nb = a.fixed_len > c0 ? (a.fixed_len - c0 < FXG_QS_STRIP ? a.fixed_len - c0 : FXG_QS_STRIP) : 0u;
+        const u64 tb = (u64)reads_per_step * a.stride;                            // bytes between a lane's rows of consecutive trips
+        u64 at = r0 * a.stride + (nb ? c0 : 0u), first = lo;                      // `first`: first read of the trip (wave-uniform)
+        if (first + (u64)(2u * D + 1u) * reads_per_step <= safe) {
+            FxgStripRow buf[D + 1];
+#pragma unroll
+            for (u32 k = 0; k < D; ++k) { buf[k].vb = fxg_ld16(a.bases + at + k * tb); buf[k].vq = fxg_ld16(a.qual + at + k * tb); buf[k].nb = nb; }
+            while (first + (u64)(2u * D + 1u) * reads_per_step <= safe) {         // a group of D + 1 trips: all of them and the D behind them lie inside the slice
+#pragma unroll
+                for (u32 k = 0; k <= D; ++k) {
+                    FxgStripRow &in = buf[(k + D) % (D + 1u)];
+                    in.vb = fxg_ld16(a.bases + at + (u64)D * tb); in.vq = fxg_ld16(a.qual + at + (u64)D * tb); in.nb = nb;
+                    if (since + reads_per_step > 65535u) {
+                        __syncthreads();
+                        fxg_stats_flush(qs_h, part, tid, FXG_QS_TBLOCK);
+                        __syncthreads();
+                        since = 0;
+                    }
+                    fxg_stats_accumulate(a, buf[k], sl, c0, mfix, qs_h);
+                    since += reads_per_step; first += reads_per_step; g0 += (u64)FXG_QS_TBLOCK; r0 += reads_per_step; at += tb;
+                }
+            }
+#pragma unroll
+            for (u32 k = 0; k < D; ++k) {                                         // the D trips whose rows are already here
+                if (since + reads_per_step > 65535u) {
+                    __syncthreads();
+                    fxg_stats_flush(qs_h, part, tid, FXG_QS_TBLOCK);
+                    __syncthreads();
+                    since = 0;
+                }
+                fxg_stats_accumulate(a, buf[k], sl, c0, mfix, qs_h);
+                since += reads_per_step; g0 += (u64)FXG_QS_TBLOCK; r0 += reads_per_step;
+            }
+        }
+    } else
+#endif
     if (!a.len && a.qual) {
         const u64 safe = hi < a.n ? hi : (a.n ? a.n - 1 : 0);                     // reads below `safe` may be read 16 bytes at a time from any column
         const u32 c0 = (a.strip0 + sl) * FXG_QS_STRIP;

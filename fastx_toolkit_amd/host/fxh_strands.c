@@ -491,6 +491,39 @@ static void *fxh_cut_main(void *arg)
     return NULL;
 }
 
+/* The chunk boundaries of one byte range [lo, hi) of the input: cut[0] = lo, cut[n] = hi, every cut in between the start of a record (found by pattern, several
+ * threads).  Returns the cuts (caller frees) with *nchunks_io / *longest set, or NULL when the range cannot be cut into chunks of about `chunk` bytes (records
+ * longer than a chunk, no record pattern in reach): such an input runs as one stream. */
+static off_t *fxh_range_cuts(int fd, int lpr, off_t lo, off_t hi, off_t file_size, size_t chunk, uint64_t *nchunks_io, size_t *longest_out)
+{
+    uint64_t nchunks = *nchunks_io;
+    off_t *cut = (off_t *)calloc(nchunks + 1, sizeof(off_t));
+    if (!cut) err(1, "out of memory");
+    cut[0] = lo; cut[nchunks] = hi;
+    fxh_cutjob cj[8];
+    pthread_t th[8];
+    const int nt = nchunks > 64 ? 8 : 1;
+    for (int i = 0; i < nt; ++i) {
+        cj[i].fd = fd; cj[i].lpr = lpr; cj[i].start = lo; cj[i].size = file_size; cj[i].chunk = chunk; cj[i].cut = cut; cj[i].bad = 0;
+        cj[i].c0 = 1 + (nchunks - 1) * (uint64_t)i / (uint64_t)nt; cj[i].c1 = 1 + (nchunks - 1) * (uint64_t)(i + 1) / (uint64_t)nt;
+    }
+    for (int i = 1; i < nt; ++i) if (pthread_create(&th[i], NULL, fxh_cut_main, &cj[i]) != 0) err(1, "pthread_create");
+    fxh_cut_main(&cj[0]);
+    for (int i = 1; i < nt; ++i) pthread_join(th[i], NULL);
+    int bad = 0;
+    for (int i = 0; i < nt; ++i) bad |= cj[i].bad;
+    while (!bad && nchunks > 1 && cut[nchunks - 1] >= hi) nchunks--;      /* a last nominal cut whose record start is the range's end: no chunk there */
+    cut[nchunks] = hi;
+    size_t longest = 0;
+    for (uint64_t c = 0; c < nchunks && !bad; ++c) {
+        if (cut[c + 1] <= cut[c]) bad = 1;               /* records longer than a chunk, or no record pattern in reach: one stream */
+        else if ((size_t)(cut[c + 1] - cut[c]) > longest) longest = (size_t)(cut[c + 1] - cut[c]);
+    }
+    if (bad || longest > chunk + chunk / 2) { free(cut); return NULL; }
+    *nchunks_io = nchunks; *longest_out = longest;
+    return cut;
+}
+
 static long fxh_env_long(const char *name, long dflt, long lo, long hi)
 {
     const char *e = getenv(name);
@@ -631,44 +664,33 @@ static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot,
      * the same cuts); from here on `start` .. `size` is that range */
     const off_t file_size = size;
     off_t my_start = start, my_end = size;
+    size_t chunk = (size_t)fxh_env_long("FXH_STRAND_KB", 0, 0, 1 << 22) << 10;     /* (tests: chunks of a few KB) */
+    if (!chunk) chunk = (size_t)fxh_env_long("FXH_STRAND_MB", 16, 1, 1024) << 20;      /* 16 MB: 54.6 against 51.7 Mreads/s with 8 (profiles/r05/f_e2e_one_file_timeline.txt) */
+    off_t *cut = NULL;
+    uint64_t nchunks = 0;
+    size_t S_longest_ = 0;
     if (world > 1) {
+        /* Whether the job runs by ranks is decided HERE, before any rank meets another, and it must be the same decision in every rank: a rank that left
+         * on a check of its own range alone would leave the others waiting in the rendezvous (the communicator has no watch of its own).  So every rank
+         * looks at EVERY rank's range -- the same cuts, the same verdict (a few thousand small reads for a file of 100 GB) -- and keeps the cuts of its own. */
         off_t lo = start;
         for (int g = 1; g <= world; ++g) {
             const off_t hi = g == world ? file_size : fxh_find_cut(rd->fd, start + (off_t)((unsigned long long)(file_size - start) * (unsigned)g / (unsigned)world), file_size, lpr, 0);
-            if (hi < 0 || hi <= lo) return -1;           /* an input too small for that many ranks */
-            if (g - 1 == rank) { my_start = lo; my_end = hi; }
+            if (hi < 0 || hi <= lo) { free(cut); return -1; }      /* an input too small for that many ranks */
+            uint64_t n = ((uint64_t)(hi - lo) + chunk - 1) / chunk;
+            size_t longest = 0;
+            off_t *c = fxh_range_cuts(rd->fd, lpr, lo, hi, file_size, chunk, &n, &longest);
+            if (!c) { free(cut); return -1; }              /* some rank's range cannot be cut: no rank starts, rank 0 runs the input as one stream */
+            if (g - 1 == rank) { my_start = lo; my_end = hi; cut = c; nchunks = n; S_longest_ = longest; } else free(c);
             lo = hi;
         }
-    }
-
-    size_t chunk = (size_t)fxh_env_long("FXH_STRAND_KB", 0, 0, 1 << 22) << 10;     /* (tests: chunks of a few KB) */
-    if (!chunk) chunk = (size_t)fxh_env_long("FXH_STRAND_MB", 16, 1, 1024) << 20;      /* 16 MB: 54.6 against 51.7 Mreads/s with 8 (profiles/r05/f_e2e_one_file_timeline.txt) */
-    uint64_t nchunks = ((uint64_t)(my_end - my_start) + chunk - 1) / chunk;
-    if (nchunks < 2 && !ranked) return -1;
-    off_t *cut = (off_t *)calloc(nchunks + 1, sizeof(off_t));
-    if (!cut) err(1, "out of memory");
-    cut[0] = my_start; cut[nchunks] = my_end;
-    {
-        fxh_cutjob cj[8];
-        pthread_t th[8];
-        const int nt = nchunks > 64 ? 8 : 1;
-        for (int i = 0; i < nt; ++i) {
-            cj[i].fd = rd->fd; cj[i].lpr = lpr; cj[i].start = my_start; cj[i].size = file_size; cj[i].chunk = chunk; cj[i].cut = cut; cj[i].bad = 0;
-            cj[i].c0 = 1 + (nchunks - 1) * (uint64_t)i / (uint64_t)nt; cj[i].c1 = 1 + (nchunks - 1) * (uint64_t)(i + 1) / (uint64_t)nt;
-        }
-        for (int i = 1; i < nt; ++i) if (pthread_create(&th[i], NULL, fxh_cut_main, &cj[i]) != 0) err(1, "pthread_create");
-        fxh_cut_main(&cj[0]);
-        for (int i = 1; i < nt; ++i) pthread_join(th[i], NULL);
-        int bad = 0;
-        for (int i = 0; i < nt; ++i) bad |= cj[i].bad;
-        while (!bad && nchunks > 1 && cut[nchunks - 1] >= my_end) nchunks--;      /* a last nominal cut whose record start is the range's end: no chunk there */
-        cut[nchunks] = my_end;
+        chunk = S_longest_;                                  /* (now: the buffer a chunk of THIS rank needs) */
+    } else {
+        nchunks = ((uint64_t)(my_end - my_start) + chunk - 1) / chunk;
+        if (nchunks < 2 && !ranked) return -1;
         size_t longest = 0;
-        for (uint64_t c = 0; c < nchunks && !bad; ++c) {
-            if (cut[c + 1] <= cut[c]) bad = 1;               /* records longer than a chunk, or no record pattern in reach: one stream */
-            else if ((size_t)(cut[c + 1] - cut[c]) > longest) longest = (size_t)(cut[c + 1] - cut[c]);
-        }
-        if (bad || longest > chunk + chunk / 2) { free(cut); return -1; }
+        cut = fxh_range_cuts(rd->fd, lpr, my_start, my_end, file_size, chunk, &nchunks, &longest);
+        if (!cut) return -1;
         chunk = longest;                                     /* (now: the buffer a chunk needs) */
     }
     /* The attempt runs in a CHILD process, like the sharded run's (fxh_parts.c): anything irregular abandons it, the child empties the
@@ -676,7 +698,13 @@ static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot,
     fflush(NULL);
     const double t_fork = fxh_now();
     const pid_t child = fork();
-    if (child < 0) { free(cut); return -1; }
+    if (child < 0) {
+        /* no process to run the attempt in.  Alone, that means one stream.  In a job the other ranks are on their way to the rendezvous: this rank cannot
+         * take part (no fork over a live runtime: see above), so it says so and ends the job -- the others' watch (fxh_watch around the rendezvous) ends them. */
+        free(cut);
+        if (world > 1) err(1, "rank %d of %d: fork", rank, world);
+        return -1;
+    }
     if (child > 0) {
         int st = 0;
         free(cut);
@@ -806,7 +834,11 @@ static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot,
         fflush(stdout);
         const int saved_out = dup(STDOUT_FILENO);
         if (saved_out >= 0) (void)dup2(STDERR_FILENO, STDOUT_FILENO);
+        /* (under a watch like the exchanges: the rendezvous time-out covers the wait for the record, not a communicator that a missing rank never completes) */
+        fxh_watch cw;
+        fxh_watch_start(&cw, rank, world, "the rendezvous (making the communicator)");
         const int crc = fxg_comm_create(S->main_ctx, rdv, (uint32_t)rank, (uint32_t)world, (int)fxh_env_long("FXH_RENDEZVOUS_TIMEOUT", 120, 1, 86400), &comm);
+        fxh_watch_stop(&cw);
         fflush(stdout);
         if (saved_out >= 0) { (void)dup2(saved_out, STDOUT_FILENO); close(saved_out); }
         if (crc != 0) errx(1, "rank %d of %d: no communicator (%d): %s", rank, world, crc, fxg_last_error(S->main_ctx));

@@ -318,12 +318,12 @@ def test_invalid_requests_and_bad_base(engine):
     assert int(e["counters"][1]) == 2000
 
 
-def _window_check(engine, seed, N, L, ad, pd, K=40000, interior=10, KI=3000, expect=None):
+def _window_check(engine, seed, N, L, ad, pd, K=40000, interior=10, KI=3000, expect=None, first=0, light=False):
     """Full-size run on device-generated reads; check a prefix window, a suffix window and `interior` seeded windows in between against
     the oracle (res[] of the window, and the window's bytes at their place in the packed stream), the offset algebra on the device,
     run-to-run determinism, and the call shape bench.py times (meta=False: same stream, same res[], same checksum)."""
     import torch
-    b, q = engine.synth(seed, 0, N, L, ad)
+    b, q = engine.synth(seed, first, N, L, ad)              # first: the shard's first read (rank g of a weak-scaling run: g * N)
     r = engine.run(b, q, _engine_params(pd), fixed_len=L)
     c = r.counters
     kept, nbytes = int(c[1]), int(c[2])
@@ -338,14 +338,14 @@ def _window_check(engine, seed, N, L, ad, pd, K=40000, interior=10, KI=3000, exp
     assert torch.equal(off, r.out_off[:kept])
     assert torch.equal(r.kept_index[:kept].to(torch.int64), torch.nonzero(keepmask).flatten())
     # prefix window
-    ob, oq = fo.synth_batch(seed, 0, K, L, ad)
+    ob, oq = fo.synth_batch(seed, first, K, L, ad)
     o = fo.run_pipeline(ob, oq, None, oracle_params(pd))
     k0, n0 = int(o["counters"][1]), int(o["counters"][2])
     assert np.array_equal(r.res[:K].cpu().numpy().view(np.uint32), o["res"])
     assert np.array_equal(r.out_bases[:n0].cpu().numpy(), o["out_bases"]) and np.array_equal(r.out_qual[:n0].cpu().numpy(), o["out_qual"])
     assert np.array_equal(r.out_len[:k0].cpu().numpy().view(np.uint16), o["out_len"])
     # suffix window: the last K reads must be the tail of the packed output
-    ob, oq = fo.synth_batch(seed, N - K, K, L, ad)
+    ob, oq = fo.synth_batch(seed, first + N - K, K, L, ad)
     o = fo.run_pipeline(ob, oq, None, oracle_params(pd))
     k1, n1 = int(o["counters"][1]), int(o["counters"][2])
     assert np.array_equal(r.res[N - K:].cpu().numpy().view(np.uint32), o["res"])
@@ -357,7 +357,7 @@ def _window_check(engine, seed, N, L, ad, pd, K=40000, interior=10, KI=3000, exp
     for r0 in sorted(int(x) for x in rng.integers(K, N - K - KI, size=interior)):
         rank = int(keepmask[:r0].sum())
         o0 = int(r.out_off[rank]) if rank < kept else nbytes
-        ob, oq = fo.synth_batch(seed, r0, KI, L, ad)
+        ob, oq = fo.synth_batch(seed, first + r0, KI, L, ad)
         o = fo.run_pipeline(ob, oq, None, oracle_params(pd))
         kw, nw = int(o["counters"][1]), int(o["counters"][2])
         assert np.array_equal(r.res[r0:r0 + KI].cpu().numpy().view(np.uint32), o["res"]), ("interior res", r0)
@@ -369,6 +369,10 @@ def _window_check(engine, seed, N, L, ad, pd, K=40000, interior=10, KI=3000, exp
     print("window_check seed %d N %d: (kept, kept_bytes, checksum) = (%d, %d, %d)" % (seed, N, kept, nbytes, cs))
     if expect is not None:                                       # bench.py pins (kept, kept_bytes, checksum) of its default workloads
         assert (kept, nbytes) == tuple(expect[:2]) and expect[2] in (None, cs), ((kept, nbytes, cs), expect)
+    if light:                                                    # (the other shards of a config: the windows and the pinned tuple, not the call-shape repeats)
+        del res, keepmask, lens, ol, off, r, b, q
+        torch.cuda.empty_cache()
+        return kept, nbytes
     # the benchmarked call shape: no per-kept-read arrays (three NULL pointers in the launch arguments).  Compared through the checksum:
     # at 200 M reads a second copy of the 56 GB stream next to two output sets does not fit beside the inputs.
     del res, keepmask, lens, ol, off, r
@@ -390,28 +394,43 @@ def test_full_size_cfg2_quality_trim_filter(engine):
     """BASELINE config 2: 50 M x 150 bp, fastq_quality_trimmer -t 20 -l 30 | fastq_quality_filter -q 20 -p 80."""
     import bench
     kept, nbytes = _window_check(engine, 2, 50_000_000, 150, False,
-                                 dict(stages=6, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80), expect=bench.EXPECTED["cfg2"])
+                                 dict(stages=6, qt_threshold=20, qt_min_len=30, qf_min_quality=20, qf_min_percent=80), expect=bench.EXPECTED["cfg2"][0])
     assert 0.6 < kept / 50e6 < 0.75
 
 
 def test_full_size_cfg4_revcomp_trim(engine):
     """BASELINE config 4 at its stated size: 200 M x 150 bp, fastx_reverse_complement | fastx_trimmer -f 5 -l 145."""
     import bench
-    kept, nbytes = _window_check(engine, 2, 200_000_000, 150, False, dict(stages=24, ft_first=5, ft_last=145), K=20000, interior=8, expect=bench.EXPECTED["cfg4"])
+    kept, nbytes = _window_check(engine, 2, 200_000_000, 150, False, dict(stages=24, ft_first=5, ft_last=145), K=20000, interior=8, expect=bench.EXPECTED["cfg4"][0])
     assert kept == 200_000_000 and nbytes == 141 * kept
 
 
 def test_full_size_cfg3_clipper(engine):
     """BASELINE config 3: 50 M x 100 bp, fastx_clipper -a AGATCGGAAGAGC -l 15 -n."""
     import bench
-    _window_check(engine, 3, 50_000_000, 100, True, dict(stages=1, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=4), K=20000, interior=8, expect=bench.EXPECTED["cfg3"])
+    _window_check(engine, 3, 50_000_000, 100, True, dict(stages=1, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=4), K=20000, interior=8, expect=bench.EXPECTED["cfg3"][0])
 
 
 def test_cfg5_pipeline_shard(engine):
     """BASELINE config 5, one rank's shard (1 B / 8 = 125 M reads x 150 bp): clip -> quality-trim -> filter in one pass."""
     _window_check(engine, 5, 125_000_000, 150, True,
                   dict(stages=7, adapter=b"AGATCGGAAGAGC", clip_min_len=15, clip_flags=4, qt_threshold=20, qt_min_len=30,
-                       qf_min_quality=20, qf_min_percent=80), K=20000, interior=8, expect=__import__("bench").EXPECTED["cfg5shard"])
+                       qf_min_quality=20, qf_min_percent=80), K=20000, interior=8, expect=__import__("bench").EXPECTED["cfg5shard"][0])
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg5shard"])
+def test_every_rank_shard_is_pinned(engine, cfg):
+    """What ranks 1..7 of an 8-GPU weak-scaling run of bench.py must produce, verified the way rank 0's tuple is: the shard's reads
+    [g * R, (g + 1) * R) generated on the device, run once, res[] and the packed streams compared with the oracle in a prefix window, a suffix
+    window and seeded interior windows, and (kept, kept bases, checksum) equal to bench.EXPECTED[cfg][g] -- so that every rank of the driver's
+    1/2/4/8 curve self-checks against an oracle-verified tuple, not only the shard that starts at read 0 (one process over one stream,
+    fastq_quality_trimmer.c:76-124: the job's output is the ranks' outputs in rank order)."""
+    import bench
+    c = bench.CONFIGS[cfg]
+    assert len(bench.EXPECTED[cfg]) == 8
+    for g in range(1, 8):
+        _window_check(engine, c["seed"], c["reads"], c["L"], c["adapter"], c["params"], K=6000, interior=3, KI=2000, expect=bench.EXPECTED[cfg][g],
+                      first=g * c["reads"], light=True)
 
 
 def test_bench_two_ranks_on_one_gpu_via_gloo():
@@ -435,9 +454,20 @@ def test_bench_two_ranks_on_one_gpu_via_gloo():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
     assert d["config"]["reads_per_gpu"] == 2000000
+    sc = d["self_check"]                                          # every rank reports; at this size nothing is pinned, so nothing may claim to be
+    assert [v["rank"] for v in sc["per_rank"]] == [0, 1] and sc["ranks_unpinned"] == [0, 1] and sc["ranks_checked"] == 0, sc
     er = d["e2e_ranks"]                                          # the tool's rank mode: one input, one output, two processes, barrier to barrier
     assert "rank mode" in er["mode"], er
     assert er["ranks"] == 2 and er["reads_per_rank"] == 500000 and 0 < er["kept_reads"] < 1000000 and er["mreads_s"] > 0, er
+    # at the config's own size both ranks hold pinned shards (rank 1: reads [50 M, 100 M) of seed 2) and BOTH check themselves; a mismatch on either fails the job
+    cmdp = cmd[:cmd.index("--steps")] + ["--steps", "2", "--warmup", "1"]
+    pp = subprocess.run(cmdp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert pp.returncode == 0, pp.stderr[-2000:]
+    dp = json.loads([l for l in pp.stdout.decode().splitlines() if l.startswith("{")][-1])
+    scp = dp["self_check"]
+    assert scp["ranks_checked"] == 2 and scp["ranks_ok"] == 2 and scp["ranks_unpinned"] == [] and [v["ok"] for v in scp["per_rank"]] == [True, True], scp
+    import bench
+    assert [(v["kept"], v["kept_bases"], v["checksum"]) for v in scp["per_rank"]] == [tuple(t) for t in bench.EXPECTED["cfg2"][:2]]
     # the same million reads through ONE rank: the job's kept reads and the md5 of its output (the ranks' outputs in rank order) must not
     # depend on how many ranks shared the work
     cmd1 = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--reads", "2000000", "--e2e", "--e2e-reads", "1000000",

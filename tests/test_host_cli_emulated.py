@@ -753,6 +753,29 @@ def test_rank_per_gpu_job_writes_the_one_file_and_rank0_reports(tools, tmp_path,
     assert all(p.returncode == 0 for p in ps) and outp.read_bytes() == (tmp_path / "single0").read_bytes() and all(o == b"" for o, _ in outs[1:])
 
 
+def test_rank_job_whose_input_one_rank_cannot_cut_starts_in_no_rank(tools, tmp_path):
+    """Whether a job runs by ranks is decided before the ranks meet, so it must be the same decision everywhere: a region that cannot be cut into chunks
+    (here: records far longer than a chunk) lies in rank 1's byte range ONLY.  Every rank looks at every rank's range, so rank 0 sees it too: no rank goes
+    to the rendezvous (a rank that did would wait there for the one that left), ranks 1 and 2 leave with 0 and rank 0 runs the input as one stream --
+    the single-process bytes and report.  Bounded by the test's own time-out: a hang is a failure."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    def rec(i, n):
+        b = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n))
+        return b"@r%d\n" % i + b + b"\n+\n" + b"I" * n + b"\n"
+    parts = [rec(i, 100) for i in range(3000)]
+    text = b"".join(parts[:1500]) + b"".join(rec(10000 + i, 20000) for i in range(6)) + b"".join(parts[1500:])      # the long records sit in the middle third
+    inp = tmp_path / "in.fq"
+    inp.write_bytes(text)
+    argv = ["fastx_reverse_complement", "-v"]
+    one = _run([os.path.join(tools, argv[0])] + argv[1:] + ["-i", str(inp), "-o", str(tmp_path / "one.fq")], b"", buf_mb="1", extra_env={"FXH_ONE_FILE": "0"})
+    assert one[0] == 0
+    res = _rank_job(tools, argv, inp, tmp_path / "job.fq", 3, tmp_path, extra={"FXH_STRAND_KB": "4", "FXH_RENDEZVOUS_TIMEOUT": "20", "FXH_RANK_TIMEOUT": "20"})
+    assert [rc for rc, _, _ in res] == [0, 0, 0], [e[-300:] for _, _, e in res]
+    assert (tmp_path / "job.fq").read_bytes() == (tmp_path / "one.fq").read_bytes() and res[0][1] == one[1]
+    assert res[1][1] == b"" and res[2][1] == b""
+
+
 def test_rank_job_is_done_when_every_rank_has_written(tools, tmp_path):
     """Rank 0's exit code is the job's.  After the ranks have written their parts they meet a second time (each rank's errno, 0 = written): a rank that could not
     write -- here: a file size limit on rank 1 alone -- says so there, rank 0 names it and leaves with 1; a rank that DIED on the way never arrives, and
