@@ -104,6 +104,9 @@ struct FxgKArgs {
     float *clip_ck;         // two-pass clipper for 17..99 adapter columns (fxg_clip_two_pass_k): score-row checkpoints, FXG_CK_SLOTS x bucket x threads floats per workgroup (null: one pass)
     u32  clip_ck_rows;      // a checkpoint every this many rows
     u32  clip_ptab_rows;    // rows of the workgroup's pair table (fxg_kernels.h: fxg_ptab_rows), 0 = the instance has none
+    u32  clip_ptab_stride;  // bytes between two of its rows (an odd multiple of 16 where rows are wider than a bank sweep: fxg_ptab_stride)
+    u32  clip_ptab_cols;    // columns per row (the instance's bucket rounded up to a multiple of four)
+    u32  clip_ptab_dia1;    // what a non-neutral diagonal step adds to the path summary of the instance's form (FXG_PK_DIA1 / FXG_K_DIA1)
 #ifdef FXG_CLIP_DEBUG
     u32 *clip_dbg;          // debug builds only (scripts/debug/clip64_bisect.py): 16 words per read of fxg_clip_two_pass_k's intermediate state
 #endif

@@ -72,6 +72,13 @@ int fxg_launch_clip_k_wide_wide(fxg_ctx *c, FxgPlan &pl, u64 *ctr)
 }
 #endif
 
+// adapters that contain N: instances of their own only in builds without the pair table (-DFXG_NO_PTAB: A/B measurements); with it an N is one more column
+// pattern of the table and the plan never asks for them (fxg_plan.h)
+#ifndef FXG_NO_PTAB
+#if !defined(FXG_CLIP_TU) || FXG_CLIP_TU == 3
+int fxg_launch_clip_n(fxg_ctx *c, FxgPlan &pl, u64 *) { return fxg_fail(c, FXG_E_INVALID, "no clip instance %d in this build", pl.amax); }
+#endif
+#else
 #if !defined(FXG_CLIP_TU) || FXG_CLIP_TU == 3
 // adapters that contain N
 int fxg_launch_clip_n(fxg_ctx *c, FxgPlan &pl, u64 *ctr)
@@ -109,5 +116,6 @@ int fxg_launch_clip_n_wide_wide(fxg_ctx *c, FxgPlan &pl, u64 *ctr)
     }
 }
 #endif
+#endif      // FXG_NO_PTAB
 #undef FXG_TILES_A
 #undef FXG_TILES_C

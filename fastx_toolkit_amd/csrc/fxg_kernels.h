@@ -374,31 +374,34 @@ FXG_HD float fxg_clip_row_score(const FxgKArgs &a, int A, u32 c, int q, float (&
 // ------------------------------------------------------------------------------------------------
 #define FXG_PTAB_LUT_BYTES 512u
 #define FXG_PTAB_ROW_BYTES 64u
-#define FXG_PTAB_N_ROW (FXG_PTAB_LUT_BYTES + FXG_PTAB_ROW_BYTES)      // offset of the 'N' pair row from the table's first byte
 #ifdef FXG_NO_PTAB      // A/B builds (scripts/clip_ab.py): the compare + select cell of rounds 3-5
 __host__ __device__ constexpr bool fxg_clip_uses_ptab(int) { return false; }
 #else
-__host__ __device__ constexpr bool fxg_clip_uses_ptab(int amax) { return amax < 0 && amax >= -16; }      // the register two-pass instances (no N in the adapter)
+__host__ __device__ constexpr bool fxg_clip_uses_ptab(int amax) { return amax < 0; }                     // every packed instance: the register two-pass forms and the 17..99-column forms
 #endif
-// rows of the table for this adapter: "other", 'N', and one per distinct byte of its first 16
+// rows of the table for this adapter: "other", 'N', and one per distinct byte of the adapter
 FXG_HD u32 fxg_ptab_rows(const char *adapter, int alen)
 {
     u32 r = 2u;
-    const int A = alen < 16 ? alen : 16;
-    for (int t = 0; t < A; ++t) {
+    for (int t = 0; t < alen; ++t) {
         bool seen = false;
         for (int u = 0; u < t; ++u) seen = seen || (adapter[u] == adapter[t]);
         r += seen ? 0u : 1u;
     }
     return r;
 }
-FXG_HD u32 fxg_ptab_bytes(u32 rows) { return FXG_PTAB_LUT_BYTES + 2u * rows * FXG_PTAB_ROW_BYTES; }
+// Row stride for `cols` columns.  Up to 16 columns a row is 64 bytes and the rows of A, C, G, T land in different bank groups as they are; wider rows
+// sweep all 64 banks, so the stride is made an ODD multiple of 16 bytes: the rows of any 16 different bytes then start in 16 different 16-byte bank groups
+// and a wave whose lanes fetch the same block of different rows has no bank conflict.
+FXG_HD u32 fxg_ptab_stride(u32 cols) { const u32 s = (cols * 4u + 15u) & ~15u; return cols <= 16u ? FXG_PTAB_ROW_BYTES : (((s >> 4) & 1u) ? s : s + 16u); }
+FXG_HD u32 fxg_ptab_bytes(u32 rows, u32 stride) { return FXG_PTAB_LUT_BYTES + 2u * rows * stride; }
+#define FXG_PTAB_MAX_ROWS_K 8u      // 17..99 columns: adapters of more than six distinct bytes (IUPAC-rich) take the general form instead (fxg_plan.h)
 
 FXG_HD void fxg_clip_ptab_build(const FxgKArgs &a, uint8_t *ptab, u32 tid, u32 nthreads)
 {
     uint16_t *lut = reinterpret_cast<uint16_t *>(ptab);
-    const int A = a.alen < 16 ? a.alen : 16;
-    const u32 R = a.clip_ptab_rows;
+    const int COLS = (int)a.clip_ptab_cols, A = a.alen < COLS ? a.alen : COLS;
+    const u32 R = a.clip_ptab_rows, ST = a.clip_ptab_stride;
     for (u32 b = tid; b < 256u; b += nthreads) {
         int first = -1, rank = 0;                          // first column that holds byte b; distinct bytes in front of it
         for (int t = 0; t < A; ++t) {
@@ -409,14 +412,15 @@ FXG_HD void fxg_clip_ptab_build(const FxgKArgs &a, uint8_t *ptab, u32 tid, u32 n
             rank += seen ? 0 : 1;
         }
         const u32 row = b == (u32)'N' ? 1u : (first < 0 ? 0u : 2u + (u32)rank);
-        lut[b] = (uint16_t)(FXG_PTAB_LUT_BYTES + row * FXG_PTAB_ROW_BYTES);
+        lut[b] = (uint16_t)(FXG_PTAB_LUT_BYTES + row * ST);
         if (b == 0u || b == (u32)'N' || first >= 0) {      // one writer per row (0 is never an adapter byte: the adapter is a C string)
-            float *pv = reinterpret_cast<float *>(ptab + FXG_PTAB_LUT_BYTES + row * FXG_PTAB_ROW_BYTES);
-            u32 *sv = reinterpret_cast<u32 *>(ptab + FXG_PTAB_LUT_BYTES + (R + row) * FXG_PTAB_ROW_BYTES);
-            for (int t = 0; t < 16; ++t) {
-                const bool eq = t < A && (u32)(uint8_t)a.adapter[t] == b;
-                pv[t] = b == (u32)'N' ? 0.1f : (eq ? 1.0f : -1.0f);
-                sv[t] = b == (u32)'N' ? 0u : (1u << 14) + (eq ? 1u : 0u);      // FXG_PK_DIA1 + FXG_PK_MAT1 where the bases are equal
+            float *pv = reinterpret_cast<float *>(ptab + FXG_PTAB_LUT_BYTES + row * ST);
+            u32 *sv = reinterpret_cast<u32 *>(ptab + FXG_PTAB_LUT_BYTES + (R + row) * ST);
+            for (int t = 0; t < COLS; ++t) {
+                const u32 tc = t < A ? (u32)(uint8_t)a.adapter[t] : 0u;
+                const bool eq = tc == b, qn = b == (u32)'N', tn = tc == (u32)'N';              // sequence_alignment.h:157-169: either base N -> neutral
+                pv[t] = tn ? (qn ? 0.0f : 0.1f) : (qn ? 0.1f : (eq ? 1.0f : -1.0f));
+                sv[t] = (tn || qn) ? 0u : a.clip_ptab_dia1 + (eq ? 1u : 0u);                   // DIA1 + MAT1 where the bases are equal; a neutral step counts neither
             }
         }
     }
@@ -615,12 +619,17 @@ FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int 
     u32 cn = 0u, gw0 = 0u, gw1 = 0u;
     int gmax = 0;                                           // GL: last dword of the array that may be read, counted from this row's first
     // staged form: pr / mult = the pair values of row q, on = table offset of row q + 1, cn = the base of row q + 2 -- each fetched a row or more ahead of its use
-    constexpr bool PT = !GL && fxg_clip_uses_ptab(-AMAX);
+    constexpr bool PT = fxg_clip_uses_ptab(-AMAX);
     u32 pr[16] = {}, st[16] = {}, on = 0u;
-    const u32 step_off = PT ? a.clip_ptab_rows * FXG_PTAB_ROW_BYTES : 0u;      // from a byte's pair row to its step row
+    const u32 step_off = PT ? a.clip_ptab_rows * a.clip_ptab_stride : 0u;      // from a byte's pair row to its step row
     if constexpr (GL) {
         gmax = fxg_gl_last_dword(a.clip_total, (u64)(rd - a.clip_src));
         gw0 = fxg_ld32(rd, 0, gmax); gw1 = fxg_ld32(rd, 1, gmax);
+        if constexpr (PT) {
+            const uint16_t *lut = reinterpret_cast<const uint16_t *>(ptab);
+            on = lut[(gw0 >> 8) & 0xFFu];
+            fxg_ptab_fetch<AMAX, false>(ptab, lut[gw0 & 0xFFu], step_off, pr, st);
+        }
     } else if constexpr (PT) {
         const uint16_t *lut = reinterpret_cast<const uint16_t *>(ptab);
         const u32 o0 = lut[rd[0]];
@@ -641,7 +650,14 @@ FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int 
         bool upd = false;                                                                                                    \
         _Pragma("unroll 1") for (; q < qend; ++q) {                                                                          \
             float rm;                                                                                                        \
-            if constexpr (GL) {                                                                                              \
+            if constexpr (GL && PT) {            /* the base of row q + 2 out of the window (q is a scalar), its table offset a row ahead of the fetch */ \
+                const u32 ca = ((((q + 2) >> 2) == (q >> 2) ? gw0 : gw1) >> ((u32)((q + 2) & 3) << 3)) & 0xFFu;             \
+                const u32 on2 = reinterpret_cast<const uint16_t *>(ptab)[ca];                                                \
+                if ((q & 3) == 3) { gw0 = gw1; gw1 = fxg_ld32(rd, (q >> 2) + 2, gmax); }                                     \
+                if (!UR && q >= rows) continue;                                                                              \
+                rm = fxg_clip_row_score_t<AMAX, EARLY>(A, q, S, Sm, pr, st, ptab, on, step_off);                             \
+                on = on2;                                                                                                    \
+            } else if constexpr (GL) {                                                                                       \
                 const u32 c = (gw0 >> ((u32)(q & 3) << 3)) & 0xFFu;                                                          \
                 if ((q & 3) == 3) { gw0 = gw1; gw1 = fxg_ld32(rd, (q >> 2) + 2, gmax); }                                     \
                 if (!UR && q >= rows) continue;                                                                              \
@@ -787,15 +803,120 @@ __host__ __device__ constexpr int fxg_clip_k_amin(int amax, bool tn = false)
     return tn ? (amax <= 16 ? 1 : amax <= 24 ? 17 : amax <= 36 ? 25 : amax <= 48 ? 37 : amax <= 64 ? 49 : 65)        // buckets 16 24 36 48 64 100 (adapters with N)
               : (amax <= 16 ? 1 : amax <= 20 ? 17 : amax <= 40 ? amax - 3 : amax <= 48 ? 41 : amax <= 64 ? 49 : 65);
 }
-template <int AMAX> struct FxgClipK { static constexpr bool SM = AMAX <= 28; static constexpr int NSM = SM ? AMAX : 1; };
+template <int AMAX> struct FxgClipK { static constexpr bool SM = AMAX <= 24; static constexpr int NSM = SM ? AMAX : 1; };
 
 // TN: the adapter may contain 'N' (sequence_alignment.h:157-169: a neutral pair scores 0.1, N against N 0.0, and counts neither as match
 // nor as mismatch).  Which columns are N is the same for every lane, so it costs scalar selects of the masks and two more VALU
 // instructions per cell (the pair value and the diagonal's step each take one more select); the instances without it are unchanged.
+// The rows of the 17..99-column forms with the pair table (round 6): block b of a table row holds the pair values of columns 4 b .. 4 b + 3, the step row
+// what a diagonal step into them adds to the summary.  The sweep is in place -- the diagonal candidate of column t + 1 is taken from column t before the sweep
+// overwrites it -- so it needs value t + 1 while it is at column t: the current block and the next one are kept (one ds_read_b128 each for pairs and steps per
+// four columns, requested a block ahead of their first use: 16 registers), and the cell is add, add, max3, two compares, two selects, add, add -- no compare
+// against the adapter, no select of the pair, no add-with-carry.  An N in the adapter is a column of the table like any other.
+template <int AMAX, bool EARLY, bool TRACK>
+FXG_HD void fxg_clip_row_kt(const FxgKArgs &a, int A, u32 c, int q, u32 vstart, float (&S)[AMAX], float (&Sm)[FxgClipK<AMAX>::NSM], u32 (&W)[AMAX],
+                            float &best, u32 &bw, u32 &bq, const uint8_t *ptab)
+{
+    constexpr bool SM = FxgClipK<AMAX>::SM;
+    constexpr int AMIN = fxg_clip_k_amin(AMAX, false);
+    const u32 po = reinterpret_cast<const uint16_t *>(ptab)[c & 0xFFu];
+    const u32x4 *pp = reinterpret_cast<const u32x4 *>(ptab + po), *sp = reinterpret_cast<const u32x4 *>(ptab + po + a.clip_ptab_rows * a.clip_ptab_stride);
+    const float best_in = best, m5 = fxg_minus5();
+    float uSm = -5.0f;                                                                   // S[q][-1] - 5
+    u32 uW = 0u;
+    u32x4 cp = pp[0], cs = sp[0];
+    float ul = 0.0f + __builtin_bit_cast(float, cp.x);                                   // S[q-1][-1] = query_border = 0
+    u32 wd = cs.x;                                                                       // no predecessor left of column 0: the step alone
+#pragma unroll
+    for (int kb = 0; kb < AMAX; kb += 4) {
+        u32x4 np = cp, ns = cs;
+        if (kb + 4 < AMAX) { np = pp[kb / 4 + 1]; ns = sp[kb / 4 + 1]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = kb + j;
+            if (t >= AMAX) break;
+            float ul_next = 0.0f;
+            u32 wd_next = 0u;
+            if (t + 1 < AMAX) {
+                const u32 pv = j == 0 ? cp.y : j == 1 ? cp.z : j == 2 ? cp.w : np.x;
+                const u32 sv = j == 0 ? cs.y : j == 1 ? cs.z : j == 2 ? cs.w : ns.x;
+                ul_next = S[t] + __builtin_bit_cast(float, pv);
+                wd_next = W[t] + sv;
+            }
+            float left = SM ? Sm[SM ? t : 0] : S[t] + m5;
+            if (EARLY && t > 3) left = (t - 3 > q) ? -100000.0f : left;                  // sequence_alignment.cpp:387-389, rows q < A - 4 only
+            const float sc = fmaxf(fmaxf(ul, uSm), left);
+            const bool isd = (sc == ul), isu = (sc == uSm);                              // diag > up > left on ties (:380-417)
+            u32 w;
+            if (t == 0) {                                                                // diag and up come from outside the matrix: the path starts here
+                const u32 fresh = FXG_K_START(vstart) + FXG_K_SZ1 + (isd ? wd : 0u);
+                w = (isd || isu) ? fresh : W[0];
+            } else {
+                w = isu ? uW : W[t];
+                w = isd ? wd : w;
+            }
+            const u32 wp = w + FXG_K_SZ1;                                                // stored already extended by one gap step, see fxg_clip_row_packed
+            const float scm = sc + m5;
+            S[t] = sc; W[t] = wp;
+            if (SM) Sm[SM ? t : 0] = scm;
+            uSm = scm; uW = wp; ul = ul_next; wd = wd_next;
+            if (!TRACK) continue;
+            if (t < AMIN) {
+                const bool gb = sc > best;
+                bw = gb ? w : bw;
+                best = fmaxf(best, sc);
+            } else {
+                const bool gb = (sc > best) && (t < A);
+                best = gb ? sc : best; bw = gb ? w : bw;
+            }
+        }
+        cp = np; cs = ns;
+    }
+    if (TRACK) bq = (best > best_in) ? (u32)q : bq;
+}
+
+// scores only (pass 1 of fxg_clip_two_pass_k and its re-run up to the first summary row)
+template <int AMAX, bool EARLY>
+FXG_HD float fxg_clip_row_score_kt(const FxgKArgs &a, int A, u32 c, int q, float (&S)[AMAX], float (&Sm)[AMAX], const uint8_t *ptab)
+{
+    constexpr bool SM = AMAX <= 48;
+    constexpr int AMIN = fxg_clip_k_amin(AMAX, false);
+    const u32 po = reinterpret_cast<const uint16_t *>(ptab)[c & 0xFFu];
+    const u32x4 *pp = reinterpret_cast<const u32x4 *>(ptab + po);
+    const float m5 = fxg_minus5();
+    float uSm = -5.0f, rowmax = -1000000.0f;
+    u32x4 cp = pp[0];
+    float ul = 0.0f + __builtin_bit_cast(float, cp.x);
+#pragma unroll
+    for (int kb = 0; kb < AMAX; kb += 4) {
+        u32x4 np = cp;
+        if (kb + 4 < AMAX) np = pp[kb / 4 + 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = kb + j;
+            if (t >= AMAX) break;
+            float ul_next = 0.0f;
+            if (t + 1 < AMAX) ul_next = S[t] + __builtin_bit_cast(float, j == 0 ? cp.y : j == 1 ? cp.z : j == 2 ? cp.w : np.x);
+            float left = SM ? Sm[SM ? t : 0] : S[t] + m5;
+            if (EARLY && t > 3) left = (t - 3 > q) ? -100000.0f : left;
+            const float sc = fmaxf(fmaxf(ul, uSm), left);
+            const float scm = sc + m5;
+            S[t] = sc;
+            if (SM) Sm[SM ? t : 0] = scm;
+            uSm = scm; ul = ul_next;
+            if (t < AMIN) rowmax = fmaxf(rowmax, sc);
+            else rowmax = (t < A) ? fmaxf(rowmax, sc) : rowmax;
+        }
+        cp = np;
+    }
+    return rowmax;
+}
+
 template <int AMAX, bool EARLY, bool TRACK, bool TN = false>
 FXG_HD void fxg_clip_row_k(const FxgKArgs &a, int A, u32 c, int q, u32 vstart, float (&S)[AMAX], float (&Sm)[FxgClipK<AMAX>::NSM], u32 (&W)[AMAX],
-                           float &best, u32 &bw, u32 &bq)
+                           float &best, u32 &bw, u32 &bq, const uint8_t *ptab = nullptr)
 {
+    if constexpr (fxg_clip_uses_ptab(-AMAX)) { fxg_clip_row_kt<AMAX, EARLY, TRACK>(a, A, c, q, vstart, S, Sm, W, best, bw, bq, ptab); return; }
     constexpr bool SM = FxgClipK<AMAX>::SM;
     constexpr int AMIN = fxg_clip_k_amin(AMAX, TN);
     const bool qn = (c == (u32)'N');
@@ -861,7 +982,7 @@ FXG_HD void fxg_clip_row_k(const FxgKArgs &a, int A, u32 c, int q, u32 vstart, f
 }
 
 template <int AMAX, bool TN>
-FXG_HD void fxg_clip_rows_k(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float &best, u32 &bw, u32 &bq, int &first_n, const bool UR = false)
+FXG_HD void fxg_clip_rows_k(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float &best, u32 &bw, u32 &bq, int &first_n, const bool UR = false, const uint8_t *ptab = nullptr)
 {
     float S[AMAX], Sm[FxgClipK<AMAX>::NSM];
     u32 W[AMAX];
@@ -884,7 +1005,7 @@ FXG_HD void fxg_clip_rows_k(const FxgKArgs &a, const uint8_t *rd, int len, int r
         cn = rd[q + 1];
         if (!UR && q >= rows) continue;
         first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
-        fxg_clip_row_k<AMAX, true, true, TN>(a, A, c, q, (u32)q, S, Sm, W, best, bw, bq);
+        fxg_clip_row_k<AMAX, true, true, TN>(a, A, c, q, (u32)q, S, Sm, W, best, bw, bq, ptab);
     }
 #pragma unroll 1
     for (; q < rows_u; ++q) {
@@ -892,7 +1013,7 @@ FXG_HD void fxg_clip_rows_k(const FxgKArgs &a, const uint8_t *rd, int len, int r
         cn = rd[q + 1];
         if (!UR && q >= rows) continue;
         first_n = (c == (u32)'N' && first_n == len && q < len) ? q : first_n;
-        fxg_clip_row_k<AMAX, false, true, TN>(a, A, c, q, (u32)q, S, Sm, W, best, bw, bq);
+        fxg_clip_row_k<AMAX, false, true, TN>(a, A, c, q, (u32)q, S, Sm, W, best, bw, bq, ptab);
     }
 }
 
@@ -906,8 +1027,9 @@ FXG_HD void fxg_clip_rows_k(const FxgKArgs &a, const uint8_t *rd, int len, int r
 // when r0 = 0), so its `start` is the row RELATIVE to r0: reads of any length fit the 9 bits.
 // ------------------------------------------------------------------------------------------------
 template <int AMAX, bool EARLY, bool TN>
-FXG_HD float fxg_clip_row_score_k(const FxgKArgs &a, int A, u32 c, int q, float (&S)[AMAX], float (&Sm)[AMAX])
+FXG_HD float fxg_clip_row_score_k(const FxgKArgs &a, int A, u32 c, int q, float (&S)[AMAX], float (&Sm)[AMAX], const uint8_t *ptab = nullptr)
 {
+    if constexpr (fxg_clip_uses_ptab(-AMAX)) return fxg_clip_row_score_kt<AMAX, EARLY>(a, A, c, q, S, Sm, ptab);
     constexpr bool SM = AMAX <= 48;                 // the score rows keep S - 5 as well where that still leaves room: nothing else is live while they run
     constexpr int AMIN = fxg_clip_k_amin(AMAX, TN);
     const bool qn = (c == (u32)'N');
@@ -957,7 +1079,8 @@ FXG_HD u32 fxg_fbits(float) { return 0u; }
 #endif
 // returns r0 (the row the `start` field of bw counts from)
 template <int AMAX, bool TN, bool GL = false>      // GL: as in fxg_clip_two_pass
-FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float *ck, u32 cks, float &best, u32 &bw, u32 &bq, int &first_n, u32 *dbg = nullptr, const bool UR = false)
+FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, int rows, float *ck, u32 cks, float &best, u32 &bw, u32 &bq, int &first_n, u32 *dbg = nullptr, const bool UR = false,
+                               const uint8_t *ptab = nullptr)
 {
     (void)dbg;
     float S[AMAX], Sm[AMAX];
@@ -993,7 +1116,7 @@ FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, in
             if ((q & 3) == 3) { gw0 = gw1; gw1 = fxg_ld32(rd, (q >> 2) + 2, gmax); }                                         \
         } else { c = cn; cn = rd[q + 1]; }                                                                                   \
         if (mine) {                                                                                                          \
-            const float rm = fxg_clip_row_score_k<AMAX, EARLY, TN>(a, A, c, q, S, Sm);                                       \
+            const float rm = fxg_clip_row_score_k<AMAX, EARLY, TN>(a, A, c, q, S, Sm, ptab);                                 \
             const bool g = rm > b1;                                                                                          \
             b1 = g ? rm : b1; bq1 = g ? q : bq1;                                                                             \
         }                                                                                                                    \
@@ -1029,7 +1152,7 @@ FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, in
 #pragma unroll 1
         for (int i = 0; i < n0u; ++i) {
             if (i >= n0) continue;
-            (void)fxg_clip_row_score_k<AMAX, true, TN>(a, A, (u32)rd[q], q, S, Sm);
+            (void)fxg_clip_row_score_k<AMAX, true, TN>(a, A, (u32)rd[q], q, S, Sm, ptab);
             ++q;
         }
     }
@@ -1055,13 +1178,13 @@ FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, in
 #pragma unroll 1
     for (int i = 0; i < n1u; ++i) {
         if (i >= n1) continue;
-        fxg_clip_row_k<AMAX, true, false, TN>(a, A, (u32)rd[q], q, (u32)(q - r0), S, Sk, W, best, bw, bq); FXG_CLIP_DBG_ROW();
+        fxg_clip_row_k<AMAX, true, false, TN>(a, A, (u32)rd[q], q, (u32)(q - r0), S, Sk, W, best, bw, bq, ptab); FXG_CLIP_DBG_ROW();
         ++q;
     }
 #pragma unroll 1
     for (int i = 0; i < n2u; ++i) {
         if (i >= n2) continue;
-        fxg_clip_row_k<AMAX, false, false, TN>(a, A, (u32)rd[q], q, (u32)(q - r0), S, Sk, W, best, bw, bq); FXG_CLIP_DBG_ROW();
+        fxg_clip_row_k<AMAX, false, false, TN>(a, A, (u32)rd[q], q, (u32)(q - r0), S, Sk, W, best, bw, bq, ptab); FXG_CLIP_DBG_ROW();
         ++q;
     }
 #if defined(FXG_CLIP_DEBUG) && FXG_CLIP_DEBUG >= 3
@@ -1076,7 +1199,7 @@ FXG_HD int fxg_clip_two_pass_k(const FxgKArgs &a, const uint8_t *rd, int len, in
 #if defined(FXG_CLIP_DEBUG) && FXG_CLIP_DEBUG >= 2
     FXG_CLIP_DBG(10, fxg_dbg_hash(S)); FXG_CLIP_DBG(11, fxg_dbg_hash(W));
 #endif
-    fxg_clip_row_k<AMAX, true, true, TN>(a, A, (u32)rd[bq1], bq1, (u32)(bq1 - r0), S, Sk, W, best, bw, bq);
+    fxg_clip_row_k<AMAX, true, true, TN>(a, A, (u32)rd[bq1], bq1, (u32)(bq1 - r0), S, Sk, W, best, bw, bq, ptab);
     FXG_CLIP_DBG(6, fxg_fbits(best)); FXG_CLIP_DBG(7, bw); FXG_CLIP_DBG(8, bq);
 #if defined(FXG_CLIP_DEBUG) && FXG_CLIP_DEBUG >= 2
     FXG_CLIP_DBG(12, fxg_dbg_hash(S)); FXG_CLIP_DBG(13, fxg_dbg_hash(W));
@@ -1105,8 +1228,8 @@ FXG_HD void fxg_clip_read_packed(const FxgKArgs &a, const uint8_t *rd, int len, 
     if constexpr (!KFORM) fxg_clip_rows_packed<AMAX, false>(a, rd, len, rows, best, bw, bq, first_n, UR);
     if constexpr (KFORM) {
         int r0 = 0;
-        if (ck) r0 = fxg_clip_two_pass_k<AMAX, TN, GL>(a, rd, len, rows, ck, cks, best, bw, bq, first_n, dbg, UR);
-        else fxg_clip_rows_k<AMAX, TN>(a, rd, len, rows, best, bw, bq, first_n, UR);
+        if (ck) r0 = fxg_clip_two_pass_k<AMAX, TN, GL>(a, rd, len, rows, ck, cks, best, bw, bq, first_n, dbg, UR, ptab);
+        else fxg_clip_rows_k<AMAX, TN>(a, rd, len, rows, best, bw, bq, first_n, UR, ptab);
         const int v = (int)(bw >> 23), matches = (int)(bw & 127u), diag = (int)((bw >> 7) & 127u);
         fxg_clip_finish(a, len, v < 256 ? r0 + v : 0, v < 256 ? 0 : v - 256, diag - matches, (int)((bw >> 14) & 511u), matches,
                         (int)bq, first_n, out_len, keep, reason, clipped, adapter_only);
@@ -1412,8 +1535,8 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
     const u32 T = a.tile_reads, stride = a.stride, tid = threadIdx.x;
     const bool use_q = (MODE == 0 && (a.stages & (FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0) || MODE == 3;
     const u32 NSLOT = (MODE == 0 && AMAX != 0) ? a.depth : 2u;        // tiles between decision and write-out (fxg_plan.h)
-    constexpr bool PTAB = MODE == 0 && !GL && fxg_clip_uses_ptab(AMAX);      // pass 1 takes its pair values from an LDS table
-    const FxgLds L = fxg_lds_layout(T, stride, fxg_bitmap_count(a, use_q, MODE == 0 && AMAX != 0), (MODE == 0 && AMAX != 0) ? (GL ? 0u : a.clip_stride) : (MODE == 4 ? stride : 0u), NSLOT, MODE == 0 && AMAX != 0, PTAB ? fxg_ptab_bytes(a.clip_ptab_rows) : 0u);
+    constexpr bool PTAB = MODE == 0 && fxg_clip_uses_ptab(AMAX);            // the DP takes its pair values from an LDS table (staged form and over-the-batch form alike)
+    const FxgLds L = fxg_lds_layout(T, stride, fxg_bitmap_count(a, use_q, MODE == 0 && AMAX != 0), (MODE == 0 && AMAX != 0) ? (GL ? 0u : a.clip_stride) : (MODE == 4 ? stride : 0u), NSLOT, MODE == 0 && AMAX != 0, PTAB ? fxg_ptab_bytes(a.clip_ptab_rows, a.clip_ptab_stride) : 0u);
     u32 m_reads = 0, m_nt = 0, art_bad = 0;      // MODE 3 report counters / MODE 4 alphabet check, folded once at the end
     u32 *bm_g = reinterpret_cast<u32 *>(smem + L.off_bm_g);
     u32 *bm_l = reinterpret_cast<u32 *>(smem + L.off_bm_l);
@@ -1480,7 +1603,7 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
             if (tid < nreads) {
                 if constexpr (MODE == 0 && AMAX < -16) {
                     float *ck = a.clip_ck ? a.clip_ck + (size_t)blockIdx.x * ((size_t)FXG_CK_SLOTS * (u32)fxg_clip_cols(AMAX) * TB) + tid : nullptr;
-                    word = fxg_decide_a<AMAX, GL>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen, ck, TB);      // (GL only with checkpoint scratch: fxg_plan.h)
+                    word = fxg_decide_a<AMAX, GL>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen, ck, TB, PTAB ? smem + L.off_ptab : nullptr);      // (GL only with checkpoint scratch: fxg_plan.h)
                 } else if constexpr (MODE == 0 && AMAX < 0) {     // register two-pass instances: the DP over the staged tile, or straight over the batch (fxg_plan.h: clip_global)
                     word = fxg_decide_a<AMAX, GL>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen, nullptr, 0u, PTAB ? smem + L.off_ptab : nullptr);
                 } else if constexpr (MODE == 0) word = fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen);

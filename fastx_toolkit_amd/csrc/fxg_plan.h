@@ -41,7 +41,7 @@ static inline FxgLds fxg_plan_layout(const FxgPlan *pl)
 {
     const FxgKArgs &ka = pl->ka;
     return pl->group_a ? fxg_lds_layout(ka.tile_reads, ka.stride, fxg_bitmap_count(ka, pl->use_q, pl->clip), (pl->clip && !ka.clip_global) ? ka.clip_stride : 0u, pl->clip ? ka.depth : 2u, pl->clip,
-                                        (pl->clip && !ka.clip_global && fxg_clip_uses_ptab(pl->amax)) ? fxg_ptab_bytes(ka.clip_ptab_rows) : 0u)
+                                        (pl->clip && fxg_clip_uses_ptab(pl->amax)) ? fxg_ptab_bytes(ka.clip_ptab_rows, ka.clip_ptab_stride) : 0u)
          : pl->mask ? fxg_lds_layout(ka.tile_reads, ka.stride, 2u, 0u)
          : pl->artifacts ? fxg_lds_layout(ka.tile_reads, ka.stride, 0u, ka.stride) : fxg_lds_layout(ka.tile_reads, ka.stride, 0u, 0u);
 }
@@ -116,22 +116,41 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
 #else
     const bool reg_any_len = true;
 #endif
-    const bool kform = pl->clip && (ka.alen > 16 || ka.adapter_has_n || (ka.clip_stride > 255u && !reg_any_len));
-    const bool two_pass_k = kform && (ka.clip_stride >= 20u + 2u * (u32)ka.alen || ka.clip_stride > 255u) && !getenv("FXG_CLIP_K_ONE_PASS");
+    // (an 'N' in the adapter is one more column pattern of the pair table: the register form serves it like any other adapter)
+    const bool kform = pl->clip && (ka.alen > 16 || (ka.adapter_has_n && !fxg_clip_uses_ptab(-16)) || (ka.clip_stride > 255u && !reg_any_len));
+    // Two passes pay while the summary rows of the second one (at most SPAN = A + (A + 1) / 5 rows up to the best row, plus the scores re-run from the last
+    // checkpoint: < clip_ck_rows) are fewer than the read's rows: a score row is ~5 VALU instructions per cell with the pair table, a summary row ~10, and the
+    // one-pass form tracks the best cell in every row (~15).  (Round 5: from 20 + 2 A bases on -- its score rows cost 7 per cell and a 44-column adapter on
+    // 100-base reads ran in one pass: 17.1 ms per 10 M reads, 12.6 with the table, two passes: profiles/r06/.)
+    ka.clip_ck_rows = (ka.clip_stride + 7u) / 8u < 4u ? 4u : (ka.clip_stride + 7u) / 8u;      // (rows - 1) / clip_ck_rows <= FXG_CK_SLOTS
+    const u32 span_k = (u32)ka.alen + ((u32)ka.alen + 1u) / 5u;
+    // (a tenth of the read as margin: with 65..73 columns on 100-base reads -- 91..99 of 100 rows -- the two passes were 7-13 % behind the one)
+    const bool two_pass_k = kform && (span_k + ka.clip_ck_rows + ka.clip_stride / 10u <= ka.clip_stride || ka.clip_stride > 255u) && !getenv("FXG_CLIP_K_ONE_PASS");
     pl->ck_per_wg = 0;
     ka.clip_ck = nullptr;
-    ka.clip_ck_rows = (ka.clip_stride + 7u) / 8u < 4u ? 4u : (ka.clip_stride + 7u) / 8u;      // (rows - 1) / clip_ck_rows <= FXG_CK_SLOTS
     if (pl->clip && (ka.clip_stride <= 255u || two_pass_k || (!kform && reg_any_len)) && !getenv("FXG_NO_PACKED_CLIP")) {
         // 36: the 33/34-base TruSeq adapters; 56 and 80 (round 5): 49..56 columns no longer pay for 64 (17.4 -> 27.7 ms between 48 and 49 bases,
         // profiles/r04/p_clip_waves_by_adapter_len.txt) and 65..80 no longer for 100
         static const int pk[] = {4, 8, 9, 10, 11, 12, 13, 14, 15, 16, 20, 24, 28, 32, 36, 40, 48, 56, 64, 80, 100};
         static const int pn[] = {16, 24, 36, 48, 56, 64, 80, 100};
         int b = 100;
-        if (ka.adapter_has_n) { for (unsigned i = 0; i < sizeof pn / sizeof pn[0]; ++i) if (ka.alen <= pn[i]) { b = pn[i]; break; } }
+        const bool n_inst = ka.adapter_has_n && kform && !fxg_clip_uses_ptab(-20);      // (builds without the pair table: the instances with per-column neutral selects)
+        if (n_inst) { for (unsigned i = 0; i < sizeof pn / sizeof pn[0]; ++i) if (ka.alen <= pn[i]) { b = pn[i]; break; } }
         else { for (unsigned i = 0; i < sizeof pk / sizeof pk[0]; ++i) if (ka.alen <= pk[i]) { b = pk[i]; break; } }
         if (b < 16 && kform) b = 16;
-        pl->amax = ka.adapter_has_n ? -(300 + b) : (b == 16 && kform) ? -216 : -b;
+        pl->amax = n_inst ? -(300 + b) : (b == 16 && kform) ? -216 : -b;
         if (two_pass_k) pl->ck_per_wg = (u64)FXG_CK_SLOTS * (u64)b * FXG_TBLOCK;
+        // the pair table of the instance (fxg_kernels.h: fxg_clip_ptab_build): as many columns as the bucket, rounded up to whole 16-byte blocks
+        if (fxg_clip_uses_ptab(pl->amax)) {
+            const bool kf = fxg_clip_kform(pl->amax);
+            ka.clip_ptab_cols = kf ? ((u32)b + 3u) & ~3u : 16u;
+            ka.clip_ptab_stride = fxg_ptab_stride(ka.clip_ptab_cols);
+            ka.clip_ptab_dia1 = kf ? FXG_K_DIA1 : FXG_PK_DIA1;
+            if (kf && ka.clip_ptab_rows > FXG_PTAB_MAX_ROWS_K) {      // an adapter of more than six distinct bytes and more than 16 columns: the general form
+                pl->amax = ka.alen <= 32 ? 32 : ka.alen <= 64 ? 64 : 100;
+                pl->ck_per_wg = 0;
+            }
+        }
     }
     // quality trim / filter with compaction over rows of 80..152 bytes: one lane per read, 64 reads per tile (fxg_rows.h).  Shorter
     // rows make its 64-read tiles too small (the tile kernel is 10-15 % ahead at 36-50 bases, ahead at 72, level at 76, 5-10 % behind from 88 on:

@@ -70,7 +70,7 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
     u64 base_c = 0, base_b = 0;
     u32 bad = 0;
     std::vector<u32> keep(T), olen(T), anchor(T);
-    if (pl.group_a && fxg_clip_uses_ptab(AMAX) && !a.clip_global) { for (u32 tid = 0; tid < NT; ++tid) fxg_clip_ptab_build(a, smem + L.off_ptab, tid, NT); }
+    if (pl.group_a && fxg_clip_uses_ptab(AMAX)) { for (u32 tid = 0; tid < NT; ++tid) fxg_clip_ptab_build(a, smem + L.off_ptab, tid, NT); }
     for (u32 tile = 0; tile < a.ntiles; ++tile) {
         const u32 r0 = tile * T;
         const u64 left = a.n - (u64)r0;
@@ -86,10 +86,11 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
                 if (AMAX == 0 && pl.rows_nw) emu_rows_decide(pl.rows_nw, pl.rows_h, a, r0 + tid, &keep[tid], &olen[tid]);   // what a lane of fxg_kernel_rows does
                 else if (AMAX < -16 && pl.ck_per_wg) {        // the two-pass form with its checkpoint scratch (here: one thread's, stride 1)
                     std::vector<float> ck((size_t)FXG_CK_SLOTS * (size_t)(AMAX < 0 ? fxg_clip_cols(AMAX) : 1), (getenv("FXG_EMU_CK_FILL") ? (float)atof(getenv("FXG_EMU_CK_FILL")) : 1.0e30f));   // the device's scratch is not cleared either
-                    if (a.clip_global) { if constexpr (AMAX < -16) fxg_decide_a<AMAX, true>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid], ck.data(), 1u); }
-                    else fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid], ck.data(), 1u);
+                    const uint8_t *pt = fxg_clip_uses_ptab(AMAX) ? smem + L.off_ptab : nullptr;
+                    if (a.clip_global) { if constexpr (AMAX < -16) fxg_decide_a<AMAX, true>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid], ck.data(), 1u, pt); }
+                    else fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid], ck.data(), 1u, pt);
                 } else if (AMAX < 0 && AMAX >= -16 && a.clip_global) {     // the DP straight over the batch (fxg_plan.h: clip_global), as the kernel calls it
-                    if constexpr (AMAX < 0 && AMAX >= -16) fxg_decide_a<AMAX, true>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid]);
+                    if constexpr (AMAX < 0 && AMAX >= -16) fxg_decide_a<AMAX, true>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid], nullptr, 0u, fxg_clip_uses_ptab(AMAX) ? smem + L.off_ptab : nullptr);
                 } else if (fxg_clip_uses_ptab(AMAX)) {                     // the staged register form: pair values out of the workgroup's table
                     fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid], nullptr, 0u, smem + L.off_ptab);
                 } else fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep[tid], &olen[tid]);

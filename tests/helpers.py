@@ -246,7 +246,10 @@ def odd_alphabet_clip_cases(seed=77):
     bytes with `==` and treats only 'N' as neutral (sequence_alignment.h:147-169), whatever the alphabet -- the pair table of the register two-pass
     instances (fxg_kernels.h: fxg_clip_ptab_build) must serve every byte value the same way.  Yields (name, bases, qual, fixed_len, params_dict)."""
     rng = np.random.default_rng(seed)
-    adapters = [b"agatcggaagagc", b"AGRYCGGAWGAGC", b"ACGTRYKMSWBDHVXZ", b"AcGtAcGtAcG", b"XXXXXXXXXXXXX", b"ACGTacgtACGTa", b"TTTTTTTTTTTTTTTT", b"A", b"zQ"]
+    adapters = [b"agatcggaagagc", b"AGRYCGGAWGAGC", b"ACGTRYKMSWBDHVXZ", b"AcGtAcGtAcG", b"XXXXXXXXXXXXX", b"ACGTacgtACGTa", b"TTTTTTTTTTTTTTTT", b"A", b"zQ",
+                b"agatcggaagagcacacgtctgaactccagtcac", b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCGTATGCCGTCTTCTGCTTG", b"AGRYCGGAWGAGCACACGTCTGAAC", b"AcGtNNAcGtAcGtAcGtAcGt" * 2]
+    # (the long ones: four distinct bytes in lower case -> the pair table of the 36-column instance; N columns in a 64-column one; seven distinct bytes -> the general form;
+    #  six distinct bytes with N columns -> still the table)
     for k, ad in enumerate(adapters):
         for stride in (13, 36, 100, 151):
             n = int(rng.integers(50, 500))

@@ -162,17 +162,16 @@ def test_clip_over_the_batch_and_over_the_staged_tile(engine, monkeypatch, mode)
 def test_clip_adversarial_every_adapter_bucket(engine, long_adapters):
     """Every clip instance on the inputs built against its assumptions (helpers.adversarial_clip_cases): adapters of 1..16 bases run
     the two-pass form in registers (reads of any length), 17..99 the two-pass form with checkpoints in scratch or,
-    for short reads, its one-pass form, adapters with N the same forms with neutral columns (instances -3xx) -- all against the oracle's
+    for short reads, its one-pass form, adapters with N the same instances (the pair table holds their neutral columns) -- all against the oracle's
     full matrix + traceback.  The kernel that ran is checked, so a bucket that silently fell back to the general form would fail here."""
     seen = set()
     for name, b, q, pd in adversarial_clip_cases(long_adapters):
         assert_same(fo.run_pipeline(b, q, None, oracle_params(pd)), _run(engine, b, q, None, pd, fixed_len=b.shape[1]), name)
         k = engine.last_launch()["kernel"]
-        assert "clip(packed" in k and ("N in the adapter" in k) == (b"N" in pd["adapter"]), (name, k)
+        assert "clip(packed" in k, (name, k)                      # (adapters with N run the same instances: an N is a column pattern of the pair table)
         seen.add(k.split(" ")[0])
-    want = {"fxg_kernel_tiles<-%d,0>" % a for a in ((20, 24, 28, 32, 36, 40, 48, 64, 100) if long_adapters else (4, 8, 9, 10, 11, 12, 13, 14, 15, 16, 316))}
+    want = {"fxg_kernel_tiles<-%d,0>" % a for a in ((20, 24, 28, 32, 36, 40, 48, 64, 100) if long_adapters else (4, 8, 9, 10, 11, 12, 13, 14, 15, 16))}
     assert want <= seen, sorted(want - seen)
-    assert not long_adapters or len([k for k in seen if k.startswith("fxg_kernel_tiles<-3") and len(k) > len("fxg_kernel_tiles<-36,0>")]) >= 3, sorted(seen)
 
 
 def test_both_quality_kernels_on_the_same_batches(engine, monkeypatch):
