@@ -240,6 +240,9 @@ static int fxg_launch_plan(fxg_ctx *c, FxgPlan &pl, u64 *ctr)
             return fxg_launch_tiles(c, fxg_kernel_rows<38, 2>, "fxg_kernel_rows<38,2> qtrim+qfilter", pl.ka, pl.lds, ctr, 64u, true);
         }
         switch (pl.rows_nw) {
+        case 10: return fxg_launch_tiles(c, fxg_kernel_rows_multi<10, 4>, "fxg_kernel_rows_multi<10,4> qtrim+qfilter", pl.ka, pl.lds, ctr, 64u, true);      // rows of 28..40 bytes, four reads per lane
+        case 14: return fxg_launch_tiles(c, fxg_kernel_rows_multi<14, 3>, "fxg_kernel_rows_multi<14,3> qtrim+qfilter", pl.ka, pl.lds, ctr, 64u, true);      // 41..56 bytes, three
+        case 20: return fxg_launch_tiles(c, fxg_kernel_rows_multi<20, 2>, "fxg_kernel_rows_multi<20,2> qtrim+qfilter", pl.ka, pl.lds, ctr, 64u, true);      // 57..79 bytes, two
         case 26: return fxg_launch_tiles(c, fxg_kernel_rows<26>, "fxg_kernel_rows<26> qtrim+qfilter", pl.ka, pl.lds, ctr, 64u, true);
         default: return fxg_launch_tiles(c, fxg_kernel_rows<38>, "fxg_kernel_rows<38> qtrim+qfilter", pl.ka, pl.lds, ctr, 64u, true);
         }

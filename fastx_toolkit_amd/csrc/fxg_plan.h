@@ -17,6 +17,7 @@ struct FxgPlan {
     u32  lds;       // dynamic LDS bytes per workgroup
     int  rows_nw;   // != 0: the quality stages run as fxg_kernel_rows<rows_nw, rows_h> (fxg_rows.h): dwords of one lane's piece of a row
     int  rows_h;    // lanes per read of that instance (1: rows up to 152 bytes, 2: up to 304)
+    int  rows_r;    // reads per lane (fxg_kernel_rows_multi: rows of 28..79 bytes; else 1)
     u32  block;     // threads per workgroup of the instance (FxgTileBlock)
     u64  ck_per_wg; // floats of checkpoint scratch per workgroup (fxg_clip_two_pass_k), 0 = the instance runs its one-pass form
 };
@@ -159,13 +160,19 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     // 2 % ahead of the tile kernel at 200 bases, 4 % / 2 % BEHIND at 250 / 300 (a 250-byte row fills 82 % of its two register pieces, and
     // the tile kernel's per-tile costs shrink with the row length) -- so it is the default up to 208 bytes only; FXG_ROWS=2 selects it
     // wherever it exists (tests, measurements), FXG_ROWS=0 never.
-    pl->rows_nw = 0; pl->rows_h = 1;
+    // Rows of 28..79 bytes (round 6): the same kernel with several reads per lane (fxg_kernel_rows_multi: 4 x 40, 3 x 56, 2 x 80 bytes), so that a tile is ~10 KB
+    // again -- 36-base reads 0.44 -> ... of the HBM peak (profiles/r06/rows_multi_short_reads.txt).
+    pl->rows_nw = 0; pl->rows_h = 1; pl->rows_r = 1;
     {
         const int want = getenv("FXG_ROWS") ? atoi(getenv("FXG_ROWS")) : 1;
         const u32 top = want >= 2 ? 304u : 208u;
         if (ga && !pl->clip && ka.compact && in->stride >= 80u && in->stride <= top && want != 0) {
             pl->rows_h = in->stride <= 152u ? 1 : 2;
             pl->rows_nw = in->stride <= 104u * (u32)pl->rows_h ? 26 : 38;
+        } else if (ga && !pl->clip && ka.compact && in->stride >= 28u && in->stride < 80u && want != 0) {
+            if (in->stride <= 40u) { pl->rows_nw = 10; pl->rows_r = 4; }
+            else if (in->stride <= 56u) { pl->rows_nw = 14; pl->rows_r = 3; }
+            else { pl->rows_nw = 20; pl->rows_r = 2; }
         }
     }
     pl->block = pl->rows_nw ? 64u : (ga && pl->amax < 0 && pl->amax >= -16) ? (u32)FXG_CLIP_TBLOCK : (u32)FXG_TBLOCK;     // FxgTileBlock
@@ -177,7 +184,7 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     // 300 bases 6.26 / 4.66 per 6 M, 1 000 bases 13.1 / 5.95 per 2 M: profiles/r04/ae_clip_global_vs_staged*.txt).  Rows must start on dword
     // boundaries; runs with clip history (ragged input of the tools) keep the staged form.  FXG_CLIP_GLOBAL=0 / 1 overrides (tests run both).
     ka.clip_global = 0u;
-    u32 T = pl->rows_nw ? 64u / (u32)pl->rows_h : fxg_pick_tile(pl->clip ? ka.clip_stride : in->stride, pl->clip || gf, pl->block);
+    u32 T = pl->rows_nw ? 64u * (u32)pl->rows_r / (u32)pl->rows_h : fxg_pick_tile(pl->clip ? ka.clip_stride : in->stride, pl->clip || gf, pl->block);
 #ifndef FXG_CLIP_ONE_PASS
     if (pl->clip && pl->amax < 0 && (pl->amax >= -16 || pl->ck_per_wg != 0) && clip_stride == 0u && (ka.clip_stride & 3u) == 0u && ((uintptr_t)ka.clip_src & 3u) == 0u) {      // (clip_stride != 0: a run with clip history, whose rows are settled after the plan)
         ka.tile_reads = T; ka.depth = 2u;
@@ -207,6 +214,6 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
         }
         if (want == 2u) ka.depth = 2u;
     }
-    pl->lds = pl->rows_nw ? fxg_rows_lds(ka.stride, (u32)pl->rows_h) : fxg_plan_lds(pl);
+    pl->lds = pl->rows_nw ? fxg_rows_lds(ka.stride, (u32)pl->rows_h, (u32)pl->rows_r) : fxg_plan_lds(pl);
     return FXG_OK;
 }

@@ -36,7 +36,7 @@
 #endif
 
 // staging buffer: the tile's rows + slack (every lane reads and packs a full register row, up to 156 bytes, whatever the stride)
-__host__ __device__ inline u32 fxg_rows_lds(u32 stride, u32 lanes_per_read = 1u) { return fxg_r16(FXG_ROWS_T / lanes_per_read * stride) + 176u; }
+__host__ __device__ inline u32 fxg_rows_lds(u32 stride, u32 lanes_per_read = 1u, u32 reads_per_lane = 1u) { return fxg_r16(FXG_ROWS_T * reads_per_lane / lanes_per_read * stride) + 176u; }
 
 // The lane's row -> its own threshold bitmap, bit i = (byte i >= thr), K = (128 - thr) * 0x01010101 (fxg_ge_flags).  Two dwords at a
 // time: the flags are bytes of 0x80 and a dot product with the byte weights (1,2,4,8) / (16,32,64,128) gathers eight of them
@@ -427,6 +427,139 @@ __global__ __launch_bounds__(64, FXG_ROWS_LB) void fxg_kernel_rows(const FxgKArg
 #ifdef FXG_ABLATION
     if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(reinterpret_cast<u64 *>(a.errflag + 10) + i, ph[i]);
 #endif
+    if (lane == 0) {
+        if (t_in) atomicAdd(&a.tally[0], t_in);
+        if (t_kept) atomicAdd(&a.tally[1], t_kept);
+        if (t_bases) atomicAdd(&a.tally[2], t_bases);
+        if (t_qtrim) atomicAdd(&a.tally[4 + FXG_R_QTRIM], t_qtrim);
+        if (t_qfilter) atomicAdd(&a.tally[4 + FXG_R_QFILTER], t_qfilter);
+    }
+}
+// ------------------------------------------------------------------------------------------------
+// Short rows (28..79 bytes: 36-, 50- and 76-base reads), round 6: R reads per lane.  A 64-read tile of 36-byte rows is 2.3 KB -- the per-tile work (ticket,
+// scan, publish, the wait for the tile's place, two flushes) then costs more than the bytes, and the tile kernel was the faster one below 80 bytes at 0.44-0.59 of
+// the HBM peak (profiles/r02/af_rows_vs_tiles_by_length.txt).  Here a tile is R sub-tiles of 64 consecutive reads (R x NW ~ 40 dwords per lane, ~10 KB per
+// tile: what a 64-read tile of 150-byte rows is), fetched by ONE LDS-DMA burst, published as ONE total, placed by ONE prefix and flushed once per array; lane l
+// holds reads l, l + 64, ... of the tile, so that sub-tile j is a contiguous run of the packed output and the sub-tiles are packed in order: what the
+// unpredicated pack of one sub-tile writes past its own bytes lands in bytes of a LATER sub-tile (or the buffer's slack) and is overwritten by it, exactly as
+// between the lanes of one sub-tile (fxg_rows_pack).  Everything else is fxg_kernel_rows<NW, 1>: same decisions (fxg_rows_decide), same scanners, same flush.
+// ------------------------------------------------------------------------------------------------
+template <int NW, int R>
+__global__ __launch_bounds__(64, FXG_ROWS_LB) void fxg_kernel_rows_multi(const FxgKArgs a)
+{
+    constexpr u32 TR = FXG_ROWS_T * (u32)R;                              // reads per tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    fxg_lds_u8 *lsm = (fxg_lds_u8 *)smem;
+    u32 lane = threadIdx.x;
+    const u32 stride = a.stride;
+    u32 role = 0;
+    if (lane == 0) role = atomicAdd(a.role, 1u);
+    role = (u32)__builtin_amdgcn_readfirstlane((int)role);
+    if (role < a.nscan) { if (a.nscan == 1u) fxg_scanner_k<FXG_ROWS_SCAN_K>(a); else fxg_scanner_multi<FXG_ROWS_SCAN_K>(a, role); return; }
+    const u32 G = a.ticket_groups, grp = blockIdx.x % G;
+    u32 *my_ticket = a.ticket + grp * FXG_TICKET_STRIDE;
+    u32 tk = 0;
+    if (lane == 0) tk = atomicAdd(my_ticket, 1u);
+    u32 cur = (u32)__builtin_amdgcn_readfirstlane((int)tk) * G + grp;
+    u64 t_in = 0, t_kept = 0, t_bases = 0, t_qtrim = 0, t_qfilter = 0;
+    u32 qp[R][NW];
+    u32 p_info[R], p_exc[R], p_totb = 0, pend = FXG_NO_TILE;            // p_info[j] = keep << 31 | kept length << 16 | byte offset in the tile's packed output
+#pragma unroll
+    for (int j = 0; j < R; ++j) { p_info[j] = 0u; p_exc[j] = 0u; }
+    for (;;) {
+        asm volatile("" : "+v"(lane));
+        const bool havec = cur < a.ntiles, havep = pend != FXG_NO_TILE;
+        u32 q[R][NW];
+        u32 c_info[R], c_exc[R], c_totb = 0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) { c_info[j] = 0u; c_exc[j] = 0u; }
+        // ------------------------------ stage A: tile `cur` ------------------------------
+        if (havec) {
+            const u32 r0 = cur * TR;
+            const u64 left = a.n - (u64)r0;
+            const u32 nreads = left < (u64)TR ? (u32)left : TR;
+            const u64 tb = (u64)r0 * stride;
+            const u32 tbytes = nreads * stride;
+            fxg_rows_fetch<NW * R>(a.qual, tb, tbytes, lsm, lane);
+            fxg_rows_landed();
+#pragma unroll
+            for (int j = 0; j < R; ++j) fxg_rows_read<NW>(smem, ((u32)j * FXG_ROWS_T + lane) * stride, q[j]);
+            FXG_WAVE_SYNC();                                                  // every lane has its rows: the buffer is free for stage B
+            u32 base = 0;                                                     // (kept reads << 16 | kept bytes) of the sub-tiles so far
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const u32 rd = (u32)j * FXG_ROWS_T + lane;
+                u32 keep = 0, olen = 0, word = 0;
+                if (rd < nreads) word = fxg_rows_decide<NW>(a, q[j], r0 + rd, &keep, &olen);
+                const u32 why = rd < nreads ? (word >> 17) & 0xFu : 0u;
+                t_qtrim += (u64)__builtin_popcountll(__ballot(why == FXG_R_QTRIM));
+                t_qfilter += (u64)__builtin_popcountll(__ballot(why == FXG_R_QFILTER));
+                const u32 mine = keep ? ((1u << 16) | olen) : 0u;
+                const u32 inc = fxg_wave_scan_dpp(mine);
+                const u32 ex = inc - mine + base;
+                base += (u32)__builtin_amdgcn_readlane((int)inc, 63);
+                c_exc[j] = ex >> 16;
+                c_info[j] = (keep ? 1u << 31 : 0u) | (olen << 16) | (ex & 0xFFFFu);
+            }
+            const u32 totc = base >> 16;
+            c_totb = base & 0xFFFFu;
+            if (lane == 0) fxg_publish_total(a, cur, totc, c_totb);
+            t_in += nreads; t_kept += totc; t_bases += c_totb;
+        }
+        // ------------------------------ stage B: tile `pend` ------------------------------
+        u64 bc[2] = {0, 0};
+        if (havep) fxg_wait_prefix_wave(a, pend, bc);
+        u32 nxt = 0;
+        if (havec && lane == 0) nxt = atomicAdd(my_ticket, 1u);
+        if (havep) {
+            const u32 r0 = pend * TR;
+            const u64 left = a.n - (u64)r0;
+            const u32 nreads = left < (u64)TR ? (u32)left : TR;
+            const u64 tb = (u64)r0 * stride;
+            const u32 tbytes = nreads * stride;
+            const bool placed = bc[0] != ~0ull;
+            u64 shortm = 0;
+#pragma unroll
+            for (int j = 0; j < R; ++j) shortm |= __ballot(placed && (p_info[j] >> 31) && ((p_info[j] >> 16) & 0x7FFFu) < 4u);
+            const bool fast = shortm == 0ull;
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const u32 keep = placed ? p_info[j] >> 31 : 0u, olen = (p_info[j] >> 16) & 0x7FFFu, exb = p_info[j] & 0xFFFFu;
+                if (keep) fxg_rows_pack<NW>(smem, exb, qp[j], olen, fast);
+            }
+            FXG_WAVE_SYNC();
+            if (placed) fxg_rows_flush(a.out_qual, bc[1], p_totb, smem, lane);
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const u32 keep = placed ? p_info[j] >> 31 : 0u, olen = (p_info[j] >> 16) & 0x7FFFu, exb = p_info[j] & 0xFFFFu;
+                if (keep) fxg_write_kept_meta(a, bc[0] + p_exc[j], olen, r0 + (u32)j * FXG_ROWS_T + lane, bc[1] + exb);
+            }
+            FXG_WAVE_SYNC();                                                  // the buffer is free again
+            u32 b[R][NW];
+            fxg_rows_fetch<NW * R>(a.bases, tb, tbytes, lsm, lane);
+            fxg_rows_landed();
+#pragma unroll
+            for (int j = 0; j < R; ++j) fxg_rows_read<NW>(smem, ((u32)j * FXG_ROWS_T + lane) * stride, b[j]);
+            FXG_WAVE_SYNC();
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const u32 keep = placed ? p_info[j] >> 31 : 0u, olen = (p_info[j] >> 16) & 0x7FFFu, exb = p_info[j] & 0xFFFFu;
+                if (keep) fxg_rows_pack<NW>(smem, exb, b[j], olen, fast);
+            }
+            FXG_WAVE_SYNC();
+            if (placed) fxg_rows_flush(a.out_bases, bc[1], p_totb, smem, lane);
+            FXG_WAVE_SYNC();
+        }
+        if (!havec) break;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+#pragma unroll
+            for (int k = 0; k < NW; ++k) qp[j][k] = q[j][k];
+            p_info[j] = c_info[j]; p_exc[j] = c_exc[j];
+        }
+        p_totb = c_totb; pend = cur;
+        cur = (u32)__builtin_amdgcn_readfirstlane((int)nxt) * G + grp;
+    }
     if (lane == 0) {
         if (t_in) atomicAdd(&a.tally[0], t_in);
         if (t_kept) atomicAdd(&a.tally[1], t_kept);

@@ -164,7 +164,7 @@ struct fxh_sf {
     uint64_t given_back;                   /* pages the head start made and the output turned out not to need, returned during the run */
     uint64_t alloc_final; int alloc_final_set;      /* the exact size, once known: strands -- every chunk published; rank job -- the exchange */
     uint64_t map_base;                     /* rank mode: file offset of map[0] (the page this rank's slice starts in) */
-    int alloc_errno, alloc_stop;
+    int alloc_errno, alloc_stop, alloc_capped;      /* alloc_capped: the head start met ENOSPC -- from here on only what a copy asks for */
     int drain_errno;                       /* rank mode: errno of the first piece of this rank's text that did not get into the file */
     pthread_t th_alloc;
     pthread_rwlock_t gate;                 /* fallocate() exclusive, copies shared; writer-preferring */
@@ -192,6 +192,7 @@ static uint64_t fxh_sf_alloc_goal(const fxh_sf *S)
         goal = S->alloc_in_total / 4;
         if (goal > ((uint64_t)8 << 30)) goal = (uint64_t)8 << 30;
     }
+    if (S->alloc_capped && !S->alloc_final_set) goal = S->need;      /* no room to run ahead in: exactly what the copies need */
     if (!S->alloc_final_set && goal < S->need) goal = S->need;
     if (goal > S->map_len) goal = S->map_len;
     return goal;
@@ -244,7 +245,10 @@ static void *fxh_sf_alloc_main(void *arg)
         pthread_rwlock_unlock(&S->gate);
         pthread_mutex_lock(&S->mu);
         S->t_alloc += dt; S->alloc_calls++;
-        if (e) S->alloc_errno = e; else S->alloc_end = a + step;
+        /* ENOSPC on pages nobody has asked for yet (the head start is a guess made before any output size is known; a filter that keeps 1 % needs a fraction
+         * of it) is not the run's problem: stop running ahead and fail only when a copy really cannot get its pages (advisor, round 5) */
+        if (e == ENOSPC && a >= S->need && !S->alloc_final_set && !S->alloc_capped) S->alloc_capped = 1;
+        else if (e) S->alloc_errno = e; else S->alloc_end = a + step;
         pthread_cond_broadcast(&S->cv);
     }
     pthread_mutex_unlock(&S->mu);
@@ -626,6 +630,15 @@ static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot,
 int fxh_run_one_file(FASTX *fx, const fxg_params *p, fxh_totals *tot)
 {
     const int world = (int)fxh_env_long("FXH_WORLD", 1, 1, 4096), rank = (int)fxh_env_long("FXH_RANK", 0, 0, world - 1);
+    if (world > 1 && rank == 0) {
+        /* A rendezvous record that a killed run of the same command left under the same name (no FXG_COMM_JOB: the job token is 0 both times) must be gone before
+         * any other rank of THIS job can look at it: rank 0 removes the name here, first thing -- fxg_comm_create does it again, but only after the runtime and
+         * RCCL have started, seconds during which a rank that is already polling could read the dead job's id twice unchanged and take it (advisor, round 5). */
+        char rdv[PATH_MAX + 16];
+        const char *re = getenv("FXH_RENDEZVOUS");
+        if (re && *re) snprintf(rdv, sizeof rdv, "%s", re); else snprintf(rdv, sizeof rdv, "%s.rdv", fx->output_file_name);
+        (void)unlink(rdv);
+    }
     const int rc = fxh_one_file_attempt(fx, p, tot, rank, world);
     if (world > 1 && rc != 0 && rank > 0) {      /* not a job for ranks (a pipe, a tiny input) or abandoned: rank 0 runs it as one stream, the reference's way */
         if (fx->writer && fx->writer->fd >= 0 && fx->writer->fd != STDOUT_FILENO) close(fx->writer->fd);
@@ -647,6 +660,7 @@ static int fxh_one_file_attempt(FASTX *fx, const fxg_params *p, fxh_totals *tot,
     if (fstat(rd->fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return -1;
     if (strcmp(fx->output_file_name, "-") == 0 || fx->compress_output || g_rename_ids || getenv("FXH_HOST_PARSE")) return -1;
     if (!w0 || w0->fd < 0 || !w0->positional || w0->len != 0 || fstat(w0->fd, &ob) != 0 || !S_ISREG(ob.st_mode)) return -1;
+    if (w0->off != 0) return -1;                 /* (the strands and the rank drain place their bytes counted from the file's first byte: a writer that does not start there runs as one stream) */
     if (ob.st_dev == sb.st_dev && ob.st_ino == sb.st_ino) return -1;
     const int clip = (p->stages & FXG_STAGE_CLIP) != 0;
     if (clip && getenv("FXH_CLIP_SERIAL") != NULL && getenv("FXH_CLIP_PARALLEL") == NULL) return -1;      /* one aligner asked for */

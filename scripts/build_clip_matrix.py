@@ -32,7 +32,7 @@ def stale(w):
 def verdict(w):
     """The ISA check's answer for one library (always computed afresh: the checker may have learnt since the library was built)."""
     chk = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_exec_zero.py"), lib(w)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    rejected = sorted({"<%s,%s>" % (a.replace("n", "-"), m) for a, m in re.findall(r"fxg_kernel_tilesILi(n?\d+)ELi(\d+)EEv", chk.stdout)})
+    rejected = sorted({"<%s,%s>" % (a.replace("n", "-"), m) for a, m in re.findall(r"fxg_kernel_tilesILi(n?\d+)ELi(\d+)E(?:Lb[01]E)?Ev", chk.stdout)})
     v = dict(waves=w, accepted=chk.returncode == 0, rejected_instances=rejected, report=chk.stdout[-4000:])
     json.dump(v, open(lib(w)[:-3] + ".json", "w"), indent=1)
     return v

@@ -47,7 +47,10 @@ static void emu_rows_decide_nw(const FxgKArgs &a, int h, u32 read, u32 *keep, u3
 }
 static void emu_rows_decide(int nw, int h, const FxgKArgs &a, u32 read, u32 *keep, u32 *olen)
 {
-    if (nw == 26) emu_rows_decide_nw<26>(a, h, read, keep, olen);
+    if (nw == 10) emu_rows_decide_nw<10>(a, h, read, keep, olen);           // (fxg_kernel_rows_multi: the same decision, shorter register rows)
+    else if (nw == 14) emu_rows_decide_nw<14>(a, h, read, keep, olen);
+    else if (nw == 20) emu_rows_decide_nw<20>(a, h, read, keep, olen);
+    else if (nw == 26) emu_rows_decide_nw<26>(a, h, read, keep, olen);
     else emu_rows_decide_nw<38>(a, h, read, keep, olen);
 }
 

@@ -178,7 +178,8 @@ def test_both_quality_kernels_on_the_same_batches(engine, monkeypatch):
     """The quality stages run as fxg_kernel_rows (rows of 80..152 bytes, compaction) or as fxg_kernel_tiles<0,0> (everything else,
     FXG_ROWS=0): same batches through both, every output array, and the oracle for the first of them.  Ragged lengths down to 1 and
     minimum lengths of 1-2 put kept reads of fewer than 4 bytes into tiles (the predicated packing path of fxg_rows_pack);
-    partial last tiles; strides at the edges of the two register-row instances (80, 104 / 105, 152) and outside them."""
+    partial last tiles; strides at the edges of the two register-row instances (80, 104 / 105, 152), of the several-reads-per-lane instances (29, 40 / 41, 79)
+    and outside them."""
     import torch
     from fastx_toolkit_amd import make_params
     kernels = set()
@@ -212,19 +213,21 @@ def test_both_quality_kernels_on_the_same_batches(engine, monkeypatch):
             if k == 0 and n <= 5000:
                 o = fo.run_pipeline(b.cpu().numpy(), q.cpu().numpy(), lens.cpu().numpy().view(np.uint16) if var else None, oracle_params(pd), fixed_len=None if var else L)
                 assert_same(o, got["1"][1], "rows vs oracle %r" % ((seed, n, L, stride, var),))
-    assert kernels == {"fxg_kernel_rows", "fxg_kernel_tiles"}, kernels
+    assert kernels == {"fxg_kernel_rows", "fxg_kernel_rows_multi", "fxg_kernel_tiles"}, kernels      # (rows_multi: the strides of 28..79 bytes above -- several reads per lane)
 
 
 def test_quality_kernels_random_shapes(engine, monkeypatch):
-    """Seeded random batch shapes (stride 60..310: one lane per read up to 152, two lanes per read up to 304, the tile kernel beyond; any
+    """Seeded random batch shapes (stride 28..310: several reads per lane below 80, one lane per read up to 152, two lanes per read up to 304, the tile kernel beyond; any
     fixed length below the stride or ragged lengths, any tile remainder), random thresholds: fxg_kernel_rows and fxg_kernel_tiles<0,0>
     must produce the same arrays, and the oracle's on the smaller batches."""
     import torch
     from fastx_toolkit_amd import make_params
     rng = np.random.default_rng(20260927)
     kept = 0
-    for trial in range(96):
-        stride = int(rng.integers(60, 153)) if trial % 2 == 0 else int(rng.integers(153, 311))
+    multi = 0
+    for trial in range(132):
+        # (every third trial: rows of 28..79 bytes -- fxg_kernel_rows_multi, two to four reads per lane: 36-, 50- and 76-base reads)
+        stride = int(rng.integers(28, 80)) if trial % 3 == 2 else int(rng.integers(60, 153)) if trial % 2 == 0 else int(rng.integers(153, 311))
         L = int(rng.integers(1, stride + 1))
         n = int(rng.integers(1, 9000))
         var = bool(rng.integers(0, 2))
@@ -236,12 +239,16 @@ def test_quality_kernels_random_shapes(engine, monkeypatch):
         for rows in ("1", "0"):
             monkeypatch.setenv("FXG_ROWS", "2" if rows == "1" else "0")
             got[rows] = engine.run(b, q, make_params(**pd), lens=lens, fixed_len=None if var else L, compact=True, meta=True).to_host()
+            if rows == "1":
+                k = engine.last_launch()["kernel"]
+                assert ("fxg_kernel_rows_multi" in k) == (stride < 80) and "fxg_kernel_rows" in k, (stride, k)
+                multi += "fxg_kernel_rows_multi" in k
         assert_same(got["0"], got["1"], "trial %d: n %d L %d stride %d ragged %s %r" % (trial, n, L, stride, var, pd))
         if n <= 2500:
             o = fo.run_pipeline(b.cpu().numpy(), q.cpu().numpy(), lens.cpu().numpy().view(np.uint16) if var else None, oracle_params(pd), fixed_len=None if var else L)
             assert_same(o, got["1"], "trial %d vs oracle" % trial)
         kept += int(got["1"]["counters"][1])
-    assert kept > 10000
+    assert kept > 10000 and multi >= 40
 
 
 def test_rows_kernel_keeps_empty_reads_with_their_metadata(engine, monkeypatch):
