@@ -241,7 +241,7 @@ def test_quality_kernels_random_shapes(engine, monkeypatch):
             got[rows] = engine.run(b, q, make_params(**pd), lens=lens, fixed_len=None if var else L, compact=True, meta=True).to_host()
             if rows == "1":
                 k = engine.last_launch()["kernel"]
-                assert ("fxg_kernel_rows_multi" in k) == (stride < 80) and "fxg_kernel_rows" in k, (stride, k)
+                assert ("fxg_kernel_rows_multi" in k) == (stride < 80) and ("fxg_kernel_rows" in k) == (stride <= 304), (stride, k)
                 multi += "fxg_kernel_rows_multi" in k
         assert_same(got["0"], got["1"], "trial %d: n %d L %d stride %d ragged %s %r" % (trial, n, L, stride, var, pd))
         if n <= 2500:
