@@ -111,6 +111,7 @@ struct FxgKArgs {
     u32 *clip_dbg;          // debug builds only (scripts/debug/clip64_bisect.py): 16 words per read of fxg_clip_two_pass_k's intermediate state
 #endif
     char adapter[100];
+    uint8_t clip_ptab_row[256];   // pair table: row of every byte value (fxg_plan.h fills it: 0 = not in the adapter, 1 = 'N', 2.. = the adapter's distinct bytes in order of first appearance); bit 7 = this byte's thread writes the row
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -67,7 +67,7 @@ int fxg_launch_clip_k_wide_wide(fxg_ctx *c, FxgPlan &pl, u64 *ctr)
         case -64: return fxg_launch_tiles(c, FXG_TILES_C(-64), "fxg_kernel_tiles<-64,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case -80: return fxg_launch_tiles(c, FXG_TILES_C(-80), "fxg_kernel_tiles<-80,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
         case -100: return fxg_launch_tiles(c, FXG_TILES_C(-100), "fxg_kernel_tiles<-100,0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg);
-    default: return fxg_fail(c, FXG_E_INVALID, "no clip instance %d", pl.amax);
+    default: return fxg_launch_clip_n(c, pl, ctr);      // (the buckets of round 6 live in the translation units the N instances left: below)
     }
 }
 #endif
@@ -75,9 +75,17 @@ int fxg_launch_clip_k_wide_wide(fxg_ctx *c, FxgPlan &pl, u64 *ctr)
 // adapters that contain N: instances of their own only in builds without the pair table (-DFXG_NO_PTAB: A/B measurements); with it an N is one more column
 // pattern of the table and the plan never asks for them (fxg_plan.h)
 #ifndef FXG_NO_PTAB
+#define FXG_K(N) case -N: return fxg_launch_tiles(c, FXG_TILES_C(-N), "fxg_kernel_tiles<-" #N ",0> clip(packed)[+qtrim+qfilter]", pl.ka, pl.lds, ctr, FXG_TBLOCK, false, pl.ck_per_wg)
 #if !defined(FXG_CLIP_TU) || FXG_CLIP_TU == 3
-int fxg_launch_clip_n(fxg_ctx *c, FxgPlan &pl, u64 *) { return fxg_fail(c, FXG_E_INVALID, "no clip instance %d in this build", pl.amax); }
+int fxg_launch_clip_n(fxg_ctx *c, FxgPlan &pl, u64 *ctr) { switch (pl.amax) { FXG_K(44); FXG_K(52); default: return fxg_launch_clip_n_wide(c, pl, ctr); } }
 #endif
+#if !defined(FXG_CLIP_TU) || FXG_CLIP_TU == 5
+int fxg_launch_clip_n_wide(fxg_ctx *c, FxgPlan &pl, u64 *ctr) { switch (pl.amax) { FXG_K(60); FXG_K(72); default: return fxg_launch_clip_n_wide_wide(c, pl, ctr); } }
+#endif
+#if !defined(FXG_CLIP_TU) || FXG_CLIP_TU == 7
+int fxg_launch_clip_n_wide_wide(fxg_ctx *c, FxgPlan &pl, u64 *ctr) { switch (pl.amax) { FXG_K(88); default: return fxg_fail(c, FXG_E_INVALID, "no clip instance %d", pl.amax); } }
+#endif
+#undef FXG_K
 #else
 #if !defined(FXG_CLIP_TU) || FXG_CLIP_TU == 3
 // adapters that contain N

@@ -384,7 +384,7 @@ FXG_HD u32 fxg_ptab_rows(const char *adapter, int alen)
 {
     u32 r = 2u;
     for (int t = 0; t < alen; ++t) {
-        bool seen = false;
+        bool seen = adapter[t] == 'N';                     // ('N' has row 1 whatever the adapter holds)
         for (int u = 0; u < t; ++u) seen = seen || (adapter[u] == adapter[t]);
         r += seen ? 0u : 1u;
     }
@@ -397,23 +397,30 @@ FXG_HD u32 fxg_ptab_stride(u32 cols) { const u32 s = (cols * 4u + 15u) & ~15u; r
 FXG_HD u32 fxg_ptab_bytes(u32 rows, u32 stride) { return FXG_PTAB_LUT_BYTES + 2u * rows * stride; }
 #define FXG_PTAB_MAX_ROWS_K 8u      // 17..99 columns: adapters of more than six distinct bytes (IUPAC-rich) take the general form instead (fxg_plan.h)
 
+// which row a byte value has (host side, fxg_make_plan): 0 = a byte the adapter does not contain, 1 = 'N', 2.. = the adapter's distinct bytes in order of first
+// appearance; bit 7 marks the ONE byte value whose thread writes the row (byte 0 for row 0: the adapter is a C string, 0 is never one of its bytes)
+FXG_HD void fxg_ptab_row_map(const char *adapter, int alen, uint8_t (&row)[256])
+{
+    for (int b = 0; b < 256; ++b) row[b] = 0u;
+    row[0] = 0x80u;
+    u32 next = 2u;
+    for (int t = 0; t < alen; ++t) {
+        const u32 c = (u32)(uint8_t)adapter[t];
+        if (c == (u32)'N' || row[c] != 0u) continue;
+        row[c] = (uint8_t)(0x80u | next++);
+    }
+    row[(u32)'N'] = 0x80u | 1u;
+}
+
 FXG_HD void fxg_clip_ptab_build(const FxgKArgs &a, uint8_t *ptab, u32 tid, u32 nthreads)
 {
     uint16_t *lut = reinterpret_cast<uint16_t *>(ptab);
     const int COLS = (int)a.clip_ptab_cols, A = a.alen < COLS ? a.alen : COLS;
     const u32 R = a.clip_ptab_rows, ST = a.clip_ptab_stride;
     for (u32 b = tid; b < 256u; b += nthreads) {
-        int first = -1, rank = 0;                          // first column that holds byte b; distinct bytes in front of it
-        for (int t = 0; t < A; ++t) {
-            const u32 tc = (u32)(uint8_t)a.adapter[t];
-            if (tc == b) { first = t; break; }
-            bool seen = false;
-            for (int u = 0; u < t; ++u) seen = seen || ((u32)(uint8_t)a.adapter[u] == tc);
-            rank += seen ? 0 : 1;
-        }
-        const u32 row = b == (u32)'N' ? 1u : (first < 0 ? 0u : 2u + (u32)rank);
+        const u32 e = a.clip_ptab_row[b], row = e & 0x7Fu;
         lut[b] = (uint16_t)(FXG_PTAB_LUT_BYTES + row * ST);
-        if (b == 0u || b == (u32)'N' || first >= 0) {      // one writer per row (0 is never an adapter byte: the adapter is a C string)
+        if (e & 0x80u) {                                   // one writer per row
             float *pv = reinterpret_cast<float *>(ptab + FXG_PTAB_LUT_BYTES + row * ST);
             u32 *sv = reinterpret_cast<u32 *>(ptab + FXG_PTAB_LUT_BYTES + (R + row) * ST);
             for (int t = 0; t < COLS; ++t) {
@@ -800,8 +807,8 @@ FXG_HD int fxg_clip_two_pass(const FxgKArgs &a, const uint8_t *rd, int len, int 
 // smallest adapter of the bucket AMAX (fxg_plan.h): columns below it always count towards the best cell
 __host__ __device__ constexpr int fxg_clip_k_amin(int amax, bool tn = false)
 {
-    return tn ? (amax <= 16 ? 1 : amax <= 24 ? 17 : amax <= 36 ? 25 : amax <= 48 ? 37 : amax <= 64 ? 49 : 65)        // buckets 16 24 36 48 64 100 (adapters with N)
-              : (amax <= 16 ? 1 : amax <= 20 ? 17 : amax <= 40 ? amax - 3 : amax <= 48 ? 41 : amax <= 64 ? 49 : 65);
+    return tn ? (amax <= 16 ? 1 : amax <= 24 ? 17 : amax <= 36 ? 25 : amax <= 48 ? 37 : amax <= 64 ? 49 : 65)        // buckets 16 24 36 48 64 100 (builds without the pair table: adapters with N)
+              : (amax <= 16 ? 1 : amax <= 20 ? 17 : amax <= 64 ? amax - 3 : amax <= 88 ? amax - 7 : 89);             // buckets every 4 columns to 64, every 8 to 88, then 100 (fxg_plan.h)
 }
 template <int AMAX> struct FxgClipK { static constexpr bool SM = AMAX <= 24; static constexpr int NSM = SM ? AMAX : 1; };
 

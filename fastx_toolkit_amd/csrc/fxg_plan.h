@@ -95,6 +95,7 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     ka.alen = (int)strlen(ka.adapter);
     ka.adapter_has_n = strchr(ka.adapter, 'N') != nullptr;
     ka.clip_ptab_rows = fxg_ptab_rows(ka.adapter, ka.alen);
+    fxg_ptab_row_map(ka.adapter, ka.alen, ka.clip_ptab_row);
 
     pl->group_a = ga;
     pl->mask = gm; pl->artifacts = gf;
@@ -132,7 +133,8 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     if (pl->clip && (ka.clip_stride <= 255u || two_pass_k || (!kform && reg_any_len)) && !getenv("FXG_NO_PACKED_CLIP")) {
         // 36: the 33/34-base TruSeq adapters; 56 and 80 (round 5): 49..56 columns no longer pay for 64 (17.4 -> 27.7 ms between 48 and 49 bases,
         // profiles/r04/p_clip_waves_by_adapter_len.txt) and 65..80 no longer for 100
-        static const int pk[] = {4, 8, 9, 10, 11, 12, 13, 14, 15, 16, 20, 24, 28, 32, 36, 40, 48, 56, 64, 80, 100};
+        // 44, 52, 60, 72, 88 (round 6): a bucket every 4 columns to 64 and every 8 to 88, so that no adapter pays for more than 8 % .. 12 % of padding columns
+        static const int pk[] = {4, 8, 9, 10, 11, 12, 13, 14, 15, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52, 56, 60, 64, 72, 80, 88, 100};
         static const int pn[] = {16, 24, 36, 48, 56, 64, 80, 100};
         int b = 100;
         const bool n_inst = ka.adapter_has_n && kform && !fxg_clip_uses_ptab(-20);      // (builds without the pair table: the instances with per-column neutral selects)

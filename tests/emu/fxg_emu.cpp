@@ -214,10 +214,8 @@ int emu_clip_group4(const FxgPlan &pl, uint64_t *ctr, char *err, size_t cap)
 int emu_clip_group5(const FxgPlan &pl, uint64_t *ctr, char *err, size_t cap)
 {
     switch (pl.amax) {
-    case -316: return emu_run<-316, false>(pl, ctr, err, cap);
-    case -324: return emu_run<-324, false>(pl, ctr, err, cap);
-    case -336: return emu_run<-336, false>(pl, ctr, err, cap);
-    case -348: return emu_run<-348, false>(pl, ctr, err, cap);
+    case -44: return emu_run<-44, false>(pl, ctr, err, cap);       // (the buckets of round 6, where the N instances used to be: an N is a column pattern of the pair table now)
+    case -52: return emu_run<-52, false>(pl, ctr, err, cap);
     default: return EMU_NOT_MINE;
     }
 }
@@ -226,8 +224,8 @@ int emu_clip_group5(const FxgPlan &pl, uint64_t *ctr, char *err, size_t cap)
 int emu_clip_group6(const FxgPlan &pl, uint64_t *ctr, char *err, size_t cap)
 {
     switch (pl.amax) {
-    case -356: return emu_run<-356, false>(pl, ctr, err, cap);
-    case -364: return emu_run<-364, false>(pl, ctr, err, cap);
+    case -60: return emu_run<-60, false>(pl, ctr, err, cap);
+    case -72: return emu_run<-72, false>(pl, ctr, err, cap);
     default: return EMU_NOT_MINE;
     }
 }
@@ -236,8 +234,7 @@ int emu_clip_group6(const FxgPlan &pl, uint64_t *ctr, char *err, size_t cap)
 int emu_clip_group7(const FxgPlan &pl, uint64_t *ctr, char *err, size_t cap)
 {
     switch (pl.amax) {
-    case -380: return emu_run<-380, false>(pl, ctr, err, cap);
-    case -400: return emu_run<-400, false>(pl, ctr, err, cap);
+    case -88: return emu_run<-88, false>(pl, ctr, err, cap);
     default: return EMU_NOT_MINE;
     }
 }

@@ -155,10 +155,10 @@ def adversarial_clip_cases(long_adapters):
     than the adapter, best cells in the first / last rows, an insertion / deletion right before a planted adapter."""
     rng = np.random.default_rng(11)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
-    for trial in range(120 if long_adapters else 96):
+    for trial in range(128 if long_adapters else 96):
         alen = 1 + trial % 16
-        if long_adapters:                                                       # both ends of every bucket (56 and 80: round 5)
-            alen = [17, 20, 21, 24, 25, 28, 29, 31, 32, 33, 34, 36, 37, 40, 41, 48, 49, 56, 57, 64, 65, 80, 81, 99][trial % 24]
+        if long_adapters:                                                       # both ends of every bucket (44, 52, 60, 72, 88: round 6)
+            alen = [17, 20, 21, 24, 25, 28, 29, 32, 33, 36, 37, 40, 41, 44, 45, 48, 49, 52, 53, 56, 57, 60, 61, 64, 65, 72, 73, 80, 81, 88, 89, 99][trial % 32]
         kind = trial % 6
         if kind == 0:
             ad = bytes(rng.choice(acgt, size=alen))

@@ -252,12 +252,13 @@ def test_clip_instance_selection(monkeypatch):
         (full[:13], 300, -13, False), (full[:13], 1000, -13, False),                      # the register form takes reads of any length
         (full[:17], 100, -20, True), (full[:17], 50, -20, True), (full[:17], 25, -20, False), (full[:24], 100, -24, True), (full[:32], 100, -32, True),
         (full[:33], 100, -36, True), (full[:34], 150, -36, True), (full[:34], 60, -36, True), (full[:34], 50, -36, False), (full[:40], 100, -40, True),
-        (full[:48], 150, -48, True), (full[:49], 150, -56, True), (full[:56], 150, -56, True), (full[:57], 150, -64, True), (full[:64], 150, -64, True), (full[:64], 100, -64, True), (full[:65], 100, -80, False),
-        (full[:65], 255, -80, True), (full[:80], 255, -80, True), (full[:81], 255, -100, True), (full[:99], 255, -100, True),
+        (full[:41], 150, -44, True), (full[:44], 150, -44, True), (full[:45], 150, -48, True), (full[:48], 150, -48, True), (full[:49], 150, -52, True), (full[:52], 150, -52, True),
+        (full[:53], 150, -56, True), (full[:56], 150, -56, True), (full[:57], 150, -60, True), (full[:61], 150, -64, True), (full[:64], 150, -64, True), (full[:64], 100, -64, True), (full[:65], 100, -72, False),
+        (full[:65], 255, -72, True), (full[:72], 255, -72, True), (full[:73], 255, -80, True), (full[:80], 255, -80, True), (full[:81], 255, -88, True), (full[:88], 255, -88, True), (full[:89], 255, -100, True), (full[:99], 255, -100, True),
         (full[:34], 300, -36, True), (full[:99], 421, -100, True),
         (with_n[:13], 100, -13, False), (with_n[:13], 30, -13, False), (with_n[:16], 100, -16, False),      # an N in a short adapter is one more pattern of the pair table (round 6)
         (with_n[:24], 100, -24, True), (with_n[:34], 100, -36, True),                                          # ... and of a long one: the same instances as an adapter without N
-        (with_n[:48], 150, -48, True), (with_n[:52], 150, -56, True), (with_n[:64], 150, -64, True), (with_n[:70], 200, -80, True), (with_n[:99], 300, -100, True),
+        (with_n[:48], 150, -48, True), (with_n[:52], 150, -52, True), (with_n[:64], 150, -64, True), (with_n[:70], 200, -72, True), (with_n[:99], 300, -100, True),
         (b"ACGTRYKMSWBDHVXZACGT", 100, 32, False), (b"ACGTRY" * 6, 100, -36, True),                             # more than six distinct bytes in a long adapter: the general form; six: still the table
         (with_n[:13], 300, -13, False),
     ]

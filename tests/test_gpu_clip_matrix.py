@@ -66,10 +66,10 @@ for long_adapters in (False, True):
         compare(fo.run_pipeline(b, q, None, oracle_params(pd)), run(b, q, None, pd), name)
 # the wide instances by name (48 .. 100 columns, with and without N in the adapter: an N is a column pattern of the pair table, the instance is the same), across strides, fixed and ragged with clip history
 rng = np.random.default_rng(404)
-ADS = {"-48": b"ACGTTGCAAGGCTTAACCGGATATCGCGTATAGCTAGCTAGGATCCA"[:44], "-64": b"GTCGTAGACCGATCGGGGACCCCTTGTTTCACGCGTCGTATAGCTGCTATGTCATTAGC"[:57],
+ADS = {"-44": b"ACGTTGCAAGGCTTAACCGGATATCGCGTATAGCTAGCTAGGATCCA"[:44], "-64": b"GTCGTAGACCGATCGGGGACCCCTTGTTTCACGCGTCGTATAGCTGCTATGTCATTAGCAAGG"[:62],
        "-56": b"GTCGTAGACCGATCGGGGACCCCTTGTTTCACGCGTCGTATAGCTGCTATGTCATTAGC"[:53], "-80": (b"ACGTTGCAAGGCTTAACCGGATATCGCGTATAG" * 3)[:77],
-       "-56 N": b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCGTATGCCGTCTTC"[:51], "-80 N": b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCGTATGCCGTCTTCTGCTTGAAAAAAAAAAGGGGGG"[:72],
-       "-100": (b"ACGTTGCA" * 12)[:91], "-48 N": b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCG"[:46], "-64 N": b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCGTATGCCGTCTTC"[:58],
+       "-52 N": b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCGTATGCCGTCTTC"[:51], "-72 N": b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCGTATGCCGTCTTCTGCTTGAAAAAAAAAAGGGGGG"[:72],
+       "-100": (b"ACGTTGCA" * 12)[:91], "-48 N": b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCG"[:46], "-60 N": b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCGTATGCCGTCTTC"[:58], "-88": (b"ACGTTGCAAGGCTTAACCGGATATCGCGTATAG" * 3)[:85],
        "-100 N": b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACNNNNNNATCTCGTATGCCGTCTTCTGCTTGAAAAAAAAAAGGGGGGGGGGCCCCCCCCCCTTTTT"[:93]}
 for tag, ad in ADS.items():
     tag = tag.split(" ")[0]
@@ -109,6 +109,6 @@ def test_clip_instances_at_every_register_budget(matrix, waves):
     d = json.loads(p.stdout.strip().splitlines()[-1])
     print("waves %d: %d cases equal to the oracle; refused instances (cases right, cases wrong): %s" % (waves, d["cases"], d["refused"]))
     ran = {k[k.index("<"):] for k in d["kernels"]} | set(v["rejected_instances"])
-    for inst in ("-4", "-8", "-13", "-16", "-20", "-24", "-28", "-32", "-36", "-40", "-48", "-56", "-64", "-80", "-100"):
+    for inst in ("-4", "-8", "-13", "-16", "-20", "-24", "-28", "-32", "-36", "-40", "-44", "-48", "-52", "-56", "-60", "-64", "-72", "-80", "-88", "-100"):
         assert "<%s,0>" % inst in ran, (inst, sorted(ran))
     assert d["cases"] > 400

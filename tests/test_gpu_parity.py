@@ -170,7 +170,7 @@ def test_clip_adversarial_every_adapter_bucket(engine, long_adapters):
         k = engine.last_launch()["kernel"]
         assert "clip(packed" in k, (name, k)                      # (adapters with N run the same instances: an N is a column pattern of the pair table)
         seen.add(k.split(" ")[0])
-    want = {"fxg_kernel_tiles<-%d,0>" % a for a in ((20, 24, 28, 32, 36, 40, 48, 64, 100) if long_adapters else (4, 8, 9, 10, 11, 12, 13, 14, 15, 16))}
+    want = {"fxg_kernel_tiles<-%d,0>" % a for a in ((20, 24, 28, 32, 36, 40, 44, 48, 52, 56, 60, 64, 72, 80, 88, 100) if long_adapters else (4, 8, 9, 10, 11, 12, 13, 14, 15, 16))}
     assert want <= seen, sorted(want - seen)
 
 
