@@ -36,12 +36,8 @@
 #define FXG_QS_LROWS 6u                                    // LDS rows per column pair: A C G T N + the spare row (bytes past the end of a read; never flushed)
 #define FXG_QS_LROW_WORDS FXG_QS_WBINS                     // 256 bytes: class k of a pair lives at byte k << 8 of the pair's block
 #define FXG_QS_LDS_WORDS ((FXG_QS_BLOCK_COLS / 2u) * FXG_QS_LROWS * FXG_QS_LROW_WORDS)   // word = two u16 counters: even column low, odd column high
-#ifndef FXG_QS_DEPTH
-#define FXG_QS_DEPTH 1u                                    // trips a lane's loads run ahead of its LDS adds.  1 = the round-4 loop and still the fastest: 2.75 ms against 2.76 / 2.86 / 2.73 at 2 / 3 / 4
-                                                           // (profiles/r06/stats_depth.txt) -- the loads ALONE take 2.49 ms in this decomposition (one add per row: -DFXG_QS_NOACC), 0.75 of the peak
-#endif
 #ifndef FXG_QS_UNROLL
-#define FXG_QS_UNROLL 1u                                   // rows per lane and trip (2.71 ms at 1, 2.83 at 2, 2.79 at 3 with the pipelined loop: profiles/r04/ab_stats_pipeline.txt)
+#define FXG_QS_UNROLL 1u                                   // rows per lane and trip of the tested loop
 #endif
 
 struct FxgStatsArgs {
@@ -52,6 +48,8 @@ struct FxgStatsArgs {
     u32  strip0;                      // first strip of this pass (column block)
     u32  nwg;                         // workgroups = slices of the reads
     u32 *partial;                     // [nwg][FXG_QS_PART_WORDS]
+    u32 *ticket;                      // chunk dispenser, zero at launch
+    u32  chunk_trips;                 // trips of 96 reads per chunk; 0: static slices through the tested loop
     u64 *hist;                        // [hist_cols][FXG_QS_CLASSES][FXG_QS_BINS]
     u32  hist_cols;
 };
@@ -59,9 +57,11 @@ struct FxgStatsArgs {
 #ifdef FXG_HOST_EMULATION
 #define FXG_LDS_ADD(p, v) ((void)(*(p) += (v)))
 #define FXG_GLOBAL_INC64(p) ((void)(++*(p)))
+#define FXG_GLOBAL_ADD32(p, v) ((void)(*(p) += (v)))
 #else
 #define FXG_LDS_ADD(p, v) ((void)atomicAdd((p), (v)))
 #define FXG_GLOBAL_INC64(p) ((void)atomicAdd((p), 1ull))
+#define FXG_GLOBAL_ADD32(p, v) ((void)__hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))   // result unused: global_atomic_add_u32 without return
 #endif
 
 // v_perm_b32: byte i of the result is byte sel[i] of the 8-byte value {hi:lo} (selectors 0..3 -> lo, 4..7 -> hi)
@@ -190,19 +190,30 @@ FXG_HD void fxg_stats_slice(const FxgStatsArgs &a, u32 g, u64 *lo, u64 *hi)
     *hi = *lo + per < a.n ? *lo + per : a.n;
 }
 
-// thread `t` of `nt`: add the LDS block to the workgroup's partial ([column-in-block][class][window bin], u32) and clear it
-FXG_HD void fxg_stats_flush(u32 *lds, u32 *part, u32 t, u32 nt)
+// thread `t` of `nt`: move the LDS block into the workgroup's partial ([column-in-block][class][window bin], u32) and clear it.
+// A word of the block always belongs to the same thread (i = t mod nt), and so do the two counters of the partial it feeds, so the
+// workgroup's FIRST flush writes them with plain stores, zeros included (the partial needs no clearing pass and no load), and every later
+// one adds the non-zero ones with fire-and-forget atomics: no thread ever waits for a value to come back from HBM.  (Round 6: the
+// flush used to be `p[0] += v` -- a dependent load, add and store per counter, 32 trips of it per thread behind a workgroup barrier,
+// three or four times per kernel, with every workgroup of the chip at the barrier at the same time.)
+FXG_HD void fxg_stats_flush(u32 *lds, u32 *part, u32 t, u32 nt, bool first)
 {
+#ifdef FXG_QS_NOFLUSH     // timing experiment (wrong counts): what the kernel takes without the flushes' traffic
+    if (!first) return;
+#endif
     for (u32 i = t; i < FXG_QS_LDS_WORDS; i += nt) {
         const u32 x = i % FXG_QS_LROW_WORDS, pk = i / FXG_QS_LROW_WORDS, k = pk % FXG_QS_LROWS, pair = pk / FXG_QS_LROWS;
         const u32 v = lds[i];
-        if (v == 0u) continue;
-        lds[i] = 0u;
+        if (v != 0u) lds[i] = 0u;
         if (k >= FXG_QS_CLASSES) continue;                                   // the spare row
+        if (v == 0u && !first) continue;
         const u32 w = x ^ (fxg_stats_swz(pair / (FXG_QS_STRIP / 2u), k) >> 2);   // undo the swizzle
         u32 *p = part + ((2u * pair) * FXG_QS_CLASSES + k) * FXG_QS_WBINS + w;
-        p[0] += v & 0xFFFFu;
-        p[FXG_QS_CLASSES * FXG_QS_WBINS] += v >> 16;
+        if (first) { p[0] = v & 0xFFFFu; p[FXG_QS_CLASSES * FXG_QS_WBINS] = v >> 16; }
+        else {
+            if (v & 0xFFFFu) FXG_GLOBAL_ADD32(p, v & 0xFFFFu);
+            if (v >> 16) FXG_GLOBAL_ADD32(p + FXG_QS_CLASSES * FXG_QS_WBINS, v >> 16);
+        }
     }
 }
 
@@ -221,136 +232,125 @@ FXG_HD void fxg_stats_fold(const FxgStatsArgs &a, u32 e)
 FXG_HD void fxg_stats_item(u64 lo, u64 g, u64 *r, u32 *sl) { *r = lo + g / FXG_QS_WAVES; *sl = (u32)(g % FXG_QS_WAVES); }
 
 #ifndef FXG_HOST_EMULATION
+// the dealt loop's row loads carry the non-temporal policy (every row is read once): 2.667 against 2.713 ms, mean of eight alternating runs
+// (profiles/r06/stats_nt_loads.txt); -DFXG_QS_NO_NTL builds the other arm
+#ifndef FXG_QS_NO_NTL
+#define FXG_QS_LD(p) __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned *>(p))
+#else
+#define FXG_QS_LD(p) fxg_ld16(p)
+#endif
+// Fixed-length batches with qualities: the reads are dealt out in CHUNKS of chunk_trips * 96 reads by a ticket counter, not in one static slice per
+// workgroup.  Measured with static slices (profiles/r06/stats_wg_clocks_static.txt): the 256 workgroups of the launch leave their loops between 2.50 and
+// 2.70 ms (median 2.58; the even XCDs 1.5 % behind the odd ones) and the kernel lasts as long as the slowest -- which workgroup counts which read does
+// not matter to a histogram.  The rows of a lane's next trip are requested BEFORE the rows of this trip go into the histogram, across chunk borders
+// too: the ticket of the next chunk is known one chunk ahead (thread 0 asks for it two chunks ahead and hands it over through LDS at the one barrier
+// a chunk has).  Only chunks whose every read may be loaded 16 bytes at a time from any column are dealt out (all but the batch's last 1..CH reads);
+// workgroup 0 counts the rest through the tested loop before it draws its first ticket.
 __global__ __launch_bounds__(FXG_QS_TBLOCK) void fxg_kernel_quality_stats(const FxgStatsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u32 qs_h[];
+    __shared__ u32 s_tk[4];
     const u32 tid = threadIdx.x;
+#ifdef FXG_QS_CLOCKS      // measurement build: when each workgroup of the launch started, left its loop and ended (100 MHz ticks), left in unused bins of the result
+    const u64 qs_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     u32 *part = a.partial + (u64)blockIdx.x * FXG_QS_PART_WORDS;
     for (u32 i = tid; i < FXG_QS_LDS_WORDS; i += FXG_QS_TBLOCK) qs_h[i] = 0u;
-    for (u32 i = tid; i < FXG_QS_PART_WORDS; i += FXG_QS_TBLOCK) part[i] = 0u;
+    const bool dealt = !a.len && a.qual && a.chunk_trips != 0u;
+    if (dealt && tid == 0) { s_tk[2] = atomicAdd(a.ticket, 1u); s_tk[3] = atomicAdd(a.ticket, 1u); }
     __syncthreads();
-    u64 lo, hi;
-    fxg_stats_slice(a, blockIdx.x, &lo, &hi);
-    const u64 nitems = (hi - lo) * FXG_QS_WAVES;
     // FXG_QS_TBLOCK is a multiple of the strips per block: item g0 + u * TBLOCK + tid is strip tid % 10 of read lo + g / 10
     const u32 sl = tid % FXG_QS_WAVES, rl = tid / FXG_QS_WAVES;
     const u32 reads_per_step = FXG_QS_TBLOCK / FXG_QS_WAVES;                                           // 96
     const u32 trip_reads = reads_per_step * FXG_QS_UNROLL;                                             // reads a trip touches
+    const u32 c0 = (a.strip0 + sl) * FXG_QS_STRIP;
+    const u32 nb = a.fixed_len > c0 ? (a.fixed_len - c0 < FXG_QS_STRIP ? a.fixed_len - c0 : FXG_QS_STRIP) : 0u;
     u32 mfix[4];                                                                                        // fixed-length batches: the lane's tail mask never changes
-    { const u32 c0 = (a.strip0 + sl) * FXG_QS_STRIP; fxg_stats_masks(a.fixed_len > c0 ? (a.fixed_len - c0 < FXG_QS_STRIP ? a.fixed_len - c0 : FXG_QS_STRIP) : 0u, mfix); }
-    u32 since = 0;                                            // reads added to the LDS block since it was last cleared
-    u64 r0 = lo + rl;
-    // Fixed-length batches, interior trips (every read of the trip and of the next one inside the slice, none of them the batch's last
-    // read): the loads need no test at all, so the rows of trip i + 1 are requested BEFORE the rows of trip i go into the histogram and
-    // stay in flight during the lane's 16 x UNROLL LDS adds -- with a test around every load the compiler waited for vmcnt(0) at the
-    // first use, i.e. for the rows it had just asked for.  A lane whose strip lies past the end of the reads (100-base reads: strips
-    // 7..9) loads its row's first bytes instead and adds nothing.
-    u64 g0 = 0;
-#if FXG_QS_DEPTH > 1
-    // Round 6 experiment (FXG_QS_DEPTH > 1): the rows of trip i + DEPTH are requested before trip i goes into the histogram (a ring of DEPTH + 1 register
-    // buffers, the loop unrolled DEPTH + 1 times so that every buffer is a fixed set of registers; the ISA waits with vmcnt(2 DEPTH)).  Measured: no gain,
-    // the kernel is not short of bytes in flight.
-    if (!a.len && a.qual && FXG_QS_UNROLL == 1u) {
-        constexpr u32 D = FXG_QS_DEPTH;
-        const u64 safe = hi < a.n ? hi : (a.n ? a.n - 1 : 0);                     // reads below `safe` may be read 16 bytes at a time from any column
-        const u32 c0 = (a.strip0 + sl) * FXG_QS_STRIP;
-        const u32 nb = a.fixed_len > c0 ? (a.fixed_len - c0 < FXG_QS_STRIP ? a.fixed_len - c0 : FXG_QS_STRIP) : 0u;
-        const u64 tb = (u64)reads_per_step * a.stride;                            // bytes between a lane's rows of consecutive trips
-        u64 at = r0 * a.stride + (nb ? c0 : 0u), first = lo;                      // `first`: first read of the trip (wave-uniform)
-        if (first + (u64)(2u * D + 1u) * reads_per_step <= safe) {
-            FxgStripRow buf[D + 1];
-#pragma unroll
-            for (u32 k = 0; k < D; ++k) { buf[k].vb = fxg_ld16(a.bases + at + k * tb); buf[k].vq = fxg_ld16(a.qual + at + k * tb); buf[k].nb = nb; }
-            while (first + (u64)(2u * D + 1u) * reads_per_step <= safe) {         // a group of D + 1 trips: all of them and the D behind them lie inside the slice
-#pragma unroll
-                for (u32 k = 0; k <= D; ++k) {
-                    FxgStripRow &in = buf[(k + D) % (D + 1u)];
-                    in.vb = fxg_ld16(a.bases + at + (u64)D * tb); in.vq = fxg_ld16(a.qual + at + (u64)D * tb); in.nb = nb;
-                    if (since + reads_per_step > 65535u) {
-                        __syncthreads();
-                        fxg_stats_flush(qs_h, part, tid, FXG_QS_TBLOCK);
-                        __syncthreads();
-                        since = 0;
-                    }
-                    fxg_stats_accumulate(a, buf[k], sl, c0, mfix, qs_h);
-                    since += reads_per_step; first += reads_per_step; g0 += (u64)FXG_QS_TBLOCK; r0 += reads_per_step; at += tb;
-                }
-            }
-#pragma unroll
-            for (u32 k = 0; k < D; ++k) {                                         // the D trips whose rows are already here
-                if (since + reads_per_step > 65535u) {
-                    __syncthreads();
-                    fxg_stats_flush(qs_h, part, tid, FXG_QS_TBLOCK);
-                    __syncthreads();
-                    since = 0;
-                }
-                fxg_stats_accumulate(a, buf[k], sl, c0, mfix, qs_h);
-                since += reads_per_step; g0 += (u64)FXG_QS_TBLOCK; r0 += reads_per_step;
-            }
-        }
-    } else
-#endif
-    if (!a.len && a.qual) {
-        const u64 safe = hi < a.n ? hi : (a.n ? a.n - 1 : 0);                     // reads below `safe` may be read 16 bytes at a time from any column
-        const u32 c0 = (a.strip0 + sl) * FXG_QS_STRIP;
-        const u32 nb = a.fixed_len > c0 ? (a.fixed_len - c0 < FXG_QS_STRIP ? a.fixed_len - c0 : FXG_QS_STRIP) : 0u;
-        const u64 tb = (u64)trip_reads * a.stride, sb = (u64)reads_per_step * a.stride;
-        u64 at = r0 * a.stride + (nb ? c0 : 0u), first = lo;                      // `first`: first read of the trip (wave-uniform)
-        if (first + 2ull * trip_reads <= safe) {
-            FxgStripRow cur[FXG_QS_UNROLL], nx[FXG_QS_UNROLL];
-#pragma unroll
-            for (u32 u = 0; u < FXG_QS_UNROLL; ++u) { cur[u].vb = fxg_ld16(a.bases + at + u * sb); cur[u].vq = fxg_ld16(a.qual + at + u * sb); cur[u].nb = nb; }
-            for (; first + 2ull * trip_reads <= safe; first += trip_reads, g0 += (u64)FXG_QS_TBLOCK * FXG_QS_UNROLL, r0 += trip_reads, at += tb) {
-#pragma unroll
-                for (u32 u = 0; u < FXG_QS_UNROLL; ++u) { nx[u].vb = fxg_ld16(a.bases + at + tb + u * sb); nx[u].vq = fxg_ld16(a.qual + at + tb + u * sb); nx[u].nb = nb; }
-                if (since + trip_reads > 65535u) {
-                    __syncthreads();
-                    fxg_stats_flush(qs_h, part, tid, FXG_QS_TBLOCK);
-                    __syncthreads();
-                    since = 0;
-                }
-#pragma unroll
-                for (u32 u = 0; u < FXG_QS_UNROLL; ++u) fxg_stats_accumulate(a, cur[u], sl, c0, mfix, qs_h);
-#pragma unroll
-                for (u32 u = 0; u < FXG_QS_UNROLL; ++u) cur[u] = nx[u];
-                since += trip_reads;
-            }
-            // the trip whose rows are already here
-            if (since + trip_reads > 65535u) {
+    fxg_stats_masks(nb, mfix);
+    u32 since = 0, nflush = 0;                                // reads added to the LDS block since it was last cleared (an upper bound); flushes so far
+    // the tested loop: ragged reads, FASTA, small batches' slices, the batch's last reads
+    auto tested = [&](u64 lo, u64 hi) {
+        const u64 nitems = (hi - lo) * FXG_QS_WAVES;
+        u64 r0 = lo + rl;
+        for (u64 g0 = 0; g0 < nitems; g0 += (u64)FXG_QS_TBLOCK * FXG_QS_UNROLL, r0 += trip_reads) {
+            if (since + trip_reads > 65535u) {                    // a 16-bit counter could wrap: move the block out (uniform branch)
                 __syncthreads();
-                fxg_stats_flush(qs_h, part, tid, FXG_QS_TBLOCK);
+                fxg_stats_flush(qs_h, part, tid, FXG_QS_TBLOCK, nflush++ == 0u);
                 __syncthreads();
                 since = 0;
             }
+            FxgStripRow row[FXG_QS_UNROLL];
 #pragma unroll
-            for (u32 u = 0; u < FXG_QS_UNROLL; ++u) fxg_stats_accumulate(a, cur[u], sl, c0, mfix, qs_h);
-            since += trip_reads; g0 += (u64)FXG_QS_TBLOCK * FXG_QS_UNROLL; r0 += trip_reads;
-        }
-    }
-    // everything else (ragged reads, FASTA, the last trips of a slice): every load tested
-    for (; g0 < nitems; g0 += (u64)FXG_QS_TBLOCK * FXG_QS_UNROLL, r0 += trip_reads) {
-        if (since + trip_reads > 65535u) {                    // a 16-bit counter could wrap: move the block out (uniform branch)
-            __syncthreads();
-            fxg_stats_flush(qs_h, part, tid, FXG_QS_TBLOCK);
-            __syncthreads();
-            since = 0;
-        }
-        FxgStripRow row[FXG_QS_UNROLL];
+            for (u32 u = 0; u < FXG_QS_UNROLL; ++u) {
+                const u64 r = r0 + (u64)u * reads_per_step;
+                row[u].nb = 0u;
+                if (r < hi) fxg_stats_load(a, r, a.strip0 + sl, row[u]);
+            }
 #pragma unroll
-        for (u32 u = 0; u < FXG_QS_UNROLL; ++u) {
-            const u64 r = r0 + (u64)u * reads_per_step;
-            row[u].nb = 0u;
-            if (r < hi) fxg_stats_load(a, r, a.strip0 + sl, row[u]);
+            for (u32 u = 0; u < FXG_QS_UNROLL; ++u) {
+                if (a.len) { u32 m[4]; fxg_stats_masks(row[u].nb, m); fxg_stats_accumulate(a, row[u], sl, c0, m, qs_h); }
+                else fxg_stats_accumulate(a, row[u], sl, c0, mfix, qs_h);
+            }
+            since += trip_reads;
         }
-#pragma unroll
-        for (u32 u = 0; u < FXG_QS_UNROLL; ++u) {
-            if (a.len) { u32 m[4]; fxg_stats_masks(row[u].nb, m); fxg_stats_accumulate(a, row[u], sl, (a.strip0 + sl) * FXG_QS_STRIP, m, qs_h); }
-            else fxg_stats_accumulate(a, row[u], sl, (a.strip0 + sl) * FXG_QS_STRIP, mfix, qs_h);
+    };
+    if (!dealt) {
+        u64 lo, hi;
+        fxg_stats_slice(a, blockIdx.x, &lo, &hi);
+        tested(lo, hi);
+    } else {
+        const u32 K = a.chunk_trips, CH = K * reads_per_step;
+        const u32 nfast = a.n ? (u32)((a.n - 1) / CH) : 0u;                       // chunks 0 .. nfast - 1: every read below n - 1
+        if (blockIdx.x == 0u) tested((u64)nfast * CH, a.n);
+        u32 tk = s_tk[2], tkn = s_tk[3], pending = 0u, j = 0u;
+        if (tid == 0) pending = atomicAdd(a.ticket, 1u);                          // the ticket after those two; handed over at the first chunk's barrier
+        if (tk < nfast) {
+            const u64 tb = (u64)reads_per_step * a.stride;                        // bytes between a lane's rows of consecutive trips
+            const u32 coff = nb ? c0 : 0u;                                        // a lane whose strip lies past the end of the reads loads its row's first bytes and adds nothing
+            u64 at = ((u64)tk * CH + rl) * a.stride + coff;
+            FxgStripRow cur, nx;
+            cur.vb = FXG_QS_LD(a.bases + at); cur.vq = FXG_QS_LD(a.qual + at); cur.nb = nb; nx = cur;
+            since += CH;
+            for (;;) {
+                for (u32 t = 0; t + 1u < K; ++t) {
+                    nx.vb = FXG_QS_LD(a.bases + at + tb); nx.vq = FXG_QS_LD(a.qual + at + tb);
+                    fxg_stats_accumulate(a, cur, sl, c0, mfix, qs_h);
+                    cur = nx; at += tb;
+                }
+                // the chunk's one barrier, ahead of its last trip: the ticket after the next one changes hands, the block is moved out if its counters could wrap
+                if (tid == 0) s_tk[j & 1u] = pending;
+                __syncthreads();
+                const u32 tk2 = s_tk[j & 1u];
+                if (since + CH > 65535u) {
+                    fxg_stats_flush(qs_h, part, tid, FXG_QS_TBLOCK, nflush++ == 0u);
+                    __syncthreads();
+                    since = 0;
+                }
+                since += CH;
+                if (tid == 0) pending = atomicAdd(a.ticket, 1u);
+                ++j;
+                const bool more = tkn < nfast;
+                if (more) {
+                    at = ((u64)tkn * CH + rl) * a.stride + coff;
+                    nx.vb = FXG_QS_LD(a.bases + at); nx.vq = FXG_QS_LD(a.qual + at);
+                }
+                fxg_stats_accumulate(a, cur, sl, c0, mfix, qs_h);
+                if (!more) break;
+                cur = nx; tk = tkn; tkn = tk2;
+            }
         }
-        since += trip_reads;
     }
     __syncthreads();
-    fxg_stats_flush(qs_h, part, tid, FXG_QS_TBLOCK);
+#ifdef FXG_QS_CLOCKS
+    const u64 qs_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    fxg_stats_flush(qs_h, part, tid, FXG_QS_TBLOCK, nflush++ == 0u);
+#ifdef FXG_QS_CLOCKS
+    if (tid == 0) {      // into bins 0..2 of (column g / 5, class g % 5): no quality byte of the measurement's input lands there
+        u64 *o = a.hist + ((u64)(blockIdx.x / 5u) * FXG_QS_CLASSES + blockIdx.x % 5u) * FXG_QS_BINS;
+        o[0] = qs_t0; o[1] = qs_t1; o[2] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 __global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_quality_stats_fold(const FxgStatsArgs a)

@@ -359,18 +359,18 @@ extern "C" int fxg_emu_run_quality_stats(const fxg_batch *in, uint64_t *hist, ui
     const u32 trip_reads = (FXG_QS_TBLOCK * FXG_QS_UNROLL + FXG_QS_WAVES - 1u) / FXG_QS_WAVES + 1u;
     for (u32 s0 = 0; s0 < nstrips; s0 += FXG_QS_WAVES) {
         a.strip0 = s0;
-        std::fill(partial.begin(), partial.end(), 0u);
+        std::fill(partial.begin(), partial.end(), 0xDEADBEEFu);     // the kernel does not clear its partial: a workgroup's first flush stores every counter
         for (u32 g = 0; g < a.nwg; ++g) {
             std::fill(lds.begin(), lds.end(), 0u);
             u32 *part = a.partial + (u64)g * FXG_QS_PART_WORDS;
             u64 lo, hi;
             fxg_stats_slice(a, g, &lo, &hi);
             const u64 nitems = (hi - lo) * FXG_QS_WAVES;
-            u32 since = 0;
+            u32 since = 0, nflush = 0;
             for (u64 g0 = 0; g0 < nitems; g0 += (u64)FXG_QS_TBLOCK * FXG_QS_UNROLL) {
                 if (since + trip_reads > (getenv("FXG_EMU_QS_FLUSH") ? 600u : 65535u)) {      // the env knob exercises the wrap guard on small inputs
-                    for (u32 t = 0; t < FXG_QS_TBLOCK; ++t) fxg_stats_flush(lds.data(), part, t, FXG_QS_TBLOCK);
-                    since = 0;
+                    for (u32 t = 0; t < FXG_QS_TBLOCK; ++t) fxg_stats_flush(lds.data(), part, t, FXG_QS_TBLOCK, nflush == 0u);
+                    since = 0; ++nflush;
                 }
                 for (u32 t = 0; t < FXG_QS_TBLOCK; ++t)
                     for (u32 u = 0; u < FXG_QS_UNROLL; ++u) {
@@ -386,7 +386,7 @@ extern "C" int fxg_emu_run_quality_stats(const fxg_batch *in, uint64_t *hist, ui
                     }
                 since += trip_reads;
             }
-            for (u32 t = 0; t < FXG_QS_TBLOCK; ++t) fxg_stats_flush(lds.data(), part, t, FXG_QS_TBLOCK);
+            for (u32 t = 0; t < FXG_QS_TBLOCK; ++t) fxg_stats_flush(lds.data(), part, t, FXG_QS_TBLOCK, nflush == 0u);
         }
         for (u32 e = 0; e < FXG_QS_PART_WORDS; ++e) fxg_stats_fold(a, e);
     }
