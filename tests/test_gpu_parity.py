@@ -614,6 +614,19 @@ def test_quality_stats_vs_oracle_and_full_size(engine):
         exp = torch.bincount(key, minlength=5 * 128).view(5, 128)
         assert torch.equal(h[col], exp), col
     print("quality_stats 50M x 150: %.3f ms = %.0f GB/s of rows" % (ms, 2 * n * L / ms / 1e6))
+    # the sizes between: chunks of 1 .. 32 trips dealt out by the ticket counter, a last chunk that is not full, batches whose last reads take the tested
+    # loop, qualities outside the LDS window -- every column against torch.bincount
+    g = torch.Generator(device=engine.device).manual_seed(11)
+    for n, L, wild in ((96 * 7 + 1, 150, False), (1_000_003, 150, False), (7_000_001, 100, True), (20_000_000, 36, False), (3_300_000, 160, False)):
+        b, q = engine.synth(2, 0, n, L, False)
+        if wild:
+            hit = torch.rand(q.shape, device=engine.device, generator=g) < 0.01
+            q = torch.where(hit, torch.randint(33, 127, q.shape, device=engine.device, generator=g, dtype=torch.int64).to(torch.uint8), q)
+        h = engine.quality_stats(b, q, fixed_len=L)
+        assert int(h.sum()) == n * L, (n, L)
+        for col in range(L):
+            key = cls[b[:, col].long()] * 128 + q[:, col].long()
+            assert torch.equal(h[col], torch.bincount(key, minlength=5 * 128).view(5, 128)), (n, L, col)
 
 
 def test_long_reads(engine):
