@@ -274,7 +274,7 @@ extern "C" int fxg_run_quality_stats(fxg_ctx *c, const fxg_batch *in, uint64_t *
     u64 nwg = (in->n + 255) / 256;
     if (nwg > (u64)c->cus) nwg = (u64)c->cus;
     a.nwg = (u32)nwg;
-    const size_t need = 256u + (size_t)a.nwg * FXG_QS_PART_WORDS * sizeof(u32);      // [0, 256): the chunk dispenser; then the partials
+    const size_t need = (size_t)a.nwg * FXG_QS_PART_WORDS * sizeof(u32);
     if (c->stats_ws_cap < need) {
         FXG_HIP(c, hipStreamSynchronize(c->stream));
         (void)hipFree(c->stats_ws);
@@ -282,16 +282,14 @@ extern "C" int fxg_run_quality_stats(fxg_ctx *c, const fxg_batch *in, uint64_t *
         FXG_HIP(c, hipMalloc((void **)&c->stats_ws, need));
         c->stats_ws_cap = need;
     }
-    a.ticket = c->stats_ws;
-    a.partial = c->stats_ws + 64;
-    // chunks of chunk_trips x 96 reads, about sixteen to a workgroup and at most 32 trips long (a barrier per chunk; the last chunks decide how evenly the launch ends)
-    { const u64 k = in->n / (96ull * a.nwg * 16ull); a.chunk_trips = (u32)(k < 1 ? 1 : k > 32 ? 32 : k); }
+    a.partial = c->stats_ws;
+    a.round_robin = 1u;
+    if (const char *e = getenv("FXG_QS_ROUND_ROBIN")) a.round_robin = (u32)strtoul(e, nullptr, 0);      // measurement knob: 0 = one static slice per workgroup, tested loads
     const u32 lds = FXG_QS_LDS_WORDS * sizeof(u32);
     FXG_HIP(c, hipFuncSetAttribute((const void *)fxg_kernel_quality_stats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const u32 nstrips = (in->stride + FXG_QS_STRIP - 1) / FXG_QS_STRIP;
     for (u32 s0 = 0; s0 < nstrips; s0 += FXG_QS_WAVES) {       // one pass per block of 160 columns (one pass for reads up to 160)
         a.strip0 = s0;
-        FXG_HIP(c, hipMemsetAsync(a.ticket, 0, sizeof(u32), c->stream));
         const bool timed = c->profiling && s0 == 0;
         if (timed) FXG_HIP(c, hipEventRecord(c->kev0[c->kev_count % FXG_KEV_RING], c->stream));
         hipLaunchKernelGGL(fxg_kernel_quality_stats, dim3(a.nwg), dim3(FXG_QS_TBLOCK), lds, c->stream, a);

@@ -1508,6 +1508,12 @@ __device__ __forceinline__ void fxg_tile_tally(u32 w, bool valid, u64 *tally)
 #define FXG_CLIP_WAVES 4  // the same for the packed clip instances up to 16 adapter columns (S, S-5 and the path summary of every column live in registers)
 #endif
 #define FXG_NO_TILE 0xFFFFFFFFu
+#ifndef FXG_PRIO_WRITEOUT
+#define FXG_PRIO_WRITEOUT 3   // s_setprio of the clip instances' write-out and staging phases (0 = none)
+#endif
+#ifndef FXG_PRIO_STAGING
+#define FXG_PRIO_STAGING 2
+#endif
 // Threads per workgroup of an instance (FXG_CLIP_TBLOCK for the two-pass clip instances).  One wave per workgroup (64-read tiles, no
 // workgroup barrier anywhere) was built and measured for them: cfg3 14.2 against 13.9 ms, cfg5 60 against 50 ms (four times the tiles
 // to scan, publish and ticket, and 13 single-wave workgroups do not spread evenly over four SIMDs) -- profiles/r03/i_ablate.txt.
@@ -1600,10 +1606,12 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
             const u32 tbytes = nreads * stride;
             unsigned char *sl = smem + slot * L.slot_bytes;
             if constexpr (MODE == 0 || MODE == 3 || MODE == 4) {
+                if constexpr (MODE == 0 && AMAX != 0) __builtin_amdgcn_s_setprio(FXG_PRIO_STAGING);      // the same for the staging loads of the next tile
                 if (use_q && !FXG_DBG(a, 8u)) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, TB);
                 if constexpr (MODE == 0 && AMAX != 0) { if (!GL && (!FXG_DBG(a, 16u) || pend == FXG_NO_TILE)) fxg_phase_stage_bases(a.clip_src, a.clip_total, (u64)r0 * a.clip_stride, nreads * a.clip_stride, sb, tid, TB); }   // 16: the DP on the workgroup's first tile over and over (the DP's own rate)
                 if constexpr (MODE == 4) fxg_phase_stage_bases(a.bases, a.total_bytes, tb, tbytes, sb, tid, TB);
                 __syncthreads();
+                if constexpr (MODE == 0 && AMAX != 0) __builtin_amdgcn_s_setprio(0);
             }
             FXG_TPHASE(0);
             u32 keep = 0, olen = 0, anchor = tid * stride, word = 0;
@@ -1649,6 +1657,9 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
         // ------------------------------ stage B: tile `pend`, decided NSLOT - 1 steps ago ------------------------------
         // (behind stage A: the scanner has had at least a whole stage A to deliver the prefix, so the wait is off the critical path)
         if (pend != FXG_NO_TILE && a.compact) {
+            // clip instances: the write-out's few, latency-bound instructions go ahead of the other workgroups' DP rows (a wave that waits here is a wave
+            // missing from its SIMD's interleave of four); with the staging below cfg5 -1.5 %, cfg3 -0.8 % (profiles/r06/w_clip_ab_setprio.txt)
+            if constexpr (MODE == 0 && AMAX != 0) __builtin_amdgcn_s_setprio(FXG_PRIO_WRITEOUT);
             const u32 ps = slot + 1u == NSLOT ? 0u : slot + 1u;
             const u32 r0 = pend * T;
             const u64 left = a.n - (u64)r0;
@@ -1672,6 +1683,7 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
                 if (REV && bad) atomicOr(a.errflag, FXG_DEV_ERR_BAD_BASE);
             }
             FXG_TPHASE(4);
+            if constexpr (MODE == 0 && AMAX != 0) __builtin_amdgcn_s_setprio(0);
         }
         if (cur >= a.ntiles && (NSLOT == 2u || (mid == FXG_NO_TILE && mid2 == FXG_NO_TILE))) break;
         __syncthreads();            // ticket written by thread 0 in stage A; also fences slot reuse NSLOT iterations apart

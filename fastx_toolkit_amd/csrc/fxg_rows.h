@@ -29,7 +29,8 @@
 #define FXG_ROWS_SCAN_K 8               // tiles per scanner batch / 64 (fxg_scanner_multi)
 #endif
 #ifndef FXG_ROWS_LD_AUX
-#define FXG_ROWS_LD_AUX 0               // cache policy bits of the row loads (2 = nt: measured, no gain)
+#define FXG_ROWS_LD_AUX 2               // cache policy bits of the row loads: 2 = nt, every row is read once (round 2 saw no gain; re-measured at HEAD: cfg2 4.13 -> 4.06 ms in
+                                        // four alternating runs, profiles/r06/y_cfg2_rows_nt.txt; a read-only LDS-DMA stream of 15 GB: 6.36 -> 6.77 TB/s, x_read_stream_by_access_form.txt)
 #endif
 #ifndef FXG_ROWS_NSCAN
 #define FXG_ROWS_NSCAN 8                // scanner waves

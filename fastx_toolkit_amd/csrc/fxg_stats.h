@@ -36,6 +36,9 @@
 #define FXG_QS_LROWS 6u                                    // LDS rows per column pair: A C G T N + the spare row (bytes past the end of a read; never flushed)
 #define FXG_QS_LROW_WORDS FXG_QS_WBINS                     // 256 bytes: class k of a pair lives at byte k << 8 of the pair's block
 #define FXG_QS_LDS_WORDS ((FXG_QS_BLOCK_COLS / 2u) * FXG_QS_LROWS * FXG_QS_LROW_WORDS)   // word = two u16 counters: even column low, odd column high
+#ifndef FXG_QS_DEPTH
+#define FXG_QS_DEPTH 3u                                    // trips a lane's row loads run ahead of its LDS adds (round-robin loop)
+#endif
 #ifndef FXG_QS_UNROLL
 #define FXG_QS_UNROLL 1u                                   // rows per lane and trip of the tested loop
 #endif
@@ -48,8 +51,7 @@ struct FxgStatsArgs {
     u32  strip0;                      // first strip of this pass (column block)
     u32  nwg;                         // workgroups = slices of the reads
     u32 *partial;                     // [nwg][FXG_QS_PART_WORDS]
-    u32 *ticket;                      // chunk dispenser, zero at launch
-    u32  chunk_trips;                 // trips of 96 reads per chunk; 0: static slices through the tested loop
+    u32  round_robin;                 // fixed-length batches with qualities: trips dealt round robin (0: static slices through the tested loop; a measurement knob)
     u64 *hist;                        // [hist_cols][FXG_QS_CLASSES][FXG_QS_BINS]
     u32  hist_cols;
 };
@@ -239,25 +241,24 @@ FXG_HD void fxg_stats_item(u64 lo, u64 g, u64 *r, u32 *sl) { *r = lo + g / FXG_Q
 #else
 #define FXG_QS_LD(p) fxg_ld16(p)
 #endif
-// Fixed-length batches with qualities: the reads are dealt out in CHUNKS of chunk_trips * 96 reads by a ticket counter, not in one static slice per
-// workgroup.  Measured with static slices (profiles/r06/stats_wg_clocks_static.txt): the 256 workgroups of the launch leave their loops between 2.50 and
-// 2.70 ms (median 2.58; the even XCDs 1.5 % behind the odd ones) and the kernel lasts as long as the slowest -- which workgroup counts which read does
-// not matter to a histogram.  The rows of a lane's next trip are requested BEFORE the rows of this trip go into the histogram, across chunk borders
-// too: the ticket of the next chunk is known one chunk ahead (thread 0 asks for it two chunks ahead and hands it over through LDS at the one barrier
-// a chunk has).  Only chunks whose every read may be loaded 16 bytes at a time from any column are dealt out (all but the batch's last 1..CH reads);
-// workgroup 0 counts the rest through the tested loop before it draws its first ticket.
+// Fixed-length batches with qualities: trip T of the launch is reads [96 T, 96 T + 96) and belongs to workgroup T mod G, so that at any moment the whole chip
+// reads ONE narrow window of each array (256 x 14 KB) -- the order the memory system serves best: a read-only stream of 15 GB takes 2.33 ms that way
+// (2.20 with the non-temporal policy) against 2.45-2.50 ms from one far-apart slice per workgroup (scripts/ubench/read_stream.hip, profiles/r06/
+// x_read_stream_by_access_form.txt; this kernel's loads alone 2.49 -> 2.33 ms).  Tickets for chunks of 2 .. 32 trips were built and measured too
+// (profiles/r06/stats_order.txt): all workgroups then end within 2 % of one another (static slices: 2.50 .. 2.70 ms, profiles/r06/stats_wg_clocks_*.txt)
+// and the kernel takes the same time or longer -- the memory system is the limit, not the slowest workgroup -- so the dispenser went again.
+// The rows of a lane's trip k + D are requested before trip k goes into the histogram (FXG_QS_DEPTH; 1 -> 4: -1.5 %).  Only trips whose every read may
+// be loaded 16 bytes at a time from any column are dealt (all but the batch's last 1..96 reads); workgroup 0 counts the rest through the tested loop.
 __global__ __launch_bounds__(FXG_QS_TBLOCK) void fxg_kernel_quality_stats(const FxgStatsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u32 qs_h[];
-    __shared__ u32 s_tk[4];
     const u32 tid = threadIdx.x;
 #ifdef FXG_QS_CLOCKS      // measurement build: when each workgroup of the launch started, left its loop and ended (100 MHz ticks), left in unused bins of the result
     const u64 qs_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
     u32 *part = a.partial + (u64)blockIdx.x * FXG_QS_PART_WORDS;
     for (u32 i = tid; i < FXG_QS_LDS_WORDS; i += FXG_QS_TBLOCK) qs_h[i] = 0u;
-    const bool dealt = !a.len && a.qual && a.chunk_trips != 0u;
-    if (dealt && tid == 0) { s_tk[2] = atomicAdd(a.ticket, 1u); s_tk[3] = atomicAdd(a.ticket, 1u); }
+    const bool dealt = !a.len && a.qual && a.round_robin != 0u;
     __syncthreads();
     // FXG_QS_TBLOCK is a multiple of the strips per block: item g0 + u * TBLOCK + tid is strip tid % 10 of read lo + g / 10
     const u32 sl = tid % FXG_QS_WAVES, rl = tid / FXG_QS_WAVES;
@@ -299,44 +300,47 @@ __global__ __launch_bounds__(FXG_QS_TBLOCK) void fxg_kernel_quality_stats(const 
         fxg_stats_slice(a, blockIdx.x, &lo, &hi);
         tested(lo, hi);
     } else {
-        const u32 K = a.chunk_trips, CH = K * reads_per_step;
-        const u32 nfast = a.n ? (u32)((a.n - 1) / CH) : 0u;                       // chunks 0 .. nfast - 1: every read below n - 1
-        if (blockIdx.x == 0u) tested((u64)nfast * CH, a.n);
-        u32 tk = s_tk[2], tkn = s_tk[3], pending = 0u, j = 0u;
-        if (tid == 0) pending = atomicAdd(a.ticket, 1u);                          // the ticket after those two; handed over at the first chunk's barrier
-        if (tk < nfast) {
-            const u64 tb = (u64)reads_per_step * a.stride;                        // bytes between a lane's rows of consecutive trips
-            const u32 coff = nb ? c0 : 0u;                                        // a lane whose strip lies past the end of the reads loads its row's first bytes and adds nothing
-            u64 at = ((u64)tk * CH + rl) * a.stride + coff;
-            FxgStripRow cur, nx;
-            cur.vb = FXG_QS_LD(a.bases + at); cur.vq = FXG_QS_LD(a.qual + at); cur.nb = nb; nx = cur;
-            since += CH;
-            for (;;) {
-                for (u32 t = 0; t + 1u < K; ++t) {
-                    nx.vb = FXG_QS_LD(a.bases + at + tb); nx.vq = FXG_QS_LD(a.qual + at + tb);
-                    fxg_stats_accumulate(a, cur, sl, c0, mfix, qs_h);
-                    cur = nx; at += tb;
-                }
-                // the chunk's one barrier, ahead of its last trip: the ticket after the next one changes hands, the block is moved out if its counters could wrap
-                if (tid == 0) s_tk[j & 1u] = pending;
-                __syncthreads();
-                const u32 tk2 = s_tk[j & 1u];
-                if (since + CH > 65535u) {
+        const u32 G = gridDim.x;
+        const u64 ntrip = a.n ? (a.n - 1) / reads_per_step : 0u;                   // trips whose every read lies below n - 1
+        if (blockIdx.x == 0u) tested(ntrip * reads_per_step, a.n);
+        if (blockIdx.x < ntrip) {
+            constexpr u32 D = FXG_QS_DEPTH;                                        // trips a lane's loads run ahead of its adds
+            const u64 cnt = (ntrip - blockIdx.x + G - 1) / G;                      // this workgroup's trips: blockIdx.x + k G
+            const u64 tb = (u64)G * reads_per_step * a.stride;
+            u64 at = ((u64)blockIdx.x * reads_per_step + rl) * a.stride + (nb ? c0 : 0u);   // (a lane whose strip lies past the reads' end loads its row's first bytes, adds nothing)
+            FxgStripRow buf[D + 1];
+#pragma unroll
+            for (u32 u = 0; u <= D; ++u) { buf[u].vb = (u32x4){0u, 0u, 0u, 0u}; buf[u].vq = buf[u].vb; buf[u].nb = nb; }
+            auto step = [&](const FxgStripRow &row) {
+                if (since + reads_per_step > 65535u) {
+                    __syncthreads();
                     fxg_stats_flush(qs_h, part, tid, FXG_QS_TBLOCK, nflush++ == 0u);
                     __syncthreads();
                     since = 0;
                 }
-                since += CH;
-                if (tid == 0) pending = atomicAdd(a.ticket, 1u);
-                ++j;
-                const bool more = tkn < nfast;
-                if (more) {
-                    at = ((u64)tkn * CH + rl) * a.stride + coff;
-                    nx.vb = FXG_QS_LD(a.bases + at); nx.vq = FXG_QS_LD(a.qual + at);
+                fxg_stats_accumulate(a, row, sl, c0, mfix, qs_h);
+                since += reads_per_step;
+            };
+            u64 k0 = 0;
+            if (cnt >= 2u * D + 1u) {
+#pragma unroll
+                for (u32 u = 0; u < D; ++u) { buf[u].vb = FXG_QS_LD(a.bases + at + u * tb); buf[u].vq = FXG_QS_LD(a.qual + at + u * tb); }
+                for (; k0 + 2u * D + 1u <= cnt; k0 += D + 1u) {                    // a group of D + 1 trips whose D successors exist: no load is tested
+#pragma unroll
+                    for (u32 u = 0; u <= D; ++u) {
+                        FxgStripRow &in = buf[(u + D) % (D + 1u)];
+                        in.vb = FXG_QS_LD(a.bases + at + (u64)D * tb); in.vq = FXG_QS_LD(a.qual + at + (u64)D * tb);
+                        step(buf[u]);
+                        at += tb;
+                    }
                 }
-                fxg_stats_accumulate(a, cur, sl, c0, mfix, qs_h);
-                if (!more) break;
-                cur = nx; tk = tkn; tkn = tk2;
+#pragma unroll
+                for (u32 u = 0; u < D; ++u) { step(buf[u]); at += tb; }          // the D trips whose rows are already on their way
+                k0 += D;
+            }
+            for (; k0 < cnt; ++k0, at += tb) {                                     // at most D + 1 more, one at a time
+                buf[0].vb = FXG_QS_LD(a.bases + at); buf[0].vq = FXG_QS_LD(a.qual + at);
+                step(buf[0]);
             }
         }
     }
