@@ -85,6 +85,14 @@ def load_library(path=None):
     global _LIB
     if _LIB is not None and path is None:
         return _LIB
+    # One HIP runtime per process: PyTorch ships its own libamdhip64 and the Python harness always ends up with torch imported (device tensors,
+    # streams).  If libfxg.so were dlopen()ed FIRST it would bring in the system's runtime and torch a second one afterwards -- two runtimes, and every
+    # HIP call behind the C-ABI fails (seen as fxg_ctx_create() = FXG_E_HIP when __graft_entry__.build() had loaded the library before smoke()
+    # imported torch).  So torch goes first wherever it exists; a C host (host/, the tools) links the system runtime and never sees torch.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     so = path or os.environ.get("FXG_LIB") or _build.LIBFXG   # FXG_LIB: A/B experiments with alternative builds
     if not os.path.exists(so):
         _build.build_engine()

@@ -36,6 +36,22 @@ __global__ void k_vgpr(const u32x4 *__restrict__ a, const u32x4 *__restrict__ b,
     if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) o[0] = acc;
 }
 
+// the same stream with cfg2's share of it written back (73 of 75 units of ONE array's worth: 7.3 GB), non-temporal stores; NTL: non-temporal loads
+template <bool NTL>
+__global__ void k_mix(const u32x4 *__restrict__ a, const u32x4 *__restrict__ b, u32x4 *o, u64 n)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32x4 xa = NTL ? __builtin_nontemporal_load(a + i) : a[i], xb = NTL ? __builtin_nontemporal_load(b + i) : b[i];
+    for (; i < n; i += stride) {
+        const u32x4 ca = xa, cb = xb;
+        const u64 j = i + stride < n ? i + stride : 0;
+        xa = NTL ? __builtin_nontemporal_load(a + j) : a[j]; xb = NTL ? __builtin_nontemporal_load(b + j) : b[j];
+        const u64 g = i / 75u, r = i - g * 75u;
+        if (r < 73u) __builtin_nontemporal_store(ca ^ cb, o + g * 73u + r);
+    }
+}
+
 // every wave owns a ring of D slots of 2 KB (1 KB per array); trip t of the workgroup = units [t * W * 64, (t + 1) * W * 64) (W waves), wave w takes its 64
 template <int D, int AUX>
 __global__ void k_lds(const unsigned char *__restrict__ a, const unsigned char *__restrict__ b, u32 *o, u64 nunits)
@@ -100,10 +116,10 @@ int main()
 {
     const u64 bytes = 7500000000ull / 61440 * 61440, n = bytes / 16;       // whole trips of 960 and of 256 lanes
     unsigned char *a, *b; u32x4 *o;
-    CK(hipMalloc(&a, bytes + 4096)); CK(hipMalloc(&b, bytes + 4096)); CK(hipMalloc(&o, 4096));
+    CK(hipMalloc(&a, bytes + 4096)); CK(hipMalloc(&b, bytes + 4096)); CK(hipMalloc(&o, bytes + 4096));
     CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 2, bytes));
-    for (int geo = 0; geo < 2; ++geo) {
-        const int grid = geo ? 1024 : 256, block = geo ? 256 : 960, W = block / 64;
+    for (int geo = 0; geo < 3; ++geo) {
+        const int grid = geo == 2 ? 2048 : geo ? 1024 : 256, block = geo ? 256 : 960, W = block / 64;
 #define VG(D, NT) { float ms = timeit([&] { hipLaunchKernelGGL((k_vgpr<D, NT>), dim3(grid), dim3(block), 0, 0, (const u32x4 *)a, (const u32x4 *)b, o, n); }); \
                     printf("grid %4d x %3d  vgpr depth %d %-7s  %7.3f ms  %5.2f TB/s\n", grid, block, D, NT ? "nt" : "default", ms, 2.0 * bytes / ms / 1e9); }
         VG(1, false) VG(2, false) VG(4, false) VG(1, true) VG(2, true) VG(4, true)
@@ -111,7 +127,9 @@ int main()
                      float ms = timeit([&] { hipLaunchKernelGGL((k_lds<D, AUX>), dim3(grid), dim3(block), W * D * 2048, 0, a, b, (u32 *)o, n); }); \
                      printf("grid %4d x %3d  lds  depth %d %-7s  %7.3f ms  %5.2f TB/s\n", grid, block, D, AUX ? "nt" : "default", ms, 2.0 * bytes / ms / 1e9); }
         LD(1, 0) LD(2, 0) LD(4, 0) LD(1, 2) LD(2, 2) LD(4, 2)
-        if (geo == 0) { }
+#define MX(NTL) { float ms = timeit([&] { hipLaunchKernelGGL((k_mix<NTL>), dim3(grid), dim3(block), 0, 0, (const u32x4 *)a, (const u32x4 *)b, o, n); }); \
+                  printf("grid %4d x %3d  mix: 15 GB read (%s) + 7.3 GB written (nt)  %7.3f ms  %5.2f TB/s\n", grid, block, NTL ? "nt" : "default", ms, (2.0 + 73.0 / 75.0) * bytes / ms / 1e9); }
+        MX(false) MX(true)
     }
     CK(hipDeviceSynchronize());
     return 0;
