@@ -303,11 +303,14 @@ __global__ __launch_bounds__(FXG_QS_TBLOCK) void fxg_kernel_quality_stats(const 
         const u32 G = gridDim.x;
         const u64 ntrip = a.n ? (a.n - 1) / reads_per_step : 0u;                   // trips whose every read lies below n - 1
         if (blockIdx.x == 0u) tested(ntrip * reads_per_step, a.n);
-        if (blockIdx.x < ntrip) {
+        // round_robin 1: this workgroup's trips are blockIdx.x + k G; 2 (measurement knob): a contiguous run of trips per workgroup through the same loop
+        const bool rr = a.round_robin != 2u;
+        const u64 per = (ntrip + G - 1) / G, first = rr ? (u64)blockIdx.x : (u64)blockIdx.x * per;
+        if (first < ntrip) {
             constexpr u32 D = FXG_QS_DEPTH;                                        // trips a lane's loads run ahead of its adds
-            const u64 cnt = (ntrip - blockIdx.x + G - 1) / G;                      // this workgroup's trips: blockIdx.x + k G
-            const u64 tb = (u64)G * reads_per_step * a.stride;
-            u64 at = ((u64)blockIdx.x * reads_per_step + rl) * a.stride + (nb ? c0 : 0u);   // (a lane whose strip lies past the reads' end loads its row's first bytes, adds nothing)
+            const u64 cnt = rr ? (ntrip - first + G - 1) / G : (first + per <= ntrip ? per : ntrip - first);
+            const u64 tb = (u64)(rr ? G : 1u) * reads_per_step * a.stride;
+            u64 at = (first * reads_per_step + rl) * a.stride + (nb ? c0 : 0u);   // (a lane whose strip lies past the reads' end loads its row's first bytes, adds nothing)
             FxgStripRow buf[D + 1];
 #pragma unroll
             for (u32 u = 0; u <= D; ++u) { buf[u].vb = (u32x4){0u, 0u, 0u, 0u}; buf[u].vq = buf[u].vb; buf[u].nb = nb; }
