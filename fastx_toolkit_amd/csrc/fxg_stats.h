@@ -234,9 +234,11 @@ FXG_HD void fxg_stats_fold(const FxgStatsArgs &a, u32 e)
 FXG_HD void fxg_stats_item(u64 lo, u64 g, u64 *r, u32 *sl) { *r = lo + g / FXG_QS_WAVES; *sl = (u32)(g % FXG_QS_WAVES); }
 
 #ifndef FXG_HOST_EMULATION
-// the dealt loop's row loads carry the non-temporal policy (every row is read once): 2.667 against 2.713 ms, mean of eight alternating runs
-// (profiles/r06/stats_nt_loads.txt); -DFXG_QS_NO_NTL builds the other arm
-#ifndef FXG_QS_NO_NTL
+// The loop's row loads keep the DEFAULT cache policy.  With the non-temporal policy the kernel is 1.0-1.7 % faster (2.667 against 2.713 ms, mean of eight
+// alternating runs, profiles/r06/stats_nt_loads.txt; 2.724 against 2.751, stats_variants_one_call.txt) but fetches 7 % more: the 16-byte pieces of 150-byte
+// rows share their first and last 128-byte lines with the neighbouring wave's, and a line marked non-temporal is gone before the neighbour asks (FETCH_SIZE
+// 1.05 -> 1.12 x the rows, profiles/r06_pmc_stats).  Bytes over the fabric are the scarcer thing; -DFXG_QS_NTL builds the other arm.
+#ifdef FXG_QS_NTL
 #define FXG_QS_LD(p) __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned *>(p))
 #else
 #define FXG_QS_LD(p) fxg_ld16(p)
