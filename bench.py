@@ -750,7 +750,8 @@ def main():
                 out["roofline"] = {
                     "bound": "hbm", **hbm, **shape,
                     **({"note": "not measured in this run: a plain streaming kernel that reads 15 GB and writes 7.3 GB (this config's algorithmic bytes, nothing "
-                                "else) takes 4.25-4.56 ms on this part, read alone 2.34-2.50 ms, write alone 1.17-1.25 ms (scripts/ubench/mix_rw.hip, profiles/r02/z_mix_rw.txt)"}
+                                "else) takes 4.21-4.56 ms on this part (4.21-4.38 with every workgroup in one narrow window, loads a trip ahead and the non-temporal policy both ways), "
+                                "read alone 2.20-2.50 ms, write alone 1.17-1.25 ms (scripts/ubench/read_stream.hip, mix_rw.hip; profiles/r06/x_read_stream_*.txt, profiles/r02/z_mix_rw.txt)"}
                        if config == "cfg2" and compact else {}),
                 }
             if self_check is not None:

@@ -295,7 +295,7 @@ extern "C" int fxg_run_quality_stats(fxg_ctx *c, const fxg_batch *in, uint64_t *
         hipLaunchKernelGGL(fxg_kernel_quality_stats, dim3(a.nwg), dim3(FXG_QS_TBLOCK), lds, c->stream, a);
         FXG_HIP(c, hipGetLastError());
         if (timed) { FXG_HIP(c, hipEventRecord(c->kev1[c->kev_count % FXG_KEV_RING], c->stream)); c->kev_count++; }
-        hipLaunchKernelGGL(fxg_kernel_quality_stats_fold, dim3((FXG_QS_PART_WORDS + FXG_BLOCK - 1) / FXG_BLOCK), dim3(FXG_BLOCK), 0, c->stream, a);
+        hipLaunchKernelGGL(fxg_kernel_quality_stats_fold, dim3((FXG_QS_PART_WORDS + FXG_QS_FOLD_E - 1) / FXG_QS_FOLD_E), dim3(256), 0, c->stream, a);
         FXG_HIP(c, hipGetLastError());
     }
     snprintf(c->last_kernel, sizeof c->last_kernel, "fxg_kernel_quality_stats");

@@ -220,14 +220,18 @@ FXG_HD void fxg_stats_flush(u32 *lds, u32 *part, u32 t, u32 nt, bool first)
 }
 
 // element e of the fold: counter (column-in-block, class, window bin) summed over the workgroups' partials
-FXG_HD void fxg_stats_fold(const FxgStatsArgs &a, u32 e)
+FXG_HD void fxg_stats_fold_put(const FxgStatsArgs &a, u32 e, u64 sum)
 {
     const u32 w = e % FXG_QS_WBINS, ck = e / FXG_QS_WBINS;
     const u32 col = a.strip0 * FXG_QS_STRIP + ck / FXG_QS_CLASSES, k = ck % FXG_QS_CLASSES;
     if (col >= a.hist_cols) return;
+    if (sum) a.hist[((u64)col * FXG_QS_CLASSES + k) * FXG_QS_BINS + FXG_QS_WBASE + w] += sum;
+}
+FXG_HD void fxg_stats_fold(const FxgStatsArgs &a, u32 e)
+{
     u64 sum = 0;
     for (u32 g = 0; g < a.nwg; ++g) sum += a.partial[(u64)g * FXG_QS_PART_WORDS + e];
-    if (sum) a.hist[((u64)col * FXG_QS_CLASSES + k) * FXG_QS_BINS + FXG_QS_WBASE + w] += sum;
+    fxg_stats_fold_put(a, e, sum);
 }
 
 // work item g of a slice that starts at read lo: read lo + g / 10, strip g % 10 of the block
@@ -362,9 +366,28 @@ __global__ __launch_bounds__(FXG_QS_TBLOCK) void fxg_kernel_quality_stats(const 
 #endif
 }
 
-__global__ __launch_bounds__(FXG_BLOCK) void fxg_kernel_quality_stats_fold(const FxgStatsArgs a)
+// 64 counters per workgroup; four groups of lanes sum a quarter of the workgroups' partials each, eight loads in flight per lane (one thread per counter walking
+// all 256 partials took 95 us per pass, 3 % on top of the kernel itself: profiles/r06_stats_kernel_stats.md)
+#define FXG_QS_FOLD_E 64u
+__global__ __launch_bounds__(256) void fxg_kernel_quality_stats_fold(const FxgStatsArgs a)
 {
-    const u32 e = blockIdx.x * FXG_BLOCK + threadIdx.x;
-    if (e < FXG_QS_PART_WORDS) fxg_stats_fold(a, e);
+    __shared__ u64 s_sum[256];
+    const u32 tid = threadIdx.x, e = blockIdx.x * FXG_QS_FOLD_E + (tid & 63u), q = tid >> 6;
+    u64 sum = 0;
+    if (e < FXG_QS_PART_WORDS) {
+        const u32 *p = a.partial + e;
+        u32 g = q;
+        for (; g + 28u < a.nwg; g += 32u) {
+            u32 v[8];
+#pragma unroll
+            for (u32 i = 0; i < 8u; ++i) v[i] = p[(u64)(g + 4u * i) * FXG_QS_PART_WORDS];
+#pragma unroll
+            for (u32 i = 0; i < 8u; ++i) sum += v[i];
+        }
+        for (; g < a.nwg; g += 4u) sum += p[(u64)g * FXG_QS_PART_WORDS];
+    }
+    s_sum[tid] = sum;
+    __syncthreads();
+    if (q == 0u && e < FXG_QS_PART_WORDS) fxg_stats_fold_put(a, e, s_sum[tid] + s_sum[tid + 64u] + s_sum[tid + 128u] + s_sum[tid + 192u]);
 }
 #endif
