@@ -284,15 +284,19 @@ extern "C" int fxg_run_quality_stats(fxg_ctx *c, const fxg_batch *in, uint64_t *
     }
     a.partial = c->stats_ws;
     a.round_robin = 1u;
-    if (const char *e = getenv("FXG_QS_ROUND_ROBIN")) a.round_robin = (u32)strtoul(e, nullptr, 0);      // measurement knob: 0 = one static slice per workgroup, tested loads
+    if (const char *e = getenv("FXG_QS_ROUND_ROBIN")) a.round_robin = (u32)strtoul(e, nullptr, 0);      // measurement knob (csrc/fxg_stats.h: FxgStatsArgs::round_robin): 0 = one static slice per workgroup, tested loads; 3 = the row-strip form where the piece form would run
     const u32 lds = FXG_QS_LDS_WORDS * sizeof(u32);
     FXG_HIP(c, hipFuncSetAttribute((const void *)fxg_kernel_quality_stats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FXG_HIP(c, hipFuncSetAttribute((const void *)fxg_kernel_quality_stats_odd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const u32 nstrips = (in->stride + FXG_QS_STRIP - 1) / FXG_QS_STRIP;
     for (u32 s0 = 0; s0 < nstrips; s0 += FXG_QS_WAVES) {       // one pass per block of 160 columns (one pass for reads up to 160)
         a.strip0 = s0;
         const bool timed = c->profiling && s0 == 0;
         if (timed) FXG_HIP(c, hipEventRecord(c->kev0[c->kev_count % FXG_KEV_RING], c->stream));
-        hipLaunchKernelGGL(fxg_kernel_quality_stats, dim3(a.nwg), dim3(FXG_QS_TBLOCK), lds, c->stream, a);
+        u32 pr = 0, pp = 0;
+        // dense batches of odd length 17 .. 159: the piece form that keeps LDS block and counter half per byte, a kernel (and a register allocation) of its own
+        if (a.round_robin == 1u && (a.fixed_len & 1u) && fxg_stats_piece_plan(a, &pr, &pp)) hipLaunchKernelGGL(fxg_kernel_quality_stats_odd, dim3(a.nwg), dim3(FXG_QS_TBLOCK), lds, c->stream, a);
+        else hipLaunchKernelGGL(fxg_kernel_quality_stats, dim3(a.nwg), dim3(FXG_QS_TBLOCK), lds, c->stream, a);
         FXG_HIP(c, hipGetLastError());
         if (timed) { FXG_HIP(c, hipEventRecord(c->kev1[c->kev_count % FXG_KEV_RING], c->stream)); c->kev_count++; }
         hipLaunchKernelGGL(fxg_kernel_quality_stats_fold, dim3((FXG_QS_PART_WORDS + FXG_QS_FOLD_E - 1) / FXG_QS_FOLD_E), dim3(256), 0, c->stream, a);

@@ -23,6 +23,8 @@
 // clears it.  Quality bytes outside the window (Phred+33 codes 33..96 are inside) go straight to the result with a global
 // atomic.  A second kernel folds the partials into the caller's u64 histogram.  Reads longer than 160 take one pass per
 // column block.  HBM-bound by design (2 bytes per base in, nothing out).
+// Dense fixed-length batches of even length 16 .. 160 (stride == length: what the text path packs and what BASELINE's batches are) run in the PIECE form
+// instead (further down): the rows are one byte stream, a lane takes an aligned 16-byte piece of it, nothing is masked and no padding byte is added.
 #pragma once
 #include "fxg_device.h"
 
@@ -51,7 +53,8 @@ struct FxgStatsArgs {
     u32  strip0;                      // first strip of this pass (column block)
     u32  nwg;                         // workgroups = slices of the reads
     u32 *partial;                     // [nwg][FXG_QS_PART_WORDS]
-    u32  round_robin;                 // fixed-length batches with qualities: trips dealt round robin (0: static slices through the tested loop; a measurement knob)
+    u32  round_robin;                 // fixed-length batches with qualities: 1 = trips dealt round robin, piece form where the batch allows it (the default); measurement knobs:
+                                      // 0 static slices through the tested loop, 2 contiguous runs of trips through the dealt loop, 3 round robin in the row-strip form everywhere
     u64 *hist;                        // [hist_cols][FXG_QS_CLASSES][FXG_QS_BINS]
     u32  hist_cols;
 };
@@ -184,6 +187,113 @@ FXG_HD void fxg_stats_accumulate(const FxgStatsArgs &a, const FxgStripRow &o, u3
     }
 }
 
+// ---- the piece form (round 6): dense fixed-length batches of even length 16 .. 160 ----
+// Rows that lie back to back (stride == length) are one byte stream, and a run of R whole reads whose bytes are a multiple of 16 is a run of ALIGNED 16-byte
+// pieces with no byte to mask: lane p of the workgroup takes piece p of every trip.  Because a trip is whole reads, the column of the lane's first byte,
+// o = 16 p mod L, is the same in every trip; the length is even, so o is even, a piece's byte pairs are the histogram's column pairs, and the one place where
+// a piece runs from the end of a read into the next one (column L - 2 -> 0) lies between two pairs.  The LDS position of the lane's eight pairs and their
+// swizzles are loop invariants (8 + 4 registers).  Against the row-strip form on 150-byte rows: no 16-byte load straddles a 16-byte boundary, no lane adds
+// the ten padding bytes of a row's last strip (160 adds per 150 bases), 900 of 960 lanes carry 16 bases each -- rows of 160 bytes, where the row-strip form
+// has all of that by itself, ran 8 % faster than rows of 150 (profiles/r06/stats_by_row_length.txt).
+// R = m * r0 reads = m * p0 pieces per trip, r0 = 16 / gcd(L, 16) the shortest run of whole reads that is whole pieces, m as large as the workgroup allows.
+FXG_HD bool fxg_stats_piece_plan(const FxgStatsArgs &a, u32 *reads, u32 *pieces)
+{
+    const u32 L = a.fixed_len;
+    if (a.len || !a.qual || L != a.stride || L < FXG_QS_STRIP || L > FXG_QS_BLOCK_COLS || a.strip0 != 0u) return false;
+    const u32 low = L & (0u - L), g = low < 16u ? low : 16u;             // gcd(L, 16)
+    const u32 r0 = 16u / g, p0 = r0 * L / 16u;                           // p0 <= 159 (odd lengths: 16 reads are L pieces)
+    // a trip whose bytes are whole 128-byte lines keeps every trip on the line grid by itself: taken when it costs at most 32 lanes against the widest trip
+    // that leaves room for the seven pieces a trip can grow by when its cuts are moved onto the grid (fxg_stats_piece_cut)
+    const u32 m_sh = (FXG_QS_TBLOCK - 7u) / p0;
+    u32 m_nat = FXG_QS_TBLOCK / p0;
+    while (m_nat && (m_nat * p0) % 8u) --m_nat;
+    const u32 m = (m_nat * p0 + 32u >= m_sh * p0) ? m_nat : m_sh;
+    *reads = m * r0; *pieces = m * p0;
+    return true;
+}
+// The cuts between trips sit on the 128-byte line grid: trip T is the bytes [cut(T), cut(T + 1)), cut(T) = T * RL moved DOWN to a line (the first cut is 0, the
+// last one the end of the last whole trip), so that every wave's load of 64 pieces is eight whole lines.  On 150-byte rows (RL = 14 400 = 112.5 lines) the trips
+// are 896 and 904 pieces by turns.  Measured before this was built, the piece form with cuts at T * RL: 2.55 ms where RL is whole lines (rows of 160), 2.65 at half
+// a line (150), 2.74-2.77 at a quarter or an eighth (144, 126, 100, 76, 36) for the same 15 GB (profiles/r06/stats_piece_vs_rows_by_length_first_form.txt).
+// A workgroup's trips are G apart; when G * RL is whole lines (G a multiple of 8: every launch that fills the chip) its distance to the grid, and with it the column
+// of every lane's first byte, is the same in all its trips.  Otherwise (`aligned` false) the cuts stay at T * RL.
+FXG_HD u64 fxg_stats_piece_cut(u64 T, u64 ntrip, u64 RL, bool aligned) { const u64 s = T * RL; return (aligned && T < ntrip) ? (s & ~127ull) : s; }
+// ODD (odd lengths: 51, 75, 101, 151 ...): the column of a lane's first byte can be odd and its parity turns over where a piece runs into the next read, so the
+// LDS block and the counter half (low for even columns, high for odd ones) are kept per BYTE instead of per byte pair: 16 + 16 registers instead of 8.
+template <bool ODD> struct FxgPieceLane { u32 o; u32 pb[ODD ? 16 : 8]; u32 val[ODD ? 16 : 1]; u32 sw4[4]; };   // column of the piece's first byte; byte offset of each pair's (byte's) LDS block; the counter halves; the strip swizzles, one per byte
+template <bool ODD>
+FXG_HD void fxg_stats_piece_lane(u32 L, u32 o, FxgPieceLane<ODD> &c)     // o: column of the piece's first byte (< L; even unless ODD)
+{
+    c.o = o;
+#pragma unroll
+    for (u32 d = 0; d < 4u; ++d) c.sw4[d] = 0u;
+    if constexpr (ODD) {
+#pragma unroll
+        for (u32 i = 0; i < 16u; ++i) {
+            u32 col = c.o + i;
+            if (col >= L) col -= L;
+            c.pb[i] = fxg_stats_pair_base(col >> 4, col & 15u);
+            c.val[i] = (col & 1u) ? 0x10000u : 1u;
+            c.sw4[i >> 2] |= (((col >> 4) * 12u) & 0xFCu) << (8u * (i & 3u));
+        }
+    } else {
+        c.val[0] = 0u;
+#pragma unroll
+        for (u32 jj = 0; jj < 8u; ++jj) {
+            u32 col = c.o + 2u * jj;
+            if (col >= L) col -= L;
+            c.pb[jj] = fxg_stats_pair_base(col >> 4, col & 15u);
+            c.sw4[jj >> 1] |= ((((col >> 4) * 12u) & 0xFCu) * 0x0101u) << (16u * (jj & 1u));
+        }
+    }
+}
+template <bool ODD>
+FXG_HD void fxg_stats_accumulate_piece(const FxgStatsArgs &a, const FxgStripRow &r, const FxgPieceLane<ODD> &c, u32 *lds)
+{
+#ifdef FXG_QS_NOACC
+    FXG_LDS_ADD(lds + (threadIdx.x & 63u), r.vb.x ^ r.vb.y ^ r.vb.z ^ r.vb.w ^ r.vq.x ^ r.vq.y ^ r.vq.z ^ r.vq.w);
+    return;
+#endif
+    const u32 wb[4] = {r.vb.x, r.vb.y, r.vb.z, r.vb.w}, wq[4] = {r.vq.x, r.vq.y, r.vq.z, r.vq.w};
+    u32 bad = 0u, k4[4], o4[4];
+#pragma unroll
+    for (u32 d = 0; d < 4u; ++d) {                                                       // as fxg_stats_accumulate's fast path; nothing to mask
+        const u32 sel = wb[d] & 0x07070707u;
+        bad |= fxg_perm(FXG_QS_EXP_HI, FXG_QS_EXP_LO, sel) ^ (wb[d] & 0xDFDFDFDFu);
+        k4[d] = fxg_perm(FXG_QS_ROW_HI, FXG_QS_ROW_LO, sel);
+        const u32 w4 = wq[d] - FXG_QS_WBASE * 0x01010101u;
+        bad |= w4 & 0xC0C0C0C0u;
+        o4[d] = (w4 << 2) ^ (k4[d] << 4) ^ c.sw4[d];
+    }
+    unsigned char *base = reinterpret_cast<unsigned char *>(lds);
+    if (!bad) {
+#pragma unroll
+        for (u32 jj = 0; jj < 8u; ++jj) {
+            const u32 h = fxg_perm(k4[jj >> 1], o4[jj >> 1], (jj & 1u) ? 0x07030602u : 0x05010400u);
+            if constexpr (ODD) {
+                FXG_LDS_ADD(reinterpret_cast<u32 *>(base + c.pb[2u * jj] + (h & 0xFFFFu)), c.val[2u * jj]);
+                FXG_LDS_ADD(reinterpret_cast<u32 *>(base + c.pb[2u * jj + 1u] + (h >> 16)), c.val[2u * jj + 1u]);
+            } else {
+                unsigned char *pb = base + c.pb[jj];
+                FXG_LDS_ADD(reinterpret_cast<u32 *>(pb + (h & 0xFFFFu)), 1u);
+                FXG_LDS_ADD(reinterpret_cast<u32 *>(pb + (h >> 16)), 0x10000u);
+            }
+        }
+        return;
+    }
+    const u32 L = a.fixed_len;
+#pragma unroll 1
+    for (u32 j = 0; j < FXG_QS_STRIP; ++j) {                                             // odd bytes, rare qualities: one base at a time
+        const u32 b = (wb[j >> 2] >> (8u * (j & 3u))) & 0xFFu, q = (wq[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
+        const u32 col = c.o + j >= L ? c.o + j - L : c.o + j;
+        const u32 k = fxg_stats_class(b);
+        if (k >= FXG_QS_CLASSES || q >= FXG_QS_BINS) continue;
+        const u32 w = q - FXG_QS_WBASE;
+        if (w < FXG_QS_WBINS) FXG_LDS_ADD(reinterpret_cast<u32 *>(base + fxg_stats_byte(col >> 4, col & 15u, k, w)), (col & 1u) ? 0x10000u : 1u);
+        else if (col < a.hist_cols) FXG_GLOBAL_INC64(&a.hist[((u64)col * FXG_QS_CLASSES + k) * FXG_QS_BINS + q]);
+    }
+}
+
 // slice of the reads that workgroup g owns
 FXG_HD void fxg_stats_slice(const FxgStatsArgs &a, u32 g, u64 *lo, u64 *hi)
 {
@@ -255,7 +365,9 @@ FXG_HD void fxg_stats_item(u64 lo, u64 g, u64 *r, u32 *sl) { *r = lo + g / FXG_Q
 // and the kernel takes the same time or longer -- the memory system is the limit, not the slowest workgroup -- so the dispenser went again.
 // The rows of a lane's trip k + D are requested before trip k goes into the histogram (FXG_QS_DEPTH; 1 -> 4: -1.5 %).  Only trips whose every read may
 // be loaded 16 bytes at a time from any column are dealt (all but the batch's last 1..96 reads); workgroup 0 counts the rest through the tested loop.
-__global__ __launch_bounds__(FXG_QS_TBLOCK) void fxg_kernel_quality_stats(const FxgStatsArgs a)
+// ODDK: the kernel for dense batches of ODD length (the piece form with block and counter half per byte: 24 registers more, an allocation of its own)
+template <bool ODDK>
+__device__ __forceinline__ void fxg_quality_stats_body(const FxgStatsArgs &a)
 {
     extern __shared__ __attribute__((aligned(16))) u32 qs_h[];
     const u32 tid = threadIdx.x;
@@ -307,50 +419,75 @@ __global__ __launch_bounds__(FXG_QS_TBLOCK) void fxg_kernel_quality_stats(const 
         tested(lo, hi);
     } else {
         const u32 G = gridDim.x;
-        const u64 ntrip = a.n ? (a.n - 1) / reads_per_step : 0u;                   // trips whose every read lies below n - 1
-        if (blockIdx.x == 0u) tested(ntrip * reads_per_step, a.n);
-        // round_robin 1: this workgroup's trips are blockIdx.x + k G; 2 (measurement knob): a contiguous run of trips per workgroup through the same loop
+        // round_robin 1: this workgroup's trips are blockIdx.x + k G -- in the piece form where the batch allows it; 3: the row-strip form everywhere;
+        // 2 (measurement knob): a contiguous run of trips per workgroup through the same loop, row-strip form
+        u32 R = reads_per_step, P = 0u;
+        const bool piece = a.round_robin == 1u && fxg_stats_piece_plan(a, &R, &P) && ((a.fixed_len & 1u) != 0u) == ODDK;      // (the host launches the kernel that matches the length)
+        const u64 ntrip = piece ? a.n / R : (a.n ? (a.n - 1) / R : 0u);            // row-strip form: trips whose every read lies below n - 1 (16-byte loads from any column)
+        if (blockIdx.x == 0u) tested(ntrip * R, a.n);
         const bool rr = a.round_robin != 2u;
         const u64 per = (ntrip + G - 1) / G, first = rr ? (u64)blockIdx.x : (u64)blockIdx.x * per;
         if (first < ntrip) {
             constexpr u32 D = FXG_QS_DEPTH;                                        // trips a lane's loads run ahead of its adds
             const u64 cnt = rr ? (ntrip - first + G - 1) / G : (first + per <= ntrip ? per : ntrip - first);
-            const u64 tb = (u64)(rr ? G : 1u) * reads_per_step * a.stride;
-            u64 at = (first * reads_per_step + rl) * a.stride + (nb ? c0 : 0u);   // (a lane whose strip lies past the reads' end loads its row's first bytes, adds nothing)
+            const u64 RL = (u64)R * a.stride, tb = (u64)(rr ? G : 1u) * RL;
+            // piece form: this workgroup's distance to the line grid before and behind each of its trips (fxg_stats_piece_cut), pieces of a trip, pieces of the
+            // batch's last trip (which ends where the whole trips end, not on the grid)
+            const bool grid = piece && tb % 128u == 0u;
+            const u32 d0 = grid ? (u32)((blockIdx.x * RL) & 127u) : 0u, d1 = grid ? (u32)(((blockIdx.x + 1ull) * RL) & 127u) : 0u;
+            const u32 Pn = (u32)((RL + d0 - d1) >> 4), Pl = (u32)((RL + d0) >> 4);
+            const bool owns_last = piece && (ntrip - 1u) % G == blockIdx.x;
+            const u32 Rup = piece ? R + 8u : R;                                   // reads a trip can add to one column (a trip moved onto the grid holds up to 112 bytes more)
+            // the lane's first 16 bytes (a row-strip lane whose strip lies past the reads' end loads its row's first bytes, a piece lane past the trip's last piece
+            // loads the trip's first one: neither adds anything)
+            u64 at = piece ? first * RL - d0 + (tid < Pl ? 16u * tid : 0u) : (first * R + rl) * a.stride + (nb ? c0 : 0u);
             FxgStripRow buf[D + 1];
 #pragma unroll
             for (u32 u = 0; u <= D; ++u) { buf[u].vb = (u32x4){0u, 0u, 0u, 0u}; buf[u].vq = buf[u].vb; buf[u].nb = nb; }
-            auto step = [&](const FxgStripRow &row) {
-                if (since + reads_per_step > 65535u) {
-                    __syncthreads();
-                    fxg_stats_flush(qs_h, part, tid, FXG_QS_TBLOCK, nflush++ == 0u);
-                    __syncthreads();
-                    since = 0;
-                }
-                fxg_stats_accumulate(a, row, sl, c0, mfix, qs_h);
-                since += reads_per_step;
-            };
-            u64 k0 = 0;
-            if (cnt >= 2u * D + 1u) {
-#pragma unroll
-                for (u32 u = 0; u < D; ++u) { buf[u].vb = FXG_QS_LD(a.bases + at + u * tb); buf[u].vq = FXG_QS_LD(a.qual + at + u * tb); }
-                for (; k0 + 2u * D + 1u <= cnt; k0 += D + 1u) {                    // a group of D + 1 trips whose D successors exist: no load is tested
-#pragma unroll
-                    for (u32 u = 0; u <= D; ++u) {
-                        FxgStripRow &in = buf[(u + D) % (D + 1u)];
-                        in.vb = FXG_QS_LD(a.bases + at + (u64)D * tb); in.vq = FXG_QS_LD(a.qual + at + (u64)D * tb);
-                        step(buf[u]);
-                        at += tb;
+            auto run = [&](const u64 trips, auto &&acc) {
+                auto step = [&](const FxgStripRow &row) {
+                    if (since + Rup > 65535u) {
+                        __syncthreads();
+                        fxg_stats_flush(qs_h, part, tid, FXG_QS_TBLOCK, nflush++ == 0u);
+                        __syncthreads();
+                        since = 0;
                     }
-                }
+                    acc(row);
+                    since += Rup;
+                };
+                u64 k0 = 0;
+                if (trips >= 2u * D + 1u) {
 #pragma unroll
-                for (u32 u = 0; u < D; ++u) { step(buf[u]); at += tb; }          // the D trips whose rows are already on their way
-                k0 += D;
-            }
-            for (; k0 < cnt; ++k0, at += tb) {                                     // at most D + 1 more, one at a time
-                buf[0].vb = FXG_QS_LD(a.bases + at); buf[0].vq = FXG_QS_LD(a.qual + at);
-                step(buf[0]);
-            }
+                    for (u32 u = 0; u < D; ++u) { buf[u].vb = FXG_QS_LD(a.bases + at + u * tb); buf[u].vq = FXG_QS_LD(a.qual + at + u * tb); }
+                    for (; k0 + 2u * D + 1u <= trips; k0 += D + 1u) {                  // a group of D + 1 trips whose D successors exist: no load is tested
+#pragma unroll
+                        for (u32 u = 0; u <= D; ++u) {
+                            FxgStripRow &in = buf[(u + D) % (D + 1u)];
+                            in.vb = FXG_QS_LD(a.bases + at + (u64)D * tb); in.vq = FXG_QS_LD(a.qual + at + (u64)D * tb);
+                            step(buf[u]);
+                            at += tb;
+                        }
+                    }
+#pragma unroll
+                    for (u32 u = 0; u < D; ++u) { step(buf[u]); at += tb; }          // the D trips whose rows are already on their way
+                    k0 += D;
+                }
+                for (; k0 < trips; ++k0, at += tb) {                                   // at most D + 1 more, one at a time
+                    buf[0].vb = FXG_QS_LD(a.bases + at); buf[0].vq = FXG_QS_LD(a.qual + at);
+                    step(buf[0]);
+                }
+            };
+            if (piece) {
+                const u32 o = tid < Pl ? (16u * tid + 8u * a.fixed_len - d0) % a.fixed_len : 0u;      // column of the lane's first byte (8 L >= 128 > d0)
+                const bool mine = tid < Pn, mine_last = tid < Pl;
+                auto pieces = [&](auto &pc) {
+                    fxg_stats_piece_lane(a.fixed_len, o, pc);
+                    run(cnt - (owns_last ? 1u : 0u), [&](const FxgStripRow &row) { if (mine) fxg_stats_accumulate_piece(a, row, pc, qs_h); });
+                    if (owns_last) run(1u, [&](const FxgStripRow &row) { if (mine_last) fxg_stats_accumulate_piece(a, row, pc, qs_h); });
+                };
+                FxgPieceLane<ODDK> pc;
+                pieces(pc);
+            } else if constexpr (!ODDK) run(cnt, [&](const FxgStripRow &row) { fxg_stats_accumulate(a, row, sl, c0, mfix, qs_h); });
         }
     }
     __syncthreads();
@@ -365,6 +502,9 @@ __global__ __launch_bounds__(FXG_QS_TBLOCK) void fxg_kernel_quality_stats(const 
     }
 #endif
 }
+
+__global__ __launch_bounds__(FXG_QS_TBLOCK) void fxg_kernel_quality_stats(const FxgStatsArgs a) { fxg_quality_stats_body<false>(a); }
+__global__ __launch_bounds__(FXG_QS_TBLOCK) void fxg_kernel_quality_stats_odd(const FxgStatsArgs a) { fxg_quality_stats_body<true>(a); }
 
 // 64 counters per workgroup; four groups of lanes sum a quarter of the workgroups' partials each, eight loads in flight per lane (one thread per counter walking
 // all 256 partials took 95 us per pass, 3 % on top of the kernel itself: profiles/r06_stats_kernel_stats.md)

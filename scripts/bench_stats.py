@@ -5,7 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from fastx_toolkit_amd import Engine
 eng = Engine(0)
-n, L = int(os.environ.get("READS", "50000000")), 150
+L = int(os.environ.get("LEN", "150"))
+n = int(os.environ.get("READS", str(50000000 * 150 // L)))
 b, q = eng.synth(2, 0, n, L, False)
 eng.set_profiling(True)
 ms = []

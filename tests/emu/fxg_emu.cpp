@@ -345,6 +345,9 @@ extern "C" unsigned fxg_emu_tile_reads(unsigned stride, int clip) { return fxg_p
 extern "C" int fxg_emu_gl_last_dword(uint64_t total, uint64_t off) { return fxg_gl_last_dword(total, off); }
 
 // fastx_quality_stats: the per-thread bodies of fxg_kernel_quality_stats / _fold, one "workgroup" after the other
+static uint64_t g_qs_piece_trips = 0, g_qs_piece_moved = 0;      // trips the piece form has run since the library was loaded (the tests ask whether the form under test ran)
+extern "C" uint64_t fxg_emu_quality_stats_piece_trips(void) { return g_qs_piece_trips; }
+extern "C" uint64_t fxg_emu_quality_stats_piece_moved(void) { return g_qs_piece_moved; }      // ... whose first cut was moved onto the line grid
 extern "C" int fxg_emu_run_quality_stats(const fxg_batch *in, uint64_t *hist, uint32_t hist_cols)
 {
     if (!in || !hist || !in->bases || in->stride == 0 || hist_cols < in->stride) return FXG_E_INVALID;
@@ -360,33 +363,62 @@ extern "C" int fxg_emu_run_quality_stats(const fxg_batch *in, uint64_t *hist, ui
     for (u32 s0 = 0; s0 < nstrips; s0 += FXG_QS_WAVES) {
         a.strip0 = s0;
         std::fill(partial.begin(), partial.end(), 0xDEADBEEFu);     // the kernel does not clear its partial: a workgroup's first flush stores every counter
+        // the piece form (dense even-length batches of 16 .. 160 bytes): workgroup g takes trips g, g + nwg, ... as the kernel's round-robin loop does, one piece per
+        // "lane"; the reads behind the last whole trip go through workgroup 0's row-strip loop.  FXG_EMU_QS_ROWS=1 keeps the row-strip form (the kernel's round_robin 3).
+        u32 pR = 0, pP = 0;
+        a.round_robin = 1u;
+        const bool piece = a.n && !getenv("FXG_EMU_QS_ROWS") && fxg_stats_piece_plan(a, &pR, &pP);
+        const u64 ntrip = piece ? a.n / pR : 0u;
+        if (piece && ntrip >= 8u && !getenv("FXG_EMU_QS_NOGRID")) a.nwg = 8u;      // (a multiple of eight workgroups: the cuts between trips go onto the line grid)
+        if (partial.size() < (size_t)a.nwg * FXG_QS_PART_WORDS) { partial.resize((size_t)a.nwg * FXG_QS_PART_WORDS); a.partial = partial.data(); std::fill(partial.begin(), partial.end(), 0xDEADBEEFu); }
+        const u32 wrap = getenv("FXG_EMU_QS_FLUSH") ? 600u : 65535u;      // the env knob exercises the wrap guard on small inputs
         for (u32 g = 0; g < a.nwg; ++g) {
             std::fill(lds.begin(), lds.end(), 0u);
             u32 *part = a.partial + (u64)g * FXG_QS_PART_WORDS;
-            u64 lo, hi;
-            fxg_stats_slice(a, g, &lo, &hi);
-            const u64 nitems = (hi - lo) * FXG_QS_WAVES;
             u32 since = 0, nflush = 0;
-            for (u64 g0 = 0; g0 < nitems; g0 += (u64)FXG_QS_TBLOCK * FXG_QS_UNROLL) {
-                if (since + trip_reads > (getenv("FXG_EMU_QS_FLUSH") ? 600u : 65535u)) {      // the env knob exercises the wrap guard on small inputs
-                    for (u32 t = 0; t < FXG_QS_TBLOCK; ++t) fxg_stats_flush(lds.data(), part, t, FXG_QS_TBLOCK, nflush == 0u);
-                    since = 0; ++nflush;
+            auto flush = [&]() { for (u32 t = 0; t < FXG_QS_TBLOCK; ++t) fxg_stats_flush(lds.data(), part, t, FXG_QS_TBLOCK, nflush == 0u); since = 0; ++nflush; };
+            auto rows = [&](u64 lo, u64 hi) {
+                const u64 nitems = (hi - lo) * FXG_QS_WAVES;
+                for (u64 g0 = 0; g0 < nitems; g0 += (u64)FXG_QS_TBLOCK * FXG_QS_UNROLL) {
+                    if (since + trip_reads > wrap) flush();
+                    for (u32 t = 0; t < FXG_QS_TBLOCK; ++t)
+                        for (u32 u = 0; u < FXG_QS_UNROLL; ++u) {
+                            const u64 it = g0 + (u64)u * FXG_QS_TBLOCK + t;
+                            if (it >= nitems) continue;
+                            u64 r; u32 sl;
+                            FxgStripRow row;
+                            fxg_stats_item(lo, it, &r, &sl);
+                            fxg_stats_load(a, r, s0 + sl, row);
+                            u32 m[4];
+                            fxg_stats_masks(row.nb, m);
+                            fxg_stats_accumulate(a, row, sl, (s0 + sl) * FXG_QS_STRIP, m, lds.data());
+                        }
+                    since += trip_reads;
                 }
-                for (u32 t = 0; t < FXG_QS_TBLOCK; ++t)
-                    for (u32 u = 0; u < FXG_QS_UNROLL; ++u) {
-                        const u64 it = g0 + (u64)u * FXG_QS_TBLOCK + t;
-                        if (it >= nitems) continue;
-                        u64 r; u32 sl;
+            };
+            if (piece) {
+                if (g == 0) rows(ntrip * pR, a.n);
+                const u64 RL = (u64)pR * a.stride;
+                const bool grid = ((u64)a.nwg * RL) % 128u == 0u;                // as the kernel: the workgroups' trips keep their distance to the line grid
+                for (u64 T = g; T < ntrip; T += a.nwg) {
+                    if (since + pR + 8u > wrap) flush();
+                    const u64 c0 = fxg_stats_piece_cut(T, ntrip, RL, grid), c1 = fxg_stats_piece_cut(T + 1, ntrip, RL, grid);
+                    if ((c1 - c0) / 16u > FXG_QS_TBLOCK) return FXG_E_DEVICE;    // more pieces than the workgroup has lanes
+                    for (u64 at = c0; at < c1; at += 16u) {
                         FxgStripRow row;
-                        fxg_stats_item(lo, it, &r, &sl);
-                        fxg_stats_load(a, r, s0 + sl, row);
-                        u32 m[4];
-                        fxg_stats_masks(row.nb, m);
-                        fxg_stats_accumulate(a, row, sl, (s0 + sl) * FXG_QS_STRIP, m, lds.data());
+                        row.nb = FXG_QS_STRIP; row.vb = fxg_ld16(a.bases + at); row.vq = fxg_ld16(a.qual + at);
+                        if (a.fixed_len & 1u) { FxgPieceLane<true> pc; fxg_stats_piece_lane(a.fixed_len, (u32)(at % a.fixed_len), pc); fxg_stats_accumulate_piece(a, row, pc, lds.data()); }
+                        else { FxgPieceLane<false> pc; fxg_stats_piece_lane(a.fixed_len, (u32)(at % a.fixed_len), pc); fxg_stats_accumulate_piece(a, row, pc, lds.data()); }
                     }
-                since += trip_reads;
+                    since += pR + 8u; ++g_qs_piece_trips;
+                    if (grid && (c0 & 127u) == 0u && c0 != T * RL) ++g_qs_piece_moved;
+                }
+            } else {
+                u64 lo, hi;
+                fxg_stats_slice(a, g, &lo, &hi);
+                rows(lo, hi);
             }
-            for (u32 t = 0; t < FXG_QS_TBLOCK; ++t) fxg_stats_flush(lds.data(), part, t, FXG_QS_TBLOCK, nflush == 0u);
+            flush();
         }
         for (u32 e = 0; e < FXG_QS_PART_WORDS; ++e) fxg_stats_fold(a, e);
     }

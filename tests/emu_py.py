@@ -92,6 +92,8 @@ def lib():
         _LIB.fxg_emu_hist_new.restype = C.c_void_p
         _LIB.fxg_emu_hist_free.argtypes = [C.c_void_p]
         _LIB.fxg_emu_run_quality_stats.argtypes = [C.POINTER(Batch), C.c_void_p, C.c_uint32]
+        _LIB.fxg_emu_quality_stats_piece_trips.restype = C.c_uint64
+        _LIB.fxg_emu_quality_stats_piece_moved.restype = C.c_uint64
     return _LIB
 
 

@@ -202,6 +202,40 @@ def test_emulated_quality_stats_histogram():
         qs.close()
 
 
+def test_emulated_quality_stats_piece_form(monkeypatch):
+    """The statistics kernel's piece form (dense rows of length 16 .. 160: lane p takes the p-th aligned 16-byte piece of every trip of whole reads): every
+    eligible length class (gcd(L, 16) = 1, 2, 4, 8, 16; odd lengths keep block and counter half per byte), reads behind the last whole trip, lower-case and foreign letters, qualities outside the LDS window, the
+    wrap guard of the 16-bit counters -- against the oracle, and equal to the row-strip form on the same batch."""
+    from helpers import random_batch
+    rng = np.random.default_rng(17)
+    for trial, L in enumerate([16, 18, 20, 24, 36, 50, 76, 100, 126, 144, 150, 158, 160, 150, 100, 36, 17, 51, 75, 101, 151, 159, 33, 151]):
+        n = int(rng.integers(1, 4000)) if trial % 3 else int(rng.integers(900, 1100))
+        b, q, _ = random_batch(rng, n, L, L, L, True)
+        if trial % 2:
+            hit = rng.random(b.shape) < 0.01
+            b[hit] = rng.choice(np.frombuffer(b"acgtn@XR.", dtype=np.uint8), size=int(hit.sum()))
+            hit = rng.random(q.shape) < 0.01
+            q[hit] = rng.integers(18, 126, size=int(hit.sum()), dtype=np.uint8)
+        if trial in (13, 14, 15, 22, 23):
+            monkeypatch.setenv("FXG_EMU_QS_FLUSH", "1")
+        if trial % 4 == 3:
+            monkeypatch.setenv("FXG_EMU_QS_NOGRID", "1")           # a launch whose workgroups are not a multiple of eight: cuts at whole trips
+        cols = L + int(rng.integers(0, 5))
+        h = emu.run_quality_stats(b, q, None, hist=None, cols=cols)
+        monkeypatch.setenv("FXG_EMU_QS_ROWS", "1")
+        h_rows = emu.run_quality_stats(b, q, None, hist=None, cols=cols)
+        monkeypatch.delenv("FXG_EMU_QS_ROWS")
+        monkeypatch.delenv("FXG_EMU_QS_FLUSH", raising=False)
+        monkeypatch.delenv("FXG_EMU_QS_NOGRID", raising=False)
+        qs = fo.QStats()
+        qs.add(b, q, None, qoffset=33)
+        assert np.array_equal(h, qs.device_layout(cols, 33)), (trial, L, n)
+        assert np.array_equal(h, h_rows), (trial, L, n)
+        qs.close()
+    assert emu.lib().fxg_emu_quality_stats_piece_trips() > 0           # the form under test did run,
+    assert emu.lib().fxg_emu_quality_stats_piece_moved() > 0           # with cuts between trips that were moved onto the 128-byte grid
+
+
 def test_emulated_long_reads():
     """Reads up to the reference reader's line limit (24 999): tiles of a few reads, 157 column blocks in the statistics kernel."""
     from helpers import random_batch

@@ -4,6 +4,8 @@ Bit-exact on every array (integer/byte work; the clipper's fp32 DP only feeds in
 is bit-exact too).  Sizes: oracle-sized seeded inputs + fuzz here, BASELINE.json's full sizes through
 size-independent properties (prefix/suffix windows vs the oracle, offset algebra, determinism).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -617,7 +619,8 @@ def test_quality_stats_vs_oracle_and_full_size(engine):
     # the sizes between: chunks of 1 .. 32 trips dealt out by the ticket counter, a last chunk that is not full, batches whose last reads take the tested
     # loop, qualities outside the LDS window -- every column against torch.bincount
     g = torch.Generator(device=engine.device).manual_seed(11)
-    for n, L, wild in ((96 * 7 + 1, 150, False), (1_000_003, 150, False), (7_000_001, 100, True), (20_000_000, 36, False), (3_300_000, 160, False)):
+    for n, L, wild in ((96 * 7 + 1, 150, False), (1_000_003, 150, False), (7_000_001, 100, True), (20_000_000, 36, False), (3_300_000, 160, False), (2_000_001, 18, True), (1_500_000, 126, True), (3_000_000, 75, False), (2_000_001, 151, True), (3_000_000, 51, False), (1_000_000, 101, True),
+                       (600_000, 170, False)):
         b, q = engine.synth(2, 0, n, L, False)
         if wild:
             hit = torch.rand(q.shape, device=engine.device, generator=g) < 0.01
@@ -627,6 +630,13 @@ def test_quality_stats_vs_oracle_and_full_size(engine):
         for col in range(L):
             key = cls[b[:, col].long()] * 128 + q[:, col].long()
             assert torch.equal(h[col], torch.bincount(key, minlength=5 * 128).view(5, 128)), (n, L, col)
+        # dense rows of length 16 .. 160 run in the piece form (csrc/fxg_stats.h; odd lengths in a kernel of their own); the row-strip form of the same loop gives the same histogram
+        os.environ["FXG_QS_ROUND_ROBIN"] = "3"
+        try:
+            h_rows = engine.quality_stats(b, q, fixed_len=L)
+        finally:
+            del os.environ["FXG_QS_ROUND_ROBIN"]
+        assert torch.equal(h, h_rows), (n, L)
 
 
 def test_long_reads(engine):
