@@ -28,6 +28,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define FXG_TBLOCK 256          // threads per workgroup of the tile kernels
 #endif
 #define FXG_TWAVES (FXG_TBLOCK / 64)
+#ifndef FXG_STORE_GRID
+#define FXG_STORE_GRID 1            // fxg_rows_flush deals its 16-byte units to lanes by the unit's place in its 128-byte line (0: by the unit's place in the tile's output; the A/B arm).
+                                    // The tile kernels' gather was measured the same way and lost 1.6-3 % (cfg4, cfg3, cfg5: profiles/r06/store_grid_other.txt): it keeps chunk ci on lane ci.
+#endif
 #ifndef FXG_CLIP_GATHER_K
 #define FXG_CLIP_GATHER_K 4     // chunks per lane in flight in the clip instances' gather (FXG_GATHER_K for the streaming instances)
 #endif
