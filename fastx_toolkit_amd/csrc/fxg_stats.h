@@ -348,14 +348,25 @@ FXG_HD void fxg_stats_fold(const FxgStatsArgs &a, u32 e)
 FXG_HD void fxg_stats_item(u64 lo, u64 g, u64 *r, u32 *sl) { *r = lo + g / FXG_QS_WAVES; *sl = (u32)(g % FXG_QS_WAVES); }
 
 #ifndef FXG_HOST_EMULATION
-// The loop's row loads keep the DEFAULT cache policy.  With the non-temporal policy the kernel is 1.0-1.7 % faster (2.667 against 2.713 ms, mean of eight
-// alternating runs, profiles/r06/stats_nt_loads.txt; 2.724 against 2.751, stats_variants_one_call.txt) but fetches 7 % more: the 16-byte pieces of 150-byte
+// Cache policy of the loop's row loads.  ROW-STRIP form: the DEFAULT policy.  With the non-temporal policy it is 1.0-1.7 % faster (2.667 against 2.713 ms, mean of
+// eight alternating runs, profiles/r06/stats_nt_loads.txt; 2.724 against 2.751, stats_variants_one_call.txt) but fetches 7 % more: the 16-byte pieces of 150-byte
 // rows share their first and last 128-byte lines with the neighbouring wave's, and a line marked non-temporal is gone before the neighbour asks (FETCH_SIZE
 // 1.05 -> 1.12 x the rows, profiles/r06_pmc_stats).  Bytes over the fabric are the scarcer thing; -DFXG_QS_NTL builds the other arm.
+// PIECE form: NON-TEMPORAL.  Its waves load whole lines that no other wave touches, so the policy costs no byte (FETCH_SIZE 1.024 x the rows either way) and the
+// kernel takes 2.42-2.44 instead of 2.52-2.54 ms, four alternating runs (profiles/r06/stats_piece_nt_depth.txt, stats_piece_nt_traffic.txt; loads 2 or 4 trips
+// ahead instead of 3: no difference, same file); -DFXG_QS_PIECE_DEFAULT_LOADS builds the other arm.
+struct FxgLdDefault {};
+struct FxgLdStream {};
+__device__ __forceinline__ u32x4 fxg_qs_ld(const uint8_t *p, FxgLdStream) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned *>(p)); }
 #ifdef FXG_QS_NTL
-#define FXG_QS_LD(p) __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned *>(p))
+__device__ __forceinline__ u32x4 fxg_qs_ld(const uint8_t *p, FxgLdDefault) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned *>(p)); }
 #else
-#define FXG_QS_LD(p) fxg_ld16(p)
+__device__ __forceinline__ u32x4 fxg_qs_ld(const uint8_t *p, FxgLdDefault) { return fxg_ld16(p); }
+#endif
+#ifdef FXG_QS_PIECE_DEFAULT_LOADS
+typedef FxgLdDefault FxgLdPiece;
+#else
+typedef FxgLdStream FxgLdPiece;
 #endif
 // Fixed-length batches with qualities: trip T of the launch is reads [96 T, 96 T + 96) and belongs to workgroup T mod G, so that at any moment the whole chip
 // reads ONE narrow window of each array (256 x 14 KB) -- the order the memory system serves best: a read-only stream of 15 GB takes 2.33 ms that way
@@ -444,7 +455,7 @@ __device__ __forceinline__ void fxg_quality_stats_body(const FxgStatsArgs &a)
             FxgStripRow buf[D + 1];
 #pragma unroll
             for (u32 u = 0; u <= D; ++u) { buf[u].vb = (u32x4){0u, 0u, 0u, 0u}; buf[u].vq = buf[u].vb; buf[u].nb = nb; }
-            auto run = [&](const u64 trips, auto &&acc) {
+            auto run = [&](const u64 trips, auto &&acc, auto pol) {
                 auto step = [&](const FxgStripRow &row) {
                     if (since + Rup > 65535u) {
                         __syncthreads();
@@ -458,12 +469,12 @@ __device__ __forceinline__ void fxg_quality_stats_body(const FxgStatsArgs &a)
                 u64 k0 = 0;
                 if (trips >= 2u * D + 1u) {
 #pragma unroll
-                    for (u32 u = 0; u < D; ++u) { buf[u].vb = FXG_QS_LD(a.bases + at + u * tb); buf[u].vq = FXG_QS_LD(a.qual + at + u * tb); }
+                    for (u32 u = 0; u < D; ++u) { buf[u].vb = fxg_qs_ld(a.bases + at + u * tb, pol); buf[u].vq = fxg_qs_ld(a.qual + at + u * tb, pol); }
                     for (; k0 + 2u * D + 1u <= trips; k0 += D + 1u) {                  // a group of D + 1 trips whose D successors exist: no load is tested
 #pragma unroll
                         for (u32 u = 0; u <= D; ++u) {
                             FxgStripRow &in = buf[(u + D) % (D + 1u)];
-                            in.vb = FXG_QS_LD(a.bases + at + (u64)D * tb); in.vq = FXG_QS_LD(a.qual + at + (u64)D * tb);
+                            in.vb = fxg_qs_ld(a.bases + at + (u64)D * tb, pol); in.vq = fxg_qs_ld(a.qual + at + (u64)D * tb, pol);
                             step(buf[u]);
                             at += tb;
                         }
@@ -473,7 +484,7 @@ __device__ __forceinline__ void fxg_quality_stats_body(const FxgStatsArgs &a)
                     k0 += D;
                 }
                 for (; k0 < trips; ++k0, at += tb) {                                   // at most D + 1 more, one at a time
-                    buf[0].vb = FXG_QS_LD(a.bases + at); buf[0].vq = FXG_QS_LD(a.qual + at);
+                    buf[0].vb = fxg_qs_ld(a.bases + at, pol); buf[0].vq = fxg_qs_ld(a.qual + at, pol);
                     step(buf[0]);
                 }
             };
@@ -482,12 +493,12 @@ __device__ __forceinline__ void fxg_quality_stats_body(const FxgStatsArgs &a)
                 const bool mine = tid < Pn, mine_last = tid < Pl;
                 auto pieces = [&](auto &pc) {
                     fxg_stats_piece_lane(a.fixed_len, o, pc);
-                    run(cnt - (owns_last ? 1u : 0u), [&](const FxgStripRow &row) { if (mine) fxg_stats_accumulate_piece(a, row, pc, qs_h); });
-                    if (owns_last) run(1u, [&](const FxgStripRow &row) { if (mine_last) fxg_stats_accumulate_piece(a, row, pc, qs_h); });
+                    run(cnt - (owns_last ? 1u : 0u), [&](const FxgStripRow &row) { if (mine) fxg_stats_accumulate_piece(a, row, pc, qs_h); }, FxgLdPiece{});
+                    if (owns_last) run(1u, [&](const FxgStripRow &row) { if (mine_last) fxg_stats_accumulate_piece(a, row, pc, qs_h); }, FxgLdPiece{});
                 };
                 FxgPieceLane<ODDK> pc;
                 pieces(pc);
-            } else if constexpr (!ODDK) run(cnt, [&](const FxgStripRow &row) { fxg_stats_accumulate(a, row, sl, c0, mfix, qs_h); });
+            } else if constexpr (!ODDK) run(cnt, [&](const FxgStripRow &row) { fxg_stats_accumulate(a, row, sl, c0, mfix, qs_h); }, FxgLdDefault{});
         }
     }
     __syncthreads();
