@@ -1,0 +1,6 @@
+#!/bin/bash
+# round 6, closing call at the statistics kernel's piece form and the rows kernel's line-grid write-out: the evidence of r06_final.sh at HEAD, then the whole GPU tier and smoke()
+bash scripts/gpu/r06_final.sh
+O=gpurun_out/r06aw; mkdir -p $O
+timeout 3000 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -n 3 $O/pytest_gpu.txt | cut -c1-300
+timeout 900 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > $O/smoke.txt 2>&1; tail -n 1 $O/smoke.txt | cut -c1-300
