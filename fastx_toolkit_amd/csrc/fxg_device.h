@@ -610,6 +610,28 @@ FXG_HD u32 fxg_rank_of(const u32 *k_off, const uint16_t *k_tab, u32 nk, u32 S, u
     return lo;
 }
 
+// v_perm_b32: byte i of the result is byte sel[i] of the 8-byte value {hi:lo} (selectors 0..3 -> lo, 4..7 -> hi)
+FXG_HD u32 fxg_perm(u32 hi, u32 lo, u32 sel)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    const u64 v = ((u64)hi << 32) | lo;
+    u32 r = 0;
+    for (int i = 0; i < 4; ++i) r |= (u32)((v >> (8u * ((sel >> (8 * i)) & 7u))) & 0xFFu) << (8 * i);
+    return r;
+#endif
+}
+
+// v_alignbyte_b32: the 4 bytes of {hi:lo} that start at byte sh (0..3)
+FXG_HD u32 fxg_alignbyte(u32 hi, u32 lo, u32 sh)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(hi, lo, sh);
+#else
+    return (u32)(((((u64)hi) << 32) | lo) >> (8u * (sh & 3u)));
+#endif
+}
 // x in [0, 4]: low x bytes set
 FXG_HD u32 fxg_lowbytes32(int x) { return x >= 4 ? 0xFFFFFFFFu : ((1u << (8 * x)) - 1u); }
 // e in [0, 16]: low e bytes of a 16-byte value set

@@ -1444,15 +1444,34 @@ FXG_HD u32 fxg_decide_mask(const FxgKArgs &a, const u32 *bm_l, u32 r0, u32 tid, 
 // base census of one read from its LDS row, shared by
 //   fastx_artifacts_filter (fastx_artifacts_filter.c:56-112): drop when one of A/C/G/T fills all but <= 3 positions
 //   fastq_to_fasta N-discard (fastq_to_fasta.c:79-82)        : drop when the read contains an N (unless -n)
-FXG_HD u32 fxg_decide_census(const FxgKArgs &a, const uint8_t *row, u32 r0, u32 tid, u32 *keep_out, u32 *len_out, u32 *bad)
+// Four bases per step (round 6; one byte per step before: 150 ds_read_u8 and ~1 650 VALU instructions per read): the row is read as ALIGNED dwords and
+// realigned with a funnel shift (rows of 150 bytes start on 2-byte boundaries; a misaligned ds_read_b32 takes the slow path), the low three bits of a letter
+// (A 1, C 3, T 4, N 6, G 7) select its one-hot flag and the byte it has to be from two 8-entry tables (v_perm_b32), a population count per letter adds the flags.
+// Upper case only, as the reference's tools have it here (fastx_artifacts_filter.c:70-95: anything else is "invalid nucleotide value").
+#define FXG_CENSUS_EXP_LO 0x43FF41FFu      // expected byte by low three bits: -- A -- C | T -- N G   (FF: no byte with those bits is valid)
+#define FXG_CENSUS_EXP_HI 0x474EFF54u
+#define FXG_CENSUS_OH_LO  0x02000100u      // one-hot flag:                   A 01, C 02, G 04, T 08, N 10
+#define FXG_CENSUS_OH_HI  0x04100008u
+// sb: the staged tile (16-byte aligned), off: where this thread's row starts in it
+FXG_HD u32 fxg_decide_census(const FxgKArgs &a, const uint8_t *sb, u32 off, u32 r0, u32 tid, u32 *keep_out, u32 *len_out, u32 *bad)
 {
     const u32 rl = a.len ? (u32)a.len[r0 + tid] : a.fixed_len;
-    u32 ca = 0, cc = 0, cg = 0, ct = 0, cn = 0;
-    for (u32 k = 0; k < rl; ++k) {
-        const u32 b = row[k];
-        ca += (b == 'A'); cc += (b == 'C'); cg += (b == 'G'); ct += (b == 'T'); cn += (b == 'N');
+    u32 ca = 0, cc = 0, cg = 0, ct = 0, cn = 0, invalid = 0;
+    const u32 sh = off & 3u;
+    const u32 *p = reinterpret_cast<const u32 *>(sb) + (off >> 2);      // (the staged tile ends 16 bytes before its region does: fxg_lds_layout)
+    u32 lo = rl ? p[0] : 0u;
+    for (u32 k = 0; k < rl; k += 4u) {                           // (four dwords requested ahead of their use: +4 %, profiles/r06/census_swar_vs_bytes.txt)
+        const u32 hi = p[(k >> 2) + 1u];
+        const u32 w = fxg_alignbyte(hi, lo, sh);                 // bytes [k, k + 4) of the read
+        lo = hi;
+        const u32 m = fxg_lowbytes32((int)(rl - k < 4u ? rl - k : 4u));
+        const u32 sel = w & 0x07070707u;
+        invalid |= (fxg_perm(FXG_CENSUS_EXP_HI, FXG_CENSUS_EXP_LO, sel) ^ w) & m;
+        const u32 oh = fxg_perm(FXG_CENSUS_OH_HI, FXG_CENSUS_OH_LO, sel) & m;
+        ca += (u32)__builtin_popcount(oh & 0x01010101u); cc += (u32)__builtin_popcount(oh & 0x02020202u); cg += (u32)__builtin_popcount(oh & 0x04040404u);
+        ct += (u32)__builtin_popcount(oh & 0x08080808u); cn += (u32)__builtin_popcount(oh & 0x10101010u);
     }
-    if (ca + cc + cg + ct + cn != rl) *bad = 1u;          // "invalid nucleotide value" in the reference
+    if (invalid) *bad = 1u;                               // "invalid nucleotide value" in the reference
     u32 keep = 1u, why = FXG_R_KEPT;
     if (a.stages & FXG_STAGE_ARTIFACTS) {
         const int lim = (int)rl - 3;
@@ -1623,7 +1642,7 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
                     word = fxg_decide_a<AMAX, GL>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen, nullptr, 0u, PTAB ? smem + L.off_ptab : nullptr);
                 } else if constexpr (MODE == 0) word = fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen);
                 else if constexpr (MODE == 3) { u32 nl; word = fxg_decide_mask(a, bm_l, r0, tid, &keep, &olen, &nl); m_nt += nl; m_reads += (nl != 0u); }
-                else if constexpr (MODE == 4) word = fxg_decide_census(a, sb + tid * stride, r0, tid, &keep, &olen, &art_bad);
+                else if constexpr (MODE == 4) word = fxg_decide_census(a, sb, tid * stride, r0, tid, &keep, &olen, &art_bad);
                 else word = fxg_decide_b<REV>(a, r0, tid, &keep, &olen, &anchor);
             }
             // the -v report counters (a12) are functions of res[]: tally the drop reasons this instance can produce, per wave, as the

@@ -69,19 +69,6 @@ struct FxgStatsArgs {
 #define FXG_GLOBAL_ADD32(p, v) ((void)__hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))   // result unused: global_atomic_add_u32 without return
 #endif
 
-// v_perm_b32: byte i of the result is byte sel[i] of the 8-byte value {hi:lo} (selectors 0..3 -> lo, 4..7 -> hi)
-FXG_HD u32 fxg_perm(u32 hi, u32 lo, u32 sel)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_perm(hi, lo, sel);
-#else
-    const u64 v = ((u64)hi << 32) | lo;
-    u32 r = 0;
-    for (int i = 0; i < 4; ++i) r |= (u32)((v >> (8u * ((sel >> (8 * i)) & 7u))) & 0xFFu) << (8 * i);
-    return r;
-#endif
-}
-
 // class of a base: A C G T N -> 0..4 (either case, fastx_quality_stats.c:142-155), anything else -> 5 (not counted)
 FXG_HD u32 fxg_stats_class(u32 c)
 {

@@ -108,7 +108,7 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
             }
         } else if (MODE == 4) {
             for (u32 tid = 0; tid < NT; ++tid) fxg_phase_stage_bases(a.bases, a.total_bytes, tb, tbytes, sb, tid, NT);
-            for (u32 tid = 0; tid < nreads; ++tid) { fxg_decide_census(a, sb + tid * stride, r0, tid, &keep[tid], &olen[tid], &bad); anchor[tid] = tid * stride; }
+            for (u32 tid = 0; tid < nreads; ++tid) { fxg_decide_census(a, sb, tid * stride, r0, tid, &keep[tid], &olen[tid], &bad); anchor[tid] = tid * stride; }
         } else {
             for (u32 tid = 0; tid < nreads; ++tid) fxg_decide_b<REV>(a, r0, tid, &keep[tid], &olen[tid], &anchor[tid]);
         }

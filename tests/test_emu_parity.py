@@ -65,6 +65,14 @@ def test_emulated_decision_only_and_bad_base():
     assert int(e["counters"][15]) & 2          # fastx_reverse_complement.c:67-68
     e = emu.run_pipeline(b2, q, None, oracle_params(dict(stages=16, ft_first=2)))
     assert int(e["counters"][15]) == 0         # the fixed trimmer never looks at the alphabet
+    # the base census (fastx_artifacts_filter.c:70-95, fastq_to_fasta): upper-case A C G T N only, at every byte position of a dword and in the read's last,
+    # partial dword; a clean batch raises nothing
+    for st in (128, 256):
+        assert int(emu.run_pipeline(b, q, None, oracle_params(dict(stages=st)))["counters"][15]) == 0
+        for pos, ch in ((0, "X"), (1, "a"), (2, "@"), (3, "n"), (48, "."), (49, "c"), (23, "\x00"), (37, "\xff")):
+            b3 = b.copy()
+            b3[41, pos] = ord(ch)
+            assert int(emu.run_pipeline(b3, q, None, oracle_params(dict(stages=st)))["counters"][15]) & 2, (st, pos, ch)
 
 
 def test_emulated_clip_history_across_batches():

@@ -324,6 +324,13 @@ def test_invalid_requests_and_bad_base(engine):
         _run(engine, b2, q, None, dict(stages=8))
     e = _run(engine, b2, q, None, dict(stages=16, ft_first=2))
     assert int(e["counters"][1]) == 2000
+    for st in (128, 256):                                                    # the base census: upper-case A C G T N only, wherever the byte sits in its dword
+        _run(engine, b, q, None, dict(stages=st))
+        for pos, ch in ((0, "X"), (1, "a"), (2, "@"), (3, "n"), (38, "."), (39, "c"), (23, "\x00"), (37, "\xff")):
+            b3 = b.copy()
+            b3[777, pos] = ord(ch)
+            with pytest.raises(FxgError, match="Invalid nucleotide"):
+                _run(engine, b3, q, None, dict(stages=st))
 
 
 def _window_check(engine, seed, N, L, ad, pd, K=40000, interior=10, KI=3000, expect=None, first=0, light=False):
