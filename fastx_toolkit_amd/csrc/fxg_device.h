@@ -149,6 +149,19 @@ FXG_HD u32 fxg_mask16(u32x4 v, u32 K)
            (fxg_pack4(fxg_ge_flags(v.z, K)) << 8) | (fxg_pack4(fxg_ge_flags(v.w, K)) << 12);
 }
 
+// the bit-7 flags of sixteen bytes (four dwords whose bytes are 0x80 or 0) as a 16-bit mask, bit i = byte i
+FXG_HD u32 fxg_flags16(u32 f0, u32 f1, u32 f2, u32 f3)
+{
+#ifndef FXG_HOST_EMULATION
+    const u32 lo = __builtin_amdgcn_udot4(f0, 0x08040201u, __builtin_amdgcn_udot4(f1, 0x80402010u, 0u, false), false);      // (as fxg_mask16: 128 x the mask)
+    const u32 hi = __builtin_amdgcn_udot4(f2, 0x08040201u, __builtin_amdgcn_udot4(f3, 0x80402010u, 0u, false), false);
+    return (lo >> 7) | (hi << 1);
+#endif
+    return fxg_pack4(f0) | (fxg_pack4(f1) << 4) | (fxg_pack4(f2) << 8) | (fxg_pack4(f3) << 12);
+}
+// bit 7 of every byte of x that is not zero
+FXG_HD u32 fxg_nonzero_flags(u32 x) { return (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u; }
+
 // 16-byte load from an arbitrarily aligned address (one global_load_dwordx4 on gfx950)
 FXG_HD u32x4 fxg_ld16(const uint8_t *p)
 {

@@ -26,11 +26,12 @@
 struct FxgLds {
     u32 slot_bytes, so_ksrc, so_kidx, so_ktab;   // slot k lives at k * slot_bytes: k_off at +0, k_src at +so_ksrc, k_idx at +so_kidx, k_tab at +so_ktab
     u32 off_scratch, off_tally, off_bm_g, off_bm_l, off_bases, off_ptab, total;
-    u32 has_tab;                                 // kernels that stage a tile of bases in LDS (clipper, census) spend no LDS on k_tab
+    u32 has_tab;                                 // kernels that stage a tile of bases in LDS (the clipper) spend no LDS on k_tab
 };
 __host__ __device__ inline u32 fxg_r16(u32 x) { return (x + 15u) & ~15u; }
 // nslots: tiles a workgroup keeps between decision and write-out (FxgTileDepth: 2, the clip instances 3)
-// bitmaps: 0 none, 2 both, 1 = ONE shared by trimmer and filter (same threshold: "below" is the complement of "at least"; off_bm_l == off_bm_g)
+// bitmaps: 0 none, 2 both, 1 = ONE shared by trimmer and filter (same threshold: "below" is the complement of "at least"; off_bm_l == off_bm_g),
+//          4 = the base census's four, back to back from off_bm_g (fxg_census_bitmaps)
 // ptab_bytes: the clip instances that take their pair values from an LDS table (fxg_clip_ptab_build, fxg_ptab_bytes)
 __host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, u32 bitmaps, u32 stage_stride, u32 nslots = 2, bool no_tab = false, u32 ptab_bytes = 0u)   // stage_stride: row stride of the LDS copy of the tile's bases, 0 = none
 {
@@ -44,7 +45,7 @@ __host__ __device__ inline FxgLds fxg_lds_layout(u32 T, u32 stride, u32 bitmaps,
     l.off_scratch = o; o += fxg_r16(48 * 4);
     l.off_tally = o;   o += FXG_NTALLY * 8;      // the workgroup's -v report tallies (u64), see fxg_tile_tally
     const u32 words = (T * stride + 31) / 32 + 2;
-    l.off_bm_g = o;    o += bitmaps ? fxg_r16(words * 4) : 0;
+    l.off_bm_g = o;    o += bitmaps ? fxg_r16(words * 4) * (bitmaps == 4u ? 4u : 1u) : 0;
     l.off_bm_l = bitmaps == 1u ? l.off_bm_g : o;    o += bitmaps == 2u ? fxg_r16(words * 4) : 0;
     l.off_bases = o;   o += stage_stride ? fxg_r16(T * stage_stride + 16) : 0;
     l.off_ptab = o;    o += fxg_r16(ptab_bytes);
@@ -1441,35 +1442,77 @@ FXG_HD u32 fxg_decide_mask(const FxgKArgs &a, const u32 *bm_l, u32 r0, u32 tid, 
     return (rl & 0xFFFFu) | (1u << 16);
 }
 
-// base census of one read from its LDS row, shared by
+// base census of one read, shared by
 //   fastx_artifacts_filter (fastx_artifacts_filter.c:56-112): drop when one of A/C/G/T fills all but <= 3 positions
 //   fastq_to_fasta N-discard (fastq_to_fasta.c:79-82)        : drop when the read contains an N (unless -n)
-// Four bases per step (round 6; one byte per step before: 150 ds_read_u8 and ~1 650 VALU instructions per read): the row is read as ALIGNED dwords and
-// realigned with a funnel shift (rows of 150 bytes start on 2-byte boundaries; a misaligned ds_read_b32 takes the slow path), the low three bits of a letter
-// (A 1, C 3, T 4, N 6, G 7) select its one-hot flag and the byte it has to be from two 8-entry tables (v_perm_b32), a population count per letter adds the flags.
-// Upper case only, as the reference's tools have it here (fastx_artifacts_filter.c:70-95: anything else is "invalid nucleotide value").
-#define FXG_CENSUS_EXP_LO 0x43FF41FFu      // expected byte by low three bits: -- A -- C | T -- N G   (FF: no byte with those bits is valid)
+// Round 6, second form: the tile's bases are not staged in LDS and walked one read per thread any more (150 ds_read_u8 and ~1 650 VALU instructions per read; four
+// bases per step through aligned dwords and two v_perm tables took 6.90 -> 6.28 ms of 50 M x 150, profiles/r06/census_swar_vs_bytes.txt).  Phase 1 streams the rows
+// once, 16 bytes per lane and five loads in flight like the quality bitmaps, and leaves FOUR bitmaps of the tile in LDS, one bit per base: bit 1 and bit 2 of the
+// letter (A 00, C 01, T 10, G and N 11), "is N", and "is none of A C G T N" (upper case only, as the reference's tools have it here: fastx_artifacts_filter.c:70-95,
+// anything else is "invalid nucleotide value").  A read's census is then five population counts over the 5-6 words of its bit range.  The bitmaps take half the
+// bytes of the staged tile, so the kernel is a streaming instance like the masker now: tiles of 20 KB and the granule table of the write-out (fxg_lds_layout).
+#define FXG_CENSUS_EXP_LO 0x43FF41FFu      // the byte a letter has to be, by its low three bits: -- A -- C | T -- N G   (FF: no byte with those bits is valid)
 #define FXG_CENSUS_EXP_HI 0x474EFF54u
-#define FXG_CENSUS_OH_LO  0x02000100u      // one-hot flag:                   A 01, C 02, G 04, T 08, N 10
-#define FXG_CENSUS_OH_HI  0x04100008u
-// sb: the staged tile (16-byte aligned), off: where this thread's row starts in it
-FXG_HD u32 fxg_decide_census(const FxgKArgs &a, const uint8_t *sb, u32 off, u32 r0, u32 tid, u32 *keep_out, u32 *len_out, u32 *bad)
+struct FxgCensusBm { u32 *b0, *b1, *bn, *bi; };
+__host__ __device__ inline u32 fxg_census_words(u32 T, u32 stride) { return fxg_r16(((T * stride + 31u) / 32u + 2u) * 4u) / 4u; }
+FXG_HD FxgCensusBm fxg_census_bitmaps(u32 *p, u32 T, u32 stride)      // p: off_bm_g of a layout with four bitmaps
+{
+    const u32 w = fxg_census_words(T, stride);
+    return FxgCensusBm{p, p + w, p + 2u * w, p + 3u * w};
+}
+FXG_HD void fxg_census_chunk(const u32x4 &v, u32 c, const FxgCensusBm &bm)
+{
+    const u32 w[4] = {v.x, v.y, v.z, v.w};
+    u32 f0[4], f1[4], fn[4], fi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f0[i] = (w[i] << 6) & 0x80808080u;                                                 // bit 1 of the letter
+        f1[i] = (w[i] << 5) & 0x80808080u;                                                 // bit 2
+        fn[i] = ~fxg_nonzero_flags(w[i] ^ 0x4E4E4E4Eu) & 0x80808080u;                      // 'N'
+        fi[i] = fxg_nonzero_flags(fxg_perm(FXG_CENSUS_EXP_HI, FXG_CENSUS_EXP_LO, w[i] & 0x07070707u) ^ w[i]);
+    }
+    reinterpret_cast<uint16_t *>(bm.b0)[c] = (uint16_t)fxg_flags16(f0[0], f0[1], f0[2], f0[3]);
+    reinterpret_cast<uint16_t *>(bm.b1)[c] = (uint16_t)fxg_flags16(f1[0], f1[1], f1[2], f1[3]);
+    reinterpret_cast<uint16_t *>(bm.bn)[c] = (uint16_t)fxg_flags16(fn[0], fn[1], fn[2], fn[3]);
+    reinterpret_cast<uint16_t *>(bm.bi)[c] = (uint16_t)fxg_flags16(fi[0], fi[1], fi[2], fi[3]);
+}
+// phase 1 (census): base rows of the tile -> the four bitmaps (the loop of fxg_phase_bitmaps)
+FXG_HD void fxg_phase_census(const FxgKArgs &a, u64 tb, u32 tbytes, const FxgCensusBm &bm, u32 tid, u32 nthreads)
+{
+    const u32 nchunks = (tbytes + 15u) >> 4;
+    const uint8_t *src = a.bases + tb;
+    if ((tbytes & 15u) == 0u && tb + tbytes <= a.total_bytes) {
+        constexpr u32 U = FXG_BITMAP_U;
+        for (u32 c0 = tid; c0 < nchunks; c0 += nthreads * U) {
+            u32x4 v[U];
+#pragma unroll
+            for (u32 u = 0; u < U; ++u) { const u32 c = c0 + u * nthreads; if (c < nchunks) v[u] = fxg_ld16(src + ((u64)c << 4)); }
+#pragma unroll
+            for (u32 u = 0; u < U; ++u) { const u32 c = c0 + u * nthreads; if (c < nchunks) fxg_census_chunk(v[u], c, bm); }
+        }
+        return;
+    }
+    for (u32 c = tid; c < nchunks; c += nthreads) {
+        const u32 o = c << 4;
+        fxg_census_chunk(fxg_window(a.bases, (long long)(tb + o), a.total_bytes, 0, (int)(tbytes - o < 16u ? tbytes - o : 16u)), c, bm);
+    }
+}
+// s0: the read's first bit in the tile's bitmaps
+FXG_HD u32 fxg_decide_census(const FxgKArgs &a, const FxgCensusBm &bm, u32 s0, u32 r0, u32 tid, u32 *keep_out, u32 *len_out, u32 *bad)
 {
     const u32 rl = a.len ? (u32)a.len[r0 + tid] : a.fixed_len;
     u32 ca = 0, cc = 0, cg = 0, ct = 0, cn = 0, invalid = 0;
-    const u32 sh = off & 3u;
-    const u32 *p = reinterpret_cast<const u32 *>(sb) + (off >> 2);      // (the staged tile ends 16 bytes before its region does: fxg_lds_layout)
-    u32 lo = rl ? p[0] : 0u;
-    for (u32 k = 0; k < rl; k += 4u) {                           // (four dwords requested ahead of their use: +4 %, profiles/r06/census_swar_vs_bytes.txt)
-        const u32 hi = p[(k >> 2) + 1u];
-        const u32 w = fxg_alignbyte(hi, lo, sh);                 // bytes [k, k + 4) of the read
-        lo = hi;
-        const u32 m = fxg_lowbytes32((int)(rl - k < 4u ? rl - k : 4u));
-        const u32 sel = w & 0x07070707u;
-        invalid |= (fxg_perm(FXG_CENSUS_EXP_HI, FXG_CENSUS_EXP_LO, sel) ^ w) & m;
-        const u32 oh = fxg_perm(FXG_CENSUS_OH_HI, FXG_CENSUS_OH_LO, sel) & m;
-        ca += (u32)__builtin_popcount(oh & 0x01010101u); cc += (u32)__builtin_popcount(oh & 0x02020202u); cg += (u32)__builtin_popcount(oh & 0x04040404u);
-        ct += (u32)__builtin_popcount(oh & 0x08080808u); cn += (u32)__builtin_popcount(oh & 0x10101010u);
+    if (rl) {
+        const u32 e1 = s0 + rl - 1u, w0 = s0 >> 5, w1 = e1 >> 5;
+        for (u32 w = w0; w <= w1; ++w) {
+            u32 m = 0xFFFFFFFFu;
+            if (w == w0) m &= 0xFFFFFFFFu << (s0 & 31u);
+            if (w == w1) m &= 0xFFFFFFFFu >> (31u - (e1 & 31u));
+            const u32 x0 = bm.b0[w], x1 = bm.b1[w], xn = bm.bn[w];
+            invalid |= bm.bi[w] & m;
+            ca += (u32)__builtin_popcount(~x0 & ~x1 & m); cc += (u32)__builtin_popcount(x0 & ~x1 & m); ct += (u32)__builtin_popcount(~x0 & x1 & m);
+            cg += (u32)__builtin_popcount(x0 & x1 & ~xn & m); cn += (u32)__builtin_popcount(xn & m);
+        }
     }
     if (invalid) *bad = 1u;                               // "invalid nucleotide value" in the reference
     u32 keep = 1u, why = FXG_R_KEPT;
@@ -1568,7 +1611,7 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
     const bool use_q = (MODE == 0 && (a.stages & (FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0) || MODE == 3;
     const u32 NSLOT = (MODE == 0 && AMAX != 0) ? a.depth : 2u;        // tiles between decision and write-out (fxg_plan.h)
     constexpr bool PTAB = MODE == 0 && fxg_clip_uses_ptab(AMAX);            // the DP takes its pair values from an LDS table (staged form and over-the-batch form alike)
-    const FxgLds L = fxg_lds_layout(T, stride, fxg_bitmap_count(a, use_q, MODE == 0 && AMAX != 0), (MODE == 0 && AMAX != 0) ? (GL ? 0u : a.clip_stride) : (MODE == 4 ? stride : 0u), NSLOT, MODE == 0 && AMAX != 0, PTAB ? fxg_ptab_bytes(a.clip_ptab_rows, a.clip_ptab_stride) : 0u);
+    const FxgLds L = fxg_lds_layout(T, stride, MODE == 4 ? 4u : fxg_bitmap_count(a, use_q, MODE == 0 && AMAX != 0), (MODE == 0 && AMAX != 0) ? (GL ? 0u : a.clip_stride) : 0u, NSLOT, MODE == 0 && AMAX != 0, PTAB ? fxg_ptab_bytes(a.clip_ptab_rows, a.clip_ptab_stride) : 0u);
     u32 m_reads = 0, m_nt = 0, art_bad = 0;      // MODE 3 report counters / MODE 4 alphabet check, folded once at the end
     u32 *bm_g = reinterpret_cast<u32 *>(smem + L.off_bm_g);
     u32 *bm_l = reinterpret_cast<u32 *>(smem + L.off_bm_l);
@@ -1628,7 +1671,7 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
                 if constexpr (MODE == 0 && AMAX != 0) __builtin_amdgcn_s_setprio(FXG_PRIO_STAGING);      // the same for the staging loads of the next tile
                 if (use_q && !FXG_DBG(a, 8u)) fxg_phase_bitmaps(a, tb, tbytes, bm_g, bm_l, tid, TB);
                 if constexpr (MODE == 0 && AMAX != 0) { if (!GL && (!FXG_DBG(a, 16u) || pend == FXG_NO_TILE)) fxg_phase_stage_bases(a.clip_src, a.clip_total, (u64)r0 * a.clip_stride, nreads * a.clip_stride, sb, tid, TB); }   // 16: the DP on the workgroup's first tile over and over (the DP's own rate)
-                if constexpr (MODE == 4) fxg_phase_stage_bases(a.bases, a.total_bytes, tb, tbytes, sb, tid, TB);
+                if constexpr (MODE == 4) fxg_phase_census(a, tb, tbytes, fxg_census_bitmaps(bm_g, T, stride), tid, TB);
                 __syncthreads();
                 if constexpr (MODE == 0 && AMAX != 0) __builtin_amdgcn_s_setprio(0);
             }
@@ -1642,7 +1685,7 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
                     word = fxg_decide_a<AMAX, GL>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen, nullptr, 0u, PTAB ? smem + L.off_ptab : nullptr);
                 } else if constexpr (MODE == 0) word = fxg_decide_a<AMAX>(a, bm_g, bm_l, sb, r0, tid, &keep, &olen);
                 else if constexpr (MODE == 3) { u32 nl; word = fxg_decide_mask(a, bm_l, r0, tid, &keep, &olen, &nl); m_nt += nl; m_reads += (nl != 0u); }
-                else if constexpr (MODE == 4) word = fxg_decide_census(a, sb, tid * stride, r0, tid, &keep, &olen, &art_bad);
+                else if constexpr (MODE == 4) word = fxg_decide_census(a, fxg_census_bitmaps(bm_g, T, stride), tid * stride, r0, tid, &keep, &olen, &art_bad);
                 else word = fxg_decide_b<REV>(a, r0, tid, &keep, &olen, &anchor);
             }
             // the -v report counters (a12) are functions of res[]: tally the drop reasons this instance can produce, per wave, as the

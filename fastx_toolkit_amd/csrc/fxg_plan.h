@@ -28,7 +28,7 @@ static inline u32 fxg_pick_tile(u32 stride, bool clip, u32 block = FXG_TBLOCK)
 {
     // Rows one workgroup covers per tile.  Streaming kernels: about 20 KB (128 reads of 150 bases) -- with the central scanner the
     // per-tile cost is small enough that the shorter pipeline step wins (cfg2: 4.13 ms at 128 reads, 4.19-4.31 at 256, 5.9 at 64;
-    // profiles/r02/variants_*.txt).  Kernels that stage the tile's bases in LDS (clipper, census): up to 60 KB so that two or
+    // profiles/r02/variants_*.txt).  Kernels that stage the tile's bases in LDS (the clipper): up to 60 KB so that two or
     // more workgroups share a CU.
     const u64 budget = clip ? 60ull * 1024 : 20ull * 1024;
     u32 T = block;                          // one thread decides one read
@@ -44,7 +44,7 @@ static inline FxgLds fxg_plan_layout(const FxgPlan *pl)
     return pl->group_a ? fxg_lds_layout(ka.tile_reads, ka.stride, fxg_bitmap_count(ka, pl->use_q, pl->clip), (pl->clip && !ka.clip_global) ? ka.clip_stride : 0u, pl->clip ? ka.depth : 2u, pl->clip,
                                         (pl->clip && fxg_clip_uses_ptab(pl->amax)) ? fxg_ptab_bytes(ka.clip_ptab_rows, ka.clip_ptab_stride) : 0u)
          : pl->mask ? fxg_lds_layout(ka.tile_reads, ka.stride, 2u, 0u)
-         : pl->artifacts ? fxg_lds_layout(ka.tile_reads, ka.stride, 0u, ka.stride) : fxg_lds_layout(ka.tile_reads, ka.stride, 0u, 0u);
+         : pl->artifacts ? fxg_lds_layout(ka.tile_reads, ka.stride, 4u, 0u) : fxg_lds_layout(ka.tile_reads, ka.stride, 0u, 0u);
 }
 static inline u32 fxg_plan_lds(const FxgPlan *pl) { return fxg_plan_layout(pl).total; }
 
@@ -186,7 +186,7 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     // 300 bases 6.26 / 4.66 per 6 M, 1 000 bases 13.1 / 5.95 per 2 M: profiles/r04/ae_clip_global_vs_staged*.txt).  Rows must start on dword
     // boundaries; runs with clip history (ragged input of the tools) keep the staged form.  FXG_CLIP_GLOBAL=0 / 1 overrides (tests run both).
     ka.clip_global = 0u;
-    u32 T = pl->rows_nw ? 64u * (u32)pl->rows_r / (u32)pl->rows_h : fxg_pick_tile(pl->clip ? ka.clip_stride : in->stride, pl->clip || gf, pl->block);
+    u32 T = pl->rows_nw ? 64u * (u32)pl->rows_r / (u32)pl->rows_h : fxg_pick_tile(pl->clip ? ka.clip_stride : in->stride, pl->clip, pl->block);
 #ifndef FXG_CLIP_ONE_PASS
     if (pl->clip && pl->amax < 0 && (pl->amax >= -16 || pl->ck_per_wg != 0) && clip_stride == 0u && (ka.clip_stride & 3u) == 0u && ((uintptr_t)ka.clip_src & 3u) == 0u) {      // (clip_stride != 0: a run with clip history, whose rows are settled after the plan)
         ka.tile_reads = T; ka.depth = 2u;

@@ -107,8 +107,9 @@ static int emu_run(const FxgPlan &pl, uint64_t *counters, char *err, size_t cap)
                 anchor[tid] = tid * stride; m_nt += nl; m_reads += (nl != 0u);
             }
         } else if (MODE == 4) {
-            for (u32 tid = 0; tid < NT; ++tid) fxg_phase_stage_bases(a.bases, a.total_bytes, tb, tbytes, sb, tid, NT);
-            for (u32 tid = 0; tid < nreads; ++tid) { fxg_decide_census(a, sb, tid * stride, r0, tid, &keep[tid], &olen[tid], &bad); anchor[tid] = tid * stride; }
+            const FxgCensusBm cb = fxg_census_bitmaps(bm_g, T, stride);
+            for (u32 tid = 0; tid < NT; ++tid) fxg_phase_census(a, tb, tbytes, cb, tid, NT);
+            for (u32 tid = 0; tid < nreads; ++tid) { fxg_decide_census(a, cb, tid * stride, r0, tid, &keep[tid], &olen[tid], &bad); anchor[tid] = tid * stride; }
         } else {
             for (u32 tid = 0; tid < nreads; ++tid) fxg_decide_b<REV>(a, r0, tid, &keep[tid], &olen[tid], &anchor[tid]);
         }
