@@ -14,7 +14,8 @@ eng.set_profiling(True)
 CASES2 = [(144, "fastx_reverse_complement, 144-byte rows (aligned, no chunk across reads)", dict(stages=8)), (152, "fastx_reverse_complement, 152-byte rows (windows at 8 mod 16, every other read straddled)", dict(stages=8)),
           (158, "fastx_reverse_complement, 158-byte rows", dict(stages=8)), (150, "fastx_reverse_complement, 150-byte rows", dict(stages=8)), (150, "fastx_trimmer -f 3 -l 150 (shift of 2)", dict(stages=16, ft_first=3, ft_last=150)),
           (150, "fastx_trimmer -t 2 (150 -> 148, end trimmed)", dict(stages=32, ft_trim_end=2)), (150, "revcomp + trimmer -f 1 -l 150", dict(stages=24, ft_first=1, ft_last=150))]
-for L, name, pd in CASES2 if os.environ.get("CASES") == "2" else [(150, "fastx_trimmer -f 1 -l 150 (no-op, aligned windows)", dict(stages=16, ft_first=1, ft_last=150)), (150, "fastx_trimmer -f 5 -l 145", dict(stages=16, ft_first=5, ft_last=145)),
+CASES3 = [(150, "revcomp + trimmer -f 1 -l %d (window start mod 4: %s)" % (l, w), dict(stages=24, ft_first=1, ft_last=l)) for l, w in ((150, "2"), (148, "0 / 2 by read"), (147, "all"), (146, "2"), (144, "0"))]
+for L, name, pd in CASES3 if os.environ.get("CASES") == "3" else CASES2 if os.environ.get("CASES") == "2" else [(150, "fastx_trimmer -f 1 -l 150 (no-op, aligned windows)", dict(stages=16, ft_first=1, ft_last=150)), (150, "fastx_trimmer -f 5 -l 145", dict(stages=16, ft_first=5, ft_last=145)),
                     (150, "fastx_trimmer -f 17 -l 150 (shift of 16: aligned)", dict(stages=16, ft_first=17, ft_last=150)), (150, "fastx_trimmer -f 2 -l 150 (shift of 1)", dict(stages=16, ft_first=2, ft_last=150)),
                     (150, "fastx_reverse_complement, 150-byte rows", dict(stages=8)), (160, "fastx_reverse_complement, 160-byte rows (aligned windows)", dict(stages=8)),
                     (150, "fastq_masker -q 20, 150-byte rows", dict(stages=64, mask_min_quality=20)), (160, "fastx_trimmer -f 5 -l 145, 160-byte rows", dict(stages=16, ft_first=5, ft_last=145))]:
