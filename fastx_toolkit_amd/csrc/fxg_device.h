@@ -99,6 +99,7 @@ struct FxgKArgs {
     u32  ft_trim_end, ft_min_len;
     u32  mask_char;         // fastq_masker -r; the mask threshold shares `fq` (byte < fq is masked)
     u32  nf_keep_n;         // fastq_to_fasta -n
+    u32  rev_dw;            // reverse complement: no source window of the launch starts on a dword boundary -> the instance with dword-aligned window loads (fxg_plan.h, fxg_ld16_dw)
     u64 *extra;             // [0] masked reads, [1] masked nucleotides (fastq_masker report)
     // what the clipper's DP reads: the batch itself, or (clip history, fxg_history.h) the queries extended by the stale tail
     const uint8_t  *clip_src;
@@ -187,6 +188,26 @@ FXG_HD void fxg_st16_stream(uint8_t *p, u32x4 v)
     __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
 #else
     *reinterpret_cast<u32x4 *>(p) = v;
+#endif
+}
+
+// The 16 bytes at p through DWORD-ALIGNED loads: four words and the one behind them, realigned with a funnel shift.  For the reverse complement's source
+// windows: a 16-byte load that starts off a dword boundary is served at a lower rate, which shows once EVERY window of a launch does -- the reversed windows of
+// 150-byte rows all start at 2 mod 4: 6.2 ms against 5.0-5.4 on rows where at least every other read's windows are dword aligned; the forward kernels never come
+// to more than three windows in four (profiles/r06/gather_alignment*.txt).  It costs a load and four funnel shifts per window: -8 % where no window is aligned,
+// +3..8 % everywhere else, and nothing gained as a run-time switch inside one kernel (rev_dword_loads_*.txt) -- hence an instance of its own,
+// fxg_kernel_tiles<0, 5>, that the plan picks for exactly those launches (FxgKArgs::rev_dw).  Reads up to 3 bytes before and 4 bytes behind the window.
+FXG_HD u32x4 fxg_ld16_dw(const uint8_t *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
+    const u32 sh = (u32)(reinterpret_cast<uintptr_t>(p) & 3u);
+    const uint8_t *q = p - sh;
+    const u32x4 v = *reinterpret_cast<const u32x4_a4 *>(q);
+    const u32 t = *reinterpret_cast<const u32 *>(q + 16);
+    return (u32x4){__builtin_amdgcn_alignbyte(v.y, v.x, sh), __builtin_amdgcn_alignbyte(v.z, v.y, sh), __builtin_amdgcn_alignbyte(v.w, v.z, sh), __builtin_amdgcn_alignbyte(t, v.w, sh)};
+#else
+    return fxg_ld16(p);
 #endif
 }
 
@@ -675,7 +696,7 @@ FXG_HD void fxg_gather_byte(const FxgKArgs &a, const uint8_t *src_b, const uint8
 #endif
 struct FxgChunk { u32 o, k; int e, e2; u32x4 wb, wq, vb, vq; };
 
-template <bool REV, bool MASK>
+template <bool REV, bool MASK, bool DW = false>      // DW (REV): windows through fxg_ld16_dw
 FXG_HD void fxg_chunk_load(FxgChunk &c, const uint8_t *src_b, const uint8_t *src_q, bool want_q, const u32 *k_off, const u32 *k_src,
                            const uint16_t *k_tab, u32 nk, u32 S, u32 o)
 {
@@ -685,20 +706,20 @@ FXG_HD void fxg_chunk_load(FxgChunk &c, const uint8_t *src_b, const uint8_t *src
     const int e = e1 - o < 16u ? (int)(e1 - o) : 16;
     const int p1 = REV ? (int)k_src[k] - j0 - 15 : (int)k_src[k] + j0;
     c.o = o; c.k = k; c.e = e; c.e2 = 16;
-    c.wb = fxg_ld16_stream(src_b + p1);
+    c.wb = DW ? fxg_ld16_dw(src_b + p1) : fxg_ld16_stream(src_b + p1);
     c.wq = (u32x4){0u, 0u, 0u, 0u};
-    if (want_q) c.wq = fxg_ld16_stream(src_q + p1);
+    if (want_q) c.wq = DW ? fxg_ld16_dw(src_q + p1) : fxg_ld16_stream(src_q + p1);
     c.vb = c.vq = (u32x4){0u, 0u, 0u, 0u};
     if (e < 16) {                                                         // the chunk continues in the next kept read
         const u32 n2 = k_off[k + 2u] - e1;
         c.e2 = n2 < (u32)(16 - e) ? e + (int)n2 : 16;
         const int p2 = REV ? (int)k_src[k + 1u] + e - 15 : (int)k_src[k + 1u] - e;
-        c.vb = fxg_ld16_stream(src_b + p2);
-        if (want_q) c.vq = fxg_ld16_stream(src_q + p2);
+        c.vb = DW ? fxg_ld16_dw(src_b + p2) : fxg_ld16_stream(src_b + p2);
+        if (want_q) c.vq = DW ? fxg_ld16_dw(src_q + p2) : fxg_ld16_stream(src_q + p2);
     }
 }
 
-template <bool REV, bool MASK = false, int GK = FXG_GATHER_K>
+template <bool REV, bool MASK = false, int GK = FXG_GATHER_K, bool DW = false>
 FXG_HD u32 fxg_tile_gather(const FxgKArgs &a, const u32 *k_off, const u32 *k_src, const uint16_t *k_tab, u32 nk,
                            u64 tile_in_base, u32 tile_bytes, u64 B, u32 S, u32 tid, u32 nthreads)
 {
@@ -708,7 +729,7 @@ FXG_HD u32 fxg_tile_gather(const FxgKArgs &a, const u32 *k_off, const u32 *k_src
     const uint8_t *src_b = a.bases + tile_in_base, *src_q = (has_q || MASK) ? a.qual + tile_in_base : nullptr;
     uint8_t *dst_b = a.out_bases + B, *dst_q = has_q ? a.out_qual + B : nullptr;
     // a window covers up to 15 bytes either side of the rows it serves: whole windows only where that stays inside the arrays
-    const bool interior = tile_in_base >= 15u && tile_in_base + tile_bytes + 15u <= a.total_bytes;
+    const bool interior = tile_in_base >= (DW ? 18u : 15u) && tile_in_base + tile_bytes + (DW ? 19u : 15u) <= a.total_bytes;      // (fxg_ld16_dw reads 3 bytes before and 4 behind its window)
     u32 o_lo = 0, nfull = 0;
     if (interior) {
         const u32 head = (16u - (u32)(B & 15u)) & 15u;                   // output bytes before the first aligned chunk
@@ -726,7 +747,7 @@ FXG_HD u32 fxg_tile_gather(const FxgKArgs &a, const u32 *k_off, const u32 *k_src
         for (int u = 0; u < GK; ++u) {
             const u32 ci = c0 + (u32)u * nthreads;
             ch[u].e = 0;
-            if (ci < nfull) fxg_chunk_load<REV, MASK>(ch[u], src_b, src_q, has_q || MASK, k_off, k_src, k_tab, nk, S, o_lo + (ci << 4));
+            if (ci < nfull) fxg_chunk_load<REV, MASK, DW>(ch[u], src_b, src_q, has_q || MASK, k_off, k_src, k_tab, nk, S, o_lo + (ci << 4));
         }
 #pragma unroll
         for (int u = 0; u < GK; ++u) {

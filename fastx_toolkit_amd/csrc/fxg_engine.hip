@@ -254,6 +254,7 @@ static int fxg_launch_plan(fxg_ctx *c, FxgPlan &pl, u64 *ctr)
     }
     if (pl.mask) return fxg_launch_tiles(c, fxg_kernel_tiles<0, 3>, "fxg_kernel_tiles<0,3> mask", pl.ka, pl.lds, ctr);
     if (pl.artifacts) return fxg_launch_tiles(c, fxg_kernel_tiles<0, 4>, "fxg_kernel_tiles<0,4> base census", pl.ka, pl.lds, ctr);
+    if (pl.rev && pl.ka.rev_dw) return fxg_launch_tiles(c, fxg_kernel_tiles<0, 5>, "fxg_kernel_tiles<0,5> revcomp[+ftrim], dword-aligned windows", pl.ka, pl.lds, ctr);
     if (pl.rev) return fxg_launch_tiles(c, fxg_kernel_tiles<0, 2>, "fxg_kernel_tiles<0,2> revcomp[+ftrim]", pl.ka, pl.lds, ctr);
     return fxg_launch_tiles(c, fxg_kernel_tiles<0, 1>, "fxg_kernel_tiles<0,1> ftrim", pl.ka, pl.lds, ctr);
 #undef FXG_TILES_A

@@ -1554,7 +1554,7 @@ __device__ __forceinline__ void fxg_tile_tally(u32 w, bool valid, u64 *tally)
             if (lead && ao) atomicAdd(&tally[3], (u64)__builtin_popcountll(ao));
         }
         count(FXG_R_QTRIM); count(FXG_R_QFILTER);
-    } else if constexpr (MODE == 1 || MODE == 2) {
+    } else if constexpr (MODE == 1 || MODE == 2 || MODE == 5) {
         count(FXG_R_FTRIM);
     } else if constexpr (MODE == 4) {
         count(FXG_R_ARTIFACT); count(FXG_R_HAS_N);
@@ -1605,7 +1605,7 @@ template <int AMAX, int MODE, bool GL = false>
 __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? FXG_MIN_WAVES : fxg_clip_waves(AMAX))) void fxg_kernel_tiles(const FxgKArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr bool REV = (MODE == 2);
+    constexpr bool REV = (MODE == 2 || MODE == 5);      // 5: the reverse complement with dword-aligned window loads (fxg_ld16_dw; picked by the plan, FxgKArgs::rev_dw)
     constexpr u32 TB = (u32)FxgTileBlock<AMAX, MODE>::threads, TW = TB / 64u;
     const u32 T = a.tile_reads, stride = a.stride, tid = threadIdx.x;
     const bool use_q = (MODE == 0 && (a.stages & (FXG_STAGE_QTRIM | FXG_STAGE_QFILTER)) != 0) || MODE == 3;
@@ -1741,7 +1741,7 @@ __global__ __launch_bounds__((FxgTileBlock<AMAX, MODE>::threads), (AMAX == 0 ? F
             if (placed && !FXG_DBG(a, 1u)) {
                 // the clip instances run four waves per SIMD: their gather keeps four chunks per lane in flight (FXG_GATHER_K)
                 constexpr int GK = (MODE == 0 && AMAX != 0) ? FXG_CLIP_GATHER_K : FXG_GATHER_K;
-                const u32 bad = fxg_tile_gather<REV, MODE == 3, GK>(a, k_off, k_src, k_tab, nk, (u64)r0 * stride, nreads * stride, base_b, totb, tid, TB);
+                const u32 bad = fxg_tile_gather<REV, MODE == 3, GK, MODE == 5>(a, k_off, k_src, k_tab, nk, (u64)r0 * stride, nreads * stride, base_b, totb, tid, TB);
                 if (REV && bad) atomicOr(a.errflag, FXG_DEV_ERR_BAD_BASE);
             }
             FXG_TPHASE(4);

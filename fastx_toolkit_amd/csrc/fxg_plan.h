@@ -199,6 +199,21 @@ static inline int fxg_make_plan(const fxg_batch *in, const fxg_params *p, const 
     const u64 ntiles = (in->n + T - 1) / T;
     if (ntiles > 0x7FFFFFFFull || in->n > 0xFFFFFFFFull) FXG_PLAN_FAIL("batch too large (%llu reads): split it", (unsigned long long)in->n);
     ka.tile_reads = T; ka.ntiles = (u32)ntiles;
+    // Reverse complement of a fixed-length batch: the bytes of an output chunk of read k come from the window that starts at  k (stride + kept length) +
+    // (length - start)  mod 4 (tiles of a multiple of four reads, every read kept alike: fxg_decide_b), so either some residue class of k has its windows on dword
+    // boundaries or none has -- and only then do dword-aligned loads pay (fxg_ld16_dw, fxg_kernel_tiles<0, 5>).  FXG_REV_DW=0/1 forces it (measurement knob).
+    ka.rev_dw = 0u;
+    if ((st & FXG_STAGE_REVCOMP) && !in->len && (T & 3u) == 0u) {
+        u32 start = 0, cur = in->fixed_len;
+        if (st & FXG_STAGE_FTRIM) {
+            if (p->ft_last != 0 && (u32)p->ft_last < cur) cur = (u32)p->ft_last;
+            if (p->ft_first != 1 && cur >= (u32)p->ft_first) { start = (u32)p->ft_first - 1u; cur -= start; }
+        }
+        if ((st & FXG_STAGE_FTRIM_END) && cur > p->ft_trim_end) cur -= p->ft_trim_end;
+        const u32 A = (in->stride + cur) & 3u, C = (in->fixed_len - start) & 3u;
+        ka.rev_dw = ((A == 0u && C != 0u) || (A == 2u && (C & 1u))) ? 1u : 0u;
+    }
+    if (const char *e = getenv("FXG_REV_DW")) ka.rev_dw = atoi(e) != 0 ? 1u : 0u;
     // clip instances: the write-out runs two steps behind the decision (three slots) unless the extra slot costs a workgroup per CU
     ka.depth = 2u;
     if (pl->clip && FXG_CLIP_DEPTH >= 3u) {
